@@ -1,0 +1,142 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference on CPU.
+
+Run in the build container only (needs /root/reference):
+    python oracle/gen_golden.py            # all cases
+    python oracle/gen_golden.py tacorl_q   # one case
+
+A fixture holds: the case config + seeds (inputs and parameters are re-derived
+from the seed with tacorl_amd.synth), the recorded noise tape, every scalar the
+reference logged, the sampled latent plans, and per-parameter fingerprints
+(l2, sum, 16 samples - synth.tensor_stats) of the gradients seen by each
+optimiser and of the parameters after each step.  No reference source text is
+stored.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_harness as H  # noqa: E402
+from tacorl_amd import synth  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+CASES = {
+    # TACORL, frozen LMP (BASELINE config 2 shape, tiny batch), Q phase
+    "tacorl_q": dict(kind="tacorl", B=3, T=16, cams={"rgb_static": (84, 84)}, latent=16,
+                     epoch=5, finetune_ad=False, steps=2, seed=11),
+    # TACORL reference default (AD fine-tune on), BC phase
+    "tacorl_bc_ad": dict(kind="tacorl", B=2, T=16, cams={"rgb_static": (84, 84)}, latent=16,
+                         epoch=0, finetune_ad=True, steps=2, seed=12),
+    # dual camera real-world-like (BASELINE config 4 shape): latent 32, 128^2 + 84^2
+    "tacorl_dualcam": dict(kind="tacorl", B=2, T=8, latent=32, epoch=5, finetune_ad=False,
+                           cams={"rgb_static": (128, 128), "rgb_gripper": (84, 84)},
+                           steps=1, seed=13, overrides=dict(deterministic_backup=False)),
+    # flat CQL baseline, discrete gripper (BASELINE config 5 shape)
+    "cql_q": dict(kind="cql", B=3, cams={"rgb_static": (84, 84)}, epoch=5, steps=2, seed=14),
+    "cql_bc": dict(kind="cql", B=3, cams={"rgb_static": (84, 84)}, epoch=0, steps=1, seed=15,
+                   overrides=dict(n_action_samples=2)),
+    # PlayLMP seq-VAE step (BASELINE config 1 shape)
+    "playlmp": dict(kind="playlmp", B=3, T=16, cams={"rgb_static": (84, 84)}, latent=16,
+                    steps=2, seed=16),
+}
+
+
+def _stats_dict(prefix, named, out):
+    for n, t in named:
+        out[f"{prefix}/{n}"] = synth.tensor_stats(t)
+
+
+def _group_of(name):
+    if name.startswith("actor."):
+        return "actor"
+    for g in ("q1", "q2", "action_decoder", "log_alpha_prime", "log_alpha"):
+        if name.startswith(g):
+            return g
+    return None
+
+
+def run_case(name, c):
+    torch.manual_seed(c["seed"])
+    torch.set_num_threads(8)
+    out = {}
+    cams = c["cams"]
+    if c["kind"] in ("tacorl", "playlmp"):
+        lmp = H.build_play_lmp(cams=tuple(sorted(cams)), latent_plan_dim=c["latent"], seq_len=c["T"])
+    if c["kind"] == "tacorl":
+        mod = H.build_tacorl(lmp, finetune_action_decoder=c["finetune_ad"], **c.get("overrides", {}))
+    elif c["kind"] == "cql":
+        mod = H.build_cql(cams=tuple(sorted(cams)), **c.get("overrides", {}))
+    else:
+        mod = lmp
+    synth.fill_params_(mod, c["seed"])
+    mod.train()
+    mod.current_epoch = c.get("epoch", 0)
+    names = [n for n, _ in mod.named_parameters()]
+    out["param_names"] = np.array(names)
+    out["param_shapes"] = np.array(json.dumps([list(p.shape) for _, p in mod.named_parameters()]))
+    out["param_requires_grad"] = np.array([p.requires_grad for _, p in mod.named_parameters()])
+
+    for step in range(c["steps"]):
+        bseed = c["seed"] * 100 + step
+        if c["kind"] == "cql":
+            batch = synth.make_transition_batch(bseed, c["B"], cams)
+        else:
+            batch = synth.make_play_batch(bseed, c["B"], c["T"], cams)
+        tape = H.NoiseTape()
+        mod.logged = {}
+        mod.grad_log = []
+        with H.record_noise(tape):
+            if c["kind"] == "tacorl":
+                # capture the sampled latent plan (north-star parity item)
+                orig = mod.get_pr_latent_plan
+                cap = {}
+
+                def wrapped(b, return_emb_states=True, _o=orig, _c=cap):
+                    r = _o(b, return_emb_states=return_emb_states)
+                    _c["plan"] = (r[0] if return_emb_states else r).detach().clone()
+                    return r
+
+                mod.get_pr_latent_plan = wrapped
+                mod.training_step(batch)
+                mod.get_pr_latent_plan = orig
+                out[f"s{step}/latent_plan"] = cap["plan"].numpy()
+            elif c["kind"] == "cql":
+                mod.training_step(batch, 0)
+            else:
+                opt = mod.optimizers()[0]
+                loss = mod.training_step(batch, 0)
+                opt.zero_grad()
+                mod.manual_backward(loss)
+                opt.step()
+        for i, (kind, t) in enumerate(tape.draws):
+            out[f"s{step}/noise/{i:02d}_{kind}"] = t.numpy()
+        out[f"s{step}/logged"] = np.array(json.dumps(mod.logged))
+        # grads as each optimiser saw them: the LAST backward that touched a group
+        # before its step is the one right after its zero_grad (reference
+        # cql_offline_lightning.py:452-454,401-404,520-538; tacorl.py:231-233).
+        if c["kind"] == "playlmp":
+            _stats_dict(f"s{step}/grad", mod.grad_log[0].items(), out)
+        else:
+            order = (["action_decoder"] if c["kind"] == "tacorl" and c["finetune_ad"] else []) + [
+                "log_alpha", "log_alpha_prime", "actor", "q1", "q2"]
+            assert len(mod.grad_log) == len(order), (len(mod.grad_log), order)
+            for g, gl in zip(order, mod.grad_log):
+                _stats_dict(f"s{step}/grad", [(n, t) for n, t in gl.items() if _group_of(n) == g], out)
+        _stats_dict(f"s{step}/param", mod.named_parameters(), out)
+        print(f"[{name}] step {step}: " + ", ".join(f"{k.split('/')[-1]}={v:.5g}" for k, v in sorted(mod.logged.items())))
+
+    cfg = {k: v for k, v in c.items()}
+    out["config"] = np.array(json.dumps(cfg))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"[{name}] wrote {os.path.getsize(os.path.join(OUT, name + '.npz')) / 1e3:.1f} kB")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(CASES)
+    for n in which:
+        run_case(n, CASES[n])

@@ -1,0 +1,116 @@
+"""Load tests/golden/*.npz (made by oracle/gen_golden.py from the unmodified reference)
+and re-derive the inputs they were computed on."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from tacorl_amd import synth
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class Golden:
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+        self.cfg = json.loads(str(self.z["config"]))
+        self.names = [str(n) for n in self.z["param_names"]]
+        self.shapes = json.loads(str(self.z["param_shapes"]))
+        self.requires_grad = [bool(b) for b in self.z["param_requires_grad"]]
+        self.cams = {k: tuple(v) for k, v in self.cfg["cams"].items()}
+
+    # ---- inputs
+    def params(self):
+        """Initial parameters {reference state-dict name: tensor} (logical shapes)."""
+        return {n: synth.param_values(n, s, self.cfg["seed"]) for n, s in zip(self.names, self.shapes)}
+
+    def batch(self, step):
+        bseed = self.cfg["seed"] * 100 + step
+        if self.cfg["kind"] == "cql":
+            return synth.make_transition_batch(bseed, self.cfg["B"], self.cams)
+        return synth.make_play_batch(bseed, self.cfg["B"], self.cfg["T"], self.cams)
+
+    def tape(self, step):
+        pre = f"s{step}/noise/"
+        keys = sorted(k for k in self.z.files if k.startswith(pre))
+        return [(k[len(pre) + 3:], torch.from_numpy(self.z[k])) for k in keys]
+
+    def noise(self, step):
+        """Name the recorded draws (order: SURVEY 8a note 1)."""
+        t = self.tape(step)
+        kind = self.cfg["kind"]
+        nz = {}
+        if kind == "playlmp":
+            assert [k for k, _ in t] == ["normal", "rand", "rand", "uniform01", "uniform01", "rand", "rand"]
+            nz = dict(eps_plan=t[0][1], rand=[t[1][1], t[2][1], t[5][1], t[6][1]], u_plan=t[3][1], u_goal=t[4][1])
+            return nz
+        i = 0
+        if kind == "tacorl":
+            nz["eps_pr"] = t[0][1]
+            i = 1
+        if kind == "cql":  # discrete gripper draws interleave (actor.py:83-97,118-132)
+            order = ["eps_pi", "g_pi", "eps_next", "g_next", "u_rand", "eps_cur", "g_cur", "eps_nxt", "g_nxt"]
+        else:
+            order = ["eps_pi", "eps_next", "u_rand", "eps_cur", "eps_nxt"]
+        assert len(t) - i == len(order), (len(t), order)
+        for k, (_, v) in zip(order, t[i:]):
+            nz[k] = v
+        return nz
+
+    # ---- expected outputs
+    def logged(self, step):
+        d = json.loads(str(self.z[f"s{step}/logged"]))
+        return {k.split("/", 1)[1]: v for k, v in d.items()}
+
+    def latent_plan(self, step):
+        return torch.from_numpy(self.z[f"s{step}/latent_plan"])
+
+    def stats(self, step, what):
+        pre = f"s{step}/{what}/"
+        return {k[len(pre):]: self.z[k] for k in self.z.files if k.startswith(pre)}
+
+
+def spec_for(g):
+    """ACSpec equal to what the reference module was built with (gen_golden.CASES +
+    config/module/{tacorl,cql_offline_goal_cond}.yaml)."""
+    from oracle import tacorl_oracle as O
+
+    c = g.cfg
+    cams = sorted(g.cams)
+    ov = c.get("overrides", {})
+    if c["kind"] == "tacorl":
+        base = dict(n=4, discount=0.95, actor_lr=1e-4, critic_lr=3e-4, deterministic_backup=True,
+                    reward_scale=10.0, bc_epochs=5, with_lagrange=True, action_decoder_lr=3e-4)
+        base.update({("n" if k == "n_action_samples" else k): v for k, v in ov.items()})
+        return O.ACSpec(cams=cams, goal_cams=cams, action_dim=c["latent"], discrete_gripper=False,
+                        target_entropy=-7.0, finetune_action_decoder=c["finetune_ad"], ac_cams=cams,
+                        pr_cams=cams, **base)
+    base = dict(n=4, discount=0.99, actor_lr=1e-4, critic_lr=3e-4, deterministic_backup=False,
+                reward_scale=10.0, bc_epochs=5, with_lagrange=True)
+    base.update({("n" if k == "n_action_samples" else k): v for k, v in ov.items()})
+    return O.ACSpec(cams=cams, goal_cams=cams, action_dim=7, discrete_gripper=True,
+                    target_entropy=-7.0, **base)
+
+
+def check_stats(got_named, expected_stats, rtol, atol=0.0, what=""):
+    """Compare tensors against (l2, sum, 16 samples) fingerprints.
+    ``atol`` (per element) absorbs Adam's g/(|g|+eps) amplification on near-zero grads
+    when comparing post-step parameters (a few % of one lr-sized update)."""
+    bad = []
+    for name, exp in expected_stats.items():
+        if name not in got_named:
+            bad.append(f"{what}{name}: missing")
+            continue
+        got = synth.tensor_stats(got_named[name])
+        scale = max(abs(exp[0]), 1e-30)
+        n = got_named[name].numel()
+        # l2: relative; sum & samples: absolute against the tensor's l2 scale
+        if abs(got[0] - exp[0]) > rtol * scale + atol * np.sqrt(n) + 1e-12:
+            bad.append(f"{what}{name}: l2 {got[0]:.8g} vs {exp[0]:.8g}")
+        elif abs(got[1] - exp[1]) > rtol * scale * np.sqrt(n) + atol * n + 1e-12:
+            bad.append(f"{what}{name}: sum {got[1]:.8g} vs {exp[1]:.8g}")
+        elif np.max(np.abs(got[2:] - exp[2:])) > rtol * max(np.max(np.abs(exp[2:])), scale / np.sqrt(n)) + atol + 1e-12:
+            bad.append(f"{what}{name}: samples max|d|={np.max(np.abs(got[2:] - exp[2:])):.3g}")
+    return bad
