@@ -1,0 +1,151 @@
+/* libtacorl_hip.so - C ABI of the MI355X (gfx950) TACO-RL offline-training hot path.
+ *
+ * The reference (ErickRosete/tacorl) is pure Python and has no FFI for this path
+ * (SURVEY.md section 8b): every entry point below replaces a stock-torch op sequence
+ * inside the reference module named in its comment.  Contract for ALL functions:
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors);
+ *     the caller keeps it alive until `stream` has been synchronised;
+ *   - work is enqueued asynchronously on `stream`; nothing allocates, nothing
+ *     synchronises (hipGraph-capturable); scratch comes from the caller through
+ *     (ws, ws_bytes) and is sized by the matching *_ws_bytes query;
+ *   - return 0 on success, negative errno-style code otherwise (never throws);
+ *     tacorl_hip_last_error() gives the text for the calling thread;
+ *   - "problem batches": arrays of `nprob` pointers describe independent problems of
+ *     the same geometry (actor / q1 / q2 / target nets) that run in ONE launch.
+ *   - fp32 row-major tensors; images NHWC; conv weights [CO][KH][KW][CI].
+ */
+#ifndef TACORL_HIP_H
+#define TACORL_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tacorl_stream_t; /* hipStream_t */
+
+#define TACORL_MAXP 16 /* max problems per batched call */
+enum { TACORL_F32 = 0, TACORL_BF16 = 1 };               /* storage / MFMA operand dtype */
+enum { TACORL_ACT_NONE = 0, TACORL_ACT_RELU = 1, TACORL_ACT_SILU = 2 };
+
+int tacorl_hip_version(void);
+int tacorl_hip_init(int device);             /* idempotent; checks the device is gfx950 */
+const char* tacorl_hip_last_error(void);
+
+/* ---- primitives ------------------------------------------------------------------ */
+/* y = act(x W^T + b), optional pre-activation z.  Replaces nn.Linear (+F.silu / nn.ReLU):
+ * reference networks/actor_critic/actor.py:252-270, critic.py:92-97, goal_encoder.py:17-23. */
+int tacorl_linear_fwd(int nprob, const float* const* x, int ldx, const float* const* w,
+                      const float* const* b, float* const* y, float* const* z, const int* M,
+                      int K, int N, int act, int compute_dtype, tacorl_stream_t stream);
+/* y = relu(conv2d(x, w) + b), no padding.  Replaces nn.Conv2d + nn.ReLU,
+ * reference networks/visual_encoders/encoder.py:369-390. x_dtype: image storage dtype. */
+int tacorl_conv2d_relu_fwd(int nprob, const void* const* x, const float* const* w,
+                           const float* const* b, float* const* y, const int* n_img, int H, int W,
+                           int C, int KH, int KW, int S, int CO, int x_dtype, int compute_dtype,
+                           tacorl_stream_t stream);
+
+/* ---- LMPVisionEncoder (reference encoder.py:349-419, utils.py:22-76) --------------- */
+/* Packed parameter block (floats, every tensor 4-float aligned):
+ *   0 conv1.w[32][8][8][3] 1 conv1.b 2 conv2.w[64][4][4][32] 3 conv2.b 4 conv3.w[64][3][3][64]
+ *   5 conv3.b 6 temperature[1] 7 fc1.w[256][128] 8 fc1.b 9 fc2.w[32][256] 10 fc2.b
+ * Writes the 11 offsets; returns the block size in floats. */
+long tacorl_encoder_param_layout(long* offsets11);
+/* Saved-activation block per problem: y1 | y2 | y3 | softargmax(128) | fc1(256). Writes the 5
+ * offsets (floats), returns the block size in floats. */
+long tacorl_encoder_act_layout(int n_img, int H, int W, long* offsets5);
+int tacorl_encoder_fwd(int nprob, const void* const* img, const float* const* params,
+                       float* const* out /*[n][32]*/, float* const* act, const int* n_img, int H,
+                       int W, int img_dtype, int compute_dtype, tacorl_stream_t stream);
+size_t tacorl_encoder_bwd_ws_bytes(int nprob, const int* n_img, int H, int W);
+/* grads: blocks in the parameter layout (overwritten, or accumulated if accumulate != 0). */
+int tacorl_encoder_bwd(int nprob, const void* const* img, const float* const* params,
+                       const float* const* act, const float* const* d_out, float* const* grads,
+                       const int* n_img, int H, int W, int img_dtype, int compute_dtype,
+                       int accumulate, void* ws, size_t ws_bytes, tacorl_stream_t stream);
+
+/* ---- MLP = chain of Linear(dims[l] -> dims[l+1]) + acts[l]  ------------------------ */
+/* Parameter block: for each layer W[out][in] then b[out], each 4-float aligned. */
+long tacorl_mlp_param_layout(int n_layers, const int* dims, long* w_off, long* b_off);
+/* Activation block for M rows: per layer [z_l if SiLU][y_l]; y_off[n_layers-1] is the output. */
+long tacorl_mlp_act_layout(int M, int n_layers, const int* dims, const int* acts, long* z_off,
+                           long* y_off);
+int tacorl_mlp_fwd(int nprob, const float* const* x, int ldx, const float* const* params,
+                   float* const* act, const int* M, int n_layers, const int* dims,
+                   const int* acts, int compute_dtype, tacorl_stream_t stream);
+size_t tacorl_mlp_bwd_ws_bytes(int nprob, const int* M, int n_layers, const int* dims);
+/* d_out: gradient w.r.t. the last layer's output [M][dims[n_layers]], leading dim ldo (last act
+ * must be NONE).
+ * grads[p] may be NULL (skip weight gradients); d_x[p] may be NULL (skip input gradient). */
+int tacorl_mlp_bwd(int nprob, const float* const* x, int ldx, const float* const* params,
+                   const float* const* act, const float* const* d_out, int ldo, float* const* grads,
+                   float* const* d_x, int ldd, const int* M, int n_layers, const int* dims,
+                   const int* acts, int compute_dtype, int accumulate, void* ws, size_t ws_bytes,
+                   tacorl_stream_t stream);
+
+/* ---- data movement ----------------------------------------------------------------- */
+/* n images (image i at src + i*img_pitch floats; NCHW if src_nchw else NHWC) -> contiguous NHWC
+ * dst (fp32 / bf16).  Replaces the states[:,0] / states[:,-1] / goal gathers of
+ * TACORL.get_rl_batch (reference modules/tacorl/tacorl.py:142-179). */
+int tacorl_pack_images(const float* src, long img_pitch, int src_nchw, void* dst, int dst_dtype,
+                       int n, int C, int H, int W, tacorl_stream_t stream);
+/* dst[r][0:cols] (+)= src[r % src_row_mod][0:cols]  (src_row_mod <= 0: r).  expand_obs on
+ * embeddings instead of images (reference utils/misc.py:132-153) and torch.cat plumbing. */
+int tacorl_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols,
+                     int src_row_mod, int accumulate, tacorl_stream_t stream);
+/* out[b][c] = sum_{j<reps} in[j*B+b][c] : gradient of that broadcast. */
+int tacorl_reduce_rows_mod(const float* in, int ld_in, float* out, int ld_out, int B, int cols,
+                           int reps, tacorl_stream_t stream);
+/* dst[r][0:A] = 2u-1 (last dim snapped to +-1 for a discrete gripper);
+ * reference modules/cql/cql_offline_lightning.py:243-250. */
+int tacorl_uniform_actions(const float* u01, float* dst, int ld_dst, int rows, int A,
+                           int discrete_gripper, tacorl_stream_t stream);
+
+/* ---- tanh-Gaussian policy head (reference actor.py:65-156, utils/distributions.py:61-153) --- */
+/* head[m] = [mean_raw(Ac) | log_std_raw(Ac) | gripper logits(2)?].  For k<n, m<M:
+ * a = tanh(mu + sd*eps[k][m]) -> act_out[(k*M+m)*ld_act ..], log pi -> logp[k*M+m].
+ * gumbel_u (n,M,2) U(0,1) or NULL: discrete gripper (hard_rsample: the rsample(hard=True) index). */
+int tacorl_tanh_normal_sample(const float* head, int ld_head, const float* eps, const float* gumbel_u,
+                              int hard_rsample, float* act_out, int ld_act, float* logp, int* grip_idx,
+                              int n, int M, int Ac, tacorl_stream_t stream);
+
+/* device-resident metric record written by the loss kernels (names = reference self.log keys) */
+enum {
+  TACORL_LG_ALPHA_LOSS = 0, TACORL_LG_ALPHA, TACORL_LG_ACTOR_LOSS, TACORL_LG_BELL1, TACORL_LG_BELL2,
+  TACORL_LG_CONS1, TACORL_LG_CONS2, TACORL_LG_Q1LOSS, TACORL_LG_Q2LOSS, TACORL_LG_ALPHA_P,
+  TACORL_LG_ALPHA_P_LOSS, TACORL_LG_Q1_DATA, TACORL_LG_Q1_RAND, TACORL_LG_Q1_POL, TACORL_LG_Q2_DATA,
+  TACORL_LG_Q2_RAND, TACORL_LG_Q2_POL, TACORL_LG_ACTION_LOSS, TACORL_LG_COUNT
+};
+/* alpha_loss and d/dlog_alpha (cql_offline_lightning.py:447-449); grad scaled by grad_scale. */
+int tacorl_alpha_loss(const float* logp, int B, const float* log_alpha, float target_entropy,
+                      float grad_scale, float* g_log_alpha, float* logs, tacorl_stream_t stream);
+/* Q phase actor loss mean(alpha*logpi - min(q1,q2)) and dL/dq_i (:463-466). */
+int tacorl_actor_qmin(const float* q1, const float* q2, const float* logp, int B, const float* log_alpha,
+                      float* dq1, float* dq2, float grad_scale, float* logs, tacorl_stream_t stream);
+/* dL_actor/d head.  g_act1/2: dL/da from the critics (Q phase) or NULL; value: dataset action for
+ * the BC phase (:459-461) or NULL. */
+int tacorl_actor_head_bwd(const float* head, int ld_head, const float* eps, const float* logp,
+                          const float* g_act1, const float* g_act2, int ld_g, const float* value,
+                          int ld_value, const int* grip_idx, const float* log_alpha, float grad_scale,
+                          float* d_head, int B, int Ac, int has_grip, float* logs, tacorl_stream_t stream);
+
+/* ---- Bellman + CQL logsumexp (+ Lagrange), forward and backward fused (:284-406) -------------- */
+size_t tacorl_cql_ws_bytes(int B);
+/* q_i / dq_i: rows [data B | random nB | current-policy nB | next-policy nB], sample-major (k*B+b). */
+int tacorl_cql_loss(const float* q1, const float* q2, float* dq1, float* dq2, const float* tq1,
+                    const float* tq2, const float* logp_cur, const float* logp_nxt, const float* next_logp,
+                    const float* reward, const float* done, const float* log_alpha,
+                    const float* log_alpha_prime, int B, int n, int A, float discount, float reward_scale,
+                    float temp, float cons_w, float gap, int deterministic_backup, float grad_scale,
+                    float* g_log_alpha_prime, float* logs, void* ws, size_t ws_bytes, tacorl_stream_t stream);
+
+/* ---- clip_grad_norm_ + Adam + Polyak over one flat block (:229-232, 519-542, 553-574) --------- */
+size_t tacorl_adam_ws_bytes(long n);
+/* max_norm <= 0: no clipping; target NULL: no soft update; step_counter: device int (t-1). */
+int tacorl_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr,
+                     float max_norm, int* step_counter, float* target, float tau, void* ws,
+                     size_t ws_bytes, tacorl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

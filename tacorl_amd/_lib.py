@@ -1,0 +1,117 @@
+"""ctypes binding of libtacorl_hip.so (C ABI: include/tacorl_hip.h).
+
+There is no CPU or eager-torch fallback: if the library is missing or a call fails,
+this raises.  Everything in tacorl_amd that computes goes through `call()`.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libtacorl_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+MAXP = 16
+
+LOG_SLOTS = [  # enum TACORL_LG_* -> reference self.log key
+    "alpha_loss", "alpha", "actor_loss", "bellman_q1_loss", "bellman_q2_loss", "conservative_q1_loss",
+    "conservative_q2_loss", "q1_loss", "q2_loss", "alpha_prime", "alpha_prime_loss", "q1_data", "q1_random",
+    "q1_policy", "q2_data", "q2_random", "q2_policy", "action_loss",
+]
+
+_p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+_SIGS = {
+    "tacorl_hip_version": (_i, []),
+    "tacorl_hip_init": (_i, [_i]),
+    "tacorl_hip_last_error": (C.c_char_p, []),
+    "tacorl_linear_fwd": (_i, [_i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "tacorl_conv2d_relu_fwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "tacorl_encoder_param_layout": (_l, [_p]),
+    "tacorl_encoder_act_layout": (_l, [_i, _i, _i, _p]),
+    "tacorl_encoder_fwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "tacorl_encoder_bwd_ws_bytes": (_sz, [_i, _p, _i, _i]),
+    "tacorl_encoder_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "tacorl_mlp_param_layout": (_l, [_i, _p, _p, _p]),
+    "tacorl_mlp_act_layout": (_l, [_i, _i, _p, _p, _p, _p]),
+    "tacorl_mlp_fwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _p, _i, _p]),
+    "tacorl_mlp_bwd_ws_bytes": (_sz, [_i, _p, _i, _p]),
+    "tacorl_mlp_bwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _sz, _p]),
+    "tacorl_pack_images": (_i, [_p, _l, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "tacorl_copy_cols": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "tacorl_reduce_rows_mod": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "tacorl_uniform_actions": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "tacorl_tanh_normal_sample": (_i, [_p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _p]),
+    "tacorl_alpha_loss": (_i, [_p, _i, _p, _f, _f, _p, _p, _p]),
+    "tacorl_actor_qmin": (_i, [_p, _p, _p, _i, _p, _p, _p, _f, _p, _p]),
+    "tacorl_actor_head_bwd": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _f, _p, _i, _i, _i, _p, _p]),
+    "tacorl_cql_ws_bytes": (_sz, [_i]),
+    "tacorl_cql_loss": (_i, [_p] * 13 + [_i, _i, _i, _f, _f, _f, _f, _f, _i, _f, _p, _p, _p, _sz, _p]),
+    "tacorl_adam_ws_bytes": (_sz, [_l]),
+    "tacorl_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _p, _p, _f, _p, _sz, _p]),
+}
+
+_lib = None
+
+
+class TacorlHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TacorlHipError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+                "Build it with `python -m tacorl_amd.build`.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name, None)
+            if fn is None:
+                continue  # optional symbol of a later round; declared_symbols() reports it
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def declared_symbols():
+    return list(_SIGS)
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    rc = fn(*args)
+    if fn.restype is _i and rc != 0:
+        raise TacorlHipError(f"{name} failed ({rc}): {lib().tacorl_hip_last_error().decode()}")
+    return rc
+
+
+# ----------------------------------------------------------------- small marshalling helpers
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    """void*[n] from tensors / raw ints / None."""
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        if t is None:
+            arr[i] = None
+        elif isinstance(t, int):
+            arr[i] = t
+        elif isinstance(t, C.c_void_p):
+            arr[i] = t.value
+        else:
+            arr[i] = t.data_ptr()
+    return arr
+
+
+def int_array(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

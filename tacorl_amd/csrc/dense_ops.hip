@@ -1,0 +1,571 @@
+// Dense ops of the TACO-RL hot path on top of the single MFMA contraction template:
+// Linear / conv forward, backward-data, backward-weights (split-R slabs + reduce),
+// spatial soft-argmax, and the composite LMPVisionEncoder / MLP forward+backward.
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/tacorl_hip.h"
+#include "functors.h"
+
+static thread_local char g_err[256] = "";
+#define FAIL(code, ...)                        \
+  do {                                         \
+    snprintf(g_err, sizeof(g_err), __VA_ARGS__); \
+    return (code);                             \
+  } while (0)
+#define CHECK(x)            \
+  do {                      \
+    int _r = (x);           \
+    if (_r != TACORL_OK) return _r; \
+  } while (0)
+
+extern "C" const char* tacorl_hip_last_error(void) { return g_err; }
+extern "C" int tacorl_hip_version(void) { return 1; }
+extern "C" int tacorl_hip_init(int device) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) FAIL(TACORL_EINVAL, "no HIP device %d", device);
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    FAIL(TACORL_EINVAL, "device %d is %s, this library is gfx950-only", device, prop.gcnArchName);
+  return TACORL_OK;
+}
+
+static inline long al4(long x) { return (x + 3) & ~3L; }
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// ============================================================== linear forward
+static int k_linear_fwd(int nprob, const float* const* x, int ldx, const float* const* w,
+                        const float* const* b, float* const* y, float* const* z, const int* M, int K,
+                        int N, int ldy, int act, int cd, hipStream_t st) {
+  if (nprob < 1 || nprob > GEMM_MAXP) FAIL(TACORL_EINVAL, "linear_fwd: nprob %d", nprob);
+  RowMajorLoader la{}, lb{};
+  BiasActStore ep{};
+  GemmArgs g{};
+  g.nprob = nprob; g.nsplit = 1; g.N = N;
+  la.cols = K; la.ld = ldx; la.vec = (ldx % 4 == 0); la.ones_col = 0;
+  lb.cols = K; lb.ld = K; lb.vec = (K % 4 == 0); lb.ones_col = 0;
+  ep.ld = ldy; ep.act = act;
+  for (int p = 0; p < nprob; p++) {
+    la.ptr[p] = x[p]; la.rows[p] = M[p]; la.vec &= aligned16(x[p]);
+    lb.ptr[p] = w[p]; lb.rows[p] = N; lb.vec &= aligned16(w[p]);
+    ep.bias[p] = b ? b[p] : nullptr; ep.y[p] = y[p]; ep.z[p] = z ? z[p] : nullptr;
+    g.M[p] = M[p]; g.R[p] = K;
+  }
+  return gemm_launch<RowMajorLoader, RowMajorLoader, false, false, BiasActStore>(la, lb, ep, g, cd, st);
+}
+
+extern "C" int tacorl_linear_fwd(int nprob, const float* const* x, int ldx, const float* const* w,
+                                 const float* const* b, float* const* y, float* const* z, const int* M,
+                                 int K, int N, int act, int compute_dtype, tacorl_stream_t stream) {
+  return k_linear_fwd(nprob, x, ldx, w, b, y, z, M, K, N, N, act, compute_dtype, (hipStream_t)stream);
+}
+
+// ================================================================ conv forward
+static ConvGeom make_geom(int H, int W, int C, int KH, int KW, int S, int CO) {
+  ConvGeom g{H, W, C, KH, KW, S, CO, (H - KH) / S + 1, (W - KW) / S + 1};
+  return g;
+}
+static bool conv_vec_ok(const ConvGeom& g) {
+  return (g.KW * g.C) % 4 == 0 && (g.W * g.C) % 4 == 0 && (g.S * g.C) % 4 == 0 && (g.H * g.W * g.C) % 4 == 0;
+}
+
+template <typename InT>
+static int k_conv_fwd(int nprob, const void* const* x, const float* const* w, const float* const* b,
+                      float* const* y, const int* n_img, const ConvGeom& cg, int cd, hipStream_t st) {
+  if (nprob < 1 || nprob > GEMM_MAXP) FAIL(TACORL_EINVAL, "conv_fwd: nprob %d", nprob);
+  if ((cg.KW * cg.C) % 4 != 0) FAIL(TACORL_EINVAL, "conv_fwd: KW*C must be a multiple of 4");
+  ConvColLoader<InT> la{};
+  RowMajorLoader lb{};
+  BiasActStore ep{};
+  GemmArgs g{};
+  const int K = cg.KH * cg.KW * cg.C;
+  g.nprob = nprob; g.nsplit = 1; g.N = cg.CO;
+  la.g = cg; la.vec = conv_vec_ok(cg); la.ones_col = 0;
+  lb.cols = K; lb.ld = K; lb.vec = 1; lb.ones_col = 0;
+  ep.ld = cg.CO; ep.act = ACT_RELU;
+  for (int p = 0; p < nprob; p++) {
+    la.ptr[p] = (const InT*)x[p]; la.rows[p] = n_img[p] * cg.OH * cg.OW; la.vec &= aligned16(x[p]);
+    lb.ptr[p] = w[p]; lb.rows[p] = cg.CO; lb.vec &= aligned16(w[p]);
+    ep.bias[p] = b[p]; ep.y[p] = y[p]; ep.z[p] = nullptr;
+    g.M[p] = la.rows[p]; g.R[p] = K;
+  }
+  return gemm_launch<ConvColLoader<InT>, RowMajorLoader, false, false, BiasActStore>(la, lb, ep, g, cd, st);
+}
+
+static int conv_fwd_any(int nprob, const void* const* x, const float* const* w, const float* const* b,
+                        float* const* y, const int* n_img, const ConvGeom& cg, int x_dtype, int cd,
+                        hipStream_t st) {
+  if (x_dtype == TACORL_BF16) return k_conv_fwd<__bf16>(nprob, x, w, b, y, n_img, cg, cd, st);
+  return k_conv_fwd<float>(nprob, x, w, b, y, n_img, cg, cd, st);
+}
+
+extern "C" int tacorl_conv2d_relu_fwd(int nprob, const void* const* x, const float* const* w,
+                                      const float* const* b, float* const* y, const int* n_img, int H,
+                                      int W, int C, int KH, int KW, int S, int CO, int x_dtype,
+                                      int compute_dtype, tacorl_stream_t stream) {
+  if (H < KH || W < KW) FAIL(TACORL_EINVAL, "conv: image smaller than kernel");
+  return conv_fwd_any(nprob, x, w, b, y, n_img, make_geom(H, W, C, KH, KW, S, CO), x_dtype, compute_dtype,
+                      (hipStream_t)stream);
+}
+
+// ============================================================== backward-data
+// linear: dX[m][i] = (sum_o dZ[m][o] W[o][i]) * act'(src[m][i])
+static int k_linear_dgrad(int nprob, const float* const* dz, int ld_dz, const float* const* w, float* const* out,
+                          int ld_out, const float* const* src, int act_src, const int* M, int O, int I,
+                          int cd, hipStream_t st) {
+  RowMajorLoader la{}, lb{};
+  DgradStore ep{};
+  GemmArgs g{};
+  g.nprob = nprob; g.nsplit = 1; g.N = I;
+  la.cols = O; la.ld = ld_dz; la.vec = (O % 4 == 0 && ld_dz % 4 == 0); la.ones_col = 0;
+  lb.cols = I; lb.ld = I; lb.vec = (I % 4 == 0); lb.ones_col = 0;
+  ep.ld = ld_out; ep.act = act_src;
+  for (int p = 0; p < nprob; p++) {
+    la.ptr[p] = dz[p]; la.rows[p] = M[p]; la.vec &= aligned16(dz[p]);
+    lb.ptr[p] = w[p]; lb.rows[p] = O; lb.vec &= aligned16(w[p]);
+    ep.out[p] = out[p]; ep.src[p] = src ? src[p] : nullptr;
+    g.M[p] = M[p]; g.R[p] = O;
+  }
+  return gemm_launch<RowMajorLoader, RowMajorLoader, false, true, DgradStore>(la, lb, ep, g, cd, st);
+}
+
+// conv: gather form, one GEMM per input-pixel parity class (S*S classes per net).
+static int k_conv_dgrad(int nnets, const float* const* dout, const float* const* w, float* const* din,
+                        const float* const* src, const int* n_img, const ConvGeom& cg, int cd,
+                        hipStream_t st) {
+  const int S = cg.S, ncls = S * S;
+  if (nnets * ncls > GEMM_MAXP) FAIL(TACORL_EINVAL, "conv_dgrad: %d nets x %d classes > %d", nnets, ncls, GEMM_MAXP);
+  if (cg.C % 4 || cg.CO % 4) FAIL(TACORL_EINVAL, "conv_dgrad: channels must be multiples of 4");
+  ConvDgradALoader la{};
+  ConvDgradWLoader lb{};
+  ConvDgradStore ep{};
+  GemmArgs g{};
+  const int TA = (cg.KH + S - 1) / S, TB = (cg.KW + S - 1) / S;
+  la.g = lb.g = ep.g = cg;
+  la.TA = lb.TA = TA; la.TB_ = lb.TB_ = TB;
+  g.nprob = nnets * ncls; g.nsplit = 1; g.N = cg.C;
+  for (int n = 0; n < nnets; n++)
+    for (int c = 0; c < ncls; c++) {
+      const int p = n * ncls + c, py = c / S, px = c % S;
+      const int nh = (cg.H - py + S - 1) / S, nw = (cg.W - px + S - 1) / S;
+      la.ptr[p] = dout[n]; la.n_img[p] = n_img[n];
+      lb.ptr[p] = w[n];
+      ep.out[p] = din[n]; ep.src[p] = src ? src[n] : nullptr;
+      g.M[p] = n_img[n] * nh * nw; g.R[p] = TA * TB * cg.CO;
+    }
+  return gemm_launch<ConvDgradALoader, ConvDgradWLoader, false, true, ConvDgradStore>(la, lb, ep, g, cd, st);
+}
+
+// ============================================================ backward-weights
+// dW[o][k] = sum_m dZ[m][o] X(m, k), db[o] = sum_m dZ[m][o]; computed as the GEMM
+// C[k][o] with the reduction over m split across blocks into slabs, then reduced.
+struct PtrTable {  // device-visible pointer arrays passed by value through a tiny kernel arg
+  const float* slab[GEMM_MAXP];
+  float* dw[GEMM_MAXP];
+  float* db[GEMM_MAXP];
+};
+__global__ void slab_reduce_kernel_tbl(PtrTable t, int nsplit, int O, int K, int accumulate) {
+  const int p = blockIdx.y;
+  const float* slab = t.slab[p];
+  float* dw = t.dw[p];
+  float* db = t.db[p];
+  const long per = (long)O * (K + 1);
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int i = 0; i < nsplit; i++) s += slab[i * per + e];
+    const int o = (int)(e / (K + 1)), k = (int)(e - (long)o * (K + 1));
+    float* dst = (k == K) ? (db ? db + o : nullptr) : dw + (long)o * K + k;
+    if (dst) *dst = accumulate ? *dst + s : s;
+  }
+}
+
+static int pick_nsplit(int nprob, int K, int O, long maxR) {
+  long tiles = (long)cdiv(K + 1, 128) * cdiv(O, O > 32 ? 64 : (O > 16 ? 32 : 16)) * nprob;
+  long ns = 768 / (tiles > 0 ? tiles : 1);
+  long cap = maxR / 128;
+  if (ns > cap) ns = cap;
+  if (ns > 128) ns = 128;
+  if (ns < 1) ns = 1;
+  return (int)ns;
+}
+static size_t wgrad_ws_bytes(int nprob, int K, int O, long maxR) {
+  return (size_t)nprob * pick_nsplit(nprob, K, O, maxR) * O * (K + 1) * sizeof(float);
+}
+
+template <class LA>
+static int k_wgrad(LA& la, int nprob, const float* const* dz, int ld_dz, const int* R, int K, int O,
+                   float* const* dw, float* const* db, int accumulate, void* ws, size_t ws_bytes, int cd,
+                   hipStream_t st) {
+  long maxR = 0;
+  for (int p = 0; p < nprob; p++) maxR = R[p] > maxR ? R[p] : maxR;
+  const int ns = pick_nsplit(nprob, K, O, maxR);
+  if (wgrad_ws_bytes(nprob, K, O, maxR) > ws_bytes) FAIL(TACORL_ENOMEM, "wgrad: workspace too small");
+  RowMajorLoader lb{};
+  WgradStore ep{};
+  GemmArgs g{};
+  PtrTable t{};
+  g.nprob = nprob; g.nsplit = ns; g.N = O;
+  lb.cols = O; lb.ld = ld_dz; lb.vec = (O % 4 == 0 && ld_dz % 4 == 0); lb.ones_col = 0;
+  ep.K = K; ep.O = O; ep.nsplit = ns;
+  const long per = (long)O * (K + 1);
+  for (int p = 0; p < nprob; p++) {
+    lb.ptr[p] = dz[p]; lb.rows[p] = R[p]; lb.vec &= aligned16(dz[p]);
+    ep.slab[p] = (float*)ws + (long)p * ns * per;
+    t.slab[p] = ep.slab[p]; t.dw[p] = dw[p]; t.db[p] = db ? db[p] : nullptr;
+    g.M[p] = K + 1; g.R[p] = R[p];
+  }
+  CHECK((gemm_launch<LA, RowMajorLoader, true, true, WgradStore>(la, lb, ep, g, cd, st)));
+  dim3 grid(cdiv(per, 256) > 256 ? 256 : cdiv(per, 256), nprob);
+  hipLaunchKernelGGL(slab_reduce_kernel_tbl, grid, dim3(256), 0, st, t, ns, O, K, accumulate);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
+static int k_linear_wgrad(int nprob, const float* const* x, int ldx, const float* const* dz, int ld_dz, const int* M,
+                          int K, int O, float* const* dw, float* const* db, int accumulate, void* ws,
+                          size_t ws_bytes, int cd, hipStream_t st) {
+  RowMajorLoader la{};
+  la.cols = K; la.ld = ldx; la.vec = (ldx % 4 == 0 && K % 4 == 0); la.ones_col = 1;
+  for (int p = 0; p < nprob; p++) { la.ptr[p] = x[p]; la.rows[p] = M[p]; la.vec &= aligned16(x[p]); }
+  return k_wgrad(la, nprob, dz, ld_dz, M, K, O, dw, db, accumulate, ws, ws_bytes, cd, st);
+}
+
+template <typename InT>
+static int k_conv_wgrad(int nprob, const void* const* x, const float* const* dz, const int* n_img,
+                        const ConvGeom& cg, float* const* dw, float* const* db, int accumulate, void* ws,
+                        size_t ws_bytes, int cd, hipStream_t st) {
+  ConvColLoader<InT> la{};
+  la.g = cg; la.vec = conv_vec_ok(cg); la.ones_col = 1;
+  int R[GEMM_MAXP];
+  for (int p = 0; p < nprob; p++) {
+    la.ptr[p] = (const InT*)x[p]; R[p] = la.rows[p] = n_img[p] * cg.OH * cg.OW; la.vec &= aligned16(x[p]);
+  }
+  return k_wgrad(la, nprob, dz, cg.CO, R, cg.KH * cg.KW * cg.C, cg.CO, dw, db, accumulate, ws, ws_bytes, cd, st);
+}
+
+// ========================================================= spatial soft-argmax
+// y3: [n][P][64] (post-ReLU conv3, NHWC); out: [n][128] interleaved (x_c, y_c) in pixel units.
+// One wave per image, lane = channel (reference networks/visual_encoders/utils.py:39-65).
+__global__ __launch_bounds__(256) void softargmax_fwd_kernel(const float* __restrict__ y3, const float* temp,
+                                                             float* __restrict__ out, int n_img, int OH, int OW) {
+  const int img = blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
+  if (img >= n_img) return;
+  const float t = temp[0];
+  const int P = OH * OW;
+  const float* q = y3 + (long)img * P * 64 + c;
+  float mx = -INFINITY;
+  for (int i = 0; i < P; i++) mx = fmaxf(mx, q[i * 64] / t);
+  float se = 0.f, sx = 0.f, sy = 0.f;
+  for (int i = 0; i < P; i++) {
+    float e = expf(q[i * 64] / t - mx);
+    se += e; sx += e * (float)(i % OW); sy += e * (float)(i / OW);
+  }
+  f32x2 r = {sx / se, sy / se};
+  *reinterpret_cast<f32x2*>(out + (long)img * 128 + 2 * c) = r;
+}
+// d_sa: [n][128]; writes dZ3 = d(y3) masked by ReLU(y3 > 0), and per-image d(temperature).
+__global__ __launch_bounds__(256) void softargmax_bwd_kernel(const float* __restrict__ y3, const float* temp,
+                                                             const float* __restrict__ sa,
+                                                             const float* __restrict__ d_sa,
+                                                             float* __restrict__ dz3, float* __restrict__ dtemp_part,
+                                                             int n_img, int OH, int OW) {
+  const int img = blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
+  if (img >= n_img) return;
+  const float t = temp[0];
+  const int P = OH * OW;
+  const float* q = y3 + (long)img * P * 64 + c;
+  float* o = dz3 + (long)img * P * 64 + c;
+  float mx = -INFINITY;
+  for (int i = 0; i < P; i++) mx = fmaxf(mx, q[i * 64] / t);
+  float se = 0.f;
+  for (int i = 0; i < P; i++) se += expf(q[i * 64] / t - mx);
+  const float gx = d_sa[(long)img * 128 + 2 * c], gy = d_sa[(long)img * 128 + 2 * c + 1];
+  const float dot = gx * sa[(long)img * 128 + 2 * c] + gy * sa[(long)img * 128 + 2 * c + 1];
+  float dt = 0.f;
+  for (int i = 0; i < P; i++) {
+    const float v = q[i * 64], s = v / t;
+    const float pr = expf(s - mx) / se;
+    const float ds = pr * (gx * (float)(i % OW) + gy * (float)(i / OW) - dot);
+    dt -= ds * s / t;
+    o[i * 64] = v > 0.f ? ds / t : 0.f;
+  }
+  dt = wave_sum(dt);
+  if (c == 0) dtemp_part[img] = dt;
+}
+__global__ void sum_to_scalar_kernel(const float* __restrict__ part, int n, float* out, int accumulate) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = sh[0] + sh[1] + sh[2] + sh[3];
+    *out = accumulate ? *out + v : v;
+  }
+}
+
+// ================================================================== encoder
+enum { E_W1, E_B1, E_W2, E_B2, E_W3, E_B3, E_T, E_FW1, E_FB1, E_FW2, E_FB2, E_N };
+extern "C" long tacorl_encoder_param_layout(long* o) {
+  const long sz[E_N] = {32 * 8 * 8 * 3, 32, 64 * 4 * 4 * 32, 64, 64 * 3 * 3 * 64, 64, 1, 256 * 128, 256, 32 * 256, 32};
+  long off = 0;
+  for (int i = 0; i < E_N; i++) { if (o) o[i] = off; off = al4(off + sz[i]); }
+  return off;
+}
+struct EncDims { ConvGeom c1, c2, c3; };
+static bool enc_dims(int H, int W, EncDims& d) {
+  if (H < 36 || W < 36) return false;  // conv stack needs >= 36 px (8/4, 4/2, 3/1)
+  d.c1 = make_geom(H, W, 3, 8, 8, 4, 32);
+  d.c2 = make_geom(d.c1.OH, d.c1.OW, 32, 4, 4, 2, 64);
+  d.c3 = make_geom(d.c2.OH, d.c2.OW, 64, 3, 3, 1, 64);
+  return d.c3.OH >= 1 && d.c3.OW >= 1;
+}
+extern "C" long tacorl_encoder_act_layout(int n, int H, int W, long* o) {
+  EncDims d;
+  if (!enc_dims(H, W, d)) return -1;
+  const long sz[5] = {(long)n * d.c1.OH * d.c1.OW * 32, (long)n * d.c2.OH * d.c2.OW * 64,
+                      (long)n * d.c3.OH * d.c3.OW * 64, (long)n * 128, (long)n * 256};
+  long off = 0;
+  for (int i = 0; i < 5; i++) { if (o) o[i] = off; off = al4(off + sz[i]); }
+  return off;
+}
+
+extern "C" int tacorl_encoder_fwd(int nprob, const void* const* img, const float* const* params,
+                                  float* const* out, float* const* act, const int* n_img, int H, int W,
+                                  int img_dtype, int cd, tacorl_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  EncDims d;
+  if (!enc_dims(H, W, d)) FAIL(TACORL_EINVAL, "encoder: image %dx%d too small", H, W);
+  if (nprob < 1 || nprob > GEMM_MAXP) FAIL(TACORL_EINVAL, "encoder_fwd: nprob %d", nprob);
+  long po[E_N];
+  tacorl_encoder_param_layout(po);
+  const float *w1[GEMM_MAXP], *b1[GEMM_MAXP], *w2[GEMM_MAXP], *b2[GEMM_MAXP], *w3[GEMM_MAXP], *b3[GEMM_MAXP],
+      *fw1[GEMM_MAXP], *fb1[GEMM_MAXP], *fw2[GEMM_MAXP], *fb2[GEMM_MAXP];
+  float *y1[GEMM_MAXP], *y2[GEMM_MAXP], *y3[GEMM_MAXP], *sa[GEMM_MAXP], *h1[GEMM_MAXP];
+  for (int p = 0; p < nprob; p++) {
+    long ao[5];
+    tacorl_encoder_act_layout(n_img[p], H, W, ao);
+    const float* P = params[p];
+    w1[p] = P + po[E_W1]; b1[p] = P + po[E_B1]; w2[p] = P + po[E_W2]; b2[p] = P + po[E_B2];
+    w3[p] = P + po[E_W3]; b3[p] = P + po[E_B3]; fw1[p] = P + po[E_FW1]; fb1[p] = P + po[E_FB1];
+    fw2[p] = P + po[E_FW2]; fb2[p] = P + po[E_FB2];
+    y1[p] = act[p] + ao[0]; y2[p] = act[p] + ao[1]; y3[p] = act[p] + ao[2]; sa[p] = act[p] + ao[3];
+    h1[p] = act[p] + ao[4];
+  }
+  CHECK(conv_fwd_any(nprob, img, w1, b1, y1, n_img, d.c1, img_dtype, cd, st));
+  CHECK(conv_fwd_any(nprob, (const void* const*)y1, w2, b2, y2, n_img, d.c2, TACORL_F32, cd, st));
+  CHECK(conv_fwd_any(nprob, (const void* const*)y2, w3, b3, y3, n_img, d.c3, TACORL_F32, cd, st));
+  for (int p = 0; p < nprob; p++) {
+    if (n_img[p] == 0) continue;
+    hipLaunchKernelGGL(softargmax_fwd_kernel, dim3(cdiv(n_img[p], 4)), dim3(256), 0, st, y3[p],
+                       params[p] + po[E_T], sa[p], n_img[p], d.c3.OH, d.c3.OW);
+  }
+  CHECK(k_linear_fwd(nprob, sa, 128, fw1, fb1, h1, nullptr, n_img, 128, 256, 256, ACT_RELU, cd, st));
+  CHECK(k_linear_fwd(nprob, h1, 256, fw2, fb2, out, nullptr, n_img, 256, 32, 32, ACT_NONE, cd, st));
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
+static size_t enc_slab_bytes(int nprob, long maxn, const EncDims& d) {
+  size_t m = 0, s;
+  s = wgrad_ws_bytes(nprob, 192, 32, maxn * d.c1.OH * d.c1.OW); m = s > m ? s : m;
+  s = wgrad_ws_bytes(nprob, 512, 64, maxn * d.c2.OH * d.c2.OW); m = s > m ? s : m;
+  s = wgrad_ws_bytes(nprob, 576, 64, maxn * d.c3.OH * d.c3.OW); m = s > m ? s : m;
+  s = wgrad_ws_bytes(nprob, 128, 256, maxn); m = s > m ? s : m;
+  s = wgrad_ws_bytes(nprob, 256, 32, maxn); m = s > m ? s : m;
+  return m;
+}
+// per-problem scratch: d_h1 | d_sa | dz3 | dz2 | dz1 | dtemp_part
+static long enc_bwd_scratch_layout(int n, const EncDims& d, long* o) {
+  const long sz[6] = {(long)n * 256, (long)n * 128, (long)n * d.c3.OH * d.c3.OW * 64,
+                      (long)n * d.c2.OH * d.c2.OW * 64, (long)n * d.c1.OH * d.c1.OW * 32, (long)n};
+  long off = 0;
+  for (int i = 0; i < 6; i++) { if (o) o[i] = off; off = al4(off + sz[i]); }
+  return off;
+}
+extern "C" size_t tacorl_encoder_bwd_ws_bytes(int nprob, const int* n_img, int H, int W) {
+  EncDims d;
+  if (!enc_dims(H, W, d)) return 0;
+  long tot = 0, maxn = 0;
+  for (int p = 0; p < nprob; p++) { tot += enc_bwd_scratch_layout(n_img[p], d, nullptr); maxn = n_img[p] > maxn ? n_img[p] : maxn; }
+  return (size_t)tot * sizeof(float) + enc_slab_bytes(nprob, maxn, d);
+}
+
+extern "C" int tacorl_encoder_bwd(int nprob, const void* const* img, const float* const* params,
+                                  const float* const* act, const float* const* d_out, float* const* grads,
+                                  const int* n_img, int H, int W, int img_dtype, int cd, int accumulate,
+                                  void* ws, size_t ws_bytes, tacorl_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  EncDims d;
+  if (!enc_dims(H, W, d)) FAIL(TACORL_EINVAL, "encoder: image %dx%d too small", H, W);
+  if (nprob < 1 || nprob * 4 > GEMM_MAXP) FAIL(TACORL_EINVAL, "encoder_bwd: nprob %d (max %d)", nprob, GEMM_MAXP / 4);
+  if (ws_bytes < tacorl_encoder_bwd_ws_bytes(nprob, n_img, H, W)) FAIL(TACORL_ENOMEM, "encoder_bwd: workspace too small");
+  long po[E_N];
+  tacorl_encoder_param_layout(po);
+  const float *w2[GEMM_MAXP], *w3[GEMM_MAXP], *fw1[GEMM_MAXP], *fw2[GEMM_MAXP];
+  const float *y1[GEMM_MAXP], *y2[GEMM_MAXP], *y3[GEMM_MAXP], *sa[GEMM_MAXP], *h1[GEMM_MAXP];
+  float *d_h1[GEMM_MAXP], *d_sa[GEMM_MAXP], *dz3[GEMM_MAXP], *dz2[GEMM_MAXP], *dz1[GEMM_MAXP], *dtp[GEMM_MAXP];
+  float *g_w1[GEMM_MAXP], *g_b1[GEMM_MAXP], *g_w2[GEMM_MAXP], *g_b2[GEMM_MAXP], *g_w3[GEMM_MAXP], *g_b3[GEMM_MAXP],
+      *g_fw1[GEMM_MAXP], *g_fb1[GEMM_MAXP], *g_fw2[GEMM_MAXP], *g_fb2[GEMM_MAXP];
+  float* cur = (float*)ws;
+  long maxn = 0;
+  for (int p = 0; p < nprob; p++) {
+    long ao[5], so[6];
+    tacorl_encoder_act_layout(n_img[p], H, W, ao);
+    const long tot = enc_bwd_scratch_layout(n_img[p], d, so);
+    const float* P = params[p];
+    w2[p] = P + po[E_W2]; w3[p] = P + po[E_W3]; fw1[p] = P + po[E_FW1]; fw2[p] = P + po[E_FW2];
+    y1[p] = act[p] + ao[0]; y2[p] = act[p] + ao[1]; y3[p] = act[p] + ao[2]; sa[p] = act[p] + ao[3]; h1[p] = act[p] + ao[4];
+    d_h1[p] = cur + so[0]; d_sa[p] = cur + so[1]; dz3[p] = cur + so[2]; dz2[p] = cur + so[3]; dz1[p] = cur + so[4]; dtp[p] = cur + so[5];
+    cur += tot;
+    float* G = grads[p];
+    g_w1[p] = G + po[E_W1]; g_b1[p] = G + po[E_B1]; g_w2[p] = G + po[E_W2]; g_b2[p] = G + po[E_B2];
+    g_w3[p] = G + po[E_W3]; g_b3[p] = G + po[E_B3]; g_fw1[p] = G + po[E_FW1]; g_fb1[p] = G + po[E_FB1];
+    g_fw2[p] = G + po[E_FW2]; g_fb2[p] = G + po[E_FB2];
+    maxn = n_img[p] > maxn ? n_img[p] : maxn;
+  }
+  void* slab = cur;
+  const size_t slab_bytes = enc_slab_bytes(nprob, maxn, d);
+  // fc2: out = h1 W2^T + b2
+  CHECK(k_linear_wgrad(nprob, h1, 256, d_out, 32, n_img, 256, 32, g_fw2, g_fb2, accumulate, slab, slab_bytes, cd, st));
+  CHECK(k_linear_dgrad(nprob, d_out, 32, fw2, d_h1, 256, h1, ACT_RELU, n_img, 32, 256, cd, st));
+  // fc1: h1 = relu(sa W1^T + b1)
+  CHECK(k_linear_wgrad(nprob, sa, 128, (const float* const*)d_h1, 256, n_img, 128, 256, g_fw1, g_fb1, accumulate, slab, slab_bytes, cd, st));
+  CHECK(k_linear_dgrad(nprob, (const float* const*)d_h1, 256, fw1, d_sa, 128, nullptr, ACT_NONE, n_img, 256, 128, cd, st));
+  // spatial soft-argmax (+ temperature) and ReLU mask of conv3
+  for (int p = 0; p < nprob; p++) {
+    if (n_img[p] == 0) continue;
+    hipLaunchKernelGGL(softargmax_bwd_kernel, dim3(cdiv(n_img[p], 4)), dim3(256), 0, st, y3[p], params[p] + po[E_T],
+                       sa[p], d_sa[p], dz3[p], dtp[p], n_img[p], d.c3.OH, d.c3.OW);
+    hipLaunchKernelGGL(sum_to_scalar_kernel, dim3(1), dim3(256), 0, st, dtp[p], n_img[p], grads[p] + po[E_T], accumulate);
+  }
+  // conv3
+  CHECK(k_conv_wgrad<float>(nprob, (const void* const*)y2, (const float* const*)dz3, n_img, d.c3, g_w3, g_b3, accumulate, slab, slab_bytes, cd, st));
+  CHECK(k_conv_dgrad(nprob, (const float* const*)dz3, w3, dz2, y2, n_img, d.c3, cd, st));
+  // conv2
+  CHECK(k_conv_wgrad<float>(nprob, (const void* const*)y1, (const float* const*)dz2, n_img, d.c2, g_w2, g_b2, accumulate, slab, slab_bytes, cd, st));
+  CHECK(k_conv_dgrad(nprob, (const float* const*)dz2, w2, dz1, y1, n_img, d.c2, cd, st));
+  // conv1 (no input gradient: images are data)
+  if (img_dtype == TACORL_BF16)
+    CHECK(k_conv_wgrad<__bf16>(nprob, img, (const float* const*)dz1, n_img, d.c1, g_w1, g_b1, accumulate, slab, slab_bytes, cd, st));
+  else
+    CHECK(k_conv_wgrad<float>(nprob, img, (const float* const*)dz1, n_img, d.c1, g_w1, g_b1, accumulate, slab, slab_bytes, cd, st));
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
+// ====================================================================== MLP
+extern "C" long tacorl_mlp_param_layout(int L, const int* dims, long* w_off, long* b_off) {
+  long off = 0;
+  for (int l = 0; l < L; l++) {
+    if (w_off) w_off[l] = off;
+    off = al4(off + (long)dims[l + 1] * dims[l]);
+    if (b_off) b_off[l] = off;
+    off = al4(off + dims[l + 1]);
+  }
+  return off;
+}
+extern "C" long tacorl_mlp_act_layout(int M, int L, const int* dims, const int* acts, long* z_off, long* y_off) {
+  long off = 0;
+  for (int l = 0; l < L; l++) {
+    if (z_off) z_off[l] = -1;
+    if (acts[l] == ACT_SILU) { if (z_off) z_off[l] = off; off = al4(off + (long)M * dims[l + 1]); }
+    if (y_off) y_off[l] = off;
+    off = al4(off + (long)M * dims[l + 1]);
+  }
+  return off;
+}
+#define MLP_MAXL 8
+
+extern "C" int tacorl_mlp_fwd(int nprob, const float* const* x, int ldx, const float* const* params,
+                              float* const* act, const int* M, int L, const int* dims, const int* acts, int cd,
+                              tacorl_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (L < 1 || L > MLP_MAXL || nprob < 1 || nprob > GEMM_MAXP) FAIL(TACORL_EINVAL, "mlp_fwd: bad L/nprob");
+  long wo[MLP_MAXL], bo[MLP_MAXL];
+  tacorl_mlp_param_layout(L, dims, wo, bo);
+  for (int l = 0; l < L; l++) {
+    const float *xin[GEMM_MAXP], *w[GEMM_MAXP], *b[GEMM_MAXP];
+    float *y[GEMM_MAXP], *z[GEMM_MAXP];
+    for (int p = 0; p < nprob; p++) {
+      long zo[MLP_MAXL], yo[MLP_MAXL];
+      tacorl_mlp_act_layout(M[p], L, dims, acts, zo, yo);
+      xin[p] = l == 0 ? x[p] : act[p] + yo[l - 1];
+      w[p] = params[p] + wo[l]; b[p] = params[p] + bo[l];
+      y[p] = act[p] + yo[l]; z[p] = zo[l] >= 0 ? act[p] + zo[l] : nullptr;
+    }
+    CHECK(k_linear_fwd(nprob, xin, l == 0 ? ldx : dims[l], w, b, y, z, M, dims[l], dims[l + 1], dims[l + 1], acts[l], cd, st));
+  }
+  return TACORL_OK;
+}
+
+static void mlp_bwd_sizes(int nprob, const int* M, int L, const int* dims, long& dz_floats, size_t& slab) {
+  int maxd = 0;
+  for (int l = 0; l <= L; l++) maxd = dims[l] > maxd ? dims[l] : maxd;
+  long maxM = 0;
+  dz_floats = 0;
+  for (int p = 0; p < nprob; p++) { dz_floats += 2 * al4((long)M[p] * maxd); maxM = M[p] > maxM ? M[p] : maxM; }
+  slab = 0;
+  for (int l = 0; l < L; l++) { size_t s = wgrad_ws_bytes(nprob, dims[l], dims[l + 1], maxM); slab = s > slab ? s : slab; }
+}
+extern "C" size_t tacorl_mlp_bwd_ws_bytes(int nprob, const int* M, int L, const int* dims) {
+  long dz; size_t slab;
+  mlp_bwd_sizes(nprob, M, L, dims, dz, slab);
+  return (size_t)dz * sizeof(float) + slab;
+}
+
+extern "C" int tacorl_mlp_bwd(int nprob, const float* const* x, int ldx, const float* const* params,
+                              const float* const* act, const float* const* d_out, int ldo, float* const* grads,
+                              float* const* d_x, int ldd, const int* M, int L, const int* dims, const int* acts,
+                              int cd, int accumulate, void* ws, size_t ws_bytes, tacorl_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (L < 1 || L > MLP_MAXL || nprob < 1 || nprob > GEMM_MAXP) FAIL(TACORL_EINVAL, "mlp_bwd: bad L/nprob");
+  if (acts[L - 1] != ACT_NONE) FAIL(TACORL_EINVAL, "mlp_bwd: last activation must be NONE");
+  long dzf; size_t slab_bytes;
+  mlp_bwd_sizes(nprob, M, L, dims, dzf, slab_bytes);
+  if (ws_bytes < (size_t)dzf * sizeof(float) + slab_bytes) FAIL(TACORL_ENOMEM, "mlp_bwd: workspace too small");
+  int maxd = 0;
+  for (int l = 0; l <= L; l++) maxd = dims[l] > maxd ? dims[l] : maxd;
+  long wo[MLP_MAXL], bo[MLP_MAXL];
+  tacorl_mlp_param_layout(L, dims, wo, bo);
+  float* buf[2][GEMM_MAXP];
+  float* cur = (float*)ws;
+  for (int p = 0; p < nprob; p++) { buf[0][p] = cur; cur += al4((long)M[p] * maxd); buf[1][p] = cur; cur += al4((long)M[p] * maxd); }
+  void* slab = cur;
+  bool any_grads = false, any_dx = false;
+  for (int p = 0; p < nprob; p++) { any_grads |= grads && grads[p]; any_dx |= d_x && d_x[p]; }
+  const float* dz[GEMM_MAXP];
+  for (int p = 0; p < nprob; p++) dz[p] = d_out[p];
+  for (int l = L - 1; l >= 0; l--) {
+    const float *xin[GEMM_MAXP], *w[GEMM_MAXP], *src[GEMM_MAXP];
+    float *dw[GEMM_MAXP], *db[GEMM_MAXP], *out[GEMM_MAXP];
+    int Mg[GEMM_MAXP], Md[GEMM_MAXP];
+    for (int p = 0; p < nprob; p++) {
+      long zo[MLP_MAXL], yo[MLP_MAXL];
+      tacorl_mlp_act_layout(M[p], L, dims, acts, zo, yo);
+      xin[p] = l == 0 ? x[p] : act[p] + yo[l - 1];
+      w[p] = params[p] + wo[l];
+      const bool hg = grads && grads[p];
+      dw[p] = hg ? grads[p] + wo[l] : nullptr; db[p] = hg ? grads[p] + bo[l] : nullptr;
+      Mg[p] = hg ? M[p] : 0;
+      if (l > 0) {
+        src[p] = acts[l - 1] == ACT_SILU ? act[p] + zo[l - 1] : (acts[l - 1] == ACT_RELU ? act[p] + yo[l - 1] : nullptr);
+        out[p] = buf[l & 1][p]; Md[p] = M[p];
+      } else {
+        src[p] = nullptr; out[p] = d_x ? d_x[p] : nullptr; Md[p] = out[p] ? M[p] : 0;
+      }
+    }
+    if (any_grads) {
+      // problems without grads get M = 0 rows: their slabs reduce to zeros, so point them at scratch
+      const float* xg[GEMM_MAXP]; const float* dzg[GEMM_MAXP]; float* dwg[GEMM_MAXP]; float* dbg[GEMM_MAXP]; int Mc[GEMM_MAXP];
+      int n2 = 0;
+      for (int p = 0; p < nprob; p++) if (Mg[p] > 0) { xg[n2] = xin[p]; dzg[n2] = dz[p]; dwg[n2] = dw[p]; dbg[n2] = db[p]; Mc[n2] = Mg[p]; n2++; }
+      if (n2) CHECK(k_linear_wgrad(n2, xg, l == 0 ? ldx : dims[l], dzg, l == L - 1 ? ldo : dims[l + 1], Mc, dims[l], dims[l + 1], dwg, dbg, accumulate, slab, slab_bytes, cd, st));
+    }
+    if (l > 0 || any_dx) {
+      const float* dzd[GEMM_MAXP]; const float* wd[GEMM_MAXP]; const float* srcd[GEMM_MAXP]; float* outd[GEMM_MAXP]; int Mc[GEMM_MAXP];
+      int n2 = 0;
+      for (int p = 0; p < nprob; p++) if (Md[p] > 0) { dzd[n2] = dz[p]; wd[n2] = w[p]; srcd[n2] = src[p]; outd[n2] = out[p]; Mc[n2] = Md[p]; n2++; }
+      if (n2) CHECK(k_linear_dgrad(n2, dzd, l == L - 1 ? ldo : dims[l + 1], wd, outd, l == 0 ? ldd : dims[l], srcd, l > 0 ? acts[l - 1] : ACT_NONE, Mc, dims[l + 1], dims[l], cd, st));
+    }
+    if (l > 0) for (int p = 0; p < nprob; p++) dz[p] = buf[l & 1][p];
+  }
+  return TACORL_OK;
+}

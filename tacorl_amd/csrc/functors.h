@@ -1,0 +1,132 @@
+// Loader / epilogue functors plugged into gemm_kernel (see gemm.h for the contract).
+#pragma once
+#include "gemm.h"
+
+// ------------------------------------------------------------------ loaders
+// Plain row-major fp32 matrix [rows][cols], leading dimension ld.  ones_col: a virtual
+// extra column (index == cols) that reads 1.0 - folds the bias gradient into wgrad.
+struct RowMajorLoader {
+  const float* ptr[GEMM_MAXP];
+  int rows[GEMM_MAXP];
+  int cols, ld, vec, ones_col;
+  __device__ __forceinline__ void load(int p, int i, int j, float (&v)[4]) const {
+    const int nr = rows[p];
+    if (i >= nr) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
+    const float* q = ptr[p] + (long)i * ld + j;
+    if (vec && j + 3 < cols) { load4_as_float<float>(q, v); return; }
+#pragma unroll
+    for (int t = 0; t < 4; t++) v[t] = (j + t < cols) ? q[t] : ((ones_col && j + t == cols) ? 1.f : 0.f);
+  }
+};
+
+struct ConvGeom {
+  int H, W, C, KH, KW, S, CO, OH, OW;
+};
+
+// Implicit im2col of an NHWC tensor: logical [m = (img, oy, ox)][k = (ky, kx, ci)].
+// (kx, ci) is one contiguous run of KW*C elements in memory (requires KW*C % 4 == 0).
+template <typename InT>
+struct ConvColLoader {
+  const InT* ptr[GEMM_MAXP];
+  int rows[GEMM_MAXP];  // n_img * OH * OW
+  ConvGeom g;
+  int vec, ones_col;
+  __device__ __forceinline__ void load(int p, int m, int k, float (&v)[4]) const {
+    const int K = g.KH * g.KW * g.C;
+    if (m >= rows[p] || k >= K) {
+#pragma unroll
+      for (int t = 0; t < 4; t++) v[t] = (ones_col && m < rows[p] && k + t == K) ? 1.f : 0.f;
+      return;
+    }
+    const int px = g.OH * g.OW, run = g.KW * g.C;
+    const int img = m / px, pp = m - img * px, oy = pp / g.OW, ox = pp - oy * g.OW;
+    const int ky = k / run, r = k - ky * run;
+    const InT* q = ptr[p] + (((long)img * g.H + oy * g.S + ky) * g.W + ox * g.S) * g.C + r;
+    if (vec) { load4_as_float<InT>(q, v); return; }
+#pragma unroll
+    for (int t = 0; t < 4; t++) v[t] = (float)q[t];
+  }
+};
+
+// Conv backward-data as a gather.  Problem index = net * S*S + (py*S + px): one GEMM per
+// input-pixel parity class.  Logical A[m = (img, y2, x2)][k' = (a, b, co)] =
+// dOut[img][y2 - a][x2 - b][co]  (zero outside), where iy = S*y2 + py, ky = py + S*a.
+struct ConvDgradALoader {
+  const float* ptr[GEMM_MAXP];  // dOut (already multiplied by the activation mask), NHWC
+  int n_img[GEMM_MAXP];
+  ConvGeom g;
+  int TA, TB_;  // taps per axis = ceil(KH / S)
+  __device__ __forceinline__ void load(int p, int m, int k, float (&v)[4]) const {
+    const int S = g.S, cls = p % (S * S), py = cls / S, px = cls % S;
+    const int nh = (g.H - py + S - 1) / S, nw = (g.W - px + S - 1) / S;
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (m >= n_img[p] * nh * nw || k >= TA * TB_ * g.CO) return;
+    const int img = m / (nh * nw), pp = m - img * nh * nw, y2 = pp / nw, x2 = pp - y2 * nw;
+    const int tap = k / g.CO, co = k - tap * g.CO, a = tap / TB_, b = tap - a * TB_;
+    const int oy = y2 - a, ox = x2 - b;
+    if (py + S * a >= g.KH || px + S * b >= g.KW || oy < 0 || oy >= g.OH || ox < 0 || ox >= g.OW) return;
+    load4_as_float<float>(ptr[p] + (((long)img * g.OH + oy) * g.OW + ox) * g.CO + co, v);
+  }
+};
+// Matching weights: logical [i = k' = (a, b, co)][j = ci] = W[co][py + S a][px + S b][ci].
+struct ConvDgradWLoader {
+  const float* ptr[GEMM_MAXP];  // W [CO][KH][KW][C]
+  ConvGeom g;
+  int TA, TB_;
+  __device__ __forceinline__ void load(int p, int k, int ci, float (&v)[4]) const {
+    const int S = g.S, cls = p % (S * S), py = cls / S, px = cls % S;
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (k >= TA * TB_ * g.CO || ci >= g.C) return;
+    const int tap = k / g.CO, co = k - tap * g.CO, a = tap / TB_, b = tap - a * TB_;
+    const int ky = py + S * a, kx = px + S * b;
+    if (ky >= g.KH || kx >= g.KW) return;
+    load4_as_float<float>(ptr[p] + (((long)co * g.KH + ky) * g.KW + kx) * g.C + ci, v);
+  }
+};
+
+// ---------------------------------------------------------------- epilogues
+// y = act(acc + bias[n]); optional pre-activation copy z.
+struct BiasActStore {
+  const float* bias[GEMM_MAXP];
+  float* y[GEMM_MAXP];
+  float* z[GEMM_MAXP];
+  int ld, act;
+  __device__ __forceinline__ void store(int p, int, int m, int n, float acc) const {
+    float zz = acc + (bias[p] ? bias[p][n] : 0.f);
+    long o = (long)m * ld + n;
+    if (z[p]) z[p][o] = zz;
+    y[p][o] = act_apply(act, zz);
+  }
+};
+// out = acc * act'(src)   (src = pre-activation for SiLU, output for ReLU; NULL = identity)
+struct DgradStore {
+  float* out[GEMM_MAXP];
+  const float* src[GEMM_MAXP];
+  int ld, act;
+  __device__ __forceinline__ void store(int p, int, int m, int n, float acc) const {
+    long o = (long)m * ld + n;
+    out[p][o] = src[p] ? acc * act_grad(act, src[p][o]) : acc;
+  }
+};
+// conv dgrad: row m of parity class -> NHWC input position; masks with ReLU of the input.
+struct ConvDgradStore {
+  float* out[GEMM_MAXP];
+  const float* src[GEMM_MAXP];  // the conv input activation (post-ReLU) or NULL
+  ConvGeom g;
+  __device__ __forceinline__ void store(int p, int, int m, int n, float acc) const {
+    const int S = g.S, cls = p % (S * S), py = cls / S, px = cls % S;
+    const int nh = (g.H - py + S - 1) / S, nw = (g.W - px + S - 1) / S;
+    const int img = m / (nh * nw), pp = m - img * nh * nw, y2 = pp / nw, x2 = pp - y2 * nw;
+    long o = (((long)img * g.H + S * y2 + py) * g.W + S * x2 + px) * g.C + n;
+    out[p][o] = (src[p] && !(src[p][o] > 0.f)) ? 0.f : acc;
+  }
+};
+// wgrad: GEMM row = k (input feature / im2col column, k == K is the bias column),
+// GEMM col = o (output feature).  Slab layout per (problem, split): [O][K+1].
+struct WgradStore {
+  float* slab[GEMM_MAXP];
+  int K, O, nsplit;
+  __device__ __forceinline__ void store(int p, int s, int k, int o, float acc) const {
+    slab[p][((long)s * O + o) * (K + 1) + k] = acc;
+  }
+};

@@ -1,0 +1,164 @@
+// One LDS-tiled MFMA contraction template for every dense op on the hot path.
+//
+//   C[p][m][n] = sum_{r in split s} A_p(m, r) * B_p(n, r)        p = problem, s = R-split
+//
+// Operands come from *loader functors* (implicit im2col, transposed weights, padded
+// gathers ...) and results leave through an *epilogue functor* (bias+activation,
+// activation-derivative masks, split-K slabs ...).  A loader exposes a logical 2-D
+// matrix [i][j] that is contiguous along j in memory and returns 4 consecutive j:
+//     load(p, i, j, v[4])        (zero-filled out of range)
+// TA/TB say whether the reduction index is j (false: rows are M/N, staged as-is) or
+// i (true: the matrix is [R][M] / [R][N] in memory and is transposed while staged).
+//
+// Tile: BM x BN x 32, 256 threads = 4 waves stacked along M, each wave owning
+// (BM/64) x (BN/16) 16x16 MFMA tiles.  Global loads for tile t+1 are issued into
+// registers before the MFMAs of tile t (register double buffering, one LDS buffer).
+#pragma once
+#include "common.h"
+
+#define GEMM_MAXP 16
+#define GEMM_BK 32
+
+struct GemmArgs {
+  int nprob;
+  int nsplit;
+  int N;             // common to all problems
+  int M[GEMM_MAXP];  // rows per problem
+  int R[GEMM_MAXP];  // reduction length per problem
+};
+
+template <class Atom, class LA, class LB, bool TA, bool TB, class Epi, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmArgs g) {
+  typedef typename Atom::elem T;
+  constexpr int BK = GEMM_BK;
+  constexpr int LD = BK + Atom::PAD;
+  constexpr int MI = BM / 64;
+  constexpr int NI = BN / 16;
+  constexpr int ACH = BM * BK / 4 / 256;  // float4 chunks per thread, A tile
+  constexpr int BCH = (BN * BK / 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) T As[BM * LD];
+  __shared__ __attribute__((aligned(16))) T Bs[BN * LD];
+
+  const int p = blockIdx.z / g.nsplit;
+  const int s = blockIdx.z % g.nsplit;
+  const int M = g.M[p], N = g.N, R = g.R[p];
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= M) return;
+  int rs = ((R + g.nsplit - 1) / g.nsplit + BK - 1) / BK * BK;
+  const int r_begin = s * rs;
+  const int r_end = min(R, r_begin + rs);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  float ra[ACH][4], rb[BCH][4];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < ACH; i++) {
+      int c = tid + i * 256;
+      if (!TA) la.load(p, m0 + c / (BK / 4), r0 + (c % (BK / 4)) * 4, ra[i]);
+      else     la.load(p, r0 + c / (BM / 4), m0 + (c % (BM / 4)) * 4, ra[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < BCH; i++) {
+      int c = tid + i * 256;
+      if (BN * BK / 4 % 256 != 0 && c >= BN * BK / 4) break;
+      if (!TB) lb.load(p, n0 + c / (BK / 4), r0 + (c % (BK / 4)) * 4, rb[i]);
+      else     lb.load(p, r0 + c / (BN / 4), n0 + (c % (BN / 4)) * 4, rb[i]);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < ACH; i++) {
+      int c = tid + i * 256;
+      if (!TA) {
+        T* d = &As[(c / (BK / 4)) * LD + (c % (BK / 4)) * 4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) d[j] = Atom::cvt(ra[i][j]);
+      } else {
+        int r = c / (BM / 4), m = (c % (BM / 4)) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) As[(m + j) * LD + r] = Atom::cvt(ra[i][j]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BCH; i++) {
+      int c = tid + i * 256;
+      if (BN * BK / 4 % 256 != 0 && c >= BN * BK / 4) break;
+      if (!TB) {
+        T* d = &Bs[(c / (BK / 4)) * LD + (c % (BK / 4)) * 4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) d[j] = Atom::cvt(rb[i][j]);
+      } else {
+        int r = c / (BN / 4), n = (c % (BN / 4)) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) Bs[(n + j) * LD + r] = Atom::cvt(rb[i][j]);
+      }
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int j = 0; j < NI; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (r_begin < r_end) fetch(r_begin);
+  for (int r0 = r_begin; r0 < r_end; r0 += BK) {
+    stash();
+    __syncthreads();
+    if (r0 + BK < r_end) fetch(r0 + BK);
+    const T* ap = &As[(wave * MI * 16 + (lane & 15)) * LD + (lane >> 4) * Atom::KPACK];
+    const T* bp = &Bs[(lane & 15) * LD + (lane >> 4) * Atom::KPACK];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += Atom::KSTEP) {
+      typename Atom::frag a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; i++) a[i] = Atom::ld(ap + i * 16 * LD + kk);
+#pragma unroll
+      for (int j = 0; j < NI; j++) b[j] = Atom::ld(bp + j * 16 * LD + kk);
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NI; j++) acc[i][j] = Atom::mma(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int j = 0; j < NI; j++) {
+      int n = n0 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        int m = m0 + wave * MI * 16 + i * 16 + (lane >> 4) * 4 + q;
+        if (m < M && n < N) epi.store(p, s, m, n, acc[i][j][q]);
+      }
+    }
+}
+
+// Host-side launcher: picks the tile for N and the atom for the compute dtype.
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+template <class LA, class LB, bool TA, bool TB, class Epi>
+static int gemm_launch(const LA& la, const LB& lb, const Epi& epi, const GemmArgs& g, int compute_dtype,
+                       hipStream_t st) {
+  int maxM = 0;
+  for (int i = 0; i < g.nprob; i++) maxM = g.M[i] > maxM ? g.M[i] : maxM;
+  if (maxM == 0 || g.N == 0) return TACORL_OK;
+#define GEMM_GO(ATOM, BM_, BN_)                                                              \
+  do {                                                                                       \
+    dim3 grid(cdiv(maxM, BM_), cdiv(g.N, BN_), g.nprob * g.nsplit);                          \
+    hipLaunchKernelGGL((gemm_kernel<ATOM, LA, LB, TA, TB, Epi, BM_, BN_>), grid, dim3(256), \
+                       0, st, la, lb, epi, g);                                               \
+  } while (0)
+#define GEMM_PICK(ATOM)                        \
+  do {                                         \
+    if (g.N > 32) GEMM_GO(ATOM, 128, 64);      \
+    else if (g.N > 16) GEMM_GO(ATOM, 128, 32); \
+    else GEMM_GO(ATOM, 128, 16);               \
+  } while (0)
+  if (compute_dtype == DT_BF16) GEMM_PICK(AtomBF16);
+  else GEMM_PICK(AtomF32);
+#undef GEMM_PICK
+#undef GEMM_GO
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}

@@ -1,0 +1,501 @@
+// HBM-/latency-bound kernels of the CQL / TACO-RL step: image packing, tanh-Gaussian
+// sampling + log-prob, the fused Bellman + CQL logsumexp loss (fwd+bwd in one pass, wave
+// shuffle reductions), the twin-Q min for the actor loss, and the fused clip+Adam+Polyak.
+#include <stdio.h>
+
+#include "../../include/tacorl_hip.h"
+#include "common.h"
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH)
+
+__device__ __forceinline__ float softplusf(float x) {  // F.softplus, threshold 20
+  return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// =================================================================== pack_images
+// src: n images, image i at src + i*img_pitch (elements); layout NCHW (src_nchw) or NHWC.
+// dst: contiguous NHWC, fp32 or bf16.
+template <typename OutT>
+__global__ void pack_images_kernel(const float* __restrict__ src, long img_pitch, int src_nchw,
+                                   OutT* __restrict__ dst, int n, int C, int HW) {
+  const long total = (long)n * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long img = i / HW;
+    const int px = (int)(i - img * HW);
+    const float* s = src + img * img_pitch;
+    OutT* d = dst + i * C;
+    for (int c = 0; c < C; c++) d[c] = (OutT)(src_nchw ? s[(long)c * HW + px] : s[(long)px * C + c]);
+  }
+}
+extern "C" int tacorl_pack_images(const float* src, long img_pitch, int src_nchw, void* dst, int dst_dtype,
+                                  int n, int C, int H, int W, tacorl_stream_t stream) {
+  if (n <= 0) return TACORL_OK;
+  const long total = (long)n * H * W;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (dst_dtype == TACORL_BF16)
+    hipLaunchKernelGGL(pack_images_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, img_pitch,
+                       src_nchw, (__bf16*)dst, n, C, H * W);
+  else
+    hipLaunchKernelGGL(pack_images_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, img_pitch,
+                       src_nchw, (float*)dst, n, C, H * W);
+  return LAUNCH_OK();
+}
+
+// ===================================================================== copy_cols
+__global__ void copy_cols_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
+                                 int rows, int cols, int src_row_mod, int accumulate) {
+  const long total = (long)rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    const int rs = src_row_mod > 0 ? r % src_row_mod : r;
+    const float v = src[(long)rs * ld_src + c];
+    float* d = dst + (long)r * ld_dst + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+// dst[r][0:cols] (+)= src[r % src_row_mod][0:cols]; pointers are pre-offset to the first column.
+extern "C" int tacorl_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols,
+                                int src_row_mod, int accumulate, tacorl_stream_t stream) {
+  if (rows <= 0 || cols <= 0) return TACORL_OK;
+  const long total = (long)rows * cols;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, rows,
+                     cols, src_row_mod, accumulate);
+  return LAUNCH_OK();
+}
+
+// out[b][c] = sum_j in[(j*B + b)][c], j < reps   (gradient of a broadcast over samples)
+__global__ void reduce_rows_mod_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int ld_out,
+                                       int B, int cols, int reps) {
+  const long total = (long)B * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / cols), c = (int)(i - (long)b * cols);
+    float s = 0.f;
+    for (int j = 0; j < reps; j++) s += in[((long)j * B + b) * ld_in + c];
+    out[(long)b * ld_out + c] = s;
+  }
+}
+extern "C" int tacorl_reduce_rows_mod(const float* in, int ld_in, float* out, int ld_out, int B, int cols, int reps,
+                                      tacorl_stream_t stream) {
+  if (B <= 0) return TACORL_OK;
+  const long total = (long)B * cols;
+  hipLaunchKernelGGL(reduce_rows_mod_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     ld_in, out, ld_out, B, cols, reps);
+  return LAUNCH_OK();
+}
+
+// uniform random actions: dst[r][0:A] = 2u - 1 (last dim snapped to +-1 if discrete gripper)
+// reference cql_offline_lightning.py:243-250
+__global__ void uniform_actions_kernel(const float* __restrict__ u01, float* __restrict__ dst, int ld_dst, int rows,
+                                       int A, int discrete_gripper) {
+  const long total = (long)rows * A;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / A), c = (int)(i - (long)r * A);
+    float v = u01[i] * 2.0f - 1.0f;
+    if (discrete_gripper && c == A - 1) v = v >= 0.f ? 1.f : -1.f;
+    dst[(long)r * ld_dst + c] = v;
+  }
+}
+extern "C" int tacorl_uniform_actions(const float* u01, float* dst, int ld_dst, int rows, int A, int discrete_gripper,
+                                      tacorl_stream_t stream) {
+  if (rows <= 0) return TACORL_OK;
+  const long total = (long)rows * A;
+  hipLaunchKernelGGL(uniform_actions_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u01,
+                     dst, ld_dst, rows, A, discrete_gripper);
+  return LAUNCH_OK();
+}
+
+// ================================================================ tanh-Gaussian
+// head[m] = [mean_raw (Ac) | log_std_raw (Ac) | gripper logits (2, optional)]
+// reference actor.py:259-265 (clamps), utils/distributions.py:78-140 (TanhNormal).
+__device__ __forceinline__ void head_stats(const float* h, int j, int Ac, float& mu, float& sd) {
+  mu = fminf(fmaxf(h[j], -9.0f), 9.0f);
+  sd = expf(fminf(fmaxf(h[Ac + j], -5.0f), 2.0f));
+}
+__device__ __forceinline__ float normal_lp(float z, float mu, float sd) {
+  const float d = z - mu;
+  return -(d * d) / (2.f * (sd * sd)) - logf(sd) - 0.9189385332046727f;
+}
+__device__ __forceinline__ float tanh_corr(float z) {  // -2(log2 - z - softplus(-2z))
+  return -2.f * (0.6931471805599453f - z - softplusf(-2.f * z));
+}
+
+// One thread per (sample k, row m): a = tanh(mu + sd*eps) written to act_out[(k*M+m)*ld_act .. +Ac),
+// log pi to logp[k*M+m].  gumbel_u (n,M,2) U(0,1) adds the discrete gripper (actor.py:118-132 /
+// :83-97): index = argmax(norm_logits - log(-log u)) or, for hard_rsample, the relaxed-categorical
+// argmax at temperature 0.5; action +-1 appended, its log-softmax added to log pi.
+__global__ void tanh_normal_sample_kernel(const float* __restrict__ head, int ld_head, const float* __restrict__ eps,
+                                          const float* __restrict__ gumbel_u, int hard_rsample,
+                                          float* __restrict__ act_out, int ld_act, float* __restrict__ logp,
+                                          int* __restrict__ grip_idx, int n, int M, int Ac) {
+  const long total = (long)n * M;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i % M);
+    const float* h = head + (long)m * ld_head;
+    float lp = 0.f, corr = 0.f;
+    for (int j = 0; j < Ac; j++) {
+      float mu, sd;
+      head_stats(h, j, Ac, mu, sd);
+      const float z = mu + eps[i * Ac + j] * sd;
+      act_out[i * ld_act + j] = tanhf(z);
+      lp += normal_lp(z, mu, sd);
+      corr += (0.6931471805599453f - z - softplusf(-2.f * z));
+    }
+    lp += -2.f * corr;
+    if (gumbel_u) {
+      const float l0 = h[2 * Ac], l1 = h[2 * Ac + 1];
+      const float mx = fmaxf(l0, l1);
+      const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+      const float n0 = l0 - lse, n1 = l1 - lse;
+      float u0 = gumbel_u[i * 2], u1 = gumbel_u[i * 2 + 1];
+      int idx;
+      if (hard_rsample) {
+        const float e = 1.1920929e-07f;
+        u0 = fminf(fmaxf(u0, e), 1.f - e); u1 = fminf(fmaxf(u1, e), 1.f - e);
+        const float s0 = (n0 - logf(-logf(u0))) / 0.5f, s1 = (n1 - logf(-logf(u1))) / 0.5f;
+        idx = s1 > s0 ? 1 : 0;
+      } else {
+        idx = (n1 - logf(-logf(u1))) > (n0 - logf(-logf(u0))) ? 1 : 0;
+      }
+      // log_softmax of the normalised logits
+      const float mm = fmaxf(n0, n1), l2 = mm + logf(expf(n0 - mm) + expf(n1 - mm));
+      lp += (idx ? n1 : n0) - l2;
+      act_out[i * ld_act + Ac] = idx ? 1.f : -1.f;
+      if (grip_idx) grip_idx[i] = idx;
+    }
+    logp[i] = lp;
+  }
+}
+extern "C" int tacorl_tanh_normal_sample(const float* head, int ld_head, const float* eps, const float* gumbel_u,
+                                         int hard_rsample, float* act_out, int ld_act, float* logp, int* grip_idx,
+                                         int n, int M, int Ac, tacorl_stream_t stream) {
+  if (n <= 0 || M <= 0) return TACORL_OK;
+  const long total = (long)n * M;
+  hipLaunchKernelGGL(tanh_normal_sample_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     head, ld_head, eps, gumbel_u, hard_rsample, act_out, ld_act, logp, grip_idx, n, M, Ac);
+  return LAUNCH_OK();
+}
+
+// ------------------------------------------------------------------ actor losses
+// logs slots (device float buffer, also the host-visible metric record)
+enum {
+  LG_ALPHA_LOSS = 0, LG_ALPHA, LG_ACTOR_LOSS, LG_BELL1, LG_BELL2, LG_CONS1, LG_CONS2, LG_Q1LOSS, LG_Q2LOSS,
+  LG_ALPHA_P, LG_ALPHA_P_LOSS, LG_Q1_DATA, LG_Q1_RAND, LG_Q1_POL, LG_Q2_DATA, LG_Q2_RAND, LG_Q2_POL, LG_ACTION_LOSS,
+  LG_COUNT
+};
+
+// alpha_loss = -mean(log_alpha * (logpi + target_entropy));  d/dlog_alpha = -mean(logpi + H)
+// (cql_offline_lightning.py:447-449).  Single block.
+__global__ __launch_bounds__(256) void alpha_loss_kernel(const float* __restrict__ logp, int B, const float* log_alpha,
+                                                         float target_entropy, float inv_world, float* g_log_alpha,
+                                                         float* logs) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) s += logp[i] + target_entropy;
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) {
+    const float mean = s / (float)B;
+    g_log_alpha[0] = -mean * inv_world;
+    logs[LG_ALPHA_LOSS] = -(log_alpha[0] * mean);
+  }
+}
+extern "C" int tacorl_alpha_loss(const float* logp, int B, const float* log_alpha, float target_entropy,
+                                 float grad_scale, float* g_log_alpha, float* logs, tacorl_stream_t stream) {
+  hipLaunchKernelGGL(alpha_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, B, log_alpha,
+                     target_entropy, grad_scale, g_log_alpha, logs);
+  return LAUNCH_OK();
+}
+
+// Q phase (cql_offline_lightning.py:463-466): actor_loss = mean(alpha*logpi - min(q1,q2)).
+// Writes d(actor_loss)/dq_i (torch.min tie rule: split evenly) and the loss.  Single block.
+__global__ __launch_bounds__(256) void actor_qmin_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                                                         const float* __restrict__ logp, int B, const float* log_alpha,
+                                                         float* __restrict__ dq1, float* __restrict__ dq2,
+                                                         float grad_scale, float* logs) {
+  __shared__ float sh[4];
+  const float alpha = expf(log_alpha[0]);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    const float a = q1[i], b = q2[i];
+    s += alpha * logp[i] - fminf(a, b);
+    const float g = -grad_scale / (float)B;
+    dq1[i] = a < b ? g : (a == b ? 0.5f * g : 0.f);
+    dq2[i] = b < a ? g : (a == b ? 0.5f * g : 0.f);
+  }
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) { logs[LG_ACTOR_LOSS] = s / (float)B; logs[LG_ALPHA] = alpha; }
+}
+extern "C" int tacorl_actor_qmin(const float* q1, const float* q2, const float* logp, int B, const float* log_alpha,
+                                 float* dq1, float* dq2, float grad_scale, float* logs, tacorl_stream_t stream) {
+  hipLaunchKernelGGL(actor_qmin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q1, q2, logp, B, log_alpha, dq1,
+                     dq2, grad_scale, logs);
+  return LAUNCH_OK();
+}
+
+// Gradient of the actor loss w.r.t. the policy head (rsample path, actor.py:106-111):
+//   L = (1/B) sum_b [ alpha*logpi_b  - Qmin_b            ]   (Q phase:  g_act = dL/da from the critics)
+//   L = (1/B) sum_b [ alpha*logpi_b  - logp_data_b       ]   (BC phase: value = dataset action)
+// d logpi/d mu_j = 2 a_j, d logpi/d logsd_j = -1 + 2 a_j eps_j sd_j (the Normal terms cancel through
+// z = mu + sd*eps), d a_j/d mu_j = 1 - a_j^2, clamp masks as torch.clamp.  One thread per row.
+// bc: also accumulates mean(alpha*logpi - logp_data) into logs (single block when bc).
+__global__ __launch_bounds__(256) void actor_head_bwd_kernel(
+    const float* __restrict__ head, int ld_head, const float* __restrict__ eps, const float* __restrict__ logp,
+    const float* __restrict__ g_act1, const float* __restrict__ g_act2, int ld_g, const float* __restrict__ value,
+    int ld_value, const int* __restrict__ grip_idx, const float* log_alpha, float grad_scale,
+    float* __restrict__ d_head, int B, int Ac, int has_grip, float* logs) {
+  __shared__ float sh[4];
+  const float alpha = expf(log_alpha[0]);
+  const float gl = alpha * grad_scale / (float)B;  // dL/dlogpi
+  float loss = 0.f;
+  for (int b = threadIdx.x + blockIdx.x * 256; b < B; b += 256 * gridDim.x) {
+    const float* h = head + (long)b * ld_head;
+    float* dh = d_head + (long)b * ld_head;
+    float lpd = 0.f;
+    for (int j = 0; j < Ac; j++) {
+      float mu, sd;
+      head_stats(h, j, Ac, mu, sd);
+      const float e = eps[(long)b * Ac + j];
+      const float a = tanhf(mu + e * sd);
+      float gm = gl * 2.f * a, gs = gl * (-1.f + 2.f * a * e * sd);
+      if (g_act1) {
+        float ga = g_act1[(long)b * ld_g + j] + (g_act2 ? g_act2[(long)b * ld_g + j] : 0.f);
+        gm += ga * (1.f - a * a);
+        gs += ga * (1.f - a * a) * e * sd;
+      }
+      if (value) {  // - (1/B) d logp_data: TanhNormal.log_prob(value), distributions.py:98-109
+        float v = fminf(fmaxf(value[(long)b * ld_value + j], -0.999f), 0.999f);
+        const float zd = 0.5f * logf(fmaxf(1.f + v, 1e-6f) / fmaxf(1.f - v, 1e-6f));
+        const float d = zd - mu, var = sd * sd;
+        lpd += normal_lp(zd, mu, sd) + tanh_corr(zd);
+        const float c = -grad_scale / (float)B;
+        gm += c * (d / var);
+        gs += c * ((d * d) / var - 1.f);
+      }
+      const float mr = h[j], lr = h[Ac + j];
+      dh[j] = (mr >= -9.f && mr <= 9.f) ? gm : 0.f;
+      dh[Ac + j] = (lr >= -5.f && lr <= 2.f) ? gs : 0.f;
+    }
+    if (has_grip) {
+      // log pi (and, in BC, log p_data) contain log_softmax(logits)[idx]: d/dlogits = onehot - softmax
+      const float l0 = h[2 * Ac], l1 = h[2 * Ac + 1], mx = fmaxf(l0, l1);
+      const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+      const int idx = grip_idx[b];
+      float g0 = gl * ((idx == 0 ? 1.f : 0.f) - p0), g1 = gl * ((idx == 1 ? 1.f : 0.f) - p1);
+      if (value) {
+        const int vi = (int)(value[(long)b * ld_value + Ac] / 2.f + 0.5f);
+        const float c = -grad_scale / (float)B;
+        g0 += c * ((vi == 0 ? 1.f : 0.f) - p0); g1 += c * ((vi == 1 ? 1.f : 0.f) - p1);
+        lpd += (vi ? l1 : l0) - (mx + logf(e0 + e1));
+      }
+      dh[2 * Ac] = g0; dh[2 * Ac + 1] = g1;
+    }
+    if (value) loss += alpha * logp[b] - lpd;
+  }
+  if (value && gridDim.x == 1) {
+    loss = block_sum_256(loss, sh);
+    if (threadIdx.x == 0) { logs[LG_ACTOR_LOSS] = loss / (float)B; logs[LG_ALPHA] = alpha; }
+  }
+}
+extern "C" int tacorl_actor_head_bwd(const float* head, int ld_head, const float* eps, const float* logp,
+                                     const float* g_act1, const float* g_act2, int ld_g, const float* value,
+                                     int ld_value, const int* grip_idx, const float* log_alpha, float grad_scale,
+                                     float* d_head, int B, int Ac, int has_grip, float* logs,
+                                     tacorl_stream_t stream) {
+  hipLaunchKernelGGL(actor_head_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, head, ld_head, eps, logp,
+                     g_act1, g_act2, ld_g, value, ld_value, grip_idx, log_alpha, grad_scale, d_head, B, Ac, has_grip,
+                     logs);
+  return LAUNCH_OK();
+}
+
+// ================================================================= CQL + Bellman
+// q_i: Q outputs for rows [data B | rand nB | cur nB | nxt nB] (sample-major k*B+b).
+// One wave per sample b: the 3n logits live one per lane (3n <= 64), logsumexp / softmax by
+// wave shuffles (reference cql_offline_lightning.py:284-314, 357-398).  Writes dL_i/dq for every
+// row, per-wave partial sums; the last phase (block 0 of a second launch) folds the partials into
+// the logged scalars and the Lagrange gradient.
+struct CqlArgs {
+  const float* q[2];       // main-row Q outputs
+  float* dq[2];            // gradients, same layout
+  const float* tq[2];      // target Q(next, a')  [B]
+  const float* logp_cur;   // [n*B]
+  const float* logp_nxt;   // [n*B]
+  const float* next_logp;  // [B] log pi(a'|s') (used when !deterministic_backup)
+  const float* reward;     // [B] float
+  const float* done;       // [B] float (0/1)
+  const float* log_alpha;
+  const float* log_alpha_prime;  // NULL when !with_lagrange
+  float* partial;          // [nblocks*4][12]
+  int B, n, A;
+  float discount, reward_scale, temp, cons_w, gap, grad_scale;
+  int deterministic_backup;
+};
+enum { CP_BELL1, CP_BELL2, CP_LSE1, CP_LSE2, CP_D1, CP_D2, CP_R1, CP_R2, CP_P1, CP_P2, CP_N };
+
+__global__ __launch_bounds__(256) void cql_loss_kernel(CqlArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int B = a.B, n = a.n, nc = 3 * n;
+  const float alpha = expf(a.log_alpha[0]);
+  const float alpha_p = a.log_alpha_prime ? fminf(fmaxf(expf(a.log_alpha_prime[0]), 0.f), 1000000.f) : 1.f;
+  const float rand_density = (float)a.A * -0.6931471805599453f;  // log(0.5^A)
+  float acc[CP_N];
+#pragma unroll
+  for (int i = 0; i < CP_N; i++) acc[i] = 0.f;
+  for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
+    float qn = fminf(a.tq[0][b], a.tq[1][b]);
+    if (!a.deterministic_backup) qn -= alpha * a.next_logp[b];
+    const float y = a.reward_scale * a.reward[b] + (1.f - a.done[b]) * a.discount * qn;
+    // which logit this lane owns: j = lane -> group g = j / n, sample k = j % n
+    const int g = lane / n, k = lane - g * n;
+    const bool on = lane < nc;
+    const long row = (long)B + ((long)g * n + k) * B + b;
+    float sub = 0.f;
+    if (on) sub = g == 0 ? rand_density : (g == 1 ? a.logp_cur[(long)k * B + b] : a.logp_nxt[(long)k * B + b]);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const float qd = a.q[i][b];
+      const float qv = on ? a.q[i][row] : 0.f;
+      const float lg = on ? (qv - sub) / a.temp : -INFINITY;
+      const float mx = wave_max(lg);
+      const float e = on ? expf(lg - mx) : 0.f;
+      const float se = wave_sum(e);
+      const float lse = mx + logf(se);
+      if (on) a.dq[i][row] = a.grad_scale * alpha_p * a.cons_w * (e / se) / (float)B;
+      const float sr = wave_sum(on && g == 0 ? qv : 0.f), sp = wave_sum(on && g == 1 ? qv : 0.f);
+      if (lane == 0) {
+        const float d = qd - y;
+        a.dq[i][b] = a.grad_scale * (2.f * d - a.cons_w * alpha_p) / (float)B;
+        acc[CP_BELL1 + i] += d * d; acc[CP_LSE1 + i] += lse; acc[CP_D1 + i] += qd;
+        acc[CP_R1 + i] += sr; acc[CP_P1 + i] += sp;
+      }
+    }
+  }
+  if (lane == 0) {
+    float* o = a.partial + ((long)blockIdx.x * 4 + wv) * CP_N;
+#pragma unroll
+    for (int i = 0; i < CP_N; i++) o[i] = acc[i];
+  }
+}
+__global__ __launch_bounds__(256) void cql_finish_kernel(CqlArgs a, int nparts, float* g_log_alpha_prime, float* logs) {
+  __shared__ float sh[4];
+  float tot[CP_N];
+  for (int i = 0; i < CP_N; i++) {
+    float s = 0.f;
+    for (int j = threadIdx.x; j < nparts; j += 256) s += a.partial[(long)j * CP_N + i];
+    tot[i] = block_sum_256(s, sh);
+  }
+  if (threadIdx.x != 0) return;
+  const float B = (float)a.B, nB = (float)a.B * (float)a.n;
+  const float ea = a.log_alpha_prime ? expf(a.log_alpha_prime[0]) : 1.f;
+  const float alpha_p = a.log_alpha_prime ? fminf(fmaxf(ea, 0.f), 1000000.f) : 1.f;
+  float cons[2], bell[2];
+  for (int i = 0; i < 2; i++) {
+    bell[i] = tot[CP_BELL1 + i] / B;
+    cons[i] = tot[CP_LSE1 + i] / B * a.cons_w * a.temp - tot[CP_D1 + i] / B * a.cons_w;
+  }
+  if (a.log_alpha_prime) {
+    const float raw = (cons[0] - a.gap) + (cons[1] - a.gap);
+    cons[0] = alpha_p * (cons[0] - a.gap); cons[1] = alpha_p * (cons[1] - a.gap);
+    logs[LG_ALPHA_P] = alpha_p;
+    logs[LG_ALPHA_P_LOSS] = (-cons[0] - cons[1]) * 0.5f;
+    // d/dlog_alpha' of -(alpha'(c1-gap) + alpha'(c2-gap))/2 ; clamp passes gradient inside [0,1e6]
+    g_log_alpha_prime[0] = (ea >= 0.f && ea <= 1000000.f) ? -0.5f * raw * ea * a.grad_scale : 0.f;
+  }
+  logs[LG_BELL1] = bell[0]; logs[LG_BELL2] = bell[1];
+  logs[LG_CONS1] = cons[0]; logs[LG_CONS2] = cons[1];
+  logs[LG_Q1LOSS] = bell[0] + cons[0]; logs[LG_Q2LOSS] = bell[1] + cons[1];
+  logs[LG_Q1_DATA] = tot[CP_D1] / B; logs[LG_Q2_DATA] = tot[CP_D2] / B;
+  logs[LG_Q1_RAND] = tot[CP_R1] / nB; logs[LG_Q2_RAND] = tot[CP_R2] / nB;
+  logs[LG_Q1_POL] = tot[CP_P1] / nB; logs[LG_Q2_POL] = tot[CP_P2] / nB;
+}
+extern "C" size_t tacorl_cql_ws_bytes(int B) {
+  const int blocks = (B + 3) / 4 > 256 ? 256 : (B + 3) / 4;
+  return (size_t)blocks * 4 * CP_N * sizeof(float);
+}
+extern "C" int tacorl_cql_loss(const float* q1, const float* q2, float* dq1, float* dq2, const float* tq1,
+                               const float* tq2, const float* logp_cur, const float* logp_nxt,
+                               const float* next_logp, const float* reward, const float* done,
+                               const float* log_alpha, const float* log_alpha_prime, int B, int n, int A,
+                               float discount, float reward_scale, float temp, float cons_w, float gap,
+                               int deterministic_backup, float grad_scale, float* g_log_alpha_prime, float* logs,
+                               void* ws, size_t ws_bytes, tacorl_stream_t stream) {
+  if (3 * n > 64 || n < 1) return TACORL_EINVAL;
+  if (ws_bytes < tacorl_cql_ws_bytes(B)) return TACORL_ENOMEM;
+  CqlArgs a{};
+  a.q[0] = q1; a.q[1] = q2; a.dq[0] = dq1; a.dq[1] = dq2; a.tq[0] = tq1; a.tq[1] = tq2;
+  a.logp_cur = logp_cur; a.logp_nxt = logp_nxt; a.next_logp = next_logp; a.reward = reward; a.done = done;
+  a.log_alpha = log_alpha; a.log_alpha_prime = log_alpha_prime; a.partial = (float*)ws;
+  a.B = B; a.n = n; a.A = A; a.discount = discount; a.reward_scale = reward_scale; a.temp = temp; a.cons_w = cons_w;
+  a.gap = gap; a.grad_scale = grad_scale; a.deterministic_backup = deterministic_backup;
+  const int blocks = (B + 3) / 4 > 256 ? 256 : (B + 3) / 4;
+  hipLaunchKernelGGL(cql_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(cql_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, blocks * 4, g_log_alpha_prime,
+                     logs);
+  return LAUNCH_OK();
+}
+
+// =========================================================== clip + Adam + Polyak
+// torch.optim.Adam (betas .9/.999, eps 1e-8) + clip_grad_norm_ (L2, eps 1e-6) + soft target
+// update (cql_offline_lightning.py:229-232, 519-542), over one flat parameter block.
+// state = {step (as float), } lives on the device so a captured graph replays correctly.
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long n, float* partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                   const float* partial, int nparts, float max_norm,
+                                                   int* step_counter, float* __restrict__ target, float tau) {
+  __shared__ float sh[4];
+  float coef = 1.f;
+  if (max_norm > 0.f) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += partial[i];
+    s = block_sum_256(s, sh);
+    coef = fminf(max_norm / (sqrtf(s) + 1e-6f), 1.0f);
+  }
+  const int t = step_counter[0] + 1;
+  const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
+  const float step_size = (float)((double)lr / bc1), rsq_bc2 = (float)sqrt(bc2);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    const float mi = m[i] * 0.9f + gi * 0.1f;
+    const float vi = v[i] * 0.999f + (gi * gi) * 0.001f;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / rsq_bc2 + 1e-8f;
+    const float pn = p[i] - step_size * (mi / denom);
+    p[i] = pn;
+    if (target) target[i] = target[i] * (1.0f - tau) + pn * tau;
+  }
+}
+__global__ void bump_step_kernel(int* step_counter) { step_counter[0] += 1; }
+
+extern "C" size_t tacorl_adam_ws_bytes(long n) {
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  return (size_t)blocks * sizeof(float);
+}
+extern "C" int tacorl_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr,
+                                float max_norm, int* step_counter, float* target, float tau, void* ws,
+                                size_t ws_bytes, tacorl_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (max_norm > 0.f) {
+    if (ws_bytes < (size_t)blocks * sizeof(float)) return TACORL_ENOMEM;
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3((int)blocks), dim3(256), 0, st, grad, n, (float*)ws);
+  }
+  hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, st, param, grad, m, v, n, lr, (const float*)ws,
+                     (int)blocks, max_norm, step_counter, target, tau);
+  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, step_counter);
+  return LAUNCH_OK();
+}

@@ -1,0 +1,373 @@
+"""Hand-scheduled actor-critic update (CQL_Offline.compute_update) on HIP kernels.
+
+One `ACEngine.update()` = the reference's `compute_update`
+(reference modules/cql/cql_offline_lightning.py:470-542) with the same loss values,
+gradients, optimiser steps and soft target update, but scheduled MI355X-first:
+
+* every unique (encoder, image set) is encoded once (11*B images instead of the reference's
+  (24+12n)*B): the sample expansion `expand_obs` happens on 64-float embeddings;
+* the five networks (actor, q1, q2, target_q1, target_q2) share launches through problem
+  batches; every buffer is pre-allocated so the whole update is hipGraph-capturable;
+* no autograd: forward and backward are explicit kernel sequences; parameters, gradients,
+  Adam moments and targets are flat blocks (clip+Adam+Polyak = 2 launches per network).
+
+Random draws are explicit inputs (`noise` dict, reference draw order - SURVEY 8a note 1).
+"""
+import torch
+
+from . import blocks, ops
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, BF16, F32, LOG_SLOTS, call, ptr
+
+
+def _al4(x):
+    return (x + 3) // 4 * 4
+
+
+class NetBlock:
+    """[encoder(cam) for cam in cams] + goal-encoder MLP + head MLP in one flat buffer."""
+
+    def __init__(self, cams, goal_cams, head_dims, head_acts, head_names, device, head_parts=None, hidden=256):
+        self.cams, self.goal_cams = list(cams), list(goal_cams)
+        self.all_cams = sorted(set(self.cams) | set(self.goal_cams))
+        self.E_obs, self.G = 32 * len(self.cams), 32 * len(self.goal_cams)
+        self.genc_dims, self.genc_acts = [self.G, hidden, hidden, self.G], [ACT_RELU, ACT_RELU, ACT_NONE]
+        self.head_dims, self.head_acts = list(head_dims), list(head_acts)
+        off = 0
+        self.enc_off = {}
+        for c in self.all_cams:
+            self.enc_off[c] = off
+            off += blocks.encoder_size()
+        self.genc_off = off
+        off += blocks.mlp_size(self.genc_dims)
+        self.head_off = off
+        off += blocks.mlp_size(self.head_dims)
+        self.size = off
+        z = lambda: torch.zeros(self.size, device=device)  # noqa: E731
+        self.param, self.grad, self.m, self.v = z(), z(), z(), z()
+        self.step = torch.zeros(1, dtype=torch.int32, device=device)
+        self.views, self.grad_views = {}, {}
+        for flat, dst in ((self.param, self.views), (self.grad, self.grad_views)):
+            for c in self.all_cams:
+                for k, v in blocks.encoder_views(flat, self.enc_off[c]).items():
+                    dst[f"encoder.networks.{c}.{k}"] = v
+            gn = [(f"goal_encoder.mlp.{i}.weight", f"goal_encoder.mlp.{i}.bias") for i in (0, 2, 4)]
+            dst.update(blocks.mlp_views(flat, self.genc_off, self.genc_dims, gn))
+            if head_parts is None:
+                dst.update(blocks.mlp_views(flat, self.head_off, self.head_dims, head_names))
+            else:
+                dst.update(blocks.mlp_views(flat, self.head_off, self.head_dims[:-1], head_names))
+                dst.update(blocks.head_views(flat, self.head_off, self.head_dims, self.head_dims[-2], head_parts))
+
+    def enc(self, cam, flat=None):
+        flat = self.param if flat is None else flat
+        return flat.data_ptr() + 4 * self.enc_off[cam]
+
+    def genc(self, flat=None):
+        return (self.param if flat is None else flat).data_ptr() + 4 * self.genc_off
+
+    def head(self, flat=None):
+        return (self.param if flat is None else flat).data_ptr() + 4 * self.head_off
+
+
+class Scalar:
+    def __init__(self, device, value=0.0):
+        self.param = torch.full((1,), float(value), device=device)
+        self.grad, self.m, self.v = (torch.zeros(1, device=device) for _ in range(3))
+        self.step = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+class ACEngine:
+    def __init__(self, cams, goal_cams, hw, action_dim, B, device, *, n=4, discount=0.99, tau=0.005, actor_lr=3e-4,
+                 critic_lr=3e-4, deterministic_backup=False, reward_scale=1.0, clip_grad_val=1.0,
+                 conservative_weight=1.0, lagrange_thresh=5.0, temp=1.0, with_lagrange=False,
+                 discrete_gripper=False, target_entropy=-7.0, policy_layers=3, q_layers=3, hidden=256,
+                 compute=F32, img_dtype=torch.float32, world_size=1):
+        if sorted(cams) != sorted(goal_cams):
+            raise NotImplementedError("observation and goal modalities must coincide (all in-scope configs)")
+        self.cams, self.hw, self.B, self.n, self.A = list(cams), dict(hw or {}), B, n, action_dim
+        self.dev, self.compute, self.img_dtype = device, compute, img_dtype
+        self.dg = bool(discrete_gripper)
+        self.Ac = action_dim - 1 if self.dg else action_dim
+        self.HD = 2 * self.Ac + (2 if self.dg else 0)
+        self.hp = dict(discount=discount, tau=tau, actor_lr=actor_lr, critic_lr=critic_lr,
+                       deterministic_backup=deterministic_backup, reward_scale=reward_scale,
+                       clip=clip_grad_val, cons_w=conservative_weight, gap=lagrange_thresh, temp=temp,
+                       target_entropy=target_entropy)
+        self.with_lagrange = with_lagrange
+        self.world = world_size
+        self.hidden = hidden
+        nc = len(self.cams)
+        self.Eo = self.G = 32 * nc
+        self.E = self.Eo + self.G
+        self.ldq = _al4(self.E + action_dim)
+        self.lds = self.E
+        pol_dims = [self.E] + [hidden] * policy_layers + [self.HD]
+        q_dims = [self.E + action_dim] + [hidden] * q_layers + [1]
+        silu_p, silu_q = [ACT_SILU] * policy_layers + [ACT_NONE], [ACT_SILU] * q_layers + [ACT_NONE]
+        pn = [(f"actor.policy.fc_layers.{i}.weight", f"actor.policy.fc_layers.{i}.bias") for i in range(policy_layers)]
+        parts = [("actor.policy.fc_mean", self.Ac), ("actor.policy.fc_log_std", self.Ac)]
+        if self.dg:
+            parts.append(("actor.policy.gripper_action", 2))
+        qn = [(f"critic.Q.fc_layers.{i}.weight", f"critic.Q.fc_layers.{i}.bias") for i in range(q_layers)]
+        qn.append(("critic.Q.out.weight", "critic.Q.out.bias"))
+        self.actor = NetBlock(cams, goal_cams, pol_dims, silu_p, pn, device, head_parts=parts, hidden=hidden)
+        mk = lambda: NetBlock(cams, goal_cams, q_dims, silu_q, qn, device, hidden=hidden)  # noqa: E731
+        self.q1, self.q2, self.tq1, self.tq2 = mk(), mk(), mk(), mk()
+        self.log_alpha, self.log_alpha_prime = Scalar(device), Scalar(device)
+        self.B = None
+        if B:
+            self.ensure_batch(B)
+
+    # ------------------------------------------------------------------ buffers
+    def ensure_batch(self, B, hw=None):
+        """(Re)allocate every batch-sized buffer; parameters and optimiser state are untouched."""
+        hw = dict(hw) if hw is not None else self.hw
+        if self.B != B or hw != self.hw:
+            self.B, self.hw = B, hw
+            self._alloc()
+
+    def _alloc(self):
+        B, n, dev = self.B, self.n, self.dev
+        f = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+        self.X3 = {c: torch.zeros(3 * B, *self.hw[c], 3, device=dev, dtype=self.img_dtype) for c in self.cams}
+        # encoder problems: (net, first image row in X3, n images, keep activations for backward)
+        self.enc_probs = [("a_og", self.actor, 0, 2 * B), ("a_nx", self.actor, 2 * B, B), ("q1", self.q1, 0, 2 * B),
+                          ("q2", self.q2, 0, 2 * B), ("tq1", self.tq1, B, 2 * B), ("tq2", self.tq2, B, 2 * B)]
+        self.enc_out = {(k, c): f(nimg, 32) for k, _, _, nimg in self.enc_probs for c in self.cams}
+        self.enc_act = {(k, c): f(ops.encoder_act_layout(nimg, *self.hw[c])[1])
+                        for k, _, _, nimg in self.enc_probs for c in self.cams}
+        self.enc_dout = {(k, c): f(2 * B, 32) for k in ("a_og", "q1", "q2") for c in self.cams}
+        nets = [("a", self.actor), ("q1", self.q1), ("q2", self.q2), ("tq1", self.tq1), ("tq2", self.tq2)]
+        self.nets = nets
+        self.gin = {k: f(B, self.G) for k, _ in nets}
+        self.gact = {k: f(ops.mlp_act_layout(B, net.genc_dims, net.genc_acts)[2]) for k, net in nets}
+        self.g_yoff = ops.mlp_act_layout(B, self.actor.genc_dims, self.actor.genc_acts)[1][-1]
+        self.S = {k: f(B, self.lds) for k in ("a", "a_nx", "q1", "q2", "tq1", "tq2")}
+        pd, pa = self.actor.head_dims, self.actor.head_acts
+        self.pact = {k: f(ops.mlp_act_layout(B, pd, pa)[2]) for k in ("a", "a_nx")}
+        self.p_yoff = ops.mlp_act_layout(B, pd, pa)[1][-1]
+        R = (3 * n + 1) * B
+        self.R = R
+        self.acts_main, self.act_pi, self.act_next = f(R, self.A), f(B, self.A), f(B, self.A)
+        self.logp_pi, self.logp_next = f(B), f(B)
+        self.logp_cur, self.logp_nxt = f(n * B), f(n * B)
+        self.grip_pi = torch.zeros(B, dtype=torch.int32, device=dev)
+        qd, qa = self.q1.head_dims, self.q1.head_acts
+        self.XQ = {k: f(R, self.ldq) for k in ("q1", "q2")}
+        self.XQpi = {k: f(B, self.ldq) for k in ("q1", "q2")}
+        self.XT = {k: f(B, self.ldq) for k in ("tq1", "tq2")}
+        self.qact = {k: f(ops.mlp_act_layout(R, qd, qa)[2]) for k in ("q1", "q2")}
+        self.qact_pi = {k: f(ops.mlp_act_layout(B, qd, qa)[2]) for k in ("q1", "q2")}
+        self.qact_t = {k: f(ops.mlp_act_layout(B, qd, qa)[2]) for k in ("tq1", "tq2")}
+        self.q_yoff_R = ops.mlp_act_layout(R, qd, qa)[1][-1]
+        self.q_yoff_B = ops.mlp_act_layout(B, qd, qa)[1][-1]
+        self.dq = {k: f(R) for k in ("q1", "q2")}
+        self.dq_pi = {k: f(B) for k in ("q1", "q2")}
+        self.dXQ = {k: f(R, self.ldq) for k in ("q1", "q2")}
+        self.dXQpi = {k: f(B, self.ldq) for k in ("q1", "q2")}
+        self.d_head = f(B, self.HD)
+        self.dS = {k: f(B, self.lds) for k in ("a", "q1", "q2")}
+        self.dgin = {k: f(B, self.G) for k in ("a", "q1", "q2")}
+        self.reward, self.done, self.action = f(B), f(B), f(B, self.A)
+        self.noise = dict(eps_pi=f(B, self.Ac), eps_next=f(B, self.Ac), u_rand=f(n * B, self.A),
+                          eps_cur=f(n, B, self.Ac), eps_nxt=f(n, B, self.Ac))
+        if self.dg:
+            self.noise.update(g_pi=f(B, 2), g_next=f(B, 2), g_cur=f(n, B, 2), g_nxt=f(n, B, 2))
+        self.logs = f(32)
+        self.cql_ws = torch.empty(max(256, ops.L.lib().tacorl_cql_ws_bytes(B)), dtype=torch.uint8, device=dev)
+
+    # ------------------------------------------------------------------- inputs
+    def set_noise(self, noise=None):
+        """Copy injected noise, or draw fresh noise with torch's device generator."""
+        for k, buf in self.noise.items():
+            if noise is not None:
+                buf.copy_(noise[k].reshape(buf.shape))
+            elif k.startswith("eps"):
+                buf.normal_()
+            else:
+                buf.uniform_()
+
+    def load_images(self, cam, obs, goal, nxt, nchw=True):
+        """obs/goal/nxt: (B,3,H,W) [nchw] or (B,H,W,3) fp32 device tensors (may be strided views with a
+        uniform image pitch, e.g. states[:,0])."""
+        H, W = self.hw[cam]
+        for i, t in enumerate((obs, goal, nxt)):
+            assert t.is_cuda and t.dtype == torch.float32 and t[0].is_contiguous()
+            pitch = t.stride(0) if t.shape[0] > 1 else 3 * H * W
+            dst_off = i * self.B * H * W * 3
+            dst = self.X3[cam].view(-1)[dst_off:]
+            call("tacorl_pack_images", ptr(t), pitch, int(nchw), ptr(dst),
+                 BF16 if self.img_dtype == torch.bfloat16 else F32, self.B, 3, H, W, ops.stream())
+
+    def load_transition(self, action, reward, done):
+        self.action.copy_(action.reshape(self.B, self.A).float())
+        self.reward.copy_(reward.reshape(self.B).float())
+        self.done.copy_(done.reshape(self.B).float())
+
+    # ----------------------------------------------------------------- forward
+    def _img_ptr(self, cam, first_row):
+        H, W = self.hw[cam]
+        return self.X3[cam].data_ptr() + first_row * H * W * 3 * self.X3[cam].element_size()
+
+    def _encode_all(self):
+        for c in self.cams:
+            H, W = self.hw[c]
+            imgs = [self._img_ptr(c, r0) for _, _, r0, _ in self.enc_probs]
+            params = [net.enc(c) for _, net, _, _ in self.enc_probs]
+            outs = [self.enc_out[(k, c)] for k, _, _, _ in self.enc_probs]
+            acts = [self.enc_act[(k, c)] for k, _, _, _ in self.enc_probs]
+            nimg = [nn_ for _, _, _, nn_ in self.enc_probs]
+            call("tacorl_encoder_fwd", len(imgs), ops.ptr_array(imgs), ops.ptr_array(params), ops.ptr_array(outs),
+                 ops.ptr_array(acts), ops.int_array(nimg), H, W, BF16 if self.img_dtype == torch.bfloat16 else F32,
+                 self.compute, ops.stream())
+
+    def _assemble_states(self):
+        B = self.B
+        # goal-encoder inputs: concat over cams of enc(goal)
+        src = {"a": ("a_og", B), "q1": ("q1", B), "q2": ("q2", B), "tq1": ("tq1", 0), "tq2": ("tq2", 0)}
+        for k, (ek, row0) in src.items():
+            for j, c in enumerate(self.cams):
+                ops.copy_cols(self.enc_out[(ek, c)], row0 * 32, 32, self.gin[k], 32 * j, self.G, B, 32)
+        nets = dict(self.nets)
+        ks = ["a", "q1", "q2", "tq1", "tq2"]
+        ops.mlp_fwd([self.gin[k] for k in ks], self.G, [nets[k].genc() for k in ks], [self.gact[k] for k in ks],
+                    [B] * 5, self.actor.genc_dims, self.actor.genc_acts, self.compute)
+        # S = [enc(obs or next) | goal_enc(enc(goal))]
+        obs_src = {"a": ("a_og", 0, "a"), "a_nx": ("a_nx", 0, "a"), "q1": ("q1", 0, "q1"), "q2": ("q2", 0, "q2"),
+                   "tq1": ("tq1", B, "tq1"), "tq2": ("tq2", B, "tq2")}
+        for k, (ek, row0, gk) in obs_src.items():
+            for j, c in enumerate(self.cams):
+                ops.copy_cols(self.enc_out[(ek, c)], row0 * 32, 32, self.S[k], 32 * j, self.lds, B, 32)
+            ops.copy_cols(self.gact[gk], self.g_yoff, self.G, self.S[k], self.Eo, self.lds, B, self.G)
+
+    def _policy_fwd(self):
+        ks = ["a", "a_nx"]
+        ops.mlp_fwd([self.S[k] for k in ks], self.lds, [self.actor.head()] * 2, [self.pact[k] for k in ks],
+                    [self.B] * 2, self.actor.head_dims, self.actor.head_acts, self.compute)
+
+    def _head(self, k):
+        return self.pact[k][self.p_yoff: self.p_yoff + self.B * self.HD]
+
+    def update(self, bc_phase, optimize=True):
+        """One compute_update.  Inputs must have been staged with load_images / load_transition /
+        set_noise.  Returns nothing; metrics are in self.logs (read with metrics())."""
+        B, n, A, Ac, hp, nz = self.B, self.n, self.A, self.Ac, self.hp, self.noise
+        gs = 1.0 / self.world
+        self._encode_all()
+        self._assemble_states()
+        self._policy_fwd()
+        head_cur, head_next = self._head("a"), self._head("a_nx")
+        g = (lambda k: nz[k]) if self.dg else (lambda k: None)
+        # actor rsample on obs, critic-target sample on next_obs, CQL samples on both
+        ops.tanh_normal_sample(head_cur, self.HD, nz["eps_pi"], g("g_pi"), True, self.act_pi, 0, A, self.logp_pi,
+                               self.grip_pi if self.dg else None, 1, B, Ac)
+        ops.tanh_normal_sample(head_next, self.HD, nz["eps_next"], g("g_next"), False, self.act_next, 0, A,
+                               self.logp_next, None, 1, B, Ac)
+        ops.copy_cols(self.action, 0, A, self.acts_main, 0, A, B, A)
+        ops.uniform_actions(nz["u_rand"], self.acts_main, B * A, A, n * B, A, self.dg)
+        ops.tanh_normal_sample(head_cur, self.HD, nz["eps_cur"], g("g_cur"), False, self.acts_main, (1 + n) * B * A, A,
+                               self.logp_cur, None, n, B, Ac)
+        ops.tanh_normal_sample(head_next, self.HD, nz["eps_nxt"], g("g_nxt"), False, self.acts_main,
+                               (1 + 2 * n) * B * A, A, self.logp_nxt, None, n, B, Ac)
+        # alpha: loss, gradient, Adam step (alpha is read post-step below; SURVEY 8a note 2)
+        call("tacorl_alpha_loss", ptr(self.logp_pi), B, ptr(self.log_alpha.param), float(hp["target_entropy"]), gs,
+             ptr(self.log_alpha.grad), ptr(self.logs), ops.stream())
+        self._allreduce([self.log_alpha.grad])
+        if optimize:
+            ops.adam_step(self.log_alpha.param, self.log_alpha.grad, self.log_alpha.m, self.log_alpha.v,
+                          hp["actor_lr"], 0.0, self.log_alpha.step)
+        # Q inputs: [S | action]
+        for k in ("q1", "q2"):
+            ops.copy_cols(self.S[k], 0, self.lds, self.XQ[k], 0, self.ldq, self.R, self.E, src_row_mod=B)
+            ops.copy_cols(self.acts_main, 0, A, self.XQ[k], self.E, self.ldq, self.R, A)
+            ops.copy_cols(self.S[k], 0, self.lds, self.XQpi[k], 0, self.ldq, B, self.E)
+            ops.copy_cols(self.act_pi, 0, A, self.XQpi[k], self.E, self.ldq, B, A)
+        for k in ("tq1", "tq2"):
+            ops.copy_cols(self.S[k], 0, self.lds, self.XT[k], 0, self.ldq, B, self.E)
+            ops.copy_cols(self.act_next, 0, A, self.XT[k], self.E, self.ldq, B, A)
+        qd, qa = self.q1.head_dims, self.q1.head_acts
+        xs = [self.XQ["q1"], self.XQ["q2"], self.XQpi["q1"], self.XQpi["q2"], self.XT["tq1"], self.XT["tq2"]]
+        ps = [self.q1.head(), self.q2.head(), self.q1.head(), self.q2.head(), self.tq1.head(), self.tq2.head()]
+        ac = [self.qact["q1"], self.qact["q2"], self.qact_pi["q1"], self.qact_pi["q2"], self.qact_t["tq1"],
+              self.qact_t["tq2"]]
+        ops.mlp_fwd(xs, self.ldq, ps, ac, [self.R, self.R, B, B, B, B], qd, qa, self.compute)
+        qout = lambda buf, off, rows: buf[off: off + rows]  # noqa: E731
+        q1m, q2m = qout(self.qact["q1"], self.q_yoff_R, self.R), qout(self.qact["q2"], self.q_yoff_R, self.R)
+        q1p, q2p = qout(self.qact_pi["q1"], self.q_yoff_B, B), qout(self.qact_pi["q2"], self.q_yoff_B, B)
+        t1, t2 = qout(self.qact_t["tq1"], self.q_yoff_B, B), qout(self.qact_t["tq2"], self.q_yoff_B, B)
+        # Bellman + CQL (+Lagrange): losses and dL/dq for every row
+        lap = self.log_alpha_prime
+        call("tacorl_cql_loss", ptr(q1m), ptr(q2m), ptr(self.dq["q1"]), ptr(self.dq["q2"]), ptr(t1), ptr(t2),
+             ptr(self.logp_cur), ptr(self.logp_nxt), ptr(self.logp_next), ptr(self.reward), ptr(self.done),
+             ptr(self.log_alpha.param), ptr(lap.param) if self.with_lagrange else None, B, n, A,
+             float(hp["discount"]), float(hp["reward_scale"]), float(hp["temp"]), float(hp["cons_w"]),
+             float(hp["gap"]), int(hp["deterministic_backup"]), gs, ptr(lap.grad), ptr(self.logs), ptr(self.cql_ws),
+             self.cql_ws.numel(), ops.stream())
+        # ---- actor backward
+        if bc_phase:
+            call("tacorl_actor_head_bwd", ptr(head_cur), self.HD, ptr(nz["eps_pi"]), ptr(self.logp_pi), None, None, 0,
+                 ptr(self.action), A, ptr(self.grip_pi) if self.dg else None, ptr(self.log_alpha.param), gs,
+                 ptr(self.d_head), B, Ac, int(self.dg), ptr(self.logs), ops.stream())
+        else:
+            call("tacorl_actor_qmin", ptr(q1p), ptr(q2p), ptr(self.logp_pi), B, ptr(self.log_alpha.param),
+                 ptr(self.dq_pi["q1"]), ptr(self.dq_pi["q2"]), gs, ptr(self.logs), ops.stream())
+            ops.mlp_bwd([self.XQpi["q1"], self.XQpi["q2"]], self.ldq, [self.q1.head(), self.q2.head()],
+                        [self.qact_pi["q1"], self.qact_pi["q2"]], [self.dq_pi["q1"], self.dq_pi["q2"]], 1,
+                        [None, None], [self.dXQpi["q1"], self.dXQpi["q2"]], self.ldq, [B, B], qd, qa, self.compute)
+            call("tacorl_actor_head_bwd", ptr(head_cur), self.HD, ptr(nz["eps_pi"]), ptr(self.logp_pi),
+                 ops._at(self.dXQpi["q1"], self.E), ops._at(self.dXQpi["q2"], self.E), self.ldq, None, 0,
+                 ptr(self.grip_pi) if self.dg else None, ptr(self.log_alpha.param), gs, ptr(self.d_head), B, Ac,
+                 int(self.dg), ptr(self.logs), ops.stream())
+        ops.mlp_bwd([self.S["a"]], self.lds, [self.actor.head()], [self.pact["a"]], [self.d_head], self.HD,
+                    [self.actor.head(self.actor.grad)], [self.dS["a"]], self.lds, [B], self.actor.head_dims,
+                    self.actor.head_acts, self.compute)
+        # ---- critic backward through the Q MLPs; sum the broadcast embedding gradient over samples
+        ops.mlp_bwd([self.XQ["q1"], self.XQ["q2"]], self.ldq, [self.q1.head(), self.q2.head()],
+                    [self.qact["q1"], self.qact["q2"]], [self.dq["q1"], self.dq["q2"]], 1,
+                    [self.q1.head(self.q1.grad), self.q2.head(self.q2.grad)], [self.dXQ["q1"], self.dXQ["q2"]],
+                    self.ldq, [self.R, self.R], qd, qa, self.compute)
+        for k in ("q1", "q2"):
+            ops.reduce_rows_mod(self.dXQ[k], 0, self.ldq, self.dS[k], 0, self.lds, B, self.E, 3 * n + 1)
+        # ---- goal encoders (3 nets, one batch), then the encoders
+        nets = {"a": self.actor, "q1": self.q1, "q2": self.q2}
+        ks = ["a", "q1", "q2"]
+        ops.mlp_bwd([self.gin[k] for k in ks], self.G, [nets[k].genc() for k in ks], [self.gact[k] for k in ks],
+                    [ops._at(self.dS[k], self.Eo) for k in ks], self.lds, [nets[k].genc(nets[k].grad) for k in ks],
+                    [self.dgin[k] for k in ks], self.G, [B] * 3, self.actor.genc_dims, self.actor.genc_acts,
+                    self.compute)
+        ek = {"a": "a_og", "q1": "q1", "q2": "q2"}
+        for j, c in enumerate(self.cams):
+            for k in ks:
+                ops.copy_cols(self.dS[k], 32 * j, self.lds, self.enc_dout[(ek[k], c)], 0, 32, B, 32)
+                ops.copy_cols(self.dgin[k], 32 * j, self.G, self.enc_dout[(ek[k], c)], B * 32, 32, B, 32)
+            H, W = self.hw[c]
+            imgs = [self._img_ptr(c, 0)] * 3
+            ops_n = [2 * B] * 3
+            nb = ops.L.lib().tacorl_encoder_bwd_ws_bytes(3, ops.int_array(ops_n), H, W)
+            ws = ops.workspace(nb, self.dev, "enc_bwd")
+            call("tacorl_encoder_bwd", 3, ops.ptr_array(imgs), ops.ptr_array([nets[k].enc(c) for k in ks]),
+                 ops.ptr_array([self.enc_act[(ek[k], c)] for k in ks]),
+                 ops.ptr_array([self.enc_dout[(ek[k], c)] for k in ks]),
+                 ops.ptr_array([nets[k].enc(c, nets[k].grad) for k in ks]), ops.int_array(ops_n), H, W,
+                 BF16 if self.img_dtype == torch.bfloat16 else F32, self.compute, 0, ptr(ws), ws.numel(), ops.stream())
+        # ---- optimiser steps (grads were all taken on the pre-step graph, as in the reference)
+        grads = [self.actor.grad, self.q1.grad, self.q2.grad] + ([lap.grad] if self.with_lagrange else [])
+        self._allreduce(grads)
+        if optimize:
+            if self.with_lagrange:
+                ops.adam_step(lap.param, lap.grad, lap.m, lap.v, hp["critic_lr"], 0.0, lap.step)
+            a = self.actor
+            ops.adam_step(a.param, a.grad, a.m, a.v, hp["actor_lr"], hp["clip"], a.step)
+            for q, t in ((self.q1, self.tq1), (self.q2, self.tq2)):
+                ops.adam_step(q.param, q.grad, q.m, q.v, hp["critic_lr"], hp["clip"], q.step, t.param, hp["tau"])
+
+    def _allreduce(self, tensors):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            for t in tensors:
+                dist.all_reduce(t)
+
+    def metrics(self):
+        v = self.logs.cpu().tolist()
+        return dict(zip(LOG_SLOTS, v))

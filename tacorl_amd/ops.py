@@ -1,0 +1,147 @@
+"""Thin torch-tensor wrappers over the C ABI (device memory + streams are torch's; the
+arithmetic is libtacorl_hip.so's).  No function here computes anything itself."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, BF16, F32, call, int_array, ptr, ptr_array, stream  # noqa: F401
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only scratch buffer per (device, tag); stable address once grown (graph-safe
+    after the warm-up step)."""
+    key = (str(device), tag)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), (t.dtype, t.device, t.is_contiguous())
+    return t
+
+
+# ------------------------------------------------------------------------- layouts
+def encoder_param_layout():
+    off = (C.c_long * 11)()
+    total = L.lib().tacorl_encoder_param_layout(off)
+    return list(off), int(total)
+
+
+def encoder_act_layout(n_img, H, W):
+    off = (C.c_long * 5)()
+    total = L.lib().tacorl_encoder_act_layout(int(n_img), H, W, off)
+    if total < 0:
+        raise L.TacorlHipError(f"encoder: image {H}x{W} too small for the conv stack")
+    return list(off), int(total)
+
+
+def mlp_param_layout(dims):
+    n = len(dims) - 1
+    w, b = (C.c_long * n)(), (C.c_long * n)()
+    total = L.lib().tacorl_mlp_param_layout(n, int_array(dims), w, b)
+    return list(w), list(b), int(total)
+
+
+def mlp_act_layout(M, dims, acts):
+    n = len(dims) - 1
+    z, y = (C.c_long * n)(), (C.c_long * n)()
+    total = L.lib().tacorl_mlp_act_layout(int(M), n, int_array(dims), int_array(acts), z, y)
+    return list(z), list(y), int(total)
+
+
+# ------------------------------------------------------------------------ primitives
+def linear_fwd(xs, ws, bs, act=ACT_NONE, compute=F32, want_z=False):
+    M = [x.shape[0] for x in xs]
+    K, N = xs[0].shape[1], ws[0].shape[0]
+    ys = [torch.empty(m, N, device=xs[0].device) for m in M]
+    zs = [torch.empty(m, N, device=xs[0].device) for m in M] if want_z else None
+    call("tacorl_linear_fwd", len(xs), ptr_array([_f32(x) for x in xs]), K, ptr_array(ws), ptr_array(bs),
+         ptr_array(ys), ptr_array(zs) if zs else None, int_array(M), K, N, act, compute, stream())
+    return (ys, zs) if want_z else ys
+
+
+def conv2d_relu_fwd(xs, ws, bs, stride, compute=F32):
+    """xs: NHWC (fp32 or bf16); ws: [CO][KH][KW][CI] fp32."""
+    n = [x.shape[0] for x in xs]
+    _, H, W, Ci = xs[0].shape
+    CO, KH, KW, _ = ws[0].shape
+    OH, OW = (H - KH) // stride + 1, (W - KW) // stride + 1
+    ys = [torch.empty(k, OH, OW, CO, device=xs[0].device) for k in n]
+    xd = BF16 if xs[0].dtype == torch.bfloat16 else F32
+    call("tacorl_conv2d_relu_fwd", len(xs), ptr_array(xs), ptr_array(ws), ptr_array(bs), ptr_array(ys),
+         int_array(n), H, W, Ci, KH, KW, stride, CO, xd, compute, stream())
+    return ys
+
+
+# --------------------------------------------------------------------------- encoder
+def encoder_fwd(imgs, params, outs, acts, H, W, compute=F32):
+    n = [i.shape[0] for i in imgs]
+    xd = BF16 if imgs[0].dtype == torch.bfloat16 else F32
+    call("tacorl_encoder_fwd", len(imgs), ptr_array(imgs), ptr_array(params), ptr_array(outs), ptr_array(acts),
+         int_array(n), H, W, xd, compute, stream())
+
+
+def encoder_bwd(imgs, params, acts, d_outs, grads, H, W, compute=F32, accumulate=False):
+    n = [i.shape[0] for i in imgs]
+    xd = BF16 if imgs[0].dtype == torch.bfloat16 else F32
+    nb = L.lib().tacorl_encoder_bwd_ws_bytes(len(imgs), int_array(n), H, W)
+    ws = workspace(nb, imgs[0].device, "enc_bwd")
+    call("tacorl_encoder_bwd", len(imgs), ptr_array(imgs), ptr_array(params), ptr_array(acts), ptr_array(d_outs),
+         ptr_array(grads), int_array(n), H, W, xd, compute, int(accumulate), ptr(ws), ws.numel(), stream())
+
+
+# ------------------------------------------------------------------------------- MLP
+def mlp_fwd(xs, ldx, params, acts_buf, M, dims, acts, compute=F32):
+    call("tacorl_mlp_fwd", len(xs), ptr_array(xs), ldx, ptr_array(params), ptr_array(acts_buf), int_array(M),
+         len(dims) - 1, int_array(dims), int_array(acts), compute, stream())
+
+
+def mlp_bwd(xs, ldx, params, acts_buf, d_outs, ldo, grads, d_xs, ldd, M, dims, acts, compute=F32, accumulate=False):
+    nb = L.lib().tacorl_mlp_bwd_ws_bytes(len(xs), int_array(M), len(dims) - 1, int_array(dims))
+    ws = workspace(nb, acts_buf[0].device, "mlp_bwd")
+    call("tacorl_mlp_bwd", len(xs), ptr_array(xs), ldx, ptr_array(params), ptr_array(acts_buf), ptr_array(d_outs), ldo,
+         ptr_array(grads), ptr_array(d_xs) if d_xs is not None else None, ldd, int_array(M), len(dims) - 1,
+         int_array(dims), int_array(acts), compute, int(accumulate), ptr(ws), ws.numel(), stream())
+
+
+# --------------------------------------------------------------------- data movement
+def pack_images(src, img_pitch, src_nchw, dst, n, Cc, H, W, src_offset=0):
+    dd = BF16 if dst.dtype == torch.bfloat16 else F32
+    call("tacorl_pack_images", C.c_void_p(src.data_ptr() + 4 * src_offset), img_pitch, int(src_nchw), ptr(dst), dd,
+         n, Cc, H, W, stream())
+
+
+def _at(t, off):
+    return C.c_void_p(t.data_ptr() + 4 * off)
+
+
+def copy_cols(src, src_off, ld_src, dst, dst_off, ld_dst, rows, cols, src_row_mod=0, accumulate=False):
+    call("tacorl_copy_cols", _at(src, src_off), ld_src, _at(dst, dst_off), ld_dst, rows, cols, src_row_mod,
+         int(accumulate), stream())
+
+
+def reduce_rows_mod(src, src_off, ld_in, dst, dst_off, ld_out, B, cols, reps):
+    call("tacorl_reduce_rows_mod", _at(src, src_off), ld_in, _at(dst, dst_off), ld_out, B, cols, reps, stream())
+
+
+def uniform_actions(u01, dst, dst_off, ld_dst, rows, A, discrete_gripper):
+    call("tacorl_uniform_actions", ptr(u01), _at(dst, dst_off), ld_dst, rows, A, int(discrete_gripper), stream())
+
+
+def tanh_normal_sample(head, ld_head, eps, gumbel_u, hard, act_out, act_off, ld_act, logp, grip_idx, n, M, Ac):
+    call("tacorl_tanh_normal_sample", ptr(head), ld_head, ptr(eps), ptr(gumbel_u), int(hard), _at(act_out, act_off),
+         ld_act, ptr(logp), ptr(grip_idx), n, M, Ac, stream())
+
+
+def adam_step(param, grad, m, v, lr, max_norm, step_counter, target=None, tau=0.0):
+    n = param.numel()
+    nb = L.lib().tacorl_adam_ws_bytes(n)
+    ws = workspace(nb, param.device, "adam")
+    call("tacorl_adam_step", ptr(param), ptr(grad), ptr(m), ptr(v), n, float(lr), float(max_norm), ptr(step_counter),
+         ptr(target), float(tau), ptr(ws), ws.numel(), stream())

@@ -1,0 +1,47 @@
+"""The C-ABI library builds, loads and exports every symbol include/tacorl_hip.h declares
+(no compute calls: there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "tacorl_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tacorl_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tacorl_amd import _lib, build
+
+    build.build(verbose=False)
+    L = _lib.lib()
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+    # the ctypes table binds exactly the header's symbols
+    assert sorted(_lib.declared_symbols()) == syms
+
+
+def test_layout_queries_run_without_gpu():
+    from tacorl_amd import ops
+
+    offs, total = ops.encoder_param_layout()
+    assert total == 117188 and offs[7] % 4 == 0  # 117185 reference params + 3 pad floats
+    _, act = ops.encoder_act_layout(2, 84, 84)
+    assert act == 2 * (400 * 32 + 81 * 64 + 49 * 64 + 128 + 256)
+    w, b, tot = ops.mlp_param_layout([71, 256, 1])
+    assert w[0] == 0 and b[0] == 71 * 256 and tot >= 71 * 256 + 256 + 256 + 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from tacorl_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libtacorl_hip.so")
+    with pytest.raises(_lib.TacorlHipError):
+        _lib.lib()

@@ -1,0 +1,297 @@
+"""Kernel-level parity: every C-ABI op against the CPU oracle / plain torch fp32 on the
+same seeded inputs.  f32 MFMA mode must meet the north-star tolerance (1e-4 rel); the bf16
+MFMA mode is checked at bf16 operand precision (tolerance stated per test)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_F32 = 1e-4
+TOL_BF16 = 3e-2  # bf16 operands (8-bit mantissa), fp32 accumulate
+
+
+def _dev():
+    from tacorl_amd import _lib
+
+    _lib.call("tacorl_hip_init", 0)
+    return torch.device("cuda:0")
+
+
+def relerr(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.mark.parametrize("compute,tol", [(0, TOL_F32), (1, TOL_BF16)])
+@pytest.mark.parametrize("M,K,N,act", [(37, 64, 256, 2), (300, 71, 256, 2), (5, 256, 1, 0), (130, 128, 32, 1),
+                                        (64, 48, 2048, 1)])
+def test_linear_fwd(compute, tol, M, K, N, act):
+    from tacorl_amd import ops
+
+    dev = _dev()
+    ld = (K + 3) // 4 * 4
+    x = torch.zeros(M, ld)
+    x[:, :K] = rnd(M, K, seed=1)
+    w, b = rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3, scale=0.1)
+    z = F.linear(x[:, :K], w, b)
+    ref = [z, F.relu(z), F.silu(z)][act]
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)  # keep alive: the ABI takes raw pointers
+    y = torch.empty(M, N, device=dev)
+    zz = torch.empty(M, N, device=dev)
+    ops.call("tacorl_linear_fwd", 1, ops.ptr_array([xd]), ld, ops.ptr_array([wd]), ops.ptr_array([bd]),
+             ops.ptr_array([y]), ops.ptr_array([zz]), ops.int_array([M]), K, N, act, compute, ops.stream())
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < tol
+    assert relerr(zz, z) < tol
+
+
+@pytest.mark.parametrize("compute,tol", [(0, TOL_F32), (1, TOL_BF16)])
+@pytest.mark.parametrize("geom", [(84, 84, 3, 8, 4, 32), (20, 20, 32, 4, 2, 64), (9, 9, 64, 3, 1, 64),
+                                  (150, 200, 3, 8, 4, 32)])
+def test_conv_fwd(compute, tol, geom):
+    from tacorl_amd import ops
+
+    dev = _dev()
+    H, W, Ci, Kk, S, CO = geom
+    n = [3, 2]
+    xs = [rnd(k, Ci, H, W, seed=10 + i) for i, k in enumerate(n)]
+    w, b = rnd(CO, Ci, Kk, Kk, seed=4, scale=1 / math.sqrt(Ci * Kk * Kk)), rnd(CO, seed=5, scale=0.1)
+    refs = [F.relu(F.conv2d(x, w, b, stride=S)).permute(0, 2, 3, 1) for x in xs]
+    xd = [x.permute(0, 2, 3, 1).contiguous().to(dev) for x in xs]
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    ys = ops.conv2d_relu_fwd(xd, [wd, wd], [b.to(dev)] * 2, S, compute)
+    torch.cuda.synchronize()
+    for y, r in zip(ys, refs):
+        assert relerr(y, r) < tol
+    if Ci == 3:  # bf16 image storage (the bench's input format)
+        xb = [x.to(torch.bfloat16) for x in xd]
+        refs_b = [F.relu(F.conv2d(x.to(torch.bfloat16).float(), w, b, stride=S)).permute(0, 2, 3, 1) for x in xs]
+        ys = ops.conv2d_relu_fwd(xb, [wd, wd], [b.to(dev)] * 2, S, compute)
+        torch.cuda.synchronize()
+        for y, r in zip(ys, refs_b):
+            assert relerr(y, r) < tol
+
+
+def _enc_params(seed):
+    from tacorl_amd import synth
+
+    names = ["model.0.weight", "model.0.bias", "model.2.weight", "model.2.bias", "model.4.weight", "model.4.bias",
+             "model.6.temperature", "fc_layers.0.weight", "fc_layers.0.bias", "fc_layers.3.weight", "fc_layers.3.bias"]
+    shapes = [(32, 3, 8, 8), (32,), (64, 32, 4, 4), (64,), (64, 64, 3, 3), (64,), (1,), (256, 128), (256,), (32, 256),
+              (32,)]
+    return {n: synth.param_values(n, s, seed) for n, s in zip(names, shapes)}
+
+
+@pytest.mark.parametrize("compute,tol", [(0, TOL_F32), (1, TOL_BF16)])
+@pytest.mark.parametrize("H,W", [(84, 84), (128, 128), (150, 200)])
+def test_encoder_fwd_bwd(compute, tol, H, W):
+    from oracle import tacorl_oracle as O
+    from tacorl_amd import blocks, ops
+
+    dev = _dev()
+    n = [5, 3]
+    flats, grads, imgs_d, outs, acts, douts, refs = [], [], [], [], [], [], []
+    for i, k in enumerate(n):
+        P = {kk: v.clone().requires_grad_(True) for kk, v in _enc_params(20 + i).items()}
+        img = rnd(k, 3, H, W, seed=30 + i)
+        out = O.encoder_fwd(P, "", img)
+        dout = rnd(k, 32, seed=40 + i)
+        (out * dout).sum().backward()
+        flat = torch.zeros(blocks.encoder_size(), device=dev)
+        blocks.load_named(blocks.encoder_views(flat), {kk: v.detach() for kk, v in P.items()})
+        flats.append(flat)
+        grads.append(torch.full_like(flat, float("nan")))
+        imgs_d.append(img.permute(0, 2, 3, 1).contiguous().to(dev))
+        outs.append(torch.empty(k, 32, device=dev))
+        acts.append(torch.empty(ops.encoder_act_layout(k, H, W)[1], device=dev))
+        douts.append(dout.to(dev))
+        refs.append((out.detach(), {kk: v.grad for kk, v in P.items()}))
+    ops.encoder_fwd(imgs_d, flats, outs, acts, H, W, compute)
+    ops.encoder_bwd(imgs_d, flats, acts, douts, grads, H, W, compute)
+    torch.cuda.synchronize()
+    for i in range(len(n)):
+        assert relerr(outs[i], refs[i][0]) < tol, "forward"
+        gv = blocks.encoder_views(grads[i])
+        for name, g in refs[i][1].items():
+            e = relerr(gv[name], g)
+            assert e < tol * (3 if compute else 1), (name, e)
+
+
+@pytest.mark.parametrize("compute,tol", [(0, TOL_F32), (1, TOL_BF16)])
+@pytest.mark.parametrize("dims,acts", [([64, 256, 256, 256, 32], [2, 2, 2, 0]), ([80, 256, 256, 256, 1], [2, 2, 2, 0]),
+                                       ([71, 256, 256, 256, 1], [2, 2, 2, 0]), ([32, 256, 256, 32], [1, 1, 0])])
+def test_mlp_fwd_bwd(compute, tol, dims, acts):
+    from tacorl_amd import blocks, ops
+
+    dev = _dev()
+    Ms = [70, 9]
+    L = len(dims) - 1
+    ld = (dims[0] + 3) // 4 * 4
+    names = [(f"l{l}.w", f"l{l}.b") for l in range(L)]
+    xs, flats, grads, actb, douts, dxs, refs = [], [], [], [], [], [], []
+    for i, M in enumerate(Ms):
+        Ws = [rnd(dims[l + 1], dims[l], seed=50 + i + l, scale=1 / math.sqrt(dims[l])).requires_grad_(True) for l in range(L)]
+        bs = [rnd(dims[l + 1], seed=60 + i + l, scale=0.1).requires_grad_(True) for l in range(L)]
+        x = rnd(M, dims[0], seed=70 + i).requires_grad_(True)
+        h = x
+        for l in range(L):
+            h = F.linear(h, Ws[l], bs[l])
+            h = [h, F.relu(h), F.silu(h)][acts[l]]
+        dout = rnd(M, dims[-1], seed=80 + i)
+        (h * dout).sum().backward()
+        flat = torch.zeros(blocks.mlp_size(dims), device=dev)
+        v = blocks.mlp_views(flat, 0, dims, names)
+        for l in range(L):
+            v[f"l{l}.w"].copy_(Ws[l].detach())
+            v[f"l{l}.b"].copy_(bs[l].detach())
+        xp = torch.zeros(M, ld, device=dev)
+        xp[:, :dims[0]] = x.detach()
+        xs.append(xp); flats.append(flat); grads.append(torch.full_like(flat, float("nan")))
+        actb.append(torch.empty(ops.mlp_act_layout(M, dims, acts)[2], device=dev))
+        douts.append(dout.to(dev)); dxs.append(torch.zeros(M, ld, device=dev))
+        refs.append((h.detach(), x.grad, [w.grad for w in Ws], [b.grad for b in bs]))
+    ops.mlp_fwd(xs, ld, flats, actb, Ms, dims, acts, compute)
+    ops.mlp_bwd(xs, ld, flats, actb, douts, dims[-1], grads, dxs, ld, Ms, dims, acts, compute)
+    torch.cuda.synchronize()
+    for i, M in enumerate(Ms):
+        yo = ops.mlp_act_layout(M, dims, acts)[1][-1]
+        y = actb[i][yo: yo + M * dims[-1]].view(M, dims[-1])
+        assert relerr(y, refs[i][0]) < tol, "forward"
+        assert relerr(dxs[i][:, :dims[0]], refs[i][1]) < tol * 2, "dx"
+        gv = blocks.mlp_views(grads[i], 0, dims, names)
+        for l in range(L):
+            assert relerr(gv[f"l{l}.w"], refs[i][2][l]) < tol * 2, ("dW", l)
+            assert relerr(gv[f"l{l}.b"], refs[i][3][l]) < tol * 2, ("db", l)
+
+
+def test_mfma_layout_identity():
+    """A = I with an asymmetric B catches a transposed C write (cdna_hip_programming.md section 3)."""
+    from tacorl_amd import ops
+
+    dev = _dev()
+    for compute in (0, 1):
+        K = N = 64
+        x = torch.eye(K, device=dev)
+        w = (torch.arange(N * K, dtype=torch.float32).view(N, K) % 17 - 8).to(dev)  # exact in bf16
+        y = ops.linear_fwd([x], [w], [torch.zeros(N, device=dev)], 0, compute)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(y, w.t().contiguous())
+
+
+@pytest.mark.parametrize("dg", [False, True])
+def test_tanh_normal_sample(dg):
+    from oracle import tacorl_oracle as O
+    from tacorl_amd import ops
+
+    dev = _dev()
+    n, M, Ac = 4, 33, 6 if dg else 16
+    HD = 2 * Ac + (2 if dg else 0)
+    head = rnd(M, HD, seed=1, scale=3.0)
+    head[0, 0], head[1, Ac] = 20.0, -9.0  # exercise the clamps
+    eps = torch.randn(n, M, Ac, generator=torch.Generator().manual_seed(2))
+    u = torch.rand(n, M, 2, generator=torch.Generator().manual_seed(3))
+    mu = head[:, :Ac].clamp(-9, 9)
+    sd = head[:, Ac:2 * Ac].clamp(-5, 2).exp()
+    z = mu + eps * sd
+    a_ref, lp_ref = torch.tanh(z), O.tanh_logprob(z, mu, sd).squeeze(-1)
+    if dg:
+        lg = head[:, 2 * Ac:]
+        idx = O.gumbel_argmax((lg - lg.logsumexp(-1, keepdim=True)).unsqueeze(0).expand(n, -1, -1), u)
+        lp_ref = lp_ref + O.gripper_logprob(lg.unsqueeze(0).expand(n, -1, -1), idx).squeeze(-1)
+        a_ref = torch.cat([a_ref, idx.unsqueeze(-1).float() * 2 - 1], -1)
+    A = Ac + (1 if dg else 0)
+    ld = 24
+    act = torch.zeros(n * M, ld, device=dev)
+    logp = torch.empty(n * M, device=dev)
+    hd_, ed_, ud_ = head.to(dev), eps.to(dev), u.to(dev)
+    ops.tanh_normal_sample(hd_, HD, ed_, ud_ if dg else None, False, act, 4, ld, logp, None, n, M, Ac)
+    torch.cuda.synchronize()
+    assert relerr(act[:, 4:4 + A].view(n, M, A), a_ref) < 1e-5
+    assert relerr(logp.view(n, M), lp_ref) < 1e-5
+
+
+def test_adam_clip_polyak():
+    from oracle import tacorl_oracle as O
+    from tacorl_amd import ops
+
+    dev = _dev()
+    N = 100003
+    P = {"w": rnd(N, seed=1)}
+    tgt = rnd(N, seed=5)
+    opt = O.Adam(["w"], 3e-4)
+    p_d, m_d, v_d = P["w"].clone().to(dev), torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    t_d, step = tgt.clone().to(dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    for it in range(3):
+        g = rnd(N, seed=10 + it, scale=0.01 * (it + 1))
+        gd = {"w": g.clone()}
+        O.clip_grads_(gd, ["w"], 1.0)
+        opt.step(P, gd)
+        tgt = tgt * (1 - 0.005) + P["w"] * 0.005
+        g_d = g.to(dev)
+        ops.adam_step(p_d, g_d, m_d, v_d, 3e-4, 1.0, step, t_d, 0.005)
+    torch.cuda.synchronize()
+    assert int(step.item()) == 3
+    assert (p_d.cpu() - P["w"]).abs().max().item() < 2e-7
+    assert (t_d.cpu() - tgt).abs().max().item() < 2e-7
+
+
+@pytest.mark.parametrize("det_backup,lagrange", [(True, True), (False, True), (False, False)])
+def test_cql_loss(det_backup, lagrange):
+    from tacorl_amd import _lib, ops
+
+    dev = _dev()
+    B, n, A = 37, 4, 16
+    R = (3 * n + 1) * B
+    g = torch.Generator().manual_seed(7)
+    q = [torch.randn(R, generator=g).requires_grad_(True) for _ in range(2)]
+    tq = [torch.randn(B, generator=g) for _ in range(2)]
+    lpc, lpn, nlp = torch.randn(n * B, generator=g) * 3, torch.randn(n * B, generator=g) * 3, torch.randn(B, generator=g)
+    rew = (torch.rand(B, generator=g) < 0.3).float()
+    la, lap = torch.tensor([0.2]), torch.tensor([-0.3], requires_grad=True)
+    disc, rs, temp, w, gap = 0.95, 10.0, 1.0, 1.0, 5.0
+    alpha = la[0].exp()
+    qn = torch.min(tq[0], tq[1]) - (0 if det_backup else alpha * nlp)
+    y = rs * rew + (1 - rew) * disc * qn
+    losses, logs_ref = [], {}
+    for i in range(2):
+        qd = q[i][:B]
+        qr, qc, qx = [q[i][B + gI * n * B: B + (gI + 1) * n * B].view(n, B).t() for gI in range(3)]
+        cat = torch.cat([qr - math.log(0.5 ** A), qc - lpc.view(n, B).t(), qx - lpn.view(n, B).t()], 1)
+        cons = torch.logsumexp(cat / temp, 1).mean() * w * temp - qd.mean() * w
+        if lagrange:
+            cons = lap[0].exp().clamp(0, 1e6) * (cons - gap)
+        bell = F.mse_loss(qd, y)
+        losses.append(bell + cons)
+        logs_ref[f"bellman_q{i + 1}_loss"], logs_ref[f"conservative_q{i + 1}_loss"] = bell.item(), cons.item()
+        logs_ref[f"q{i + 1}_random"], logs_ref[f"q{i + 1}_policy"] = qr.mean().item(), qc.mean().item()
+    g1, = torch.autograd.grad(losses[0], q[0], retain_graph=True)
+    g2, = torch.autograd.grad(losses[1], q[1], retain_graph=True)
+    if lagrange:
+        ap_loss = (-(losses[0] - F.mse_loss(q[0][:B], y)) - (losses[1] - F.mse_loss(q[1][:B], y))) * 0.5
+        glap, = torch.autograd.grad(ap_loss, lap)
+    dq = [torch.empty(R, device=dev) for _ in range(2)]
+    logs = torch.zeros(32, device=dev)
+    g_lap = torch.zeros(1, device=dev)
+    ws = torch.empty(_lib.lib().tacorl_cql_ws_bytes(B), dtype=torch.uint8, device=dev)
+    # keep every device tensor alive: the ABI takes raw pointers
+    T = [t.detach().to(dev) for t in (q[0], q[1], tq[0], tq[1], lpc, lpn, nlp, rew, la, lap)]
+    ops.call("tacorl_cql_loss", ops.ptr(T[0]), ops.ptr(T[1]), ops.ptr(dq[0]), ops.ptr(dq[1]), ops.ptr(T[2]),
+             ops.ptr(T[3]), ops.ptr(T[4]), ops.ptr(T[5]), ops.ptr(T[6]), ops.ptr(T[7]), ops.ptr(T[7]),
+             ops.ptr(T[8]), ops.ptr(T[9]) if lagrange else None, B, n, A, disc, rs, temp, w, gap, int(det_backup),
+             1.0, ops.ptr(g_lap), ops.ptr(logs), ops.ptr(ws), ws.numel(), ops.stream())
+    torch.cuda.synchronize()
+    assert relerr(dq[0], g1) < 1e-5 and relerr(dq[1], g2) < 1e-5
+    lg = dict(zip(_lib.LOG_SLOTS, logs.cpu().tolist()))
+    for k, v in logs_ref.items():
+        assert abs(lg[k] - v) < 1e-4 * max(1.0, abs(v)), (k, lg[k], v)
+    if lagrange:
+        assert abs(g_lap.item() - glap.item()) < 1e-4 * abs(glap.item())

@@ -1,0 +1,84 @@
+"""Whole-step parity on the GPU: the HIP modules against (a) the goldens produced by the
+unmodified reference and (b) the CPU oracle run on the same inputs with full tensors.
+Tolerance: 1e-4 relative on every logged loss and on the sampled latent plans (north star),
+f32 MFMA mode.  The bf16 MFMA mode is checked separately at a stated, looser tolerance."""
+import pytest
+import torch
+
+from tests.golden_util import Golden, check_stats, spec_for
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+GRAD_RTOL = 3e-4  # gradients: sums of ~1e5 fp32 products re-associated by the split-R wgrad
+PARAM_ATOL = 1.5e-5  # Adam g/(|g|+eps) amplification on near-zero grads (a few % of one lr update)
+
+ACTOR = {"policy": {"num_layers": 3, "hidden_dim": 256}}
+CRITIC = {"q_network": {"num_layers": 3, "hidden_dim": 256, "last_layer_activation": "Identity"}}
+CQL_YAML = dict(discount=0.99, actor_lr=1e-4, critic_lr=3e-4, conservative_weight=1.0, n_action_samples=4,
+                with_lagrange=True, reward_scale=10.0, deterministic_backup=False, bc_epochs=5)
+TACORL_YAML = dict(action_decoder_lr=3e-4, actor_lr=1e-4, critic_lr=3e-4, discount=0.95, conservative_weight=1.0,
+                   reward_scale=10.0, n_action_samples=4, with_lagrange=True, deterministic_backup=True, bc_epochs=5)
+
+
+def to_dev(x, dev):
+    if isinstance(x, dict):
+        return {k: to_dev(v, dev) for k, v in x.items()}
+    return x.to(dev) if torch.is_tensor(x) else x
+
+
+def check_logs(got, exp, rtol=RTOL):
+    bad = []
+    for k, v in exp.items():
+        if k not in got:
+            bad.append(f"{k}: missing")
+        elif abs(got[k] - v) > rtol * max(abs(v), 1e-2):
+            bad.append(f"{k}: {got[k]:.8g} vs {v:.8g}")
+    return bad
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def compare_with_oracle_grads(mod, oracle_grads, rtol):
+    bad = []
+    got = mod.named_gradients()
+    for k, v in oracle_grads.items():
+        if k in got:
+            e = relerr(got[k].reshape(v.shape), v)
+            if e > rtol and v.norm() > 1e-12:
+                bad.append(f"grad {k}: relerr {e:.3g}")
+    return bad
+
+
+@pytest.mark.parametrize("name", ["cql_q", "cql_bc"])
+def test_cql_offline_step(name):
+    from oracle import tacorl_oracle as O
+    from tacorl_amd.modules.cql.cql_offline_lightning import CQL_Offline
+
+    g = Golden(name)
+    cams = sorted(g.cams)
+    kw = dict(CQL_YAML)
+    kw.update(g.cfg.get("overrides", {}))
+    mod = CQL_Offline(actor=dict(ACTOR, discrete_gripper=True), critic=CRITIC, real_world=True, obs_modalities=cams,
+                      goal_modalities=cams, action_dim=7, device="cuda:0", compute_dtype="f32", **kw)
+    assert sorted(mod.state_dict()) == sorted(g.names)
+    mod.load_state_dict(g.params())
+    mod.current_epoch = g.cfg["epoch"]
+    spec = spec_for(g)
+    P = O.require_grad_(g.params())
+    opts = O.make_opts(P, spec)
+    for step in range(g.cfg["steps"]):
+        batch, noise = g.batch(step), g.noise(step)
+        mod.logged = {}
+        mod.training_step(to_dev(batch, mod.device), 0, noise=to_dev(noise, mod.device))
+        torch.cuda.synchronize()
+        got = {k.split("/", 1)[1]: v for k, v in mod.logged.items()}
+        _, ograds = O.cql_step(P, opts, spec, batch, noise, g.cfg["epoch"])
+        bad = check_logs(got, g.logged(step))
+        bad += compare_with_oracle_grads(mod, ograds, GRAD_RTOL)
+        bad += check_stats(mod.named_gradients(), g.stats(step, "grad"), rtol=GRAD_RTOL, what="golden grad ")
+        bad += check_stats(mod.state_dict(), g.stats(step, "param"), rtol=RTOL, atol=PARAM_ATOL, what="golden param ")
+        assert not bad, f"step {step}:\n" + "\n".join(bad[:25])
