@@ -37,6 +37,12 @@ const char* tacorl_hip_last_error(void);
 int tacorl_linear_fwd(int nprob, const float* const* x, int ldx, const float* const* w,
                       const float* const* b, float* const* y, float* const* z, const int* M,
                       int K, int N, int act, int compute_dtype, tacorl_stream_t stream);
+/* y = act(x W^T + b + addend), y with leading dim ldy: one ReLU-RNN time step
+ * (torch nn.RNN relu; reference networks/action_decoders/rnn_models.py:5-16). */
+int tacorl_linear_add_fwd(int nprob, const float* const* x, int ldx, const float* const* w,
+                          const float* const* b, const float* const* addend, int ld_add, float* const* y,
+                          int ldy, const int* M, int K, int N, int act, int compute_dtype,
+                          tacorl_stream_t stream);
 /* y = relu(conv2d(x, w) + b), no padding.  Replaces nn.Conv2d + nn.ReLU,
  * reference networks/visual_encoders/encoder.py:369-390. x_dtype: image storage dtype. */
 int tacorl_conv2d_relu_fwd(int nprob, const void* const* x, const float* const* w,
@@ -107,6 +113,33 @@ int tacorl_uniform_actions(const float* u01, float* dst, int ld_dst, int rows, i
 int tacorl_tanh_normal_sample(const float* head, int ld_head, const float* eps, const float* gumbel_u,
                               int hard_rsample, float* act_out, int ld_act, float* logp, int* grip_idx,
                               int n, int M, int Ac, tacorl_stream_t stream);
+
+/* ---- plan-recognition transformer glue (reference plan_recognition_transformer.py:70-105) ---- */
+/* out[r] = [x[r] (D, zero-padded to Dp)] + add[r % T]  (position embeddings). */
+int tacorl_add_rows_bcast(const float* x, int ldx, const float* add, float* out, int R, int T, int D,
+                          int Dp, tacorl_stream_t stream);
+/* softmax(q k^T / sqrt(hd)) v per (batch, head); qkv [B*T][3D], out [B*T][D]; T <= 64, hd <= 16. */
+int tacorl_attention_fwd(const float* qkv, float* out, int B, int T, int D, int H, tacorl_stream_t stream);
+/* y = LayerNorm(x + res); stats[r] = {mean, rstd} (may be NULL). D <= 256. */
+int tacorl_add_layernorm_fwd(const float* x, const float* res, const float* w, const float* b, float* y,
+                             float* stats, int R, int D, float eps, tacorl_stream_t stream);
+int tacorl_mean_over_t(const float* x, float* out, int B, int T, int D, tacorl_stream_t stream);
+/* head [B][2A] = [mean | var_raw]; std = softplus(var_raw)+min_std; plan = tanh(mean + eps*std). */
+int tacorl_pr_sample(const float* head, const float* eps, float* plan, float* mu_out, float* std_out,
+                     int B, int A, float min_std, tacorl_stream_t stream);
+
+/* ---- action decoder (reference networks/action_decoders/action_decoder_logistic.py) ---------- */
+/* Time-major RNN input x[(t*B+b)] = [plan[b] | emb[b*T+t]], t < Tm (:279-281). */
+int tacorl_build_ad_input(const float* plan, const float* emb, int ld_emb, float* out, int B, int T,
+                          int Tm, int P, int E, tacorl_stream_t stream);
+size_t tacorl_logistic_mixture_ws_bytes(int B, int Tm, int Da);
+/* Discretised-logistic-mixture NLL + gripper CE (:110-235), forward + backward fused.
+ * heads[(t*B+b)] = [means Da*K | log_scales Da*K | logit_probs Da*K | gripper 2]; actions batch-major
+ * [B][T][Da+1]; d_heads may be NULL (loss only); loss_out: one device float. */
+int tacorl_logistic_mixture_loss(const float* heads, int ldh, const float* actions, float* d_heads,
+                                 float* loss_out, int B, int T, int Tm, int Da, int K, int num_classes,
+                                 float gripper_alpha, float grad_scale, void* ws, size_t ws_bytes,
+                                 tacorl_stream_t stream);
 
 /* device-resident metric record written by the loss kernels (names = reference self.log keys) */
 enum {

@@ -25,6 +25,15 @@ _SIGS = {
     "tacorl_hip_init": (_i, [_i]),
     "tacorl_hip_last_error": (C.c_char_p, []),
     "tacorl_linear_fwd": (_i, [_i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "tacorl_linear_add_fwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
+    "tacorl_add_rows_bcast": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "tacorl_attention_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "tacorl_add_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "tacorl_mean_over_t": (_i, [_p, _p, _i, _i, _i, _p]),
+    "tacorl_pr_sample": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "tacorl_build_ad_input": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "tacorl_logistic_mixture_ws_bytes": (_sz, [_i, _i, _i]),
+    "tacorl_logistic_mixture_loss": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p]),
     "tacorl_conv2d_relu_fwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "tacorl_encoder_param_layout": (_l, [_p]),
     "tacorl_encoder_act_layout": (_l, [_i, _i, _i, _p]),

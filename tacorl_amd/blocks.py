@@ -67,3 +67,33 @@ def head_views(flat, base, dims, hidden, parts):
 def load_named(views, P, prefix=""):
     for n, t in views.items():
         t.copy_(P[prefix + n].to(t.device))
+
+
+class TensorBlock:
+    """Generic flat block: a list of (reference name, shape) tensors, each 4-float aligned."""
+
+    def __init__(self, spec, device, trainable=True):
+        self.spec = list(spec)
+        self.off = {}
+        off = 0
+        for name, shape in self.spec:
+            n = 1
+            for s in shape:
+                n *= s
+            self.off[name] = (off, tuple(shape), n)
+            off = (off + n + 3) // 4 * 4
+        self.size = off
+        self.param = torch.zeros(off, device=device)
+        self.views = {k: self.param[o: o + n].view(*shp) for k, (o, shp, n) in self.off.items()}
+        self.trainable = trainable
+        if trainable:
+            self.grad, self.m, self.v = (torch.zeros(off, device=device) for _ in range(3))
+            self.step = torch.zeros(1, dtype=torch.int32, device=device)
+            self.grad_views = {k: self.grad[o: o + n].view(*shp) for k, (o, shp, n) in self.off.items()}
+
+    def p(self, name, flat=None):
+        """Raw device address of tensor `name` inside `flat` (default: the parameter block)."""
+        return (self.param if flat is None else flat).data_ptr() + 4 * self.off[name][0]
+
+    def g(self, name):
+        return self.p(name, self.grad)

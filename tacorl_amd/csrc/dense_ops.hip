@@ -35,7 +35,8 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // ============================================================== linear forward
 static int k_linear_fwd(int nprob, const float* const* x, int ldx, const float* const* w,
                         const float* const* b, float* const* y, float* const* z, const int* M, int K,
-                        int N, int ldy, int act, int cd, hipStream_t st) {
+                        int N, int ldy, int act, int cd, hipStream_t st, const float* const* addend = nullptr,
+                        int ld_add = 0) {
   if (nprob < 1 || nprob > GEMM_MAXP) FAIL(TACORL_EINVAL, "linear_fwd: nprob %d", nprob);
   RowMajorLoader la{}, lb{};
   BiasActStore ep{};
@@ -43,11 +44,12 @@ static int k_linear_fwd(int nprob, const float* const* x, int ldx, const float* 
   g.nprob = nprob; g.nsplit = 1; g.N = N;
   la.cols = K; la.ld = ldx; la.vec = (ldx % 4 == 0); la.ones_col = 0;
   lb.cols = K; lb.ld = K; lb.vec = (K % 4 == 0); lb.ones_col = 0;
-  ep.ld = ldy; ep.act = act;
+  ep.ld = ldy; ep.act = act; ep.ld_add = ld_add;
   for (int p = 0; p < nprob; p++) {
     la.ptr[p] = x[p]; la.rows[p] = M[p]; la.vec &= aligned16(x[p]);
     lb.ptr[p] = w[p]; lb.rows[p] = N; lb.vec &= aligned16(w[p]);
     ep.bias[p] = b ? b[p] : nullptr; ep.y[p] = y[p]; ep.z[p] = z ? z[p] : nullptr;
+    ep.addend[p] = addend ? addend[p] : nullptr;
     g.M[p] = M[p]; g.R[p] = K;
   }
   return gemm_launch<RowMajorLoader, RowMajorLoader, false, false, BiasActStore>(la, lb, ep, g, cd, st);
@@ -57,6 +59,15 @@ extern "C" int tacorl_linear_fwd(int nprob, const float* const* x, int ldx, cons
                                  const float* const* b, float* const* y, float* const* z, const int* M,
                                  int K, int N, int act, int compute_dtype, tacorl_stream_t stream) {
   return k_linear_fwd(nprob, x, ldx, w, b, y, z, M, K, N, N, act, compute_dtype, (hipStream_t)stream);
+}
+// y = act(x W^T + b + addend): one ReLU-RNN time step h_t = relu(W_hh h_{t-1} + b_hh + (W_ih x_t + b_ih))
+// (torch nn.RNN(nonlinearity="relu"), reference networks/action_decoders/rnn_models.py:5-16)
+extern "C" int tacorl_linear_add_fwd(int nprob, const float* const* x, int ldx, const float* const* w,
+                                     const float* const* b, const float* const* addend, int ld_add,
+                                     float* const* y, int ldy, const int* M, int K, int N, int act,
+                                     int compute_dtype, tacorl_stream_t stream) {
+  return k_linear_fwd(nprob, x, ldx, w, b, y, nullptr, M, K, N, ldy, act, compute_dtype, (hipStream_t)stream, addend,
+                      ld_add);
 }
 
 // ================================================================ conv forward

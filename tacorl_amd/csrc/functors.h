@@ -88,11 +88,13 @@ struct ConvDgradWLoader {
 // y = act(acc + bias[n]); optional pre-activation copy z.
 struct BiasActStore {
   const float* bias[GEMM_MAXP];
+  const float* addend[GEMM_MAXP];  // optional [M][N] matrix added before the activation (RNN input term)
   float* y[GEMM_MAXP];
   float* z[GEMM_MAXP];
-  int ld, act;
+  int ld, act, ld_add;
   __device__ __forceinline__ void store(int p, int, int m, int n, float acc) const {
     float zz = acc + (bias[p] ? bias[p][n] : 0.f);
+    if (addend[p]) zz += addend[p][(long)m * ld_add + n];
     long o = (long)m * ld + n;
     if (z[p]) z[p][o] = zz;
     y[p][o] = act_apply(act, zz);

@@ -1,0 +1,288 @@
+// Sequence-side kernels of the plan-recognition transformer (reference
+// networks/plan_encoders/plan_recognition_transformer.py:70-105 + torch's post-norm
+// nn.TransformerEncoderLayer) and of the plan sampling.  The GEMMs go through
+// tacorl_linear_fwd; these are the small latency-bound pieces between them.
+#include <stdio.h>
+
+#include "../../include/tacorl_hip.h"
+#include "common.h"
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH)
+
+// out[r][0:D] = x[r][0:D] + add[r % T][0:D];  out[r][D:Dp] = add[r % T][D:Dp]  (zero-padded x)
+__global__ void add_rows_bcast_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ add,
+                                      float* __restrict__ out, int R, int T, int D, int Dp) {
+  const long total = (long)R * Dp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / Dp), d = (int)(i - (long)r * Dp);
+    out[i] = (d < D ? x[(long)r * ldx + d] : 0.f) + add[(long)(r % T) * Dp + d];
+  }
+}
+extern "C" int tacorl_add_rows_bcast(const float* x, int ldx, const float* add, float* out, int R, int T, int D, int Dp,
+                                     tacorl_stream_t stream) {
+  if (R <= 0) return TACORL_OK;
+  const long total = (long)R * Dp;
+  hipLaunchKernelGGL(add_rows_bcast_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     add, out, R, T, D, Dp);
+  return LAUNCH_OK();
+}
+
+// Multi-head self-attention core for short sequences (T <= 64, head_dim <= 16).
+// qkv: [B*T][3D] (q | k | v, heads contiguous inside each), out: [B*T][D].
+// One thread per (b, head, query): scores = (q/sqrt(hd)) . k, softmax over keys, weighted sum of v.
+#define ATT_MAX_T 64
+#define ATT_MAX_HD 16
+__global__ void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int T, int D, int H) {
+  const int hd = D / H;
+  const long total = (long)B * H * T;
+  const float scale = 1.0f / sqrtf((float)hd);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T), h = (int)((i / T) % H), b = (int)(i / ((long)T * H));
+    const float* base = qkv + (long)b * T * 3 * D;
+    float q[ATT_MAX_HD], o[ATT_MAX_HD], s[ATT_MAX_T];
+    for (int e = 0; e < hd; e++) { q[e] = base[(long)t * 3 * D + h * hd + e] * scale; o[e] = 0.f; }
+    float mx = -INFINITY;
+    for (int j = 0; j < T; j++) {
+      float a = 0.f;
+      for (int e = 0; e < hd; e++) a += q[e] * base[(long)j * 3 * D + D + h * hd + e];
+      s[j] = a; mx = fmaxf(mx, a);
+    }
+    float se = 0.f;
+    for (int j = 0; j < T; j++) { s[j] = expf(s[j] - mx); se += s[j]; }
+    for (int j = 0; j < T; j++) {
+      const float p = s[j] / se;
+      for (int e = 0; e < hd; e++) o[e] += p * base[(long)j * 3 * D + 2 * D + h * hd + e];
+    }
+    for (int e = 0; e < hd; e++) out[((long)b * T + t) * D + h * hd + e] = o[e];
+  }
+}
+extern "C" int tacorl_attention_fwd(const float* qkv, float* out, int B, int T, int D, int H, tacorl_stream_t stream) {
+  if (T > ATT_MAX_T || D % H || D / H > ATT_MAX_HD) return TACORL_EINVAL;
+  const long total = (long)B * H * T;
+  if (total <= 0) return TACORL_OK;
+  hipLaunchKernelGGL(attention_fwd_kernel, dim3((int)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream, qkv, out,
+                     B, T, D, H);
+  return LAUNCH_OK();
+}
+
+// y = LayerNorm(x + res) * w + b  (eps inside sqrt, biased variance: torch F.layer_norm);
+// stats[r] = {mean, rstd} kept for the backward.  One wave per row, D <= 256.
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                float* __restrict__ y, float* __restrict__ stats, int R,
+                                                                int D, float eps) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int d = lane + 64 * i;
+    v[i] = d < D ? x[(long)r * D + d] + (res ? res[(long)r * D + d] : 0.f) : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int d = lane + 64 * i;
+    const float c = d < D ? v[i] - mean : 0.f;
+    q += c * c;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int d = lane + 64 * i;
+    if (d < D) y[(long)r * D + d] = (v[i] - mean) * rstd * w[d] + b[d];
+  }
+  if (stats && lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+}
+extern "C" int tacorl_add_layernorm_fwd(const float* x, const float* res, const float* w, const float* b, float* y,
+                                        float* stats, int R, int D, float eps, tacorl_stream_t stream) {
+  if (D > 256) return TACORL_EINVAL;
+  if (R <= 0) return TACORL_OK;
+  hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, res, w, b, y,
+                     stats, R, D, eps);
+  return LAUNCH_OK();
+}
+
+// out[b][d] = mean_t x[b*T + t][d]
+__global__ void mean_over_t_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int T, int D) {
+  const long total = (long)B * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / D), d = (int)(i - (long)b * D);
+    float s = 0.f;
+    for (int t = 0; t < T; t++) s += x[((long)b * T + t) * D + d];
+    out[i] = s / (float)T;
+  }
+}
+extern "C" int tacorl_mean_over_t(const float* x, float* out, int B, int T, int D, tacorl_stream_t stream) {
+  const long total = (long)B * D;
+  if (total <= 0) return TACORL_OK;
+  hipLaunchKernelGGL(mean_over_t_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, B,
+                     T, D);
+  return LAUNCH_OK();
+}
+
+// Posterior head: head[b] = [mean (A) | var_raw (A)]; std = softplus(var_raw) + min_std;
+// plan = tanh(mean + eps*std)  (plan_recognition_transformer.py:100-104, distributions.py:137-140).
+__global__ void pr_sample_kernel(const float* __restrict__ head, const float* __restrict__ eps, float* __restrict__ plan,
+                                 float* __restrict__ mu_out, float* __restrict__ std_out, int B, int A, float min_std) {
+  const long total = (long)B * A;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / A), j = (int)(i - (long)b * A);
+    const float mu = head[(long)b * 2 * A + j], vr = head[(long)b * 2 * A + A + j];
+    const float sd = (vr > 20.f ? vr : log1pf(expf(vr))) + min_std;
+    if (plan) plan[i] = tanhf(mu + eps[i] * sd);
+    if (mu_out) mu_out[i] = mu;
+    if (std_out) std_out[i] = sd;
+  }
+}
+extern "C" int tacorl_pr_sample(const float* head, const float* eps, float* plan, float* mu_out, float* std_out, int B,
+                                int A, float min_std, tacorl_stream_t stream) {
+  const long total = (long)B * A;
+  if (total <= 0) return TACORL_OK;
+  hipLaunchKernelGGL(pr_sample_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, head, eps,
+                     plan, mu_out, std_out, B, A, min_std);
+  return LAUNCH_OK();
+}
+
+// =============================================================== action decoder glue
+// x_seq[(t*B + b)] = [plan[b] (P) | emb[(b*T + t)] (E)]  for t < Tm  (time-major RNN input;
+// reference action_decoder_logistic.py:279-281 with perceptual_emb = emb[:, :-1])
+__global__ void build_ad_input_kernel(const float* __restrict__ plan, const float* __restrict__ emb, int ld_emb,
+                                      float* __restrict__ out, int B, int T, int Tm, int P, int E) {
+  const int W = P + E;
+  const long total = (long)Tm * B * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % W);
+    const long r = i / W;
+    const int b = (int)(r % B), t = (int)(r / B);
+    out[i] = c < P ? plan[(long)b * P + c] : emb[((long)b * T + t) * ld_emb + (c - P)];
+  }
+}
+extern "C" int tacorl_build_ad_input(const float* plan, const float* emb, int ld_emb, float* out, int B, int T, int Tm,
+                                     int P, int E, tacorl_stream_t stream) {
+  const long total = (long)Tm * B * (P + E);
+  if (total <= 0) return TACORL_OK;
+  hipLaunchKernelGGL(build_ad_input_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, plan,
+                     emb, ld_emb, out, B, T, Tm, P, E);
+  return LAUNCH_OK();
+}
+
+// Discretised logistic mixture NLL + gripper cross-entropy, forward and backward fused
+// (reference action_decoder_logistic.py:110-235; bounds +-1, num_classes bins, n_mix mixtures).
+// heads[(t*B+b)] = [means (Da*K) | log_scales (Da*K) | logit_probs (Da*K) | gripper (2)], ld = ldh.
+// actions: batch-major [B][T][Da+1] (the first Tm steps are used).  One thread per (row, action dim).
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float softplus_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+#define LM_MAXK 16
+__global__ __launch_bounds__(256) void logistic_mixture_kernel(const float* __restrict__ heads, int ldh,
+                                                               const float* __restrict__ actions, float* __restrict__ d_heads,
+                                                               float* __restrict__ partial, int B, int T, int Tm, int Da,
+                                                               int K, float half_bin, float log_bins_half,
+                                                               float gripper_alpha, float grad_scale) {
+  __shared__ float sh[4];
+  const int R = Tm * B;
+  const long total = (long)R * Da;
+  float loss = 0.f;
+  const float gR = grad_scale / (float)R;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(i % Da);
+    const long r = i / Da;
+    const int b = (int)(r % B), t = (int)(r / B);
+    const float* h = heads + r * ldh;
+    const float x = actions[((long)b * T + t) * (Da + 1) + a];
+    float lp[LM_MAXK], gm[LM_MAXK], gs[LM_MAXK], pl[LM_MAXK];
+    float mxl = -INFINITY;
+    for (int k = 0; k < K; k++) { pl[k] = h[2 * Da * K + a * K + k]; mxl = fmaxf(mxl, pl[k]); }
+    float sel = 0.f;
+    for (int k = 0; k < K; k++) sel += expf(pl[k] - mxl);
+    const float lse_l = mxl + logf(sel);
+    float mx = -INFINITY;
+    for (int k = 0; k < K; k++) {
+      const float m = h[a * K + k], lsr = h[Da * K + a * K + k];
+      const float ls = fmaxf(lsr, -5.0f);
+      const float c = x - m, inv = expf(-ls);
+      const float plus_in = inv * (c + half_bin), min_in = inv * (c - half_bin), mid_in = inv * c;
+      const float cp = sigmoidf_(plus_in), cm = sigmoidf_(min_in), delta = cp - cm;
+      float v, dm, ds;
+      if (x < -1.0f + 1e-3f) {
+        v = plus_in - softplus_(plus_in);
+        const float g = 1.f - cp; dm = g * (-inv); ds = g * (-plus_in);
+      } else if (x > 1.0f - 1e-3f) {
+        v = -softplus_(min_in);
+        const float g = -cm; dm = g * (-inv); ds = g * (-min_in);
+      } else if (delta > 1e-5f) {
+        v = logf(fmaxf(delta, 1e-12f));
+        const float gp = cp * (1.f - cp) / delta, gq = -cm * (1.f - cm) / delta;
+        dm = (gp + gq) * (-inv); ds = gp * (-plus_in) + gq * (-min_in);
+      } else {
+        v = mid_in - ls - 2.f * softplus_(mid_in) - log_bins_half;
+        const float g = 1.f - 2.f * sigmoidf_(mid_in); dm = g * (-inv); ds = g * (-mid_in) - 1.f;
+      }
+      if (lsr < -5.0f) ds = 0.f;
+      lp[k] = v + (pl[k] - lse_l); gm[k] = dm; gs[k] = ds;
+      mx = fmaxf(mx, lp[k]);
+    }
+    float se = 0.f;
+    for (int k = 0; k < K; k++) se += expf(lp[k] - mx);
+    loss -= mx + logf(se);
+    if (d_heads) {
+      float* d = d_heads + r * ldh;
+      for (int k = 0; k < K; k++) {
+        const float w = expf(lp[k] - mx) / se, p = expf(pl[k] - lse_l);
+        d[a * K + k] = -gR * w * gm[k];
+        d[Da * K + a * K + k] = -gR * w * gs[k];
+        d[2 * Da * K + a * K + k] = -gR * (w - p);
+      }
+    }
+    if (a == 0) {  // gripper cross-entropy for this row (nn.CrossEntropyLoss, mean over rows)
+      const float g0 = h[3 * Da * K], g1 = h[3 * Da * K + 1], mg = fmaxf(g0, g1);
+      const float lz = mg + logf(expf(g0 - mg) + expf(g1 - mg));
+      const int y = actions[((long)b * T + t) * (Da + 1) + Da] == -1.0f ? 0 : (int)actions[((long)b * T + t) * (Da + 1) + Da];
+      loss += gripper_alpha * (lz - (y ? g1 : g0));
+      if (d_heads) {
+        float* d = d_heads + r * ldh;
+        d[3 * Da * K] = gR * gripper_alpha * (expf(g0 - lz) - (y == 0 ? 1.f : 0.f));
+        d[3 * Da * K + 1] = gR * gripper_alpha * (expf(g1 - lz) - (y == 1 ? 1.f : 0.f));
+      }
+    }
+  }
+  loss = wave_sum(loss);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = loss;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void scaled_sum_kernel(const float* __restrict__ partial, int n, float scale, float* out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1] + sh[2] + sh[3]) * scale;
+}
+extern "C" size_t tacorl_logistic_mixture_ws_bytes(int B, int Tm, int Da) {
+  long blocks = ((long)B * Tm * Da + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  return (size_t)blocks * sizeof(float);
+}
+extern "C" int tacorl_logistic_mixture_loss(const float* heads, int ldh, const float* actions, float* d_heads,
+                                            float* loss_out, int B, int T, int Tm, int Da, int K, int num_classes,
+                                            float gripper_alpha, float grad_scale, void* ws, size_t ws_bytes,
+                                            tacorl_stream_t stream) {
+  if (K > LM_MAXK) return TACORL_EINVAL;
+  if (ws_bytes < tacorl_logistic_mixture_ws_bytes(B, Tm, Da)) return TACORL_ENOMEM;
+  long blocks = ((long)B * Tm * Da + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks <= 0) return TACORL_OK;
+  hipLaunchKernelGGL(logistic_mixture_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, heads, ldh, actions,
+                     d_heads, (float*)ws, B, T, Tm, Da, K, 1.0f / (float)(num_classes - 1),
+                     logf((float)(num_classes - 1) / 2.f), gripper_alpha, grad_scale);
+  hipLaunchKernelGGL(scaled_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (int)blocks,
+                     1.0f / (float)(B * Tm), loss_out);
+  return LAUNCH_OK();
+}

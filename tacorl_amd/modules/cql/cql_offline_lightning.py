@@ -70,8 +70,6 @@ class CQL_Offline(LoggerMixin, nn.Module):
             e = to_plain(env) if env else {}
             obs_modalities = obs_modalities or list(e.get("modalities", []))
             goal_modalities = goal_modalities or list(e.get("goal_modalities", []))
-        if not obs_modalities:
-            raise ValueError("obs_modalities / goal_modalities are required (real_world=True style construction)")
         self.obs_modalities, self.goal_modalities = list(obs_modalities), list(goal_modalities)
         self.action_dim = action_dim
         # target entropy: -action_dim (real world, :93-94) or -prod(env.action_space.shape) = -7 (:96-98)
@@ -91,6 +89,8 @@ class CQL_Offline(LoggerMixin, nn.Module):
                     discrete_gripper=bool(self.actor_cfg.get("discrete_gripper", False)))
 
     def build_networks(self):
+        if not self.obs_modalities:
+            raise ValueError("obs_modalities / goal_modalities are required (real_world=True style construction)")
         a = self._arch()
         if a["hidden"] != self.critic_cfg.get("q_network", {}).get("hidden_dim", 256):
             raise NotImplementedError("actor and critic hidden sizes must match")

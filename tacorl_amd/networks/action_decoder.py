@@ -1,0 +1,124 @@
+"""ActionDecoderLogistic on HIP kernels (reference
+networks/action_decoders/action_decoder_logistic.py:21-300, rnn_models.py:5-16):
+2-layer ReLU RNN (hidden 2048) over [plan | perceptual emb] -> mixture heads -> discretised
+logistic-mixture NLL + gripper cross-entropy.
+
+Internals are time-major ([t][b] rows) so every per-step slice and every BPTT operand pair is a
+contiguous row range; the four heads (mean_fc | log_scale_fc | prob_fc | gripper_fc) are stored
+back to back and evaluated as one GEMM.
+"""
+import torch
+
+from .. import ops
+from .._lib import ACT_NONE, ACT_RELU, call, ptr
+from ..blocks import TensorBlock
+
+
+class ActionDecoderLogistic:
+    def __init__(self, device, state_dim=32, goal_dim=32, latent_plan_dim=16, hidden_size=256, out_features=7,
+                 act_max_bound=(1.0,) * 7, act_min_bound=(-1.0,) * 7, gripper_alpha=1.0, policy_rnn_dropout_p=0.0,
+                 num_layers=2, rnn_model="rnn_decoder", discrete_gripper=True, include_goal=False, num_classes=10,
+                 n_mixtures=10, **unused):
+        if rnn_model != "rnn_decoder" or not discrete_gripper or include_goal or policy_rnn_dropout_p != 0.0:
+            raise NotImplementedError("only the configured decoder (relu nn.RNN, discrete gripper, no goal) is in scope")
+        if any(abs(b - 1.0) > 0 for b in act_max_bound) or any(abs(b + 1.0) > 0 for b in act_min_bound):
+            raise NotImplementedError("action bounds other than +-1 (config/networks/action_decoder/logistic.yaml)")
+        self.dev, self.P, self.E, self.hidden, self.L = device, latent_plan_dim, state_dim, hidden_size, num_layers
+        self.Da, self.K, self.num_classes, self.gripper_alpha = out_features - 1, n_mixtures, num_classes, gripper_alpha
+        self.include_goal = include_goal
+        H, In, DK = hidden_size, state_dim + latent_plan_dim, (out_features - 1) * n_mixtures
+        spec = []
+        for l in range(num_layers):
+            spec += [(f"rnn.weight_ih_l{l}", (H, In if l == 0 else H)), (f"rnn.weight_hh_l{l}", (H, H)),
+                     (f"rnn.bias_ih_l{l}", (H,)), (f"rnn.bias_hh_l{l}", (H,))]
+        spec += [("mean_fc.weight", (DK, H)), ("log_scale_fc.weight", (DK, H)), ("prob_fc.weight", (DK, H)),
+                 ("gripper_fc.weight", (2, H)), ("mean_fc.bias", (DK,)), ("log_scale_fc.bias", (DK,)),
+                 ("prob_fc.bias", (DK,)), ("gripper_fc.bias", (2,))]
+        self.blk = TensorBlock(spec, device)
+        self.NH = 3 * DK + 2
+        assert DK % 4 == 0, "head packing needs Da*K % 4 == 0"
+        t = lambda v: torch.tensor(v, device=device, dtype=torch.float32)  # noqa: E731
+        mx, mn = t(list(act_max_bound)[:-1]), t(list(act_min_bound)[:-1])
+        self.buffers = {  # register_buffer'ed by the reference (state-dict interchange)
+            "one_hot_embedding_eye": torch.eye(n_mixtures, device=device),
+            "ones": torch.ones(1, 1, n_mixtures, device=device),
+            "gripper_bounds": t([act_min_bound[-1], act_max_bound[-1]]),
+            "action_max_bound": mx.view(1, 1, -1, 1) * torch.ones(1, 1, 1, n_mixtures, device=device),
+            "action_min_bound": mn.view(1, 1, -1, 1) * torch.ones(1, 1, 1, n_mixtures, device=device),
+        }
+        self._shape = None
+        self.hidden_state = None
+
+    def clear_hidden_state(self):
+        self.hidden_state = None
+
+    def _ensure(self, B, Tm):
+        if self._shape == (B, Tm):
+            return
+        f = lambda *s: torch.zeros(*s, device=self.dev)  # noqa: E731
+        R, H = B * Tm, self.hidden
+        self.x_seq = f(R, self.P + self.E)
+        self.xin = [f(R, H) for _ in range(self.L)]
+        self.h = [f(R, H) for _ in range(self.L)]
+        self.h0 = f(B, H)
+        self.heads, self.d_heads = f(R, self.NH), f(R, self.NH)
+        self.ws = torch.empty(max(256, ops.L.lib().tacorl_logistic_mixture_ws_bytes(B, Tm, self.Da)), dtype=torch.uint8,
+                              device=self.dev)
+        self._shape = (B, Tm)
+
+    def _lin(self, x, ldx, w, b, y, M, K, N, act, compute):
+        call("tacorl_linear_fwd", 1, ops.ptr_array([x]), ldx, ops.ptr_array([w]), ops.ptr_array([b]),
+             ops.ptr_array([y]), None, ops.int_array([M]), K, N, act, compute, ops.stream())
+
+    def forward(self, plan, emb, ld_emb, B, T, Tm, compute):
+        """plan (B,P); emb [B*T][ld_emb] batch-major frame embeddings; uses steps t < Tm.  Fills self.heads."""
+        self._ensure(B, Tm)
+        blk, H, R = self.blk, self.hidden, B * Tm
+        call("tacorl_build_ad_input", ptr(plan), ptr(emb), ld_emb, ptr(self.x_seq), B, T, Tm, self.P, self.E,
+             ops.stream())
+        x, K = self.x_seq, self.P + self.E
+        for l in range(self.L):
+            self._lin(x, K, blk.p(f"rnn.weight_ih_l{l}"), blk.p(f"rnn.bias_ih_l{l}"), self.xin[l], R, K, H, ACT_NONE,
+                      compute)
+            for t in range(Tm):
+                prev = self.h0 if t == 0 else ops._at(self.h[l], (t - 1) * B * H)
+                call("tacorl_linear_add_fwd", 1, ops.ptr_array([prev]), H, ops.ptr_array([blk.p(f"rnn.weight_hh_l{l}")]),
+                     ops.ptr_array([blk.p(f"rnn.bias_hh_l{l}")]), ops.ptr_array([ops._at(self.xin[l], t * B * H)]), H,
+                     ops.ptr_array([ops._at(self.h[l], t * B * H)]), H, ops.int_array([B]), H, H, ACT_RELU, compute,
+                     ops.stream())
+            x, K = self.h[l], H
+        self._lin(x, H, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.heads, R, H, self.NH, ACT_NONE, compute)
+
+    def loss(self, actions, loss_out, B, T, Tm, want_grad, grad_scale=1.0):
+        """actions: device [B][T][Da+1]; writes the scalar loss to loss_out (device float) and, if
+        want_grad, dL/dheads into self.d_heads."""
+        call("tacorl_logistic_mixture_loss", ptr(self.heads), self.NH, ptr(actions), ptr(self.d_heads) if want_grad else None,
+             loss_out, B, T, Tm, self.Da, self.K, self.num_classes, float(self.gripper_alpha), float(grad_scale),
+             ptr(self.ws), self.ws.numel(), ops.stream())
+
+    def loss_step(self, module, actions, plan, B, T, optimize):
+        """TACORL.compute_action_decoder_update (reference tacorl.py:206-233): loss on emb[:, :-1],
+        actions[:, :-1]; logged always, Adam step when fine-tuning."""
+        from .._lib import LOG_SLOTS
+
+        acts = actions.to(self.dev).float().contiguous()
+        cams = module.action_decoder_modalities
+        if cams == module.plan_recognition_modalities:
+            emb, ld = module.pr_in, module.pr_in.shape[1]
+        else:
+            if getattr(module, "_ad_in", None) is None or module._ad_in.shape[0] != B * T:
+                module._ad_in = torch.zeros(B * T, 32 * len(cams), device=self.dev)
+            for j, c in enumerate(cams):
+                ops.copy_cols(module.f_out[c], 0, 32, module._ad_in, 32 * j, module._ad_in.shape[1], B * T, 32)
+            emb, ld = module._ad_in, module._ad_in.shape[1]
+        self.forward(plan, emb, ld, B, T, T - 1, module.compute)
+        slot = ops._at(module.engine.logs, LOG_SLOTS.index("action_loss"))
+        self.loss(acts, slot, B, T, T - 1, want_grad=optimize, grad_scale=1.0 / module.world_size)
+        if optimize:
+            self.backward(B, T - 1, module.compute, need_input_grad=False)
+            module.engine._allreduce([self.blk.grad])
+            ops.adam_step(self.blk.param, self.blk.grad, self.blk.m, self.blk.v, module.action_decoder_lr, 0.0,
+                          self.blk.step)
+
+    def backward(self, B, Tm, compute, need_input_grad=False):
+        raise NotImplementedError("action-decoder backward (BPTT) lands with the PlayLMP step")

@@ -1,0 +1,92 @@
+"""PlanRecognitionTransformersNetwork on HIP kernels (reference
+networks/plan_encoders/plan_recognition_transformer.py:10-105).
+
+Parameters keep the reference's state-dict names (position_embeddings, layernorm,
+transformer_encoder.layers.N.{self_attn.in_proj_*, self_attn.out_proj.*, linear1/2.*, norm1/2.*},
+fc, mean_fc, variance_fc).  mean_fc and variance_fc are stored back to back so the two heads
+are one GEMM.  `fc` is applied after the mean over time (fc is affine, so
+mean_t(fc(x_t)) == fc(mean_t(x_t)); saves 16x of the 32->4096 GEMM).
+"""
+import torch
+
+from .. import ops
+from .._lib import ACT_NONE, ACT_RELU, call, ptr
+from ..blocks import TensorBlock
+
+
+class PlanRecognition:
+    def __init__(self, state_dim, latent_plan_dim, device, num_heads=8, num_layers=2, encoder_hidden_size=2048,
+                 fc_hidden_size=4096, max_position_embeddings=16, min_std=1e-4, dropout_p=0.0, trainable=True,
+                 **unused):
+        self.D_in = state_dim
+        self.pad = (-state_dim) % num_heads
+        self.D = state_dim + self.pad
+        self.A, self.H, self.L = latent_plan_dim, num_heads, num_layers
+        self.FF, self.FC, self.T_max, self.min_std = encoder_hidden_size, fc_hidden_size, max_position_embeddings, min_std
+        self.latent_plan_dim = latent_plan_dim
+        self.dropout_p = dropout_p
+        D, FF, FC, A = self.D, self.FF, self.FC, self.A
+        spec = [("position_embeddings.weight", (self.T_max, D)), ("layernorm.weight", (D,)), ("layernorm.bias", (D,))]
+        for l in range(num_layers):
+            p = f"transformer_encoder.layers.{l}."
+            spec += [(p + "self_attn.in_proj_weight", (3 * D, D)), (p + "self_attn.in_proj_bias", (3 * D,)),
+                     (p + "self_attn.out_proj.weight", (D, D)), (p + "self_attn.out_proj.bias", (D,)),
+                     (p + "linear1.weight", (FF, D)), (p + "linear1.bias", (FF,)),
+                     (p + "linear2.weight", (D, FF)), (p + "linear2.bias", (D,)),
+                     (p + "norm1.weight", (D,)), (p + "norm1.bias", (D,)),
+                     (p + "norm2.weight", (D,)), (p + "norm2.bias", (D,))]
+        spec += [("fc.weight", (FC, D)), ("fc.bias", (FC,)), ("mean_fc.weight", (A, FC)),
+                 ("variance_fc.weight", (A, FC)), ("mean_fc.bias", (A,)), ("variance_fc.bias", (A,))]
+        self.blk = TensorBlock(spec, device, trainable=trainable)
+        self.dev = device
+        self._shape = None
+
+    def _ensure(self, B, T):
+        if self._shape == (B, T):
+            return
+        if T > self.T_max:
+            raise ValueError(f"sequence length {T} > max_position_embeddings {self.T_max}")
+        f = lambda *s: torch.zeros(*s, device=self.dev)  # noqa: E731
+        R, D = B * T, self.D
+        self.x = [f(R, D) for _ in range(2 * self.L + 1)]  # layer inputs / post-norm1 / post-norm2
+        self.qkv = [f(R, 3 * D) for _ in range(self.L)]
+        self.att = [f(R, D) for _ in range(self.L)]
+        self.proj = [f(R, D) for _ in range(self.L)]
+        self.ff1 = [f(R, self.FF) for _ in range(self.L)]
+        self.ff2 = [f(R, D) for _ in range(self.L)]
+        self.stats = [f(R, 2) for _ in range(2 * self.L)]
+        self.pooled, self.fc_out, self.head = f(B, D), f(B, self.FC), f(B, 2 * self.A)
+        self._shape = (B, T)
+
+    def _lin(self, x, ldx, w, b, y, M, K, N, act, compute):
+        call("tacorl_linear_fwd", 1, ops.ptr_array([x]), ldx, ops.ptr_array([w]), ops.ptr_array([b]),
+             ops.ptr_array([y]), None, ops.int_array([M]), K, N, act, compute, ops.stream())
+
+    def forward(self, emb, ld_emb, B, T, compute):
+        """emb: device tensor/pointer of [B*T][ld_emb] per-frame embeddings (first D_in columns used).
+        Returns the (B, 2A) head buffer [mean | var_raw]."""
+        self._ensure(B, T)
+        blk, D, R = self.blk, self.D, B * T
+        call("tacorl_add_rows_bcast", ptr(emb), ld_emb, blk.p("position_embeddings.weight"), ptr(self.x[0]), R, T,
+             self.D_in, D, ops.stream())
+        for l in range(self.L):
+            p = f"transformer_encoder.layers.{l}."
+            xin, x1, x2 = self.x[2 * l], self.x[2 * l + 1], self.x[2 * l + 2]
+            self._lin(xin, D, blk.p(p + "self_attn.in_proj_weight"), blk.p(p + "self_attn.in_proj_bias"), self.qkv[l],
+                      R, D, 3 * D, ACT_NONE, compute)
+            call("tacorl_attention_fwd", ptr(self.qkv[l]), ptr(self.att[l]), B, T, D, self.H, ops.stream())
+            self._lin(self.att[l], D, blk.p(p + "self_attn.out_proj.weight"), blk.p(p + "self_attn.out_proj.bias"),
+                      self.proj[l], R, D, D, ACT_NONE, compute)
+            call("tacorl_add_layernorm_fwd", ptr(xin), ptr(self.proj[l]), blk.p(p + "norm1.weight"),
+                 blk.p(p + "norm1.bias"), ptr(x1), ptr(self.stats[2 * l]), R, D, 1e-5, ops.stream())
+            self._lin(x1, D, blk.p(p + "linear1.weight"), blk.p(p + "linear1.bias"), self.ff1[l], R, D, self.FF,
+                      ACT_RELU, compute)
+            self._lin(self.ff1[l], self.FF, blk.p(p + "linear2.weight"), blk.p(p + "linear2.bias"), self.ff2[l], R,
+                      self.FF, D, ACT_NONE, compute)
+            call("tacorl_add_layernorm_fwd", ptr(x1), ptr(self.ff2[l]), blk.p(p + "norm2.weight"),
+                 blk.p(p + "norm2.bias"), ptr(x2), ptr(self.stats[2 * l + 1]), R, D, 1e-5, ops.stream())
+        call("tacorl_mean_over_t", ptr(self.x[2 * self.L]), ptr(self.pooled), B, T, D, ops.stream())
+        self._lin(self.pooled, D, blk.p("fc.weight"), blk.p("fc.bias"), self.fc_out, B, D, self.FC, ACT_NONE, compute)
+        self._lin(self.fc_out, self.FC, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.head, B, self.FC,
+                  2 * self.A, ACT_NONE, compute)
+        return self.head
