@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Headline benchmark: TACO-RL offline grad steps per second (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1] / SURVEY 8d "C2"): TACORL.training_step, frozen LMP
+(finetune_action_decoder=False), batch 256 per GPU, T=16 window, 84x84x3 frames, latent plan 16,
+n_action_samples=4, Q phase (epoch >= bc_epochs), bf16 MFMA operands with fp32 accumulation and
+fp32 master weights.  Synthetic data (U(-1,1) frames, reference initialisers, random-init LMP).
+One process per GPU; for N>1 start with torch.distributed.run (RCCL all-reduce of the flat
+gradient blocks).  Prints ONE JSON line on rank 0.
+
+"step" = one full training_step on one 256-sample batch per GPU (weak scaling);
+value = batch-256 grad steps per second summed over GPUs (= global samples/s / 256).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENC_FLOP_PER_IMG_84 = 13.918e6  # 2 * 6 959 104 MAC
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+
+
+def synth_batch(B, T, H, W, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    u = lambda *s: torch.rand(*s, device=dev, generator=g) * 2 - 1  # noqa: E731
+    acts = u(B, T, 7)
+    acts[..., -1] = torch.where(acts[..., -1] >= 0, 1.0, -1.0)
+    disp = torch.empty(B, device=dev).geometric_(0.3, generator=g).long()
+    disp[torch.rand(B, device=dev, generator=g) < 0.1] = -1
+    return {"states": {"rgb_static": u(B, T, 3, H, W)}, "goal": {"rgb_static": u(B, 3, H, W)}, "actions": acts,
+            "disp": disp}
+
+
+def build_module(dev, compute, T, world):
+    from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
+    from tacorl_amd.modules.tacorl.tacorl import TACORL
+
+    cams = ["rgb_static"]
+    actor = {"policy": {"num_layers": 3, "hidden_dim": 256}}
+    critic = {"q_network": {"num_layers": 3, "hidden_dim": 256, "last_layer_activation": "Identity"}}
+    pr = dict(num_heads=8, num_layers=2, encoder_hidden_size=2048, fc_hidden_size=4096, latent_plan_dim=16,
+              min_std=1e-4, dropout_p=0.0, max_position_embeddings=T)
+    ad = dict(n_mixtures=10, num_layers=2, hidden_size=2048, out_features=7, num_classes=10, latent_plan_dim=16,
+              rnn_model="rnn_decoder", include_goal=False)
+    torch.manual_seed(0)
+    lmp = PlayLMP(plan_proposal=actor, plan_recognition=pr, action_decoder=ad, plan_proposal_obs_modalities=cams,
+                  plan_proposal_goal_modalities=cams, plan_recognition_modalities=cams, action_decoder_modalities=cams,
+                  real_world=True, device=dev, compute_dtype=compute, image_dtype=compute)
+    mod = TACORL(play_lmp=lmp, finetune_action_decoder=False, critic=critic, real_world=True, device=dev,
+                 compute_dtype=compute, image_dtype=compute, world_size=world,
+                 # config/module/tacorl.yaml:8-30
+                 action_decoder_lr=3e-4, actor_lr=1e-4, critic_lr=3e-4, discount=0.95, conservative_weight=1.0,
+                 reward_scale=10.0, n_action_samples=4, with_lagrange=True, deterministic_backup=True, bc_epochs=5)
+    mod.current_epoch = 5  # Q phase
+    return mod
+
+
+def time_encoder_fwd(mod, B, H, W, iters=20):
+    """HIP-event timing of the encoder-forward launches on the stream they run on (torch's current
+    stream): the 6-problem batch the step issues (11*B images) - the roofline kernel."""
+    e = mod.engine
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        e._encode_all()
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(iters):
+        e._encode_all()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / iters
+    n_img = sum(n for _, _, _, n in e.enc_probs)
+    return ms, n_img
+
+
+def cpu_baseline(mod, batch_cpu, noise_cpu, B, budget_s=25.0):
+    """The oracle's reference-faithful schedule ((24+12n)B + 16B encoder images, as the reference
+    executes them) timed on this host's cores.  Reported baseline, not the target."""
+    from oracle import tacorl_oracle as O
+
+    cams = ["rgb_static"]
+    spec = O.ACSpec(cams=cams, goal_cams=cams, action_dim=16, n=4, discount=0.95, actor_lr=1e-4, critic_lr=3e-4,
+                    deterministic_backup=True, reward_scale=10.0, bc_epochs=5, with_lagrange=True,
+                    discrete_gripper=False, target_entropy=-7.0, finetune_action_decoder=False, ac_cams=cams, pr_cams=cams)
+    P = {k: v.detach().cpu().clone().contiguous() for k, v in mod.state_dict().items() if v.dtype == torch.float32
+         and not any(k.endswith(s) for s in ("one_hot_embedding_eye", "ones", "gripper_bounds", "action_max_bound",
+                                               "action_min_bound"))}
+    O.require_grad_(P, frozen_prefixes=("perceptual_encoder.", "plan_recognition."))
+    opts = O.make_opts(P, spec)
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    O.tacorl_step(P, opts, spec, batch_cpu, noise_cpu, 5, faithful=True)  # warm-up (allocator, threads)
+    first = time.perf_counter() - t0
+    reps = max(1, min(5, int(budget_s / max(first, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.tacorl_step(P, opts, spec, batch_cpu, noise_cpu, 5, faithful=True)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(1.0 / dt, 4), "unit": "grad-steps/s (batch 256)", "cores": cores, "kind": "port",
+            "sample": f"{reps} full training steps at batch {B} (T=16, 84x84, n=4, Q phase), reference schedule "
+                      f"(88*B encoder images/step), after 1 warm-up step; torch-CPU fp32, {cores} threads",
+            "s_per_step": round(dt, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        sys.exit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from tacorl_amd import _lib
+
+    _lib.call("tacorl_hip_init", local)
+    B, T, H, W = a.batch, 16, 84, 84
+    mod = build_module(dev, a.dtype, T, world)
+    batch = synth_batch(B, T, H, W, dev, 1234 + rank)
+    use_graph = (not a.no_graph) and hasattr(mod, "enable_graph")
+    if use_graph:
+        mod.enable_graph()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        mod.training_step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        mod.training_step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms_step = dt / a.steps * 1e3
+    logs = mod.engine.metrics()
+    finite = all(v == v and abs(v) < 1e30 for v in logs.values())
+
+    out = None
+    if rank == 0:
+        enc_ms, n_img = time_encoder_fwd(mod, B, H, W)
+        tflops = n_img * ENC_FLOP_PER_IMG_84 / (enc_ms * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        out = {
+            "metric": "offline grad-steps/sec (batch=256, 84x84 RGB)",
+            "value": round(world * (B / 256.0) / (ms_step * 1e-3), 3),
+            "unit": "grad-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "tacorl actor-critic training_step, frozen LMP (BASELINE configs[1])",
+                       "per_gpu_batch": B, "global_batch": B * world, "window": T, "image": f"{H}x{W}x3",
+                       "latent_plan": 16, "n_action_samples": 4, "phase": "Q (epoch>=bc_epochs)",
+                       "action_decoder_loss_logged": True, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                       "samples_per_s": round(world * B / (ms_step * 1e-3), 1), "losses_finite": finite},
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(tflops / peak, 4), "traffic": None,
+                         "kernel": "LMPVisionEncoder forward (tacorl_encoder_fwd, 6-problem batch of the step)",
+                         "images_per_launch": n_img, "avg_ms": round(enc_ms, 4)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            from tacorl_amd import synth  # noqa: F401
+
+            bc = {"states": {"rgb_static": batch["states"]["rgb_static"].cpu()},
+                  "goal": {"rgb_static": batch["goal"]["rgb_static"].cpu()}, "actions": batch["actions"].cpu(),
+                  "disp": batch["disp"].cpu()}
+            nz = {k: v.cpu().clone() for k, v in mod.engine.noise.items()}
+            nz["eps_pr"] = mod.eps_pr.cpu().clone()
+            out["cpu_baseline"] = cpu_baseline(mod, bc, nz, B)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

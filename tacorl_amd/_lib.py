@@ -70,6 +70,10 @@ def lib():
     """Load the HIP library (once).  Raises if it has not been built."""
     global _lib
     if _lib is None:
+        # torch ships its own libamdhip64; import it first so this library binds to the SAME HIP
+        # runtime instance (streams and device pointers are shared with torch).
+        import torch  # noqa: F401
+
         if not os.path.exists(LIB_PATH):
             raise TacorlHipError(
                 f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
