@@ -66,19 +66,22 @@ def time_encoder_fwd(mod, B, H, W, iters=20):
     """HIP-event timing of the encoder-forward launches on the stream they run on (torch's current
     stream): the 6-problem batch the step issues (11*B images) - the roofline kernel."""
     e = mod.engine
+    fused = all(e._fused_ok(c) for c in e.cams)
+    fn = e.encode_fused_only if fused else e._encode_all
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(3):
-        e._encode_all()
+        n_img = fn()
     torch.cuda.synchronize()
     ev0.record()
     for _ in range(iters):
-        e._encode_all()
+        fn()
     ev1.record()
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / iters
-    n_img = sum(n for _, _, _, n in e.enc_probs)
-    return ms, n_img
+    if not fused:
+        n_img = sum(n for _, _, _, n in e.enc_probs) + sum(x["n"] for x in e.extra_enc)
+    return ms, n_img, fused
 
 
 def cpu_baseline(mod, batch_cpu, noise_cpu, B, budget_s=25.0):
@@ -143,6 +146,7 @@ def main():
     use_graph = (not a.no_graph) and hasattr(mod, "enable_graph")
     if use_graph:
         mod.enable_graph()
+    mod.log_every_n_steps = 50  # PL Trainer default: metrics are read back every 50 steps
 
     def barrier():
         if world > 1:
@@ -167,7 +171,7 @@ def main():
 
     out = None
     if rank == 0:
-        enc_ms, n_img = time_encoder_fwd(mod, B, H, W)
+        enc_ms, n_img, fused = time_encoder_fwd(mod, B, H, W)
         tflops = n_img * ENC_FLOP_PER_IMG_84 / (enc_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
         out = {
@@ -184,7 +188,9 @@ def main():
                        "samples_per_s": round(world * B / (ms_step * 1e-3), 1), "losses_finite": finite},
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tflops / peak, 4), "traffic": None,
-                         "kernel": "LMPVisionEncoder forward (tacorl_encoder_fwd, 6-problem batch of the step)",
+                         "kernel": ("encoder_fused_kernel: the step's no-grad LMPVisionEncoder forward launch "
+                                    "(frozen LMP over B*T frames + actor(next) + both targets)") if fused else
+                                   "LMPVisionEncoder forward, per-layer kernels (tacorl_encoder_fwd)",
                          "images_per_launch": n_img, "avg_ms": round(enc_ms, 4)},
         }
         if world == 1 and not a.no_cpu_baseline:

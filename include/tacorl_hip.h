@@ -39,10 +39,23 @@ int tacorl_linear_fwd(int nprob, const float* const* x, int ldx, const float* co
                       int K, int N, int act, int compute_dtype, tacorl_stream_t stream);
 /* y = act(x W^T + b + addend), y with leading dim ldy: one ReLU-RNN time step
  * (torch nn.RNN relu; reference networks/action_decoders/rnn_models.py:5-16). */
+size_t tacorl_linear_add_fwd_ws_bytes(int nprob, const int* M, int K, int N);
+/* ws (may be NULL): scratch for the split-reduction path used when M is too small to fill the chip. */
 int tacorl_linear_add_fwd(int nprob, const float* const* x, int ldx, const float* const* w,
                           const float* const* b, const float* const* addend, int ld_add, float* const* y,
-                          int ldy, const int* M, int K, int N, int act, int compute_dtype,
-                          tacorl_stream_t stream);
+                          int ldy, const int* M, int K, int N, int act, int compute_dtype, void* ws,
+                          size_t ws_bytes, tacorl_stream_t stream);
+/* Backward primitives of y = act(x W^T + b):
+ *   dgrad: out[m][i] = (sum_o dz[m][o] W[o][i] + addend[m][i]) * act'(src[m][i])
+ *   wgrad: dw[o][k] (+)= sum_m dz[m][o] x[m][k], db[o] (+)= sum_m dz[m][o]  (split-R slabs in ws). */
+int tacorl_linear_dgrad(int nprob, const float* const* dz, int ld_dz, const float* const* w,
+                        float* const* out, int ld_out, const float* const* src, int ld_src, int act_src,
+                        const float* const* addend, int ld_add, const int* M, int O, int I,
+                        int compute_dtype, tacorl_stream_t stream);
+size_t tacorl_linear_wgrad_ws_bytes(int nprob, const int* M, int K, int O);
+int tacorl_linear_wgrad(int nprob, const float* const* x, int ldx, const float* const* dz, int ld_dz,
+                        const int* M, int K, int O, float* const* dw, float* const* db, int accumulate,
+                        int compute_dtype, void* ws, size_t ws_bytes, tacorl_stream_t stream);
 /* y = relu(conv2d(x, w) + b), no padding.  Replaces nn.Conv2d + nn.ReLU,
  * reference networks/visual_encoders/encoder.py:369-390. x_dtype: image storage dtype. */
 int tacorl_conv2d_relu_fwd(int nprob, const void* const* x, const float* const* w,
@@ -68,6 +81,17 @@ int tacorl_encoder_bwd(int nprob, const void* const* img, const float* const* pa
                        const float* const* act, const float* const* d_out, float* const* grads,
                        const int* n_img, int H, int W, int img_dtype, int compute_dtype,
                        int accumulate, void* ws, size_t ws_bytes, tacorl_stream_t stream);
+
+/* Fused inference forward (no saved activations): one launch, bf16 MFMA, register-stationary weights,
+ * LDS-resident intermediates; bf16 NHWC images only.  `packed` = tacorl_encoder_pack_weights output
+ * (tacorl_encoder_fused_wpk_bytes() bytes per network; re-pack whenever the fp32 block changes). */
+long tacorl_encoder_fused_wpk_bytes(void);
+int tacorl_encoder_fused_supported(int H, int W);
+int tacorl_encoder_pack_weights(int nprob, const float* const* params, void* const* packed,
+                                tacorl_stream_t stream);
+int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const void* const* packed,
+                             const float* const* params, float* const* out, const int* n_img, int H, int W,
+                             tacorl_stream_t stream);
 
 /* ---- MLP = chain of Linear(dims[l] -> dims[l+1]) + acts[l]  ------------------------ */
 /* Parameter block: for each layer W[out][in] then b[out], each 4-float aligned. */
@@ -135,11 +159,32 @@ int tacorl_build_ad_input(const float* plan, const float* emb, int ld_emb, float
 size_t tacorl_logistic_mixture_ws_bytes(int B, int Tm, int Da);
 /* Discretised-logistic-mixture NLL + gripper CE (:110-235), forward + backward fused.
  * heads[(t*B+b)] = [means Da*K | log_scales Da*K | logit_probs Da*K | gripper 2]; actions batch-major
- * [B][T][Da+1]; d_heads may be NULL (loss only); loss_out: one device float. */
+ * [B][T][Da+1]; d_heads may be NULL (loss only); loss_out: two device floats {loss, gripper accuracy}. */
 int tacorl_logistic_mixture_loss(const float* heads, int ldh, const float* actions, float* d_heads,
                                  float* loss_out, int B, int T, int Tm, int Da, int K, int num_classes,
                                  float gripper_alpha, float grad_scale, void* ws, size_t ws_bytes,
                                  tacorl_stream_t stream);
+
+/* ---- backward glue: ReLU-RNN BPTT, transformer, seq-VAE KL ---------------------------------- */
+int tacorl_relu_mask_mul(const float* dy, const float* add, const float* h, float* out, long n,
+                         tacorl_stream_t stream);
+int tacorl_ad_input_bwd(const float* dx, float* d_plan, float* d_emb, int ld_emb, int B, int T, int Tm,
+                        int P, int E, int accumulate, tacorl_stream_t stream);
+int tacorl_bcast_over_t(const float* src, float* dst, int B, int T, int D, float scale, int accumulate,
+                        tacorl_stream_t stream);
+int tacorl_attention_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int D, int H,
+                         tacorl_stream_t stream);
+size_t tacorl_add_layernorm_bwd_ws_bytes(int R, int D);
+int tacorl_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* w,
+                             const float* stats, float* dv, float* dw, float* db, int R, int D,
+                             int accumulate, void* ws, size_t ws_bytes, tacorl_stream_t stream);
+/* Balanced KL(q||p) of PlayLMP.compute_kl_loss (reference play_lmp_for_rl.py:259-301), fwd+bwd:
+ * out2 = {kl, kl_beta*kl}; d_head_* = d(kl_beta*kl)/d(raw heads) * grad_scale. */
+int tacorl_gauss_kl_balanced(const float* head_q, const float* head_p, float* d_head_q, float* d_head_p,
+                             int B, int A, float kl_alpha, float kl_beta, float min_std, int balanced,
+                             float grad_scale, float* out2, tacorl_stream_t stream);
+int tacorl_pr_sample_bwd(const float* head, const float* eps, const float* d_plan, float* d_head, int B,
+                         int A, float min_std, tacorl_stream_t stream);
 
 /* device-resident metric record written by the loss kernels (names = reference self.log keys) */
 enum {

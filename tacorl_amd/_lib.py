@@ -25,7 +25,8 @@ _SIGS = {
     "tacorl_hip_init": (_i, [_i]),
     "tacorl_hip_last_error": (C.c_char_p, []),
     "tacorl_linear_fwd": (_i, [_i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "tacorl_linear_add_fwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
+    "tacorl_linear_add_fwd_ws_bytes": (_sz, [_i, _p, _i, _i]),
+    "tacorl_linear_add_fwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "tacorl_add_rows_bcast": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "tacorl_attention_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "tacorl_add_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
@@ -34,12 +35,27 @@ _SIGS = {
     "tacorl_build_ad_input": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "tacorl_logistic_mixture_ws_bytes": (_sz, [_i, _i, _i]),
     "tacorl_logistic_mixture_loss": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p]),
+    "tacorl_linear_dgrad": (_i, [_i, _p, _i, _p, _p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p]),
+    "tacorl_linear_wgrad_ws_bytes": (_sz, [_i, _p, _i, _i]),
+    "tacorl_linear_wgrad": (_i, [_i, _p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _p, _sz, _p]),
+    "tacorl_relu_mask_mul": (_i, [_p, _p, _p, _p, _l, _p]),
+    "tacorl_ad_input_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "tacorl_bcast_over_t": (_i, [_p, _p, _i, _i, _i, _f, _i, _p]),
+    "tacorl_attention_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "tacorl_add_layernorm_bwd_ws_bytes": (_sz, [_i, _i]),
+    "tacorl_add_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
+    "tacorl_gauss_kl_balanced": (_i, [_p, _p, _p, _p, _i, _i, _f, _f, _f, _i, _f, _p, _p]),
+    "tacorl_pr_sample_bwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "tacorl_conv2d_relu_fwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "tacorl_encoder_param_layout": (_l, [_p]),
     "tacorl_encoder_act_layout": (_l, [_i, _i, _i, _p]),
     "tacorl_encoder_fwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "tacorl_encoder_bwd_ws_bytes": (_sz, [_i, _p, _i, _i]),
     "tacorl_encoder_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "tacorl_encoder_fused_wpk_bytes": (_l, []),
+    "tacorl_encoder_fused_supported": (_i, [_i, _i]),
+    "tacorl_encoder_pack_weights": (_i, [_i, _p, _p, _p]),
+    "tacorl_encoder_fwd_fused": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p]),
     "tacorl_mlp_param_layout": (_l, [_i, _p, _p, _p]),
     "tacorl_mlp_act_layout": (_l, [_i, _i, _p, _p, _p, _p]),
     "tacorl_mlp_fwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _p, _i, _p]),

@@ -60,14 +60,86 @@ extern "C" int tacorl_linear_fwd(int nprob, const float* const* x, int ldx, cons
                                  int K, int N, int act, int compute_dtype, tacorl_stream_t stream) {
   return k_linear_fwd(nprob, x, ldx, w, b, y, z, M, K, N, N, act, compute_dtype, (hipStream_t)stream);
 }
+// Skinny GEMMs (M <= 256, long K: the RNN recurrence) launch too few tiles to hide HBM/L2 latency:
+// split the reduction over blocks, then finish bias + addend + activation in a second pass.
+struct ReduceTbl {
+  const float* slab[GEMM_MAXP];
+  const float* bias[GEMM_MAXP];
+  const float* addend[GEMM_MAXP];
+  float* y[GEMM_MAXP];
+  int M[GEMM_MAXP];
+};
+__global__ void bias_act_reduce_kernel(ReduceTbl t, int nsplit, int N, int ldy, int ld_add, int act) {
+  const int p = blockIdx.y, M = t.M[p];
+  const long total = (long)M * N;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(e / N), n = (int)(e - (long)m * N);
+    float z = t.bias[p] ? t.bias[p][n] : 0.f;
+    for (int s = 0; s < nsplit; s++) z += t.slab[p][(long)s * total + e];
+    if (t.addend[p]) z += t.addend[p][(long)m * ld_add + n];
+    t.y[p][(long)m * ldy + n] = act_apply(act, z);
+  }
+}
+static int splitk_choice(int nprob, const int* M, int K, int N) {
+  long maxM = 0;
+  for (int p = 0; p < nprob; p++) maxM = M[p] > maxM ? M[p] : maxM;
+  const long tiles = (long)cdiv(maxM, 128) * cdiv(N, N > 32 ? 64 : (N > 16 ? 32 : 16)) * nprob;
+  if (tiles >= 192 || K < 512) return 1;
+  long ns = 512 / tiles;
+  if (ns > K / 128) ns = K / 128;
+  if (ns > 16) ns = 16;
+  return ns < 2 ? 1 : (int)ns;
+}
+static int k_linear_fwd_splitk(int nprob, const float* const* x, int ldx, const float* const* w, const float* const* b,
+                               const float* const* addend, int ld_add, float* const* y, int ldy, const int* M, int K,
+                               int N, int act, int cd, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int ns = splitk_choice(nprob, M, K, N);
+  long need = 0;
+  for (int p = 0; p < nprob; p++) need += (long)ns * M[p] * N;
+  if (ns == 1 || ws == nullptr || (size_t)need * sizeof(float) > ws_bytes)
+    return k_linear_fwd(nprob, x, ldx, w, b, y, nullptr, M, K, N, ldy, act, cd, st, addend, ld_add);
+  RowMajorLoader la{}, lb{};
+  SplitStore ep{};
+  GemmArgs g{};
+  ReduceTbl t{};
+  g.nprob = nprob; g.nsplit = ns; g.N = N;
+  la.cols = K; la.ld = ldx; la.vec = (ldx % 4 == 0); la.ones_col = 0;
+  lb.cols = K; lb.ld = K; lb.vec = (K % 4 == 0); lb.ones_col = 0;
+  ep.N = N;
+  float* cur = (float*)ws;
+  int maxM = 0;
+  for (int p = 0; p < nprob; p++) {
+    la.ptr[p] = x[p]; la.rows[p] = M[p]; la.vec &= aligned16(x[p]);
+    lb.ptr[p] = w[p]; lb.rows[p] = N; lb.vec &= aligned16(w[p]);
+    ep.slab[p] = cur; ep.M[p] = M[p];
+    t.slab[p] = cur; t.bias[p] = b ? b[p] : nullptr; t.addend[p] = addend ? addend[p] : nullptr; t.y[p] = y[p]; t.M[p] = M[p];
+    cur += (long)ns * M[p] * N;
+    g.M[p] = M[p]; g.R[p] = K;
+    maxM = M[p] > maxM ? M[p] : maxM;
+  }
+  CHECK((gemm_launch<RowMajorLoader, RowMajorLoader, false, false, SplitStore>(la, lb, ep, g, cd, st)));
+  const long total = (long)maxM * N;
+  dim3 grid((unsigned)(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), nprob);
+  hipLaunchKernelGGL(bias_act_reduce_kernel, grid, dim3(256), 0, st, t, ns, N, ldy, ld_add, act);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+extern "C" size_t tacorl_linear_add_fwd_ws_bytes(int nprob, const int* M, int K, int N) {
+  const int ns = splitk_choice(nprob, M, K, N);
+  if (ns == 1) return 0;
+  long need = 0;
+  for (int p = 0; p < nprob; p++) need += (long)ns * M[p] * N;
+  return (size_t)need * sizeof(float);
+}
+
 // y = act(x W^T + b + addend): one ReLU-RNN time step h_t = relu(W_hh h_{t-1} + b_hh + (W_ih x_t + b_ih))
 // (torch nn.RNN(nonlinearity="relu"), reference networks/action_decoders/rnn_models.py:5-16)
 extern "C" int tacorl_linear_add_fwd(int nprob, const float* const* x, int ldx, const float* const* w,
                                      const float* const* b, const float* const* addend, int ld_add,
                                      float* const* y, int ldy, const int* M, int K, int N, int act,
-                                     int compute_dtype, tacorl_stream_t stream) {
-  return k_linear_fwd(nprob, x, ldx, w, b, y, nullptr, M, K, N, ldy, act, compute_dtype, (hipStream_t)stream, addend,
-                      ld_add);
+                                     int compute_dtype, void* ws, size_t ws_bytes, tacorl_stream_t stream) {
+  if (nprob < 1 || nprob > GEMM_MAXP) FAIL(TACORL_EINVAL, "linear_add_fwd: nprob %d", nprob);
+  return k_linear_fwd_splitk(nprob, x, ldx, w, b, addend, ld_add, y, ldy, M, K, N, act, compute_dtype, ws, ws_bytes,
+                             (hipStream_t)stream);
 }
 
 // ================================================================ conv forward
@@ -122,21 +194,33 @@ extern "C" int tacorl_conv2d_relu_fwd(int nprob, const void* const* x, const flo
 // linear: dX[m][i] = (sum_o dZ[m][o] W[o][i]) * act'(src[m][i])
 static int k_linear_dgrad(int nprob, const float* const* dz, int ld_dz, const float* const* w, float* const* out,
                           int ld_out, const float* const* src, int act_src, const int* M, int O, int I,
-                          int cd, hipStream_t st) {
+                          int cd, hipStream_t st, const float* const* addend = nullptr, int ld_add = 0,
+                          int ld_src = -1) {
   RowMajorLoader la{}, lb{};
   DgradStore ep{};
   GemmArgs g{};
   g.nprob = nprob; g.nsplit = 1; g.N = I;
   la.cols = O; la.ld = ld_dz; la.vec = (O % 4 == 0 && ld_dz % 4 == 0); la.ones_col = 0;
   lb.cols = I; lb.ld = I; lb.vec = (I % 4 == 0); lb.ones_col = 0;
-  ep.ld = ld_out; ep.act = act_src;
+  ep.ld = ld_out; ep.act = act_src; ep.ld_add = ld_add; ep.ld_src = ld_src < 0 ? ld_out : ld_src;
   for (int p = 0; p < nprob; p++) {
     la.ptr[p] = dz[p]; la.rows[p] = M[p]; la.vec &= aligned16(dz[p]);
     lb.ptr[p] = w[p]; lb.rows[p] = O; lb.vec &= aligned16(w[p]);
-    ep.out[p] = out[p]; ep.src[p] = src ? src[p] : nullptr;
+    ep.out[p] = out[p]; ep.src[p] = src ? src[p] : nullptr; ep.addend[p] = addend ? addend[p] : nullptr;
     g.M[p] = M[p]; g.R[p] = O;
   }
   return gemm_launch<RowMajorLoader, RowMajorLoader, false, true, DgradStore>(la, lb, ep, g, cd, st);
+}
+
+// C-ABI primitives: backward of y = act(x W^T + b) for callers that schedule their own chains
+// (the ReLU-RNN BPTT and the transformer backward).
+extern "C" int tacorl_linear_dgrad(int nprob, const float* const* dz, int ld_dz, const float* const* w,
+                                   float* const* out, int ld_out, const float* const* src, int ld_src, int act_src,
+                                   const float* const* addend, int ld_add, const int* M, int O, int I,
+                                   int compute_dtype, tacorl_stream_t stream) {
+  if (nprob < 1 || nprob > GEMM_MAXP) FAIL(TACORL_EINVAL, "linear_dgrad: nprob %d", nprob);
+  return k_linear_dgrad(nprob, dz, ld_dz, w, out, ld_out, src, act_src, M, O, I, compute_dtype, (hipStream_t)stream,
+                        addend, ld_add, ld_src);
 }
 
 // conv: gather form, one GEMM per input-pixel parity class (S*S classes per net).
@@ -237,6 +321,19 @@ static int k_linear_wgrad(int nprob, const float* const* x, int ldx, const float
   la.cols = K; la.ld = ldx; la.vec = (ldx % 4 == 0 && K % 4 == 0); la.ones_col = 1;
   for (int p = 0; p < nprob; p++) { la.ptr[p] = x[p]; la.rows[p] = M[p]; la.vec &= aligned16(x[p]); }
   return k_wgrad(la, nprob, dz, ld_dz, M, K, O, dw, db, accumulate, ws, ws_bytes, cd, st);
+}
+
+extern "C" size_t tacorl_linear_wgrad_ws_bytes(int nprob, const int* M, int K, int O) {
+  long maxM = 0;
+  for (int p = 0; p < nprob; p++) maxM = M[p] > maxM ? M[p] : maxM;
+  return wgrad_ws_bytes(nprob, K, O, maxM);
+}
+extern "C" int tacorl_linear_wgrad(int nprob, const float* const* x, int ldx, const float* const* dz, int ld_dz,
+                                   const int* M, int K, int O, float* const* dw, float* const* db, int accumulate,
+                                   int compute_dtype, void* ws, size_t ws_bytes, tacorl_stream_t stream) {
+  if (nprob < 1 || nprob > GEMM_MAXP) FAIL(TACORL_EINVAL, "linear_wgrad: nprob %d", nprob);
+  return k_linear_wgrad(nprob, x, ldx, dz, ld_dz, M, K, O, dw, db, accumulate, ws, ws_bytes, compute_dtype,
+                        (hipStream_t)stream);
 }
 
 template <typename InT>

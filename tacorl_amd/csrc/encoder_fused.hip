@@ -1,0 +1,395 @@
+// Fused LMPVisionEncoder forward (inference / no-grad problems): conv8x8s4+ReLU -> conv4x4s2+ReLU ->
+// conv3x3s1+ReLU -> spatial soft-argmax -> FC128-256+ReLU -> FC256-32, one launch, bf16 MFMA with
+// fp32 accumulation, every intermediate on chip (reference networks/visual_encoders/encoder.py:369-419,
+// utils.py:39-65).
+//
+// Design (MI355X_MICROARCH / cdna_hip_programming guides):
+//  * weights are REGISTER-stationary: each of the 4 waves of a workgroup owns 16 output channels of
+//    conv2/conv3 (a quarter of fc1, half of conv1/fc2) as pre-packed MFMA fragments (~256 VGPRs, one
+//    wave per SIMD); they are loaded once per workgroup and reused for every image it processes;
+//  * activations live in LDS: the raw NHWC bf16 image (double-buffered, next image prefetched through
+//    registers while the current one is computed), conv1 output [pixel][32ch] with an 80-byte pixel
+//    stride and conv2 output [pixel][64ch] with a 160-byte stride - strides chosen so that the
+//    im2col fragment reads (ds_read_b128, 16 consecutive output pixels x 8 channels) hit 16 distinct
+//    16-byte slots per lane group (conflict-free);
+//  * MFMA orientation D[channel][pixel] = W[channel][k] * im2col[k][pixel]: a lane ends up with 4
+//    consecutive channels of one pixel -> one 8-byte LDS store per tile;
+//  * conv3's accumulators never leave registers: bias+ReLU+soft-argmax (max / sum-exp / E[x], E[y])
+//    are reduced with 4 xor-shuffles across the 16 pixel lanes;
+//  * the FC tail runs once per chunk of 8 images (pixels -> images on the MFMA column axis).
+// HBM traffic = the bf16 image (42 336 B @84x84) + 128 B of output per image.
+#include <stdio.h>
+
+#include "../../include/tacorl_hip.h"
+#include "common.h"
+
+#define EF_CHUNK 8      // images per FC batch
+#define EF_MAXCH 12     // 16-byte chunks per thread for one image (<= 49 152 B: up to ~90x90x3 bf16)
+#define EF_MAXP 16
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct EFProblem {
+  const __bf16* img;   // [n][H][W][3]
+  const u32x4* wpk;    // packed bf16 fragments (tacorl_encoder_pack_weights)
+  const float* params; // fp32 block (biases, temperature)
+  float* out;          // [n][32]
+  int n_img;
+  int first_block, nblocks;
+};
+struct EFArgs {
+  EFProblem p[EF_MAXP];
+  int nprob;
+  int H, W, OH1, OW1, OH2, OW2, OH3, OW3;
+  int img_bytes;   // H*W*3*2
+  int lds_img;     // bytes reserved per image buffer (multiple of 16)
+};
+
+// packed-fragment offsets (in 16-byte units, 64 lanes per fragment)
+#define WP_C1 0                      // [2 ntile][6 kstep][64]
+#define WP_C2 (WP_C1 + 2 * 6 * 64)   // [4][16][64]
+#define WP_C3 (WP_C2 + 4 * 16 * 64)  // [4][18][64]
+#define WP_F1 (WP_C3 + 4 * 18 * 64)  // [16][4][64]
+#define WP_F2 (WP_F1 + 16 * 4 * 64)  // [2][8][64]
+#define WP_TOTAL (WP_F2 + 2 * 8 * 64)
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d) {
+  bf16x4 t = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+  return __builtin_bit_cast(u32x2, t);
+}
+
+// ------------------------------------------------------------------ weight packing
+// frag(j, s, l)[e] = W[16 j + (l & 15)][32 s + 8 (l >> 4) + e]   (W row-major [N][K], fp32 -> bf16)
+__global__ void ef_pack_kernel(const float* __restrict__ params, u32x4* __restrict__ out, long o_w1, long o_w2,
+                               long o_w3, long o_f1, long o_f2) {
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;  // fragment id
+  if (f >= WP_TOTAL / 64) return;
+  const float* W; int K, j, s;
+  if (f < WP_C2 / 64) { W = params + o_w1; K = 192; j = f / 6; s = f % 6; }
+  else if (f < WP_C3 / 64) { int r = f - WP_C2 / 64; W = params + o_w2; K = 512; j = r / 16; s = r % 16; }
+  else if (f < WP_F1 / 64) { int r = f - WP_C3 / 64; W = params + o_w3; K = 576; j = r / 18; s = r % 18; }
+  else if (f < WP_F2 / 64) { int r = f - WP_F1 / 64; W = params + o_f1; K = 128; j = r / 4; s = r % 4; }
+  else { int r = f - WP_F2 / 64; W = params + o_f2; K = 256; j = r / 8; s = r % 8; }
+  const float* src = W + (long)(16 * j + (l & 15)) * K + 32 * s + 8 * (l >> 4);
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; e++) v[e] = (__bf16)src[e];
+  out[(long)f * 64 + l] = __builtin_bit_cast(u32x4, v);
+}
+
+extern "C" long tacorl_encoder_fused_wpk_bytes(void) { return (long)WP_TOTAL * 16; }
+extern "C" int tacorl_encoder_pack_weights(int nprob, const float* const* params, void* const* packed,
+                                           tacorl_stream_t stream) {
+  long po[11];
+  tacorl_encoder_param_layout(po);
+  for (int p = 0; p < nprob; p++)
+    hipLaunchKernelGGL(ef_pack_kernel, dim3((WP_TOTAL / 64 + 3) / 4), dim3(256), 0, (hipStream_t)stream, params[p],
+                       (u32x4*)packed[p], po[0], po[2], po[4], po[7], po[9]);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
+// MFMA with the weight fragment held in AGPRs (the conv2/conv3 weights fill 136 AGPRs; as plain
+// builtin operands hipcc keeps them in arch VGPRs, runs out, and serialises every LDS read behind one
+// shared destination register).  Inline asm is invisible to hipcc's hazard recogniser, so the chain
+// brackets itself: s_nop before the first MFMA (VALU-written accumulator) and after the last one
+// (MFMA result read by VALU) - cdna_hip_programming.md section 5.7.
+#define MFMA_AW(acc, wfrag, bfrag) \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wfrag), "v"(bfrag))
+#define MFMA_CHAIN_BEGIN(acc) asm volatile("s_nop 1" : "+v"(acc))
+#define MFMA_CHAIN_END(acc) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc))
+
+// ------------------------------------------------------------------------- kernel
+#define ACT1_STRIDE 80   // bytes per conv1-output pixel (32 ch bf16 + 16 pad)
+#define ACT2_STRIDE 160  // bytes per conv2-output pixel (64 ch bf16 + 32 pad)
+#define SA_STRIDE 272    // bytes per image of soft-argmax features (128 bf16 + 16 pad)
+#define H1_STRIDE 528    // bytes per image of fc1 output (256 bf16 + 16 pad)
+
+__global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r16 = l & 15, g = l >> 4;
+  // which problem / worker am I
+  int pi = 0;
+  for (int i = 1; i < a.nprob; i++)
+    if ((int)blockIdx.x >= a.p[i].first_block) pi = i;
+  const EFProblem P = a.p[pi];
+  const int worker = blockIdx.x - P.first_block, nworkers = P.nblocks;
+  const int n_chunks = (P.n_img + EF_CHUNK - 1) / EF_CHUNK;
+  if (worker >= n_chunks) return;
+
+  unsigned char* act1 = lds + 2 * a.lds_img;
+  const int npx1 = a.OH1 * a.OW1, npx2 = a.OH2 * a.OW2, npx3 = a.OH3 * a.OW3;
+  unsigned char* act2 = act1 + ((npx1 * ACT1_STRIDE + 15) & ~15);
+  unsigned char* sa = act2 + ((npx2 * ACT2_STRIDE + 15) & ~15);
+  unsigned char* h1 = sa + EF_CHUNK * SA_STRIDE;
+
+  // ---- register-stationary weights and biases
+  long po[11];
+  {
+    const long sz[11] = {32 * 8 * 8 * 3, 32, 64 * 4 * 4 * 32, 64, 64 * 3 * 3 * 64, 64, 1, 256 * 128, 256, 32 * 256, 32};
+    long off = 0;
+    for (int i = 0; i < 11; i++) { po[i] = off; off = (off + sz[i] + 3) & ~3L; }
+  }
+  const int nt1 = w >> 1, mh1 = w & 1;
+  bf16x8 wc1[6];
+  u32x4 wc2[16], wc3[18];
+#pragma unroll
+  for (int s = 0; s < 6; s++) wc1[s] = as_bf16x8(P.wpk[WP_C1 + (nt1 * 6 + s) * 64 + l]);
+#pragma unroll
+  for (int s = 0; s < 16; s++) wc2[s] = P.wpk[WP_C2 + (w * 16 + s) * 64 + l];
+#pragma unroll
+  for (int s = 0; s < 18; s++) wc3[s] = P.wpk[WP_C3 + (w * 18 + s) * 64 + l];
+  float b1[4], b2[4], b3[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    b1[q] = P.params[po[1] + 16 * nt1 + 4 * g + q];
+    b2[q] = P.params[po[3] + 16 * w + 4 * g + q];
+    b3[q] = P.params[po[5] + 16 * w + 4 * g + q];
+  }
+  const float temp = P.params[po[6]];
+
+  // conv1 per-lane k offsets: chunk c = 4 s + g -> ky = c / 3, 8-element group (c % 3) inside the 24-run
+  int k1off[6];
+#pragma unroll
+  for (int s = 0; s < 6; s++) { const int c = 4 * s + g; k1off[s] = ((c / 3) * a.W * 3 + (c % 3) * 8) * 2; }
+
+  // ---- image streaming: global -> registers (early) -> LDS (late)
+  const int n16 = a.img_bytes >> 4;  // 16-byte chunks per image
+  u32x4 pf[EF_MAXCH];
+  auto issue_load = [&](long img_idx) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(P.img) + img_idx * a.img_bytes);
+#pragma unroll
+    for (int i = 0; i < EF_MAXCH; i++) {
+      const int c = tid + i * 256;
+      if (c < n16) pf[i] = src[c];
+    }
+  };
+  auto commit_load = [&](int buf) {
+    u32x4* dst = reinterpret_cast<u32x4*>(lds + buf * a.lds_img);
+#pragma unroll
+    for (int i = 0; i < EF_MAXCH; i++) {
+      const int c = tid + i * 256;
+      if (c < n16) dst[c] = pf[i];
+    }
+  };
+
+  // images this workgroup processes, in order: chunk = worker, worker+nworkers, ... ; 8 images each
+  int chunk = worker;
+  int slot = 0;  // image index within the chunk
+  long cur = (long)chunk * EF_CHUNK;
+  int buf = 0;
+  issue_load(cur);
+  commit_load(0);
+  __syncthreads();
+
+  while (true) {
+    // next image (for the prefetch)
+    int nslot = slot + 1, nchunk = chunk;
+    long nxt = cur + 1;
+    if (nslot == EF_CHUNK || nxt >= P.n_img) { nchunk = chunk + nworkers; nslot = 0; nxt = (long)nchunk * EF_CHUNK; }
+    const bool has_next = nchunk < n_chunks;
+    if (has_next) issue_load(nxt);
+
+    // ------------------------------------------------ conv1: 8x8 stride 4, 3 -> 32
+    {
+      const unsigned char* ib = lds + buf * a.lds_img;
+      const int ntile1 = (npx1 + 15) >> 4, half = (ntile1 + 1) >> 1;
+      const int t0 = mh1 * half, t1 = min(ntile1, t0 + half);
+      for (int mt = t0; mt < t1; mt++) {
+        const int pm = mt * 16 + r16, pc = min(pm, npx1 - 1);
+        const int oy = pc / a.OW1, ox = pc - oy * a.OW1;
+        const unsigned char* base = ib + ((4 * oy * a.W + 4 * ox) * 3) * 2;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        u32x4 bfr[6];
+#pragma unroll
+        for (int s = 0; s < 6; s++) {
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(base + k1off[s]);
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(base + k1off[s] + 8);
+          bfr[s] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+#pragma unroll
+        for (int s = 0; s < 6; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc1[s], as_bf16x8(bfr[s]), acc, 0, 0, 0);
+        if (pm < npx1)
+          *reinterpret_cast<u32x2*>(act1 + pm * ACT1_STRIDE + (16 * nt1 + 4 * g) * 2) =
+              pack4_bf16(fmaxf(acc[0] + b1[0], 0.f), fmaxf(acc[1] + b1[1], 0.f), fmaxf(acc[2] + b1[2], 0.f),
+                         fmaxf(acc[3] + b1[3], 0.f));
+      }
+    }
+    __syncthreads();
+    if (has_next) commit_load(buf ^ 1);  // the other buffer was last read by the previous image's conv1
+
+    // ------------------------------------------------ conv2: 4x4 stride 2, 32 -> 64 (wave = 16 channels)
+    {
+      const int ntile2 = (npx2 + 15) >> 4;
+      for (int mt = 0; mt < ntile2; mt++) {
+        const int pm = mt * 16 + r16, pc = min(pm, npx2 - 1);
+        const int oy = pc / a.OW2, ox = pc - oy * a.OW2;
+        const unsigned char* base = act1 + ((2 * oy) * a.OW1 + 2 * ox) * ACT1_STRIDE + 16 * g;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        u32x4 bfr[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+          const int ky = s >> 2, kx = s & 3;
+          bfr[s] = *reinterpret_cast<const u32x4*>(base + (ky * a.OW1 + kx) * ACT1_STRIDE);
+        }
+        MFMA_CHAIN_BEGIN(acc);
+#pragma unroll
+        for (int s = 0; s < 16; s++) MFMA_AW(acc, wc2[s], bfr[s]);
+        MFMA_CHAIN_END(acc);
+        if (pm < npx2)
+          *reinterpret_cast<u32x2*>(act2 + pm * ACT2_STRIDE + (16 * w + 4 * g) * 2) =
+              pack4_bf16(fmaxf(acc[0] + b2[0], 0.f), fmaxf(acc[1] + b2[1], 0.f), fmaxf(acc[2] + b2[2], 0.f),
+                         fmaxf(acc[3] + b2[3], 0.f));
+      }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------ conv3: 3x3 stride 1, 64 -> 64 + soft-argmax in registers
+    {
+      const int ntile3 = (npx3 + 15) >> 4;
+      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      float se[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0};
+      for (int mt = 0; mt < ntile3; mt++) {
+        const int pm = mt * 16 + r16, pc = min(pm, npx3 - 1);
+        const int oy = pc / a.OW3, ox = pc - oy * a.OW3;
+        const unsigned char* base = act2 + (oy * a.OW2 + ox) * ACT2_STRIDE + 16 * g;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        u32x4 bfr[18];
+#pragma unroll
+        for (int s = 0; s < 18; s++) {
+          const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
+          bfr[s] = *reinterpret_cast<const u32x4*>(base + (ky * a.OW2 + kx) * ACT2_STRIDE + 64 * (s & 1));
+        }
+        MFMA_CHAIN_BEGIN(acc);
+#pragma unroll
+        for (int s = 0; s < 18; s++) MFMA_AW(acc, wc3[s], bfr[s]);
+        MFMA_CHAIN_END(acc);
+        // online soft-argmax update (per channel q, over this lane's pixel)
+        const bool ok = pm < npx3;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float v = fmaxf(acc[q] + b3[q], 0.f) / temp;
+          const float m_new = ok ? fmaxf(mx[q], v) : mx[q];
+          const float sc = (mx[q] == -INFINITY) ? 0.f : expf(mx[q] - m_new);
+          const float e = ok ? expf(v - m_new) : 0.f;
+          se[q] = se[q] * sc + e; sx[q] = sx[q] * sc + e * (float)ox; sy[q] = sy[q] * sc + e * (float)oy;
+          mx[q] = m_new;
+        }
+      }
+      // merge the 16 pixel lanes (xor shuffles inside each 16-lane group)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          const float m2 = __shfl_xor(mx[q], o, 64), e2 = __shfl_xor(se[q], o, 64);
+          const float x2 = __shfl_xor(sx[q], o, 64), y2 = __shfl_xor(sy[q], o, 64);
+          const float mn = fmaxf(mx[q], m2);
+          const float c1 = (mx[q] == -INFINITY) ? 0.f : expf(mx[q] - mn), c2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+          se[q] = se[q] * c1 + e2 * c2; sx[q] = sx[q] * c1 + x2 * c2; sy[q] = sy[q] * c1 + y2 * c2;
+          mx[q] = mn;
+        }
+      }
+      if (r16 == 0) {
+        // features interleaved [x_c, y_c]; channels 16 w + 4 g + q
+        __bf16* dst = reinterpret_cast<__bf16*>(sa + slot * SA_STRIDE) + 2 * (16 * w + 4 * g);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { dst[2 * q] = (__bf16)(sx[q] / se[q]); dst[2 * q + 1] = (__bf16)(sy[q] / se[q]); }
+      }
+    }
+
+    // ------------------------------------------------ FC tail once per chunk
+    const bool chunk_done = (nslot == 0);
+    if (chunk_done) {
+      __syncthreads();  // soft-argmax features of the whole chunk are in LDS
+      const int n_in_chunk = slot + 1;
+      {
+        const unsigned char* base = sa + min(r16, EF_CHUNK - 1) * SA_STRIDE + 16 * g;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          u32x4 wf[4];
+#pragma unroll
+          for (int s = 0; s < 4; s++) wf[s] = P.wpk[WP_F1 + ((4 * w + j) * 4 + s) * 64 + l];
+          const float* bb = P.params + po[8] + 16 * (4 * w + j) + 4 * g;
+          const float c0 = bb[0], c1 = bb[1], c2 = bb[2], c3 = bb[3];
+#pragma unroll
+          for (int s = 0; s < 4; s++)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wf[s]), as_bf16x8(*reinterpret_cast<const u32x4*>(base + 64 * s)), acc, 0, 0, 0);
+          if (r16 < EF_CHUNK)
+            *reinterpret_cast<u32x2*>(h1 + r16 * H1_STRIDE + (16 * (4 * w + j) + 4 * g) * 2) =
+                pack4_bf16(fmaxf(acc[0] + c0, 0.f), fmaxf(acc[1] + c1, 0.f), fmaxf(acc[2] + c2, 0.f),
+                           fmaxf(acc[3] + c3, 0.f));
+        }
+      }
+      __syncthreads();
+      if (w < 2) {
+        const unsigned char* base = h1 + min(r16, EF_CHUNK - 1) * H1_STRIDE + 16 * g;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        u32x4 wf[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) wf[s] = P.wpk[WP_F2 + (w * 8 + s) * 64 + l];
+        const float* bb = P.params + po[10] + 16 * w + 4 * g;
+        const float c0 = bb[0], c1 = bb[1], c2 = bb[2], c3 = bb[3];
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wf[s]), as_bf16x8(*reinterpret_cast<const u32x4*>(base + 64 * s)), acc, 0, 0, 0);
+        if (r16 < n_in_chunk) {
+          float* o = P.out + ((long)chunk * EF_CHUNK + r16) * 32 + 16 * w + 4 * g;
+          f32x4 r = {acc[0] + c0, acc[1] + c1, acc[2] + c2, acc[3] + c3};
+          *reinterpret_cast<f32x4*>(o) = r;
+        }
+      }
+    }
+    if (!has_next) break;
+    __syncthreads();  // next image committed to LDS; sa/h1 free for the next chunk
+    cur = nxt; chunk = nchunk; slot = nslot; buf ^= 1;
+  }
+}
+
+extern "C" int tacorl_encoder_fused_supported(int H, int W) {
+  if (H < 36 || W < 36) return 0;
+  const long img_bytes = (long)H * W * 6;
+  if (img_bytes % 16 || img_bytes > (long)EF_MAXCH * 256 * 16) return 0;
+  const int OH1 = (H - 8) / 4 + 1, OW1 = (W - 8) / 4 + 1, OH2 = (OH1 - 4) / 2 + 1, OW2 = (OW1 - 4) / 2 + 1;
+  const long lds = 2 * ((img_bytes + 15) & ~15L) + (((long)OH1 * OW1 * ACT1_STRIDE + 15) & ~15L) +
+                   (((long)OH2 * OW2 * ACT2_STRIDE + 15) & ~15L) + EF_CHUNK * (SA_STRIDE + H1_STRIDE) + 64;
+  return lds <= 160 * 1024;
+}
+
+extern "C" int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const void* const* packed,
+                                        const float* const* params, float* const* out, const int* n_img, int H,
+                                        int W, tacorl_stream_t stream) {
+  if (nprob < 1 || nprob > EF_MAXP || !tacorl_encoder_fused_supported(H, W)) return TACORL_EINVAL;
+  EFArgs a{};
+  a.nprob = nprob; a.H = H; a.W = W;
+  a.OH1 = (H - 8) / 4 + 1; a.OW1 = (W - 8) / 4 + 1;
+  a.OH2 = (a.OH1 - 4) / 2 + 1; a.OW2 = (a.OW1 - 4) / 2 + 1;
+  a.OH3 = a.OH2 - 2; a.OW3 = a.OW2 - 2;
+  a.img_bytes = H * W * 6;
+  a.lds_img = (a.img_bytes + 15) & ~15;
+  long total_chunks = 0;
+  for (int p = 0; p < nprob; p++) total_chunks += (n_img[p] + EF_CHUNK - 1) / EF_CHUNK;
+  if (total_chunks == 0) return TACORL_OK;
+  // one workgroup per CU; workers are shared out in proportion to each problem's chunks
+  const int budget = 256;
+  int nb = 0;
+  for (int p = 0; p < nprob; p++) {
+    const long ch = (n_img[p] + EF_CHUNK - 1) / EF_CHUNK;
+    int k = (int)((ch * (budget - nprob)) / total_chunks) + (ch > 0 ? 1 : 0);  // floor share + 1: sum <= budget
+    if (k > ch) k = (int)ch;
+    a.p[p].img = (const __bf16*)img[p]; a.p[p].wpk = (const u32x4*)packed[p]; a.p[p].params = params[p];
+    a.p[p].out = out[p]; a.p[p].n_img = n_img[p]; a.p[p].first_block = nb; a.p[p].nblocks = k;
+    nb += k;
+  }
+  const size_t lds = 2 * (size_t)a.lds_img + (((size_t)a.OH1 * a.OW1 * ACT1_STRIDE + 15) & ~15UL) +
+                     (((size_t)a.OH2 * a.OW2 * ACT2_STRIDE + 15) & ~15UL) + EF_CHUNK * (SA_STRIDE + H1_STRIDE);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(encoder_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(encoder_fused_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}

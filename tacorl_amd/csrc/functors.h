@@ -100,14 +100,25 @@ struct BiasActStore {
     y[p][o] = act_apply(act, zz);
   }
 };
+// split-R forward: partial sums into slab[(s*M + m)*N + n]; finished by bias_act_reduce_kernel
+struct SplitStore {
+  float* slab[GEMM_MAXP];
+  int M[GEMM_MAXP];
+  int N;
+  __device__ __forceinline__ void store(int p, int s, int m, int n, float acc) const {
+    slab[p][((long)s * M[p] + m) * N + n] = acc;
+  }
+};
 // out = acc * act'(src)   (src = pre-activation for SiLU, output for ReLU; NULL = identity)
 struct DgradStore {
   float* out[GEMM_MAXP];
   const float* src[GEMM_MAXP];
-  int ld, act;
+  const float* addend[GEMM_MAXP];  // optional [M][N] added before the mask (BPTT: dH_{t-1})
+  int ld, act, ld_add, ld_src;
   __device__ __forceinline__ void store(int p, int, int m, int n, float acc) const {
     long o = (long)m * ld + n;
-    out[p][o] = src[p] ? acc * act_grad(act, src[p][o]) : acc;
+    if (addend[p]) acc += addend[p][(long)m * ld_add + n];
+    out[p][o] = src[p] ? acc * act_grad(act, src[p][(long)m * ld_src + n]) : acc;
   }
 };
 // conv dgrad: row m of parity class -> NHWC input position; masks with ReLU of the input.

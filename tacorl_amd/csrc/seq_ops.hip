@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void logistic_mixture_kernel(const float* __re
   __shared__ float sh[4];
   const int R = Tm * B;
   const long total = (long)R * Da;
-  float loss = 0.f;
+  float loss = 0.f, hits = 0.f;
   const float gR = grad_scale / (float)R;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int a = (int)(i % Da);
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void logistic_mixture_kernel(const float* __re
       const float lz = mg + logf(expf(g0 - mg) + expf(g1 - mg));
       const int y = actions[((long)b * T + t) * (Da + 1) + Da] == -1.0f ? 0 : (int)actions[((long)b * T + t) * (Da + 1) + Da];
       loss += gripper_alpha * (lz - (y ? g1 : g0));
+      hits += ((g1 > g0) ? 1 : 0) == y ? 1.f : 0.f;  // gripper_bounds[argmax] vs ground truth (play_lmp_for_rl.py:166-176)
       if (d_heads) {
         float* d = d_heads + r * ldh;
         d[3 * Da * K] = gR * gripper_alpha * (expf(g0 - lz) - (y == 0 ? 1.f : 0.f));
@@ -251,24 +252,33 @@ __global__ __launch_bounds__(256) void logistic_mixture_kernel(const float* __re
     }
   }
   loss = wave_sum(loss);
+  hits = wave_sum(hits);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = loss;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = hits;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
+// out[0] = scale * sum(partial[0:n]), out[1] = scale * sum(partial[n:2n])
 __global__ void scaled_sum_kernel(const float* __restrict__ partial, int n, float scale, float* out) {
   __shared__ float sh[4];
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1] + sh[2] + sh[3]) * scale;
+  for (int k = 0; k < 2; k++) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[k * n + i];
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[k] = (sh[0] + sh[1] + sh[2] + sh[3]) * scale;
+  }
 }
 extern "C" size_t tacorl_logistic_mixture_ws_bytes(int B, int Tm, int Da) {
   long blocks = ((long)B * Tm * Da + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  return (size_t)blocks * sizeof(float);
+  return (size_t)blocks * 2 * sizeof(float);
 }
 extern "C" int tacorl_logistic_mixture_loss(const float* heads, int ldh, const float* actions, float* d_heads,
                                             float* loss_out, int B, int T, int Tm, int Da, int K, int num_classes,
@@ -284,5 +294,288 @@ extern "C" int tacorl_logistic_mixture_loss(const float* heads, int ldh, const f
                      logf((float)(num_classes - 1) / 2.f), gripper_alpha, grad_scale);
   hipLaunchKernelGGL(scaled_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (int)blocks,
                      1.0f / (float)(B * Tm), loss_out);
+  return LAUNCH_OK();
+}
+
+// ====================================================================== backward glue
+// out = (dy (+ add)) * [h > 0]    (ReLU-RNN: last BPTT step, no recurrent term yet)
+__global__ void relu_mask_mul_kernel(const float* __restrict__ dy, const float* __restrict__ add,
+                                     const float* __restrict__ h, float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = h[i] > 0.f ? dy[i] + (add ? add[i] : 0.f) : 0.f;
+}
+extern "C" int tacorl_relu_mask_mul(const float* dy, const float* add, const float* h, float* out, long n,
+                                    tacorl_stream_t stream) {
+  if (n <= 0) return TACORL_OK;
+  hipLaunchKernelGGL(relu_mask_mul_kernel, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, add, h, out, n);
+  return LAUNCH_OK();
+}
+
+// Backward of build_ad_input: d_plan[b] = sum_t dx[(t,b)][0:P]; d_emb[(b*T+t)][0:E] (+)= dx[(t,b)][P:], t < Tm.
+__global__ void ad_input_bwd_kernel(const float* __restrict__ dx, float* __restrict__ d_plan, float* __restrict__ d_emb,
+                                    int ld_emb, int B, int T, int Tm, int P, int E, int accumulate) {
+  const int W = P + E;
+  const long total = (long)B * (P + (long)Tm * E);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (i < (long)B * P) {
+      const int b = (int)(i / P), c = (int)(i % P);
+      float s = 0.f;
+      for (int t = 0; t < Tm; t++) s += dx[((long)t * B + b) * W + c];
+      d_plan[i] = s;
+    } else {
+      const long j = i - (long)B * P;
+      const int c = (int)(j % E);
+      const long r = j / E;
+      const int t = (int)(r % Tm), b = (int)(r / Tm);
+      float* d = d_emb + ((long)b * T + t) * ld_emb + c;
+      const float v = dx[((long)t * B + b) * W + P + c];
+      *d = accumulate ? *d + v : v;
+    }
+  }
+}
+extern "C" int tacorl_ad_input_bwd(const float* dx, float* d_plan, float* d_emb, int ld_emb, int B, int T, int Tm, int P,
+                                   int E, int accumulate, tacorl_stream_t stream) {
+  const long total = (long)B * (P + (long)Tm * E);
+  if (total <= 0) return TACORL_OK;
+  hipLaunchKernelGGL(ad_input_bwd_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dx,
+                     d_plan, d_emb, ld_emb, B, T, Tm, P, E, accumulate);
+  return LAUNCH_OK();
+}
+
+// dst[(b*T+t)][d] (+)= src[b][d] * scale   (backward of the mean over time)
+__global__ void bcast_over_t_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int T, int D,
+                                    float scale, int accumulate) {
+  const long total = (long)B * T * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const long b = i / ((long)T * D);
+    const float v = src[b * D + d] * scale;
+    dst[i] = accumulate ? dst[i] + v : v;
+  }
+}
+extern "C" int tacorl_bcast_over_t(const float* src, float* dst, int B, int T, int D, float scale, int accumulate,
+                                   tacorl_stream_t stream) {
+  const long total = (long)B * T * D;
+  if (total <= 0) return TACORL_OK;
+  hipLaunchKernelGGL(bcast_over_t_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     B, T, D, scale, accumulate);
+  return LAUNCH_OK();
+}
+
+// Attention backward, one block of T threads per (batch, head); probabilities are recomputed.
+__global__ void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ d_out,
+                                     float* __restrict__ d_qkv, int B, int T, int D, int H) {
+  __shared__ float s_m[ATT_MAX_T], s_l[ATT_MAX_T], s_dd[ATT_MAX_T];
+  const int hd = D / H, b = blockIdx.x / H, h = blockIdx.x % H, i = threadIdx.x;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const float* base = qkv + (long)b * T * 3 * D;
+  const float* dob = d_out + (long)b * T * D;
+  float* dqb = d_qkv + (long)b * T * 3 * D;
+  float q[ATT_MAX_HD], dO[ATT_MAX_HD], acc[ATT_MAX_HD];
+  if (i < T) {
+    for (int e = 0; e < hd; e++) { q[e] = base[(long)i * 3 * D + h * hd + e] * scale; dO[e] = dob[(long)i * D + h * hd + e]; }
+    float mx = -INFINITY;
+    for (int j = 0; j < T; j++) {
+      float a = 0.f;
+      for (int e = 0; e < hd; e++) a += q[e] * base[(long)j * 3 * D + D + h * hd + e];
+      mx = fmaxf(mx, a);
+    }
+    float l = 0.f, dd = 0.f;
+    for (int j = 0; j < T; j++) {
+      float a = 0.f, dp = 0.f;
+      for (int e = 0; e < hd; e++) {
+        a += q[e] * base[(long)j * 3 * D + D + h * hd + e];
+        dp += dO[e] * base[(long)j * 3 * D + 2 * D + h * hd + e];
+      }
+      const float w = expf(a - mx);
+      l += w; dd += w * dp;
+    }
+    dd /= l;
+    s_m[i] = mx; s_l[i] = l; s_dd[i] = dd;
+    // dq_i = scale * sum_j dS_ij k_j
+    for (int e = 0; e < hd; e++) acc[e] = 0.f;
+    for (int j = 0; j < T; j++) {
+      float a = 0.f, dp = 0.f;
+      for (int e = 0; e < hd; e++) {
+        a += q[e] * base[(long)j * 3 * D + D + h * hd + e];
+        dp += dO[e] * base[(long)j * 3 * D + 2 * D + h * hd + e];
+      }
+      const float ds = expf(a - mx) / l * (dp - dd);
+      for (int e = 0; e < hd; e++) acc[e] += ds * base[(long)j * 3 * D + D + h * hd + e];
+    }
+    for (int e = 0; e < hd; e++) dqb[(long)i * 3 * D + h * hd + e] = acc[e] * scale;
+  }
+  __syncthreads();
+  if (i < T) {  // this thread now owns key/value j = i
+    float k[ATT_MAX_HD], v[ATT_MAX_HD], dk[ATT_MAX_HD], dv[ATT_MAX_HD];
+    for (int e = 0; e < hd; e++) {
+      k[e] = base[(long)i * 3 * D + D + h * hd + e]; v[e] = base[(long)i * 3 * D + 2 * D + h * hd + e];
+      dk[e] = 0.f; dv[e] = 0.f;
+    }
+    for (int r = 0; r < T; r++) {
+      float a = 0.f, dp = 0.f;
+      for (int e = 0; e < hd; e++) {
+        const float qs = base[(long)r * 3 * D + h * hd + e] * scale;
+        a += qs * k[e];
+        dp += dob[(long)r * D + h * hd + e] * v[e];
+      }
+      const float p = expf(a - s_m[r]) / s_l[r];
+      const float ds = p * (dp - s_dd[r]);
+      for (int e = 0; e < hd; e++) {
+        dk[e] += ds * base[(long)r * 3 * D + h * hd + e] * scale;
+        dv[e] += p * dob[(long)r * D + h * hd + e];
+      }
+    }
+    for (int e = 0; e < hd; e++) {
+      dqb[(long)i * 3 * D + D + h * hd + e] = dk[e];
+      dqb[(long)i * 3 * D + 2 * D + h * hd + e] = dv[e];
+    }
+  }
+}
+extern "C" int tacorl_attention_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int D, int H,
+                                    tacorl_stream_t stream) {
+  if (T > ATT_MAX_T || D % H || D / H > ATT_MAX_HD) return TACORL_EINVAL;
+  if (B <= 0) return TACORL_OK;
+  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, qkv, d_out, d_qkv, B, T, D, H);
+  return LAUNCH_OK();
+}
+
+// LayerNorm(x + res) backward.  dv (gradient of x + res) and per-block partial sums of dw, db.
+// partial: [nblocks][2*D]; finished by tacorl_colsum.
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ res, const float* __restrict__ w,
+                                                                const float* __restrict__ stats, float* __restrict__ dv,
+                                                                float* __restrict__ partial, int R, int D) {
+  __shared__ float sh[4][2 * 256];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wv;
+  float gw[4] = {0, 0, 0, 0}, gb[4] = {0, 0, 0, 0};
+  if (r < R) {
+    const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+    float xh[4], g[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int d = lane + 64 * i;
+      if (d < D) {
+        xh[i] = (x[(long)r * D + d] + (res ? res[(long)r * D + d] : 0.f) - mean) * rstd;
+        const float dyv = dy[(long)r * D + d];
+        g[i] = dyv * w[d];
+        gw[i] = dyv * xh[i]; gb[i] = dyv;
+        s1 += g[i]; s2 += g[i] * xh[i];
+      } else { xh[i] = 0.f; g[i] = 0.f; }
+    }
+    s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int d = lane + 64 * i;
+      if (d < D) dv[(long)r * D + d] = rstd * (g[i] - s1 - xh[i] * s2);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int d = lane + 64 * i;
+    if (d < D) { sh[wv][d] = gw[i]; sh[wv][256 + d] = gb[i]; }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) {
+    partial[(long)blockIdx.x * 2 * D + d] = sh[0][d] + sh[1][d] + sh[2][d] + sh[3][d];
+    partial[(long)blockIdx.x * 2 * D + D + d] = sh[0][256 + d] + sh[1][256 + d] + sh[2][256 + d] + sh[3][256 + d];
+  }
+}
+// column sums of the [rows][2D] partial matrix: first D columns -> dw, last D -> db
+__global__ void colsum2_kernel(const float* __restrict__ in, int rows, int D, float* __restrict__ dw,
+                               float* __restrict__ db, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * D) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; r++) s += in[(long)r * 2 * D + c];
+  float* o = c < D ? dw + c : db + (c - D);
+  *o = accumulate ? *o + s : s;
+}
+extern "C" size_t tacorl_add_layernorm_bwd_ws_bytes(int R, int D) { return (size_t)((R + 3) / 4) * 2 * D * sizeof(float); }
+extern "C" int tacorl_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* w,
+                                        const float* stats, float* dv, float* dw, float* db, int R, int D,
+                                        int accumulate, void* ws, size_t ws_bytes, tacorl_stream_t stream) {
+  if (D > 256) return TACORL_EINVAL;
+  if (R <= 0) return TACORL_OK;
+  if (ws_bytes < tacorl_add_layernorm_bwd_ws_bytes(R, D)) return TACORL_ENOMEM;
+  const int nb = (R + 3) / 4;
+  hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, x, res, w, stats, dv,
+                     (float*)ws, R, D);
+  hipLaunchKernelGGL(colsum2_kernel, dim3((2 * D + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)ws, nb,
+                     D, dw, db, accumulate);
+  return LAUNCH_OK();
+}
+
+// Balanced KL between the plan-recognition posterior q and the plan-proposal prior p on the
+// underlying Normals (reference play_lmp_for_rl.py:259-301), forward + backward fused:
+//   kl = alpha*KL(sg(q)||p) + (1-alpha)*KL(q||sg(p)),  mean over batch;  loss = beta*kl.
+// head_q = [mean | var_raw] (std = softplus+min_std), head_p = [mean_raw | log_std_raw] (policy clamps).
+// d_head_* receive d(beta*kl)/d(raw head).  One block.
+__global__ __launch_bounds__(256) void gauss_kl_kernel(const float* __restrict__ hq, const float* __restrict__ hp,
+                                                       float* __restrict__ dq, float* __restrict__ dp, int B, int A,
+                                                       float alpha, float beta, float min_std, int balanced,
+                                                       float grad_scale, float* out /*[2]: kl, beta*kl*/) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  const float c = beta * grad_scale / (float)B;
+  for (int i = threadIdx.x; i < B * A; i += 256) {
+    const int b = i / A, j = i - b * A;
+    const float mq = hq[(long)b * 2 * A + j], vr = hq[(long)b * 2 * A + A + j];
+    const float sq = (vr > 20.f ? vr : log1pf(expf(vr))) + min_std;
+    const float mr = hp[(long)b * 2 * A + j], lr = hp[(long)b * 2 * A + A + j];
+    const float mp = fminf(fmaxf(mr, -9.f), 9.f), sp = expf(fminf(fmaxf(lr, -5.f), 2.f));
+    const float vratio = (sq / sp) * (sq / sp), d = mq - mp, t1 = (d / sp) * (d / sp);
+    const float kl = 0.5f * (vratio + t1 - 1.f - logf(vratio));
+    s += kl;  // both terms have the same value; only their gradients differ
+    // gradient of KL wrt posterior (m1,s1) and prior (m2,s2)
+    const float g_m1 = d / (sp * sp), g_s1 = sq / (sp * sp) - 1.f / sq;
+    const float g_m2 = -d / (sp * sp), g_s2 = -(sq * sq) / (sp * sp * sp) - (d * d) / (sp * sp * sp) + 1.f / sp;
+    const float wq = balanced ? (1.f - alpha) : 1.f, wp = balanced ? alpha : 1.f;
+    const float sig = vr > 20.f ? 1.f : 1.f / (1.f + expf(-vr));  // softplus'
+    dq[(long)b * 2 * A + j] = c * wq * g_m1;
+    dq[(long)b * 2 * A + A + j] = c * wq * g_s1 * sig;
+    dp[(long)b * 2 * A + j] = (mr >= -9.f && mr <= 9.f) ? c * wp * g_m2 : 0.f;
+    dp[(long)b * 2 * A + A + j] = (lr >= -5.f && lr <= 2.f) ? c * wp * g_s2 * sp : 0.f;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float kl = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)B;
+    out[0] = kl; out[1] = kl * beta;
+  }
+}
+extern "C" int tacorl_gauss_kl_balanced(const float* head_q, const float* head_p, float* d_head_q, float* d_head_p,
+                                        int B, int A, float kl_alpha, float kl_beta, float min_std, int balanced,
+                                        float grad_scale, float* out2, tacorl_stream_t stream) {
+  hipLaunchKernelGGL(gauss_kl_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, head_q, head_p, d_head_q, d_head_p, B,
+                     A, kl_alpha, kl_beta, min_std, balanced, grad_scale, out2);
+  return LAUNCH_OK();
+}
+
+// rsample backward: plan = tanh(mean + eps*std), std = softplus(var_raw)+min_std:
+// d_head_q[mean] += dplan*(1-a^2);  d_head_q[var_raw] += dplan*(1-a^2)*eps*sigmoid(var_raw)
+__global__ void pr_sample_bwd_kernel(const float* __restrict__ head, const float* __restrict__ eps,
+                                     const float* __restrict__ d_plan, float* __restrict__ d_head, int B, int A,
+                                     float min_std) {
+  const long total = (long)B * A;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / A), j = (int)(i - (long)b * A);
+    const float mu = head[(long)b * 2 * A + j], vr = head[(long)b * 2 * A + A + j];
+    const float sd = (vr > 20.f ? vr : log1pf(expf(vr))) + min_std;
+    const float a = tanhf(mu + eps[i] * sd), g = d_plan[i] * (1.f - a * a);
+    const float sig = vr > 20.f ? 1.f : 1.f / (1.f + expf(-vr));
+    d_head[(long)b * 2 * A + j] += g;
+    d_head[(long)b * 2 * A + A + j] += g * eps[i] * sig;
+  }
+}
+extern "C" int tacorl_pr_sample_bwd(const float* head, const float* eps, const float* d_plan, float* d_head, int B,
+                                    int A, float min_std, tacorl_stream_t stream) {
+  const long total = (long)B * A;
+  if (total <= 0) return TACORL_OK;
+  hipLaunchKernelGGL(pr_sample_bwd_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, head,
+                     eps, d_plan, d_head, B, A, min_std);
   return LAUNCH_OK();
 }

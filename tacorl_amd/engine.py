@@ -114,6 +114,7 @@ class ACEngine:
         mk = lambda: NetBlock(cams, goal_cams, q_dims, silu_q, qn, device, hidden=hidden)  # noqa: E731
         self.q1, self.q2, self.tq1, self.tq2 = mk(), mk(), mk(), mk()
         self.log_alpha, self.log_alpha_prime = Scalar(device), Scalar(device)
+        self.extra_enc, self._wpk = [], {}
         self.B = None
         if B:
             self.ensure_batch(B)
@@ -209,17 +210,65 @@ class ACEngine:
         H, W = self.hw[cam]
         return self.X3[cam].data_ptr() + first_row * H * W * 3 * self.X3[cam].element_size()
 
+    # Encoder problems that need saved activations (a backward follows) go through the per-layer path;
+    # the no-grad ones (next-obs actor pass, both targets, and any externally registered problem such as
+    # TACORL's frozen B*T-frame encoder) go through the fused single-launch kernel when it applies
+    # (bf16 images + bf16 MFMA + image small enough for LDS).
+    GRAD_PROBS = ("a_og", "q1", "q2")
+
+    def _fused_ok(self, c):
+        if self.compute != BF16 or self.img_dtype != torch.bfloat16:
+            return False
+        return bool(ops.L.lib().tacorl_encoder_fused_supported(*self.hw[c]))
+
+    def _packed(self, net, c):
+        key = (id(net), c)
+        if key not in self._wpk:
+            self._wpk[key] = torch.empty(ops.L.lib().tacorl_encoder_fused_wpk_bytes(), dtype=torch.uint8, device=self.dev)
+        return self._wpk[key]
+
+    def _nograd_problems(self, c):
+        """(image pointer, net, out tensor, act tensor, n_img) of every no-grad encoder problem of camera c."""
+        pr = [(self._img_ptr(c, r0), net, self.enc_out[(k, c)], self.enc_act[(k, c)], n)
+              for k, net, r0, n in self.enc_probs if k not in self.GRAD_PROBS]
+        pr += [(x["img"], x["net"], x["out"], x["act"], x["n"]) for x in self.extra_enc if x["cam"] == c]
+        return pr
+
+    def encode_fused_only(self):
+        """Just the fused no-grad launch (bench roofline probe).  Returns images per launch (first cam)."""
+        n_total = 0
+        for c in self.cams:
+            if not self._fused_ok(c):
+                continue
+            H, W = self.hw[c]
+            pr = self._nograd_problems(c)
+            call("tacorl_encoder_fwd_fused", len(pr), ops.ptr_array([x[0] for x in pr]),
+                 ops.ptr_array([self._packed(x[1], c) for x in pr]), ops.ptr_array([x[1].enc(c) for x in pr]),
+                 ops.ptr_array([x[2] for x in pr]), ops.int_array([x[4] for x in pr]), H, W, ops.stream())
+            n_total += sum(x[4] for x in pr)
+        return n_total
+
     def _encode_all(self):
+        xd = BF16 if self.img_dtype == torch.bfloat16 else F32
         for c in self.cams:
             H, W = self.hw[c]
-            imgs = [self._img_ptr(c, r0) for _, _, r0, _ in self.enc_probs]
-            params = [net.enc(c) for _, net, _, _ in self.enc_probs]
-            outs = [self.enc_out[(k, c)] for k, _, _, _ in self.enc_probs]
-            acts = [self.enc_act[(k, c)] for k, _, _, _ in self.enc_probs]
-            nimg = [nn_ for _, _, _, nn_ in self.enc_probs]
-            call("tacorl_encoder_fwd", len(imgs), ops.ptr_array(imgs), ops.ptr_array(params), ops.ptr_array(outs),
-                 ops.ptr_array(acts), ops.int_array(nimg), H, W, BF16 if self.img_dtype == torch.bfloat16 else F32,
-                 self.compute, ops.stream())
+            fused = self._fused_ok(c)
+            gen = [(self._img_ptr(c, r0), net, self.enc_out[(k, c)], self.enc_act[(k, c)], n)
+                   for k, net, r0, n in self.enc_probs if (k in self.GRAD_PROBS or not fused)]
+            if not fused:
+                gen += [(x["img"], x["net"], x["out"], x["act"], x["n"]) for x in self.extra_enc if x["cam"] == c]
+            call("tacorl_encoder_fwd", len(gen), ops.ptr_array([x[0] for x in gen]),
+                 ops.ptr_array([x[1].enc(c) for x in gen]), ops.ptr_array([x[2] for x in gen]),
+                 ops.ptr_array([x[3] for x in gen]), ops.int_array([x[4] for x in gen]), H, W, xd, self.compute,
+                 ops.stream())
+            if fused:
+                pr = self._nograd_problems(c)
+                nets = {id(x[1]): x[1] for x in pr}
+                call("tacorl_encoder_pack_weights", len(nets), ops.ptr_array([n_.enc(c) for n_ in nets.values()]),
+                     ops.ptr_array([self._packed(n_, c) for n_ in nets.values()]), ops.stream())
+                call("tacorl_encoder_fwd_fused", len(pr), ops.ptr_array([x[0] for x in pr]),
+                     ops.ptr_array([self._packed(x[1], c) for x in pr]), ops.ptr_array([x[1].enc(c) for x in pr]),
+                     ops.ptr_array([x[2] for x in pr]), ops.int_array([x[4] for x in pr]), H, W, ops.stream())
 
     def _assemble_states(self):
         B = self.B
@@ -248,12 +297,14 @@ class ACEngine:
     def _head(self, k):
         return self.pact[k][self.p_yoff: self.p_yoff + self.B * self.HD]
 
-    def update(self, bc_phase, optimize=True):
+    def update(self, bc_phase, optimize=True, encoded=False):
         """One compute_update.  Inputs must have been staged with load_images / load_transition /
-        set_noise.  Returns nothing; metrics are in self.logs (read with metrics())."""
+        set_noise.  Returns nothing; metrics are in self.logs (read with metrics()).
+        encoded=True: the caller already ran _encode_all() for this batch."""
         B, n, A, Ac, hp, nz = self.B, self.n, self.A, self.Ac, self.hp, self.noise
         gs = 1.0 / self.world
-        self._encode_all()
+        if not encoded:
+            self._encode_all()
         self._assemble_states()
         self._policy_fwd()
         head_cur, head_next = self._head("a"), self._head("a_nx")

@@ -57,6 +57,9 @@ class CQL_Offline(LoggerMixin, nn.Module):
         self.compute = compute_flag(compute_dtype)
         self.img_dtype = torch.bfloat16 if compute_flag(image_dtype) == _lib.BF16 else torch.float32
         self.world_size = world_size
+        self.log_every_n_steps = 1  # PL Trainer(log_every_n_steps=...) semantics: metrics are read back (one D2H
+        self._step_count = 0        # sync) only on these steps
+        self._graph, self._graph_key, self._use_graph = None, None, False
         self._hp = dict(discount=discount, tau=tau, actor_lr=actor_lr, critic_lr=critic_lr,
                         deterministic_backup=deterministic_backup, reward_scale=reward_scale,
                         clip_grad_val=float(clip_grad_val) if clip_grad else 0.0,
@@ -155,13 +158,38 @@ class CQL_Offline(LoggerMixin, nn.Module):
         e.load_transition(action.to(self.dev), reward.to(self.dev), done.to(self.dev))
         e.set_noise(noise)
 
+    def enable_graph(self, on=True):
+        """Replay the device side of the step from a captured hipGraph (single-GPU only: the RCCL
+        all-reduces of the multi-GPU path stay eager)."""
+        self._use_graph = bool(on) and self.world_size == 1
+        self._graph = None
+
+    def _run_device(self, key, fn):
+        """Run `fn` (kernel launches only, fixed buffers) eagerly, or capture/replay it as a hipGraph."""
+        if not self._use_graph:
+            return fn()
+        if self._graph is None or self._graph_key != key:
+            fn()  # warm-up: sizes every workspace, so the capture allocates nothing
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self._graph, self._graph_key = g, key
+            return
+        self._graph.replay()
+
     def compute_update(self, batch, optimize: bool = True, log_type: str = "train", noise=None):
         obs, action, nxt, reward, done = batch
         self._stage(obs["observation"], obs["goal"], nxt["observation"], action, reward, done, noise)
-        self.engine.update(bc_phase=self.current_epoch < self.bc_epochs, optimize=optimize)
+        bc = self.current_epoch < self.bc_epochs
+        self._run_device(("cql", self.engine.B, bc, optimize),
+                         lambda: self.engine.update(bc_phase=bc, optimize=optimize))
         self._publish_logs(log_type)
 
     def _publish_logs(self, log_type, extra=()):
+        self._step_count += 1
+        if self.log_every_n_steps > 1 and self._step_count % self.log_every_n_steps:
+            return
         m = self.engine.metrics()
         skip = {"action_loss"} | (set() if self.with_lagrange else {"alpha_prime", "alpha_prime_loss"})
         for k, v in m.items():

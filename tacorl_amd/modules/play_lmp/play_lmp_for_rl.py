@@ -120,3 +120,138 @@ def load_play_lmp(play_lmp_dir, epoch=-1, overwrite_cfg=None, device=None, compu
     sd = torch.load(ckpt, map_location="cpu", weights_only=False)
     mod.load_state_dict(sd.get("state_dict", sd))
     return mod
+
+
+# --------------------------------------------------------------------------- training step
+def _playlmp_ensure(self, B, T, hw):
+    key = (B, T, tuple(sorted(hw.items())))
+    if getattr(self, "_shape", None) == key:
+        return
+    from ... import ops
+
+    dev, cams, net = self.dev, self.plan_proposal_obs_modalities, self.net
+    f = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+    R, Ec = B * T, 32 * len(cams)
+    self.frames = {c: torch.zeros(R, *hw[c], 3, device=dev, dtype=self.img_dtype) for c in cams}
+    self.f_out = {c: f(R, 32) for c in cams}
+    self.f_act = {c: f(ops.encoder_act_layout(R, *hw[c])[1]) for c in cams}
+    self.f_dout = {c: f(R, 32) for c in cams}
+    self.emb, self.d_emb = f(R, Ec), f(R, Ec)
+    self.gin, self.dgin = f(B, Ec), f(B, Ec)
+    self.gact = f(ops.mlp_act_layout(B, net.genc_dims, net.genc_acts)[2])
+    self.g_yoff = ops.mlp_act_layout(B, net.genc_dims, net.genc_acts)[1][-1]
+    self.S, self.dS = f(B, 2 * Ec), f(B, 2 * Ec)
+    self.pact = f(ops.mlp_act_layout(B, net.head_dims, net.head_acts)[2])
+    self.p_yoff = ops.mlp_act_layout(B, net.head_dims, net.head_acts)[1][-1]
+    A = self.pr.A
+    self.d_head_pp, self.d_head_pr = f(B, 2 * A), f(B, 2 * A)
+    self.plan, self.rplan, self.d_plan = f(B, A), f(B, A), f(B, A)
+    self.noise = dict(eps_plan=f(B, A), u_plan=f(B, A))
+    self.logs = f(16)  # 0 kl, 1 kl_scaled, 2 action_loss, 3 gripper_acc, 4 rand action_loss, 5 rand gripper_acc
+    self._shape = key
+
+
+def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw=True):
+    """PlayLMP.training_step + the single Adam (reference play_lmp_for_rl.py:200-257,307-317,362-368)."""
+    from ... import ops
+    from ..._lib import BF16, F32, call, ptr
+
+    states = batch["states"]
+    cams, net, pr, ad = self.plan_proposal_obs_modalities, self.net, self.pr, self.ad
+    B, T = next(iter(states.values())).shape[:2]
+    hw = {c: (tuple(v.shape[-2:]) if nchw else tuple(v.shape[-3:-1])) for c, v in states.items()}
+    _playlmp_ensure(self, B, T, hw)
+    R, Ec, A, cd = B * T, 32 * len(cams), pr.A, self.compute
+    xd = BF16 if self.img_dtype == torch.bfloat16 else F32
+    gs = 1.0 / getattr(self, "world_size", 1)
+    for k, buf in self.noise.items():
+        if noise is not None:
+            buf.copy_(noise[k].reshape(buf.shape))
+        elif k.startswith("eps"):
+            buf.normal_()
+        else:
+            buf.uniform_()
+    # ---- forward
+    for j, c in enumerate(cams):
+        H, W = hw[c]
+        v = states[c].to(self.dev)
+        call("tacorl_pack_images", ptr(v), 3 * H * W, int(nchw), ptr(self.frames[c]), xd, R, 3, H, W, ops.stream())
+        call("tacorl_encoder_fwd", 1, ops.ptr_array([self.frames[c]]), ops.ptr_array([net.enc(c)]),
+             ops.ptr_array([self.f_out[c]]), ops.ptr_array([self.f_act[c]]), ops.int_array([R]), H, W, xd, cd, ops.stream())
+        ops.copy_cols(self.f_out[c], 0, 32, self.emb, 32 * j, Ec, R, 32)
+    ops.copy_cols(self.emb, (T - 1) * Ec, T * Ec, self.gin, 0, Ec, B, Ec)  # pp_goal input = emb[:, -1]
+    ops.mlp_fwd([self.gin], Ec, [net.genc()], [self.gact], [B], net.genc_dims, net.genc_acts, cd)
+    ops.copy_cols(self.emb, 0, T * Ec, self.S, 0, 2 * Ec, B, Ec)  # pp_state = emb[:, 0]
+    ops.copy_cols(self.gact, self.g_yoff, Ec, self.S, Ec, 2 * Ec, B, Ec)
+    ops.mlp_fwd([self.S], 2 * Ec, [net.head()], [self.pact], [B], net.head_dims, net.head_acts, cd)
+    head_pp = self.pact[self.p_yoff: self.p_yoff + B * 2 * A]
+    head_pr = pr.forward(self.emb, Ec, B, T, cd)
+    call("tacorl_gauss_kl_balanced", ptr(head_pr), ptr(head_pp), ptr(self.d_head_pr), ptr(self.d_head_pp), B, A,
+         float(self.kl_alpha), float(self.kl_beta), float(pr.min_std), int(self.kl_balancing), gs, ptr(self.logs),
+         ops.stream())
+    acts = batch["actions"].to(self.dev).float().contiguous()
+    # logging-only pass with a uniform random plan (reference :243-252) - first, so the real pass's
+    # activations are the ones the backward sees
+    call("tacorl_uniform_actions", ptr(self.noise["u_plan"]), ptr(self.rplan), A, B, A, 0, ops.stream())
+    ad.forward(self.rplan, self.emb, Ec, B, T, T - 1, cd)
+    ad.loss(acts, ops._at(self.logs, 4), B, T, T - 1, want_grad=False)
+    call("tacorl_pr_sample", ptr(head_pr), ptr(self.noise["eps_plan"]), ptr(self.plan), None, None, B, A,
+         float(pr.min_std), ops.stream())
+    ad.forward(self.plan, self.emb, Ec, B, T, T - 1, cd)
+    ad.loss(acts, ops._at(self.logs, 2), B, T, T - 1, want_grad=True, grad_scale=gs)
+    if self.add_random_plan_loss:
+        raise NotImplementedError("add_random_plan_loss=True is not used by any in-scope config")
+    # ---- backward
+    ad.backward(B, T - 1, cd, need_input_grad=True)
+    self.d_emb.zero_()
+    call("tacorl_ad_input_bwd", ptr(ad.dx_seq), ptr(self.d_plan), ptr(self.d_emb), Ec, B, T, T - 1, ad.P, ad.E, 1,
+         ops.stream())
+    call("tacorl_pr_sample_bwd", ptr(head_pr), ptr(self.noise["eps_plan"]), ptr(self.d_plan), ptr(self.d_head_pr), B, A,
+         float(pr.min_std), ops.stream())
+    dx = pr.backward(self.d_head_pr, B, T, cd)
+    ops.copy_cols(dx, 0, pr.D, self.d_emb, 0, Ec, R, pr.D_in, accumulate=True)
+    ops.mlp_bwd([self.S], 2 * Ec, [net.head()], [self.pact], [self.d_head_pp], 2 * A, [net.head(net.grad)], [self.dS],
+                2 * Ec, [B], net.head_dims, net.head_acts, cd)
+    ops.copy_cols(self.dS, 0, 2 * Ec, self.d_emb, 0, T * Ec, B, Ec, accumulate=True)
+    ops.mlp_bwd([self.gin], Ec, [net.genc()], [self.gact], [ops._at(self.dS, Ec)], 2 * Ec, [net.genc(net.grad)],
+                [self.dgin], Ec, [B], net.genc_dims, net.genc_acts, cd)
+    ops.copy_cols(self.dgin, 0, Ec, self.d_emb, (T - 1) * Ec, T * Ec, B, Ec, accumulate=True)
+    for j, c in enumerate(cams):
+        H, W = hw[c]
+        ops.copy_cols(self.d_emb, 32 * j, Ec, self.f_dout[c], 0, 32, R, 32)
+        ops.encoder_bwd([self.frames[c]], [net.enc(c)], [self.f_act[c]], [self.f_dout[c]], [net.enc(c, net.grad)], H, W, cd)
+    if optimize:
+        for blk in (net, pr.blk, ad.blk):
+            if getattr(self, "world_size", 1) > 1:
+                import torch.distributed as dist
+
+                dist.all_reduce(blk.grad)
+            ops.adam_step(blk.param, blk.grad, blk.m, blk.v, self.lr, 0.0, blk.step)
+    lg = self.logs.cpu().tolist()
+    names = ["kl_loss", "kl_loss_scaled", "action_loss", "gripper_accuracy", "random_plan_action_loss",
+             "random_plan_gripper_accuracy"]
+    for k, v in zip(names, lg):
+        self.log(f"{log_type}/{k}", v, on_step=True, on_epoch=True, sync_dist=True)
+    total = lg[1] + lg[2]
+    self.log(f"{log_type}/total_loss", total, on_step=True, on_epoch=True, sync_dist=True)
+    return total
+
+
+def _named_gradients(self):
+    out = {}
+    for k, v in self.net.grad_views.items():
+        if k.startswith("encoder."):
+            out["perceptual_encoder." + k[len("encoder."):]] = v
+        elif k.startswith("actor.policy."):
+            out["plan_proposal.policy." + k[len("actor.policy."):]] = v
+        else:
+            out[k] = v
+    out.update({f"plan_recognition.{k}": v for k, v in self.pr.blk.grad_views.items()})
+    out.update({f"action_decoder.{k}": v for k, v in self.ad.blk.grad_views.items()})
+    return out
+
+
+PlayLMP.training_step = lambda self, batch, batch_idx=0, noise=None: _playlmp_step(self, batch, noise, True, "train")
+PlayLMP.validation_step = lambda self, batch, batch_idx=0, noise=None: _playlmp_step(self, batch, noise, False, "validation")
+PlayLMP.named_gradients = _named_gradients
+PlayLMP.configure_optimizers = lambda self: [self.net, self.pr.blk, self.ad.blk]

@@ -89,15 +89,18 @@ class TACORL(CQL_Offline):
         self.eps_pr = torch.zeros(B, self.action_dim, device=dev)
         self.plan = torch.zeros(B, self.action_dim, device=dev)
         self.reward = torch.zeros(B, device=dev)
+        # the frozen LMP encoder over the B*T window frames rides in the engine's encoder launches
+        self.engine.extra_enc = [dict(cam=c, img=self.frames[c], net=self.lmp_net, out=self.f_out[c],
+                                      act=self.f_act[c], n=B * T) for c in self.all_modalities]
         self._T = (B, T, tuple(sorted(hw.items())))
 
-    def get_pr_latent_plan(self, batch, noise=None, nchw=True):
-        """reference tacorl.py:235-252 (no_grad / eval).  Leaves the plan in self.plan and the per-frame
-        embeddings in self.f_out; returns the plan tensor."""
+    def _stage_frames(self, batch, noise, nchw=True):
+        """Eager part of the step: pack the window frames (reference NCHW fp32 -> NHWC image dtype) into
+        fixed buffers, copy the small tensors, draw / copy the noise."""
         states = batch["states"]
-        any_c = next(iter(states.values()))
-        B, T = any_c.shape[:2]
+        B, T = next(iter(states.values())).shape[:2]
         hw = {c: (tuple(v.shape[-2:]) if nchw else tuple(v.shape[-3:-1])) for c, v in states.items()}
+        self.engine.ensure_batch(B, {c: hw[c] for c in self.engine.cams})
         self._ensure_seq(B, T, hw)
         xd = BF16 if self.img_dtype == torch.bfloat16 else F32
         for c in self.all_modalities:
@@ -106,16 +109,49 @@ class TACORL(CQL_Offline):
             assert v.is_cuda and v.is_contiguous() and v.dtype == torch.float32
             call("tacorl_pack_images", ptr(v), 3 * H * W, int(nchw), ptr(self.frames[c]), xd, B * T, 3, H, W,
                  ops.stream())
+        if noise is not None:
+            self.eps_pr.copy_(noise["eps_pr"])
+        else:
+            self.eps_pr.normal_()
+        if self.ad is not None:
+            if getattr(self, "acts", None) is None or self.acts.shape[:2] != (B, T):
+                self.acts = torch.zeros(B, T, 7, device=self.dev)
+            self.acts.copy_(batch["actions"])
+        self.reward.copy_(batch["disp"] == 1)
+        # get_rl_batch (tacorl.py:142-179) as strided views: s = states[:,0], s' = states[:,-1]
+        e = self.engine
+        for c in e.cams:
+            e.load_images(c, states[c][:, 0], batch["goal"][c], states[c][:, -1], nchw=nchw)
+        e.set_noise(noise)
+        return B, T, hw
+
+    def _device_step(self, B, T, hw, optimize):
+        """Graph-capturable part: all encoders (frozen LMP + actor/critics/targets) -> plan recognition ->
+        plan -> AD loss -> CQL update."""
+        self.engine._encode_all()
+        for j, c in enumerate(self.plan_recognition_modalities):
+            ops.copy_cols(self.f_out[c], 0, 32, self.pr_in, 32 * j, self.pr_in.shape[1], B * T, 32)
+        head = self.pr.forward(self.pr_in, self.pr_in.shape[1], B, T, self.compute)
+        call("tacorl_pr_sample", ptr(head), ptr(self.eps_pr), ptr(self.plan), None, None, B, self.action_dim,
+             float(self.pr.min_std), ops.stream())
+        if self.ad is not None:
+            # compute_action_decoder_update (tacorl.py:206-233): loss always logged, stepped if fine-tuning
+            self.ad.loss_step(self, self.acts, self.plan, B, T, optimize and self.finetune_action_decoder)
+        self.engine.load_transition(self.plan, self.reward, self.reward)
+        self.engine.update(bc_phase=self.current_epoch < self.bc_epochs, optimize=optimize, encoded=True)
+
+    def get_pr_latent_plan(self, batch, noise=None, nchw=True):
+        """reference tacorl.py:235-252 (no_grad / eval): returns the sampled latent plan (device tensor)."""
+        B, T, hw = self._stage_frames(batch, noise, nchw)
+        xd = BF16 if self.img_dtype == torch.bfloat16 else F32
+        for c in self.all_modalities:
+            H, W = hw[c]
             call("tacorl_encoder_fwd", 1, ops.ptr_array([self.frames[c]]), ops.ptr_array([self.lmp_net.enc(c)]),
                  ops.ptr_array([self.f_out[c]]), ops.ptr_array([self.f_act[c]]), ops.int_array([B * T]), H, W, xd,
                  self.compute, ops.stream())
         for j, c in enumerate(self.plan_recognition_modalities):
             ops.copy_cols(self.f_out[c], 0, 32, self.pr_in, 32 * j, self.pr_in.shape[1], B * T, 32)
         head = self.pr.forward(self.pr_in, self.pr_in.shape[1], B, T, self.compute)
-        if noise is not None:
-            self.eps_pr.copy_(noise["eps_pr"])
-        else:
-            self.eps_pr.normal_()
         call("tacorl_pr_sample", ptr(head), ptr(self.eps_pr), ptr(self.plan), None, None, B, self.action_dim,
              float(self.pr.min_std), ops.stream())
         return self.plan
@@ -127,23 +163,10 @@ class TACORL(CQL_Offline):
         self._step(batch, noise, optimize=False, log_type="validation")
 
     def _step(self, batch, noise, optimize, log_type, nchw=True):
-        B, T = next(iter(batch["states"].values())).shape[:2]
-        hw = {c: (tuple(v.shape[-2:]) if nchw else tuple(v.shape[-3:-1])) for c, v in batch["states"].items()}
-        self.engine.ensure_batch(B, {c: hw[c] for c in self.engine.cams})
-        plan = self.get_pr_latent_plan(batch, noise, nchw=nchw)
-        extra = ()
-        if self.ad is not None:
-            # compute_action_decoder_update (tacorl.py:206-233): loss always logged, stepped if fine-tuning
-            self.ad.loss_step(self, batch["actions"], plan, B, T, optimize and self.finetune_action_decoder)
-            extra = ("action_loss",)
-        # get_rl_batch (tacorl.py:142-179) as strided views: s = states[:,0], s' = states[:,-1]
-        states = batch["states"]
-        obs = {c: states[c][:, 0] for c in self.engine.cams}
-        nxt = {c: states[c][:, -1] for c in self.engine.cams}
-        r = (batch["disp"].to(self.dev) == 1).float()
-        self._stage(obs, batch["goal"], nxt, plan, r, r, noise, nchw=nchw)
-        self.engine.update(bc_phase=self.current_epoch < self.bc_epochs, optimize=optimize)
-        self._publish_logs(log_type, extra=extra)
+        B, T, hw = self._stage_frames(batch, noise, nchw)
+        key = ("tacorl", B, T, tuple(sorted(hw.items())), self.current_epoch < self.bc_epochs, optimize)
+        self._run_device(key, lambda: self._device_step(B, T, hw, optimize))
+        self._publish_logs(log_type, extra=("action_loss",) if self.ad is not None else ())
 
     def configure_optimizers(self):
         o = super().configure_optimizers()

@@ -64,6 +64,8 @@ class ActionDecoderLogistic:
         self.heads, self.d_heads = f(R, self.NH), f(R, self.NH)
         self.ws = torch.empty(max(256, ops.L.lib().tacorl_logistic_mixture_ws_bytes(B, Tm, self.Da)), dtype=torch.uint8,
                               device=self.dev)
+        nb = ops.L.lib().tacorl_linear_add_fwd_ws_bytes(1, ops.int_array([B]), H, H)
+        self.rnn_ws = torch.empty(max(256, nb), dtype=torch.uint8, device=self.dev)
         self._shape = (B, Tm)
 
     def _lin(self, x, ldx, w, b, y, M, K, N, act, compute):
@@ -85,7 +87,7 @@ class ActionDecoderLogistic:
                 call("tacorl_linear_add_fwd", 1, ops.ptr_array([prev]), H, ops.ptr_array([blk.p(f"rnn.weight_hh_l{l}")]),
                      ops.ptr_array([blk.p(f"rnn.bias_hh_l{l}")]), ops.ptr_array([ops._at(self.xin[l], t * B * H)]), H,
                      ops.ptr_array([ops._at(self.h[l], t * B * H)]), H, ops.int_array([B]), H, H, ACT_RELU, compute,
-                     ops.stream())
+                     ptr(self.rnn_ws), self.rnn_ws.numel(), ops.stream())
             x, K = self.h[l], H
         self._lin(x, H, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.heads, R, H, self.NH, ACT_NONE, compute)
 
@@ -101,7 +103,7 @@ class ActionDecoderLogistic:
         actions[:, :-1]; logged always, Adam step when fine-tuning."""
         from .._lib import LOG_SLOTS
 
-        acts = actions.to(self.dev).float().contiguous()
+        acts = actions
         cams = module.action_decoder_modalities
         if cams == module.plan_recognition_modalities:
             emb, ld = module.pr_in, module.pr_in.shape[1]
@@ -120,5 +122,52 @@ class ActionDecoderLogistic:
             ops.adam_step(self.blk.param, self.blk.grad, self.blk.m, self.blk.v, module.action_decoder_lr, 0.0,
                           self.blk.step)
 
+    # ------------------------------------------------------------------ backward (BPTT)
+    def _wgrad(self, x, ldx, dz, ld_dz, M, K, O, dw, db, compute):
+        nb = ops.L.lib().tacorl_linear_wgrad_ws_bytes(1, ops.int_array([M]), K, O)
+        ws = ops.workspace(nb, self.dev, "lin_wgrad")
+        call("tacorl_linear_wgrad", 1, ops.ptr_array([x]), ldx, ops.ptr_array([dz]), ld_dz, ops.int_array([M]), K, O,
+             ops.ptr_array([dw]), ops.ptr_array([db]) if db is not None else None, 0, compute, ptr(ws), ws.numel(),
+             ops.stream())
+
+    def _dgrad(self, dz, ld_dz, w, out, ld_out, M, O, I, compute, src=None, ld_src=0, act=ACT_NONE, addend=None,
+               ld_add=0):
+        call("tacorl_linear_dgrad", 1, ops.ptr_array([dz]), ld_dz, ops.ptr_array([w]), ops.ptr_array([out]), ld_out,
+             ops.ptr_array([src]) if src is not None else None, ld_src, act,
+             ops.ptr_array([addend]) if addend is not None else None, ld_add, ops.int_array([M]), O, I, compute,
+             ops.stream())
+
     def backward(self, B, Tm, compute, need_input_grad=False):
-        raise NotImplementedError("action-decoder backward (BPTT) lands with the PlayLMP step")
+        """Gradients of the loss (dL/dheads in self.d_heads) into self.blk.grad; optionally
+        d(x_seq) into self.dx_seq.  ReLU-RNN BPTT: dz_{t-1} = (dz_t W_hh + dH_{t-1}) * [h_{t-1} > 0]."""
+        blk, H, R, L = self.blk, self.hidden, B * Tm, self.L
+        if getattr(self, "_bshape", None) != (B, Tm):
+            f = lambda *s: torch.zeros(*s, device=self.dev)  # noqa: E731
+            self.dH = f(R, H)
+            self.DZ = [f(R, H) for _ in range(L)]
+            self.dx_seq = f(R, self.P + self.E)
+            self._bshape = (B, Tm)
+        at = ops._at
+        self._wgrad(self.h[L - 1], H, self.d_heads, self.NH, R, H, self.NH, blk.g("mean_fc.weight"),
+                    blk.g("mean_fc.bias"), compute)
+        self._dgrad(self.d_heads, self.NH, blk.p("mean_fc.weight"), self.dH, H, R, self.NH, H, compute)
+        for l in reversed(range(L)):
+            h, DZ = self.h[l], self.DZ[l]
+            last = (Tm - 1) * B * H
+            call("tacorl_relu_mask_mul", at(self.dH, last), None, at(h, last), at(DZ, last), B * H, ops.stream())
+            for t in range(Tm - 1, 0, -1):
+                self._dgrad(at(DZ, t * B * H), H, blk.p(f"rnn.weight_hh_l{l}"), at(DZ, (t - 1) * B * H), H, B, H, H,
+                            compute, src=at(h, (t - 1) * B * H), ld_src=H, act=ACT_RELU,
+                            addend=at(self.dH, (t - 1) * B * H), ld_add=H)
+            if Tm > 1:
+                self._wgrad(h, H, at(DZ, B * H), H, (Tm - 1) * B, H, H, blk.g(f"rnn.weight_hh_l{l}"), None, compute)
+            else:
+                blk.grad_views[f"rnn.weight_hh_l{l}"].zero_()
+            xin, K = (self.x_seq, self.P + self.E) if l == 0 else (self.h[l - 1], H)
+            self._wgrad(xin, K, DZ, H, R, K, H, blk.g(f"rnn.weight_ih_l{l}"), blk.g(f"rnn.bias_ih_l{l}"), compute)
+            call("tacorl_copy_cols", blk.g(f"rnn.bias_ih_l{l}"), H, blk.g(f"rnn.bias_hh_l{l}"), H, 1, H, 0, 0,
+                 ops.stream())
+            if l > 0:
+                self._dgrad(DZ, H, blk.p(f"rnn.weight_ih_l{l}"), self.dH, H, R, H, H, compute)
+            elif need_input_grad:
+                self._dgrad(DZ, H, blk.p("rnn.weight_ih_l0"), self.dx_seq, K, R, H, K, compute)

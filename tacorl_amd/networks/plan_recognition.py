@@ -90,3 +90,65 @@ class PlanRecognition:
         self._lin(self.fc_out, self.FC, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.head, B, self.FC,
                   2 * self.A, ACT_NONE, compute)
         return self.head
+
+    # ------------------------------------------------------------------------ backward
+    def _wgrad(self, x, ldx, dz, ld_dz, M, K, O, dw, db, compute):
+        nb = ops.L.lib().tacorl_linear_wgrad_ws_bytes(1, ops.int_array([M]), K, O)
+        ws = ops.workspace(nb, self.dev, "lin_wgrad")
+        call("tacorl_linear_wgrad", 1, ops.ptr_array([x]), ldx, ops.ptr_array([dz]), ld_dz, ops.int_array([M]), K, O,
+             ops.ptr_array([dw]), ops.ptr_array([db]), 0, compute, ptr(ws), ws.numel(), ops.stream())
+
+    def _dgrad(self, dz, ld_dz, w, out, ld_out, M, O, I, compute, src=None, ld_src=0, act=ACT_NONE, addend=None,
+               ld_add=0):
+        call("tacorl_linear_dgrad", 1, ops.ptr_array([dz]), ld_dz, ops.ptr_array([w]), ops.ptr_array([out]), ld_out,
+             ops.ptr_array([src]) if src is not None else None, ld_src, act,
+             ops.ptr_array([addend]) if addend is not None else None, ld_add, ops.int_array([M]), O, I, compute,
+             ops.stream())
+
+    def _ln_bwd(self, dy, x, res, w, stats, dv, dw, db, R, D):
+        nb = ops.L.lib().tacorl_add_layernorm_bwd_ws_bytes(R, D)
+        ws = ops.workspace(nb, self.dev, "ln_bwd")
+        call("tacorl_add_layernorm_bwd", ptr(dy), ptr(x), ptr(res), w, ptr(stats), ptr(dv), dw, db, R, D, 0, ptr(ws),
+             ws.numel(), ops.stream())
+
+    def backward(self, d_head, B, T, compute):
+        """d_head: (B, 2A) gradient w.r.t. [mean | var_raw].  Fills self.blk.grad and returns the
+        (B*T, D) gradient w.r.t. the (padded) input embeddings."""
+        blk, D, R, FF, FC, A2 = self.blk, self.D, B * T, self.FF, self.FC, 2 * self.A
+        if getattr(self, "_bshape", None) != (B, T):
+            f = lambda *s: torch.zeros(*s, device=self.dev)  # noqa: E731
+            self.d_fc, self.d_pool = f(B, FC), f(B, D)
+            self.dx, self.dv, self.d_ff1, self.d_x1, self.d_att, self.d_qkv = f(R, D), f(R, D), f(R, FF), f(R, D), f(R, D), f(R, 3 * D)
+            self.dv1 = f(R, D)
+            self._bshape = (B, T)
+        self._wgrad(self.fc_out, FC, d_head, A2, B, FC, A2, blk.g("mean_fc.weight"), blk.g("mean_fc.bias"), compute)
+        self._dgrad(d_head, A2, blk.p("mean_fc.weight"), self.d_fc, FC, B, A2, FC, compute)
+        self._wgrad(self.pooled, D, self.d_fc, FC, B, D, FC, blk.g("fc.weight"), blk.g("fc.bias"), compute)
+        self._dgrad(self.d_fc, FC, blk.p("fc.weight"), self.d_pool, D, B, FC, D, compute)
+        call("tacorl_bcast_over_t", ptr(self.d_pool), ptr(self.dx), B, T, D, 1.0 / T, 0, ops.stream())
+        for l in reversed(range(self.L)):
+            p = f"transformer_encoder.layers.{l}."
+            xin, x1 = self.x[2 * l], self.x[2 * l + 1]
+            self._ln_bwd(self.dx, x1, self.ff2[l], blk.p(p + "norm2.weight"), self.stats[2 * l + 1], self.dv,
+                         blk.g(p + "norm2.weight"), blk.g(p + "norm2.bias"), R, D)
+            self._wgrad(self.ff1[l], FF, self.dv, D, R, FF, D, blk.g(p + "linear2.weight"), blk.g(p + "linear2.bias"), compute)
+            self._dgrad(self.dv, D, blk.p(p + "linear2.weight"), self.d_ff1, FF, R, D, FF, compute, src=self.ff1[l],
+                        ld_src=FF, act=ACT_RELU)
+            self._wgrad(x1, D, self.d_ff1, FF, R, D, FF, blk.g(p + "linear1.weight"), blk.g(p + "linear1.bias"), compute)
+            self._dgrad(self.d_ff1, FF, blk.p(p + "linear1.weight"), self.d_x1, D, R, FF, D, compute, addend=self.dv,
+                        ld_add=D)
+            self._ln_bwd(self.d_x1, xin, self.proj[l], blk.p(p + "norm1.weight"), self.stats[2 * l], self.dv1,
+                         blk.g(p + "norm1.weight"), blk.g(p + "norm1.bias"), R, D)
+            self._wgrad(self.att[l], D, self.dv1, D, R, D, D, blk.g(p + "self_attn.out_proj.weight"),
+                        blk.g(p + "self_attn.out_proj.bias"), compute)
+            self._dgrad(self.dv1, D, blk.p(p + "self_attn.out_proj.weight"), self.d_att, D, R, D, D, compute)
+            call("tacorl_attention_bwd", ptr(self.qkv[l]), ptr(self.d_att), ptr(self.d_qkv), B, T, D, self.H, ops.stream())
+            self._wgrad(xin, D, self.d_qkv, 3 * D, R, D, 3 * D, blk.g(p + "self_attn.in_proj_weight"),
+                        blk.g(p + "self_attn.in_proj_bias"), compute)
+            self._dgrad(self.d_qkv, 3 * D, blk.p(p + "self_attn.in_proj_weight"), self.dx, D, R, 3 * D, D, compute,
+                        addend=self.dv1, ld_add=D)
+        # position embeddings: sum over the batch of rows with the same t
+        call("tacorl_reduce_rows_mod", ptr(self.dx), D, blk.g("position_embeddings.weight"), D, T, D, B, ops.stream())
+        if self.T_max > T:
+            blk.grad_views["position_embeddings.weight"][T:].zero_()
+        return self.dx
