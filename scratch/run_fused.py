@@ -1,0 +1,25 @@
+import sys, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tacorl_amd import _lib, blocks, ops
+dev = torch.device('cuda:0')
+H = W = 84
+n = [int(x) for x in (sys.argv[1:] or ["4096", "256", "512", "512"])]
+flats, imgs, outs, packed = [], [], [], []
+for k in n:
+    flat = torch.randn(blocks.encoder_size(), device=dev) * 0.05
+    flats.append(flat)
+    imgs.append((torch.rand(k, H, W, 3, device=dev) * 2 - 1).to(torch.bfloat16))
+    outs.append(torch.empty(k, 32, device=dev))
+    packed.append(torch.empty(_lib.lib().tacorl_encoder_fused_wpk_bytes(), dtype=torch.uint8, device=dev))
+ops.call("tacorl_encoder_pack_weights", len(n), ops.ptr_array(flats), ops.ptr_array(packed), ops.stream())
+def run():
+    ops.call("tacorl_encoder_fwd_fused", len(n), ops.ptr_array(imgs), ops.ptr_array(packed), ops.ptr_array(flats),
+             ops.ptr_array(outs), ops.int_array(n), H, W, ops.stream())
+for _ in range(3): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 20
+print(f"imgs {sum(n)} ms {ms:.4f} TF {sum(n)*13.918e6/ms/1e9:.1f}")

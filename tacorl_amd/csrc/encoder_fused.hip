@@ -62,6 +62,8 @@ __device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d) 
 
 // ------------------------------------------------------------------ weight packing
 // frag(j, s, l)[e] = W[16 j + (l & 15)][32 s + 8 (l >> 4) + e]   (W row-major [N][K], fp32 -> bf16)
+// conv1 uses a permuted K order so that the im2col LDS address of lane group g is base + g*rowbytes +
+// an immediate: k-step s, group g, element e  <->  ky = 4 (s / 3) + g, (kx, ci) run offset 8 (s % 3) + e.
 __global__ void ef_pack_kernel(const float* __restrict__ params, u32x4* __restrict__ out, long o_w1, long o_w2,
                                long o_w3, long o_f1, long o_f2) {
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;  // fragment id
@@ -73,6 +75,7 @@ __global__ void ef_pack_kernel(const float* __restrict__ params, u32x4* __restri
   else if (f < WP_F2 / 64) { int r = f - WP_F1 / 64; W = params + o_f1; K = 128; j = r / 4; s = r % 4; }
   else { int r = f - WP_F2 / 64; W = params + o_f2; K = 256; j = r / 8; s = r % 8; }
   const float* src = W + (long)(16 * j + (l & 15)) * K + 32 * s + 8 * (l >> 4);
+  if (f < WP_C2 / 64) src = W + (long)(16 * j + (l & 15)) * K + (4 * (s / 3) + (l >> 4)) * 24 + 8 * (s % 3);
   bf16x8 v;
 #pragma unroll
   for (int e = 0; e < 8; e++) v[e] = (__bf16)src[e];
@@ -106,17 +109,35 @@ extern "C" int tacorl_encoder_pack_weights(int nprob, const float* const* params
 #define SA_STRIDE 272    // bytes per image of soft-argmax features (128 bf16 + 16 pad)
 #define H1_STRIDE 528    // bytes per image of fc1 output (256 bf16 + 16 pad)
 
-__global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a) {
+template <int H_, int W_>
+struct EFGeom {
+  static constexpr int H = H_, W = W_;
+  static constexpr int OH1 = (H - 8) / 4 + 1, OW1 = (W - 8) / 4 + 1;
+  static constexpr int OH2 = (OH1 - 4) / 2 + 1, OW2 = (OW1 - 4) / 2 + 1;
+  static constexpr int OH3 = OH2 - 2, OW3 = OW2 - 2;
+  static constexpr int IMG_BYTES = H * W * 6, LDS_IMG = (IMG_BYTES + 15) & ~15;
+  static constexpr int NPX1 = OH1 * OW1, NPX2 = OH2 * OW2, NPX3 = OH3 * OW3;
+  static constexpr int ACT1_BYTES = (NPX1 * 80 + 15) & ~15, ACT2_BYTES = (NPX2 * 160 + 15) & ~15;
+  static constexpr int LDS_BYTES = 2 * LDS_IMG + ACT1_BYTES + ACT2_BYTES + EF_CHUNK * (272 + 528);
+  static constexpr bool OK = IMG_BYTES % 16 == 0 && IMG_BYTES <= EF_MAXCH * 256 * 16 && LDS_BYTES <= 160 * 1024 &&
+                             OH3 >= 1 && OW3 >= 1;
+};
+
+template <int H_, int W_>
+__global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
+  typedef EFGeom<H_, W_> G;
+  struct { int W, OW1, OW2, OW3, OH1, OH2, OH3, img_bytes, lds_img, nprob; const EFProblem* p; } a;
+  a.W = G::W; a.OW1 = G::OW1; a.OW2 = G::OW2; a.OW3 = G::OW3; a.OH1 = G::OH1; a.OH2 = G::OH2; a.OH3 = G::OH3;
+  a.img_bytes = G::IMG_BYTES; a.lds_img = G::LDS_IMG; a.nprob = a_.nprob; a.p = a_.p;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r16 = l & 15, g = l >> 4;
   // which problem / worker am I
   int pi = 0;
   for (int i = 1; i < a.nprob; i++)
-    if ((int)blockIdx.x >= a.p[i].first_block) pi = i;
-  const EFProblem P = a.p[pi];
+    if ((int)blockIdx.x >= a_.p[i].first_block) pi = i;
+  const EFProblem P = a_.p[pi];
   const int worker = blockIdx.x - P.first_block, nworkers = P.nblocks;
-  const int n_chunks = (P.n_img + EF_CHUNK - 1) / EF_CHUNK;
-  if (worker >= n_chunks) return;
+  if (worker >= P.n_img) return;
 
   unsigned char* act1 = lds + 2 * a.lds_img;
   const int npx1 = a.OH1 * a.OW1, npx2 = a.OH2 * a.OW2, npx3 = a.OH3 * a.OW3;
@@ -149,157 +170,198 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a) {
   }
   const float temp = P.params[po[6]];
 
-  // conv1 per-lane k offsets: chunk c = 4 s + g -> ky = c / 3, 8-element group (c % 3) inside the 24-run
-  int k1off[6];
-#pragma unroll
-  for (int s = 0; s < 6; s++) { const int c = 4 * s + g; k1off[s] = ((c / 3) * a.W * 3 + (c % 3) * 8) * 2; }
+  // conv1 k offsets (bytes): lane group g reads image row 4 (s / 3) + g, 8-element group s % 3 of the 24-run
+  const int k1g = g * a.W * 6;
 
-  // ---- image streaming: global -> registers (early) -> LDS (late)
+  // ---- image streaming: LDS-DMA (global_load_lds_dwordx4: no staging registers).  One wave-instruction
+  // moves 64 x 16 B = 1 KiB from a contiguous global span to a contiguous LDS span (wave-uniform LDS base).
   const int n16 = a.img_bytes >> 4;  // 16-byte chunks per image
-  u32x4 pf[EF_MAXCH];
-  auto issue_load = [&](long img_idx) {
-    const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(P.img) + img_idx * a.img_bytes);
+  auto dma_load = [&](long img_idx, int buf) {
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img) + img_idx * a.img_bytes;
+    unsigned char* dstb = lds + buf * a.lds_img;
 #pragma unroll
     for (int i = 0; i < EF_MAXCH; i++) {
-      const int c = tid + i * 256;
-      if (c < n16) pf[i] = src[c];
-    }
-  };
-  auto commit_load = [&](int buf) {
-    u32x4* dst = reinterpret_cast<u32x4*>(lds + buf * a.lds_img);
-#pragma unroll
-    for (int i = 0; i < EF_MAXCH; i++) {
-      const int c = tid + i * 256;
-      if (c < n16) dst[c] = pf[i];
+      const int c0 = i * 256 + w * 64;  // first chunk of this wave-instruction (wave-uniform)
+      if (c0 < n16) {
+        if (c0 + l < n16)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(src + (long)(c0 + l) * 16),
+              (__attribute__((address_space(3))) void*)(dstb + c0 * 16), 16, 0, 0);
+      }
     }
   };
 
-  // images this workgroup processes, in order: chunk = worker, worker+nworkers, ... ; 8 images each
-  int chunk = worker;
-  int slot = 0;  // image index within the chunk
-  long cur = (long)chunk * EF_CHUNK;
-  int buf = 0;
-  issue_load(cur);
-  commit_load(0);
+  // images this workgroup processes: worker, worker + nworkers, ... (image granularity: at most one image
+  // of imbalance); the FC tail runs after every EF_CHUNK processed images (slots) or at the end.
+  long cur = worker;
+  int it = 0, buf = 0;
+  dma_load(cur, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   while (true) {
-    // next image (for the prefetch)
-    int nslot = slot + 1, nchunk = chunk;
-    long nxt = cur + 1;
-    if (nslot == EF_CHUNK || nxt >= P.n_img) { nchunk = chunk + nworkers; nslot = 0; nxt = (long)nchunk * EF_CHUNK; }
-    const bool has_next = nchunk < n_chunks;
-    if (has_next) issue_load(nxt);
+    const int slot = it & (EF_CHUNK - 1);
+    const long nxt = cur + nworkers;
+    const bool has_next = nxt < P.n_img;
+    if (has_next) dma_load(nxt, buf ^ 1);  // that buffer was last read by the previous image's conv1
 
+    // Every conv phase is software-pipelined by hand: the LDS reads of the next half-tile are issued
+    // before the MFMA chain of the current one (one wave per SIMD: nothing else hides LDS latency).
     // ------------------------------------------------ conv1: 8x8 stride 4, 3 -> 32
     {
       const unsigned char* ib = lds + buf * a.lds_img;
-      const int ntile1 = (npx1 + 15) >> 4, half = (ntile1 + 1) >> 1;
-      const int t0 = mh1 * half, t1 = min(ntile1, t0 + half);
-      for (int mt = t0; mt < t1; mt++) {
-        const int pm = mt * 16 + r16, pc = min(pm, npx1 - 1);
+      constexpr int NT1 = (G::NPX1 + 15) >> 4, HALF1 = (NT1 + 1) >> 1;
+      const int t0 = mh1 * HALF1;
+      auto base1 = [&](int mt) {
+        const int pc = min(mt * 16 + r16, npx1 - 1);
         const int oy = pc / a.OW1, ox = pc - oy * a.OW1;
-        const unsigned char* base = ib + ((4 * oy * a.W + 4 * ox) * 3) * 2;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        u32x4 bfr[6];
+        return ib + ((4 * oy * a.W + 4 * ox) * 3) * 2 + k1g;
+      };
+      auto ld1 = [&](const unsigned char* base, u32x4 (&bf)[6]) {
 #pragma unroll
         for (int s = 0; s < 6; s++) {
-          const u32x2 lo = *reinterpret_cast<const u32x2*>(base + k1off[s]);
-          const u32x2 hi = *reinterpret_cast<const u32x2*>(base + k1off[s] + 8);
-          bfr[s] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          const int off = (s / 3) * 4 * G::W * 6 + (s % 3) * 16;  // compile-time immediate
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(base + off);
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(base + off + 8);
+          bf[s] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
+      };
+      auto tile1 = [&](int mt, u32x4 (&bf)[6]) {
+        f32x4 acc = {b1[0], b1[1], b1[2], b1[3]};
 #pragma unroll
-        for (int s = 0; s < 6; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc1[s], as_bf16x8(bfr[s]), acc, 0, 0, 0);
+        for (int s = 0; s < 6; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc1[s], as_bf16x8(bf[s]), acc, 0, 0, 0);
+        const int pm = mt * 16 + r16;
         if (pm < npx1)
           *reinterpret_cast<u32x2*>(act1 + pm * ACT1_STRIDE + (16 * nt1 + 4 * g) * 2) =
-              pack4_bf16(fmaxf(acc[0] + b1[0], 0.f), fmaxf(acc[1] + b1[1], 0.f), fmaxf(acc[2] + b1[2], 0.f),
-                         fmaxf(acc[3] + b1[3], 0.f));
+              pack4_bf16(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+      };
+      u32x4 fa[6], fb[6];
+      ld1(base1(t0), fa);
+#pragma unroll
+      for (int i = 0; i < HALF1; i += 2) {
+        if (t0 + i + 1 < NT1 && i + 1 < HALF1) ld1(base1(t0 + i + 1), fb);
+        if (t0 + i < NT1) tile1(t0 + i, fa);
+        if (t0 + i + 2 < NT1 && i + 2 < HALF1) ld1(base1(t0 + i + 2), fa);
+        if (t0 + i + 1 < NT1 && i + 1 < HALF1) tile1(t0 + i + 1, fb);
       }
     }
-    __syncthreads();
-    if (has_next) commit_load(buf ^ 1);  // the other buffer was last read by the previous image's conv1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     // ------------------------------------------------ conv2: 4x4 stride 2, 32 -> 64 (wave = 16 channels)
     {
-      const int ntile2 = (npx2 + 15) >> 4;
-      for (int mt = 0; mt < ntile2; mt++) {
-        const int pm = mt * 16 + r16, pc = min(pm, npx2 - 1);
+      constexpr int NT2 = (G::NPX2 + 15) >> 4;
+      auto base2 = [&](int mt) {
+        const int pc = min(mt * 16 + r16, npx2 - 1);
         const int oy = pc / a.OW2, ox = pc - oy * a.OW2;
-        const unsigned char* base = act1 + ((2 * oy) * a.OW1 + 2 * ox) * ACT1_STRIDE + 16 * g;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        u32x4 bfr[16];
+        return act1 + ((2 * oy) * a.OW1 + 2 * ox) * ACT1_STRIDE + 16 * g;
+      };
+      auto ld2 = [&](const unsigned char* base, int h, u32x4 (&bf)[8]) {
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
-          const int ky = s >> 2, kx = s & 3;
-          bfr[s] = *reinterpret_cast<const u32x4*>(base + (ky * a.OW1 + kx) * ACT1_STRIDE);
+        for (int i = 0; i < 8; i++) {
+          const int s = 8 * h + i, ky = s >> 2, kx = s & 3;
+          bf[i] = *reinterpret_cast<const u32x4*>(base + (ky * a.OW1 + kx) * ACT1_STRIDE);
         }
+      };
+      u32x4 fa[8], fb[8];
+      const unsigned char* bcur = base2(0);
+      ld2(bcur, 0, fa);
+#pragma unroll
+      for (int mt = 0; mt < NT2; mt++) {
+        f32x4 acc = {b2[0], b2[1], b2[2], b2[3]};
+        ld2(bcur, 1, fb);
         MFMA_CHAIN_BEGIN(acc);
 #pragma unroll
-        for (int s = 0; s < 16; s++) MFMA_AW(acc, wc2[s], bfr[s]);
+        for (int i = 0; i < 8; i++) MFMA_AW(acc, wc2[i], fa[i]);
+        if (mt + 1 < NT2) { bcur = base2(mt + 1); ld2(bcur, 0, fa); }
+#pragma unroll
+        for (int i = 0; i < 8; i++) MFMA_AW(acc, wc2[8 + i], fb[i]);
         MFMA_CHAIN_END(acc);
+        const int pm = mt * 16 + r16;
         if (pm < npx2)
           *reinterpret_cast<u32x2*>(act2 + pm * ACT2_STRIDE + (16 * w + 4 * g) * 2) =
-              pack4_bf16(fmaxf(acc[0] + b2[0], 0.f), fmaxf(acc[1] + b2[1], 0.f), fmaxf(acc[2] + b2[2], 0.f),
-                         fmaxf(acc[3] + b2[3], 0.f));
+              pack4_bf16(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
       }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     // ------------------------------------------------ conv3: 3x3 stride 1, 64 -> 64 + soft-argmax in registers
     {
-      const int ntile3 = (npx3 + 15) >> 4;
-      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      float se[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0};
-      for (int mt = 0; mt < ntile3; mt++) {
-        const int pm = mt * 16 + r16, pc = min(pm, npx3 - 1);
-        const int oy = pc / a.OW3, ox = pc - oy * a.OW3;
-        const unsigned char* base = act2 + (oy * a.OW2 + ox) * ACT2_STRIDE + 16 * g;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        u32x4 bfr[18];
+      constexpr int NT3 = (G::NPX3 + 15) >> 4;
+      const float inv_t = 1.0f / temp;
+      f32x4 v3[NT3];
+      float fx[NT3], fy[NT3];
+      auto base3 = [&](int mt, int& ox, int& oy) {
+        const int pc = min(mt * 16 + r16, npx3 - 1);
+        oy = pc / a.OW3; ox = pc - oy * a.OW3;
+        return act2 + (oy * a.OW2 + ox) * ACT2_STRIDE + 16 * g;
+      };
+      auto ld3 = [&](const unsigned char* base, int h, u32x4 (&bf)[9]) {
 #pragma unroll
-        for (int s = 0; s < 18; s++) {
-          const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
-          bfr[s] = *reinterpret_cast<const u32x4*>(base + (ky * a.OW2 + kx) * ACT2_STRIDE + 64 * (s & 1));
+        for (int i = 0; i < 9; i++) {
+          const int s = 9 * h + i, tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
+          bf[i] = *reinterpret_cast<const u32x4*>(base + (ky * a.OW2 + kx) * ACT2_STRIDE + 64 * (s & 1));
         }
+      };
+      u32x4 fa[9], fb[9];
+      int ox, oy;
+      const unsigned char* bcur = base3(0, ox, oy);
+      ld3(bcur, 0, fa);
+#pragma unroll
+      for (int mt = 0; mt < NT3; mt++) {
+        f32x4 acc = {b3[0], b3[1], b3[2], b3[3]};
+        fx[mt] = (float)ox; fy[mt] = (float)oy;
+        ld3(bcur, 1, fb);
         MFMA_CHAIN_BEGIN(acc);
 #pragma unroll
-        for (int s = 0; s < 18; s++) MFMA_AW(acc, wc3[s], bfr[s]);
-        MFMA_CHAIN_END(acc);
-        // online soft-argmax update (per channel q, over this lane's pixel)
-        const bool ok = pm < npx3;
+        for (int i = 0; i < 9; i++) MFMA_AW(acc, wc3[i], fa[i]);
+        if (mt + 1 < NT3) { bcur = base3(mt + 1, ox, oy); ld3(bcur, 0, fa); }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const float v = fmaxf(acc[q] + b3[q], 0.f) / temp;
-          const float m_new = ok ? fmaxf(mx[q], v) : mx[q];
-          const float sc = (mx[q] == -INFINITY) ? 0.f : expf(mx[q] - m_new);
-          const float e = ok ? expf(v - m_new) : 0.f;
-          se[q] = se[q] * sc + e; sx[q] = sx[q] * sc + e * (float)ox; sy[q] = sy[q] * sc + e * (float)oy;
-          mx[q] = m_new;
-        }
+        for (int i = 0; i < 9; i++) MFMA_AW(acc, wc3[9 + i], fb[i]);
+        MFMA_CHAIN_END(acc);
+        const bool ok = mt * 16 + r16 < npx3;
+#pragma unroll
+        for (int q = 0; q < 4; q++) v3[mt][q] = ok ? fmaxf(acc[q], 0.f) * inv_t : -INFINITY;
       }
-      // merge the 16 pixel lanes (xor shuffles inside each 16-lane group)
+      // pass 1: per-channel max over the image (tiles in registers, then the 16 pixel lanes)
+      float mx[4], se[4], sx[4], sy[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
+        float m = v3[0][q];
+#pragma unroll
+        for (int mt = 1; mt < NT3; mt++) m = fmaxf(m, v3[mt][q]);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        mx[q] = m; se[q] = 0.f; sx[q] = 0.f; sy[q] = 0.f;
+      }
+      // pass 2: exp and the three sums (exp(-inf) = 0 masks the padded pixels)
+#pragma unroll
+      for (int mt = 0; mt < NT3; mt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float e = __expf(v3[mt][q] - mx[q]);
+          se[q] += e; sx[q] += e * fx[mt]; sy[q] += e * fy[mt];
+        }
+#pragma unroll
+      for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
-          const float m2 = __shfl_xor(mx[q], o, 64), e2 = __shfl_xor(se[q], o, 64);
-          const float x2 = __shfl_xor(sx[q], o, 64), y2 = __shfl_xor(sy[q], o, 64);
-          const float mn = fmaxf(mx[q], m2);
-          const float c1 = (mx[q] == -INFINITY) ? 0.f : expf(mx[q] - mn), c2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
-          se[q] = se[q] * c1 + e2 * c2; sx[q] = sx[q] * c1 + x2 * c2; sy[q] = sy[q] * c1 + y2 * c2;
-          mx[q] = mn;
+          se[q] += __shfl_xor(se[q], o, 64); sx[q] += __shfl_xor(sx[q], o, 64); sy[q] += __shfl_xor(sy[q], o, 64);
         }
-      }
       if (r16 == 0) {
         // features interleaved [x_c, y_c]; channels 16 w + 4 g + q
         __bf16* dst = reinterpret_cast<__bf16*>(sa + slot * SA_STRIDE) + 2 * (16 * w + 4 * g);
 #pragma unroll
-        for (int q = 0; q < 4; q++) { dst[2 * q] = (__bf16)(sx[q] / se[q]); dst[2 * q + 1] = (__bf16)(sy[q] / se[q]); }
+        for (int q = 0; q < 4; q++) {
+          const float r = 1.0f / se[q];
+          dst[2 * q] = (__bf16)(sx[q] * r); dst[2 * q + 1] = (__bf16)(sy[q] * r);
+        }
       }
     }
 
     // ------------------------------------------------ FC tail once per chunk
-    const bool chunk_done = (nslot == 0);
+    const bool chunk_done = (slot == EF_CHUNK - 1) || !has_next;
     if (chunk_done) {
       __syncthreads();  // soft-argmax features of the whole chunk are in LDS
       const int n_in_chunk = slot + 1;
@@ -335,26 +397,40 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a) {
         for (int s = 0; s < 8; s++)
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wf[s]), as_bf16x8(*reinterpret_cast<const u32x4*>(base + 64 * s)), acc, 0, 0, 0);
         if (r16 < n_in_chunk) {
-          float* o = P.out + ((long)chunk * EF_CHUNK + r16) * 32 + 16 * w + 4 * g;
+          const long img_of_slot = worker + (long)(it - slot + r16) * nworkers;
+          float* o = P.out + img_of_slot * 32 + 16 * w + 4 * g;
           f32x4 r = {acc[0] + c0, acc[1] + c1, acc[2] + c2, acc[3] + c3};
           *reinterpret_cast<f32x4*>(o) = r;
         }
       }
     }
     if (!has_next) break;
-    __syncthreads();  // next image committed to LDS; sa/h1 free for the next chunk
-    cur = nxt; chunk = nchunk; slot = nslot; buf ^= 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next image has landed
+    __syncthreads();                                  // ... and everyone's; sa/h1 free for the next chunk
+    cur = nxt; it++; buf ^= 1;
   }
 }
 
+#define EF_GEOMS(X) X(84, 84) X(64, 64) X(44, 60)
+
 extern "C" int tacorl_encoder_fused_supported(int H, int W) {
-  if (H < 36 || W < 36) return 0;
-  const long img_bytes = (long)H * W * 6;
-  if (img_bytes % 16 || img_bytes > (long)EF_MAXCH * 256 * 16) return 0;
-  const int OH1 = (H - 8) / 4 + 1, OW1 = (W - 8) / 4 + 1, OH2 = (OH1 - 4) / 2 + 1, OW2 = (OW1 - 4) / 2 + 1;
-  const long lds = 2 * ((img_bytes + 15) & ~15L) + (((long)OH1 * OW1 * ACT1_STRIDE + 15) & ~15L) +
-                   (((long)OH2 * OW2 * ACT2_STRIDE + 15) & ~15L) + EF_CHUNK * (SA_STRIDE + H1_STRIDE) + 64;
-  return lds <= 160 * 1024;
+#define X(h, w) if (H == h && W == w) return EFGeom<h, w>::OK ? 1 : 0;
+  EF_GEOMS(X)
+#undef X
+  return 0;
+}
+
+template <int H, int W>
+static int ef_launch(EFArgs& a, int nb, hipStream_t st) {
+  static bool attr_set = false;
+  auto kfn = encoder_fused_kernel<H, W>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  constexpr size_t lds_bytes = EFGeom<H, W>::LDS_BYTES;
+  hipLaunchKernelGGL(kfn, dim3(nb), dim3(256), lds_bytes, st, a);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
 extern "C" int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const void* const* packed,
@@ -363,33 +439,21 @@ extern "C" int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const
   if (nprob < 1 || nprob > EF_MAXP || !tacorl_encoder_fused_supported(H, W)) return TACORL_EINVAL;
   EFArgs a{};
   a.nprob = nprob; a.H = H; a.W = W;
-  a.OH1 = (H - 8) / 4 + 1; a.OW1 = (W - 8) / 4 + 1;
-  a.OH2 = (a.OH1 - 4) / 2 + 1; a.OW2 = (a.OW1 - 4) / 2 + 1;
-  a.OH3 = a.OH2 - 2; a.OW3 = a.OW2 - 2;
-  a.img_bytes = H * W * 6;
-  a.lds_img = (a.img_bytes + 15) & ~15;
-  long total_chunks = 0;
-  for (int p = 0; p < nprob; p++) total_chunks += (n_img[p] + EF_CHUNK - 1) / EF_CHUNK;
-  if (total_chunks == 0) return TACORL_OK;
-  // one workgroup per CU; workers are shared out in proportion to each problem's chunks
+  long total = 0;
+  for (int p = 0; p < nprob; p++) total += n_img[p];
+  if (total == 0) return TACORL_OK;
+  // one workgroup per CU; workers are shared out in proportion to each problem's images
   const int budget = 256;
   int nb = 0;
   for (int p = 0; p < nprob; p++) {
-    const long ch = (n_img[p] + EF_CHUNK - 1) / EF_CHUNK;
-    int k = (int)((ch * (budget - nprob)) / total_chunks) + (ch > 0 ? 1 : 0);  // floor share + 1: sum <= budget
-    if (k > ch) k = (int)ch;
+    int k = (int)(((long)n_img[p] * (budget - nprob)) / total) + (n_img[p] > 0 ? 1 : 0);  // floor share + 1
+    if (k > n_img[p]) k = n_img[p];
     a.p[p].img = (const __bf16*)img[p]; a.p[p].wpk = (const u32x4*)packed[p]; a.p[p].params = params[p];
     a.p[p].out = out[p]; a.p[p].n_img = n_img[p]; a.p[p].first_block = nb; a.p[p].nblocks = k;
     nb += k;
   }
-  const size_t lds = 2 * (size_t)a.lds_img + (((size_t)a.OH1 * a.OW1 * ACT1_STRIDE + 15) & ~15UL) +
-                     (((size_t)a.OH2 * a.OW2 * ACT2_STRIDE + 15) & ~15UL) + EF_CHUNK * (SA_STRIDE + H1_STRIDE);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(encoder_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(encoder_fused_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, a);
-  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+#define X(h, w) if (H == h && W == w) return ef_launch<h, w>(a, nb, (hipStream_t)stream);
+  EF_GEOMS(X)
+#undef X
+  return TACORL_EINVAL;
 }
