@@ -152,19 +152,18 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     long off = 0;
     for (int i = 0; i < 11; i++) { po[i] = off; off = (off + sz[i] + 3) & ~3L; }
   }
-  const int nt1 = w >> 1, mh1 = w & 1;
-  bf16x8 wc1[6];
-  u32x4 wc2[16], wc3[18];
+  u32x4 wc1a[6], wc1b[6], wc2[16], wc3[18];  // all AGPR-resident (184 AGPRs)
 #pragma unroll
-  for (int s = 0; s < 6; s++) wc1[s] = as_bf16x8(P.wpk[WP_C1 + (nt1 * 6 + s) * 64 + l]);
+  for (int s = 0; s < 6; s++) { wc1a[s] = P.wpk[WP_C1 + s * 64 + l]; wc1b[s] = P.wpk[WP_C1 + (6 + s) * 64 + l]; }
 #pragma unroll
   for (int s = 0; s < 16; s++) wc2[s] = P.wpk[WP_C2 + (w * 16 + s) * 64 + l];
 #pragma unroll
   for (int s = 0; s < 18; s++) wc3[s] = P.wpk[WP_C3 + (w * 18 + s) * 64 + l];
-  float b1[4], b2[4], b3[4];
+  float b1[2][4], b2[4], b3[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    b1[q] = P.params[po[1] + 16 * nt1 + 4 * g + q];
+    b1[0][q] = P.params[po[1] + 4 * g + q];
+    b1[1][q] = P.params[po[1] + 16 + 4 * g + q];
     b2[q] = P.params[po[3] + 16 * w + 4 * g + q];
     b3[q] = P.params[po[5] + 16 * w + 4 * g + q];
   }
@@ -210,8 +209,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     // ------------------------------------------------ conv1: 8x8 stride 4, 3 -> 32
     {
       const unsigned char* ib = lds + buf * a.lds_img;
-      constexpr int NT1 = (G::NPX1 + 15) >> 4, HALF1 = (NT1 + 1) >> 1;
-      const int t0 = mh1 * HALF1;
+      constexpr int NT1 = (G::NPX1 + 15) >> 4, PER1 = (NT1 + 3) >> 2;
       auto base1 = [&](int mt) {
         const int pc = min(mt * 16 + r16, npx1 - 1);
         const int oy = pc / a.OW1, ox = pc - oy * a.OW1;
@@ -227,22 +225,30 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         }
       };
       auto tile1 = [&](int mt, u32x4 (&bf)[6]) {
-        f32x4 acc = {b1[0], b1[1], b1[2], b1[3]};
+        f32x4 acc0 = {b1[0][0], b1[0][1], b1[0][2], b1[0][3]}, acc1 = {b1[1][0], b1[1][1], b1[1][2], b1[1][3]};
+        MFMA_CHAIN_BEGIN(acc0);
 #pragma unroll
-        for (int s = 0; s < 6; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc1[s], as_bf16x8(bf[s]), acc, 0, 0, 0);
+        for (int s = 0; s < 6; s++) MFMA_AW(acc0, wc1a[s], bf[s]);
+        MFMA_CHAIN_BEGIN(acc1);  // each accumulator chain stays strictly back-to-back (asm MFMAs get no
+#pragma unroll                   // compiler hazard handling: interleaving two chains returned wrong sums)
+        for (int s = 0; s < 6; s++) MFMA_AW(acc1, wc1b[s], bf[s]);
+        MFMA_CHAIN_END(acc1);
         const int pm = mt * 16 + r16;
-        if (pm < npx1)
-          *reinterpret_cast<u32x2*>(act1 + pm * ACT1_STRIDE + (16 * nt1 + 4 * g) * 2) =
-              pack4_bf16(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+        if (pm < npx1) {
+          *reinterpret_cast<u32x2*>(act1 + pm * ACT1_STRIDE + (4 * g) * 2) =
+              pack4_bf16(fmaxf(acc0[0], 0.f), fmaxf(acc0[1], 0.f), fmaxf(acc0[2], 0.f), fmaxf(acc0[3], 0.f));
+          *reinterpret_cast<u32x2*>(act1 + pm * ACT1_STRIDE + (16 + 4 * g) * 2) =
+              pack4_bf16(fmaxf(acc1[0], 0.f), fmaxf(acc1[1], 0.f), fmaxf(acc1[2], 0.f), fmaxf(acc1[3], 0.f));
+        }
       };
       u32x4 fa[6], fb[6];
-      ld1(base1(t0), fa);
+      ld1(base1(w), fa);
 #pragma unroll
-      for (int i = 0; i < HALF1; i += 2) {
-        if (t0 + i + 1 < NT1 && i + 1 < HALF1) ld1(base1(t0 + i + 1), fb);
-        if (t0 + i < NT1) tile1(t0 + i, fa);
-        if (t0 + i + 2 < NT1 && i + 2 < HALF1) ld1(base1(t0 + i + 2), fa);
-        if (t0 + i + 1 < NT1 && i + 1 < HALF1) tile1(t0 + i + 1, fb);
+      for (int i = 0; i < PER1; i += 2) {
+        if (w + 4 * (i + 1) < NT1 && i + 1 < PER1) ld1(base1(w + 4 * (i + 1)), fb);
+        if (w + 4 * i < NT1) tile1(w + 4 * i, fa);
+        if (w + 4 * (i + 2) < NT1 && i + 2 < PER1) ld1(base1(w + 4 * (i + 2)), fa);
+        if (w + 4 * (i + 1) < NT1 && i + 1 < PER1) tile1(w + 4 * (i + 1), fb);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
