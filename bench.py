@@ -38,7 +38,7 @@ def synth_batch(B, T, H, W, dev, seed):
             "disp": disp}
 
 
-def build_module(dev, compute, T, world):
+def build_module(dev, compute, T, world, ad_every=1):
     from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
     from tacorl_amd.modules.tacorl.tacorl import TACORL
 
@@ -54,7 +54,7 @@ def build_module(dev, compute, T, world):
                   plan_proposal_goal_modalities=cams, plan_recognition_modalities=cams, action_decoder_modalities=cams,
                   real_world=True, device=dev, compute_dtype=compute, image_dtype=compute)
     mod = TACORL(play_lmp=lmp, finetune_action_decoder=False, critic=critic, real_world=True, device=dev,
-                 compute_dtype=compute, image_dtype=compute, world_size=world,
+                 compute_dtype=compute, image_dtype=compute, world_size=world, action_loss_every_n_steps=ad_every,
                  # config/module/tacorl.yaml:8-30
                  action_decoder_lr=3e-4, actor_lr=1e-4, critic_lr=3e-4, discount=0.95, conservative_weight=1.0,
                  reward_scale=10.0, n_action_samples=4, with_lagrange=True, deterministic_backup=True, bc_epochs=5)
@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--ad-every", type=int, default=1,
+                    help="evaluate the (logging-only, frozen) action-decoder loss every k-th step; 1 = every step "
+                         "as the reference does")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,7 +144,7 @@ def main():
 
     _lib.call("tacorl_hip_init", local)
     B, T, H, W = a.batch, 16, 84, 84
-    mod = build_module(dev, a.dtype, T, world)
+    mod = build_module(dev, a.dtype, T, world, a.ad_every)
     batch = synth_batch(B, T, H, W, dev, 1234 + rank)
     use_graph = (not a.no_graph) and hasattr(mod, "enable_graph")
     if use_graph:
@@ -184,7 +187,8 @@ def main():
             "config": {"workload": "tacorl actor-critic training_step, frozen LMP (BASELINE configs[1])",
                        "per_gpu_batch": B, "global_batch": B * world, "window": T, "image": f"{H}x{W}x3",
                        "latent_plan": 16, "n_action_samples": 4, "phase": "Q (epoch>=bc_epochs)",
-                       "action_decoder_loss_logged": True, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                       "action_decoder_loss": ("every step (reference behaviour)" if a.ad_every <= 1 else
+                                               f"every {a.ad_every} steps (logging cadence)"), "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
                        "samples_per_s": round(world * B / (ms_step * 1e-3), 1), "losses_finite": finite},
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tflops / peak, 4), "traffic": None,

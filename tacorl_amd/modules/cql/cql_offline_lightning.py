@@ -59,7 +59,7 @@ class CQL_Offline(LoggerMixin, nn.Module):
         self.world_size = world_size
         self.log_every_n_steps = 1  # PL Trainer(log_every_n_steps=...) semantics: metrics are read back (one D2H
         self._step_count = 0        # sync) only on these steps
-        self._graph, self._graph_key, self._use_graph = None, None, False
+        self._graphs, self._use_graph = {}, False
         self._hp = dict(discount=discount, tau=tau, actor_lr=actor_lr, critic_lr=critic_lr,
                         deterministic_backup=deterministic_backup, reward_scale=reward_scale,
                         clip_grad_val=float(clip_grad_val) if clip_grad else 0.0,
@@ -162,21 +162,22 @@ class CQL_Offline(LoggerMixin, nn.Module):
         """Replay the device side of the step from a captured hipGraph (single-GPU only: the RCCL
         all-reduces of the multi-GPU path stay eager)."""
         self._use_graph = bool(on) and self.world_size == 1
-        self._graph = None
+        self._graphs = {}
 
     def _run_device(self, key, fn):
         """Run `fn` (kernel launches only, fixed buffers) eagerly, or capture/replay it as a hipGraph."""
         if not self._use_graph:
             return fn()
-        if self._graph is None or self._graph_key != key:
+        g = self._graphs.get(key)
+        if g is None:
             fn()  # warm-up: sizes every workspace, so the capture allocates nothing
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fn()
-            self._graph, self._graph_key = g, key
+            self._graphs[key] = g
             return
-        self._graph.replay()
+        g.replay()
 
     def compute_update(self, batch, optimize: bool = True, log_type: str = "train", noise=None):
         obs, action, nxt, reward, done = batch

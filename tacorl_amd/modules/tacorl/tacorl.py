@@ -25,6 +25,11 @@ class TACORL(CQL_Offline):
         self.overwrite_lmp_cfg = overwrite_lmp_cfg
         self.finetune_action_decoder = finetune_action_decoder
         self.action_decoder_lr = action_decoder_lr
+        # The reference evaluates the action-decoder loss on every step even when the decoder is frozen,
+        # although the value only reaches the logger (tacorl.py:206-233, optimize=False).  With
+        # `action_loss_every_n_steps=k` that logging-only forward runs on every k-th step (match it to
+        # Trainer(log_every_n_steps)); fine-tuning (`finetune_action_decoder=True`) always runs it.
+        self.action_loss_every_n_steps = kwargs.pop("action_loss_every_n_steps", 1)
         self.__dict__["_play_lmp"] = play_lmp  # nn.Module: must not be registered as a sub-module
         super().__init__(*args, **kwargs)
 
@@ -125,7 +130,11 @@ class TACORL(CQL_Offline):
         e.set_noise(noise)
         return B, T, hw
 
-    def _device_step(self, B, T, hw, optimize):
+    def _ad_due(self):
+        k = self.action_loss_every_n_steps
+        return self.ad is not None and (self.finetune_action_decoder or k <= 1 or (self._step_count + 1) % k == 0)
+
+    def _device_step(self, B, T, hw, optimize, with_ad=True):
         """Graph-capturable part: all encoders (frozen LMP + actor/critics/targets) -> plan recognition ->
         plan -> AD loss -> CQL update."""
         self.engine._encode_all()
@@ -134,8 +143,8 @@ class TACORL(CQL_Offline):
         head = self.pr.forward(self.pr_in, self.pr_in.shape[1], B, T, self.compute)
         call("tacorl_pr_sample", ptr(head), ptr(self.eps_pr), ptr(self.plan), None, None, B, self.action_dim,
              float(self.pr.min_std), ops.stream())
-        if self.ad is not None:
-            # compute_action_decoder_update (tacorl.py:206-233): loss always logged, stepped if fine-tuning
+        if with_ad:
+            # compute_action_decoder_update (tacorl.py:206-233): loss logged, stepped if fine-tuning
             self.ad.loss_step(self, self.acts, self.plan, B, T, optimize and self.finetune_action_decoder)
         self.engine.load_transition(self.plan, self.reward, self.reward)
         self.engine.update(bc_phase=self.current_epoch < self.bc_epochs, optimize=optimize, encoded=True)
@@ -164,9 +173,10 @@ class TACORL(CQL_Offline):
 
     def _step(self, batch, noise, optimize, log_type, nchw=True):
         B, T, hw = self._stage_frames(batch, noise, nchw)
-        key = ("tacorl", B, T, tuple(sorted(hw.items())), self.current_epoch < self.bc_epochs, optimize)
-        self._run_device(key, lambda: self._device_step(B, T, hw, optimize))
-        self._publish_logs(log_type, extra=("action_loss",) if self.ad is not None else ())
+        with_ad = self._ad_due()
+        key = ("tacorl", B, T, tuple(sorted(hw.items())), self.current_epoch < self.bc_epochs, optimize, with_ad)
+        self._run_device(key, lambda: self._device_step(B, T, hw, optimize, with_ad))
+        self._publish_logs(log_type, extra=("action_loss",) if with_ad else ())
 
     def configure_optimizers(self):
         o = super().configure_optimizers()

@@ -69,8 +69,16 @@ class ActionDecoderLogistic:
         self._shape = (B, Tm)
 
     def _lin(self, x, ldx, w, b, y, M, K, N, act, compute):
-        call("tacorl_linear_fwd", 1, ops.ptr_array([x]), ldx, ops.ptr_array([w]), ops.ptr_array([b]),
-             ops.ptr_array([y]), None, ops.int_array([M]), K, N, act, compute, ops.stream())
+        # split-K capable entry (skinny outputs with a long K: linear2 2048->32, the 2048->182 heads)
+        import os
+        if os.environ.get("TACORL_NO_SPLITK"):
+            call("tacorl_linear_fwd", 1, ops.ptr_array([x]), ldx, ops.ptr_array([w]), ops.ptr_array([b]),
+                 ops.ptr_array([y]), None, ops.int_array([M]), K, N, act, compute, ops.stream())
+            return
+        nb = ops.L.lib().tacorl_linear_add_fwd_ws_bytes(1, ops.int_array([M]), K, N)
+        ws = ops.workspace(nb, self.dev, "lin_splitk")
+        call("tacorl_linear_add_fwd", 1, ops.ptr_array([x]), ldx, ops.ptr_array([w]), ops.ptr_array([b]), None, 0,
+             ops.ptr_array([y]), N, ops.int_array([M]), K, N, act, compute, ptr(ws), ws.numel(), ops.stream())
 
     def forward(self, plan, emb, ld_emb, B, T, Tm, compute):
         """plan (B,P); emb [B*T][ld_emb] batch-major frame embeddings; uses steps t < Tm.  Fills self.heads."""
