@@ -50,10 +50,16 @@ struct AtomF32 {  // v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fmaf chain)
   typedef float elem;
   static constexpr int KPACK = 1;  // consecutive k per lane
   static constexpr int KSTEP = 4;  // k per instruction
+  static constexpr int BK = 32;    // k per LDS tile
   static constexpr int PAD = 2;    // LDS row pad (elems): stride 34 -> conflict-free ds_read_b32
   typedef float frag;
   static __device__ __forceinline__ elem cvt(float x) { return x; }
   static __device__ __forceinline__ frag ld(const elem* p) { return *p; }
+  // 4 consecutive k of one row: LD = 34 floats -> 8-byte aligned only
+  static __device__ __forceinline__ void st4(elem* d, const float (&v)[4]) {
+    *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[1]};
+    *reinterpret_cast<f32x2*>(d + 2) = f32x2{v[2], v[3]};
+  }
   static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
@@ -62,10 +68,14 @@ struct AtomBF16 {  // v_mfma_f32_16x16x32_bf16: bf16 operands, fp32 accumulate
   typedef __bf16 elem;
   static constexpr int KPACK = 8;
   static constexpr int KSTEP = 32;
+  static constexpr int BK = 32;  // (64 measured 6 % slower on the whole step: fewer resident blocks per CU)
   static constexpr int PAD = 8;  // 16 B
   typedef bf16x8 frag;
   static __device__ __forceinline__ elem cvt(float x) { return (__bf16)x; }
   static __device__ __forceinline__ frag ld(const elem* p) { return *reinterpret_cast<const bf16x8*>(p); }
+  static __device__ __forceinline__ void st4(elem* d, const float (&v)[4]) {  // one ds_write_b64
+    *reinterpret_cast<bf16x4*>(d) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  }
   static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }

@@ -30,7 +30,7 @@ struct GemmArgs {
 template <class Atom, class LA, class LB, bool TA, bool TB, class Epi, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmArgs g) {
   typedef typename Atom::elem T;
-  constexpr int BK = GEMM_BK;
+  constexpr int BK = Atom::BK;
   constexpr int LD = BK + Atom::PAD;
   constexpr int MI = BM / 64;
   constexpr int NI = BN / 16;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmAr
   const int M = g.M[p], N = g.N, R = g.R[p];
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   if (m0 >= M) return;
-  int rs = ((R + g.nsplit - 1) / g.nsplit + BK - 1) / BK * BK;
+  int rs = ((R + g.nsplit - 1) / g.nsplit + 63) / 64 * 64;  // multiple of every atom's BK
   const int r_begin = s * rs;
   const int r_end = min(R, r_begin + rs);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,9 +70,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmAr
     for (int i = 0; i < ACH; i++) {
       int c = tid + i * 256;
       if (!TA) {
-        T* d = &As[(c / (BK / 4)) * LD + (c % (BK / 4)) * 4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) d[j] = Atom::cvt(ra[i][j]);
+        Atom::st4(&As[(c / (BK / 4)) * LD + (c % (BK / 4)) * 4], ra[i]);
       } else {
         int r = c / (BM / 4), m = (c % (BM / 4)) * 4;
 #pragma unroll
@@ -84,9 +82,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmAr
       int c = tid + i * 256;
       if (BN * BK / 4 % 256 != 0 && c >= BN * BK / 4) break;
       if (!TB) {
-        T* d = &Bs[(c / (BK / 4)) * LD + (c % (BK / 4)) * 4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) d[j] = Atom::cvt(rb[i][j]);
+        Atom::st4(&Bs[(c / (BK / 4)) * LD + (c % (BK / 4)) * 4], rb[i]);
       } else {
         int r = c / (BN / 4), n = (c % (BN / 4)) * 4;
 #pragma unroll
