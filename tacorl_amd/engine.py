@@ -300,7 +300,25 @@ class ACEngine:
     def update(self, bc_phase, optimize=True, encoded=False):
         """One compute_update.  Inputs must have been staged with load_images / load_transition /
         set_noise.  Returns nothing; metrics are in self.logs (read with metrics()).
-        encoded=True: the caller already ran _encode_all() for this batch."""
+        encoded=True: the caller already ran _encode_all() for this batch.
+
+        Three collective-free phases (each hipGraph-capturable) separated by the step's two all-reduces:
+        a) forward up to the alpha gradient; b) alpha step, critics, losses, every backward;
+        c) optimiser steps + soft target update."""
+        self.phase_a(encoded)
+        self.allreduce_alpha()
+        self.phase_b(bc_phase, optimize)
+        self.allreduce_grads()
+        self.phase_c(optimize)
+
+    def allreduce_alpha(self):
+        self._allreduce([self.log_alpha.grad])
+
+    def allreduce_grads(self):
+        self._allreduce([self.actor.grad, self.q1.grad, self.q2.grad] +
+                        ([self.log_alpha_prime.grad] if self.with_lagrange else []))
+
+    def phase_a(self, encoded=False):
         B, n, A, Ac, hp, nz = self.B, self.n, self.A, self.Ac, self.hp, self.noise
         gs = 1.0 / self.world
         if not encoded:
@@ -323,7 +341,11 @@ class ACEngine:
         # alpha: loss, gradient, Adam step (alpha is read post-step below; SURVEY 8a note 2)
         call("tacorl_alpha_loss", ptr(self.logp_pi), B, ptr(self.log_alpha.param), float(hp["target_entropy"]), gs,
              ptr(self.log_alpha.grad), ptr(self.logs), ops.stream())
-        self._allreduce([self.log_alpha.grad])
+
+    def phase_b(self, bc_phase, optimize=True):
+        B, n, A, Ac, hp, nz = self.B, self.n, self.A, self.Ac, self.hp, self.noise
+        gs = 1.0 / self.world
+        head_cur = self._head("a")
         if optimize:
             ops.adam_step(self.log_alpha.param, self.log_alpha.grad, self.log_alpha.m, self.log_alpha.v,
                           hp["actor_lr"], 0.0, self.log_alpha.step)
@@ -401,9 +423,10 @@ class ACEngine:
                  ops.ptr_array([self.enc_dout[(ek[k], c)] for k in ks]),
                  ops.ptr_array([nets[k].enc(c, nets[k].grad) for k in ks]), ops.int_array(ops_n), H, W,
                  BF16 if self.img_dtype == torch.bfloat16 else F32, self.compute, 0, ptr(ws), ws.numel(), ops.stream())
-        # ---- optimiser steps (grads were all taken on the pre-step graph, as in the reference)
-        grads = [self.actor.grad, self.q1.grad, self.q2.grad] + ([lap.grad] if self.with_lagrange else [])
-        self._allreduce(grads)
+
+    def phase_c(self, optimize=True):
+        """Optimiser steps (grads were all taken on the pre-step graph, as in the reference)."""
+        hp, lap = self.hp, self.log_alpha_prime
         if optimize:
             if self.with_lagrange:
                 ops.adam_step(lap.param, lap.grad, lap.m, lap.v, hp["critic_lr"], 0.0, lap.step)

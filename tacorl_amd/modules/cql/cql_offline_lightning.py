@@ -161,30 +161,50 @@ class CQL_Offline(LoggerMixin, nn.Module):
     def enable_graph(self, on=True):
         """Replay the device side of the step from a captured hipGraph (single-GPU only: the RCCL
         all-reduces of the multi-GPU path stay eager)."""
-        self._use_graph = bool(on) and self.world_size == 1
+        self._use_graph = bool(on)
         self._graphs = {}
 
-    def _run_device(self, key, fn):
-        """Run `fn` (kernel launches only, fixed buffers) eagerly, or capture/replay it as a hipGraph."""
+    def _run_segments(self, key, segs, collectives):
+        """Run the device side of a step: `segs` are collective-free kernel sequences over fixed buffers,
+        `collectives[i]` runs between segs[i] and segs[i+1] (RCCL all-reduces; no-ops on one GPU).
+        Eager, or - with enable_graph() - each segment replayed from a captured hipGraph (one graph for
+        the whole step on a single GPU; collectives always stay eager between graphs)."""
+        def eager():
+            for i, f in enumerate(segs):
+                f()
+                if i < len(collectives):
+                    collectives[i]()
+
         if not self._use_graph:
-            return fn()
-        g = self._graphs.get(key)
-        if g is None:
-            fn()  # warm-up: sizes every workspace, so the capture allocates nothing
+            return eager()
+        gs = self._graphs.get(key)
+        if gs is None:
+            eager()  # warm-up: sizes every workspace, so the capture allocates nothing
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                fn()
-            self._graphs[key] = g
+            split = self.world_size > 1 or getattr(self, "_force_graph_split", False)
+            parts = [[f] for f in segs] if split else [segs]
+            gs = []
+            for part in parts:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for f in part:
+                        f()
+                gs.append(g)
+            self._graphs[key] = gs
             return
-        g.replay()
+        for i, g in enumerate(gs):
+            g.replay()
+            if len(gs) > 1 and i < len(collectives):
+                collectives[i]()
 
     def compute_update(self, batch, optimize: bool = True, log_type: str = "train", noise=None):
         obs, action, nxt, reward, done = batch
         self._stage(obs["observation"], obs["goal"], nxt["observation"], action, reward, done, noise)
         bc = self.current_epoch < self.bc_epochs
-        self._run_device(("cql", self.engine.B, bc, optimize),
-                         lambda: self.engine.update(bc_phase=bc, optimize=optimize))
+        e = self.engine
+        self._run_segments(("cql", e.B, bc, optimize),
+                           [lambda: e.phase_a(), lambda: e.phase_b(bc, optimize), lambda: e.phase_c(optimize)],
+                           [e.allreduce_alpha, e.allreduce_grads])
         self._publish_logs(log_type)
 
     def _publish_logs(self, log_type, extra=()):

@@ -134,9 +134,9 @@ class TACORL(CQL_Offline):
         k = self.action_loss_every_n_steps
         return self.ad is not None and (self.finetune_action_decoder or k <= 1 or (self._step_count + 1) % k == 0)
 
-    def _device_step(self, B, T, hw, optimize, with_ad=True):
-        """Graph-capturable part: all encoders (frozen LMP + actor/critics/targets) -> plan recognition ->
-        plan -> AD loss -> CQL update."""
+    def _device_front(self, B, T, hw, optimize, with_ad=True):
+        """Graph-capturable: all encoders (frozen LMP + actor/critics/targets) -> plan recognition -> plan ->
+        AD loss -> first phase of the CQL update (up to the alpha gradient)."""
         self.engine._encode_all()
         for j, c in enumerate(self.plan_recognition_modalities):
             ops.copy_cols(self.f_out[c], 0, 32, self.pr_in, 32 * j, self.pr_in.shape[1], B * T, 32)
@@ -147,7 +147,7 @@ class TACORL(CQL_Offline):
             # compute_action_decoder_update (tacorl.py:206-233): loss logged, stepped if fine-tuning
             self.ad.loss_step(self, self.acts, self.plan, B, T, optimize and self.finetune_action_decoder)
         self.engine.load_transition(self.plan, self.reward, self.reward)
-        self.engine.update(bc_phase=self.current_epoch < self.bc_epochs, optimize=optimize, encoded=True)
+        self.engine.phase_a(encoded=True)
 
     def get_pr_latent_plan(self, batch, noise=None, nchw=True):
         """reference tacorl.py:235-252 (no_grad / eval): returns the sampled latent plan (device tensor)."""
@@ -175,7 +175,13 @@ class TACORL(CQL_Offline):
         B, T, hw = self._stage_frames(batch, noise, nchw)
         with_ad = self._ad_due()
         key = ("tacorl", B, T, tuple(sorted(hw.items())), self.current_epoch < self.bc_epochs, optimize, with_ad)
-        self._run_device(key, lambda: self._device_step(B, T, hw, optimize, with_ad))
+        e, bc = self.engine, self.current_epoch < self.bc_epochs
+        if with_ad and optimize and self.finetune_action_decoder and self.world_size > 1 and self._use_graph:
+            raise NotImplementedError("hipGraph + multi-GPU + action-decoder fine-tuning: its extra all-reduce sits "
+                                      "inside the first segment; run this combination eagerly")
+        self._run_segments(key, [lambda: self._device_front(B, T, hw, optimize, with_ad),
+                                 lambda: e.phase_b(bc, optimize), lambda: e.phase_c(optimize)],
+                           [e.allreduce_alpha, e.allreduce_grads])
         self._publish_logs(log_type, extra=("action_loss",) if with_ad else ())
 
     def configure_optimizers(self):

@@ -171,3 +171,29 @@ def test_playlmp_step():
         bad += check_stats(mod.state_dict(), g.stats(step, "param"), rtol=RTOL, atol=PARAM_ATOL if step == 0 else 2e-4,
                            what="golden param ")
         assert not bad, f"step {step}:\n" + "\n".join(bad[:25])
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_tacorl_step_hipgraph(split):
+    """The captured-graph path (one graph, and the 3-segment form the multi-GPU path replays around its
+    two all-reduces) reproduces the eager step: same goldens, two steps (first = warm-up + capture)."""
+    g = Golden("tacorl_q")
+    mod = build_tacorl(g)
+    mod.load_state_dict(g.params(), strict=False)
+    mod.current_epoch = g.cfg["epoch"]
+    mod._force_graph_split = split
+    mod.enable_graph()
+    for step in range(g.cfg["steps"]):
+        mod.logged = {}
+        mod.training_step(to_dev(g.batch(step), mod.device), noise=to_dev(g.noise(step), mod.device))
+        torch.cuda.synchronize()
+        got = {k.split("/", 1)[1]: v for k, v in mod.logged.items()}
+        bad = check_logs(got, g.logged(step))
+        bad += check_stats(mod.state_dict(), g.stats(step, "param"), rtol=RTOL, atol=PARAM_ATOL, what="golden param ")
+        assert not bad, f"step {step}:\n" + "\n".join(bad[:25])
+    # a third step replays the captured graph(s): must stay finite and move the parameters
+    before = mod.engine.actor.param.clone()
+    mod.training_step(to_dev(g.batch(1), mod.device), noise=to_dev(g.noise(1), mod.device))
+    torch.cuda.synchronize()
+    assert torch.isfinite(mod.engine.logs).all() and not torch.equal(before, mod.engine.actor.param)
+    assert len(mod._graphs) == 1 and len(next(iter(mod._graphs.values()))) == (3 if split else 1)
