@@ -83,15 +83,17 @@ int tacorl_encoder_bwd(int nprob, const void* const* img, const float* const* pa
                        int accumulate, void* ws, size_t ws_bytes, tacorl_stream_t stream);
 
 /* Fused inference forward (no saved activations): one launch, bf16 MFMA, register-stationary weights,
- * LDS-resident intermediates; bf16 NHWC images only.  `packed` = tacorl_encoder_pack_weights output
+ * LDS-resident intermediates; bf16 NHWC images only; optionally saves the activations a backward needs.  `packed` = tacorl_encoder_pack_weights output
  * (tacorl_encoder_fused_wpk_bytes() bytes per network; re-pack whenever the fp32 block changes). */
 long tacorl_encoder_fused_wpk_bytes(void);
 int tacorl_encoder_fused_supported(int H, int W);
 int tacorl_encoder_pack_weights(int nprob, const float* const* params, void* const* packed,
                                 tacorl_stream_t stream);
+/* act: NULL, or per-problem pointers (NULL entries allowed) to tacorl_encoder_act_layout blocks that
+ * receive the fp32 activations tacorl_encoder_bwd needs. */
 int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const void* const* packed,
-                             const float* const* params, float* const* out, const int* n_img, int H, int W,
-                             tacorl_stream_t stream);
+                             const float* const* params, float* const* out, float* const* act,
+                             const int* n_img, int H, int W, tacorl_stream_t stream);
 
 /* ---- MLP = chain of Linear(dims[l] -> dims[l+1]) + acts[l]  ------------------------ */
 /* Parameter block: for each layer W[out][in] then b[out], each 4-float aligned. */

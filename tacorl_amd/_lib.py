@@ -55,7 +55,7 @@ _SIGS = {
     "tacorl_encoder_fused_wpk_bytes": (_l, []),
     "tacorl_encoder_fused_supported": (_i, [_i, _i]),
     "tacorl_encoder_pack_weights": (_i, [_i, _p, _p, _p]),
-    "tacorl_encoder_fwd_fused": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "tacorl_encoder_fwd_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "tacorl_mlp_param_layout": (_l, [_i, _p, _p, _p]),
     "tacorl_mlp_act_layout": (_l, [_i, _i, _p, _p, _p, _p]),
     "tacorl_mlp_fwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _p, _i, _p]),

@@ -35,6 +35,8 @@ struct EFProblem {
   const u32x4* wpk;    // packed bf16 fragments (tacorl_encoder_pack_weights)
   const float* params; // fp32 block (biases, temperature)
   float* out;          // [n][32]
+  float* act;          // optional saved activations (tacorl_encoder_act_layout) for a later backward
+  long a_y2, a_y3, a_sa, a_h1;  // float offsets of y2 / y3 / soft-argmax / fc1 inside act (y1 at 0)
   int n_img;
   int first_block, nblocks;
 };
@@ -229,16 +231,22 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         MFMA_CHAIN_BEGIN(acc0);
 #pragma unroll
         for (int s = 0; s < 6; s++) MFMA_AW(acc0, wc1a[s], bf[s]);
+        MFMA_CHAIN_END(acc0);    // the compiler may schedule acc0's epilogue right here: cover the hazard
         MFMA_CHAIN_BEGIN(acc1);  // each accumulator chain stays strictly back-to-back (asm MFMAs get no
 #pragma unroll                   // compiler hazard handling: interleaving two chains returned wrong sums)
         for (int s = 0; s < 6; s++) MFMA_AW(acc1, wc1b[s], bf[s]);
         MFMA_CHAIN_END(acc1);
         const int pm = mt * 16 + r16;
         if (pm < npx1) {
-          *reinterpret_cast<u32x2*>(act1 + pm * ACT1_STRIDE + (4 * g) * 2) =
-              pack4_bf16(fmaxf(acc0[0], 0.f), fmaxf(acc0[1], 0.f), fmaxf(acc0[2], 0.f), fmaxf(acc0[3], 0.f));
-          *reinterpret_cast<u32x2*>(act1 + pm * ACT1_STRIDE + (16 + 4 * g) * 2) =
-              pack4_bf16(fmaxf(acc1[0], 0.f), fmaxf(acc1[1], 0.f), fmaxf(acc1[2], 0.f), fmaxf(acc1[3], 0.f));
+          const f32x4 r0 = {fmaxf(acc0[0], 0.f), fmaxf(acc0[1], 0.f), fmaxf(acc0[2], 0.f), fmaxf(acc0[3], 0.f)};
+          const f32x4 r1 = {fmaxf(acc1[0], 0.f), fmaxf(acc1[1], 0.f), fmaxf(acc1[2], 0.f), fmaxf(acc1[3], 0.f)};
+          *reinterpret_cast<u32x2*>(act1 + pm * ACT1_STRIDE + (4 * g) * 2) = pack4_bf16(r0[0], r0[1], r0[2], r0[3]);
+          *reinterpret_cast<u32x2*>(act1 + pm * ACT1_STRIDE + (16 + 4 * g) * 2) = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
+          if (P.act) {
+            float* y = P.act + ((long)cur * npx1 + pm) * 32 + 4 * g;
+            *reinterpret_cast<f32x4*>(y) = r0;
+            *reinterpret_cast<f32x4*>(y + 16) = r1;
+          }
         }
       };
       u32x4 fa[6], fb[6];
@@ -284,9 +292,11 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         for (int i = 0; i < 8; i++) MFMA_AW(acc, wc2[8 + i], fb[i]);
         MFMA_CHAIN_END(acc);
         const int pm = mt * 16 + r16;
-        if (pm < npx2)
-          *reinterpret_cast<u32x2*>(act2 + pm * ACT2_STRIDE + (16 * w + 4 * g) * 2) =
-              pack4_bf16(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+        if (pm < npx2) {
+          const f32x4 r = {fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f)};
+          *reinterpret_cast<u32x2*>(act2 + pm * ACT2_STRIDE + (16 * w + 4 * g) * 2) = pack4_bf16(r[0], r[1], r[2], r[3]);
+          if (P.act) *reinterpret_cast<f32x4*>(P.act + P.a_y2 + ((long)cur * npx2 + pm) * 64 + 16 * w + 4 * g) = r;
+        }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -327,6 +337,9 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         for (int i = 0; i < 9; i++) MFMA_AW(acc, wc3[9 + i], fb[i]);
         MFMA_CHAIN_END(acc);
         const bool ok = mt * 16 + r16 < npx3;
+        if (P.act && ok)
+          *reinterpret_cast<f32x4*>(P.act + P.a_y3 + ((long)cur * npx3 + mt * 16 + r16) * 64 + 16 * w + 4 * g) =
+              f32x4{fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f)};
 #pragma unroll
         for (int q = 0; q < 4; q++) v3[mt][q] = ok ? fmaxf(acc[q], 0.f) * inv_t : -INFINITY;
       }
@@ -362,6 +375,10 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         for (int q = 0; q < 4; q++) {
           const float r = 1.0f / se[q];
           dst[2 * q] = (__bf16)(sx[q] * r); dst[2 * q + 1] = (__bf16)(sy[q] * r);
+          if (P.act) {
+            float* f = P.act + P.a_sa + (long)cur * 128 + 2 * (16 * w + 4 * g + q);
+            f[0] = sx[q] * r; f[1] = sy[q] * r;
+          }
         }
       }
     }
@@ -384,10 +401,12 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #pragma unroll
           for (int s = 0; s < 4; s++)
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wf[s]), as_bf16x8(*reinterpret_cast<const u32x4*>(base + 64 * s)), acc, 0, 0, 0);
+          const f32x4 r = {fmaxf(acc[0] + c0, 0.f), fmaxf(acc[1] + c1, 0.f), fmaxf(acc[2] + c2, 0.f), fmaxf(acc[3] + c3, 0.f)};
           if (r16 < EF_CHUNK)
-            *reinterpret_cast<u32x2*>(h1 + r16 * H1_STRIDE + (16 * (4 * w + j) + 4 * g) * 2) =
-                pack4_bf16(fmaxf(acc[0] + c0, 0.f), fmaxf(acc[1] + c1, 0.f), fmaxf(acc[2] + c2, 0.f),
-                           fmaxf(acc[3] + c3, 0.f));
+            *reinterpret_cast<u32x2*>(h1 + r16 * H1_STRIDE + (16 * (4 * w + j) + 4 * g) * 2) = pack4_bf16(r[0], r[1], r[2], r[3]);
+          if (P.act && r16 < n_in_chunk)
+            *reinterpret_cast<f32x4*>(P.act + P.a_h1 + (worker + (long)(it - slot + r16) * nworkers) * 256 +
+                                      16 * (4 * w + j) + 4 * g) = r;
         }
       }
       __syncthreads();
@@ -440,8 +459,8 @@ static int ef_launch(EFArgs& a, int nb, hipStream_t st) {
 }
 
 extern "C" int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const void* const* packed,
-                                        const float* const* params, float* const* out, const int* n_img, int H,
-                                        int W, tacorl_stream_t stream) {
+                                        const float* const* params, float* const* out, float* const* act,
+                                        const int* n_img, int H, int W, tacorl_stream_t stream) {
   if (nprob < 1 || nprob > EF_MAXP || !tacorl_encoder_fused_supported(H, W)) return TACORL_EINVAL;
   EFArgs a{};
   a.nprob = nprob; a.H = H; a.W = W;
@@ -456,6 +475,12 @@ extern "C" int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const
     if (k > n_img[p]) k = n_img[p];
     a.p[p].img = (const __bf16*)img[p]; a.p[p].wpk = (const u32x4*)packed[p]; a.p[p].params = params[p];
     a.p[p].out = out[p]; a.p[p].n_img = n_img[p]; a.p[p].first_block = nb; a.p[p].nblocks = k;
+    a.p[p].act = act ? act[p] : nullptr;
+    if (a.p[p].act) {
+      long ao[5];
+      tacorl_encoder_act_layout(n_img[p], H, W, ao);
+      a.p[p].a_y2 = ao[1]; a.p[p].a_y3 = ao[2]; a.p[p].a_sa = ao[3]; a.p[p].a_h1 = ao[4];
+    }
     nb += k;
   }
 #define X(h, w) if (H == h && W == w) return ef_launch<h, w>(a, nb, (hipStream_t)stream);

@@ -227,48 +227,48 @@ class ACEngine:
             self._wpk[key] = torch.empty(ops.L.lib().tacorl_encoder_fused_wpk_bytes(), dtype=torch.uint8, device=self.dev)
         return self._wpk[key]
 
-    def _nograd_problems(self, c):
-        """(image pointer, net, out tensor, act tensor, n_img) of every no-grad encoder problem of camera c."""
-        pr = [(self._img_ptr(c, r0), net, self.enc_out[(k, c)], self.enc_act[(k, c)], n)
-              for k, net, r0, n in self.enc_probs if k not in self.GRAD_PROBS]
-        pr += [(x["img"], x["net"], x["out"], x["act"], x["n"]) for x in self.extra_enc if x["cam"] == c]
+    def _all_problems(self, c):
+        """(image pointer, net, out, act, n_img, needs_backward) of every encoder problem of camera c."""
+        pr = [(self._img_ptr(c, r0), net, self.enc_out[(k, c)], self.enc_act[(k, c)], n, k in self.GRAD_PROBS)
+              for k, net, r0, n in self.enc_probs]
+        pr += [(x["img"], x["net"], x["out"], x["act"], x["n"], False) for x in self.extra_enc if x["cam"] == c]
         return pr
 
+    def _launch_fused(self, c, pr):
+        H, W = self.hw[c]
+        call("tacorl_encoder_fwd_fused", len(pr), ops.ptr_array([x[0] for x in pr]),
+             ops.ptr_array([self._packed(x[1], c) for x in pr]), ops.ptr_array([x[1].enc(c) for x in pr]),
+             ops.ptr_array([x[2] for x in pr]), ops.ptr_array([x[3] if x[5] else None for x in pr]),
+             ops.int_array([x[4] for x in pr]), H, W, ops.stream())
+
     def encode_fused_only(self):
-        """Just the fused no-grad launch (bench roofline probe).  Returns images per launch (first cam)."""
+        """Just the fused encoder launch of the step (bench roofline probe).  Returns images per launch."""
         n_total = 0
         for c in self.cams:
-            if not self._fused_ok(c):
-                continue
-            H, W = self.hw[c]
-            pr = self._nograd_problems(c)
-            call("tacorl_encoder_fwd_fused", len(pr), ops.ptr_array([x[0] for x in pr]),
-                 ops.ptr_array([self._packed(x[1], c) for x in pr]), ops.ptr_array([x[1].enc(c) for x in pr]),
-                 ops.ptr_array([x[2] for x in pr]), ops.int_array([x[4] for x in pr]), H, W, ops.stream())
-            n_total += sum(x[4] for x in pr)
+            if self._fused_ok(c):
+                pr = self._all_problems(c)
+                self._launch_fused(c, pr)
+                n_total += sum(x[4] for x in pr)
         return n_total
 
     def _encode_all(self):
+        """Every encoder forward of the step: ONE fused launch per camera (27*B images at TACORL shapes:
+        frozen LMP window, actor(obs, goal, next), q1, q2 and both targets), activations saved only for the
+        problems that have a backward; the per-layer path covers fp32 mode / images too large for LDS."""
         xd = BF16 if self.img_dtype == torch.bfloat16 else F32
         for c in self.cams:
             H, W = self.hw[c]
-            fused = self._fused_ok(c)
-            gen = [(self._img_ptr(c, r0), net, self.enc_out[(k, c)], self.enc_act[(k, c)], n)
-                   for k, net, r0, n in self.enc_probs if (k in self.GRAD_PROBS or not fused)]
-            if not fused:
-                gen += [(x["img"], x["net"], x["out"], x["act"], x["n"]) for x in self.extra_enc if x["cam"] == c]
-            call("tacorl_encoder_fwd", len(gen), ops.ptr_array([x[0] for x in gen]),
-                 ops.ptr_array([x[1].enc(c) for x in gen]), ops.ptr_array([x[2] for x in gen]),
-                 ops.ptr_array([x[3] for x in gen]), ops.int_array([x[4] for x in gen]), H, W, xd, self.compute,
-                 ops.stream())
-            if fused:
-                pr = self._nograd_problems(c)
+            pr = self._all_problems(c)
+            if self._fused_ok(c):
                 nets = {id(x[1]): x[1] for x in pr}
                 call("tacorl_encoder_pack_weights", len(nets), ops.ptr_array([n_.enc(c) for n_ in nets.values()]),
                      ops.ptr_array([self._packed(n_, c) for n_ in nets.values()]), ops.stream())
-                call("tacorl_encoder_fwd_fused", len(pr), ops.ptr_array([x[0] for x in pr]),
-                     ops.ptr_array([self._packed(x[1], c) for x in pr]), ops.ptr_array([x[1].enc(c) for x in pr]),
-                     ops.ptr_array([x[2] for x in pr]), ops.int_array([x[4] for x in pr]), H, W, ops.stream())
+                self._launch_fused(c, pr)
+            else:
+                call("tacorl_encoder_fwd", len(pr), ops.ptr_array([x[0] for x in pr]),
+                     ops.ptr_array([x[1].enc(c) for x in pr]), ops.ptr_array([x[2] for x in pr]),
+                     ops.ptr_array([x[3] for x in pr]), ops.int_array([x[4] for x in pr]), H, W, xd, self.compute,
+                     ops.stream())
 
     def _assemble_states(self):
         B = self.B

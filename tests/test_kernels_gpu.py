@@ -327,11 +327,19 @@ def test_encoder_fused_forward(H, W):
         acts.append(torch.empty(ops.encoder_act_layout(k, H, W)[1], device=dev))
         packed.append(torch.empty(_lib.lib().tacorl_encoder_fused_wpk_bytes(), dtype=torch.uint8, device=dev))
     ops.call("tacorl_encoder_pack_weights", len(n), ops.ptr_array(flats), ops.ptr_array(packed), ops.stream())
+    acts_f = [torch.full_like(a, float("nan")) for a in acts]
     ops.call("tacorl_encoder_fwd_fused", len(n), ops.ptr_array(imgs), ops.ptr_array(packed), ops.ptr_array(flats),
-             ops.ptr_array(outs_f), ops.int_array(n), H, W, ops.stream())
+             ops.ptr_array(outs_f), ops.ptr_array([acts_f[0], None, acts_f[2]]), ops.int_array(n), H, W, ops.stream())
     ops.encoder_fwd(imgs, flats, outs_g, acts, H, W, 1)
     torch.cuda.synchronize()
     for i in range(len(n)):
         assert torch.isfinite(outs_f[i]).all()
         assert relerr(outs_f[i], outs_g[i]) < 1e-2, ("vs generic bf16", relerr(outs_f[i], outs_g[i]))
         assert relerr(outs_f[i], refs[i]) < TOL_BF16, ("vs oracle", relerr(outs_f[i], refs[i]))
+    for i in (0, 2):  # saved activations (what tacorl_encoder_bwd reads) equal the per-layer path's
+        offs, tot = ops.encoder_act_layout(n[i], H, W)
+        for j, name in enumerate(["y1", "y2", "y3", "softargmax", "fc1"]):
+            end = offs[j + 1] if j + 1 < 5 else tot
+            a, b = acts_f[i][offs[j]:end], acts[i][offs[j]:end]
+            assert torch.isfinite(a).all(), name
+            assert relerr(a, b) < 1e-2, (name, relerr(a, b))
