@@ -14,7 +14,7 @@ for k in n:
 ops.call("tacorl_encoder_pack_weights", len(n), ops.ptr_array(flats), ops.ptr_array(packed), ops.stream())
 def run():
     ops.call("tacorl_encoder_fwd_fused", len(n), ops.ptr_array(imgs), ops.ptr_array(packed), ops.ptr_array(flats),
-             ops.ptr_array(outs), ops.int_array(n), H, W, ops.stream())
+             ops.ptr_array(outs), None, ops.int_array(n), H, W, ops.stream())
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -332,7 +332,6 @@ class ACEngine:
                                self.grip_pi if self.dg else None, 1, B, Ac)
         ops.tanh_normal_sample(head_next, self.HD, nz["eps_next"], g("g_next"), False, self.act_next, 0, A,
                                self.logp_next, None, 1, B, Ac)
-        ops.copy_cols(self.action, 0, A, self.acts_main, 0, A, B, A)
         ops.uniform_actions(nz["u_rand"], self.acts_main, B * A, A, n * B, A, self.dg)
         ops.tanh_normal_sample(head_cur, self.HD, nz["eps_cur"], g("g_cur"), False, self.acts_main, (1 + n) * B * A, A,
                                self.logp_cur, None, n, B, Ac)
@@ -349,7 +348,12 @@ class ACEngine:
         if optimize:
             ops.adam_step(self.log_alpha.param, self.log_alpha.grad, self.log_alpha.m, self.log_alpha.v,
                           hp["actor_lr"], 0.0, self.log_alpha.step)
-        # Q inputs: [S | action]
+        # Q inputs: [S | action]; the data action is read here first (phase_a does not need it, so a caller
+        # may still be producing it - TACORL's plan recognition runs beside phase_a): wait for it if asked
+        if getattr(self, "action_ready", None) is not None:
+            torch.cuda.current_stream().wait_event(self.action_ready)
+            self.action_ready = None
+        ops.copy_cols(self.action, 0, A, self.acts_main, 0, A, B, A)
         for k in ("q1", "q2"):
             ops.copy_cols(self.S[k], 0, self.lds, self.XQ[k], 0, self.ldq, self.R, self.E, src_row_mod=B)
             ops.copy_cols(self.acts_main, 0, A, self.XQ[k], self.E, self.ldq, self.R, A)
@@ -376,7 +380,28 @@ class ACEngine:
              float(hp["discount"]), float(hp["reward_scale"]), float(hp["temp"]), float(hp["cons_w"]),
              float(hp["gap"]), int(hp["deterministic_backup"]), gs, ptr(lap.grad), ptr(self.logs), ptr(self.cql_ws),
              self.cql_ws.numel(), ops.stream())
-        # ---- actor backward
+        # ---- actor backward: independent of the critic backward until the goal encoders, so it runs on a
+        # side stream (a parallel branch of the captured graph); both are chains of small launches that
+        # fill only part of the chip on their own
+        if getattr(self, "_bwd_stream", None) is None:
+            self._bwd_stream = torch.cuda.Stream(device=self.dev)
+        main_stream = torch.cuda.current_stream()
+        self._bwd_stream.wait_stream(main_stream)
+        with torch.cuda.stream(self._bwd_stream):
+            self._actor_backward(bc_phase, head_cur, q1p, q2p, gs)
+        # ---- critic backward through the Q MLPs; sum the broadcast embedding gradient over samples
+        ops.mlp_bwd([self.XQ["q1"], self.XQ["q2"]], self.ldq, [self.q1.head(), self.q2.head()],
+                    [self.qact["q1"], self.qact["q2"]], [self.dq["q1"], self.dq["q2"]], 1,
+                    [self.q1.head(self.q1.grad), self.q2.head(self.q2.grad)], [self.dXQ["q1"], self.dXQ["q2"]],
+                    self.ldq, [self.R, self.R], qd, qa, self.compute)
+        for k in ("q1", "q2"):
+            ops.reduce_rows_mod(self.dXQ[k], 0, self.ldq, self.dS[k], 0, self.lds, B, self.E, 3 * n + 1)
+        main_stream.wait_stream(self._bwd_stream)
+        self._encoders_backward()
+
+    def _actor_backward(self, bc_phase, head_cur, q1p, q2p, gs):
+        B, A, Ac, nz = self.B, self.A, self.Ac, self.noise
+        qd, qa = self.q1.head_dims, self.q1.head_acts
         if bc_phase:
             call("tacorl_actor_head_bwd", ptr(head_cur), self.HD, ptr(nz["eps_pi"]), ptr(self.logp_pi), None, None, 0,
                  ptr(self.action), A, ptr(self.grip_pi) if self.dg else None, ptr(self.log_alpha.param), gs,
@@ -386,22 +411,19 @@ class ACEngine:
                  ptr(self.dq_pi["q1"]), ptr(self.dq_pi["q2"]), gs, ptr(self.logs), ops.stream())
             ops.mlp_bwd([self.XQpi["q1"], self.XQpi["q2"]], self.ldq, [self.q1.head(), self.q2.head()],
                         [self.qact_pi["q1"], self.qact_pi["q2"]], [self.dq_pi["q1"], self.dq_pi["q2"]], 1,
-                        [None, None], [self.dXQpi["q1"], self.dXQpi["q2"]], self.ldq, [B, B], qd, qa, self.compute)
+                        [None, None], [self.dXQpi["q1"], self.dXQpi["q2"]], self.ldq, [B, B], qd, qa, self.compute,
+                        ws_tag="mlp_bwd_actor")
             call("tacorl_actor_head_bwd", ptr(head_cur), self.HD, ptr(nz["eps_pi"]), ptr(self.logp_pi),
                  ops._at(self.dXQpi["q1"], self.E), ops._at(self.dXQpi["q2"], self.E), self.ldq, None, 0,
                  ptr(self.grip_pi) if self.dg else None, ptr(self.log_alpha.param), gs, ptr(self.d_head), B, Ac,
                  int(self.dg), ptr(self.logs), ops.stream())
         ops.mlp_bwd([self.S["a"]], self.lds, [self.actor.head()], [self.pact["a"]], [self.d_head], self.HD,
                     [self.actor.head(self.actor.grad)], [self.dS["a"]], self.lds, [B], self.actor.head_dims,
-                    self.actor.head_acts, self.compute)
-        # ---- critic backward through the Q MLPs; sum the broadcast embedding gradient over samples
-        ops.mlp_bwd([self.XQ["q1"], self.XQ["q2"]], self.ldq, [self.q1.head(), self.q2.head()],
-                    [self.qact["q1"], self.qact["q2"]], [self.dq["q1"], self.dq["q2"]], 1,
-                    [self.q1.head(self.q1.grad), self.q2.head(self.q2.grad)], [self.dXQ["q1"], self.dXQ["q2"]],
-                    self.ldq, [self.R, self.R], qd, qa, self.compute)
-        for k in ("q1", "q2"):
-            ops.reduce_rows_mod(self.dXQ[k], 0, self.ldq, self.dS[k], 0, self.lds, B, self.E, 3 * n + 1)
-        # ---- goal encoders (3 nets, one batch), then the encoders
+                    self.actor.head_acts, self.compute, ws_tag="mlp_bwd_actor")
+
+    def _encoders_backward(self):
+        """Goal encoders (3 nets, one batch), then the three encoders (actor(obs, goal), q1, q2)."""
+        B = self.B
         nets = {"a": self.actor, "q1": self.q1, "q2": self.q2}
         ks = ["a", "q1", "q2"]
         ops.mlp_bwd([self.gin[k] for k in ks], self.G, [nets[k].genc() for k in ks], [self.gact[k] for k in ks],

@@ -137,17 +137,53 @@ class TACORL(CQL_Offline):
     def _device_front(self, B, T, hw, optimize, with_ad=True):
         """Graph-capturable: all encoders (frozen LMP + actor/critics/targets) -> plan recognition -> plan ->
         AD loss -> first phase of the CQL update (up to the alpha gradient)."""
-        self.engine._encode_all()
-        for j, c in enumerate(self.plan_recognition_modalities):
-            ops.copy_cols(self.f_out[c], 0, 32, self.pr_in, 32 * j, self.pr_in.shape[1], B * T, 32)
-        head = self.pr.forward(self.pr_in, self.pr_in.shape[1], B, T, self.compute)
-        call("tacorl_pr_sample", ptr(head), ptr(self.eps_pr), ptr(self.plan), None, None, B, self.action_dim,
-             float(self.pr.min_std), ops.stream())
-        if with_ad:
-            # compute_action_decoder_update (tacorl.py:206-233): loss logged, stepped if fine-tuning
-            self.ad.loss_step(self, self.acts, self.plan, B, T, optimize and self.finetune_action_decoder)
-        self.engine.load_transition(self.plan, self.reward, self.reward)
-        self.engine.phase_a(encoded=True)
+        e = self.engine
+        e._encode_all()
+        # Plan recognition -> plan -> (action-decoder loss) only need the frame embeddings; the first phase of
+        # the CQL update does not need the plan.  They run as parallel branches of the step's graph:
+        #   side stream 1: PR transformer -> sampled plan -> RL "action"/reward staged -> event action_ready
+        #   side stream 2 (forked after the plan): frozen action-decoder forward + loss (logging only)
+        #   main stream  : policy / sampling / alpha (phase_a); phase_b waits for action_ready
+        if getattr(self, "_pr_stream", None) is None:
+            self._pr_stream, self._side_stream = torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream()
+        self._ad_join = None
+        ad_on_side = with_ad and not (optimize and self.finetune_action_decoder)
+        self._pr_stream.wait_stream(main)
+        with torch.cuda.stream(self._pr_stream):
+            for j, c in enumerate(self.plan_recognition_modalities):
+                ops.copy_cols(self.f_out[c], 0, 32, self.pr_in, 32 * j, self.pr_in.shape[1], B * T, 32)
+            head = self.pr.forward(self.pr_in, self.pr_in.shape[1], B, T, self.compute)
+            call("tacorl_pr_sample", ptr(head), ptr(self.eps_pr), ptr(self.plan), None, None, B, self.action_dim,
+                 float(self.pr.min_std), ops.stream())
+            e.load_transition(self.plan, self.reward, self.reward)
+            ready = torch.cuda.Event()
+            ready.record(self._pr_stream)
+            if with_ad and not ad_on_side:
+                # fine-tuning: loss + BPTT + Adam (+ all-reduce) stay in line on this branch
+                self.ad.loss_step(self, self.acts, self.plan, B, T, True)
+        if ad_on_side:
+            # compute_action_decoder_update (tacorl.py:206-233), frozen decoder: 30 small dependent GEMMs that each
+            # fill a fraction of the chip -> their own branch, joined at the end of the step
+            self._side_stream.wait_event(ready)
+            with torch.cuda.stream(self._side_stream):
+                self.ad.loss_step(self, self.acts, self.plan, B, T, False)
+            self._ad_join = self._side_stream
+        e.action_ready = ready
+        e.phase_a(encoded=True)
+        segmented = self.world_size > 1 or getattr(self, "_force_graph_split", False) or not self._use_graph
+        if with_ad and not ad_on_side:
+            main.wait_stream(self._pr_stream)
+        if segmented:
+            # every segment must be self-contained (its graph is replayed on its own)
+            main.wait_stream(self._pr_stream)
+            e.action_ready = None
+            self._join_ad()
+
+    def _join_ad(self):
+        if getattr(self, "_ad_join", None) is not None:
+            torch.cuda.current_stream().wait_stream(self._ad_join)
+            self._ad_join = None
 
     def get_pr_latent_plan(self, batch, noise=None, nchw=True):
         """reference tacorl.py:235-252 (no_grad / eval): returns the sampled latent plan (device tensor)."""
@@ -179,8 +215,12 @@ class TACORL(CQL_Offline):
         if with_ad and optimize and self.finetune_action_decoder and self.world_size > 1 and self._use_graph:
             raise NotImplementedError("hipGraph + multi-GPU + action-decoder fine-tuning: its extra all-reduce sits "
                                       "inside the first segment; run this combination eagerly")
+        def tail():
+            e.phase_c(optimize)
+            self._join_ad()
+
         self._run_segments(key, [lambda: self._device_front(B, T, hw, optimize, with_ad),
-                                 lambda: e.phase_b(bc, optimize), lambda: e.phase_c(optimize)],
+                                 lambda: e.phase_b(bc, optimize), tail],
                            [e.allreduce_alpha, e.allreduce_grads])
         self._publish_logs(log_type, extra=("action_loss",) if with_ad else ())
 

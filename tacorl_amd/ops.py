@@ -102,9 +102,11 @@ def mlp_fwd(xs, ldx, params, acts_buf, M, dims, acts, compute=F32):
          len(dims) - 1, int_array(dims), int_array(acts), compute, stream())
 
 
-def mlp_bwd(xs, ldx, params, acts_buf, d_outs, ldo, grads, d_xs, ldd, M, dims, acts, compute=F32, accumulate=False):
+def mlp_bwd(xs, ldx, params, acts_buf, d_outs, ldo, grads, d_xs, ldd, M, dims, acts, compute=F32, accumulate=False,
+            ws_tag="mlp_bwd"):
+    """ws_tag: scratch buffer name - calls that may overlap on different streams need different tags."""
     nb = L.lib().tacorl_mlp_bwd_ws_bytes(len(xs), int_array(M), len(dims) - 1, int_array(dims))
-    ws = workspace(nb, acts_buf[0].device, "mlp_bwd")
+    ws = workspace(nb, acts_buf[0].device, ws_tag)
     call("tacorl_mlp_bwd", len(xs), ptr_array(xs), ldx, ptr_array(params), ptr_array(acts_buf), ptr_array(d_outs), ldo,
          ptr_array(grads), ptr_array(d_xs) if d_xs is not None else None, ldd, int_array(M), len(dims) - 1,
          int_array(dims), int_array(acts), compute, int(accumulate), ptr(ws), ws.numel(), stream())
