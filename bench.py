@@ -63,8 +63,9 @@ def build_module(dev, compute, T, world, ad_every=1):
 
 
 def time_encoder_fwd(mod, B, H, W, iters=20):
-    """HIP-event timing of the encoder-forward launches on the stream they run on (torch's current
-    stream): the 6-problem batch the step issues (11*B images) - the roofline kernel."""
+    """HIP-event timing of the step's encoder-forward launch on the stream it runs on (torch's current
+    stream): ONE encoder_fused_kernel launch over all 27*B encoder images of the step (frozen LMP B*T
+    frames, actor/q1/q2 over [obs;goal], actor(next) and both targets) - the roofline kernel."""
     e = mod.engine
     fused = all(e._fused_ok(c) for c in e.cams)
     fn = e.encode_fused_only if fused else e._encode_all
@@ -82,6 +83,20 @@ def time_encoder_fwd(mod, B, H, W, iters=20):
     if not fused:
         n_img = sum(n for _, _, _, n in e.enc_probs) + sum(x["n"] for x in e.extra_enc)
     return ms, n_img, fused
+
+
+def measured_traffic(n_img, fused, dtype):
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes
+    (profiles/r01_fused_traffic.json: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of this
+    very command, gfx950 correction applied).  null when this run's launch is not the measured one."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_fused_traffic.json")) as f:
+            m = json.load(f)["bench_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+    if fused and dtype == "bf16" and m["images_per_launch"] == n_img:
+        return m["hbm_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(mod, batch_cpu, noise_cpu, B, budget_s=25.0):
@@ -191,9 +206,11 @@ def main():
                                                f"every {a.ad_every} steps (logging cadence)"), "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
                        "samples_per_s": round(world * B / (ms_step * 1e-3), 1), "losses_finite": finite},
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(tflops / peak, 4), "traffic": None,
-                         "kernel": ("encoder_fused_kernel: the step's no-grad LMPVisionEncoder forward launch "
-                                    "(frozen LMP over B*T frames + actor(next) + both targets)") if fused else
+                         "frac": round(tflops / peak, 4), "traffic": measured_traffic(n_img, fused, a.dtype),
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
+                         "kernel": ("encoder_fused_kernel: the step's single LMPVisionEncoder forward launch "
+                                    "(all 27*B encoder images: frozen LMP B*T frames, actor/q1/q2 over "
+                                    "[obs;goal], actor(next), both targets)") if fused else
                                    "LMPVisionEncoder forward, per-layer kernels (tacorl_encoder_fwd)",
                          "images_per_launch": n_img, "avg_ms": round(enc_ms, 4)},
         }
