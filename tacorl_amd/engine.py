@@ -210,14 +210,14 @@ class ACEngine:
         H, W = self.hw[cam]
         return self.X3[cam].data_ptr() + first_row * H * W * 3 * self.X3[cam].element_size()
 
-    # Encoder problems that need saved activations (a backward follows) go through the per-layer path;
-    # the no-grad ones (next-obs actor pass, both targets, and any externally registered problem such as
-    # TACORL's frozen B*T-frame encoder) go through the fused single-launch kernel when it applies
-    # (bf16 images + bf16 MFMA + image small enough for LDS).
+    # Every encoder problem of a camera goes through the fused single-launch kernel when it applies
+    # (bf16 images + bf16 MFMA + a templated camera geometry); the ones a backward follows (GRAD_PROBS)
+    # also get their activations saved by that launch.  Otherwise: the per-layer path.
     GRAD_PROBS = ("a_og", "q1", "q2")
+    use_fused = True  # tests flip this to compare the fused launch against the per-layer path
 
     def _fused_ok(self, c):
-        if self.compute != BF16 or self.img_dtype != torch.bfloat16:
+        if not self.use_fused or self.compute != BF16 or self.img_dtype != torch.bfloat16:
             return False
         return bool(ops.L.lib().tacorl_encoder_fused_supported(*self.hw[c]))
 

@@ -1,0 +1,165 @@
+"""Full-size checks (BASELINE configs[1]: B=256, T=16, 84x84, latent 16, n=4, Q phase) of the TACORL
+step on the GPU: direct comparison with the oracle in exact-fp32 mode, plus the size-independent
+properties the step offers - run-to-run bit determinism, batch-mean linearity of the critic gradients
+(full batch == mean of the two half batches, the property the data-parallel sharding relies on), and
+fused-launch == per-layer encoder in bf16 mode."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+
+B, T, H, W = 256, 16, 84, 84
+
+
+def _mod(compute, graph=False, batch=B):
+    import bench
+
+    torch.manual_seed(0)
+    mod = bench.build_module(torch.device("cuda:0"), compute, T, 1)
+    if graph:
+        mod.enable_graph()
+    return mod
+
+
+def _batch(n=B, seed=77):
+    import bench
+
+    return bench.synth_batch(n, T, H, W, torch.device("cuda:0"), seed)
+
+
+def _logs(mod):
+    torch.cuda.synchronize()
+    return {k.split("/", 1)[1]: float(v) for k, v in mod.logged.items()}
+
+
+def _noise(mod):
+    nz = {k: v.clone() for k, v in mod.engine.noise.items()}
+    nz["eps_pr"] = mod.eps_pr.clone()
+    return nz
+
+
+def _oracle_inputs(mod):
+    from oracle import tacorl_oracle as O
+
+    cams = ["rgb_static"]
+    spec = O.ACSpec(cams=cams, goal_cams=cams, action_dim=16, n=4, discount=0.95, actor_lr=1e-4, critic_lr=3e-4,
+                    deterministic_backup=True, reward_scale=10.0, bc_epochs=5, with_lagrange=True,
+                    discrete_gripper=False, target_entropy=-7.0, finetune_action_decoder=False, ac_cams=cams,
+                    pr_cams=cams)
+    skip = ("one_hot_embedding_eye", "ones", "gripper_bounds", "action_max_bound", "action_min_bound")
+    P = {k: v.detach().cpu().clone().contiguous() for k, v in mod.state_dict().items()
+         if v.dtype == torch.float32 and not any(k.endswith(s) for s in skip)}
+    O.require_grad_(P, frozen_prefixes=("perceptual_encoder.", "plan_recognition."))
+    return O, spec, P
+
+
+def _cpu(x):
+    if isinstance(x, dict):
+        return {k: _cpu(v) for k, v in x.items()}
+    return x.cpu() if torch.is_tensor(x) else x
+
+
+def test_fullsize_f32_step_matches_oracle():
+    """B=256 exact-fp32 step vs the CPU oracle on the same parameters, batch and noise: every logged
+    loss and the sampled latent plans within 1e-4 rel (north-star tolerance), gradients within 1e-3."""
+    mod = _mod("f32")
+    O, spec, P = _oracle_inputs(mod)
+    opts = O.make_opts(P, spec)
+    batch = _batch()
+    mod.logged = {}
+    mod.training_step(batch)
+    got, nz = _logs(mod), _cpu(_noise(mod))
+    ologs, oplan, ograds = O.tacorl_step(P, opts, spec, _cpu(batch), nz, 5)
+    bad = []
+    for k, v in ologs.items():
+        v = float(v)
+        if k in got and abs(got[k] - v) > 1e-4 * max(abs(v), 1e-3):
+            bad.append(f"{k}: hip {got[k]:.8g} oracle {v:.8g}")
+    assert len(set(ologs) & set(got)) >= 8, (sorted(ologs), sorted(got))
+    e = (mod.plan.cpu() - oplan).norm() / oplan.norm()
+    if e > 1e-4:
+        bad.append(f"latent plan relerr {e:.3g}")
+    grads = mod.named_gradients()
+    for k, g in ograds.items():
+        if k in grads and g is not None:
+            d = (grads[k].cpu().reshape(g.shape) - g).norm() / max(g.norm().item(), 1e-12)
+            if d > 1e-3 and g.norm() > 1e-6:
+                bad.append(f"grad {k}: relerr {d:.3g}")
+    assert not bad, "\n".join(bad[:30])
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_fullsize_bf16_bit_deterministic(graph):
+    """Two runs from the same seed (three optimiser steps each, side streams and graph branches
+    included) end in bit-identical parameters: no atomics, fixed reduction orders."""
+    ends = []
+    for _ in range(2):
+        mod = _mod("bf16", graph)
+        batch = _batch()
+        torch.manual_seed(5)
+        for _ in range(3 if not graph else 5):
+            mod.training_step(batch)
+        torch.cuda.synchronize()
+        ends.append({k: v.detach().clone() for k, v in mod.state_dict().items()})
+        logs = mod.engine.metrics()
+        assert all(v == v for v in logs.values())
+    diff = [k for k in ends[0] if not torch.equal(ends[0][k], ends[1][k])]
+    assert not diff, diff[:10]
+
+
+def test_fullsize_critic_grads_are_batch_means():
+    """Gradient linearity at full size: critic gradients of the 256-sample step equal the mean of the
+    two 128-sample half steps (same parameters, noise sliced by sample).  With deterministic_backup
+    the critic loss does not read alpha, so this holds to fp32 re-association error."""
+    from tacorl_amd.dist import shard_batch, shard_noise
+
+    full = _mod("f32")
+    batch = _batch()
+    full.training_step(batch)
+    torch.cuda.synchronize()
+    nz = _noise(full)
+    gfull = {k: v.clone() for k, v in full.named_gradients().items() if k.startswith(("q1.", "q2."))}
+    acc = {k: torch.zeros_like(v) for k, v in gfull.items()}
+    for r in range(2):
+        half = _mod("f32")
+        half.training_step(shard_batch(batch, r, 2), noise=shard_noise(nz, r, 2, 4))
+        torch.cuda.synchronize()
+        for k, v in half.named_gradients().items():
+            if k in acc:
+                acc[k] += 0.5 * v
+        del half
+    bad = []
+    for k, g in gfull.items():
+        d = (acc[k] - g).norm() / max(g.norm().item(), 1e-12)
+        if d > 5e-4 and g.norm() > 1e-6:
+            bad.append(f"{k}: {d:.3g}")
+    assert gfull and not bad, bad[:20]
+
+
+def test_fullsize_fused_encoder_equals_per_layer():
+    """bf16 mode: the single fused encoder launch (27*B images) and the per-layer kernels give the same
+    step - same bf16 operand rounding, different fp32 accumulation order only."""
+    res = []
+    for fused in (True, False):
+        mod = _mod("bf16")
+        mod.engine.use_fused = fused
+        batch = _batch()
+        torch.manual_seed(9)
+        mod.logged = {}
+        mod.training_step(batch)
+        res.append((_logs(mod), mod.plan.clone(), {k: v.clone() for k, v in mod.named_gradients().items()}))
+    (la, pa, ga), (lb, pb, gb) = res
+    assert torch.equal(pa, pb) or (pa - pb).norm() / pb.norm() < 2e-3
+    bad = [f"{k}: {la[k]:.6g} vs {lb[k]:.6g}" for k in la if abs(la[k] - lb[k]) > 3e-3 * max(abs(lb[k]), 1e-2)]
+    for k in ga:
+        n = gb[k].norm().item()
+        if n > 1e-6:
+            cos = torch.dot(ga[k].flatten(), gb[k].flatten()).item() / (ga[k].norm().item() * n)
+            if cos < 0.995:
+                bad.append(f"grad {k}: cosine {cos:.4f}")
+    assert not bad, "\n".join(bad[:20])
