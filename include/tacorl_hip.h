@@ -95,6 +95,17 @@ int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const void* cons
                              const float* const* params, float* const* out, float* const* act,
                              const int* n_img, int H, int W, tacorl_stream_t stream);
 
+/* Backward twin of the fused forward (same preconditions: bf16 NHWC images, bf16 MFMA, a geometry
+ * tacorl_encoder_fused_supported() accepts; at most 4 problems): FC tail and soft-argmax as
+ * tacorl_encoder_bwd, the three convolutions' dgrad/wgrad as per-image LDS-resident kernels. Same
+ * argument meaning as tacorl_encoder_bwd. Replaces autograd through
+ * networks/vision/lmp_vision_network.py:32-66. */
+size_t tacorl_encoder_bwd_fused_ws_bytes(int nprob, const int* n_img, int H, int W);
+int tacorl_encoder_bwd_fused(int nprob, const void* const* img, const float* const* params,
+                             const float* const* act, const float* const* d_out,
+                             float* const* grads, const int* n_img, int H, int W, int accumulate,
+                             void* ws, size_t ws_bytes, tacorl_stream_t stream);
+
 /* ---- MLP = chain of Linear(dims[l] -> dims[l+1]) + acts[l]  ------------------------ */
 /* Parameter block: for each layer W[out][in] then b[out], each 4-float aligned. */
 long tacorl_mlp_param_layout(int n_layers, const int* dims, long* w_off, long* b_off);
@@ -124,6 +135,10 @@ int tacorl_pack_images(const float* src, long img_pitch, int src_nchw, void* dst
  * embeddings instead of images (reference utils/misc.py:132-153) and torch.cat plumbing. */
 int tacorl_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols,
                      int src_row_mod, int accumulate, tacorl_stream_t stream);
+/* n <= 32 mutually independent tacorl_copy_cols in one launch (no copy may read what another writes). */
+int tacorl_copy_cols_batch(int n, const float* const* src, const int* ld_src, float* const* dst,
+                           const int* ld_dst, const int* rows, const int* cols,
+                           const int* src_row_mod, const int* accumulate, tacorl_stream_t stream);
 /* out[b][c] = sum_{j<reps} in[j*B+b][c] : gradient of that broadcast. */
 int tacorl_reduce_rows_mod(const float* in, int ld_in, float* out, int ld_out, int B, int cols,
                            int reps, tacorl_stream_t stream);

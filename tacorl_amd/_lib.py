@@ -56,6 +56,8 @@ _SIGS = {
     "tacorl_encoder_fused_supported": (_i, [_i, _i]),
     "tacorl_encoder_pack_weights": (_i, [_i, _p, _p, _p]),
     "tacorl_encoder_fwd_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "tacorl_encoder_bwd_fused_ws_bytes": (_sz, [_i, _p, _i, _i]),
+    "tacorl_encoder_bwd_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "tacorl_mlp_param_layout": (_l, [_i, _p, _p, _p]),
     "tacorl_mlp_act_layout": (_l, [_i, _i, _p, _p, _p, _p]),
     "tacorl_mlp_fwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _p, _i, _p]),
@@ -63,6 +65,7 @@ _SIGS = {
     "tacorl_mlp_bwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _sz, _p]),
     "tacorl_pack_images": (_i, [_p, _l, _i, _p, _i, _i, _i, _i, _i, _p]),
     "tacorl_copy_cols": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "tacorl_copy_cols_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "tacorl_reduce_rows_mod": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "tacorl_uniform_actions": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "tacorl_tanh_normal_sample": (_i, [_p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _p]),

@@ -4,7 +4,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "../../include/tacorl_hip.h"
+#include "enc_bwd_fused.h"
 #include "functors.h"
 
 static thread_local char g_err[256] = "";
@@ -398,6 +401,74 @@ __global__ __launch_bounds__(256) void softargmax_bwd_kernel(const float* __rest
   dt = wave_sum(dt);
   if (c == 0) dtemp_part[img] = dt;
 }
+// Same math, all problems of the fused backward in one launch: one workgroup per image, a wave owns 16
+// channels x 4 pixel groups, every activation is read once and kept in registers.
+#define SAB_MAXI 13  // pixels per lane: conv3 output <= 52 pixels (the fused geometries have 49 / 16 / 8)
+struct SabArgs {
+  const float* y3[EBW_MAXP];
+  const float* temp[EBW_MAXP];
+  const float* sa[EBW_MAXP];
+  const float* d_sa[EBW_MAXP];
+  float* dz3[EBW_MAXP];
+  float* dtp[EBW_MAXP];
+  float* gtemp[EBW_MAXP];
+  int n[EBW_MAXP];
+};
+__global__ __launch_bounds__(256) void softargmax_bwd_batch_kernel(SabArgs a, int P, int OW) {
+  const int p = blockIdx.y, img = blockIdx.x;
+  if (img >= a.n[p]) return;
+  __shared__ float sh[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = 16 * w + (lane & 15), g = lane >> 4;
+  const float t = a.temp[p][0];
+  const float* q = a.y3[p] + (long)img * P * 64 + c;
+  float* o = a.dz3[p] + (long)img * P * 64 + c;
+  float v[SAB_MAXI];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < SAB_MAXI; k++) {
+    const int i = g + 4 * k;
+    v[k] = i < P ? q[i * 64] : 0.f;
+    if (i < P) mx = fmaxf(mx, v[k] / t);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float se = 0.f;
+#pragma unroll
+  for (int k = 0; k < SAB_MAXI; k++)
+    if (g + 4 * k < P) se += expf(v[k] / t - mx);
+  se += __shfl_xor(se, 16, 64);
+  se += __shfl_xor(se, 32, 64);
+  const float gx = a.d_sa[p][(long)img * 128 + 2 * c], gy = a.d_sa[p][(long)img * 128 + 2 * c + 1];
+  const float dot = gx * a.sa[p][(long)img * 128 + 2 * c] + gy * a.sa[p][(long)img * 128 + 2 * c + 1];
+  float dt = 0.f;
+#pragma unroll
+  for (int k = 0; k < SAB_MAXI; k++) {
+    const int i = g + 4 * k;
+    if (i < P) {
+      const float s = v[k] / t, pr = expf(s - mx) / se;
+      const float ds = pr * (gx * (float)(i % OW) + gy * (float)(i / OW) - dot);
+      dt -= ds * s / t;
+      o[i * 64] = v[k] > 0.f ? ds / t : 0.f;
+    }
+  }
+  dt = wave_sum(dt);
+  if (lane == 0) sh[w] = dt;
+  __syncthreads();
+  if (threadIdx.x == 0) a.dtp[p][img] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void sum_to_scalar_batch_kernel(SabArgs a, int accumulate) {
+  __shared__ float sh[4];
+  const int p = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < a.n[p]; i += 256) s += a.dtp[p][i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = sh[0] + sh[1] + sh[2] + sh[3];
+    *a.gtemp[p] = accumulate ? *a.gtemp[p] + v : v;
+  }
+}
 __global__ void sum_to_scalar_kernel(const float* __restrict__ part, int n, float* out, int accumulate) {
   __shared__ float sh[4];
   float s = 0.f;
@@ -556,6 +627,78 @@ extern "C" int tacorl_encoder_bwd(int nprob, const void* const* img, const float
     CHECK(k_conv_wgrad<__bf16>(nprob, img, (const float* const*)dz1, n_img, d.c1, g_w1, g_b1, accumulate, slab, slab_bytes, cd, st));
   else
     CHECK(k_conv_wgrad<float>(nprob, img, (const float* const*)dz1, n_img, d.c1, g_w1, g_b1, accumulate, slab, slab_bytes, cd, st));
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
+// ---- bf16 / bf16-image / templated-geometry variant: FC tail and soft-argmax as above, the three
+// convolutions' backward through the per-image LDS-resident kernels of encoder_bwd_fused.hip.
+static size_t enc_fc_slab_bytes(int nprob, long maxn) {
+  size_t a = wgrad_ws_bytes(nprob, 256, 32, maxn), b = wgrad_ws_bytes(nprob, 128, 256, maxn);
+  return ((a > b ? a : b) + 255) & ~(size_t)255;
+}
+extern "C" size_t tacorl_encoder_bwd_fused_ws_bytes(int nprob, const int* n_img, int H, int W) {
+  EncDims d;
+  if (!enc_dims(H, W, d) || !ebw_supported(H, W) || nprob < 1 || nprob > EBW_MAXP) return 0;
+  long tot = 0, maxn = 0;
+  for (int p = 0; p < nprob; p++) { tot += enc_bwd_scratch_layout(n_img[p], d, nullptr); maxn = n_img[p] > maxn ? n_img[p] : maxn; }
+  return (((size_t)tot * sizeof(float) + 255) & ~(size_t)255) + enc_fc_slab_bytes(nprob, maxn) + ebw_ws_bytes(nprob, n_img, H, W);
+}
+
+extern "C" int tacorl_encoder_bwd_fused(int nprob, const void* const* img, const float* const* params,
+                                        const float* const* act, const float* const* d_out, float* const* grads,
+                                        const int* n_img, int H, int W, int accumulate, void* ws, size_t ws_bytes,
+                                        tacorl_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  EncDims d;
+  if (!enc_dims(H, W, d) || !ebw_supported(H, W)) FAIL(TACORL_EINVAL, "encoder_bwd_fused: geometry %dx%d not instantiated", H, W);
+  if (nprob < 1 || nprob > EBW_MAXP) FAIL(TACORL_EINVAL, "encoder_bwd_fused: nprob %d (max %d)", nprob, EBW_MAXP);
+  if (ws_bytes < tacorl_encoder_bwd_fused_ws_bytes(nprob, n_img, H, W)) FAIL(TACORL_ENOMEM, "encoder_bwd_fused: workspace too small");
+  const int cd = TACORL_BF16;
+  long po[E_N];
+  tacorl_encoder_param_layout(po);
+  const float *fw1[GEMM_MAXP], *fw2[GEMM_MAXP], *y3[GEMM_MAXP], *sa[GEMM_MAXP], *h1[GEMM_MAXP];
+  float *d_h1[GEMM_MAXP], *d_sa[GEMM_MAXP], *dz3[GEMM_MAXP], *dtp[GEMM_MAXP];
+  float *g_fw1[GEMM_MAXP], *g_fb1[GEMM_MAXP], *g_fw2[GEMM_MAXP], *g_fb2[GEMM_MAXP];
+  EbwProblem pr[EBW_MAXP];
+  float* cur = (float*)ws;
+  long maxn = 0, tot_f = 0;
+  for (int p = 0; p < nprob; p++) {
+    long ao[5], so[6];
+    tacorl_encoder_act_layout(n_img[p], H, W, ao);
+    const long tot = enc_bwd_scratch_layout(n_img[p], d, so);
+    const float* P = params[p];
+    float* G = grads[p];
+    fw1[p] = P + po[E_FW1]; fw2[p] = P + po[E_FW2];
+    y3[p] = act[p] + ao[2]; sa[p] = act[p] + ao[3]; h1[p] = act[p] + ao[4];
+    d_h1[p] = cur + so[0]; d_sa[p] = cur + so[1]; dz3[p] = cur + so[2]; dtp[p] = cur + so[5];
+    cur += tot; tot_f += tot;
+    g_fw1[p] = G + po[E_FW1]; g_fb1[p] = G + po[E_FB1]; g_fw2[p] = G + po[E_FW2]; g_fb2[p] = G + po[E_FB2];
+    pr[p].img = img[p]; pr[p].y1 = act[p] + ao[0]; pr[p].y2 = act[p] + ao[1]; pr[p].dz3 = dz3[p];
+    pr[p].w2 = P + po[E_W2]; pr[p].w3 = P + po[E_W3];
+    pr[p].g_w1 = G + po[E_W1]; pr[p].g_b1 = G + po[E_B1]; pr[p].g_w2 = G + po[E_W2]; pr[p].g_b2 = G + po[E_B2];
+    pr[p].g_w3 = G + po[E_W3]; pr[p].g_b3 = G + po[E_B3]; pr[p].n = n_img[p];
+    maxn = n_img[p] > maxn ? n_img[p] : maxn;
+  }
+  unsigned char* slab = (unsigned char*)ws + (((size_t)tot_f * sizeof(float) + 255) & ~(size_t)255);
+  const size_t slab_bytes = enc_fc_slab_bytes(nprob, maxn);
+  unsigned char* cws = slab + slab_bytes;
+  const size_t cws_bytes = ws_bytes - (size_t)(cws - (unsigned char*)ws);
+  CHECK(k_linear_wgrad(nprob, h1, 256, d_out, 32, n_img, 256, 32, g_fw2, g_fb2, accumulate, slab, slab_bytes, cd, st));
+  CHECK(k_linear_dgrad(nprob, d_out, 32, fw2, d_h1, 256, h1, ACT_RELU, n_img, 32, 256, cd, st));
+  CHECK(k_linear_wgrad(nprob, sa, 128, (const float* const*)d_h1, 256, n_img, 128, 256, g_fw1, g_fb1, accumulate, slab, slab_bytes, cd, st));
+  CHECK(k_linear_dgrad(nprob, (const float* const*)d_h1, 256, fw1, d_sa, 128, nullptr, ACT_NONE, n_img, 256, 128, cd, st));
+  if (d.c3.OH * d.c3.OW > 4 * SAB_MAXI) FAIL(TACORL_EINVAL, "encoder_bwd_fused: conv3 output too large");
+  SabArgs sb{};
+  for (int p = 0; p < nprob; p++) {
+    sb.y3[p] = y3[p]; sb.temp[p] = params[p] + po[E_T]; sb.sa[p] = sa[p]; sb.d_sa[p] = d_sa[p]; sb.dz3[p] = dz3[p];
+    sb.dtp[p] = dtp[p]; sb.gtemp[p] = grads[p] + po[E_T]; sb.n[p] = n_img[p];
+  }
+  if (maxn > 0) {
+    hipLaunchKernelGGL(softargmax_bwd_batch_kernel, dim3((unsigned)maxn, nprob), dim3(256), 0, st, sb, d.c3.OH * d.c3.OW, d.c3.OW);
+    hipLaunchKernelGGL(sum_to_scalar_batch_kernel, dim3(nprob), dim3(256), 0, st, sb, accumulate);
+  }
+  const int rc = ebw_conv_backward(nprob, pr, H, W, accumulate, cws, cws_bytes, st);
+  if (rc != TACORL_OK) FAIL(rc, "encoder_bwd_fused: conv backward launch failed (%d)", rc);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 

@@ -1,0 +1,24 @@
+// Launchers of the per-image, LDS-resident convolution backward of the LMPVisionEncoder
+// (encoder_bwd_fused.hip), called from the tacorl_encoder_bwd_fused composite in dense_ops.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#define EBW_MAXP 4  // problems (networks) per call
+
+struct EbwProblem {
+  const void* img;   // [n][H][W][3] bf16
+  const float* y1;   // [n][OH1*OW1][32] saved conv1 output (post-ReLU, fp32)
+  const float* y2;   // [n][OH2*OW2][64]
+  const float* dz3;  // [n][OH3*OW3][64] gradient of conv3's pre-activation (fp32)
+  const float* w2;   // [64][4][4][32] fp32
+  const float* w3;   // [64][3][3][64] fp32
+  float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3;
+  int n;
+};
+
+bool ebw_supported(int H, int W);
+size_t ebw_ws_bytes(int nprob, const int* n_img, int H, int W);
+// dW1,db1,dW2,db2,dW3,db3 (+)= conv backward of every problem; deterministic (fixed reduction order).
+int ebw_conv_backward(int nprob, const EbwProblem* pr, int H, int W, int accumulate, void* ws, size_t ws_bytes,
+                      hipStream_t st);

@@ -1,0 +1,512 @@
+// Convolution backward of the LMPVisionEncoder (conv 8x8/4 -> 4x4/2 -> 3x3/1) as per-image,
+// LDS-resident MFMA kernels for gfx950 - the backward twin of encoder_fused.hip.
+//
+// Replaces, for bf16 compute + bf16 images + a templated camera geometry, the generic-GEMM conv
+// backward of tacorl_encoder_bwd (implicit-im2col gather loaders with per-element index arithmetic).
+// Reference semantics: autograd of nn.Conv2d/ReLU in networks/vision/lmp_vision_network.py:32-48.
+//
+//   dgrad  dX[y][x][ci] = sum_{ky,kx,co} dZ[(y-ky)/S][(x-kx)/S][co] W[co][ky][kx][ci], times ReLU mask.
+//          Per stride-phase class (y%S, x%S) a dense GEMM  M = class pixels, N = ci, K = taps x co.
+//          dZ of one image lives in LDS as NHWC with a zero halo, so every A fragment is one aligned
+//          ds_read_b128 at a compile-time offset; W^T fragments stay in registers for the whole kernel.
+//   wgrad  dW[co][tap] = sum_pixels dZ[pixel][co] * im2col[pixel][tap].  The reduction index of an MFMA is
+//          the lane-contiguous one, and it is the *pixel* here, so both operands are re-laid in LDS
+//          pixel-contiguous: dZ as planes [co][q], the input as space-to-depth planes
+//          [(y%S, x%S, ci)][Y*PW + X]; with q = oy*PW + ox (output rows padded to the plane pitch) the 8
+//          pixels a lane needs for tap (ky,kx,ci) are 8 consecutive plane elements at offset
+//          (ky/S)*PW + kx/S - an (unaligned) ds_read_b128.  Padded q carry dZ = 0.
+//          dW accumulates in registers across the images of a workgroup; one partial slab per workgroup,
+//          summed in fixed order by ebw_reduce_kernel (deterministic, no atomics).
+//   The bias gradient rides on the same MFMAs with an all-ones B fragment.
+#include "enc_bwd_fused.h"
+
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 512;  // 8 waves: 2 per SIMD
+constexpr int NW = NT / 64;
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+// smallest p >= need with p % 16 == 8: rows 16 B aligned and 16 consecutive rows spread over all LDS banks
+constexpr int pitch8(int need) { return (need % 16 <= 8) ? need - need % 16 + 8 : need - need % 16 + 24; }
+
+template <int KH_, int S_, int CI_, int CO_, int IH_, int IW_>
+struct ConvL {
+  static constexpr int KH = KH_, KW = KH_, S = S_, CI = CI_, CO = CO_, IH = IH_, IW = IW_;
+  static constexpr int OH = (IH - KH) / S + 1, OW = (IW - KW) / S + 1;
+  static constexpr int PH = (IH + S - 1) / S, PW = (IW + S - 1) / S;  // space-to-depth plane
+  static constexpr int KA = KH / S, KB = KW / S;                      // taps per stride-phase class
+  static constexpr int TAPS = KH * KW * CI;
+  static constexpr int NPL = CI * S * S;
+  static constexpr int KQ = (OH * PW + 31) / 32 * 32;  // padded pixel-reduction length
+  static constexpr int OFFMAX = (KA - 1) * PW + (KB - 1);
+  static constexpr int PLP = pitch8(cmax(PH * PW + 1, OFFMAX + KQ));  // plane pitch (elements)
+  static constexpr int DZP = KQ + 8;                                  // dZ plane pitch
+  static constexpr int MT = CO / 16, NTL = TAPS / 16;
+  static constexpr int SLABF = CO * TAPS + CO;  // floats per partial slab (dW | db)
+  // dgrad
+  static constexpr int HA = KA - 1, HB = KB - 1, R = PH + HA, C = PW + HB, PP = CO + 8;
+  static constexpr int KS = KA * KB * CO / 32;
+  static constexpr int NCLS = S * S, NTI = CI / 16;
+  static constexpr int MTC = (PH * PW + 15) / 16;
+  static constexpr int NCOMBO = NCLS * NTI;
+  static_assert(TAPS % 16 == 0 && CO % 32 == 0 && KH % S == 0, "tile shapes");
+};
+
+template <int H, int W>
+struct Geo {
+  using L1 = ConvL<8, 4, 3, 32, H, W>;
+  using L2 = ConvL<4, 2, 32, 64, L1::OH, L1::OW>;
+  using L3 = ConvL<3, 1, 64, 64, L2::OH, L2::OW>;
+};
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  const __bf16 x = (__bf16)a, y = (__bf16)b;
+  return (uint32_t)__builtin_bit_cast(unsigned short, x) | ((uint32_t)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ void load8(const __bf16* p, float (&v)[8]) {
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; j++) v[j] = (float)a[j];
+}
+__device__ __forceinline__ bf16x8 load8v(const float* p) {
+  float v[8];
+  load8(p, v);
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r[j] = (__bf16)v[j];
+  return r;
+}
+__device__ __forceinline__ bf16x8 load8v(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// ===================================================================== wgrad
+struct WgArgs {
+  const void* in[EBW_MAXP];
+  const void* dz[EBW_MAXP];
+  int n[EBW_MAXP];
+  float* slab;
+  int wpp;  // workgroups per problem
+};
+
+// dZ of one image, [OH*OW][CO] -> planes [CO][q = oy*PW + ox] (bf16 pairs), zero at padded q
+template <class L, class DzT>
+__device__ __forceinline__ void stage_dz(const DzT* __restrict__ dz, uint32_t* dzp32, int tid) {
+  constexpr int ND = L::KQ / 2, NCG = L::CO / 8;
+  for (int c = tid; c < ND * NCG; c += NT) {
+    const int cg = c / ND, d = c - cg * ND;
+    float v[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int q = 2 * d + h, oy = q / L::PW, ox = q - oy * L::PW;
+      if (oy < L::OH && ox < L::OW) {
+        load8(dz + (oy * L::OW + ox) * L::CO + 8 * cg, v[h]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[h][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) dzp32[(8 * cg + j) * (L::DZP / 2) + d] = pack2(v[0][j], v[1][j]);
+  }
+}
+
+// layer input of one image, NHWC fp32 [IH][IW][CI] -> space-to-depth planes (bf16 pairs)
+template <class L>
+__device__ __forceinline__ void stage_planes(const float* __restrict__ in, uint32_t* pl32, __bf16*, int tid) {
+  constexpr int NDP = (L::PH * L::PW + 1) / 2, NCG = L::CI / 8, NPH = L::S * L::S;
+  for (int c = tid; c < NPH * NCG * NDP; c += NT) {
+    const int d = c % NDP, t = c / NDP, cg = t % NCG, ph = t / NCG, sy = ph / L::S, sx = ph % L::S;
+    float v[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int pos = 2 * d + h, Y = pos / L::PW, X = pos - Y * L::PW, y = L::S * Y + sy, x = L::S * X + sx;
+      if (pos < L::PH * L::PW && y < L::IH && x < L::IW) {
+        load8(in + (y * L::IW + x) * L::CI + 8 * cg, v[h]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[h][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) pl32[(ph * L::CI + 8 * cg + j) * (L::PLP / 2) + d] = pack2(v[0][j], v[1][j]);
+  }
+}
+// bf16 NHWC image (CI = 3): coalesced raw copy into LDS, then LDS -> planes
+template <class L>
+__device__ __forceinline__ void stage_planes(const __bf16* __restrict__ in, uint32_t* pl32, __bf16* raw, int tid) {
+  constexpr int NCHUNK = L::IH * L::IW * L::CI * 2 / 16;
+  static_assert(L::IH * L::IW * L::CI * 2 % 16 == 0, "image bytes must be a multiple of 16");
+  for (int c = tid; c < NCHUNK; c += NT) reinterpret_cast<uint4*>(raw)[c] = reinterpret_cast<const uint4*>(in)[c];
+  __syncthreads();
+  constexpr int NDP = (L::PH * L::PW + 1) / 2;
+  const unsigned short* r16 = reinterpret_cast<const unsigned short*>(raw);
+  for (int c = tid; c < L::NPL * NDP; c += NT) {
+    const int d = c % NDP, pln = c / NDP, ci = pln % L::CI, ph = pln / L::CI, sy = ph / L::S, sx = ph % L::S;
+    uint32_t v[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int pos = 2 * d + h, Y = pos / L::PW, X = pos - Y * L::PW, y = L::S * Y + sy, x = L::S * X + sx;
+      v[h] = (pos < L::PH * L::PW && y < L::IH && x < L::IW) ? r16[(y * L::IW + x) * L::CI + ci] : 0u;
+    }
+    pl32[pln * (L::PLP / 2) + d] = v[0] | (v[1] << 16);
+  }
+}
+
+template <class L, class InT>
+constexpr size_t wgrad_lds_bytes() {
+  return ((size_t)L::NPL * L::PLP + (size_t)L::CO * L::DZP + (sizeof(InT) == 2 ? (size_t)L::IH * L::IW * L::CI : 0)) * 2;
+}
+
+// MG = M tiles (16 output channels each) per wave
+template <class L, class InT, class DzT, int MG>
+__global__ __launch_bounds__(NT) void ebw_wgrad_kernel(WgArgs a) {
+  constexpr int NGR = L::MT / MG, WPG = NW / NGR, UPW = L::NTL / WPG;
+  static_assert(L::MT % MG == 0 && NW % NGR == 0 && L::NTL % WPG == 0, "wave tiling");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* pl = reinterpret_cast<__bf16*>(smem);  // [NPL][PLP]
+  __bf16* dzp = pl + L::NPL * L::PLP;            // [CO][DZP]
+  __bf16* raw = dzp + L::CO * L::DZP;            // bf16-image layers only
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int p = blockIdx.x / a.wpp, j0 = blockIdx.x - p * a.wpp;
+  for (int e = tid; e < L::NPL * L::PLP / 2; e += NT) reinterpret_cast<uint32_t*>(pl)[e] = 0u;
+  const int mgrp = w % NGR, nslot = w / NGR;
+  int poff[UPW];
+#pragma unroll
+  for (int u = 0; u < UPW; u++) {
+    const int n = 16 * (nslot + u * WPG) + i, ky = n / (L::KW * L::CI), kx = (n / L::CI) % L::KW, ci = n % L::CI;
+    poff[u] = (((ky % L::S) * L::S + (kx % L::S)) * L::CI + ci) * L::PLP + (ky / L::S) * L::PW + kx / L::S + 8 * g;
+  }
+  f32x4 acc[UPW][MG], bacc[MG];
+#pragma unroll
+  for (int j = 0; j < MG; j++) {
+    bacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < UPW; u++) acc[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; j++) ones[j] = (__bf16)1.0f;
+  const int n_img = a.n[p];
+  const InT* in = reinterpret_cast<const InT*>(a.in[p]);
+  const DzT* dz = reinterpret_cast<const DzT*>(a.dz[p]);
+  const __bf16* arow = dzp + (16 * (mgrp * MG) + i) * L::DZP + 8 * g;
+  for (int img = j0; img < n_img; img += a.wpp) {
+    __syncthreads();  // previous image's fragments consumed (first pass: zero fill visible)
+    stage_dz<L, DzT>(dz + (long)img * L::OH * L::OW * L::CO, reinterpret_cast<uint32_t*>(dzp), tid);
+    stage_planes<L>(in + (long)img * L::IH * L::IW * L::CI, reinterpret_cast<uint32_t*>(pl), raw, tid);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < L::KQ / 32; s++) {
+      bf16x8 A[MG];
+#pragma unroll
+      for (int j = 0; j < MG; j++) A[j] = *reinterpret_cast<const bf16x8*>(arow + 16 * j * L::DZP + 32 * s);
+#pragma unroll
+      for (int u = 0; u < UPW; u++) {
+        bf16x8 B;
+        __builtin_memcpy(&B, pl + poff[u] + 32 * s, 16);  // 2-byte aligned: unaligned ds_read_b128
+#pragma unroll
+        for (int j = 0; j < MG; j++) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], B, acc[u][j], 0, 0, 0);
+      }
+      if (nslot == 0) {
+#pragma unroll
+        for (int j = 0; j < MG; j++) bacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], ones, bacc[j], 0, 0, 0);
+      }
+    }
+  }
+  float* sl = a.slab + (long)blockIdx.x * L::SLABF;
+#pragma unroll
+  for (int j = 0; j < MG; j++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int co = 16 * (mgrp * MG + j) + 4 * g + r;
+#pragma unroll
+      for (int u = 0; u < UPW; u++) sl[co * L::TAPS + 16 * (nslot + u * WPG) + i] = acc[u][j][r];
+      if (nslot == 0 && i == 0) sl[L::CO * L::TAPS + co] = bacc[j][r];
+    }
+}
+
+// Sum of the per-workgroup slabs of all three layers and all problems in one launch, fixed order:
+// 4 waves take every 4th slab for 64 consecutive elements, then the four partial sums are added 0..3.
+struct RdArgs {
+  const float* slab[3];
+  float* gw[3][EBW_MAXP];
+  float* gb[3][EBW_MAXP];
+  int nW[3], nB[3];
+  int wpp, accumulate;
+};
+__global__ __launch_bounds__(256) void ebw_reduce_kernel(RdArgs a) {
+  __shared__ float sh[4][64];
+  const int l = blockIdx.y % 3, p = blockIdx.y / 3, per = a.nW[l] + a.nB[l];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), kg = threadIdx.x >> 6;
+  if (blockIdx.x * 64 >= per) return;
+  float sum = 0.f;
+  if (e < per) {
+    const float* s = a.slab[l] + (long)p * a.wpp * per + e;
+    for (int k = kg; k < a.wpp; k += 4) sum += s[(long)k * per];
+  }
+  sh[kg][threadIdx.x & 63] = sum;
+  __syncthreads();
+  if (kg == 0 && e < per) {
+    const float v = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+    float* o = e < a.nW[l] ? a.gw[l][p] + e : a.gb[l][p] + (e - a.nW[l]);
+    *o = a.accumulate ? *o + v : v;
+  }
+}
+
+// ===================================================================== dgrad
+struct DgArgs {
+  const void* dz[EBW_MAXP];    // [n][OH*OW][CO]
+  const float* yin[EBW_MAXP];  // [n][IH*IW][CI] layer input (post-ReLU): mask
+  const uint4* wpk[EBW_MAXP];  // packed W^T fragments
+  __bf16* dx[EBW_MAXP];        // [n][IH*IW][CI] masked input gradient = dZ of the previous layer
+  int n[EBW_MAXP];
+  int wpp;
+};
+struct PkArgs {
+  const float* w[EBW_MAXP];
+  uint4* out[EBW_MAXP];
+};
+
+// wpk[(combo*KS + ks)*64 + lane]: combo = class*NTI + ntile; the lane's 8 consecutive co of
+// W[co][py + S*a][px + S*b][16*ntile + (lane&15)], ks = (a*KB + b)*(CO/32) + half.
+template <class L>
+__global__ __launch_bounds__(256) void ebw_pack_kernel(PkArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= L::NCOMBO * L::KS * 64) return;
+  const int lane = idx & 63, ks = (idx >> 6) % L::KS, combo = (idx >> 6) / L::KS;
+  const int cls = combo / L::NTI, nt = combo % L::NTI, py = cls / L::S, px = cls % L::S;
+  const int tp = ks / (L::CO / 32), hf = ks % (L::CO / 32), ta = tp / L::KB, tb = tp % L::KB;
+  const int ky = py + L::S * ta, kx = px + L::S * tb, ci = 16 * nt + (lane & 15), co0 = 32 * hf + 8 * (lane >> 4);
+  const float* w = a.w[blockIdx.y];
+  uint32_t v[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+    v[e] = pack2(w[(((co0 + 2 * e) * L::KH + ky) * L::KW + kx) * L::CI + ci],
+                 w[(((co0 + 2 * e + 1) * L::KH + ky) * L::KW + kx) * L::CI + ci]);
+  a.out[blockIdx.y][idx] = make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+template <class L>
+constexpr size_t dgrad_lds_bytes() { return (size_t)2 * L::R * L::C * L::PP * 2; }
+
+template <class L, class DzT>
+__global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
+  constexpr int MPARTS = NW / L::NCOMBO, MTW = (L::MTC + MPARTS - 1) / MPARTS;
+  static_assert(NW % L::NCOMBO == 0, "wave tiling");
+  constexpr int BUF = L::R * L::C * L::PP;
+  constexpr int NCG = L::CO / 8, NCH = L::OH * L::OW * NCG, CPT = (NCH + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* dzh = reinterpret_cast<__bf16*>(smem);  // 2 x [R][C][PP], zero halo
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int p = blockIdx.x / a.wpp, j0 = blockIdx.x - p * a.wpp;
+  const int n_img = a.n[p];
+  for (int e = tid; e < 2 * BUF / 2; e += NT) reinterpret_cast<uint32_t*>(dzh)[e] = 0u;
+  const int combo = w % L::NCOMBO, mpart = w / L::NCOMBO, cls = combo / L::NTI, nt = combo % L::NTI;
+  const int py = cls / L::S, px = cls % L::S;
+  bf16x8 Bf[L::KS];
+#pragma unroll
+  for (int ks = 0; ks < L::KS; ks++) {
+    const uint4 t = a.wpk[p][(combo * L::KS + ks) * 64 + lane];
+    Bf[ks] = __builtin_bit_cast(bf16x8, t);
+  }
+  int abase[MTW];
+#pragma unroll
+  for (int t = 0; t < MTW; t++) {
+    int m = 16 * (mpart + t * MPARTS) + i;
+    m = m < L::PH * L::PW ? m : L::PH * L::PW - 1;
+    const int Y = m / L::PW, X = m - Y * L::PW;
+    abase[t] = ((Y + L::HA) * L::C + X + L::HB) * L::PP + 8 * g;
+  }
+  const DzT* dz = reinterpret_cast<const DzT*>(a.dz[p]);
+  const float* yin = a.yin[p];
+  __bf16* dx = a.dx[p];
+  bf16x8 pre[CPT];
+  auto fetch = [&](int img) {
+#pragma unroll
+    for (int r = 0; r < CPT; r++) {
+      const int c = tid + r * NT;
+      if (c < NCH) pre[r] = load8v(dz + ((long)img * L::OH * L::OW + c / NCG) * L::CO + 8 * (c % NCG));
+    }
+  };
+  auto put = [&](__bf16* buf) {
+#pragma unroll
+    for (int r = 0; r < CPT; r++) {
+      const int c = tid + r * NT;
+      if (c < NCH) {
+        const int pix = c / NCG, cg = c - pix * NCG, oy = pix / L::OW, ox = pix - oy * L::OW;
+        *reinterpret_cast<bf16x8*>(buf + ((oy + L::HA) * L::C + ox + L::HB) * L::PP + 8 * cg) = pre[r];
+      }
+    }
+  };
+  __syncthreads();  // zero fill done
+  if (j0 < n_img) { fetch(j0); put(dzh); }
+  __syncthreads();
+  int k = 0;
+  for (int img = j0; img < n_img; img += a.wpp, k ^= 1) {
+    const int nxt = img + a.wpp;
+    if (nxt < n_img) fetch(nxt);
+    const __bf16* buf = dzh + k * BUF;
+#pragma unroll
+    for (int t = 0; t < MTW; t++) {
+      const int mt = mpart + t * MPARTS;
+      if (mt >= L::MTC) break;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < L::KS; ks++) {
+        const int tp = ks / (L::CO / 32), hf = ks % (L::CO / 32), ta = tp / L::KB, tb = tp % L::KB;
+        const bf16x8 A = *reinterpret_cast<const bf16x8*>(buf + abase[t] - (ta * L::C + tb) * L::PP + 32 * hf);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bf[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = 16 * mt + 4 * g + r, Y = m / L::PW, X = m - Y * L::PW, y = L::S * Y + py, x = L::S * X + px;
+        if (m < L::PH * L::PW && y < L::IH && x < L::IW) {
+          const long idx = ((long)img * L::IH * L::IW + y * L::IW + x) * L::CI + 16 * nt + i;
+          dx[idx] = (__bf16)(yin[idx] > 0.f ? acc[r] : 0.f);
+        }
+      }
+    }
+    if (nxt < n_img) put(dzh + (k ^ 1) * BUF);
+    __syncthreads();
+  }
+}
+
+// ====================================================================== host
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int cdivi(long a, long b) { return (int)((a + b - 1) / b); }
+
+struct WsPlan {
+  size_t wpk2[EBW_MAXP], wpk3[EBW_MAXP], dz2[EBW_MAXP], dz1[EBW_MAXP], slab1, slab2, slab3, total;
+  int wpp;
+};
+template <class G>
+WsPlan plan(int nprob, const int* n) {
+  WsPlan w{};
+  long maxn = 1;
+  for (int p = 0; p < nprob; p++) maxn = n[p] > maxn ? n[p] : maxn;
+  // one workgroup per CU (256 CUs), never more: a second round of workgroups would double the time
+  const int per = 256 / nprob > 1 ? 256 / nprob : 1;
+  w.wpp = (int)(per < maxn ? per : maxn);
+  size_t off = 0;
+  for (int p = 0; p < nprob; p++) {
+    w.wpk2[p] = off; off += al256((size_t)G::L2::NCOMBO * G::L2::KS * 64 * 16);
+    w.wpk3[p] = off; off += al256((size_t)G::L3::NCOMBO * G::L3::KS * 64 * 16);
+    w.dz2[p] = off; off += al256((size_t)n[p] * G::L3::IH * G::L3::IW * 64 * 2);
+    w.dz1[p] = off; off += al256((size_t)n[p] * G::L2::IH * G::L2::IW * 32 * 2);
+  }
+  const size_t nwg = (size_t)nprob * w.wpp;
+  w.slab1 = off; off += al256(nwg * G::L1::SLABF * 4);
+  w.slab2 = off; off += al256(nwg * G::L2::SLABF * 4);
+  w.slab3 = off; off += al256(nwg * G::L3::SLABF * 4);
+  w.total = off;
+  return w;
+}
+
+template <class K>
+int set_lds(K kern, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) ==
+                 hipSuccess ? 0 : -1;
+}
+
+template <class L, class InT, class DzT, int MG>
+int launch_wgrad(const WgArgs& a, int nwg, hipStream_t st) {
+  auto kern = ebw_wgrad_kernel<L, InT, DzT, MG>;
+  constexpr size_t lds = wgrad_lds_bytes<L, InT>();
+  static int once = set_lds(kern, lds);
+  if (once) return TACORL_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, st, a);
+  return TACORL_OK;
+}
+template <class L, class DzT>
+int launch_dgrad(const DgArgs& a, int nwg, hipStream_t st) {
+  auto kern = ebw_dgrad_kernel<L, DzT>;
+  constexpr size_t lds = dgrad_lds_bytes<L>();
+  static int once = set_lds(kern, lds);
+  if (once) return TACORL_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, st, a);
+  return TACORL_OK;
+}
+template <class G>
+int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  using L1 = typename G::L1; using L2 = typename G::L2; using L3 = typename G::L3;
+  int n[EBW_MAXP];
+  for (int p = 0; p < nprob; p++) n[p] = pr[p].n;
+  const WsPlan w = plan<G>(nprob, n);
+  if (ws_bytes < w.total) return TACORL_ENOMEM;
+  unsigned char* base = (unsigned char*)ws;
+  const int nwg = nprob * w.wpp;
+  // W^T fragments for the two dgrads
+  PkArgs k2{}, k3{};
+  for (int p = 0; p < nprob; p++) {
+    k2.w[p] = pr[p].w2; k2.out[p] = (uint4*)(base + w.wpk2[p]);
+    k3.w[p] = pr[p].w3; k3.out[p] = (uint4*)(base + w.wpk3[p]);
+  }
+  hipLaunchKernelGGL(ebw_pack_kernel<L2>, dim3(cdivi(L2::NCOMBO * L2::KS * 64, 256), nprob), dim3(256), 0, st, k2);
+  hipLaunchKernelGGL(ebw_pack_kernel<L3>, dim3(cdivi(L3::NCOMBO * L3::KS * 64, 256), nprob), dim3(256), 0, st, k3);
+  DgArgs d3{}, d2{};
+  WgArgs g3{}, g2{}, g1{};
+  float *gw1[EBW_MAXP], *gb1[EBW_MAXP], *gw2[EBW_MAXP], *gb2[EBW_MAXP], *gw3[EBW_MAXP], *gb3[EBW_MAXP];
+  for (int p = 0; p < nprob; p++) {
+    __bf16* dz2 = (__bf16*)(base + w.dz2[p]);
+    __bf16* dz1 = (__bf16*)(base + w.dz1[p]);
+    d3.dz[p] = pr[p].dz3; d3.yin[p] = pr[p].y2; d3.wpk[p] = k3.out[p]; d3.dx[p] = dz2; d3.n[p] = n[p];
+    d2.dz[p] = dz2; d2.yin[p] = pr[p].y1; d2.wpk[p] = k2.out[p]; d2.dx[p] = dz1; d2.n[p] = n[p];
+    g3.in[p] = pr[p].y2; g3.dz[p] = pr[p].dz3; g3.n[p] = n[p];
+    g2.in[p] = pr[p].y1; g2.dz[p] = dz2; g2.n[p] = n[p];
+    g1.in[p] = pr[p].img; g1.dz[p] = dz1; g1.n[p] = n[p];
+    gw1[p] = pr[p].g_w1; gb1[p] = pr[p].g_b1; gw2[p] = pr[p].g_w2; gb2[p] = pr[p].g_b2;
+    gw3[p] = pr[p].g_w3; gb3[p] = pr[p].g_b3;
+  }
+  d3.wpp = d2.wpp = g3.wpp = g2.wpp = g1.wpp = w.wpp;
+  g1.slab = (float*)(base + w.slab1); g2.slab = (float*)(base + w.slab2); g3.slab = (float*)(base + w.slab3);
+  int rc;
+  if ((rc = launch_dgrad<L3, float>(d3, nwg, st))) return rc;
+  if ((rc = launch_wgrad<L3, float, float, 2>(g3, nwg, st))) return rc;
+  if ((rc = launch_dgrad<L2, __bf16>(d2, nwg, st))) return rc;
+  if ((rc = launch_wgrad<L2, float, __bf16, 4>(g2, nwg, st))) return rc;
+  if ((rc = launch_wgrad<L1, __bf16, __bf16, 1>(g1, nwg, st))) return rc;
+  RdArgs r{};
+  r.slab[0] = g1.slab; r.slab[1] = g2.slab; r.slab[2] = g3.slab;
+  r.nW[0] = L1::CO * L1::TAPS; r.nW[1] = L2::CO * L2::TAPS; r.nW[2] = L3::CO * L3::TAPS;
+  r.nB[0] = L1::CO; r.nB[1] = L2::CO; r.nB[2] = L3::CO;
+  r.wpp = w.wpp; r.accumulate = accumulate;
+  for (int p = 0; p < nprob; p++) {
+    r.gw[0][p] = gw1[p]; r.gb[0][p] = gb1[p]; r.gw[1][p] = gw2[p]; r.gb[1][p] = gb2[p];
+    r.gw[2][p] = gw3[p]; r.gb[2][p] = gb3[p];
+  }
+  constexpr int maxper = cmax(L1::SLABF, cmax(L2::SLABF, L3::SLABF));
+  hipLaunchKernelGGL(ebw_reduce_kernel, dim3(cdivi(maxper, 64), 3 * nprob), dim3(256), 0, st, r);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
+}  // namespace
+
+// the geometries encoder_fused.hip is instantiated for (the cameras of the reference's configs)
+#define EBW_GEOMS(X) X(84, 84) X(64, 64) X(44, 60)
+
+bool ebw_supported(int H, int W) {
+#define X(h, w) if (H == h && W == w) return true;
+  EBW_GEOMS(X)
+#undef X
+  return false;
+}
+size_t ebw_ws_bytes(int nprob, const int* n_img, int H, int W) {
+  if (nprob < 1 || nprob > EBW_MAXP) return 0;
+#define X(h, w) if (H == h && W == w) return plan<Geo<h, w>>(nprob, n_img).total;
+  EBW_GEOMS(X)
+#undef X
+  return 0;
+}
+int ebw_conv_backward(int nprob, const EbwProblem* pr, int H, int W, int accumulate, void* ws, size_t ws_bytes,
+                      hipStream_t st) {
+  if (nprob < 1 || nprob > EBW_MAXP) return TACORL_EINVAL;
+#define X(h, w) if (H == h && W == w) return run<Geo<h, w>>(nprob, pr, accumulate, ws, ws_bytes, st);
+  EBW_GEOMS(X)
+#undef X
+  return TACORL_EINVAL;
+}

@@ -66,8 +66,13 @@ __device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d) 
 // frag(j, s, l)[e] = W[16 j + (l & 15)][32 s + 8 (l >> 4) + e]   (W row-major [N][K], fp32 -> bf16)
 // conv1 uses a permuted K order so that the im2col LDS address of lane group g is base + g*rowbytes +
 // an immediate: k-step s, group g, element e  <->  ky = 4 (s / 3) + g, (kx, ci) run offset 8 (s % 3) + e.
-__global__ void ef_pack_kernel(const float* __restrict__ params, u32x4* __restrict__ out, long o_w1, long o_w2,
-                               long o_w3, long o_f1, long o_f2) {
+struct EFPackArgs {
+  const float* params[16];
+  u32x4* out[16];
+};
+__global__ void ef_pack_kernel(EFPackArgs a, long o_w1, long o_w2, long o_w3, long o_f1, long o_f2) {
+  const float* __restrict__ params = a.params[blockIdx.y];
+  u32x4* __restrict__ out = a.out[blockIdx.y];
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;  // fragment id
   if (f >= WP_TOTAL / 64) return;
   const float* W; int K, j, s;
@@ -89,9 +94,11 @@ extern "C" int tacorl_encoder_pack_weights(int nprob, const float* const* params
                                            tacorl_stream_t stream) {
   long po[11];
   tacorl_encoder_param_layout(po);
-  for (int p = 0; p < nprob; p++)
-    hipLaunchKernelGGL(ef_pack_kernel, dim3((WP_TOTAL / 64 + 3) / 4), dim3(256), 0, (hipStream_t)stream, params[p],
-                       (u32x4*)packed[p], po[0], po[2], po[4], po[7], po[9]);
+  if (nprob < 1 || nprob > 16) return TACORL_EINVAL;
+  EFPackArgs a{};
+  for (int p = 0; p < nprob; p++) { a.params[p] = params[p]; a.out[p] = (u32x4*)packed[p]; }
+  hipLaunchKernelGGL(ef_pack_kernel, dim3((WP_TOTAL / 64 + 3) / 4, nprob), dim3(256), 0, (hipStream_t)stream, a, po[0],
+                     po[2], po[4], po[7], po[9]);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 

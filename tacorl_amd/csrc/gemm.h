@@ -27,10 +27,10 @@ struct GemmArgs {
   int R[GEMM_MAXP];  // reduction length per problem
 };
 
-template <class Atom, class LA, class LB, bool TA, bool TB, class Epi, int BM, int BN>
+template <class Atom, class LA, class LB, bool TA, bool TB, class Epi, int BM, int BN, int BKT = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmArgs g) {
   typedef typename Atom::elem T;
-  constexpr int BK = Atom::BK;
+  constexpr int BK = BKT ? BKT : Atom::BK;
   constexpr int LD = BK + Atom::PAD;
   constexpr int MI = BM / 64;
   constexpr int NI = BN / 16;
@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmAr
   const int M = g.M[p], N = g.N, R = g.R[p];
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   if (m0 >= M) return;
-  int rs = ((R + g.nsplit - 1) / g.nsplit + 63) / 64 * 64;  // multiple of every atom's BK
+  constexpr int RQ = BK > 64 ? BK : 64;  // split boundaries: multiple of every tile depth in use
+  int rs = ((R + g.nsplit - 1) / g.nsplit + RQ - 1) / RQ * RQ;
   const int r_begin = s * rs;
   const int r_end = min(R, r_begin + rs);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,12 +135,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmAr
 // Host-side launcher: picks the tile for N and the atom for the compute dtype.
 enum { DT_F32 = 0, DT_BF16 = 1 };
 
-template <class LA, class LB, bool TA, bool TB, class Epi>
+// DEEPK: also instantiate a 128-deep K tile (bf16 only) for reductions >= 96 per split.  Measured on the
+// step's skinny GEMMs (M 256-4096, K 64-272): no gain - a single-K-tile GEMM already costs 13 us of
+// launch + dependent round trips (kernarg -> operands -> bias), so no caller enables it.
+template <class LA, class LB, bool TA, bool TB, class Epi, bool DEEPK = false>
 static int gemm_launch(const LA& la, const LB& lb, const Epi& epi, const GemmArgs& g, int compute_dtype,
                        hipStream_t st) {
-  int maxM = 0;
-  for (int i = 0; i < g.nprob; i++) maxM = g.M[i] > maxM ? g.M[i] : maxM;
+  int maxM = 0, maxR = 0;
+  for (int i = 0; i < g.nprob; i++) { maxM = g.M[i] > maxM ? g.M[i] : maxM; maxR = g.R[i] > maxR ? g.R[i] : maxR; }
   if (maxM == 0 || g.N == 0) return TACORL_OK;
+  if constexpr (DEEPK) {
+    if (compute_dtype == DT_BF16 && (maxR + g.nsplit - 1) / g.nsplit >= 96) {
+#define GEMM_GO_DEEP(BN_)                                                                                  \
+  do {                                                                                                     \
+    dim3 grid(cdiv(maxM, 128), cdiv(g.N, BN_), g.nprob * g.nsplit);                                        \
+    hipLaunchKernelGGL((gemm_kernel<AtomBF16, LA, LB, TA, TB, Epi, 128, BN_, 128>), grid, dim3(256), 0, st, \
+                       la, lb, epi, g);                                                                    \
+  } while (0)
+      if (g.N > 32) GEMM_GO_DEEP(64);
+      else if (g.N > 16) GEMM_GO_DEEP(32);
+      else GEMM_GO_DEEP(16);
+#undef GEMM_GO_DEEP
+      return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+    }
+  }
 #define GEMM_GO(ATOM, BM_, BN_)                                                              \
   do {                                                                                       \
     dim3 grid(cdiv(maxM, BM_), cdiv(g.N, BN_), g.nprob * g.nsplit);                          \

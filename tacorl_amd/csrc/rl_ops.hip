@@ -71,6 +71,48 @@ extern "C" int tacorl_copy_cols(const float* src, int ld_src, float* dst, int ld
   return LAUNCH_OK();
 }
 
+// Up to 32 independent copy_cols in one launch (blockIdx.y = descriptor): the state / Q-input
+// assembly is a dozen 32-256 column concatenations, each far smaller than a launch.
+#define COPY_MAXB 32
+struct CopyTbl {
+  const float* src[COPY_MAXB];
+  float* dst[COPY_MAXB];
+  int ld_src[COPY_MAXB], ld_dst[COPY_MAXB], rows[COPY_MAXB], cols[COPY_MAXB], mod[COPY_MAXB], acc[COPY_MAXB];
+};
+__global__ void copy_cols_batch_kernel(CopyTbl t) {
+  const int d = blockIdx.y, cols = t.cols[d], mod = t.mod[d], acc = t.acc[d];
+  const long total = (long)t.rows[d] * cols;
+  const float* __restrict__ src = t.src[d];
+  float* __restrict__ dst = t.dst[d];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    const int rs = mod > 0 ? r % mod : r;
+    const float v = src[(long)rs * t.ld_src[d] + c];
+    float* o = dst + (long)r * t.ld_dst[d] + c;
+    *o = acc ? *o + v : v;
+  }
+}
+extern "C" int tacorl_copy_cols_batch(int n, const float* const* src, const int* ld_src, float* const* dst,
+                                      const int* ld_dst, const int* rows, const int* cols, const int* src_row_mod,
+                                      const int* accumulate, tacorl_stream_t stream) {
+  if (n < 0 || n > COPY_MAXB) return TACORL_EINVAL;
+  CopyTbl t{};
+  long maxt = 0;
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    if (rows[i] <= 0 || cols[i] <= 0) continue;
+    t.src[m] = src[i]; t.dst[m] = dst[i]; t.ld_src[m] = ld_src[i]; t.ld_dst[m] = ld_dst[i]; t.rows[m] = rows[i];
+    t.cols[m] = cols[i]; t.mod[m] = src_row_mod ? src_row_mod[i] : 0; t.acc[m] = accumulate ? accumulate[i] : 0;
+    const long tot = (long)rows[i] * cols[i];
+    maxt = tot > maxt ? tot : maxt;
+    m++;
+  }
+  if (m == 0) return TACORL_OK;
+  const int blocks = (int)((maxt + 255) / 256 > 512 ? 512 : (maxt + 255) / 256);
+  hipLaunchKernelGGL(copy_cols_batch_kernel, dim3(blocks, m), dim3(256), 0, (hipStream_t)stream, t);
+  return LAUNCH_OK();
+}
+
 // out[b][c] = sum_j in[(j*B + b)][c], j < reps   (gradient of a broadcast over samples)
 __global__ void reduce_rows_mod_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int ld_out,
                                        int B, int cols, int reps) {

@@ -274,9 +274,10 @@ class ACEngine:
         B = self.B
         # goal-encoder inputs: concat over cams of enc(goal)
         src = {"a": ("a_og", B), "q1": ("q1", B), "q2": ("q2", B), "tq1": ("tq1", 0), "tq2": ("tq2", 0)}
-        for k, (ek, row0) in src.items():
-            for j, c in enumerate(self.cams):
-                ops.copy_cols(self.enc_out[(ek, c)], row0 * 32, 32, self.gin[k], 32 * j, self.G, B, 32)
+        with ops.copy_batch():
+            for k, (ek, row0) in src.items():
+                for j, c in enumerate(self.cams):
+                    ops.copy_cols(self.enc_out[(ek, c)], row0 * 32, 32, self.gin[k], 32 * j, self.G, B, 32)
         nets = dict(self.nets)
         ks = ["a", "q1", "q2", "tq1", "tq2"]
         ops.mlp_fwd([self.gin[k] for k in ks], self.G, [nets[k].genc() for k in ks], [self.gact[k] for k in ks],
@@ -284,10 +285,11 @@ class ACEngine:
         # S = [enc(obs or next) | goal_enc(enc(goal))]
         obs_src = {"a": ("a_og", 0, "a"), "a_nx": ("a_nx", 0, "a"), "q1": ("q1", 0, "q1"), "q2": ("q2", 0, "q2"),
                    "tq1": ("tq1", B, "tq1"), "tq2": ("tq2", B, "tq2")}
-        for k, (ek, row0, gk) in obs_src.items():
-            for j, c in enumerate(self.cams):
-                ops.copy_cols(self.enc_out[(ek, c)], row0 * 32, 32, self.S[k], 32 * j, self.lds, B, 32)
-            ops.copy_cols(self.gact[gk], self.g_yoff, self.G, self.S[k], self.Eo, self.lds, B, self.G)
+        with ops.copy_batch():
+            for k, (ek, row0, gk) in obs_src.items():
+                for j, c in enumerate(self.cams):
+                    ops.copy_cols(self.enc_out[(ek, c)], row0 * 32, 32, self.S[k], 32 * j, self.lds, B, 32)
+                ops.copy_cols(self.gact[gk], self.g_yoff, self.G, self.S[k], self.Eo, self.lds, B, self.G)
 
     def _policy_fwd(self):
         ks = ["a", "a_nx"]
@@ -353,15 +355,17 @@ class ACEngine:
         if getattr(self, "action_ready", None) is not None:
             torch.cuda.current_stream().wait_event(self.action_ready)
             self.action_ready = None
-        ops.copy_cols(self.action, 0, A, self.acts_main, 0, A, B, A)
-        for k in ("q1", "q2"):
-            ops.copy_cols(self.S[k], 0, self.lds, self.XQ[k], 0, self.ldq, self.R, self.E, src_row_mod=B)
-            ops.copy_cols(self.acts_main, 0, A, self.XQ[k], self.E, self.ldq, self.R, A)
-            ops.copy_cols(self.S[k], 0, self.lds, self.XQpi[k], 0, self.ldq, B, self.E)
-            ops.copy_cols(self.act_pi, 0, A, self.XQpi[k], self.E, self.ldq, B, A)
-        for k in ("tq1", "tq2"):
-            ops.copy_cols(self.S[k], 0, self.lds, self.XT[k], 0, self.ldq, B, self.E)
-            ops.copy_cols(self.act_next, 0, A, self.XT[k], self.E, self.ldq, B, A)
+        with ops.copy_batch():  # one launch; rows [0,B) of the Q input take the data action straight from its source
+            ops.copy_cols(self.action, 0, A, self.acts_main, 0, A, B, A)
+            for k in ("q1", "q2"):
+                ops.copy_cols(self.S[k], 0, self.lds, self.XQ[k], 0, self.ldq, self.R, self.E, src_row_mod=B)
+                ops.copy_cols(self.action, 0, A, self.XQ[k], self.E, self.ldq, B, A)
+                ops.copy_cols(self.acts_main, B * A, A, self.XQ[k], B * self.ldq + self.E, self.ldq, self.R - B, A)
+                ops.copy_cols(self.S[k], 0, self.lds, self.XQpi[k], 0, self.ldq, B, self.E)
+                ops.copy_cols(self.act_pi, 0, A, self.XQpi[k], self.E, self.ldq, B, A)
+            for k in ("tq1", "tq2"):
+                ops.copy_cols(self.S[k], 0, self.lds, self.XT[k], 0, self.ldq, B, self.E)
+                ops.copy_cols(self.act_next, 0, A, self.XT[k], self.E, self.ldq, B, A)
         qd, qa = self.q1.head_dims, self.q1.head_acts
         xs = [self.XQ["q1"], self.XQ["q2"], self.XQpi["q1"], self.XQpi["q2"], self.XT["tq1"], self.XT["tq2"]]
         ps = [self.q1.head(), self.q2.head(), self.q1.head(), self.q2.head(), self.tq1.head(), self.tq2.head()]
@@ -431,13 +435,24 @@ class ACEngine:
                     [self.dgin[k] for k in ks], self.G, [B] * 3, self.actor.genc_dims, self.actor.genc_acts,
                     self.compute)
         ek = {"a": "a_og", "q1": "q1", "q2": "q2"}
+        with ops.copy_batch():
+            for j, c in enumerate(self.cams):
+                for k in ks:
+                    ops.copy_cols(self.dS[k], 32 * j, self.lds, self.enc_dout[(ek[k], c)], 0, 32, B, 32)
+                    ops.copy_cols(self.dgin[k], 32 * j, self.G, self.enc_dout[(ek[k], c)], B * 32, 32, B, 32)
         for j, c in enumerate(self.cams):
-            for k in ks:
-                ops.copy_cols(self.dS[k], 32 * j, self.lds, self.enc_dout[(ek[k], c)], 0, 32, B, 32)
-                ops.copy_cols(self.dgin[k], 32 * j, self.G, self.enc_dout[(ek[k], c)], B * 32, 32, B, 32)
             H, W = self.hw[c]
             imgs = [self._img_ptr(c, 0)] * 3
             ops_n = [2 * B] * 3
+            pa = [ops.ptr_array(imgs), ops.ptr_array([nets[k].enc(c) for k in ks]),
+                  ops.ptr_array([self.enc_act[(ek[k], c)] for k in ks]),
+                  ops.ptr_array([self.enc_dout[(ek[k], c)] for k in ks]),
+                  ops.ptr_array([nets[k].enc(c, nets[k].grad) for k in ks]), ops.int_array(ops_n), H, W]
+            if self._fused_ok(c):  # per-image LDS-resident conv backward (encoder_bwd_fused.hip)
+                nb = ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(3, ops.int_array(ops_n), H, W)
+                ws = ops.workspace(nb, self.dev, "enc_bwd_fused")
+                call("tacorl_encoder_bwd_fused", 3, *pa, 0, ptr(ws), ws.numel(), ops.stream())
+                continue
             nb = ops.L.lib().tacorl_encoder_bwd_ws_bytes(3, ops.int_array(ops_n), H, W)
             ws = ops.workspace(nb, self.dev, "enc_bwd")
             call("tacorl_encoder_bwd", 3, ops.ptr_array(imgs), ops.ptr_array([nets[k].enc(c) for k in ks]),

@@ -87,9 +87,19 @@ def encoder_fwd(imgs, params, outs, acts, H, W, compute=F32):
          int_array(n), H, W, xd, compute, stream())
 
 
-def encoder_bwd(imgs, params, acts, d_outs, grads, H, W, compute=F32, accumulate=False):
+def encoder_bwd(imgs, params, acts, d_outs, grads, H, W, compute=F32, accumulate=False, fused=False):
+    """fused=True: the per-image LDS-resident conv backward (bf16 images + bf16 MFMA + supported geometry)."""
     n = [i.shape[0] for i in imgs]
     xd = BF16 if imgs[0].dtype == torch.bfloat16 else F32
+    if fused:
+        assert xd == BF16 and compute == BF16
+        nb = L.lib().tacorl_encoder_bwd_fused_ws_bytes(len(imgs), int_array(n), H, W)
+        if nb == 0:
+            raise L.TacorlHipError(f"encoder_bwd_fused: geometry {H}x{W} / {len(imgs)} problems not supported")
+        ws = workspace(nb, imgs[0].device, "enc_bwd_fused")
+        call("tacorl_encoder_bwd_fused", len(imgs), ptr_array(imgs), ptr_array(params), ptr_array(acts),
+             ptr_array(d_outs), ptr_array(grads), int_array(n), H, W, int(accumulate), ptr(ws), ws.numel(), stream())
+        return
     nb = L.lib().tacorl_encoder_bwd_ws_bytes(len(imgs), int_array(n), H, W)
     ws = workspace(nb, imgs[0].device, "enc_bwd")
     call("tacorl_encoder_bwd", len(imgs), ptr_array(imgs), ptr_array(params), ptr_array(acts), ptr_array(d_outs),
@@ -123,7 +133,38 @@ def _at(t, off):
     return C.c_void_p(t.data_ptr() + 4 * off)
 
 
+_copy_batch = None
+
+
+class copy_batch:
+    """`with ops.copy_batch():` turns the copy_cols calls inside into ONE launch (<= 32 per launch).
+    The copies of a batch must be independent: none may read what another one writes."""
+
+    def __enter__(self):
+        global _copy_batch
+        assert _copy_batch is None, "copy_batch does not nest"
+        _copy_batch = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _copy_batch
+        items, _copy_batch = _copy_batch, None
+        if et is not None:
+            return False
+        for i in range(0, len(items), 32):
+            ch = items[i:i + 32]
+            cols = list(zip(*ch))
+            call("tacorl_copy_cols_batch", len(ch), (C.c_void_p * len(ch))(*cols[0]), int_array(cols[1]),
+                 (C.c_void_p * len(ch))(*cols[2]), int_array(cols[3]), int_array(cols[4]), int_array(cols[5]),
+                 int_array(cols[6]), int_array(cols[7]), stream())
+        return False
+
+
 def copy_cols(src, src_off, ld_src, dst, dst_off, ld_dst, rows, cols, src_row_mod=0, accumulate=False):
+    if _copy_batch is not None:
+        _copy_batch.append((src.data_ptr() + 4 * src_off, ld_src, dst.data_ptr() + 4 * dst_off, ld_dst, rows, cols,
+                            src_row_mod, int(accumulate)))
+        return
     call("tacorl_copy_cols", _at(src, src_off), ld_src, _at(dst, dst_off), ld_dst, rows, cols, src_row_mod,
          int(accumulate), stream())
 

@@ -343,3 +343,50 @@ def test_encoder_fused_forward(H, W):
             a, b = acts_f[i][offs[j]:end], acts[i][offs[j]:end]
             assert torch.isfinite(a).all(), name
             assert relerr(a, b) < 1e-2, (name, relerr(a, b))
+
+
+@pytest.mark.parametrize("H,W", [(84, 84), (64, 64), (44, 60)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_encoder_fused_backward(H, W, accumulate):
+    """Per-image LDS-resident conv backward (tacorl_encoder_bwd_fused) vs the generic bf16 path on the
+    same saved activations (same bf16 operand rounding, different fp32 summation order only), and vs
+    fp32 autograd of the oracle (bf16 tolerance: cosine)."""
+    from oracle import tacorl_oracle as O
+    from tacorl_amd import _lib, blocks, ops
+
+    dev = _dev()
+    assert _lib.lib().tacorl_encoder_fused_supported(H, W) == 1
+    n = [7, 13, 2]
+    flats, imgs, outs, acts, douts, refs = [], [], [], [], [], []
+    for i, k in enumerate(n):
+        P = {kk: v.clone().requires_grad_(True) for kk, v in _enc_params(120 + i).items()}
+        img = rnd(k, 3, H, W, seed=130 + i).to(torch.bfloat16).float()
+        out = O.encoder_fwd(P, "", img)
+        dout = rnd(k, 32, seed=140 + i)
+        (out * dout).sum().backward()
+        flat = torch.zeros(blocks.encoder_size(), device=dev)
+        blocks.load_named(blocks.encoder_views(flat), {kk: v.detach() for kk, v in P.items()})
+        flats.append(flat)
+        imgs.append(img.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16))
+        outs.append(torch.empty(k, 32, device=dev))
+        acts.append(torch.empty(ops.encoder_act_layout(k, H, W)[1], device=dev))
+        douts.append(dout.to(dev))
+        refs.append({kk: v.grad for kk, v in P.items()})
+    ops.encoder_fwd(imgs, flats, outs, acts, H, W, 1)
+    base = 0.25 if accumulate else float("nan")
+    g_gen = [torch.full_like(f, base) for f in flats]
+    g_fus = [torch.full_like(f, base) for f in flats]
+    ops.encoder_bwd(imgs, flats, acts, douts, g_gen, H, W, 1, accumulate=accumulate)
+    ops.encoder_bwd(imgs, flats, acts, douts, g_fus, H, W, 1, accumulate=accumulate, fused=True)
+    torch.cuda.synchronize()
+    for i in range(len(n)):
+        vg, vf = blocks.encoder_views(g_gen[i]), blocks.encoder_views(g_fus[i])
+        for name, g in refs[i].items():
+            assert torch.isfinite(vf[name]).all(), name
+            e = relerr(vf[name] - (0.25 if accumulate else 0.0), vg[name] - (0.25 if accumulate else 0.0))
+            assert e < 2e-3, ("vs generic bf16", name, e)
+            a, b = (vf[name] - (0.25 if accumulate else 0.0)).reshape(-1).double().cpu(), g.reshape(-1).double()
+            cos = (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
+            c = (vg[name] - (0.25 if accumulate else 0.0)).reshape(-1).double().cpu()
+            cos_gen = (c @ b / (c.norm() * b.norm()).clamp_min(1e-30)).item()
+            assert cos > 0.97 and cos > cos_gen - 0.005, ("vs fp32 autograd", name, cos, cos_gen)
