@@ -20,6 +20,8 @@
 //   The bias gradient rides on the same MFMAs with an all-ones B fragment.
 #include "enc_bwd_fused.h"
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -93,67 +95,158 @@ struct WgArgs {
   int wpp;  // workgroups per problem
 };
 
+// Staging maps are image-independent, so each thread resolves its chunks once per kernel (the index
+// arithmetic - divisions by the plane pitch - would otherwise dominate the per-image work).
+// A chunk = 8 channels x 2 adjacent plane positions: two 8-element source vectors (offset -1 = zeros),
+// eight dword stores (one per channel plane) at dst + j * pitch.
+struct Chunk { int s0, s1, dst; };
+
 // dZ of one image, [OH*OW][CO] -> planes [CO][q = oy*PW + ox] (bf16 pairs), zero at padded q
-template <class L, class DzT>
-__device__ __forceinline__ void stage_dz(const DzT* __restrict__ dz, uint32_t* dzp32, int tid) {
-  constexpr int ND = L::KQ / 2, NCG = L::CO / 8;
-  for (int c = tid; c < ND * NCG; c += NT) {
-    const int cg = c / ND, d = c - cg * ND;
-    float v[2][8];
+template <class L>
+struct DzMap {
+  static constexpr int ND = L::KQ / 2, NCG = L::CO / 8, NCH = ND * NCG, CPT = (NCH + NT - 1) / NT;
+  Chunk ch[CPT];
+  __device__ __forceinline__ void init(int tid) {
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int q = 2 * d + h, oy = q / L::PW, ox = q - oy * L::PW;
-      if (oy < L::OH && ox < L::OW) {
-        load8(dz + (oy * L::OW + ox) * L::CO + 8 * cg, v[h]);
-      } else {
+    for (int r = 0; r < CPT; r++) {
+      const int c = tid + r * NT, cg = c / ND, d = c - cg * ND;
+      int so[2];
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[h][j] = 0.f;
+      for (int h = 0; h < 2; h++) {
+        const int q = 2 * d + h, oy = q / L::PW, ox = q - oy * L::PW;
+        so[h] = (oy < L::OH && ox < L::OW) ? (oy * L::OW + ox) * L::CO + 8 * cg : -1;
       }
+      ch[r] = Chunk{so[0], so[1], c < NCH ? (8 * cg) * (L::DZP / 2) + d : -1};
     }
+  }
+};
+// layer input of one image, NHWC fp32 [IH][IW][CI] -> space-to-depth planes (bf16 pairs)
+template <class L>
+struct PlMap {
+  static constexpr int NDP = (L::PH * L::PW + 1) / 2, NCG = L::CI / 8, NCH = L::S * L::S * NCG * NDP,
+                       CPT = (NCH + NT - 1) / NT;
+  Chunk ch[CPT];
+  __device__ __forceinline__ void init(int tid) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) dzp32[(8 * cg + j) * (L::DZP / 2) + d] = pack2(v[0][j], v[1][j]);
+    for (int r = 0; r < CPT; r++) {
+      const int c = tid + r * NT, d = c % NDP, t = c / NDP, cg = t % NCG, ph = t / NCG, sy = ph / L::S, sx = ph % L::S;
+      int so[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int pos = 2 * d + h, Y = pos / L::PW, X = pos - Y * L::PW, y = L::S * Y + sy, x = L::S * X + sx;
+        so[h] = (pos < L::PH * L::PW && y < L::IH && x < L::IW) ? (y * L::IW + x) * L::CI + 8 * cg : -1;
+      }
+      ch[r] = Chunk{so[0], so[1], c < NCH ? (ph * L::CI + 8 * cg) * (L::PLP / 2) + d : -1};
+    }
+  }
+};
+// Staging is split so that the global loads of image i+1 are in flight during the MFMAs of image i:
+// fetch_chunks = global -> registers (raw bits), put_chunks = registers -> LDS planes (bf16 pairs).
+template <class T> struct RawVec;  // 8 source elements as loaded
+template <> struct RawVec<float> { uint4 q[2]; };
+template <> struct RawVec<__bf16> { uint4 q[1]; };
+// loads are unconditional (callers clamp the address) and masked afterwards: a conditional load would
+// keep the register array in scratch
+__device__ __forceinline__ uint4 mask4(uint4 v, bool on) {
+  const uint32_t m = on ? 0xffffffffu : 0u;
+  return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
+__device__ __forceinline__ void raw_load(RawVec<float>& v, const float* p, bool on) {
+  v.q[0] = mask4(reinterpret_cast<const uint4*>(p)[0], on);
+  v.q[1] = mask4(reinterpret_cast<const uint4*>(p)[1], on);
+}
+__device__ __forceinline__ void raw_load(RawVec<__bf16>& v, const __bf16* p, bool on) {
+  v.q[0] = mask4(reinterpret_cast<const uint4*>(p)[0], on);
+}
+// dword j of the result = {bf16(a[j]) low, bf16(b[j]) high}
+__device__ __forceinline__ void raw_pair(const RawVec<float>& a, const RawVec<float>& b, uint32_t (&o)[8]) {
+  const uint32_t aw[8] = {a.q[0].x, a.q[0].y, a.q[0].z, a.q[0].w, a.q[1].x, a.q[1].y, a.q[1].z, a.q[1].w};
+  const uint32_t bw[8] = {b.q[0].x, b.q[0].y, b.q[0].z, b.q[0].w, b.q[1].x, b.q[1].y, b.q[1].z, b.q[1].w};
+#pragma unroll
+  for (int j = 0; j < 8; j++) o[j] = pack2(__builtin_bit_cast(float, aw[j]), __builtin_bit_cast(float, bw[j]));
+}
+__device__ __forceinline__ void raw_pair(const RawVec<__bf16>& a, const RawVec<__bf16>& b, uint32_t (&o)[8]) {
+  const uint32_t aw[4] = {a.q[0].x, a.q[0].y, a.q[0].z, a.q[0].w}, bw[4] = {b.q[0].x, b.q[0].y, b.q[0].z, b.q[0].w};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    o[2 * k] = (aw[k] & 0xffffu) | (bw[k] << 16);
+    o[2 * k + 1] = (aw[k] >> 16) | (bw[k] & 0xffff0000u);
+  }
+}
+template <int CPT, class T>
+__device__ __forceinline__ void fetch_chunks(const Chunk (&ch)[CPT], const T* __restrict__ src, RawVec<T> (&v)[CPT][2]) {
+#pragma unroll
+  for (int r = 0; r < CPT; r++) {
+    raw_load(v[r][0], src + (ch[r].s0 >= 0 ? ch[r].s0 : 0), ch[r].dst >= 0 && ch[r].s0 >= 0);
+    raw_load(v[r][1], src + (ch[r].s1 >= 0 ? ch[r].s1 : 0), ch[r].dst >= 0 && ch[r].s1 >= 0);
+  }
+}
+template <int CPT, int PITCH2, class T>
+__device__ __forceinline__ void put_chunks(const Chunk (&ch)[CPT], const RawVec<T> (&v)[CPT][2], uint32_t* dst32) {
+#pragma unroll
+  for (int r = 0; r < CPT; r++) {
+    if (ch[r].dst < 0) continue;
+    uint32_t o[8];
+    raw_pair(v[r][0], v[r][1], o);
+#pragma unroll
+    for (int j = 0; j < 8; j++) dst32[ch[r].dst + j * PITCH2] = o[j];
   }
 }
 
-// layer input of one image, NHWC fp32 [IH][IW][CI] -> space-to-depth planes (bf16 pairs)
+// bf16 NHWC image (CI = 3): coalesced raw copy into LDS, then LDS -> planes.  A wave takes every 8th
+// plane; a lane owns the same plane positions in every plane, so their raw offsets are resolved once.
 template <class L>
-__device__ __forceinline__ void stage_planes(const float* __restrict__ in, uint32_t* pl32, __bf16*, int tid) {
-  constexpr int NDP = (L::PH * L::PW + 1) / 2, NCG = L::CI / 8, NPH = L::S * L::S;
-  for (int c = tid; c < NPH * NCG * NDP; c += NT) {
-    const int d = c % NDP, t = c / NDP, cg = t % NCG, ph = t / NCG, sy = ph / L::S, sx = ph % L::S;
-    float v[2][8];
+struct ImgMap {
+  static constexpr int NDP = (L::PH * L::PW + 1) / 2, NJ = (NDP + 63) / 64;
+  int o0[NJ], o1[NJ];  // raw element offset of (Y, X) relative to the plane origin, -1 = outside
+  __device__ __forceinline__ void init(int lane) {
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int pos = 2 * d + h, Y = pos / L::PW, X = pos - Y * L::PW, y = L::S * Y + sy, x = L::S * X + sx;
-      if (pos < L::PH * L::PW && y < L::IH && x < L::IW) {
-        load8(in + (y * L::IW + x) * L::CI + 8 * cg, v[h]);
-      } else {
+    for (int j = 0; j < NJ; j++) {
+      const int d = lane + 64 * j;
+      int so[2];
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[h][j] = 0.f;
+      for (int h = 0; h < 2; h++) {
+        const int pos = 2 * d + h, Y = pos / L::PW, X = pos - Y * L::PW;
+        // phases (sy, sx) < S never leave the image when IH, IW are multiples of S (asserted below)
+        so[h] = (d < NDP && pos < L::PH * L::PW) ? (L::S * Y * L::IW + L::S * X) * L::CI : -1;
+      }
+      o0[j] = so[0]; o1[j] = so[1];
+    }
+  }
+};
+template <class L>
+struct ImgRaw {
+  static constexpr int NCHUNK = L::IH * L::IW * L::CI * 2 / 16, NR = (NCHUNK + NT - 1) / NT;
+  static_assert(L::IH * L::IW * L::CI * 2 % 16 == 0, "image bytes must be a multiple of 16");
+  static_assert(L::IH % L::S == 0 && L::IW % L::S == 0, "image size must be a multiple of the conv1 stride");
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 q[NR];
+  __device__ __forceinline__ void fetch(const __bf16* __restrict__ in, int tid) {
+#pragma unroll
+    for (int r = 0; r < NR; r++) {  // unconditional (clamped) so that q stays in registers
+      const int c = tid + r * NT;
+      q[r] = reinterpret_cast<const u32x4*>(in)[c < NCHUNK ? c : NCHUNK - 1];
+    }
+  }
+  __device__ __forceinline__ void put(__bf16* raw, int tid) const {
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+      if (tid + r * NT < NCHUNK) reinterpret_cast<u32x4*>(raw)[tid + r * NT] = q[r];
+  }
+};
+template <class L>
+__device__ __forceinline__ void transpose_image(const ImgMap<L>& m, uint32_t* pl32, const __bf16* raw, int tid) {
+  const unsigned short* r16 = reinterpret_cast<const unsigned short*>(raw);
+  const int lane = tid & 63, w = tid >> 6;
+  for (int pln = w; pln < L::NPL; pln += NW) {
+    const int ci = pln % L::CI, ph = pln / L::CI, base = ((ph / L::S) * L::IW + ph % L::S) * L::CI + ci;
+#pragma unroll
+    for (int j = 0; j < ImgMap<L>::NJ; j++) {
+      if (lane + 64 * j < ImgMap<L>::NDP) {
+        const uint32_t v0 = m.o0[j] >= 0 ? r16[base + m.o0[j]] : 0u, v1 = m.o1[j] >= 0 ? r16[base + m.o1[j]] : 0u;
+        pl32[pln * (L::PLP / 2) + lane + 64 * j] = v0 | (v1 << 16);
       }
     }
-#pragma unroll
-    for (int j = 0; j < 8; j++) pl32[(ph * L::CI + 8 * cg + j) * (L::PLP / 2) + d] = pack2(v[0][j], v[1][j]);
-  }
-}
-// bf16 NHWC image (CI = 3): coalesced raw copy into LDS, then LDS -> planes
-template <class L>
-__device__ __forceinline__ void stage_planes(const __bf16* __restrict__ in, uint32_t* pl32, __bf16* raw, int tid) {
-  constexpr int NCHUNK = L::IH * L::IW * L::CI * 2 / 16;
-  static_assert(L::IH * L::IW * L::CI * 2 % 16 == 0, "image bytes must be a multiple of 16");
-  for (int c = tid; c < NCHUNK; c += NT) reinterpret_cast<uint4*>(raw)[c] = reinterpret_cast<const uint4*>(in)[c];
-  __syncthreads();
-  constexpr int NDP = (L::PH * L::PW + 1) / 2;
-  const unsigned short* r16 = reinterpret_cast<const unsigned short*>(raw);
-  for (int c = tid; c < L::NPL * NDP; c += NT) {
-    const int d = c % NDP, pln = c / NDP, ci = pln % L::CI, ph = pln / L::CI, sy = ph / L::S, sx = ph % L::S;
-    uint32_t v[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int pos = 2 * d + h, Y = pos / L::PW, X = pos - Y * L::PW, y = L::S * Y + sy, x = L::S * X + sx;
-      v[h] = (pos < L::PH * L::PW && y < L::IH && x < L::IW) ? r16[(y * L::IW + x) * L::CI + ci] : 0u;
-    }
-    pl32[pln * (L::PLP / 2) + d] = v[0] | (v[1] << 16);
   }
 }
 
@@ -195,11 +288,31 @@ __global__ __launch_bounds__(NT) void ebw_wgrad_kernel(WgArgs a) {
   const InT* in = reinterpret_cast<const InT*>(a.in[p]);
   const DzT* dz = reinterpret_cast<const DzT*>(a.dz[p]);
   const __bf16* arow = dzp + (16 * (mgrp * MG) + i) * L::DZP + 8 * g;
+  constexpr bool IMG = sizeof(InT) == 2;  // bf16 NHWC image (conv1) vs fp32 activations
+  DzMap<L> dmap;
+  dmap.init(tid);
+  typename std::conditional<IMG, ImgMap<L>, PlMap<L>>::type imap;
+  imap.init(IMG ? lane : tid);
+  RawVec<DzT> dzr[DzMap<L>::CPT][2];
+  typename std::conditional<IMG, ImgRaw<L>, RawVec<InT>[std::conditional<IMG, DzMap<L>, PlMap<L>>::type::CPT][2]>::type inr;
+  auto fetch = [&](int img) {
+    fetch_chunks<DzMap<L>::CPT>(dmap.ch, dz + (long)img * L::OH * L::OW * L::CO, dzr);
+    if constexpr (IMG) inr.fetch(in + (long)img * L::IH * L::IW * L::CI, tid);
+    else fetch_chunks<PlMap<L>::CPT>(imap.ch, in + (long)img * L::IH * L::IW * L::CI, inr);
+  };
+  if (j0 < n_img) fetch(j0);
   for (int img = j0; img < n_img; img += a.wpp) {
     __syncthreads();  // previous image's fragments consumed (first pass: zero fill visible)
-    stage_dz<L, DzT>(dz + (long)img * L::OH * L::OW * L::CO, reinterpret_cast<uint32_t*>(dzp), tid);
-    stage_planes<L>(in + (long)img * L::IH * L::IW * L::CI, reinterpret_cast<uint32_t*>(pl), raw, tid);
+    put_chunks<DzMap<L>::CPT, L::DZP / 2>(dmap.ch, dzr, reinterpret_cast<uint32_t*>(dzp));
+    if constexpr (IMG) {
+      inr.put(raw, tid);
+      __syncthreads();
+      transpose_image<L>(imap, reinterpret_cast<uint32_t*>(pl), raw, tid);
+    } else {
+      put_chunks<PlMap<L>::CPT, L::PLP / 2>(imap.ch, inr, reinterpret_cast<uint32_t*>(pl));
+    }
     __syncthreads();
+    if (img + a.wpp < n_img) fetch(img + a.wpp);  // in flight during the MFMAs below
 #pragma unroll
     for (int s = 0; s < L::KQ / 32; s++) {
       bf16x8 A[MG];
@@ -218,16 +331,20 @@ __global__ __launch_bounds__(NT) void ebw_wgrad_kernel(WgArgs a) {
       }
     }
   }
+  // partial slab in accumulator order (one coalesced 16 B store per tile and lane):
+  //   dW: [wave][u][j][lane][4]   db: [CO] after the CO*TAPS tile floats
   float* sl = a.slab + (long)blockIdx.x * L::SLABF;
 #pragma unroll
-  for (int j = 0; j < MG; j++)
+  for (int u = 0; u < UPW; u++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int co = 16 * (mgrp * MG + j) + 4 * g + r;
+    for (int j = 0; j < MG; j++)
+      *reinterpret_cast<f32x4*>(sl + (((w * UPW + u) * MG + j) * 64 + lane) * 4) = acc[u][j];
+  if (nslot == 0 && i == 0) {
 #pragma unroll
-      for (int u = 0; u < UPW; u++) sl[co * L::TAPS + 16 * (nslot + u * WPG) + i] = acc[u][j][r];
-      if (nslot == 0 && i == 0) sl[L::CO * L::TAPS + co] = bacc[j][r];
-    }
+    for (int j = 0; j < MG; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) sl[L::CO * L::TAPS + 16 * (mgrp * MG + j) + 4 * g + r] = bacc[j][r];
+  }
 }
 
 // Sum of the per-workgroup slabs of all three layers and all problems in one launch, fixed order:
@@ -236,7 +353,7 @@ struct RdArgs {
   const float* slab[3];
   float* gw[3][EBW_MAXP];
   float* gb[3][EBW_MAXP];
-  int nW[3], nB[3];
+  int nW[3], nB[3], taps[3], mg[3], upw[3], ngr[3];  // wave tiling of each layer's wgrad kernel
   int wpp, accumulate;
 };
 __global__ __launch_bounds__(256) void ebw_reduce_kernel(RdArgs a) {
@@ -253,7 +370,15 @@ __global__ __launch_bounds__(256) void ebw_reduce_kernel(RdArgs a) {
   __syncthreads();
   if (kg == 0 && e < per) {
     const float v = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
-    float* o = e < a.nW[l] ? a.gw[l][p] + e : a.gb[l][p] + (e - a.nW[l]);
+    float* o;
+    if (e < a.nW[l]) {  // slab element (wave, u, j, lane, r) -> dW[co][tap]
+      const int r = e & 3, lane = (e >> 2) & 63, t = e >> 8, MG = a.mg[l], UPW = a.upw[l], NGR = a.ngr[l];
+      const int j = t % MG, u = (t / MG) % UPW, w = t / (MG * UPW), mgrp = w % NGR, nslot = w / NGR, WPG = NW / NGR;
+      const int co = 16 * (mgrp * MG + j) + 4 * (lane >> 4) + r, tap = 16 * (nslot + u * WPG) + (lane & 15);
+      o = a.gw[l][p] + (long)co * a.taps[l] + tap;
+    } else {
+      o = a.gb[l][p] + (e - a.nW[l]);
+    }
     *o = a.accumulate ? *o + v : v;
   }
 }
@@ -292,7 +417,9 @@ __global__ __launch_bounds__(256) void ebw_pack_kernel(PkArgs a) {
 }
 
 template <class L>
-constexpr size_t dgrad_lds_bytes() { return (size_t)2 * L::R * L::C * L::PP * 2; }
+constexpr int dgrad_mask_bytes() { return (L::IH * L::IW * L::CI / 8 + 15) / 16 * 16; }
+template <class L>
+constexpr size_t dgrad_lds_bytes() { return (size_t)2 * L::R * L::C * L::PP * 2 + 2 * dgrad_mask_bytes<L>(); }
 
 template <class L, class DzT>
 __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
@@ -302,6 +429,11 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
   constexpr int NCG = L::CO / 8, NCH = L::OH * L::OW * NCG, CPT = (NCH + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* dzh = reinterpret_cast<__bf16*>(smem);  // 2 x [R][C][PP], zero halo
+  // ReLU mask of the layer input, one bit per element ([pixel][ci] order), 2 buffers: the fp32
+  // activations are read once, coalesced, by the staging threads instead of 4 B gathers in the epilogue
+  constexpr int MKB = dgrad_mask_bytes<L>(), NYC = L::IH * L::IW * L::CI / 8, CPY = (NYC + NT - 1) / NT;
+  static_assert(L::CI % 8 == 0, "mask bytes hold 8 channels of one pixel");
+  unsigned char* mkb = smem + (size_t)2 * BUF * 2;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
   const int p = blockIdx.x / a.wpp, j0 = blockIdx.x - p * a.wpp;
   const int n_img = a.n[p];
@@ -322,18 +454,44 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
     const int Y = m / L::PW, X = m - Y * L::PW;
     abase[t] = ((Y + L::HA) * L::C + X + L::HB) * L::PP + 8 * g;
   }
+  // output element (relative to the image) of accumulator register r of tile t, -1 = padding
+  int oidx[MTW][4];
+#pragma unroll
+  for (int t = 0; t < MTW; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int m = 16 * (mpart + t * MPARTS) + 4 * g + r, Y = m / L::PW, X = m - Y * L::PW;
+      const int y = L::S * Y + py, x = L::S * X + px;
+      oidx[t][r] = (m < L::PH * L::PW && y < L::IH && x < L::IW) ? (y * L::IW + x) * L::CI + 16 * nt + i : -1;
+    }
   const DzT* dz = reinterpret_cast<const DzT*>(a.dz[p]);
   const float* yin = a.yin[p];
   __bf16* dx = a.dx[p];
   bf16x8 pre[CPT];
+  float ypre[CPY][8];
   auto fetch = [&](int img) {
 #pragma unroll
     for (int r = 0; r < CPT; r++) {
       const int c = tid + r * NT;
       if (c < NCH) pre[r] = load8v(dz + ((long)img * L::OH * L::OW + c / NCG) * L::CO + 8 * (c % NCG));
     }
+#pragma unroll
+    for (int r = 0; r < CPY; r++) {
+      const int c = tid + r * NT;
+      if (c < NYC) load8(yin + (long)img * L::IH * L::IW * L::CI + 8 * c, ypre[r]);
+    }
   };
-  auto put = [&](__bf16* buf) {
+  auto put = [&](__bf16* buf, unsigned char* mb) {
+#pragma unroll
+    for (int r = 0; r < CPY; r++) {
+      const int c = tid + r * NT;
+      if (c < NYC) {
+        unsigned b = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) b |= (ypre[r][j] > 0.f ? 1u : 0u) << j;
+        mb[c] = (unsigned char)b;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < CPT; r++) {
       const int c = tid + r * NT;
@@ -344,13 +502,15 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
     }
   };
   __syncthreads();  // zero fill done
-  if (j0 < n_img) { fetch(j0); put(dzh); }
+  if (j0 < n_img) { fetch(j0); put(dzh, mkb); }
   __syncthreads();
   int k = 0;
   for (int img = j0; img < n_img; img += a.wpp, k ^= 1) {
     const int nxt = img + a.wpp;
     if (nxt < n_img) fetch(nxt);
     const __bf16* buf = dzh + k * BUF;
+    const unsigned char* mb = mkb + k * MKB;
+    const long ibase = (long)img * L::IH * L::IW * L::CI;
 #pragma unroll
     for (int t = 0; t < MTW; t++) {
       const int mt = mpart + t * MPARTS;
@@ -363,15 +523,13 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bf[ks], acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int m = 16 * mt + 4 * g + r, Y = m / L::PW, X = m - Y * L::PW, y = L::S * Y + py, x = L::S * X + px;
-        if (m < L::PH * L::PW && y < L::IH && x < L::IW) {
-          const long idx = ((long)img * L::IH * L::IW + y * L::IW + x) * L::CI + 16 * nt + i;
-          dx[idx] = (__bf16)(yin[idx] > 0.f ? acc[r] : 0.f);
+      for (int r = 0; r < 4; r++)
+        if (oidx[t][r] >= 0) {
+          const bool on = (mb[oidx[t][r] >> 3] >> (oidx[t][r] & 7)) & 1;
+          dx[ibase + oidx[t][r]] = (__bf16)(on ? acc[r] : 0.f);
         }
-      }
     }
-    if (nxt < n_img) put(dzh + (k ^ 1) * BUF);
+    if (nxt < n_img) put(dzh + (k ^ 1) * BUF, mkb + (k ^ 1) * MKB);
     __syncthreads();
   }
 }
@@ -474,6 +632,11 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
   r.slab[0] = g1.slab; r.slab[1] = g2.slab; r.slab[2] = g3.slab;
   r.nW[0] = L1::CO * L1::TAPS; r.nW[1] = L2::CO * L2::TAPS; r.nW[2] = L3::CO * L3::TAPS;
   r.nB[0] = L1::CO; r.nB[1] = L2::CO; r.nB[2] = L3::CO;
+  r.taps[0] = L1::TAPS; r.taps[1] = L2::TAPS; r.taps[2] = L3::TAPS;
+  constexpr int MG1 = 1, MG2 = 4, MG3 = 2;  // must match the launch_wgrad instantiations above
+  r.mg[0] = MG1; r.mg[1] = MG2; r.mg[2] = MG3;
+  r.ngr[0] = L1::MT / MG1; r.ngr[1] = L2::MT / MG2; r.ngr[2] = L3::MT / MG3;
+  r.upw[0] = L1::NTL / (NW / r.ngr[0]); r.upw[1] = L2::NTL / (NW / r.ngr[1]); r.upw[2] = L3::NTL / (NW / r.ngr[2]);
   r.wpp = w.wpp; r.accumulate = accumulate;
   for (int p = 0; p < nprob; p++) {
     r.gw[0][p] = gw1[p]; r.gb[0][p] = gb1[p]; r.gw[1][p] = gw2[p]; r.gb[1][p] = gb2[p];
