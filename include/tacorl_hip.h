@@ -45,6 +45,7 @@ int tacorl_linear_add_fwd(int nprob, const float* const* x, int ldx, const float
                           const float* const* b, const float* const* addend, int ld_add, float* const* y,
                           int ldy, const int* M, int K, int N, int act, int compute_dtype, void* ws,
                           size_t ws_bytes, tacorl_stream_t stream);
+
 /* Backward primitives of y = act(x W^T + b):
  *   dgrad: out[m][i] = (sum_o dz[m][o] W[o][i] + addend[m][i]) * act'(src[m][i])
  *   wgrad: dw[o][k] (+)= sum_m dz[m][o] x[m][k], db[o] (+)= sum_m dz[m][o]  (split-R slabs in ws). */
@@ -115,6 +116,17 @@ long tacorl_mlp_act_layout(int M, int n_layers, const int* dims, const int* acts
 int tacorl_mlp_fwd(int nprob, const float* const* x, int ldx, const float* const* params,
                    float* const* act, const int* M, int n_layers, const int* dims,
                    const int* acts, int compute_dtype, tacorl_stream_t stream);
+/* The same forward as ONE launch (bf16 MFMA only; <= 8 problems, <= 4 layers, every layer input width a
+ * multiple of 8 and all widths <= 256, ldx % 4 == 0 - query with _supported).  params_bf16[p] is a bf16
+ * copy of params[p] at the same element offsets (tacorl_to_bf16_batch); the caller refreshes it
+ * whenever the fp32 block changes.  Saved activations are identical in layout to tacorl_mlp_fwd's. */
+int tacorl_mlp_fwd_fused_supported(int nprob, int n_layers, const int* dims, int ldx);
+int tacorl_mlp_fwd_fused(int nprob, const float* const* x, int ldx, const float* const* params,
+                         const void* const* params_bf16, float* const* act, const int* M,
+                         int n_layers, const int* dims, const int* acts, tacorl_stream_t stream);
+/* dst[i][:] = bf16(src[i][:]) for n <= 16 buffers in one launch (count[i] % 4 == 0). */
+int tacorl_to_bf16_batch(int n, const float* const* src, void* const* dst, const long* count,
+                         tacorl_stream_t stream);
 size_t tacorl_mlp_bwd_ws_bytes(int nprob, const int* M, int n_layers, const int* dims);
 /* d_out: gradient w.r.t. the last layer's output [M][dims[n_layers]], leading dim ldo (last act
  * must be NONE).

@@ -8,6 +8,7 @@
 
 #include "../../include/tacorl_hip.h"
 #include "enc_bwd_fused.h"
+#include "mlp_fused.h"
 #include "functors.h"
 
 static thread_local char g_err[256] = "";
@@ -745,6 +746,51 @@ extern "C" int tacorl_mlp_fwd(int nprob, const float* const* x, int ldx, const f
     CHECK(k_linear_fwd(nprob, xin, l == 0 ? ldx : dims[l], w, b, y, z, M, dims[l], dims[l + 1], dims[l + 1], acts[l], cd, st));
   }
   return TACORL_OK;
+}
+
+// Whole MLP forward in one launch (mlp_fused.hip): bf16 MFMA only; params_bf16[p] = bf16 copy of
+// params[p] (tacorl_to_bf16_batch), which the caller refreshes whenever the fp32 block changes.
+extern "C" int tacorl_mlp_fwd_fused_supported(int nprob, int L, const int* dims, int ldx) {
+  return mlp_fused_fwd_ok(nprob, L, dims, ldx) ? 1 : 0;
+}
+extern "C" int tacorl_mlp_fwd_fused(int nprob, const float* const* x, int ldx, const float* const* params,
+                                    const void* const* params_bf16, float* const* act, const int* M, int L,
+                                    const int* dims, const int* acts, tacorl_stream_t stream) {
+  if (!mlp_fused_fwd_ok(nprob, L, dims, ldx)) FAIL(TACORL_EINVAL, "mlp_fwd_fused: shapes not supported");
+  long wo[MLP_MAXL], bo[MLP_MAXL];
+  tacorl_mlp_param_layout(L, dims, wo, bo);
+  long zo[MF_MAXP * MF_MAXL], yo[MF_MAXP * MF_MAXL];
+  for (int p = 0; p < nprob; p++) {
+    long z1[MLP_MAXL], y1[MLP_MAXL];
+    tacorl_mlp_act_layout(M[p], L, dims, acts, z1, y1);
+    for (int l = 0; l < L; l++) { zo[p * MF_MAXL + l] = z1[l]; yo[p * MF_MAXL + l] = y1[l]; }
+  }
+  const int rc = mlp_fused_fwd(nprob, x, ldx, params, params_bf16, act, M, L, dims, acts, zo, yo, wo, bo, (hipStream_t)stream);
+  if (rc != TACORL_OK) FAIL(rc, "mlp_fwd_fused: launch failed (%d)", rc);
+  return TACORL_OK;
+}
+struct ToBf16Tbl { const float* src[16]; __bf16* dst[16]; long n4[16]; };
+__global__ void to_bf16_batch_kernel(ToBf16Tbl t) {
+  const int b = blockIdx.y;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < t.n4[b]; q += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(t.src[b])[q];
+    reinterpret_cast<bf16x4*>(t.dst[b])[q] = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  }
+}
+extern "C" int tacorl_to_bf16_batch(int n, const float* const* src, void* const* dst, const long* count,
+                                    tacorl_stream_t stream) {
+  if (n < 1 || n > 16) FAIL(TACORL_EINVAL, "to_bf16_batch: n %d", n);
+  ToBf16Tbl t{};
+  long mx = 0;
+  for (int i = 0; i < n; i++) {
+    if (count[i] % 4 || !aligned16(src[i]) || ((uintptr_t)dst[i] & 7)) FAIL(TACORL_EINVAL, "to_bf16_batch: count %% 4 and alignment");
+    t.src[i] = src[i]; t.dst[i] = (__bf16*)dst[i]; t.n4[i] = count[i] / 4;
+    mx = t.n4[i] > mx ? t.n4[i] : mx;
+  }
+  if (mx == 0) return TACORL_OK;
+  hipLaunchKernelGGL(to_bf16_batch_kernel, dim3((unsigned)(cdiv(mx, 256) > 1024 ? 1024 : cdiv(mx, 256)), n), dim3(256), 0,
+                     (hipStream_t)stream, t);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
 static void mlp_bwd_sizes(int nprob, const int* M, int L, const int* dims, long& dz_floats, size_t& slab) {

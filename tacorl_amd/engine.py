@@ -44,6 +44,9 @@ class NetBlock:
         self.size = off
         z = lambda: torch.zeros(self.size, device=device)  # noqa: E731
         self.param, self.grad, self.m, self.v = z(), z(), z(), z()
+        # bf16 copy of the MLP part of the block (the fused MLP forward's MFMA operand); refreshed from
+        # the fp32 master at the start of every update (ACEngine._refresh_bf16)
+        self.param_bf16 = torch.zeros(self.size, device=device, dtype=torch.bfloat16)
         self.step = torch.zeros(1, dtype=torch.int32, device=device)
         self.views, self.grad_views = {}, {}
         for flat, dst in ((self.param, self.views), (self.grad, self.grad_views)):
@@ -67,6 +70,12 @@ class NetBlock:
 
     def head(self, flat=None):
         return (self.param if flat is None else flat).data_ptr() + 4 * self.head_off
+
+    def genc_bf16(self):
+        return self.param_bf16.data_ptr() + 2 * self.genc_off
+
+    def head_bf16(self):
+        return self.param_bf16.data_ptr() + 2 * self.head_off
 
 
 class Scalar:
@@ -270,6 +279,15 @@ class ACEngine:
                      ops.ptr_array([x[3] for x in pr]), ops.int_array([x[4] for x in pr]), H, W, xd, self.compute,
                      ops.stream())
 
+    def _refresh_bf16(self):
+        """bf16 copies of the five networks' MLP weights (one launch); the fp32 blocks stay the masters."""
+        if self.compute != BF16:
+            return
+        nets = [self.actor, self.q1, self.q2, self.tq1, self.tq2]
+        call("tacorl_to_bf16_batch", len(nets), ops.ptr_array([n_.genc() for n_ in nets]),
+             ops.ptr_array([n_.genc_bf16() for n_ in nets]), (ops.C.c_long * len(nets))(*[n_.size - n_.genc_off for n_ in nets]),
+             ops.stream())
+
     def _assemble_states(self):
         B = self.B
         # goal-encoder inputs: concat over cams of enc(goal)
@@ -281,7 +299,8 @@ class ACEngine:
         nets = dict(self.nets)
         ks = ["a", "q1", "q2", "tq1", "tq2"]
         ops.mlp_fwd([self.gin[k] for k in ks], self.G, [nets[k].genc() for k in ks], [self.gact[k] for k in ks],
-                    [B] * 5, self.actor.genc_dims, self.actor.genc_acts, self.compute)
+                    [B] * 5, self.actor.genc_dims, self.actor.genc_acts, self.compute,
+                    params_bf16=[nets[k].genc_bf16() for k in ks])
         # S = [enc(obs or next) | goal_enc(enc(goal))]
         obs_src = {"a": ("a_og", 0, "a"), "a_nx": ("a_nx", 0, "a"), "q1": ("q1", 0, "q1"), "q2": ("q2", 0, "q2"),
                    "tq1": ("tq1", B, "tq1"), "tq2": ("tq2", B, "tq2")}
@@ -294,7 +313,8 @@ class ACEngine:
     def _policy_fwd(self):
         ks = ["a", "a_nx"]
         ops.mlp_fwd([self.S[k] for k in ks], self.lds, [self.actor.head()] * 2, [self.pact[k] for k in ks],
-                    [self.B] * 2, self.actor.head_dims, self.actor.head_acts, self.compute)
+                    [self.B] * 2, self.actor.head_dims, self.actor.head_acts, self.compute,
+                    params_bf16=[self.actor.head_bf16()] * 2)
 
     def _head(self, k):
         return self.pact[k][self.p_yoff: self.p_yoff + self.B * self.HD]
@@ -325,6 +345,7 @@ class ACEngine:
         gs = 1.0 / self.world
         if not encoded:
             self._encode_all()
+        self._refresh_bf16()
         self._assemble_states()
         self._policy_fwd()
         head_cur, head_next = self._head("a"), self._head("a_nx")
@@ -371,7 +392,9 @@ class ACEngine:
         ps = [self.q1.head(), self.q2.head(), self.q1.head(), self.q2.head(), self.tq1.head(), self.tq2.head()]
         ac = [self.qact["q1"], self.qact["q2"], self.qact_pi["q1"], self.qact_pi["q2"], self.qact_t["tq1"],
               self.qact_t["tq2"]]
-        ops.mlp_fwd(xs, self.ldq, ps, ac, [self.R, self.R, B, B, B, B], qd, qa, self.compute)
+        pb = [self.q1.head_bf16(), self.q2.head_bf16(), self.q1.head_bf16(), self.q2.head_bf16(), self.tq1.head_bf16(),
+              self.tq2.head_bf16()]
+        ops.mlp_fwd(xs, self.ldq, ps, ac, [self.R, self.R, B, B, B, B], qd, qa, self.compute, params_bf16=pb)
         qout = lambda buf, off, rows: buf[off: off + rows]  # noqa: E731
         q1m, q2m = qout(self.qact["q1"], self.q_yoff_R, self.R), qout(self.qact["q2"], self.q_yoff_R, self.R)
         q1p, q2p = qout(self.qact_pi["q1"], self.q_yoff_B, B), qout(self.qact_pi["q2"], self.q_yoff_B, B)

@@ -107,7 +107,14 @@ def encoder_bwd(imgs, params, acts, d_outs, grads, H, W, compute=F32, accumulate
 
 
 # ------------------------------------------------------------------------------- MLP
-def mlp_fwd(xs, ldx, params, acts_buf, M, dims, acts, compute=F32):
+def mlp_fwd(xs, ldx, params, acts_buf, M, dims, acts, compute=F32, params_bf16=None):
+    """params_bf16: bf16 copies of the parameter blocks -> the whole MLP runs as one launch when the
+    shapes qualify (bf16 mode only); otherwise one GEMM launch per layer."""
+    if (params_bf16 is not None and compute == BF16
+            and L.lib().tacorl_mlp_fwd_fused_supported(len(xs), len(dims) - 1, int_array(dims), ldx)):
+        call("tacorl_mlp_fwd_fused", len(xs), ptr_array(xs), ldx, ptr_array(params), ptr_array(params_bf16),
+             ptr_array(acts_buf), int_array(M), len(dims) - 1, int_array(dims), int_array(acts), stream())
+        return
     call("tacorl_mlp_fwd", len(xs), ptr_array(xs), ldx, ptr_array(params), ptr_array(acts_buf), int_array(M),
          len(dims) - 1, int_array(dims), int_array(acts), compute, stream())
 

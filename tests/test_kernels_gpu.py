@@ -390,3 +390,43 @@ def test_encoder_fused_backward(H, W, accumulate):
             c = (vg[name] - (0.25 if accumulate else 0.0)).reshape(-1).double().cpu()
             cos_gen = (c @ b / (c.norm() * b.norm()).clamp_min(1e-30)).item()
             assert cos > 0.97 and cos > cos_gen - 0.005, ("vs fp32 autograd", name, cos, cos_gen)
+
+
+@pytest.mark.parametrize("dims,acts", [([64, 256, 256, 256, 32], [2, 2, 2, 0]), ([80, 256, 256, 256, 1], [2, 2, 2, 0]),
+                                       ([32, 256, 256, 32], [1, 1, 0]), ([64, 128, 24], [2, 0])])
+def test_mlp_fused_forward(dims, acts):
+    """Single-launch MLP forward vs the per-layer bf16 path (same operand rounding) - outputs and every
+    saved activation - and vs fp32 torch at bf16 tolerance; ragged row counts, several problems."""
+    from tacorl_amd import _lib, blocks, ops
+
+    dev = _dev()
+    Ms = [70, 9, 300]
+    L = len(dims) - 1
+    assert _lib.lib().tacorl_mlp_fwd_fused_supported(len(Ms), L, ops.int_array(dims), dims[0]) == 1
+    xs, flats, fb, a_f, a_g, refs = [], [], [], [], [], []
+    for i, M in enumerate(Ms):
+        flat = torch.zeros(blocks.mlp_size(dims), device=dev)
+        v = blocks.mlp_views(flat, 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+        h = rnd(M, dims[0], seed=170 + i)
+        xs.append(h.to(dev).contiguous())
+        for l in range(L):
+            W = rnd(dims[l + 1], dims[l], seed=150 + i + l, scale=1 / math.sqrt(dims[l]))
+            b = rnd(dims[l + 1], seed=160 + i + l, scale=0.1)
+            v[f"l{l}.w"].copy_(W); v[f"l{l}.b"].copy_(b)
+            h = F.linear(h, W, b)
+            h = [h, F.relu(h), F.silu(h)][acts[l]]
+        refs.append(h)
+        flats.append(flat)
+        fb.append(flat.to(torch.bfloat16))
+        n_act = ops.mlp_act_layout(M, dims, acts)[2]
+        a_f.append(torch.zeros(n_act, device=dev))  # (4-float alignment gaps between layers stay unwritten)
+        a_g.append(torch.zeros(n_act, device=dev))
+    ops.mlp_fwd(xs, dims[0], flats, a_g, Ms, dims, acts, 1)
+    ops.mlp_fwd(xs, dims[0], flats, a_f, Ms, dims, acts, 1, params_bf16=fb)
+    torch.cuda.synchronize()
+    for i, M in enumerate(Ms):
+        assert torch.isfinite(a_f[i]).all()
+        assert relerr(a_f[i], a_g[i]) < 2e-3, relerr(a_f[i], a_g[i])
+        yo = ops.mlp_act_layout(M, dims, acts)[1][-1]
+        y = a_f[i][yo: yo + M * dims[-1]].view(M, dims[-1])
+        assert relerr(y, refs[i]) < TOL_BF16
