@@ -147,13 +147,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         sys.exit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    # Test hooks (never set by the driver): run the N-rank code path on a 1-GPU box - every rank on
+    # cuda:0 and gloo instead of RCCL (which refuses two ranks on one device).
+    if os.environ.get("TACORL_BENCH_SINGLE_DEVICE"):
+        local = 0
+    backend = os.environ.get("TACORL_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from tacorl_amd import _lib
 
@@ -186,6 +194,14 @@ def main():
     ms_step = dt / a.steps * 1e3
     logs = mod.engine.metrics()
     finite = all(v == v and abs(v) < 1e30 for v in logs.values())
+    in_sync = None
+    if world > 1:  # replicas must hold identical parameters after the timed steps (same all-reduced grads)
+        e = mod.engine
+        cs = torch.stack([x.param.double().sum() for x in (e.actor, e.q1, e.q2)]).to(dev)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(torch.equal(lo, hi))
 
     out = None
     if rank == 0:
@@ -204,7 +220,8 @@ def main():
                        "latent_plan": 16, "n_action_samples": 4, "phase": "Q (epoch>=bc_epochs)",
                        "action_decoder_loss": ("every step (reference behaviour)" if a.ad_every <= 1 else
                                                f"every {a.ad_every} steps (logging cadence)"), "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
-                       "samples_per_s": round(world * B / (ms_step * 1e-3), 1), "losses_finite": finite},
+                       "samples_per_s": round(world * B / (ms_step * 1e-3), 1), "losses_finite": finite,
+                       "replicas_in_sync": in_sync},
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tflops / peak, 4), "traffic": measured_traffic(n_img, fused, a.dtype),
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
