@@ -179,23 +179,45 @@ class ACEngine:
         self.dS = {k: f(B, self.lds) for k in ("a", "q1", "q2")}
         self.dgin = {k: f(B, self.G) for k in ("a", "q1", "q2")}
         self.reward, self.done, self.action = f(B), f(B), f(B, self.A)
-        self.noise = dict(eps_pi=f(B, self.Ac), eps_next=f(B, self.Ac), u_rand=f(n * B, self.A),
-                          eps_cur=f(n, B, self.Ac), eps_nxt=f(n, B, self.Ac))
+        # all noise of a step in two flat buffers (normal | uniform): two generator launches per step
+        shapes = dict(eps_pi=(B, self.Ac), eps_next=(B, self.Ac), eps_cur=(n, B, self.Ac), eps_nxt=(n, B, self.Ac))
+        shapes.update(getattr(self, "extra_normal", {}))  # e.g. TACORL's plan-recognition eps
+        ushapes = dict(u_rand=(n * B, self.A))
         if self.dg:
-            self.noise.update(g_pi=f(B, 2), g_next=f(B, 2), g_cur=f(n, B, 2), g_nxt=f(n, B, 2))
+            ushapes.update(g_pi=(B, 2), g_next=(B, 2), g_cur=(n, B, 2), g_nxt=(n, B, 2))
+
+        def carve(sh):
+            import math
+            sizes = {k: _al4(math.prod(v)) for k, v in sh.items()}
+            flat = f(sum(sizes.values()))
+            out, off = {}, 0
+            for k, v in sh.items():
+                out[k] = flat[off: off + math.prod(v)].view(*v)
+                off += sizes[k]
+            return flat, out
+
+        self._noise_normal, nn_ = carve(shapes)
+        self._noise_uniform, nu_ = carve(ushapes)
+        self.extra_noise = {k: nn_.pop(k) for k in getattr(self, "extra_normal", {})}
+        self.noise = dict(eps_pi=nn_["eps_pi"], eps_next=nn_["eps_next"], u_rand=nu_["u_rand"], eps_cur=nn_["eps_cur"],
+                          eps_nxt=nn_["eps_nxt"])
+        if self.dg:
+            self.noise.update({k: nu_[k] for k in ("g_pi", "g_next", "g_cur", "g_nxt")})
         self.logs = f(32)
         self.cql_ws = torch.empty(max(256, ops.L.lib().tacorl_cql_ws_bytes(B)), dtype=torch.uint8, device=dev)
 
     # ------------------------------------------------------------------- inputs
     def set_noise(self, noise=None):
-        """Copy injected noise, or draw fresh noise with torch's device generator."""
+        """Copy injected noise, or draw fresh noise with torch's device generator (two launches)."""
+        if noise is None:
+            self._noise_normal.normal_()
+            self._noise_uniform.uniform_()
+            return
         for k, buf in self.noise.items():
-            if noise is not None:
+            buf.copy_(noise[k].reshape(buf.shape))
+        for k, buf in self.extra_noise.items():
+            if k in noise:
                 buf.copy_(noise[k].reshape(buf.shape))
-            elif k.startswith("eps"):
-                buf.normal_()
-            else:
-                buf.uniform_()
 
     def load_images(self, cam, obs, goal, nxt, nchw=True):
         """obs/goal/nxt: (B,3,H,W) [nchw] or (B,H,W,3) fp32 device tensors (may be strided views with a

@@ -91,7 +91,6 @@ class TACORL(CQL_Offline):
         self.f_act = {c: torch.zeros(ops.encoder_act_layout(B * T, *hw[c])[1], device=dev) for c in self.all_modalities}
         npr = len(self.plan_recognition_modalities)
         self.pr_in = torch.zeros(B * T, 32 * npr, device=dev)
-        self.eps_pr = torch.zeros(B, self.action_dim, device=dev)
         self.plan = torch.zeros(B, self.action_dim, device=dev)
         self.reward = torch.zeros(B, device=dev)
         # the frozen LMP encoder over the B*T window frames rides in the engine's encoder launches
@@ -105,7 +104,9 @@ class TACORL(CQL_Offline):
         states = batch["states"]
         B, T = next(iter(states.values())).shape[:2]
         hw = {c: (tuple(v.shape[-2:]) if nchw else tuple(v.shape[-3:-1])) for c, v in states.items()}
+        self.engine.extra_normal = {"eps_pr": (B, self.action_dim)}  # drawn with the engine's noise (one launch)
         self.engine.ensure_batch(B, {c: hw[c] for c in self.engine.cams})
+        self.eps_pr = self.engine.extra_noise["eps_pr"]
         self._ensure_seq(B, T, hw)
         xd = BF16 if self.img_dtype == torch.bfloat16 else F32
         for c in self.all_modalities:
@@ -114,10 +115,6 @@ class TACORL(CQL_Offline):
             assert v.is_cuda and v.is_contiguous() and v.dtype == torch.float32
             call("tacorl_pack_images", ptr(v), 3 * H * W, int(nchw), ptr(self.frames[c]), xd, B * T, 3, H, W,
                  ops.stream())
-        if noise is not None:
-            self.eps_pr.copy_(noise["eps_pr"])
-        else:
-            self.eps_pr.normal_()
         if self.ad is not None:
             if getattr(self, "acts", None) is None or self.acts.shape[:2] != (B, T):
                 self.acts = torch.zeros(B, T, 7, device=self.dev)
