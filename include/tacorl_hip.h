@@ -143,6 +143,10 @@ int tacorl_mlp_bwd(int nprob, const float* const* x, int ldx, const float* const
  * TACORL.get_rl_batch (reference modules/tacorl/tacorl.py:142-179). */
 int tacorl_pack_images(const float* src, long img_pitch, int src_nchw, void* dst, int dst_dtype,
                        int n, int C, int H, int W, tacorl_stream_t stream);
+/* Up to 8 NCHW (C = 3, H*W % 4 == 0, 16-byte aligned) -> NHWC packs in one launch: the B*T window frames
+ * and the obs / goal / next-obs images of a TACORL step (reference get_rl_batch, tacorl.py:142-179). */
+int tacorl_pack_images_batch(int njobs, const float* const* src, const long* img_pitch, void* const* dst,
+                             const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream);
 /* dst[r][0:cols] (+)= src[r % src_row_mod][0:cols]  (src_row_mod <= 0: r).  expand_obs on
  * embeddings instead of images (reference utils/misc.py:132-153) and torch.cat plumbing. */
 int tacorl_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols,

@@ -64,27 +64,32 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
     }
   }
   __syncthreads();
+  // LDS-only barrier: the fp32 activation rows written for the backward stay in flight across layers
+  // (nothing in this kernel reads them back), __syncthreads() would drain them at every layer
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  const int n0 = 64 * w;
+  bf16x8 B[8][4];
+  auto load_layer = [&](int l) {  // every weight fragment of the layer in flight at once (K <= 256)
+    const int K = a.dims[l], N = a.dims[l + 1];
+    const __bf16* Wb = a.pbf[p] + a.woff[l];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) B[ks][nt] = load_w(Wb, K, N, n0 + 16 * nt + i, 32 * ks + 8 * g);
+  };
+  if (n0 < a.dims[1]) load_layer(0);
   int cur = 0;
   for (int l = 0; l < a.L; l++) {
     const int K = a.dims[l], N = a.dims[l + 1], KS = (K + 31) / 32, act = a.acts[l];
     const float* bias = a.params[p] + a.boff[l];
     const __bf16* xin = X + cur * BMF * XP;
     __bf16* xout = X + (cur ^ 1) * BMF * XP;
-    const int n0 = 64 * w;
+    f32x4 acc[4][4];
     if (n0 < N) {  // wave-uniform: this wave owns output columns [n0, n0 + 64)
-      f32x4 acc[4][4];
 #pragma unroll
       for (int mt = 0; mt < 4; mt++)
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // all weight fragments of the layer in flight at once (K <= 256: 8 k-steps x 4 N tiles), so a
-      // layer costs one global round trip instead of one per k-step
-      const __bf16* Wb = a.pbf[p] + a.woff[l];
-      bf16x8 B[8][4];
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++)
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) B[ks][nt] = load_w(Wb, K, N, n0 + 16 * nt + i, 32 * ks + 8 * g);
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
         if (ks >= KS) break;
@@ -98,6 +103,10 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
             for (int mt = 0; mt < 4; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt], B[ks][nt], acc[mt][nt], 0, 0, 0);
           }
       }
+    }
+    // the next layer's weights travel while this layer's epilogue runs
+    if (l + 1 < a.L && n0 < a.dims[l + 2]) load_layer(l + 1);
+    if (n0 < N) {
       float* zb = a.zoff[p][l] >= 0 ? a.act[p] + a.zoff[p][l] : nullptr;
       float* yb = a.act[p] + a.yoff[p][l];
 #pragma unroll
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
           }
       }
     }
-    __syncthreads();
+    lds_barrier();
     cur ^= 1;
   }
 }

@@ -48,6 +48,63 @@ extern "C" int tacorl_pack_images(const float* src, long img_pitch, int src_nchw
   return LAUNCH_OK();
 }
 
+// Several NCHW fp32 -> NHWC packs in one launch (blockIdx.y = job), 4 pixels per thread: three 16 B
+// plane reads, 24 B (bf16) or 48 B (fp32) of contiguous interleaved output.  C = 3, H*W % 4 == 0.
+#define PACK_MAXJ 8
+struct PackTbl {
+  const float* src[PACK_MAXJ];
+  void* dst[PACK_MAXJ];
+  long pitch[PACK_MAXJ];
+  int n[PACK_MAXJ];
+};
+template <typename OutT>
+__global__ void pack_nchw3_batch_kernel(PackTbl t, int HW) {
+  const int j = blockIdx.y, q4 = HW / 4;
+  const long total = (long)t.n[j] * q4;
+  const float* __restrict__ src = t.src[j];
+  OutT* __restrict__ dst = reinterpret_cast<OutT*>(t.dst[j]);
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const long img = q / q4;
+    const int p = (int)(q - img * q4) * 4;
+    const float* s = src + img * t.pitch[j] + p;
+    const f32x4 r = *reinterpret_cast<const f32x4*>(s), g = *reinterpret_cast<const f32x4*>(s + HW),
+                b = *reinterpret_cast<const f32x4*>(s + 2 * HW);
+    const float v[12] = {r[0], g[0], b[0], r[1], g[1], b[1], r[2], g[2], b[2], r[3], g[3], b[3]};
+    OutT* d = dst + (img * HW + p) * 3;
+    if constexpr (sizeof(OutT) == 2) {
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        *reinterpret_cast<bf16x4*>(d + 4 * k) = bf16x4{(__bf16)v[4 * k], (__bf16)v[4 * k + 1], (__bf16)v[4 * k + 2], (__bf16)v[4 * k + 3]};
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        *reinterpret_cast<f32x4*>(d + 4 * k) = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+    }
+  }
+}
+extern "C" int tacorl_pack_images_batch(int njobs, const float* const* src, const long* img_pitch, void* const* dst,
+                                        const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream) {
+  if (njobs < 1 || njobs > PACK_MAXJ || (H * W) % 4) return TACORL_EINVAL;
+  PackTbl t{};
+  long mx = 0;
+  int m = 0;
+  for (int j = 0; j < njobs; j++) {
+    if (n_img[j] <= 0) continue;
+    if (((uintptr_t)src[j] & 15) || ((uintptr_t)dst[j] & 15) || img_pitch[j] % 4) return TACORL_EINVAL;
+    t.src[m] = src[j]; t.dst[m] = dst[j]; t.pitch[m] = img_pitch[j]; t.n[m] = n_img[j];
+    const long tot = (long)n_img[j] * (H * W / 4);
+    mx = tot > mx ? tot : mx;
+    m++;
+  }
+  if (m == 0) return TACORL_OK;
+  const int blocks = (int)((mx + 255) / 256 > 8192 ? 8192 : (mx + 255) / 256);
+  if (dst_dtype == TACORL_BF16)
+    hipLaunchKernelGGL(pack_nchw3_batch_kernel<__bf16>, dim3(blocks, m), dim3(256), 0, (hipStream_t)stream, t, H * W);
+  else
+    hipLaunchKernelGGL(pack_nchw3_batch_kernel<float>, dim3(blocks, m), dim3(256), 0, (hipStream_t)stream, t, H * W);
+  return LAUNCH_OK();
+}
+
 // ===================================================================== copy_cols
 __global__ void copy_cols_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
                                  int rows, int cols, int src_row_mod, int accumulate) {

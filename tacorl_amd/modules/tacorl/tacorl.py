@@ -109,21 +109,33 @@ class TACORL(CQL_Offline):
         self.eps_pr = self.engine.extra_noise["eps_pr"]
         self._ensure_seq(B, T, hw)
         xd = BF16 if self.img_dtype == torch.bfloat16 else F32
-        for c in self.all_modalities:
+        e = self.engine
+        # get_rl_batch (tacorl.py:142-179) as strided views: s = states[:,0], s' = states[:,-1]
+        for c in sorted(set(self.all_modalities) | set(e.cams)):
             H, W = hw[c]
             v = states[c]
             assert v.is_cuda and v.is_contiguous() and v.dtype == torch.float32
-            call("tacorl_pack_images", ptr(v), 3 * H * W, int(nchw), ptr(self.frames[c]), xd, B * T, 3, H, W,
-                 ops.stream())
+            jobs = [(v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), B * T)] if c in self.all_modalities else []
+            if c in e.cams:
+                g = batch["goal"][c]
+                assert g.is_cuda and g.is_contiguous() and g.dtype == torch.float32
+                esz, img = e.X3[c].element_size(), H * W * 3
+                x3 = e.X3[c].data_ptr()
+                jobs += [(v.data_ptr(), T * 3 * H * W, x3, B), (g.data_ptr(), 3 * H * W, x3 + B * img * esz, B),
+                         (v.data_ptr() + 4 * (T - 1) * 3 * H * W, T * 3 * H * W, x3 + 2 * B * img * esz, B)]
+            if nchw and (H * W) % 4 == 0:  # one launch for the window frames and the obs / goal / next images
+                import ctypes as C
+                call("tacorl_pack_images_batch", len(jobs), (C.c_void_p * len(jobs))(*[j[0] for j in jobs]),
+                     (C.c_long * len(jobs))(*[j[1] for j in jobs]), (C.c_void_p * len(jobs))(*[j[2] for j in jobs]),
+                     ops.int_array([j[3] for j in jobs]), xd, H, W, ops.stream())
+            else:
+                for src, pitch, dst, n in jobs:
+                    call("tacorl_pack_images", src, pitch, int(nchw), dst, xd, n, 3, H, W, ops.stream())
         if self.ad is not None:
             if getattr(self, "acts", None) is None or self.acts.shape[:2] != (B, T):
                 self.acts = torch.zeros(B, T, 7, device=self.dev)
             self.acts.copy_(batch["actions"])
         self.reward.copy_(batch["disp"] == 1)
-        # get_rl_batch (tacorl.py:142-179) as strided views: s = states[:,0], s' = states[:,-1]
-        e = self.engine
-        for c in e.cams:
-            e.load_images(c, states[c][:, 0], batch["goal"][c], states[c][:, -1], nchw=nchw)
         e.set_noise(noise)
         return B, T, hw
 
