@@ -12,9 +12,9 @@
 //   wgrad  dW[co][tap] = sum_pixels dZ[pixel][co] * im2col[pixel][tap].  The reduction index of an MFMA is
 //          the lane-contiguous one, and it is the *pixel* here, so both operands are re-laid in LDS
 //          pixel-contiguous: dZ as planes [co][q], the input as space-to-depth planes
-//          [(y%S, x%S, ci)][Y*PW + X]; with q = oy*PW + ox (output rows padded to the plane pitch) the 8
-//          pixels a lane needs for tap (ky,kx,ci) are 8 consecutive plane elements at offset
-//          (ky/S)*PW + kx/S - an (unaligned) ds_read_b128.  Padded q carry dZ = 0.
+//          [(y%S, x%S, ci)][Y*PWP + X]; with q = oy*PWP + ox (rows padded to a multiple of 8) the 8 pixels
+//          a lane needs for tap (ky,kx,ci) are 8 consecutive plane elements at offset (ky/S)*PWP + kx/S.
+//          One plane copy per kx/S, pre-shifted, makes that an aligned ds_read_b128.  Padded q carry dZ = 0.
 //          dW accumulates in registers across the images of a workgroup; one partial slab per workgroup,
 //          summed in fixed order by ebw_reduce_kernel (deterministic, no atomics).
 //   The bias gradient rides on the same MFMAs with an all-ones B fragment.
@@ -41,10 +41,14 @@ struct ConvL {
   static constexpr int KA = KH / S, KB = KW / S;                      // taps per stride-phase class
   static constexpr int TAPS = KH * KW * CI;
   static constexpr int NPL = CI * S * S;
-  static constexpr int KQ = (OH * PW + 31) / 32 * 32;  // padded pixel-reduction length
-  static constexpr int OFFMAX = (KA - 1) * PW + (KB - 1);
-  static constexpr int PLP = pitch8(cmax(PH * PW + 1, OFFMAX + KQ));  // plane pitch (elements)
-  static constexpr int DZP = KQ + 8;                                  // dZ plane pitch
+  // wgrad planes: row pitch PWP (multiple of 8) and one copy per horizontal tap offset b = kx / S, copy b
+  // holding plane[Y][X + b] at [Y][X] - every B fragment (8 pixels of one tap) is then a 16-byte
+  // ALIGNED ds_read_b128 (2-byte aligned reads of a single copy measured 2.3x slower per kernel)
+  static constexpr int PWP = (PW + 7) / 8 * 8;
+  static constexpr int KQ = (OH * PWP + 31) / 32 * 32;  // padded pixel-reduction length, q = oy*PWP + ox
+  static constexpr int PLP = pitch8(cmax(PH * PWP, (KA - 1) * PWP + KQ));  // plane pitch (elements)
+  static constexpr int NCOPY = KB;
+  static constexpr int DZP = KQ + 8;  // dZ plane pitch
   static constexpr int MT = CO / 16, NTL = TAPS / 16;
   static constexpr int SLABF = CO * TAPS + CO;  // floats per partial slab (dW | db)
   // dgrad
@@ -113,7 +117,7 @@ struct DzMap {
       int so[2];
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const int q = 2 * d + h, oy = q / L::PW, ox = q - oy * L::PW;
+        const int q = 2 * d + h, oy = q / L::PWP, ox = q - oy * L::PWP;
         so[h] = (oy < L::OH && ox < L::OW) ? (oy * L::OW + ox) * L::CO + 8 * cg : -1;
       }
       ch[r] = Chunk{so[0], so[1], c < NCH ? (8 * cg) * (L::DZP / 2) + d : -1};
@@ -123,7 +127,7 @@ struct DzMap {
 // layer input of one image, NHWC fp32 [IH][IW][CI] -> space-to-depth planes (bf16 pairs)
 template <class L>
 struct PlMap {
-  static constexpr int NDP = (L::PH * L::PW + 1) / 2, NCG = L::CI / 8, NCH = L::S * L::S * NCG * NDP,
+  static constexpr int NDP = L::PH * L::PWP / 2, NCG = L::CI / 8, NCH = L::S * L::S * NCG * NDP,
                        CPT = (NCH + NT - 1) / NT;
   Chunk ch[CPT];
   __device__ __forceinline__ void init(int tid) {
@@ -133,8 +137,8 @@ struct PlMap {
       int so[2];
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const int pos = 2 * d + h, Y = pos / L::PW, X = pos - Y * L::PW, y = L::S * Y + sy, x = L::S * X + sx;
-        so[h] = (pos < L::PH * L::PW && y < L::IH && x < L::IW) ? (y * L::IW + x) * L::CI + 8 * cg : -1;
+        const int pos = 2 * d + h, Y = pos / L::PWP, X = pos - Y * L::PWP, y = L::S * Y + sy, x = L::S * X + sx;
+        so[h] = (X < L::PW && y < L::IH && x < L::IW) ? (y * L::IW + x) * L::CI + 8 * cg : -1;
       }
       ch[r] = Chunk{so[0], so[1], c < NCH ? (ph * L::CI + 8 * cg) * (L::PLP / 2) + d : -1};
     }
@@ -197,20 +201,17 @@ __device__ __forceinline__ void put_chunks(const Chunk (&ch)[CPT], const RawVec<
 // plane; a lane owns the same plane positions in every plane, so their raw offsets are resolved once.
 template <class L>
 struct ImgMap {
-  static constexpr int NDP = (L::PH * L::PW + 1) / 2, NJ = (NDP + 63) / 64;
-  int o0[NJ], o1[NJ];  // raw element offset of (Y, X) relative to the plane origin, -1 = outside
+  static constexpr int NDP = L::PH * L::PWP / 2, NJ = (NDP + 63) / 64;
+  static_assert(L::NCOPY == 2, "the image path builds the two plane copies of the stride-4 8x8 convolution");
+  int o[NJ][3];  // raw element offsets of (Y, X), (Y, X+1), (Y, X+2) relative to the plane origin, -1 = outside
   __device__ __forceinline__ void init(int lane) {
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-      const int d = lane + 64 * j;
-      int so[2];
+      const int d = lane + 64 * j, pos = 2 * d, Y = pos / L::PWP, X = pos - Y * L::PWP;
+      // phases (sy, sx) < S never leave the image when IH, IW are multiples of S (asserted below)
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int pos = 2 * d + h, Y = pos / L::PW, X = pos - Y * L::PW;
-        // phases (sy, sx) < S never leave the image when IH, IW are multiples of S (asserted below)
-        so[h] = (d < NDP && pos < L::PH * L::PW) ? (L::S * Y * L::IW + L::S * X) * L::CI : -1;
-      }
-      o0[j] = so[0]; o1[j] = so[1];
+      for (int h = 0; h < 3; h++)
+        o[j][h] = (d < NDP && X + h < L::PW) ? (L::S * Y * L::IW + L::S * (X + h)) * L::CI : -1;
     }
   }
 };
@@ -243,16 +244,42 @@ __device__ __forceinline__ void transpose_image(const ImgMap<L>& m, uint32_t* pl
 #pragma unroll
     for (int j = 0; j < ImgMap<L>::NJ; j++) {
       if (lane + 64 * j < ImgMap<L>::NDP) {
-        const uint32_t v0 = m.o0[j] >= 0 ? r16[base + m.o0[j]] : 0u, v1 = m.o1[j] >= 0 ? r16[base + m.o1[j]] : 0u;
-        pl32[pln * (L::PLP / 2) + lane + 64 * j] = v0 | (v1 << 16);
+        uint32_t v[3];
+#pragma unroll
+        for (int h = 0; h < 3; h++) v[h] = m.o[j][h] >= 0 ? r16[base + m.o[j][h]] : 0u;
+        pl32[pln * (L::PLP / 2) + lane + 64 * j] = v[0] | (v[1] << 16);                // copy 0: plane[Y][X]
+        pl32[(L::NPL + pln) * (L::PLP / 2) + lane + 64 * j] = v[1] | (v[2] << 16);     // copy 1: plane[Y][X + 1]
       }
+    }
+  }
+}
+// fp32-activation layers: copy 0 was staged from global memory; copy b = copy 0 shifted by b elements
+// (aligned 16-byte LDS reads, funnel shift by a compile-time amount, aligned writes)
+template <class L>
+__device__ __forceinline__ void shift_copies(__bf16* pl, int tid) {
+  constexpr int C8 = L::PLP / 8;
+  static_assert(L::PLP % 8 == 0 && L::NCOPY <= 3, "plane pitch / tap offsets");
+  for (int c = tid; c < L::NPL * C8; c += NT) {
+    const int pln = c / C8, k8 = (c - pln * C8) * 8;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(pl + pln * L::PLP + k8);
+    const uint4 lo = *reinterpret_cast<const uint4*>(src);
+    const uint32_t w[6] = {lo.x, lo.y, lo.z, lo.w, k8 + 8 < L::PLP ? src[4] : 0u, 0u};
+#pragma unroll
+    for (int b = 1; b < L::NCOPY; b++) {
+      uint32_t o[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) o[k] = b == 1 ? (w[k] >> 16) | (w[k + 1] << 16) : w[k + 1];
+      *reinterpret_cast<uint4*>(pl + (b * L::NPL + pln) * L::PLP + k8) = make_uint4(o[0], o[1], o[2], o[3]);
     }
   }
 }
 
 template <class L, class InT>
 constexpr size_t wgrad_lds_bytes() {
-  return ((size_t)L::NPL * L::PLP + (size_t)L::CO * L::DZP + (sizeof(InT) == 2 ? (size_t)L::IH * L::IW * L::CI : 0)) * 2;
+  // bf16-image layers: the raw NHWC image and the dZ planes share one region (raw is dead once the planes
+  // are built; dZ is staged after that)
+  const size_t dz = (size_t)L::CO * L::DZP, raw = sizeof(InT) == 2 ? (size_t)L::IH * L::IW * L::CI : 0;
+  return ((size_t)L::NCOPY * L::NPL * L::PLP + (dz > raw ? dz : raw)) * 2;
 }
 
 // MG = M tiles (16 output channels each) per wave
@@ -261,18 +288,18 @@ __global__ __launch_bounds__(NT) void ebw_wgrad_kernel(WgArgs a) {
   constexpr int NGR = L::MT / MG, WPG = NW / NGR, UPW = L::NTL / WPG;
   static_assert(L::MT % MG == 0 && NW % NGR == 0 && L::NTL % WPG == 0, "wave tiling");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __bf16* pl = reinterpret_cast<__bf16*>(smem);  // [NPL][PLP]
-  __bf16* dzp = pl + L::NPL * L::PLP;            // [CO][DZP]
-  __bf16* raw = dzp + L::CO * L::DZP;            // bf16-image layers only
+  __bf16* pl = reinterpret_cast<__bf16*>(smem);  // [NCOPY][NPL][PLP]
+  __bf16* dzp = pl + L::NCOPY * L::NPL * L::PLP;  // [CO][DZP]
+  __bf16* raw = dzp;                              // bf16-image layers: raw NHWC image, aliases dzp
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
   const int p = blockIdx.x / a.wpp, j0 = blockIdx.x - p * a.wpp;
-  for (int e = tid; e < L::NPL * L::PLP / 2; e += NT) reinterpret_cast<uint32_t*>(pl)[e] = 0u;
+  for (int e = tid; e < L::NCOPY * L::NPL * L::PLP / 2; e += NT) reinterpret_cast<uint32_t*>(pl)[e] = 0u;
   const int mgrp = w % NGR, nslot = w / NGR;
   int poff[UPW];
 #pragma unroll
   for (int u = 0; u < UPW; u++) {
     const int n = 16 * (nslot + u * WPG) + i, ky = n / (L::KW * L::CI), kx = (n / L::CI) % L::KW, ci = n % L::CI;
-    poff[u] = (((ky % L::S) * L::S + (kx % L::S)) * L::CI + ci) * L::PLP + (ky / L::S) * L::PW + kx / L::S + 8 * g;
+    poff[u] = ((kx / L::S) * L::NPL + ((ky % L::S) * L::S + (kx % L::S)) * L::CI + ci) * L::PLP + (ky / L::S) * L::PWP + 8 * g;
   }
   f32x4 acc[UPW][MG], bacc[MG];
 #pragma unroll
@@ -303,13 +330,17 @@ __global__ __launch_bounds__(NT) void ebw_wgrad_kernel(WgArgs a) {
   if (j0 < n_img) fetch(j0);
   for (int img = j0; img < n_img; img += a.wpp) {
     __syncthreads();  // previous image's fragments consumed (first pass: zero fill visible)
-    put_chunks<DzMap<L>::CPT, L::DZP / 2>(dmap.ch, dzr, reinterpret_cast<uint32_t*>(dzp));
     if constexpr (IMG) {
       inr.put(raw, tid);
       __syncthreads();
       transpose_image<L>(imap, reinterpret_cast<uint32_t*>(pl), raw, tid);
+      __syncthreads();  // raw is dead: its region now takes the dZ planes
+      put_chunks<DzMap<L>::CPT, L::DZP / 2>(dmap.ch, dzr, reinterpret_cast<uint32_t*>(dzp));
     } else {
+      put_chunks<DzMap<L>::CPT, L::DZP / 2>(dmap.ch, dzr, reinterpret_cast<uint32_t*>(dzp));
       put_chunks<PlMap<L>::CPT, L::PLP / 2>(imap.ch, inr, reinterpret_cast<uint32_t*>(pl));
+      __syncthreads();
+      shift_copies<L>(pl, tid);
     }
     __syncthreads();
     if (img + a.wpp < n_img) fetch(img + a.wpp);  // in flight during the MFMAs below
@@ -320,8 +351,7 @@ __global__ __launch_bounds__(NT) void ebw_wgrad_kernel(WgArgs a) {
       for (int j = 0; j < MG; j++) A[j] = *reinterpret_cast<const bf16x8*>(arow + 16 * j * L::DZP + 32 * s);
 #pragma unroll
       for (int u = 0; u < UPW; u++) {
-        bf16x8 B;
-        __builtin_memcpy(&B, pl + poff[u] + 32 * s, 16);  // 2-byte aligned: unaligned ds_read_b128
+        const bf16x8 B = *reinterpret_cast<const bf16x8*>(pl + poff[u] + 32 * s);
 #pragma unroll
         for (int j = 0; j < MG; j++) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], B, acc[u][j], 0, 0, 0);
       }
