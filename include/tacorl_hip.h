@@ -136,6 +136,23 @@ int tacorl_mlp_bwd(int nprob, const float* const* x, int ldx, const float* const
                    float* const* d_x, int ldd, const int* M, int n_layers, const int* dims,
                    const int* acts, int compute_dtype, int accumulate, void* ws, size_t ws_bytes,
                    tacorl_stream_t stream);
+/* bf16 mode, <= 8 problems, <= 4 layers, widths <= 256: the backward split in two calls that share `ws`.
+ *   _dgrad: the whole input-gradient chain dZ_{l-1} = (dZ_l W_l) * act'_{l-1} in ONE launch (plus a weight
+ *           transpose launch); leaves every dZ_l in ws and writes d_x[p] (NULL = not wanted).
+ *   _wgrad: weight / bias gradients from those dZ_l (grads[p] NULL = skip the problem); may run on
+ *           another stream once _dgrad has finished - it is not on the dependent chain of the step.
+ * Together they equal tacorl_mlp_bwd (autograd through the Linear/SiLU/ReLU stacks of
+ * networks/actor_critic/{actor,critic}.py and visual_encoders/goal_encoder.py). */
+int tacorl_mlp_bwd_fused_supported(int nprob, int n_layers, const int* dims, int ldo, int ldd);
+size_t tacorl_mlp_bwd_fused_ws_bytes(int nprob, const int* M, int n_layers, const int* dims);
+int tacorl_mlp_bwd_fused_dgrad(int nprob, const float* const* params, const float* const* act,
+                               const float* const* d_out, int ldo, float* const* d_x, int ldd,
+                               const int* M, int n_layers, const int* dims, const int* acts,
+                               void* ws, size_t ws_bytes, tacorl_stream_t stream);
+int tacorl_mlp_bwd_fused_wgrad(int nprob, const float* const* x, int ldx, const float* const* act,
+                               const float* const* d_out, int ldo, float* const* grads, const int* M,
+                               int n_layers, const int* dims, const int* acts, int accumulate,
+                               void* ws, size_t ws_bytes, tacorl_stream_t stream);
 
 /* ---- data movement ----------------------------------------------------------------- */
 /* n images (image i at src + i*img_pitch floats; NCHW if src_nchw else NHWC) -> contiguous NHWC

@@ -793,6 +793,86 @@ extern "C" int tacorl_to_bf16_batch(int n, const float* const* src, void* const*
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
+// ---- MLP backward, bf16 mode: the input-gradient chain as one launch (mlp_fused.hip) and the weight
+// gradients as a separate call, so that a caller can take them off the dependent chain (another stream).
+// Workspace: [dZ_l of every problem, l = 0..L-2][transposed bf16 weights][wgrad slabs].
+struct MlpBwdWs { long dzoff[MF_MAXP * MF_MAXL]; size_t dz_floats, wt_off[MF_MAXP], wt_bytes_each, slab_off, slab_bytes, total; };
+static MlpBwdWs mlp_bwd_fused_plan(int nprob, const int* M, int L, const int* dims) {
+  MlpBwdWs w{};
+  long off = 0, maxM = 0;
+  for (int p = 0; p < nprob; p++) {
+    for (int l = 0; l + 1 < L; l++) { w.dzoff[p * MF_MAXL + l] = off; off += al4((long)M[p] * dims[l + 1]); }
+    maxM = M[p] > maxM ? M[p] : maxM;
+  }
+  w.dz_floats = (size_t)off;
+  size_t b = ((size_t)off * sizeof(float) + 255) & ~(size_t)255;
+  w.wt_bytes_each = (mlp_fused_wt_elems(L, dims, nullptr) * 2 + 255) & ~(size_t)255;
+  for (int p = 0; p < nprob; p++) { w.wt_off[p] = b; b += w.wt_bytes_each; }
+  w.slab_off = b;
+  for (int l = 0; l < L; l++) { size_t s = wgrad_ws_bytes(nprob, dims[l], dims[l + 1], maxM); w.slab_bytes = s > w.slab_bytes ? s : w.slab_bytes; }
+  w.total = b + w.slab_bytes;
+  return w;
+}
+extern "C" int tacorl_mlp_bwd_fused_supported(int nprob, int L, const int* dims, int ldo, int ldd) {
+  return mlp_fused_bwd_ok(nprob, L, dims, ldo, ldd) ? 1 : 0;
+}
+extern "C" size_t tacorl_mlp_bwd_fused_ws_bytes(int nprob, const int* M, int L, const int* dims) {
+  if (nprob < 1 || nprob > MF_MAXP || L < 1 || L > MF_MAXL) return 0;
+  return mlp_bwd_fused_plan(nprob, M, L, dims).total;
+}
+extern "C" int tacorl_mlp_bwd_fused_dgrad(int nprob, const float* const* params, const float* const* act,
+                                          const float* const* d_out, int ldo, float* const* d_x, int ldd, const int* M,
+                                          int L, const int* dims, const int* acts, void* ws, size_t ws_bytes,
+                                          tacorl_stream_t stream) {
+  if (!mlp_fused_bwd_ok(nprob, L, dims, ldo, ldd)) FAIL(TACORL_EINVAL, "mlp_bwd_fused: shapes not supported");
+  if (acts[L - 1] != ACT_NONE) FAIL(TACORL_EINVAL, "mlp_bwd_fused: last activation must be NONE");
+  const MlpBwdWs w = mlp_bwd_fused_plan(nprob, M, L, dims);
+  if (ws_bytes < w.total) FAIL(TACORL_ENOMEM, "mlp_bwd_fused: workspace too small");
+  long wo[MLP_MAXL], bo[MLP_MAXL], src[MF_MAXP * MF_MAXL];
+  tacorl_mlp_param_layout(L, dims, wo, bo);
+  float* dz[MF_MAXP];
+  void* wt[MF_MAXP];
+  for (int p = 0; p < nprob; p++) {
+    long zo[MLP_MAXL], yo[MLP_MAXL];
+    tacorl_mlp_act_layout(M[p], L, dims, acts, zo, yo);
+    for (int l = 0; l < L; l++) src[p * MF_MAXL + l] = acts[l] == ACT_SILU ? zo[l] : (acts[l] == ACT_RELU ? yo[l] : -1);
+    dz[p] = (float*)ws;
+    wt[p] = (unsigned char*)ws + w.wt_off[p];
+  }
+  const int rc = mlp_fused_bwd(nprob, params, act, d_out, ldo, dz, d_x, ldd, wt, M, L, dims, acts, src, w.dzoff, wo,
+                               (hipStream_t)stream);
+  if (rc != TACORL_OK) FAIL(rc, "mlp_bwd_fused: launch failed (%d)", rc);
+  return TACORL_OK;
+}
+extern "C" int tacorl_mlp_bwd_fused_wgrad(int nprob, const float* const* x, int ldx, const float* const* act,
+                                          const float* const* d_out, int ldo, float* const* grads, const int* M, int L,
+                                          const int* dims, const int* acts, int accumulate, void* ws, size_t ws_bytes,
+                                          tacorl_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (nprob < 1 || nprob > MF_MAXP || L < 1 || L > MF_MAXL) FAIL(TACORL_EINVAL, "mlp_bwd_fused_wgrad: bad L/nprob");
+  const MlpBwdWs w = mlp_bwd_fused_plan(nprob, M, L, dims);
+  if (ws_bytes < w.total) FAIL(TACORL_ENOMEM, "mlp_bwd_fused_wgrad: workspace too small");
+  long wo[MLP_MAXL], bo[MLP_MAXL];
+  tacorl_mlp_param_layout(L, dims, wo, bo);
+  void* slab = (unsigned char*)ws + w.slab_off;
+  for (int l = L - 1; l >= 0; l--) {
+    const float *xg[GEMM_MAXP], *dzg[GEMM_MAXP];
+    float *dwg[GEMM_MAXP], *dbg[GEMM_MAXP];
+    int Mc[GEMM_MAXP], n2 = 0;
+    for (int p = 0; p < nprob; p++) {
+      if (!grads[p] || M[p] <= 0) continue;
+      long zo[MLP_MAXL], yo[MLP_MAXL];
+      tacorl_mlp_act_layout(M[p], L, dims, acts, zo, yo);
+      xg[n2] = l == 0 ? x[p] : act[p] + yo[l - 1];
+      dzg[n2] = l == L - 1 ? d_out[p] : (const float*)ws + w.dzoff[p * MF_MAXL + l];
+      dwg[n2] = grads[p] + wo[l]; dbg[n2] = grads[p] + bo[l]; Mc[n2] = M[p]; n2++;
+    }
+    if (n2) CHECK(k_linear_wgrad(n2, xg, l == 0 ? ldx : dims[l], dzg, l == L - 1 ? ldo : dims[l + 1], Mc, dims[l], dims[l + 1],
+                                 dwg, dbg, accumulate, slab, w.slab_bytes, TACORL_BF16, st));
+  }
+  return TACORL_OK;
+}
+
 static void mlp_bwd_sizes(int nprob, const int* M, int L, const int* dims, long& dz_floats, size_t& slab) {
   int maxd = 0;
   for (int l = 0; l <= L; l++) maxd = dims[l] > maxd ? dims[l] : maxd;

@@ -14,3 +14,14 @@ int mlp_fused_fwd(int nprob, const float* const* x, int ldx, const float* const*
                   float* const* act,
                   const int* M, int L, const int* dims, const int* acts, const long* zoff, const long* yoff,
                   const long* woff, const long* boff, hipStream_t st);
+
+// Backward input-gradient chain in one launch (+ one weight-transpose pack launch): writes dZ_l (fp32,
+// [M][dims[l+1]]) for l = 0..L-2 at dz[p] + dzoff[p*MF_MAXL + l] and, if d_x[p] != NULL, the input gradient.
+// The last layer's dZ is d_out itself.  srcoff[p*MF_MAXL + l] = offset in act[p] of the activation
+// derivative source of layer l's output (pre-activation for SiLU, output for ReLU), -1 for identity.
+// wt[p]: scratch of mlp_fused_wt_elems() bf16 elements (16-byte aligned).
+bool mlp_fused_bwd_ok(int nprob, int L, const int* dims, int ldo, int ldd);
+size_t mlp_fused_wt_elems(int L, const int* dims, long* wtoff);
+int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act, const float* const* d_out, int ldo,
+                  float* const* dz, float* const* d_x, int ldd, void* const* wt, const int* M, int L, const int* dims,
+                  const int* acts, const long* srcoff, const long* dzoff, const long* woff, hipStream_t st);

@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
         for (int nt = 0; nt < 4; nt++)
           if (n0 + 16 * nt < N) {
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt], B[ks][nt], acc[mt][nt], 0, 0, 0);
+            // weights as the A operand: D[n][m] - a lane then holds 4 CONSECUTIVE output columns of one row,
+            // so the epilogue moves 16-byte vectors instead of 4-byte gathers
+            for (int mt = 0; mt < 4; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nt], A[mt], acc[mt][nt], 0, 0, 0);
           }
       }
     }
@@ -109,25 +111,176 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
     if (n0 < N) {
       float* zb = a.zoff[p][l] >= 0 ? a.act[p] + a.zoff[p][l] : nullptr;
       float* yb = a.act[p] + a.yoff[p][l];
+      const bool vec = (N & 3) == 0;
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) {
-        const int col = n0 + 16 * nt + i;
+        const int col = n0 + 16 * nt + 4 * g;  // this lane's 4 consecutive columns
         if (n0 + 16 * nt >= N) continue;
-        const bool cok = col < N;
-        const float bv = cok ? bias[col] : 0.f;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (vec && col < N) bv = *reinterpret_cast<const f32x4*>(bias + col);
+        else {
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
+          for (int r = 0; r < 4; r++) bv[r] = col + r < N ? bias[col + r] : 0.f;
+        }
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int row = 16 * mt + 4 * g + r;
-            const float z = acc[mt][nt][r] + bv, y = act_apply(act, z);
-            if (cok && m0 + row < M) {
-              const long o = (long)(m0 + row) * N + col;
-              if (zb) zb[o] = z;
-              yb[o] = y;
+        for (int mt = 0; mt < 4; mt++) {
+          const int row = 16 * mt + i;
+          f32x4 z = acc[mt][nt] + bv, y;
+#pragma unroll
+          for (int r = 0; r < 4; r++) y[r] = col + r < N ? act_apply(act, z[r]) : 0.f;
+          if (m0 + row < M) {
+            const long o = (long)(m0 + row) * N + col;
+            if (vec && col < N) {
+              if (zb) *reinterpret_cast<f32x4*>(zb + o) = z;
+              *reinterpret_cast<f32x4*>(yb + o) = y;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                if (col + r < N) { if (zb) zb[o + r] = z[r]; yb[o + r] = y[r]; }
             }
-            xout[row * XP + col] = (__bf16)(cok ? y : 0.f);
           }
+          *reinterpret_cast<bf16x4*>(xout + row * XP + col) = bf16x4{(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
+        }
+      }
+    }
+    lds_barrier();
+    cur ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------- backward
+// The input-gradient chain dZ_{l-1} = (dZ_l W_l) * act'_{l-1} of the whole MLP in one launch: the same
+// 64-row resident structure run through the transposed network.  Wt_l = W_l^T (bf16, [K_l][NP_l], NP_l =
+// N_l rounded up to 8, zero padded) comes from mlp_pack_wt_kernel.  Every dZ_l is also written to HBM
+// (fp32) for the weight-gradient GEMMs, which no longer sit on the dependent chain.
+struct MlpBwdArgs {
+  const float* d_out[MF_MAXP];   // [M][ldo] gradient of the MLP output (= dZ of the last layer)
+  const float* act[MF_MAXP];     // saved activations of the forward
+  const __bf16* wt[MF_MAXP];     // packed transposed weights, all layers
+  float* dz[MF_MAXP];            // dZ_l for l = 0 .. L-2 at dzoff[p][l] (floats), [M][dims[l+1]]
+  float* d_x[MF_MAXP];           // optional [M][ldd] input gradient
+  int M[MF_MAXP];
+  long srcoff[MF_MAXP][MF_MAXL];  // activation-derivative source of layer l's output (z for SiLU, y for ReLU), -1 none
+  long dzoff[MF_MAXP][MF_MAXL];
+  long wtoff[MF_MAXL];            // element offsets into wt[p]
+  int dims[MF_MAXL + 1], acts[MF_MAXL];
+  int L, ldo, ldd;
+};
+
+struct WtPackArgs {
+  const float* params[MF_MAXP];
+  __bf16* wt[MF_MAXP];
+  long woff[MF_MAXL], wtoff[MF_MAXL];
+  int dims[MF_MAXL + 1];
+  int L;
+};
+// grid (blocks, L, nprob): Wt[kin][n] = bf16(W[n][kin]), n < NP = roundup(N, 8) (zeros for n >= N)
+__global__ __launch_bounds__(256) void mlp_pack_wt_kernel(WtPackArgs a) {
+  const int l = blockIdx.y, p = blockIdx.z, K = a.dims[l], N = a.dims[l + 1], NP = (N + 7) / 8 * 8;
+  const float* __restrict__ W = a.params[p] + a.woff[l];
+  __bf16* __restrict__ T = a.wt[p] + a.wtoff[l];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < K * NP; e += gridDim.x * 256) {
+    const int kin = e / NP, n = e - kin * NP;
+    T[e] = (__bf16)(n < N ? W[(long)n * K + kin] : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* X = reinterpret_cast<__bf16*>(smem);  // [2][BMF][XP]
+  const int p = blockIdx.y, m0 = blockIdx.x * BMF, M = a.M[p];
+  if (m0 >= M) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
+  for (int e = tid; e < 2 * BMF * XP / 8; e += 256) reinterpret_cast<f32x4*>(X)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  {  // stage dZ of the last layer (= d_out rows) as bf16
+    const int NL = a.dims[a.L];
+    const float* d = a.d_out[p];
+    for (int c = tid; c < BMF * NL; c += 256) {
+      const int row = c / NL, n = c - row * NL;
+      if (m0 + row < M) X[row * XP + n] = (__bf16)d[(long)(m0 + row) * a.ldo + n];
+    }
+  }
+  __syncthreads();
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  const int n0 = 64 * w;  // this wave's output columns (input features of the layer)
+  bf16x8 B[8][4];
+  auto load_layer = [&](int l) {
+    const int KO = a.dims[l], NP = (a.dims[l + 1] + 7) / 8 * 8;  // outputs, (padded) reduction length
+    const __bf16* T = a.wt[p] + a.wtoff[l];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) B[ks][nt] = load_w(T, NP, KO, n0 + 16 * nt + i, 32 * ks + 8 * g);
+  };
+  const int l_last = a.d_x[p] ? 0 : 1;  // layer 0's dgrad only if the input gradient is wanted
+  if (a.L - 1 >= l_last && n0 < a.dims[a.L - 1]) load_layer(a.L - 1);
+  int cur = 0;
+  for (int l = a.L - 1; l >= l_last; l--) {
+    const int KO = a.dims[l], NR = a.dims[l + 1], KS = (NR + 31) / 32;
+    const __bf16* xin = X + cur * BMF * XP;
+    __bf16* xout = X + (cur ^ 1) * BMF * XP;
+    f32x4 acc[4][4];
+    if (n0 < KO) {
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        if (ks >= KS) break;
+        bf16x8 A[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) A[mt] = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+          if (n0 + 16 * nt < KO) {
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nt], A[mt], acc[mt][nt], 0, 0, 0);
+          }
+      }
+    }
+    if (l - 1 >= l_last && n0 < a.dims[l - 1]) load_layer(l - 1);
+    if (n0 < KO) {
+      const int pact = l > 0 ? a.acts[l - 1] : ACT_NONE;
+      const float* src = (l > 0 && a.srcoff[p][l - 1] >= 0) ? a.act[p] + a.srcoff[p][l - 1] : nullptr;
+      float* out = l > 0 ? a.dz[p] + a.dzoff[p][l - 1] : a.d_x[p];
+      const int ldout = l > 0 ? KO : a.ldd;
+      const bool vec = (KO & 3) == 0 && (ldout & 3) == 0;
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) {
+        const int col = n0 + 16 * nt + 4 * g;  // this lane's 4 consecutive columns (D = W^T-frag x dZ-frag)
+        if (n0 + 16 * nt >= KO) continue;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+          const int row = 16 * mt + i;
+          const bool rok = m0 + row < M;
+          f32x4 v = acc[mt][nt];
+          if (rok && src) {
+            if (vec && col < KO) {
+              const f32x4 sv = *reinterpret_cast<const f32x4*>(src + (long)(m0 + row) * KO + col);
+#pragma unroll
+              for (int r = 0; r < 4; r++) v[r] *= act_grad(pact, sv[r]);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                if (col + r < KO) v[r] *= act_grad(pact, src[(long)(m0 + row) * KO + col + r]);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (!rok || col + r >= KO) v[r] = 0.f;
+          if (rok) {
+            float* o = out + (long)(m0 + row) * ldout + col;
+            if (vec && col < KO) *reinterpret_cast<f32x4*>(o) = v;
+            else {
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                if (col + r < KO) o[r] = v[r];
+            }
+          }
+          *reinterpret_cast<bf16x4*>(xout + row * XP + col) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
       }
     }
     lds_barrier();
@@ -136,6 +289,50 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
 }
 
 }  // namespace
+
+bool mlp_fused_bwd_ok(int nprob, int L, const int* dims, int ldo, int ldd) {
+  if (nprob < 1 || nprob > MF_MAXP || L < 1 || L > MF_MAXL) return false;
+  for (int l = 0; l <= L; l++)
+    if (dims[l] < 1 || dims[l] > MAXD) return false;
+  return true;
+}
+size_t mlp_fused_wt_elems(int L, const int* dims, long* wtoff) {
+  size_t off = 0;
+  for (int l = 0; l < L; l++) {
+    if (wtoff) wtoff[l] = (long)off;
+    off += (size_t)dims[l] * ((dims[l + 1] + 7) / 8 * 8);
+    off = (off + 7) & ~(size_t)7;  // 16-byte aligned matrices
+  }
+  return off;
+}
+int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act, const float* const* d_out, int ldo,
+                  float* const* dz, float* const* d_x, int ldd, void* const* wt, const int* M, int L, const int* dims,
+                  const int* acts, const long* srcoff, const long* dzoff, const long* woff, hipStream_t st) {
+  MlpBwdArgs a{};
+  WtPackArgs k{};
+  long wtoff[MF_MAXL];
+  mlp_fused_wt_elems(L, dims, wtoff);
+  int maxM = 0;
+  for (int p = 0; p < nprob; p++) {
+    if ((uintptr_t)wt[p] & 15) return TACORL_EINVAL;
+    a.d_out[p] = d_out[p]; a.act[p] = act[p]; a.wt[p] = (const __bf16*)wt[p]; a.dz[p] = dz[p];
+    a.d_x[p] = d_x ? d_x[p] : nullptr; a.M[p] = M[p];
+    k.params[p] = params[p]; k.wt[p] = (__bf16*)wt[p];
+    for (int l = 0; l < L; l++) { a.srcoff[p][l] = srcoff[p * MF_MAXL + l]; a.dzoff[p][l] = dzoff[p * MF_MAXL + l]; }
+    maxM = M[p] > maxM ? M[p] : maxM;
+  }
+  for (int l = 0; l < L; l++) { a.wtoff[l] = wtoff[l]; k.wtoff[l] = wtoff[l]; k.woff[l] = woff[l]; a.acts[l] = acts[l]; }
+  for (int l = 0; l <= L; l++) { a.dims[l] = dims[l]; k.dims[l] = dims[l]; }
+  a.L = L; k.L = L; a.ldo = ldo; a.ldd = ldd;
+  if (maxM == 0) return TACORL_OK;
+  hipLaunchKernelGGL(mlp_pack_wt_kernel, dim3(64, L, nprob), dim3(256), 0, st, k);
+  constexpr size_t lds = (size_t)2 * BMF * XP * 2;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_bwd_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
+  if (once) return TACORL_ELAUNCH;
+  hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3((maxM + BMF - 1) / BMF, nprob), dim3(256), lds, st, a);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
 
 bool mlp_fused_fwd_ok(int nprob, int L, const int* dims, int ldx) {
   if (nprob < 1 || nprob > MF_MAXP || L < 1 || L > MF_MAXL || ldx % 4) return false;

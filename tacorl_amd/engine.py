@@ -246,6 +246,11 @@ class ACEngine:
     # also get their activations saved by that launch.  Otherwise: the per-layer path.
     GRAD_PROBS = ("a_og", "q1", "q2")
     use_fused = True  # tests flip this to compare the fused launch against the per-layer path
+    # MLP weight gradients on side streams (parallel graph branches): shortens the dependent chain of the
+    # update (1.52 -> 1.45 ms/step without the action-decoder branch); with TACORL's PR/action-decoder
+    # branches already running beside the update the extra concurrency costs more than it saves
+    # (1.87 -> 1.91 ms), so TACORL turns it off when that branch runs every step.
+    wgrad_side_streams = True
 
     def _fused_ok(self, c):
         if not self.use_fused or self.compute != BF16 or self.img_dtype != torch.bfloat16:
@@ -439,14 +444,46 @@ class ACEngine:
         with torch.cuda.stream(self._bwd_stream):
             self._actor_backward(bc_phase, head_cur, q1p, q2p, gs)
         # ---- critic backward through the Q MLPs; sum the broadcast embedding gradient over samples
-        ops.mlp_bwd([self.XQ["q1"], self.XQ["q2"]], self.ldq, [self.q1.head(), self.q2.head()],
-                    [self.qact["q1"], self.qact["q2"]], [self.dq["q1"], self.dq["q2"]], 1,
-                    [self.q1.head(self.q1.grad), self.q2.head(self.q2.grad)], [self.dXQ["q1"], self.dXQ["q2"]],
-                    self.ldq, [self.R, self.R], qd, qa, self.compute)
+        self._mlp_backward("q", [self.XQ["q1"], self.XQ["q2"]], self.ldq, [self.q1.head(), self.q2.head()],
+                           [self.qact["q1"], self.qact["q2"]], [self.dq["q1"], self.dq["q2"]], 1,
+                           [self.q1.head(self.q1.grad), self.q2.head(self.q2.grad)], [self.dXQ["q1"], self.dXQ["q2"]],
+                           self.ldq, [self.R, self.R], qd, qa)
         for k in ("q1", "q2"):
             ops.reduce_rows_mod(self.dXQ[k], 0, self.ldq, self.dS[k], 0, self.lds, B, self.E, 3 * n + 1)
         main_stream.wait_stream(self._bwd_stream)
         self._encoders_backward()
+        self._join_wgrads()
+
+    def _mlp_backward(self, tag, xs, ldx, params, acts_buf, d_outs, ldo, grads, d_xs, ldd, M, dims, acts):
+        """MLP backward.  bf16 mode: the input-gradient chain is ONE launch on the current stream and the
+        weight gradients go to a side stream of their own (a parallel graph branch joined before the
+        optimiser) - they are needed only by Adam, not by anything downstream in the backward.
+        Otherwise: the per-layer path."""
+        n = len(xs)
+        if not ops.mlp_bwd_fused_ok(n, dims, ldo, ldd, self.compute):
+            ops.mlp_bwd(xs, ldx, params, acts_buf, d_outs, ldo, grads, d_xs, ldd, M, dims, acts, self.compute,
+                        ws_tag="mlp_bwd_" + tag)
+            return
+        ops.mlp_bwd_fused_dgrad(params, acts_buf, d_outs, ldo, d_xs, ldd, M, dims, acts, "mlp_bwdf_" + tag)
+        if all(g is None for g in grads):
+            return
+        if not self.wgrad_side_streams:
+            ops.mlp_bwd_fused_wgrad(xs, ldx, acts_buf, d_outs, ldo, grads, M, dims, acts, "mlp_bwdf_" + tag)
+            return
+        if not hasattr(self, "_wg_streams"):
+            self._wg_streams, self._wg_pending = {}, []
+        if tag not in self._wg_streams:
+            self._wg_streams[tag] = torch.cuda.Stream(device=self.dev)
+        ws_ = self._wg_streams[tag]
+        ws_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ws_):
+            ops.mlp_bwd_fused_wgrad(xs, ldx, acts_buf, d_outs, ldo, grads, M, dims, acts, "mlp_bwdf_" + tag)
+        self._wg_pending.append(ws_)
+
+    def _join_wgrads(self):
+        for ws_ in getattr(self, "_wg_pending", []):
+            torch.cuda.current_stream().wait_stream(ws_)
+        self._wg_pending = []
 
     def _actor_backward(self, bc_phase, head_cur, q1p, q2p, gs):
         B, A, Ac, nz = self.B, self.A, self.Ac, self.noise
@@ -458,27 +495,26 @@ class ACEngine:
         else:
             call("tacorl_actor_qmin", ptr(q1p), ptr(q2p), ptr(self.logp_pi), B, ptr(self.log_alpha.param),
                  ptr(self.dq_pi["q1"]), ptr(self.dq_pi["q2"]), gs, ptr(self.logs), ops.stream())
-            ops.mlp_bwd([self.XQpi["q1"], self.XQpi["q2"]], self.ldq, [self.q1.head(), self.q2.head()],
-                        [self.qact_pi["q1"], self.qact_pi["q2"]], [self.dq_pi["q1"], self.dq_pi["q2"]], 1,
-                        [None, None], [self.dXQpi["q1"], self.dXQpi["q2"]], self.ldq, [B, B], qd, qa, self.compute,
-                        ws_tag="mlp_bwd_actor")
+            self._mlp_backward("qpi", [self.XQpi["q1"], self.XQpi["q2"]], self.ldq, [self.q1.head(), self.q2.head()],
+                               [self.qact_pi["q1"], self.qact_pi["q2"]], [self.dq_pi["q1"], self.dq_pi["q2"]], 1,
+                               [None, None], [self.dXQpi["q1"], self.dXQpi["q2"]], self.ldq, [B, B], qd, qa)
             call("tacorl_actor_head_bwd", ptr(head_cur), self.HD, ptr(nz["eps_pi"]), ptr(self.logp_pi),
                  ops._at(self.dXQpi["q1"], self.E), ops._at(self.dXQpi["q2"], self.E), self.ldq, None, 0,
                  ptr(self.grip_pi) if self.dg else None, ptr(self.log_alpha.param), gs, ptr(self.d_head), B, Ac,
                  int(self.dg), ptr(self.logs), ops.stream())
-        ops.mlp_bwd([self.S["a"]], self.lds, [self.actor.head()], [self.pact["a"]], [self.d_head], self.HD,
-                    [self.actor.head(self.actor.grad)], [self.dS["a"]], self.lds, [B], self.actor.head_dims,
-                    self.actor.head_acts, self.compute, ws_tag="mlp_bwd_actor")
+        self._mlp_backward("pi", [self.S["a"]], self.lds, [self.actor.head()], [self.pact["a"]], [self.d_head], self.HD,
+                           [self.actor.head(self.actor.grad)], [self.dS["a"]], self.lds, [B], self.actor.head_dims,
+                           self.actor.head_acts)
 
     def _encoders_backward(self):
         """Goal encoders (3 nets, one batch), then the three encoders (actor(obs, goal), q1, q2)."""
         B = self.B
         nets = {"a": self.actor, "q1": self.q1, "q2": self.q2}
         ks = ["a", "q1", "q2"]
-        ops.mlp_bwd([self.gin[k] for k in ks], self.G, [nets[k].genc() for k in ks], [self.gact[k] for k in ks],
-                    [ops._at(self.dS[k], self.Eo) for k in ks], self.lds, [nets[k].genc(nets[k].grad) for k in ks],
-                    [self.dgin[k] for k in ks], self.G, [B] * 3, self.actor.genc_dims, self.actor.genc_acts,
-                    self.compute)
+        self._mlp_backward("genc", [self.gin[k] for k in ks], self.G, [nets[k].genc() for k in ks],
+                           [self.gact[k] for k in ks], [ops._at(self.dS[k], self.Eo) for k in ks], self.lds,
+                           [nets[k].genc(nets[k].grad) for k in ks], [self.dgin[k] for k in ks], self.G, [B] * 3,
+                           self.actor.genc_dims, self.actor.genc_acts)
         ek = {"a": "a_og", "q1": "q1", "q2": "q2"}
         with ops.copy_batch():
             for j, c in enumerate(self.cams):

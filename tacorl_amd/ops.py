@@ -129,6 +129,28 @@ def mlp_bwd(xs, ldx, params, acts_buf, d_outs, ldo, grads, d_xs, ldd, M, dims, a
          int_array(dims), int_array(acts), compute, int(accumulate), ptr(ws), ws.numel(), stream())
 
 
+def mlp_bwd_fused_ok(n, dims, ldo, ldd, compute):
+    return compute == BF16 and bool(L.lib().tacorl_mlp_bwd_fused_supported(n, len(dims) - 1, int_array(dims), ldo, ldd))
+
+
+def mlp_bwd_fused_dgrad(params, acts_buf, d_outs, ldo, d_xs, ldd, M, dims, acts, ws_tag):
+    """Input-gradient chain of the whole MLP in one launch; leaves every layer's dZ in workspace(ws_tag)
+    for mlp_bwd_fused_wgrad (same ws_tag, same shapes)."""
+    nb = L.lib().tacorl_mlp_bwd_fused_ws_bytes(len(params), int_array(M), len(dims) - 1, int_array(dims))
+    ws = workspace(nb, acts_buf[0].device, ws_tag)
+    call("tacorl_mlp_bwd_fused_dgrad", len(params), ptr_array(params), ptr_array(acts_buf), ptr_array(d_outs), ldo,
+         ptr_array(d_xs) if d_xs is not None else ptr_array([None] * len(params)), ldd, int_array(M), len(dims) - 1,
+         int_array(dims), int_array(acts), ptr(ws), ws.numel(), stream())
+
+
+def mlp_bwd_fused_wgrad(xs, ldx, acts_buf, d_outs, ldo, grads, M, dims, acts, ws_tag, accumulate=False):
+    nb = L.lib().tacorl_mlp_bwd_fused_ws_bytes(len(xs), int_array(M), len(dims) - 1, int_array(dims))
+    ws = workspace(nb, acts_buf[0].device, ws_tag)
+    call("tacorl_mlp_bwd_fused_wgrad", len(xs), ptr_array(xs), ldx, ptr_array(acts_buf), ptr_array(d_outs), ldo,
+         ptr_array(grads), int_array(M), len(dims) - 1, int_array(dims), int_array(acts), int(accumulate), ptr(ws),
+         ws.numel(), stream())
+
+
 # --------------------------------------------------------------------- data movement
 def pack_images(src, img_pitch, src_nchw, dst, n, Cc, H, W, src_offset=0):
     dd = BF16 if dst.dtype == torch.bfloat16 else F32

@@ -430,3 +430,46 @@ def test_mlp_fused_forward(dims, acts):
         yo = ops.mlp_act_layout(M, dims, acts)[1][-1]
         y = a_f[i][yo: yo + M * dims[-1]].view(M, dims[-1])
         assert relerr(y, refs[i]) < TOL_BF16
+
+
+@pytest.mark.parametrize("dims,acts", [([64, 256, 256, 256, 32], [2, 2, 2, 0]), ([80, 256, 256, 256, 1], [2, 2, 2, 0]),
+                                       ([71, 256, 256, 256, 1], [2, 2, 2, 0]), ([32, 256, 256, 32], [1, 1, 0])])
+@pytest.mark.parametrize("want_dx", [True, False])
+def test_mlp_fused_backward(dims, acts, want_dx):
+    """Single-launch input-gradient chain + separate weight-gradient call vs the per-layer bf16 backward
+    on the same saved activations (same operand rounding; fp32 summation order differs)."""
+    from tacorl_amd import blocks, ops
+
+    dev = _dev()
+    Ms = [70, 9, 300]
+    L = len(dims) - 1
+    ld = (dims[0] + 3) // 4 * 4
+    assert ops.mlp_bwd_fused_ok(len(Ms), dims, dims[-1], ld, 1)
+    xs, flats, actb, douts = [], [], [], []
+    for i, M in enumerate(Ms):
+        flat = torch.zeros(blocks.mlp_size(dims), device=dev)
+        v = blocks.mlp_views(flat, 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+        for l in range(L):
+            v[f"l{l}.w"].copy_(rnd(dims[l + 1], dims[l], seed=250 + i + l, scale=1 / math.sqrt(dims[l])))
+            v[f"l{l}.b"].copy_(rnd(dims[l + 1], seed=260 + i + l, scale=0.1))
+        xp = torch.zeros(M, ld, device=dev)
+        xp[:, :dims[0]] = rnd(M, dims[0], seed=270 + i).to(dev)
+        xs.append(xp); flats.append(flat)
+        actb.append(torch.zeros(ops.mlp_act_layout(M, dims, acts)[2], device=dev))
+        douts.append(rnd(M, dims[-1], seed=280 + i).to(dev))
+    ops.mlp_fwd(xs, ld, flats, actb, Ms, dims, acts, 1)
+    g_ref = [torch.zeros_like(f) for f in flats]  # (4-float alignment gaps of the block stay unwritten)
+    g_fus = [torch.zeros_like(f) for f in flats]
+    dx_ref = [torch.zeros(M, ld, device=dev) for M in Ms]
+    dx_fus = [torch.zeros(M, ld, device=dev) for M in Ms]
+    ops.mlp_bwd(xs, ld, flats, actb, douts, dims[-1], g_ref, dx_ref if want_dx else None, ld, Ms, dims, acts, 1)
+    ops.mlp_bwd_fused_dgrad(flats, actb, douts, dims[-1], dx_fus if want_dx else None, ld, Ms, dims, acts, "t_mlp_fused")
+    g_fus[1] = None  # a problem without parameter gradients (the actor's pass through the Q networks)
+    ops.mlp_bwd_fused_wgrad(xs, ld, actb, douts, dims[-1], g_fus, Ms, dims, acts, "t_mlp_fused")
+    torch.cuda.synchronize()
+    for i in range(len(Ms)):
+        if want_dx:
+            assert relerr(dx_fus[i], dx_ref[i]) < 3e-3, ("dx", i, relerr(dx_fus[i], dx_ref[i]))
+        if g_fus[i] is not None:
+            assert torch.isfinite(g_fus[i]).all()
+            assert relerr(g_fus[i], g_ref[i]) < 3e-3, ("grads", i, relerr(g_fus[i], g_ref[i]))
