@@ -45,6 +45,15 @@ int tacorl_linear_add_fwd(int nprob, const float* const* x, int ldx, const float
                           const float* const* b, const float* const* addend, int ld_add, float* const* y,
                           int ldy, const int* M, int K, int N, int act, int compute_dtype, void* ws,
                           size_t ws_bytes, tacorl_stream_t stream);
+/* y = act(x W^T + b + addend) with bf16 operands resident in HBM (x [M][K], W [N][K]; K % 128 == 0,
+ * N % 32 == 0): the stacked ReLU-RNN of the action decoder (reference rnn_models.py:5-16, torch nn.RNN) -
+ * recurrent step (M = batch) and per-layer input projection (M = batch*T).  One launch, no split-K: a
+ * 4-stage LDS-DMA ring streams K.  Writes y fp32 and, if y_bf16 != NULL, the bf16 copy that is the next
+ * step's operand.  bf16 MFMA, fp32 accumulate. */
+int tacorl_rnn_linear_supported(int M, int K, int N);
+int tacorl_rnn_linear_fwd(const void* x_bf16, const void* w_bf16, const float* bias, const float* addend,
+                          int ld_add, float* y, void* y_bf16, int M, int K, int N, int act,
+                          tacorl_stream_t stream);
 
 /* Backward primitives of y = act(x W^T + b):
  *   dgrad: out[m][i] = (sum_o dz[m][o] W[o][i] + addend[m][i]) * act'(src[m][i])

@@ -1,0 +1,120 @@
+// y = act(x W^T + bias + addend) for the action decoder's stacked ReLU-RNN (reference
+// networks/action_decoders/rnn_models.py:5-16 -> torch nn.RNN(nonlinearity="relu"), hidden 2048):
+// the recurrent step (M = batch rows) and the per-layer input projection (M = batch * T rows).
+//
+// The generic GEMM needs split-K plus a reduce launch for this shape ([256 x 2048] x [2048 x 2048]:
+// 16 us + 7.6 us per step, 31 dependent steps per forward) and exposes one global round trip per K tile.
+// Here operands are bf16 in HBM and stream through a 4-stage LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, three K tiles in flight per workgroup), one
+// 64 x 32 output tile per workgroup over the whole K - no split, no second launch; bias, the
+// input-projection addend and the activation are applied in the epilogue, which also writes the bf16
+// copy that is the next step's operand.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tacorl_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int RB_M = 64, RB_N = 32, RB_K = 128, RB_S = 4;
+constexpr int ROW_BYTES = RB_K * 2;                      // 256 B per staged row (16 chunks of 16 B)
+constexpr int STAGE_BYTES = (RB_M + RB_N) * ROW_BYTES;   // 24 KiB
+constexpr int DMA_PER_WAVE = (RB_M + RB_N) / 4 / 4;      // wave-instructions per stage and wave (4 rows each)
+
+struct RnnArgs {
+  const __bf16* x;
+  const __bf16* w;
+  const float* bias;
+  const float* addend;
+  float* y;
+  __bf16* yb;
+  int M, K, N, ld_add, act;
+};
+
+// LDS row r keeps its 16-byte chunk c at position c ^ (r & 15): a fragment read (16 lanes = 16 rows, same
+// c) then spreads over all banks.  The DMA writes lane-contiguous, so the swizzle is applied to the
+// *global* chunk each lane fetches.
+__global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * RB_M, n0 = blockIdx.y * RB_N;
+  const int nk = a.K / RB_K;
+
+  auto issue = [&](int kt, int slot) {
+    unsigned char* base = lds + slot * STAGE_BYTES;
+#pragma unroll
+    for (int q = 0; q < DMA_PER_WAVE; q++) {
+      const int row4 = (w + 4 * q) * 4;           // first of the 4 rows this wave-instruction fills
+      const int r = row4 + (lane >> 4), cpos = lane & 15, c = cpos ^ (r & 15);
+      const int xm = m0 + r < a.M ? m0 + r : a.M - 1;  // rows past M are loaded (clamped) but never stored
+      const __bf16* src = (r < RB_M ? a.x + (long)xm * a.K : a.w + (long)(n0 + r - RB_M) * a.K) + kt * RB_K + c * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + row4 * ROW_BYTES), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int s = 0; s < RB_S - 1; s++)
+    if (s < nk) issue(s, s);
+  const int arow = 16 * w + i;  // this lane's activation row inside the tile
+  for (int kt = 0; kt < nk; kt++) {
+    // stage kt has landed once at most the RB_S-2 younger stages of this wave are outstanding
+    if (kt + RB_S - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE * (RB_S - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // raw barrier (__syncthreads would also drain the younger DMA stages): every wave's share of stage kt
+    // is visible and everyone is done reading stage kt-1
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + RB_S - 1 < nk) issue(kt + RB_S - 1, (kt + RB_S - 1) % RB_S);
+    const unsigned char* st = lds + (kt % RB_S) * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < RB_K / 32; ks++) {
+      const int c = 4 * ks + g;
+      const bf16x8 X = *reinterpret_cast<const bf16x8*>(st + arow * ROW_BYTES + ((c ^ (arow & 15)) << 4));
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        const int r = RB_M + 16 * nt + i;
+        const bf16x8 Wf = *reinterpret_cast<const bf16x8*>(st + r * ROW_BYTES + ((c ^ (r & 15)) << 4));
+        // weights as the A operand: D[n][m], a lane ends with 4 consecutive output columns of one row
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf, X, acc[nt], 0, 0, 0);
+      }
+    }
+  }
+  const int m = m0 + arow;
+  if (m < a.M) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+      const int n = n0 + 16 * nt + 4 * g;
+      f32x4 z = acc[nt];
+      if (a.bias) z += *reinterpret_cast<const f32x4*>(a.bias + n);
+      if (a.addend) z += *reinterpret_cast<const f32x4*>(a.addend + (long)m * a.ld_add + n);
+#pragma unroll
+      for (int r = 0; r < 4; r++) z[r] = act_apply(a.act, z[r]);
+      *reinterpret_cast<f32x4*>(a.y + (long)m * a.N + n) = z;
+      if (a.yb) *reinterpret_cast<bf16x4*>(a.yb + (long)m * a.N + n) = bf16x4{(__bf16)z[0], (__bf16)z[1], (__bf16)z[2], (__bf16)z[3]};
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tacorl_rnn_linear_supported(int M, int K, int N) {
+  return M >= 1 && K >= RB_K && K % RB_K == 0 && N >= RB_N && N % RB_N == 0 ? 1 : 0;
+}
+
+extern "C" int tacorl_rnn_linear_fwd(const void* x_bf16, const void* w_bf16, const float* bias, const float* addend,
+                                     int ld_add, float* y, void* y_bf16, int M, int K, int N, int act,
+                                     tacorl_stream_t stream) {
+  if (!tacorl_rnn_linear_supported(M, K, N) || (addend && ld_add % 4)) return TACORL_EINVAL;
+  if (((uintptr_t)x_bf16 | (uintptr_t)w_bf16 | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)addend) & 15) return TACORL_EINVAL;
+  if ((uintptr_t)y_bf16 & 7) return TACORL_EINVAL;
+  RnnArgs a{(const __bf16*)x_bf16, (const __bf16*)w_bf16, bias, addend, y, (__bf16*)y_bf16, M, K, N, ld_add, act};
+  constexpr int lds = RB_S * STAGE_BYTES;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_gemm_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess ? 0 : -1;
+  if (once) return TACORL_ELAUNCH;
+  hipLaunchKernelGGL(rnn_gemm_kernel, dim3((M + RB_M - 1) / RB_M, N / RB_N), dim3(256), lds, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}

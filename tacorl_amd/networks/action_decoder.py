@@ -7,6 +7,8 @@ Internals are time-major ([t][b] rows) so every per-step slice and every BPTT op
 contiguous row range; the four heads (mean_fc | log_scale_fc | prob_fc | gripper_fc) are stored
 back to back and evaluated as one GEMM.
 """
+import ctypes as C
+
 import torch
 
 from .. import ops
@@ -66,6 +68,11 @@ class ActionDecoderLogistic:
                               device=self.dev)
         nb = ops.L.lib().tacorl_linear_add_fwd_ws_bytes(1, ops.int_array([B]), H, H)
         self.rnn_ws = torch.empty(max(256, nb), dtype=torch.uint8, device=self.dev)
+        # bf16 mode: hidden states and the H x H recurrent weights also live as bf16 (the ring GEMM's operands)
+        bf = lambda *s: torch.zeros(*s, device=self.dev, dtype=torch.bfloat16)  # noqa: E731
+        self.hb = [bf(R, H) for _ in range(self.L)]
+        self.h0b = bf(B, H)
+        self.whb = [bf(H, H) for _ in range(self.L)]
         self._shape = (B, Tm)
 
     def _lin(self, x, ldx, w, b, y, M, K, N, act, compute):
@@ -87,14 +94,27 @@ class ActionDecoderLogistic:
         call("tacorl_build_ad_input", ptr(plan), ptr(emb), ld_emb, ptr(self.x_seq), B, T, Tm, self.P, self.E,
              ops.stream())
         x, K = self.x_seq, self.P + self.E
+        # bf16 mode: the recurrent step runs as ONE launch (LDS-DMA ring GEMM, rnn_ops.hip) on bf16 copies of
+        # W_hh (refreshed here: the weights may have been stepped) and of the previous hidden state
+        fast = compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H))
+        if fast:
+            call("tacorl_to_bf16_batch", self.L, ops.ptr_array([blk.p(f"rnn.weight_hh_l{l}") for l in range(self.L)]),
+                 ops.ptr_array(self.whb), (C.c_long * self.L)(*([H * H] * self.L)), ops.stream())
+        at = ops._at
         for l in range(self.L):
             self._lin(x, K, blk.p(f"rnn.weight_ih_l{l}"), blk.p(f"rnn.bias_ih_l{l}"), self.xin[l], R, K, H, ACT_NONE,
                       compute)
             for t in range(Tm):
-                prev = self.h0 if t == 0 else ops._at(self.h[l], (t - 1) * B * H)
+                if fast:
+                    prevb = ptr(self.h0b) if t == 0 else C.c_void_p(self.hb[l].data_ptr() + 2 * (t - 1) * B * H)
+                    call("tacorl_rnn_linear_fwd", prevb, ptr(self.whb[l]), blk.p(f"rnn.bias_hh_l{l}"), at(self.xin[l], t * B * H),
+                         H, at(self.h[l], t * B * H), C.c_void_p(self.hb[l].data_ptr() + 2 * t * B * H), B, H, H, ACT_RELU,
+                         ops.stream())
+                    continue
+                prev = self.h0 if t == 0 else at(self.h[l], (t - 1) * B * H)
                 call("tacorl_linear_add_fwd", 1, ops.ptr_array([prev]), H, ops.ptr_array([blk.p(f"rnn.weight_hh_l{l}")]),
-                     ops.ptr_array([blk.p(f"rnn.bias_hh_l{l}")]), ops.ptr_array([ops._at(self.xin[l], t * B * H)]), H,
-                     ops.ptr_array([ops._at(self.h[l], t * B * H)]), H, ops.int_array([B]), H, H, ACT_RELU, compute,
+                     ops.ptr_array([blk.p(f"rnn.bias_hh_l{l}")]), ops.ptr_array([at(self.xin[l], t * B * H)]), H,
+                     ops.ptr_array([at(self.h[l], t * B * H)]), H, ops.int_array([B]), H, H, ACT_RELU, compute,
                      ptr(self.rnn_ws), self.rnn_ws.numel(), ops.stream())
             x, K = self.h[l], H
         self._lin(x, H, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.heads, R, H, self.NH, ACT_NONE, compute)

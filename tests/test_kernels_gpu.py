@@ -473,3 +473,26 @@ def test_mlp_fused_backward(dims, acts, want_dx):
         if g_fus[i] is not None:
             assert torch.isfinite(g_fus[i]).all()
             assert relerr(g_fus[i], g_ref[i]) < 3e-3, ("grads", i, relerr(g_fus[i], g_ref[i]))
+
+
+@pytest.mark.parametrize("M,K,N,act", [(256, 2048, 2048, 1), (100, 256, 64, 0), (3840, 2048, 2048, 0), (64, 128, 32, 1)])
+def test_rnn_linear_bf16(M, K, N, act):
+    """LDS-DMA ring GEMM of the ReLU-RNN (bf16 operands in HBM): vs fp32 torch on the same bf16-rounded
+    operands (only the fp32 accumulation order differs), with bias, addend, ReLU and the bf16 output copy."""
+    from tacorl_amd import _lib, ops
+
+    dev = _dev()
+    assert _lib.lib().tacorl_rnn_linear_supported(M, K, N) == 1
+    x = rnd(M, K, seed=1).to(torch.bfloat16)
+    w = (rnd(N, K, seed=2) / math.sqrt(K)).to(torch.bfloat16)
+    b, add = rnd(N, seed=3, scale=0.1), rnd(M, N + 4, seed=4)
+    z = x.float() @ w.float().t() + b + add[:, :N]
+    ref = F.relu(z) if act == 1 else z
+    xd, wd, bd, addd = x.to(dev), w.to(dev), b.to(dev), add.to(dev)
+    y = torch.full((M, N), float("nan"), device=dev)
+    yb = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    ops.call("tacorl_rnn_linear_fwd", ops.ptr(xd), ops.ptr(wd), ops.ptr(bd), ops.ptr(addd), N + 4, ops.ptr(y), ops.ptr(yb),
+             M, K, N, act, ops.stream())
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < 1e-5, relerr(y, ref)
+    assert torch.equal(yb, y.to(torch.bfloat16))
