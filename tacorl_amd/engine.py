@@ -246,10 +246,8 @@ class ACEngine:
     # also get their activations saved by that launch.  Otherwise: the per-layer path.
     GRAD_PROBS = ("a_og", "q1", "q2")
     use_fused = True  # tests flip this to compare the fused launch against the per-layer path
-    # MLP weight gradients on side streams (parallel graph branches): shortens the dependent chain of the
-    # update (1.52 -> 1.45 ms/step without the action-decoder branch); with TACORL's PR/action-decoder
-    # branches already running beside the update the extra concurrency costs more than it saves
-    # (1.87 -> 1.91 ms), so TACORL turns it off when that branch runs every step.
+    # MLP weight gradients on side streams (parallel graph branches): they are needed only by Adam, so
+    # they leave the dependent chain of the update (1.70 -> 1.60 ms/step at the bench shapes)
     wgrad_side_streams = True
 
     def _fused_ok(self, c):

@@ -147,7 +147,6 @@ class TACORL(CQL_Offline):
         """Graph-capturable: all encoders (frozen LMP + actor/critics/targets) -> plan recognition -> plan ->
         AD loss -> first phase of the CQL update (up to the alpha gradient)."""
         e = self.engine
-        e.wgrad_side_streams = not (with_ad and self.action_loss_every_n_steps <= 1)
         e._encode_all()
         # Plan recognition -> plan -> (action-decoder loss) only need the frame embeddings; the first phase of
         # the CQL update does not need the plan.  They run as parallel branches of the step's graph:
