@@ -18,10 +18,8 @@
 
 namespace {
 
-constexpr int RB_M = 64, RB_N = 32, RB_K = 128, RB_S = 4;
-constexpr int ROW_BYTES = RB_K * 2;                      // 256 B per staged row (16 chunks of 16 B)
-constexpr int STAGE_BYTES = (RB_M + RB_N) * ROW_BYTES;   // 24 KiB
-constexpr int DMA_PER_WAVE = (RB_M + RB_N) / 4 / 4;      // wave-instructions per stage and wave (4 rows each)
+constexpr int RB_K = 128;
+constexpr int ROW_BYTES = RB_K * 2;  // 256 B per staged row (16 chunks of 16 B)
 
 struct RnnArgs {
   const __bf16* x;
@@ -33,10 +31,16 @@ struct RnnArgs {
   int M, K, N, ld_add, act;
 };
 
+// One RB_M x RB_N output tile per workgroup (4 waves stacked along M), RB_S-stage ring.
 // LDS row r keeps its 16-byte chunk c at position c ^ (r & 15): a fragment read (16 lanes = 16 rows, same
 // c) then spreads over all banks.  The DMA writes lane-contiguous, so the swizzle is applied to the
 // *global* chunk each lane fetches.
+template <int RB_M, int RB_N, int RB_S>
 __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnArgs a) {
+  constexpr int STAGE_BYTES = (RB_M + RB_N) * ROW_BYTES;
+  constexpr int DMA_PER_WAVE = (RB_M + RB_N) / 4 / 4;  // wave-instructions per stage and wave (4 rows each)
+  constexpr int MI = RB_M / 64, NI = RB_N / 16;        // 16x16 tiles per wave
+  static_assert((RB_M + RB_N) % 16 == 0 && RB_M % 64 == 0 && RB_N % 16 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * RB_M, n0 = blockIdx.y * RB_N;
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnArgs a) {
     unsigned char* base = lds + slot * STAGE_BYTES;
 #pragma unroll
     for (int q = 0; q < DMA_PER_WAVE; q++) {
-      const int row4 = (w + 4 * q) * 4;           // first of the 4 rows this wave-instruction fills
+      const int row4 = (w + 4 * q) * 4;  // first of the 4 rows this wave-instruction fills
       const int r = row4 + (lane >> 4), cpos = lane & 15, c = cpos ^ (r & 15);
       const int xm = m0 + r < a.M ? m0 + r : a.M - 1;  // rows past M are loaded (clamped) but never stored
       const __bf16* src = (r < RB_M ? a.x + (long)xm * a.K : a.w + (long)(n0 + r - RB_M) * a.K) + kt * RB_K + c * 8;
@@ -55,11 +59,15 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnArgs a) {
     }
   };
 
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int nt = 0; nt < NI; nt++) acc[mi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < RB_S - 1; s++)
     if (s < nk) issue(s, s);
-  const int arow = 16 * w + i;  // this lane's activation row inside the tile
+  const int arow = 16 * MI * w + i;  // this lane's first activation row inside the tile
   for (int kt = 0; kt < nk; kt++) {
     // stage kt has landed once at most the RB_S-2 younger stages of this wave are outstanding
     if (kt + RB_S - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE * (RB_S - 2)) : "memory");
@@ -72,22 +80,30 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnArgs a) {
 #pragma unroll
     for (int ks = 0; ks < RB_K / 32; ks++) {
       const int c = 4 * ks + g;
-      const bf16x8 X = *reinterpret_cast<const bf16x8*>(st + arow * ROW_BYTES + ((c ^ (arow & 15)) << 4));
+      bf16x8 X[MI];
 #pragma unroll
-      for (int nt = 0; nt < 2; nt++) {
+      for (int mi = 0; mi < MI; mi++) {
+        const int r = arow + 16 * mi;
+        X[mi] = *reinterpret_cast<const bf16x8*>(st + r * ROW_BYTES + ((c ^ (r & 15)) << 4));
+      }
+#pragma unroll
+      for (int nt = 0; nt < NI; nt++) {
         const int r = RB_M + 16 * nt + i;
         const bf16x8 Wf = *reinterpret_cast<const bf16x8*>(st + r * ROW_BYTES + ((c ^ (r & 15)) << 4));
         // weights as the A operand: D[n][m], a lane ends with 4 consecutive output columns of one row
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf, X, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf, X[mi], acc[mi][nt], 0, 0, 0);
       }
     }
   }
-  const int m = m0 + arow;
-  if (m < a.M) {
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
+  for (int mi = 0; mi < MI; mi++) {
+    const int m = m0 + arow + 16 * mi;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < NI; nt++) {
       const int n = n0 + 16 * nt + 4 * g;
-      f32x4 z = acc[nt];
+      f32x4 z = acc[mi][nt];
       if (a.bias) z += *reinterpret_cast<const f32x4*>(a.bias + n);
       if (a.addend) z += *reinterpret_cast<const f32x4*>(a.addend + (long)m * a.ld_add + n);
 #pragma unroll
@@ -98,10 +114,21 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnArgs a) {
   }
 }
 
+template <int RB_M, int RB_N, int RB_S>
+int launch_ring(const RnnArgs& a, hipStream_t st) {
+  constexpr int lds = RB_S * (RB_M + RB_N) * ROW_BYTES;
+  auto kern = rnn_gemm_kernel<RB_M, RB_N, RB_S>;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) ==
+                            hipSuccess ? 0 : -1;
+  if (once) return TACORL_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((a.M + RB_M - 1) / RB_M, a.N / RB_N), dim3(256), lds, st, a);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
 }  // namespace
 
 extern "C" int tacorl_rnn_linear_supported(int M, int K, int N) {
-  return M >= 1 && K >= RB_K && K % RB_K == 0 && N >= RB_N && N % RB_N == 0 ? 1 : 0;
+  return M >= 1 && K >= RB_K && K % RB_K == 0 && N >= 32 && N % 32 == 0 ? 1 : 0;
 }
 
 extern "C" int tacorl_rnn_linear_fwd(const void* x_bf16, const void* w_bf16, const float* bias, const float* addend,
@@ -111,10 +138,8 @@ extern "C" int tacorl_rnn_linear_fwd(const void* x_bf16, const void* w_bf16, con
   if (((uintptr_t)x_bf16 | (uintptr_t)w_bf16 | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)addend) & 15) return TACORL_EINVAL;
   if ((uintptr_t)y_bf16 & 7) return TACORL_EINVAL;
   RnnArgs a{(const __bf16*)x_bf16, (const __bf16*)w_bf16, bias, addend, y, (__bf16*)y_bf16, M, K, N, ld_add, act};
-  constexpr int lds = RB_S * STAGE_BYTES;
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_gemm_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess ? 0 : -1;
-  if (once) return TACORL_ELAUNCH;
-  hipLaunchKernelGGL(rnn_gemm_kernel, dim3((M + RB_M - 1) / RB_M, N / RB_N), dim3(256), lds, (hipStream_t)stream, a);
-  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+  // a recurrent step (M = batch) wants many small tiles to fill the chip; the sequence-wide input projection
+  // (M = batch*T) wants the larger tile (fewer re-reads of W)
+  if ((long)M * N >= 256L * 64 * 128 && N % 64 == 0) return launch_ring<128, 64, 3>(a, (hipStream_t)stream);
+  return launch_ring<64, 32, 4>(a, (hipStream_t)stream);
 }

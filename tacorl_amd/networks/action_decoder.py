@@ -73,6 +73,7 @@ class ActionDecoderLogistic:
         self.hb = [bf(R, H) for _ in range(self.L)]
         self.h0b = bf(B, H)
         self.whb = [bf(H, H) for _ in range(self.L)]
+        self.wib = [None] + [bf(H, H) for _ in range(1, self.L)]  # W_ih of layers >= 1 (H x H)
         self._shape = (B, Tm)
 
     def _lin(self, x, ldx, w, b, y, M, K, N, act, compute):
@@ -98,12 +99,18 @@ class ActionDecoderLogistic:
         # W_hh (refreshed here: the weights may have been stepped) and of the previous hidden state
         fast = compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H))
         if fast:
-            call("tacorl_to_bf16_batch", self.L, ops.ptr_array([blk.p(f"rnn.weight_hh_l{l}") for l in range(self.L)]),
-                 ops.ptr_array(self.whb), (C.c_long * self.L)(*([H * H] * self.L)), ops.stream())
+            srcs = [blk.p(f"rnn.weight_hh_l{l}") for l in range(self.L)] + [blk.p(f"rnn.weight_ih_l{l}") for l in range(1, self.L)]
+            dsts = self.whb + self.wib[1:]
+            call("tacorl_to_bf16_batch", len(srcs), ops.ptr_array(srcs), ops.ptr_array(dsts),
+                 (C.c_long * len(srcs))(*([H * H] * len(srcs))), ops.stream())
         at = ops._at
         for l in range(self.L):
-            self._lin(x, K, blk.p(f"rnn.weight_ih_l{l}"), blk.p(f"rnn.bias_ih_l{l}"), self.xin[l], R, K, H, ACT_NONE,
-                      compute)
+            if fast and l > 0:  # sequence-wide input projection from the bf16 hidden states of the layer below
+                call("tacorl_rnn_linear_fwd", ptr(self.hb[l - 1]), ptr(self.wib[l]), blk.p(f"rnn.bias_ih_l{l}"), None, 0,
+                     ptr(self.xin[l]), None, R, H, H, ACT_NONE, ops.stream())
+            else:
+                self._lin(x, K, blk.p(f"rnn.weight_ih_l{l}"), blk.p(f"rnn.bias_ih_l{l}"), self.xin[l], R, K, H, ACT_NONE,
+                          compute)
             for t in range(Tm):
                 if fast:
                     prevb = ptr(self.h0b) if t == 0 else C.c_void_p(self.hb[l].data_ptr() + 2 * (t - 1) * B * H)
