@@ -14,7 +14,9 @@
 
 namespace {
 
-constexpr int BMF = 64;   // rows per workgroup
+constexpr int BMF = 32;   // rows per workgroup (32: twice the workgroups of 64 - these kernels are latency-bound,
+                          // the Q MLP's 3328 rows give 104 vs 208 workgroups on 256 CUs)
+constexpr int MTF = BMF / 16;
 constexpr int XP = 264;   // LDS row pitch (bf16): 528 B -> 16 consecutive rows hit distinct bank groups
 constexpr int MAXD = 256; // widest layer
 
@@ -29,6 +31,22 @@ struct MlpFwdArgs {
   int dims[MF_MAXL + 1], acts[MF_MAXL];
   int L, ldx;
 };
+
+// bf16-mode activation math: hardware exp / reciprocal (relative error ~1e-6, far below the bf16 operand
+// rounding of these kernels); the exact expf / IEEE-division forms cost ~3 us per layer and workgroup here
+__device__ __forceinline__ float act_fast(int act, float z) {
+  if (act == ACT_RELU) return z > 0.f ? z : 0.f;
+  if (act == ACT_SILU) return z * __frcp_rn(1.f + __expf(-z));
+  return z;
+}
+__device__ __forceinline__ float act_grad_fast(int act, float zy) {
+  if (act == ACT_RELU) return zy > 0.f ? 1.f : 0.f;
+  if (act == ACT_SILU) {
+    const float sg = __frcp_rn(1.f + __expf(-zy));
+    return sg * (1.f + zy * (1.f - sg));
+  }
+  return 1.f;
+}
 
 // 8 consecutive bf16 weights of output row n (zeros outside the matrix); rows are 8-byte aligned
 __device__ __forceinline__ bf16x8 load_w(const __bf16* __restrict__ W, int K, int N, int n, int k) {
@@ -84,25 +102,25 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
     const float* bias = a.params[p] + a.boff[l];
     const __bf16* xin = X + cur * BMF * XP;
     __bf16* xout = X + (cur ^ 1) * BMF * XP;
-    f32x4 acc[4][4];
+    f32x4 acc[MTF][4];
     if (n0 < N) {  // wave-uniform: this wave owns output columns [n0, n0 + 64)
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++)
+      for (int mt = 0; mt < MTF; mt++)
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
         if (ks >= KS) break;
-        bf16x8 A[4];
+        bf16x8 A[MTF];
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) A[mt] = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
+        for (int mt = 0; mt < MTF; mt++) A[mt] = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
 #pragma unroll
         for (int nt = 0; nt < 4; nt++)
           if (n0 + 16 * nt < N) {
 #pragma unroll
             // weights as the A operand: D[n][m] - a lane then holds 4 CONSECUTIVE output columns of one row,
             // so the epilogue moves 16-byte vectors instead of 4-byte gathers
-            for (int mt = 0; mt < 4; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nt], A[mt], acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < MTF; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nt], A[mt], acc[mt][nt], 0, 0, 0);
           }
       }
     }
@@ -123,11 +141,11 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
           for (int r = 0; r < 4; r++) bv[r] = col + r < N ? bias[col + r] : 0.f;
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
+        for (int mt = 0; mt < MTF; mt++) {
           const int row = 16 * mt + i;
           f32x4 z = acc[mt][nt] + bv, y;
 #pragma unroll
-          for (int r = 0; r < 4; r++) y[r] = col + r < N ? act_apply(act, z[r]) : 0.f;
+          for (int r = 0; r < 4; r++) y[r] = col + r < N ? act_fast(act, z[r]) : 0.f;
           if (m0 + row < M) {
             const long o = (long)(m0 + row) * N + col;
             if (vec && col < N) {
@@ -220,23 +238,23 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
     const int KO = a.dims[l], NR = a.dims[l + 1], KS = (NR + 31) / 32;
     const __bf16* xin = X + cur * BMF * XP;
     __bf16* xout = X + (cur ^ 1) * BMF * XP;
-    f32x4 acc[4][4];
+    f32x4 acc[MTF][4];
     if (n0 < KO) {
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++)
+      for (int mt = 0; mt < MTF; mt++)
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
         if (ks >= KS) break;
-        bf16x8 A[4];
+        bf16x8 A[MTF];
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) A[mt] = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
+        for (int mt = 0; mt < MTF; mt++) A[mt] = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
 #pragma unroll
         for (int nt = 0; nt < 4; nt++)
           if (n0 + 16 * nt < KO) {
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nt], A[mt], acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < MTF; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nt], A[mt], acc[mt][nt], 0, 0, 0);
           }
       }
     }
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
         const int col = n0 + 16 * nt + 4 * g;  // this lane's 4 consecutive columns (D = W^T-frag x dZ-frag)
         if (n0 + 16 * nt >= KO) continue;
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
+        for (int mt = 0; mt < MTF; mt++) {
           const int row = 16 * mt + i;
           const bool rok = m0 + row < M;
           f32x4 v = acc[mt][nt];
@@ -260,11 +278,11 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
             if (vec && col < KO) {
               const f32x4 sv = *reinterpret_cast<const f32x4*>(src + (long)(m0 + row) * KO + col);
 #pragma unroll
-              for (int r = 0; r < 4; r++) v[r] *= act_grad(pact, sv[r]);
+              for (int r = 0; r < 4; r++) v[r] *= act_grad_fast(pact, sv[r]);
             } else {
 #pragma unroll
               for (int r = 0; r < 4; r++)
-                if (col + r < KO) v[r] *= act_grad(pact, src[(long)(m0 + row) * KO + col + r]);
+                if (col + r < KO) v[r] *= act_grad_fast(pact, src[(long)(m0 + row) * KO + col + r]);
             }
           }
 #pragma unroll
