@@ -196,6 +196,14 @@ int tacorl_uniform_actions(const float* u01, float* dst, int ld_dst, int rows, i
 int tacorl_tanh_normal_sample(const float* head, int ld_head, const float* eps, const float* gumbel_u,
                               int hard_rsample, float* act_out, int ld_act, float* logp, int* grip_idx,
                               int n, int M, int Ac, tacorl_stream_t stream);
+/* njobs <= 6 tacorl_tanh_normal_sample calls sharing (M, Ac, ld_head, ld_act) in one launch, optionally with
+ * the tacorl_uniform_actions(u01, u_dst, ld_act, u_rows, A, u_discrete) of the step (u01 NULL = none). */
+int tacorl_tanh_normal_sample_batch(int njobs, const float* const* head, int ld_head,
+                                    const float* const* eps, const float* const* gumbel_u,
+                                    const int* hard_rsample, float* const* act_out, int ld_act,
+                                    float* const* logp, int* const* grip_idx, const int* n, int M, int Ac,
+                                    const float* u01, float* u_dst, int u_rows, int A, int u_discrete,
+                                    tacorl_stream_t stream);
 
 /* ---- plan-recognition transformer glue (reference plan_recognition_transformer.py:70-105) ---- */
 /* out[r] = [x[r] (D, zero-padded to Dp)] + add[r % T]  (position embeddings). */

@@ -282,6 +282,100 @@ extern "C" int tacorl_tanh_normal_sample(const float* head, int ld_head, const f
   return LAUNCH_OK();
 }
 
+// All tanh-Gaussian draws of a step in one launch (blockIdx.y = job): 32 lanes per (sample, row), one
+// per action dimension, log pi reduced with xor-shuffles - the one-thread-per-row kernel above leaves
+// 1-4 workgroups with a serial loop over the dimensions (~13 us per call, 4 calls per step).
+// Job j < njobs: same arguments as tacorl_tanh_normal_sample.  An optional job of uniform actions
+// (u01 -> 2u-1, reference cql_offline_lightning.py:355-362) rides along as the last blockIdx.y.
+#define TNS_MAXJ 6
+struct TnsTbl {
+  const float* head[TNS_MAXJ];
+  const float* eps[TNS_MAXJ];
+  const float* gumbel[TNS_MAXJ];
+  float* act_out[TNS_MAXJ];
+  float* logp[TNS_MAXJ];
+  int* grip[TNS_MAXJ];
+  int hard[TNS_MAXJ], n[TNS_MAXJ];
+  const float* u01;
+  float* u_dst;
+  int u_rows, u_disc;
+};
+__global__ __launch_bounds__(256) void tanh_normal_sample_batch_kernel(TnsTbl t, int njobs, int M, int Ac, int ld_head,
+                                                                       int ld_act, int A) {
+  const int job = blockIdx.y;
+  if (job == njobs) {  // uniform actions
+    const long total = (long)t.u_rows * A;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const int r = (int)(i / A), c = (int)(i - (long)r * A);
+      float v = t.u01[i] * 2.0f - 1.0f;
+      if (t.u_disc && c == A - 1) v = v >= 0.f ? 1.f : -1.f;
+      t.u_dst[(long)r * ld_act + c] = v;
+    }
+    return;
+  }
+  const long rows = (long)t.n[job] * M;
+  const int j = threadIdx.x & 31;
+  for (long i = (long)blockIdx.x * 8 + (threadIdx.x >> 5); i < rows; i += (long)gridDim.x * 8) {
+    const int m = (int)(i % M);
+    const float* h = t.head[job] + (long)m * ld_head;
+    float lp = 0.f;
+    if (j < Ac) {
+      float mu, sd;
+      head_stats(h, j, Ac, mu, sd);
+      const float z = mu + t.eps[job][i * Ac + j] * sd;
+      t.act_out[job][i * ld_act + j] = tanhf(z);
+      lp = normal_lp(z, mu, sd) + tanh_corr(z);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) lp += __shfl_xor(lp, o, 64);
+    if (j == 0) {
+      if (t.gumbel[job]) {
+        const float l0 = h[2 * Ac], l1 = h[2 * Ac + 1];
+        const float mx = fmaxf(l0, l1);
+        const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+        const float n0 = l0 - lse, n1 = l1 - lse;
+        float u0 = t.gumbel[job][i * 2], u1 = t.gumbel[job][i * 2 + 1];
+        int idx;
+        if (t.hard[job]) {
+          const float e = 1.1920929e-07f;
+          u0 = fminf(fmaxf(u0, e), 1.f - e); u1 = fminf(fmaxf(u1, e), 1.f - e);
+          const float s0 = (n0 - logf(-logf(u0))) / 0.5f, s1 = (n1 - logf(-logf(u1))) / 0.5f;
+          idx = s1 > s0 ? 1 : 0;
+        } else {
+          idx = (n1 - logf(-logf(u1))) > (n0 - logf(-logf(u0))) ? 1 : 0;
+        }
+        const float mm = fmaxf(n0, n1), l2 = mm + logf(expf(n0 - mm) + expf(n1 - mm));
+        lp += (idx ? n1 : n0) - l2;
+        t.act_out[job][i * ld_act + Ac] = idx ? 1.f : -1.f;
+        if (t.grip[job]) t.grip[job][i] = idx;
+      }
+      t.logp[job][i] = lp;
+    }
+  }
+}
+extern "C" int tacorl_tanh_normal_sample_batch(int njobs, const float* const* head, int ld_head, const float* const* eps,
+                                               const float* const* gumbel_u, const int* hard_rsample,
+                                               float* const* act_out, int ld_act, float* const* logp,
+                                               int* const* grip_idx, const int* n, int M, int Ac, const float* u01,
+                                               float* u_dst, int u_rows, int A, int u_discrete, tacorl_stream_t stream) {
+  if (njobs < 1 || njobs > TNS_MAXJ || Ac > 32 || M <= 0) return TACORL_EINVAL;
+  TnsTbl t{};
+  long maxrows = 0;
+  for (int j = 0; j < njobs; j++) {
+    t.head[j] = head[j]; t.eps[j] = eps[j]; t.gumbel[j] = gumbel_u ? gumbel_u[j] : nullptr; t.act_out[j] = act_out[j];
+    t.logp[j] = logp[j]; t.grip[j] = grip_idx ? grip_idx[j] : nullptr; t.hard[j] = hard_rsample[j]; t.n[j] = n[j];
+    maxrows = (long)n[j] * M > maxrows ? (long)n[j] * M : maxrows;
+  }
+  t.u01 = u01; t.u_dst = u_dst; t.u_rows = u01 ? u_rows : 0; t.u_disc = u_discrete;
+  const long urows8 = u01 ? ((long)u_rows * A + 255) / 256 : 0;
+  long blocks = (maxrows + 7) / 8;
+  if (urows8 > blocks) blocks = urows8;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(tanh_normal_sample_batch_kernel, dim3((unsigned)blocks, njobs + (u01 ? 1 : 0)), dim3(256), 0,
+                     (hipStream_t)stream, t, njobs, M, Ac, ld_head, ld_act, A);
+  return LAUNCH_OK();
+}
+
 // ------------------------------------------------------------------ actor losses
 // logs slots (device float buffer, also the host-visible metric record)
 enum {

@@ -376,15 +376,17 @@ class ACEngine:
         head_cur, head_next = self._head("a"), self._head("a_nx")
         g = (lambda k: nz[k]) if self.dg else (lambda k: None)
         # actor rsample on obs, critic-target sample on next_obs, CQL samples on both
-        ops.tanh_normal_sample(head_cur, self.HD, nz["eps_pi"], g("g_pi"), True, self.act_pi, 0, A, self.logp_pi,
-                               self.grip_pi if self.dg else None, 1, B, Ac)
-        ops.tanh_normal_sample(head_next, self.HD, nz["eps_next"], g("g_next"), False, self.act_next, 0, A,
-                               self.logp_next, None, 1, B, Ac)
-        ops.uniform_actions(nz["u_rand"], self.acts_main, B * A, A, n * B, A, self.dg)
-        ops.tanh_normal_sample(head_cur, self.HD, nz["eps_cur"], g("g_cur"), False, self.acts_main, (1 + n) * B * A, A,
-                               self.logp_cur, None, n, B, Ac)
-        ops.tanh_normal_sample(head_next, self.HD, nz["eps_nxt"], g("g_nxt"), False, self.acts_main,
-                               (1 + 2 * n) * B * A, A, self.logp_nxt, None, n, B, Ac)
+        # one launch: rsample on obs, critic-target sample on next_obs, the n CQL samples on both, uniform actions
+        at = ops._at
+        jobs = [(head_cur, nz["eps_pi"], g("g_pi"), 1, ptr(self.act_pi), self.logp_pi, self.grip_pi if self.dg else None, 1),
+                (head_next, nz["eps_next"], g("g_next"), 0, ptr(self.act_next), self.logp_next, None, 1),
+                (head_cur, nz["eps_cur"], g("g_cur"), 0, at(self.acts_main, (1 + n) * B * A), self.logp_cur, None, n),
+                (head_next, nz["eps_nxt"], g("g_nxt"), 0, at(self.acts_main, (1 + 2 * n) * B * A), self.logp_nxt, None, n)]
+        call("tacorl_tanh_normal_sample_batch", len(jobs), ops.ptr_array([j[0] for j in jobs]), self.HD,
+             ops.ptr_array([j[1] for j in jobs]), ops.ptr_array([j[2] for j in jobs]), ops.int_array([j[3] for j in jobs]),
+             ops.ptr_array([j[4] for j in jobs]), A, ops.ptr_array([j[5] for j in jobs]),
+             ops.ptr_array([j[6] for j in jobs]), ops.int_array([j[7] for j in jobs]), B, Ac, ptr(nz["u_rand"]),
+             at(self.acts_main, B * A), n * B, A, int(self.dg), ops.stream())
         # alpha: loss, gradient, Adam step (alpha is read post-step below; SURVEY 8a note 2)
         call("tacorl_alpha_loss", ptr(self.logp_pi), B, ptr(self.log_alpha.param), float(hp["target_entropy"]), gs,
              ptr(self.log_alpha.grad), ptr(self.logs), ops.stream())
