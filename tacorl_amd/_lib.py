@@ -87,6 +87,8 @@ _SIGS = {
     "tacorl_cql_loss": (_i, [_p] * 13 + [_i, _i, _i, _f, _f, _f, _f, _f, _i, _f, _p, _p, _p, _sz, _p]),
     "tacorl_adam_ws_bytes": (_sz, [_l]),
     "tacorl_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _p, _p, _f, _p, _sz, _p]),
+    "tacorl_adam_batch_ws_bytes": (_sz, [_i]),
+    "tacorl_adam_step_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
 }
 
 _lib = None

@@ -672,6 +672,92 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 __global__ void bump_step_kernel(int* step_counter) { step_counter[0] += 1; }
 
+// Several parameter blocks in three launches (norms, updates, step counters) instead of three each:
+// the optimiser phase is the tail of the step's dependent chain.  Same per-block partitioning as
+// tacorl_adam_step, so results are bit-identical to it.
+#define ADAM_MAXB 8
+struct AdamTbl {
+  float* p[ADAM_MAXB];
+  const float* g[ADAM_MAXB];
+  float* m[ADAM_MAXB];
+  float* v[ADAM_MAXB];
+  float* target[ADAM_MAXB];
+  int* step[ADAM_MAXB];
+  float* partial[ADAM_MAXB];
+  long n[ADAM_MAXB];
+  float lr[ADAM_MAXB], max_norm[ADAM_MAXB], tau[ADAM_MAXB];
+  int blocks[ADAM_MAXB];
+};
+__global__ __launch_bounds__(256) void sqnorm_partial_batch_kernel(AdamTbl t) {
+  __shared__ float sh[4];
+  const int b = blockIdx.y;
+  if ((int)blockIdx.x >= t.blocks[b] || !(t.max_norm[b] > 0.f)) return;
+  const float* __restrict__ g = t.g[b];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < t.n[b]; i += (long)t.blocks[b] * 256) s += g[i] * g[i];
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) t.partial[b][blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void adam_batch_kernel(AdamTbl t) {
+  __shared__ float sh[4];
+  const int b = blockIdx.y, nb = t.blocks[b];
+  if ((int)blockIdx.x >= nb) return;
+  float coef = 1.f;
+  if (t.max_norm[b] > 0.f) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += t.partial[b][i];
+    s = block_sum_256(s, sh);
+    coef = fminf(t.max_norm[b] / (sqrtf(s) + 1e-6f), 1.0f);
+  }
+  const int st = t.step[b][0] + 1;
+  const double bc1 = 1.0 - pow(0.9, (double)st), bc2 = 1.0 - pow(0.999, (double)st);
+  const float step_size = (float)((double)t.lr[b] / bc1), rsq_bc2 = (float)sqrt(bc2);
+  float* __restrict__ p = t.p[b];
+  const float* __restrict__ g = t.g[b];
+  float* __restrict__ m = t.m[b];
+  float* __restrict__ v = t.v[b];
+  float* __restrict__ target = t.target[b];
+  const float tau = t.tau[b];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < t.n[b]; i += (long)nb * 256) {
+    const float gi = g[i] * coef;
+    const float mi = m[i] * 0.9f + gi * 0.1f;
+    const float vi = v[i] * 0.999f + (gi * gi) * 0.001f;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / rsq_bc2 + 1e-8f;
+    const float pn = p[i] - step_size * (mi / denom);
+    p[i] = pn;
+    if (target) target[i] = target[i] * (1.0f - tau) + pn * tau;
+  }
+}
+__global__ void bump_step_batch_kernel(AdamTbl t, int nb) {
+  if ((int)threadIdx.x < nb) t.step[threadIdx.x][0] += 1;
+}
+extern "C" size_t tacorl_adam_batch_ws_bytes(int nb) { return (size_t)nb * 1024 * sizeof(float); }
+extern "C" int tacorl_adam_step_batch(int nb, float* const* param, const float* const* grad, float* const* m,
+                                      float* const* v, const long* n, const float* lr, const float* max_norm,
+                                      int* const* step_counter, float* const* target, const float* tau, void* ws,
+                                      size_t ws_bytes, tacorl_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (nb < 1 || nb > ADAM_MAXB) return TACORL_EINVAL;
+  if (ws_bytes < tacorl_adam_batch_ws_bytes(nb)) return TACORL_ENOMEM;
+  AdamTbl t{};
+  int maxb = 0;
+  bool any_clip = false;
+  for (int b = 0; b < nb; b++) {
+    long blocks = (n[b] + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    t.p[b] = param[b]; t.g[b] = grad[b]; t.m[b] = m[b]; t.v[b] = v[b]; t.target[b] = target ? target[b] : nullptr;
+    t.step[b] = step_counter[b]; t.partial[b] = (float*)ws + (long)b * 1024; t.n[b] = n[b]; t.lr[b] = lr[b];
+    t.max_norm[b] = max_norm[b]; t.tau[b] = tau ? tau[b] : 0.f; t.blocks[b] = (int)blocks;
+    maxb = (int)blocks > maxb ? (int)blocks : maxb;
+    any_clip |= max_norm[b] > 0.f;
+  }
+  if (any_clip) hipLaunchKernelGGL(sqnorm_partial_batch_kernel, dim3(maxb, nb), dim3(256), 0, st, t);
+  hipLaunchKernelGGL(adam_batch_kernel, dim3(maxb, nb), dim3(256), 0, st, t);
+  hipLaunchKernelGGL(bump_step_batch_kernel, dim3(1), dim3(64), 0, st, t, nb);
+  return LAUNCH_OK();
+}
+
 extern "C" size_t tacorl_adam_ws_bytes(long n) {
   long blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;

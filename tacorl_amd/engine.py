@@ -546,12 +546,12 @@ class ACEngine:
         """Optimiser steps (grads were all taken on the pre-step graph, as in the reference)."""
         hp, lap = self.hp, self.log_alpha_prime
         if optimize:
-            if self.with_lagrange:
-                ops.adam_step(lap.param, lap.grad, lap.m, lap.v, hp["critic_lr"], 0.0, lap.step)
             a = self.actor
-            ops.adam_step(a.param, a.grad, a.m, a.v, hp["actor_lr"], hp["clip"], a.step)
+            items = [(lap.param, lap.grad, lap.m, lap.v, hp["critic_lr"], 0.0, lap.step, None, 0.0)] if self.with_lagrange else []
+            items.append((a.param, a.grad, a.m, a.v, hp["actor_lr"], hp["clip"], a.step, None, 0.0))
             for q, t in ((self.q1, self.tq1), (self.q2, self.tq2)):
-                ops.adam_step(q.param, q.grad, q.m, q.v, hp["critic_lr"], hp["clip"], q.step, t.param, hp["tau"])
+                items.append((q.param, q.grad, q.m, q.v, hp["critic_lr"], hp["clip"], q.step, t.param, hp["tau"]))
+            ops.adam_step_batch(items)  # three launches for all blocks
 
     def _allreduce(self, tensors):
         if self.world > 1:

@@ -211,6 +211,19 @@ def tanh_normal_sample(head, ld_head, eps, gumbel_u, hard, act_out, act_off, ld_
          ld_act, ptr(logp), ptr(grip_idx), n, M, Ac, stream())
 
 
+def adam_step_batch(items):
+    """items: list of (param, grad, m, v, lr, max_norm, step_counter, target_or_None, tau) - one
+    norm launch, one update launch, one counter launch for all of them."""
+    k = len(items)
+    nb = L.lib().tacorl_adam_batch_ws_bytes(k)
+    ws = workspace(nb, items[0][0].device, "adam_batch")
+    call("tacorl_adam_step_batch", k, ptr_array([i[0] for i in items]), ptr_array([i[1] for i in items]),
+         ptr_array([i[2] for i in items]), ptr_array([i[3] for i in items]), (C.c_long * k)(*[i[0].numel() for i in items]),
+         (C.c_float * k)(*[float(i[4]) for i in items]), (C.c_float * k)(*[float(i[5]) for i in items]),
+         ptr_array([i[6] for i in items]), ptr_array([i[7] for i in items]), (C.c_float * k)(*[float(i[8]) for i in items]),
+         ptr(ws), ws.numel(), stream())
+
+
 def adam_step(param, grad, m, v, lr, max_norm, step_counter, target=None, tau=0.0):
     n = param.numel()
     nb = L.lib().tacorl_adam_ws_bytes(n)
