@@ -115,6 +115,23 @@ int tacorl_encoder_bwd_fused(int nprob, const void* const* img, const float* con
                              const float* const* act, const float* const* d_out,
                              float* const* grads, const int* n_img, int H, int W, int accumulate,
                              void* ws, size_t ws_bytes, tacorl_stream_t stream);
+/* The same backward in parts that share `ws`, so that a caller can keep only the dependent chain on its
+ * main stream:  _pack (weight-only preparation: any time after the last optimiser step) -> _head (FC tail
+ * input-gradient chain, one launch) -> _conv (soft-argmax + conv backward); _fc_wgrad (FC weight
+ * gradients) may run on another stream any time after _head.  prepacked = 1: _pack already ran for the
+ * current weights. */
+int tacorl_encoder_bwd_fused_pack(int nprob, const float* const* params, const int* n_img, int H, int W,
+                                  void* ws, size_t ws_bytes, tacorl_stream_t stream);
+int tacorl_encoder_bwd_fused_head(int nprob, const float* const* params, const float* const* act,
+                                  const float* const* d_out, const int* n_img, int H, int W,
+                                  int prepacked, void* ws, size_t ws_bytes, tacorl_stream_t stream);
+int tacorl_encoder_bwd_fused_fc_wgrad(int nprob, const float* const* act, const float* const* d_out,
+                                      float* const* grads, const int* n_img, int H, int W,
+                                      int accumulate, void* ws, size_t ws_bytes, tacorl_stream_t stream);
+int tacorl_encoder_bwd_fused_conv(int nprob, const void* const* img, const float* const* params,
+                                  const float* const* act, float* const* grads, const int* n_img, int H,
+                                  int W, int accumulate, int prepacked, void* ws, size_t ws_bytes,
+                                  tacorl_stream_t stream);
 
 /* ---- MLP = chain of Linear(dims[l] -> dims[l+1]) + acts[l]  ------------------------ */
 /* Parameter block: for each layer W[out][in] then b[out], each 4-float aligned. */
@@ -157,7 +174,11 @@ size_t tacorl_mlp_bwd_fused_ws_bytes(int nprob, const int* M, int n_layers, cons
 int tacorl_mlp_bwd_fused_dgrad(int nprob, const float* const* params, const float* const* act,
                                const float* const* d_out, int ldo, float* const* d_x, int ldd,
                                const int* M, int n_layers, const int* dims, const int* acts,
-                               void* ws, size_t ws_bytes, tacorl_stream_t stream);
+                               int prepacked, void* ws, size_t ws_bytes, tacorl_stream_t stream);
+/* The weight transposes _dgrad needs, alone (they depend only on the parameters: run them early / on
+ * another stream, then pass prepacked = 1 to _dgrad). */
+int tacorl_mlp_bwd_fused_pack(int nprob, const float* const* params, const int* M, int n_layers,
+                              const int* dims, void* ws, size_t ws_bytes, tacorl_stream_t stream);
 int tacorl_mlp_bwd_fused_wgrad(int nprob, const float* const* x, int ldx, const float* const* act,
                                const float* const* d_out, int ldo, float* const* grads, const int* M,
                                int n_layers, const int* dims, const int* acts, int accumulate,

@@ -32,7 +32,8 @@ _SIGS = {
     "tacorl_to_bf16_batch": (_i, [_i, _p, _p, _p, _p]),
     "tacorl_mlp_bwd_fused_supported": (_i, [_i, _i, _p, _i, _i]),
     "tacorl_mlp_bwd_fused_ws_bytes": (_sz, [_i, _p, _i, _p]),
-    "tacorl_mlp_bwd_fused_dgrad": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _p]),
+    "tacorl_mlp_bwd_fused_dgrad": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _sz, _p]),
+    "tacorl_mlp_bwd_fused_pack": (_i, [_i, _p, _p, _i, _p, _p, _sz, _p]),
     "tacorl_mlp_bwd_fused_wgrad": (_i, [_i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _sz, _p]),
     "tacorl_mlp_fwd_fused_supported": (_i, [_i, _i, _p, _i]),
     "tacorl_mlp_fwd_fused": (_i, [_i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p]),
@@ -67,6 +68,10 @@ _SIGS = {
     "tacorl_encoder_fwd_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "tacorl_encoder_bwd_fused_ws_bytes": (_sz, [_i, _p, _i, _i]),
     "tacorl_encoder_bwd_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
+    "tacorl_encoder_bwd_fused_pack": (_i, [_i, _p, _p, _i, _i, _p, _sz, _p]),
+    "tacorl_encoder_bwd_fused_head": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
+    "tacorl_encoder_bwd_fused_fc_wgrad": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
+    "tacorl_encoder_bwd_fused_conv": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "tacorl_mlp_param_layout": (_l, [_i, _p, _p, _p]),
     "tacorl_mlp_act_layout": (_l, [_i, _i, _p, _p, _p, _p]),
     "tacorl_mlp_fwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _p, _i, _p]),

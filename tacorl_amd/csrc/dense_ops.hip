@@ -637,70 +637,163 @@ static size_t enc_fc_slab_bytes(int nprob, long maxn) {
   size_t a = wgrad_ws_bytes(nprob, 256, 32, maxn), b = wgrad_ws_bytes(nprob, 128, 256, maxn);
   return ((a > b ? a : b) + 255) & ~(size_t)255;
 }
-extern "C" size_t tacorl_encoder_bwd_fused_ws_bytes(int nprob, const int* n_img, int H, int W) {
+// Workspace of the fused encoder backward: [per-problem scratch d_h1 | d_sa | dz3 | .. | dtemp][FC W^T (bf16)]
+// [FC wgrad slabs][conv backward workspace (ebw_ws_bytes)].
+struct EncBwdPlan {
   EncDims d;
-  if (!enc_dims(H, W, d) || !ebw_supported(H, W) || nprob < 1 || nprob > EBW_MAXP) return 0;
-  long tot = 0, maxn = 0;
-  for (int p = 0; p < nprob; p++) { tot += enc_bwd_scratch_layout(n_img[p], d, nullptr); maxn = n_img[p] > maxn ? n_img[p] : maxn; }
-  return (((size_t)tot * sizeof(float) + 255) & ~(size_t)255) + enc_fc_slab_bytes(nprob, maxn) + ebw_ws_bytes(nprob, n_img, H, W);
+  long po[E_N];
+  size_t scratch_bytes, fcwt_off[EBW_MAXP], fcwt_each, slab_off, slab_bytes, conv_off, total;
+  long so[EBW_MAXP][6], ao[EBW_MAXP][5], sbase[EBW_MAXP];  // scratch / activation offsets (floats)
+  long maxn;
+};
+static const int kFcDims[3] = {128, 256, 32};
+static const int kFcActs[2] = {ACT_RELU, ACT_NONE};
+static bool enc_bwd_plan(int nprob, const int* n_img, int H, int W, EncBwdPlan& pl) {
+  if (!enc_dims(H, W, pl.d) || !ebw_supported(H, W) || nprob < 1 || nprob > EBW_MAXP) return false;
+  tacorl_encoder_param_layout(pl.po);
+  long tot = 0;
+  pl.maxn = 0;
+  for (int p = 0; p < nprob; p++) {
+    pl.sbase[p] = tot;
+    tot += enc_bwd_scratch_layout(n_img[p], pl.d, pl.so[p]);
+    tacorl_encoder_act_layout(n_img[p], H, W, pl.ao[p]);
+    pl.maxn = n_img[p] > pl.maxn ? n_img[p] : pl.maxn;
+  }
+  size_t b = ((size_t)tot * sizeof(float) + 255) & ~(size_t)255;
+  pl.scratch_bytes = b;
+  pl.fcwt_each = (mlp_fused_wt_elems(2, kFcDims, nullptr) * 2 + 255) & ~(size_t)255;
+  for (int p = 0; p < nprob; p++) { pl.fcwt_off[p] = b; b += pl.fcwt_each; }
+  pl.slab_off = b;
+  pl.slab_bytes = enc_fc_slab_bytes(nprob, pl.maxn);
+  b += pl.slab_bytes;
+  pl.conv_off = b;
+  pl.total = b + ebw_ws_bytes(nprob, n_img, H, W);
+  return true;
+}
+extern "C" size_t tacorl_encoder_bwd_fused_ws_bytes(int nprob, const int* n_img, int H, int W) {
+  EncBwdPlan pl;
+  return enc_bwd_plan(nprob, n_img, H, W, pl) ? pl.total : 0;
+}
+static void enc_bwd_conv_problems(int nprob, const void* const* img, const float* const* params, const float* const* act,
+                                  float* const* grads, const int* n_img, const EncBwdPlan& pl, void* ws, EbwProblem* pr) {
+  for (int p = 0; p < nprob; p++) {
+    const float* P = params[p];
+    float* G = grads ? grads[p] : nullptr;
+    float* sc = (float*)ws + pl.sbase[p];
+    pr[p].img = img ? img[p] : nullptr;
+    pr[p].y1 = act ? act[p] + pl.ao[p][0] : nullptr; pr[p].y2 = act ? act[p] + pl.ao[p][1] : nullptr;
+    pr[p].dz3 = sc + pl.so[p][2];
+    pr[p].w2 = P + pl.po[E_W2]; pr[p].w3 = P + pl.po[E_W3];
+    pr[p].g_w1 = G ? G + pl.po[E_W1] : nullptr; pr[p].g_b1 = G ? G + pl.po[E_B1] : nullptr;
+    pr[p].g_w2 = G ? G + pl.po[E_W2] : nullptr; pr[p].g_b2 = G ? G + pl.po[E_B2] : nullptr;
+    pr[p].g_w3 = G ? G + pl.po[E_W3] : nullptr; pr[p].g_b3 = G ? G + pl.po[E_B3] : nullptr;
+    pr[p].n = n_img[p];
+  }
+}
+// FC tail (Linear 128->256 + ReLU -> Linear 256->32): its input-gradient chain through the fused MLP kernel.
+// mode 1 = transpose the FC weights only, 2 = chain with the weights already transposed, 0 = both.
+static int enc_bwd_fc_chain(int nprob, const float* const* params, const float* const* act, const float* const* d_out,
+                            const int* n_img, const EncBwdPlan& pl, void* ws, hipStream_t st, int mode) {
+  long wo[2], bo[2], src[MF_MAXP * MF_MAXL], dzo[MF_MAXP * MF_MAXL];
+  tacorl_mlp_param_layout(2, kFcDims, wo, bo);
+  const float* fcp[EBW_MAXP];
+  float *dz[EBW_MAXP], *dsa[EBW_MAXP];
+  void* wt[EBW_MAXP];
+  for (int p = 0; p < nprob; p++) {
+    fcp[p] = params[p] + pl.po[E_FW1];
+    src[p * MF_MAXL + 0] = pl.ao[p][4];  // ReLU: derivative source = the layer output h1
+    src[p * MF_MAXL + 1] = -1;
+    dzo[p * MF_MAXL + 0] = pl.sbase[p] + pl.so[p][0];  // dZ of fc1 = d_h1
+    dz[p] = (float*)ws;
+    dsa[p] = (float*)ws + pl.sbase[p] + pl.so[p][1];
+    wt[p] = (unsigned char*)ws + pl.fcwt_off[p];
+  }
+  return mlp_fused_bwd(nprob, fcp, act, d_out, 32, dz, dsa, 128, wt, n_img, 2, kFcDims, kFcActs, src, dzo, wo, st, mode);
 }
 
+/* Weight-dependent preparation of the fused encoder backward (transposed FC weights, conv W^T fragments):
+ * depends only on the parameters, so a caller can run it early, off the dependent chain, and pass
+ * prepacked = 1 to the calls below. */
+extern "C" int tacorl_encoder_bwd_fused_pack(int nprob, const float* const* params, const int* n_img, int H, int W,
+                                             void* ws, size_t ws_bytes, tacorl_stream_t stream) {
+  EncBwdPlan pl;
+  if (!enc_bwd_plan(nprob, n_img, H, W, pl)) FAIL(TACORL_EINVAL, "encoder_bwd_fused_pack: geometry %dx%d / nprob %d", H, W, nprob);
+  if (ws_bytes < pl.total) FAIL(TACORL_ENOMEM, "encoder_bwd_fused_pack: workspace too small");
+  EbwProblem pr[EBW_MAXP];
+  enc_bwd_conv_problems(nprob, nullptr, params, nullptr, nullptr, n_img, pl, ws, pr);
+  int rc = enc_bwd_fc_chain(nprob, params, nullptr, nullptr, n_img, pl, ws, (hipStream_t)stream, 1);
+  if (rc == TACORL_OK) rc = ebw_conv_backward(nprob, pr, H, W, 0, (unsigned char*)ws + pl.conv_off, pl.total - pl.conv_off, (hipStream_t)stream, 1);
+  if (rc != TACORL_OK) FAIL(rc, "encoder_bwd_fused_pack: launch failed (%d)", rc);
+  return TACORL_OK;
+}
+/* part 1 (dependent chain): d_out -> d(soft-argmax features) through the FC tail, one launch. */
+extern "C" int tacorl_encoder_bwd_fused_head(int nprob, const float* const* params, const float* const* act,
+                                             const float* const* d_out, const int* n_img, int H, int W, int prepacked,
+                                             void* ws, size_t ws_bytes, tacorl_stream_t stream) {
+  EncBwdPlan pl;
+  if (!enc_bwd_plan(nprob, n_img, H, W, pl)) FAIL(TACORL_EINVAL, "encoder_bwd_fused_head: geometry %dx%d / nprob %d", H, W, nprob);
+  if (ws_bytes < pl.total) FAIL(TACORL_ENOMEM, "encoder_bwd_fused_head: workspace too small");
+  const int rc = enc_bwd_fc_chain(nprob, params, act, d_out, n_img, pl, ws, (hipStream_t)stream, prepacked ? 2 : 0);
+  if (rc != TACORL_OK) FAIL(rc, "encoder_bwd_fused_head: launch failed (%d)", rc);
+  return TACORL_OK;
+}
+/* FC weight / bias gradients (needs part 1's d_h1; not on the dependent chain - any stream after part 1). */
+extern "C" int tacorl_encoder_bwd_fused_fc_wgrad(int nprob, const float* const* act, const float* const* d_out,
+                                                 float* const* grads, const int* n_img, int H, int W, int accumulate,
+                                                 void* ws, size_t ws_bytes, tacorl_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  EncBwdPlan pl;
+  if (!enc_bwd_plan(nprob, n_img, H, W, pl)) FAIL(TACORL_EINVAL, "encoder_bwd_fused_fc_wgrad: geometry %dx%d / nprob %d", H, W, nprob);
+  if (ws_bytes < pl.total) FAIL(TACORL_ENOMEM, "encoder_bwd_fused_fc_wgrad: workspace too small");
+  const float *sa[EBW_MAXP], *h1[EBW_MAXP], *d_h1[EBW_MAXP];
+  float *g_fw1[EBW_MAXP], *g_fb1[EBW_MAXP], *g_fw2[EBW_MAXP], *g_fb2[EBW_MAXP];
+  for (int p = 0; p < nprob; p++) {
+    sa[p] = act[p] + pl.ao[p][3]; h1[p] = act[p] + pl.ao[p][4];
+    d_h1[p] = (const float*)ws + pl.sbase[p] + pl.so[p][0];
+    float* G = grads[p];
+    g_fw1[p] = G + pl.po[E_FW1]; g_fb1[p] = G + pl.po[E_FB1]; g_fw2[p] = G + pl.po[E_FW2]; g_fb2[p] = G + pl.po[E_FB2];
+  }
+  void* slab = (unsigned char*)ws + pl.slab_off;
+  CHECK(k_linear_wgrad(nprob, h1, 256, d_out, 32, n_img, 256, 32, g_fw2, g_fb2, accumulate, slab, pl.slab_bytes, TACORL_BF16, st));
+  CHECK(k_linear_wgrad(nprob, sa, 128, d_h1, 256, n_img, 128, 256, g_fw1, g_fb1, accumulate, slab, pl.slab_bytes, TACORL_BF16, st));
+  return TACORL_OK;
+}
+/* part 2 (dependent chain): soft-argmax backward (+ temperature gradient) and the three convolutions. */
+extern "C" int tacorl_encoder_bwd_fused_conv(int nprob, const void* const* img, const float* const* params,
+                                             const float* const* act, float* const* grads, const int* n_img, int H, int W,
+                                             int accumulate, int prepacked, void* ws, size_t ws_bytes,
+                                             tacorl_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  EncBwdPlan pl;
+  if (!enc_bwd_plan(nprob, n_img, H, W, pl)) FAIL(TACORL_EINVAL, "encoder_bwd_fused_conv: geometry %dx%d / nprob %d", H, W, nprob);
+  if (ws_bytes < pl.total) FAIL(TACORL_ENOMEM, "encoder_bwd_fused_conv: workspace too small");
+  if (pl.d.c3.OH * pl.d.c3.OW > 4 * SAB_MAXI) FAIL(TACORL_EINVAL, "encoder_bwd_fused: conv3 output too large");
+  EbwProblem pr[EBW_MAXP];
+  enc_bwd_conv_problems(nprob, img, params, act, grads, n_img, pl, ws, pr);
+  SabArgs sb{};
+  for (int p = 0; p < nprob; p++) {
+    float* sc = (float*)ws + pl.sbase[p];
+    sb.y3[p] = act[p] + pl.ao[p][2]; sb.temp[p] = params[p] + pl.po[E_T]; sb.sa[p] = act[p] + pl.ao[p][3];
+    sb.d_sa[p] = sc + pl.so[p][1]; sb.dz3[p] = sc + pl.so[p][2]; sb.dtp[p] = sc + pl.so[p][5];
+    sb.gtemp[p] = grads[p] + pl.po[E_T]; sb.n[p] = n_img[p];
+  }
+  if (pl.maxn > 0) {
+    hipLaunchKernelGGL(softargmax_bwd_batch_kernel, dim3((unsigned)pl.maxn, nprob), dim3(256), 0, st, sb, pl.d.c3.OH * pl.d.c3.OW, pl.d.c3.OW);
+    hipLaunchKernelGGL(sum_to_scalar_batch_kernel, dim3(nprob), dim3(256), 0, st, sb, accumulate);
+  }
+  const int rc = ebw_conv_backward(nprob, pr, H, W, accumulate, (unsigned char*)ws + pl.conv_off, pl.total - pl.conv_off, st, prepacked ? 2 : 0);
+  if (rc != TACORL_OK) FAIL(rc, "encoder_bwd_fused_conv: conv backward launch failed (%d)", rc);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+/* everything on one stream: head, FC weight gradients, conv */
 extern "C" int tacorl_encoder_bwd_fused(int nprob, const void* const* img, const float* const* params,
                                         const float* const* act, const float* const* d_out, float* const* grads,
                                         const int* n_img, int H, int W, int accumulate, void* ws, size_t ws_bytes,
                                         tacorl_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
-  EncDims d;
-  if (!enc_dims(H, W, d) || !ebw_supported(H, W)) FAIL(TACORL_EINVAL, "encoder_bwd_fused: geometry %dx%d not instantiated", H, W);
-  if (nprob < 1 || nprob > EBW_MAXP) FAIL(TACORL_EINVAL, "encoder_bwd_fused: nprob %d (max %d)", nprob, EBW_MAXP);
-  if (ws_bytes < tacorl_encoder_bwd_fused_ws_bytes(nprob, n_img, H, W)) FAIL(TACORL_ENOMEM, "encoder_bwd_fused: workspace too small");
-  const int cd = TACORL_BF16;
-  long po[E_N];
-  tacorl_encoder_param_layout(po);
-  const float *fw1[GEMM_MAXP], *fw2[GEMM_MAXP], *y3[GEMM_MAXP], *sa[GEMM_MAXP], *h1[GEMM_MAXP];
-  float *d_h1[GEMM_MAXP], *d_sa[GEMM_MAXP], *dz3[GEMM_MAXP], *dtp[GEMM_MAXP];
-  float *g_fw1[GEMM_MAXP], *g_fb1[GEMM_MAXP], *g_fw2[GEMM_MAXP], *g_fb2[GEMM_MAXP];
-  EbwProblem pr[EBW_MAXP];
-  float* cur = (float*)ws;
-  long maxn = 0, tot_f = 0;
-  for (int p = 0; p < nprob; p++) {
-    long ao[5], so[6];
-    tacorl_encoder_act_layout(n_img[p], H, W, ao);
-    const long tot = enc_bwd_scratch_layout(n_img[p], d, so);
-    const float* P = params[p];
-    float* G = grads[p];
-    fw1[p] = P + po[E_FW1]; fw2[p] = P + po[E_FW2];
-    y3[p] = act[p] + ao[2]; sa[p] = act[p] + ao[3]; h1[p] = act[p] + ao[4];
-    d_h1[p] = cur + so[0]; d_sa[p] = cur + so[1]; dz3[p] = cur + so[2]; dtp[p] = cur + so[5];
-    cur += tot; tot_f += tot;
-    g_fw1[p] = G + po[E_FW1]; g_fb1[p] = G + po[E_FB1]; g_fw2[p] = G + po[E_FW2]; g_fb2[p] = G + po[E_FB2];
-    pr[p].img = img[p]; pr[p].y1 = act[p] + ao[0]; pr[p].y2 = act[p] + ao[1]; pr[p].dz3 = dz3[p];
-    pr[p].w2 = P + po[E_W2]; pr[p].w3 = P + po[E_W3];
-    pr[p].g_w1 = G + po[E_W1]; pr[p].g_b1 = G + po[E_B1]; pr[p].g_w2 = G + po[E_W2]; pr[p].g_b2 = G + po[E_B2];
-    pr[p].g_w3 = G + po[E_W3]; pr[p].g_b3 = G + po[E_B3]; pr[p].n = n_img[p];
-    maxn = n_img[p] > maxn ? n_img[p] : maxn;
-  }
-  unsigned char* slab = (unsigned char*)ws + (((size_t)tot_f * sizeof(float) + 255) & ~(size_t)255);
-  const size_t slab_bytes = enc_fc_slab_bytes(nprob, maxn);
-  unsigned char* cws = slab + slab_bytes;
-  const size_t cws_bytes = ws_bytes - (size_t)(cws - (unsigned char*)ws);
-  CHECK(k_linear_wgrad(nprob, h1, 256, d_out, 32, n_img, 256, 32, g_fw2, g_fb2, accumulate, slab, slab_bytes, cd, st));
-  CHECK(k_linear_dgrad(nprob, d_out, 32, fw2, d_h1, 256, h1, ACT_RELU, n_img, 32, 256, cd, st));
-  CHECK(k_linear_wgrad(nprob, sa, 128, (const float* const*)d_h1, 256, n_img, 128, 256, g_fw1, g_fb1, accumulate, slab, slab_bytes, cd, st));
-  CHECK(k_linear_dgrad(nprob, (const float* const*)d_h1, 256, fw1, d_sa, 128, nullptr, ACT_NONE, n_img, 256, 128, cd, st));
-  if (d.c3.OH * d.c3.OW > 4 * SAB_MAXI) FAIL(TACORL_EINVAL, "encoder_bwd_fused: conv3 output too large");
-  SabArgs sb{};
-  for (int p = 0; p < nprob; p++) {
-    sb.y3[p] = y3[p]; sb.temp[p] = params[p] + po[E_T]; sb.sa[p] = sa[p]; sb.d_sa[p] = d_sa[p]; sb.dz3[p] = dz3[p];
-    sb.dtp[p] = dtp[p]; sb.gtemp[p] = grads[p] + po[E_T]; sb.n[p] = n_img[p];
-  }
-  if (maxn > 0) {
-    hipLaunchKernelGGL(softargmax_bwd_batch_kernel, dim3((unsigned)maxn, nprob), dim3(256), 0, st, sb, d.c3.OH * d.c3.OW, d.c3.OW);
-    hipLaunchKernelGGL(sum_to_scalar_batch_kernel, dim3(nprob), dim3(256), 0, st, sb, accumulate);
-  }
-  const int rc = ebw_conv_backward(nprob, pr, H, W, accumulate, cws, cws_bytes, st);
-  if (rc != TACORL_OK) FAIL(rc, "encoder_bwd_fused: conv backward launch failed (%d)", rc);
-  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+  int rc = tacorl_encoder_bwd_fused_head(nprob, params, act, d_out, n_img, H, W, 0, ws, ws_bytes, stream);
+  if (rc == TACORL_OK) rc = tacorl_encoder_bwd_fused_fc_wgrad(nprob, act, d_out, grads, n_img, H, W, accumulate, ws, ws_bytes, stream);
+  if (rc == TACORL_OK) rc = tacorl_encoder_bwd_fused_conv(nprob, img, params, act, grads, n_img, H, W, accumulate, 0, ws, ws_bytes, stream);
+  return rc;
 }
 
 // ====================================================================== MLP
@@ -822,8 +915,8 @@ extern "C" size_t tacorl_mlp_bwd_fused_ws_bytes(int nprob, const int* M, int L, 
 }
 extern "C" int tacorl_mlp_bwd_fused_dgrad(int nprob, const float* const* params, const float* const* act,
                                           const float* const* d_out, int ldo, float* const* d_x, int ldd, const int* M,
-                                          int L, const int* dims, const int* acts, void* ws, size_t ws_bytes,
-                                          tacorl_stream_t stream) {
+                                          int L, const int* dims, const int* acts, int prepacked, void* ws,
+                                          size_t ws_bytes, tacorl_stream_t stream) {
   if (!mlp_fused_bwd_ok(nprob, L, dims, ldo, ldd)) FAIL(TACORL_EINVAL, "mlp_bwd_fused: shapes not supported");
   if (acts[L - 1] != ACT_NONE) FAIL(TACORL_EINVAL, "mlp_bwd_fused: last activation must be NONE");
   const MlpBwdWs w = mlp_bwd_fused_plan(nprob, M, L, dims);
@@ -840,8 +933,26 @@ extern "C" int tacorl_mlp_bwd_fused_dgrad(int nprob, const float* const* params,
     wt[p] = (unsigned char*)ws + w.wt_off[p];
   }
   const int rc = mlp_fused_bwd(nprob, params, act, d_out, ldo, dz, d_x, ldd, wt, M, L, dims, acts, src, w.dzoff, wo,
-                               (hipStream_t)stream);
+                               (hipStream_t)stream, prepacked ? 2 : 0);
   if (rc != TACORL_OK) FAIL(rc, "mlp_bwd_fused: launch failed (%d)", rc);
+  return TACORL_OK;
+}
+/* The weight transposes _dgrad needs, alone: they depend only on the parameters, so a caller can run them
+ * early / on another stream and pass prepacked = 1. */
+extern "C" int tacorl_mlp_bwd_fused_pack(int nprob, const float* const* params, const int* M, int L, const int* dims,
+                                         void* ws, size_t ws_bytes, tacorl_stream_t stream) {
+  if (nprob < 1 || nprob > MF_MAXP || L < 1 || L > MF_MAXL) FAIL(TACORL_EINVAL, "mlp_bwd_fused_pack: bad L/nprob");
+  const MlpBwdWs w = mlp_bwd_fused_plan(nprob, M, L, dims);
+  if (ws_bytes < w.total) FAIL(TACORL_ENOMEM, "mlp_bwd_fused_pack: workspace too small");
+  long wo[MLP_MAXL], bo[MLP_MAXL], zero[MF_MAXP * MF_MAXL] = {0};
+  int acts[MLP_MAXL] = {0};
+  tacorl_mlp_param_layout(L, dims, wo, bo);
+  float* dz[MF_MAXP];
+  void* wt[MF_MAXP];
+  for (int p = 0; p < nprob; p++) { dz[p] = (float*)ws; wt[p] = (unsigned char*)ws + w.wt_off[p]; }
+  const int rc = mlp_fused_bwd(nprob, params, nullptr, nullptr, 0, dz, nullptr, 0, wt, M, L, dims, acts, zero, zero, wo,
+                               (hipStream_t)stream, 1);
+  if (rc != TACORL_OK) FAIL(rc, "mlp_bwd_fused_pack: launch failed (%d)", rc);
   return TACORL_OK;
 }
 extern "C" int tacorl_mlp_bwd_fused_wgrad(int nprob, const float* const* x, int ldx, const float* const* act,

@@ -20,5 +20,7 @@ struct EbwProblem {
 bool ebw_supported(int H, int W);
 size_t ebw_ws_bytes(int nprob, const int* n_img, int H, int W);
 // dW1,db1,dW2,db2,dW3,db3 (+)= conv backward of every problem; deterministic (fixed reduction order).
+// mode: 0 = pack the W^T fragments, then run; 1 = pack only (needs pr[].w2 / w3 / n only); 2 = run with the
+// fragments already packed in ws for this step's weights.
 int ebw_conv_backward(int nprob, const EbwProblem* pr, int H, int W, int accumulate, void* ws, size_t ws_bytes,
-                      hipStream_t st);
+                      hipStream_t st, int mode);

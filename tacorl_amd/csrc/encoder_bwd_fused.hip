@@ -620,7 +620,7 @@ int launch_dgrad(const DgArgs& a, int nwg, hipStream_t st) {
   return TACORL_OK;
 }
 template <class G>
-int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int mode) {
   using L1 = typename G::L1; using L2 = typename G::L2; using L3 = typename G::L3;
   int n[EBW_MAXP];
   for (int p = 0; p < nprob; p++) n[p] = pr[p].n;
@@ -634,8 +634,11 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
     k2.w[p] = pr[p].w2; k2.out[p] = (uint4*)(base + w.wpk2[p]);
     k3.w[p] = pr[p].w3; k3.out[p] = (uint4*)(base + w.wpk3[p]);
   }
-  hipLaunchKernelGGL(ebw_pack_kernel<L2>, dim3(cdivi(L2::NCOMBO * L2::KS * 64, 256), nprob), dim3(256), 0, st, k2);
-  hipLaunchKernelGGL(ebw_pack_kernel<L3>, dim3(cdivi(L3::NCOMBO * L3::KS * 64, 256), nprob), dim3(256), 0, st, k3);
+  if (mode != 2) {
+    hipLaunchKernelGGL(ebw_pack_kernel<L2>, dim3(cdivi(L2::NCOMBO * L2::KS * 64, 256), nprob), dim3(256), 0, st, k2);
+    hipLaunchKernelGGL(ebw_pack_kernel<L3>, dim3(cdivi(L3::NCOMBO * L3::KS * 64, 256), nprob), dim3(256), 0, st, k3);
+  }
+  if (mode == 1) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
   DgArgs d3{}, d2{};
   WgArgs g3{}, g2{}, g1{};
   float *gw1[EBW_MAXP], *gb1[EBW_MAXP], *gw2[EBW_MAXP], *gb2[EBW_MAXP], *gw3[EBW_MAXP], *gb3[EBW_MAXP];
@@ -696,9 +699,9 @@ size_t ebw_ws_bytes(int nprob, const int* n_img, int H, int W) {
   return 0;
 }
 int ebw_conv_backward(int nprob, const EbwProblem* pr, int H, int W, int accumulate, void* ws, size_t ws_bytes,
-                      hipStream_t st) {
+                      hipStream_t st, int mode) {
   if (nprob < 1 || nprob > EBW_MAXP) return TACORL_EINVAL;
-#define X(h, w) if (H == h && W == w) return run<Geo<h, w>>(nprob, pr, accumulate, ws, ws_bytes, st);
+#define X(h, w) if (H == h && W == w) return run<Geo<h, w>>(nprob, pr, accumulate, ws, ws_bytes, st, mode);
   EBW_GEOMS(X)
 #undef X
   return TACORL_EINVAL;

@@ -24,4 +24,6 @@ bool mlp_fused_bwd_ok(int nprob, int L, const int* dims, int ldo, int ldd);
 size_t mlp_fused_wt_elems(int L, const int* dims, long* wtoff);
 int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act, const float* const* d_out, int ldo,
                   float* const* dz, float* const* d_x, int ldd, void* const* wt, const int* M, int L, const int* dims,
-                  const int* acts, const long* srcoff, const long* dzoff, const long* woff, hipStream_t st);
+                  const int* acts, const long* srcoff, const long* dzoff, const long* woff, hipStream_t st, int mode);
+// mode: 0 = transpose the weights, then run the chain; 1 = transpose only (d_out / act / dz unused);
+//       2 = chain only (wt already holds this step's transposed weights)

@@ -325,7 +325,7 @@ size_t mlp_fused_wt_elems(int L, const int* dims, long* wtoff) {
 }
 int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act, const float* const* d_out, int ldo,
                   float* const* dz, float* const* d_x, int ldd, void* const* wt, const int* M, int L, const int* dims,
-                  const int* acts, const long* srcoff, const long* dzoff, const long* woff, hipStream_t st) {
+                  const int* acts, const long* srcoff, const long* dzoff, const long* woff, hipStream_t st, int mode) {
   MlpBwdArgs a{};
   WtPackArgs k{};
   long wtoff[MF_MAXL];
@@ -333,7 +333,7 @@ int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act
   int maxM = 0;
   for (int p = 0; p < nprob; p++) {
     if ((uintptr_t)wt[p] & 15) return TACORL_EINVAL;
-    a.d_out[p] = d_out[p]; a.act[p] = act[p]; a.wt[p] = (const __bf16*)wt[p]; a.dz[p] = dz[p];
+    a.d_out[p] = d_out ? d_out[p] : nullptr; a.act[p] = act ? act[p] : nullptr; a.wt[p] = (const __bf16*)wt[p]; a.dz[p] = dz[p];
     a.d_x[p] = d_x ? d_x[p] : nullptr; a.M[p] = M[p];
     k.params[p] = params[p]; k.wt[p] = (__bf16*)wt[p];
     for (int l = 0; l < L; l++) { a.srcoff[p][l] = srcoff[p * MF_MAXL + l]; a.dzoff[p][l] = dzoff[p * MF_MAXL + l]; }
@@ -343,7 +343,8 @@ int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act
   for (int l = 0; l <= L; l++) { a.dims[l] = dims[l]; k.dims[l] = dims[l]; }
   a.L = L; k.L = L; a.ldo = ldo; a.ldd = ldd;
   if (maxM == 0) return TACORL_OK;
-  hipLaunchKernelGGL(mlp_pack_wt_kernel, dim3(64, L, nprob), dim3(256), 0, st, k);
+  if (mode != 2) hipLaunchKernelGGL(mlp_pack_wt_kernel, dim3(64, L, nprob), dim3(256), 0, st, k);
+  if (mode == 1) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
   constexpr size_t lds = (size_t)2 * BMF * XP * 2;
   static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_bwd_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;

@@ -313,6 +313,40 @@ class ACEngine:
              ops.ptr_array([n_.genc_bf16() for n_ in nets]), (ops.C.c_long * len(nets))(*[n_.size - n_.genc_off for n_ in nets]),
              ops.stream())
 
+    def _mlp_bwd_sites(self):
+        """(tag, params, M, dims) of every fused-MLP backward of the update, as _mlp_backward receives them."""
+        B = self.B
+        qd, pd, gd = self.q1.head_dims, self.actor.head_dims, self.actor.genc_dims
+        return [("q", [self.q1.head(), self.q2.head()], [self.R, self.R], qd),
+                ("qpi", [self.q1.head(), self.q2.head()], [B, B], qd),
+                ("pi", [self.actor.head()], [B], pd),
+                ("genc", [self.actor.genc(), self.q1.genc(), self.q2.genc()], [B] * 3, gd)]
+
+    def _prepack_backward(self):
+        """Weight-only preparation of the backward kernels (transposed MLP weights, conv W^T fragments) on a
+        side stream while the forward runs: six small launches that would otherwise sit on the dependent
+        chain of the backward."""
+        self._prepacked = False
+        if self.compute != BF16:
+            return
+        if getattr(self, "_pack_stream", None) is None:
+            self._pack_stream = torch.cuda.Stream(device=self.dev)
+        ps = self._pack_stream
+        ps.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ps):
+            for tag, params, M, dims in self._mlp_bwd_sites():
+                ops.mlp_bwd_fused_pack(params, M, dims, "mlp_bwdf_" + tag, self.dev)
+            nets = [self.actor, self.q1, self.q2]
+            for c in self.cams:
+                if self._fused_ok(c):
+                    H, W = self.hw[c]
+                    n3 = ops.int_array([2 * self.B] * 3)
+                    nb = ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(3, n3, H, W)
+                    ws = ops.workspace(nb, self.dev, "enc_bwd_fused_" + c)
+                    call("tacorl_encoder_bwd_fused_pack", 3, ops.ptr_array([x.enc(c) for x in nets]), n3, H, W, ptr(ws),
+                         ws.numel(), ops.stream())
+        self._prepacked = True
+
     def _assemble_states(self):
         B = self.B
         # goal-encoder inputs: concat over cams of enc(goal)
@@ -371,6 +405,7 @@ class ACEngine:
         if not encoded:
             self._encode_all()
         self._refresh_bf16()
+        self._prepack_backward()
         self._assemble_states()
         self._policy_fwd()
         head_cur, head_next = self._head("a"), self._head("a_nx")
@@ -390,6 +425,8 @@ class ACEngine:
         # alpha: loss, gradient, Adam step (alpha is read post-step below; SURVEY 8a note 2)
         call("tacorl_alpha_loss", ptr(self.logp_pi), B, ptr(self.log_alpha.param), float(hp["target_entropy"]), gs,
              ptr(self.log_alpha.grad), ptr(self.logs), ops.stream())
+        if getattr(self, "_prepacked", False):  # the side branch ends inside this phase
+            torch.cuda.current_stream().wait_stream(self._pack_stream)
 
     def phase_b(self, bc_phase, optimize=True):
         B, n, A, Ac, hp, nz = self.B, self.n, self.A, self.Ac, self.hp, self.noise
@@ -464,7 +501,8 @@ class ACEngine:
             ops.mlp_bwd(xs, ldx, params, acts_buf, d_outs, ldo, grads, d_xs, ldd, M, dims, acts, self.compute,
                         ws_tag="mlp_bwd_" + tag)
             return
-        ops.mlp_bwd_fused_dgrad(params, acts_buf, d_outs, ldo, d_xs, ldd, M, dims, acts, "mlp_bwdf_" + tag)
+        ops.mlp_bwd_fused_dgrad(params, acts_buf, d_outs, ldo, d_xs, ldd, M, dims, acts, "mlp_bwdf_" + tag,
+                                prepacked=getattr(self, "_prepacked", False))
         if all(g is None for g in grads):
             return
         if not self.wgrad_side_streams:
@@ -531,8 +569,17 @@ class ACEngine:
                   ops.ptr_array([nets[k].enc(c, nets[k].grad) for k in ks]), ops.int_array(ops_n), H, W]
             if self._fused_ok(c):  # per-image LDS-resident conv backward (encoder_bwd_fused.hip)
                 nb = ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(3, ops.int_array(ops_n), H, W)
-                ws = ops.workspace(nb, self.dev, "enc_bwd_fused")
-                call("tacorl_encoder_bwd_fused", 3, *pa, 0, ptr(ws), ws.numel(), ops.stream())
+                ws = ops.workspace(nb, self.dev, "enc_bwd_fused_" + c)
+                pk = int(getattr(self, "_prepacked", False))
+                img_p, par_p, act_p, dout_p, grad_p, n_p = pa[:6]
+                # dependent chain: FC-tail input gradients (one launch) -> soft-argmax + conv backward
+                call("tacorl_encoder_bwd_fused_head", 3, par_p, act_p, dout_p, n_p, H, W, pk, ptr(ws), ws.numel(), ops.stream())
+                call("tacorl_encoder_bwd_fused_conv", 3, img_p, par_p, act_p, grad_p, n_p, H, W, 0, pk, ptr(ws), ws.numel(),
+                     ops.stream())
+                # FC weight gradients last and in line: on a side branch they ran beside the conv-backward
+                # kernels, whose 255 one-per-CU workgroups then no longer fit in one round (+0.13 ms/step)
+                call("tacorl_encoder_bwd_fused_fc_wgrad", 3, act_p, dout_p, grad_p, n_p, H, W, 0, ptr(ws), ws.numel(),
+                     ops.stream())
                 continue
             nb = ops.L.lib().tacorl_encoder_bwd_ws_bytes(3, ops.int_array(ops_n), H, W)
             ws = ops.workspace(nb, self.dev, "enc_bwd")
