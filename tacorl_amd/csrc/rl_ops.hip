@@ -544,23 +544,36 @@ __global__ __launch_bounds__(256) void cql_loss_kernel(CqlArgs a) {
     float qn = fminf(a.tq[0][b], a.tq[1][b]);
     if (!a.deterministic_backup) qn -= alpha * a.next_logp[b];
     const float y = a.reward_scale * a.reward[b] + (1.f - a.done[b]) * a.discount * qn;
-    // which logit this lane owns: j = lane -> group g = j / n, sample k = j % n
-    const int g = lane / n, k = lane - g * n;
-    const bool on = lane < nc;
-    const long row = (long)B + ((long)g * n + k) * B + b;
-    float sub = 0.f;
-    if (on) sub = g == 0 ? rand_density : (g == 1 ? a.logp_cur[(long)k * B + b] : a.logp_nxt[(long)k * B + b]);
+    // which logits this lane owns: j = lane + 64 s (s < 2) -> group g = j / n, sample k = j % n
+    // (3n <= 128: n = 4 in the TACORL configs, n = 32 in the CQL baseline)
+    int gq[2]; bool on[2]; long row[2]; float sub[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int j = lane + 64 * s, g = j / n, k = j - g * n;
+      gq[s] = g; on[s] = j < nc;
+      row[s] = (long)B + ((long)g * n + k) * B + b;
+      sub[s] = 0.f;
+      if (on[s]) sub[s] = g == 0 ? rand_density : (g == 1 ? a.logp_cur[(long)k * B + b] : a.logp_nxt[(long)k * B + b]);
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const float qd = a.q[i][b];
-      const float qv = on ? a.q[i][row] : 0.f;
-      const float lg = on ? (qv - sub) / a.temp : -INFINITY;
-      const float mx = wave_max(lg);
-      const float e = on ? expf(lg - mx) : 0.f;
-      const float se = wave_sum(e);
+      float qv[2], lg[2], e[2];
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        qv[s] = on[s] ? a.q[i][row[s]] : 0.f;
+        lg[s] = on[s] ? (qv[s] - sub[s]) / a.temp : -INFINITY;
+      }
+      const float mx = wave_max(fmaxf(lg[0], lg[1]));
+#pragma unroll
+      for (int s = 0; s < 2; s++) e[s] = on[s] ? expf(lg[s] - mx) : 0.f;
+      const float se = wave_sum(e[0] + e[1]);
       const float lse = mx + logf(se);
-      if (on) a.dq[i][row] = a.grad_scale * alpha_p * a.cons_w * (e / se) / (float)B;
-      const float sr = wave_sum(on && g == 0 ? qv : 0.f), sp = wave_sum(on && g == 1 ? qv : 0.f);
+#pragma unroll
+      for (int s = 0; s < 2; s++)
+        if (on[s]) a.dq[i][row[s]] = a.grad_scale * alpha_p * a.cons_w * (e[s] / se) / (float)B;
+      const float sr = wave_sum((on[0] && gq[0] == 0 ? qv[0] : 0.f) + (on[1] && gq[1] == 0 ? qv[1] : 0.f));
+      const float sp = wave_sum((on[0] && gq[0] == 1 ? qv[0] : 0.f) + (on[1] && gq[1] == 1 ? qv[1] : 0.f));
       if (lane == 0) {
         const float d = qd - y;
         a.dq[i][b] = a.grad_scale * (2.f * d - a.cons_w * alpha_p) / (float)B;
@@ -618,7 +631,7 @@ extern "C" int tacorl_cql_loss(const float* q1, const float* q2, float* dq1, flo
                                float discount, float reward_scale, float temp, float cons_w, float gap,
                                int deterministic_backup, float grad_scale, float* g_log_alpha_prime, float* logs,
                                void* ws, size_t ws_bytes, tacorl_stream_t stream) {
-  if (3 * n > 64 || n < 1) return TACORL_EINVAL;
+  if (3 * n > 128 || n < 1) return TACORL_EINVAL;
   if (ws_bytes < tacorl_cql_ws_bytes(B)) return TACORL_ENOMEM;
   CqlArgs a{};
   a.q[0] = q1; a.q[1] = q2; a.dq[0] = dq1; a.dq[1] = dq2; a.tq[0] = tq1; a.tq[1] = tq2;

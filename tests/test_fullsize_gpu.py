@@ -163,3 +163,31 @@ def test_fullsize_fused_encoder_equals_per_layer():
             if cos < 0.995:
                 bad.append(f"grad {k}: cosine {cos:.4f}")
     assert not bad, "\n".join(bad[:20])
+
+
+def test_fullsize_cql_baseline_c5():
+    """BASELINE configs C5: CQL_Offline, discrete gripper, A=7, n=32 action samples, B=1024, 84x84, bf16 -
+    runs (hipGraph), losses finite, second step changes the parameters."""
+    from tacorl_amd import synth
+    from tacorl_amd.modules.cql.cql_offline_lightning import CQL_Offline
+
+    dev = torch.device("cuda:0")
+    Bc = 1024
+    mod = CQL_Offline(actor={"policy": {"num_layers": 3, "hidden_dim": 256}, "discrete_gripper": True},
+                      critic={"q_network": {"num_layers": 3, "hidden_dim": 256, "last_layer_activation": "Identity"}},
+                      real_world=True, obs_modalities=["rgb_static"], goal_modalities=["rgb_static"], action_dim=7, device="cuda:0",
+                      compute_dtype="bf16", image_dtype="bf16", discount=0.99, actor_lr=1e-4, critic_lr=3e-4,
+                      conservative_weight=1.0, n_action_samples=32, with_lagrange=True, reward_scale=10.0,
+                      deterministic_backup=False, bc_epochs=5)
+    mod.current_epoch = 5
+    batch = synth.make_transition_batch(7, Bc, {"rgb_static": (84, 84)})
+    batch = {k: ({kk: ({c: t.to(dev) for c, t in vv.items()}) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev))
+             for k, v in batch.items()}
+    mod.enable_graph()
+    before = mod.engine.q1.param.clone()
+    for _ in range(3):
+        mod.training_step(batch, 0)
+    torch.cuda.synchronize()
+    logs = mod.engine.metrics()
+    assert all(v == v and abs(v) < 1e30 for v in logs.values()), logs
+    assert not torch.equal(before, mod.engine.q1.param)

@@ -252,11 +252,12 @@ def test_adam_clip_polyak():
 
 
 @pytest.mark.parametrize("det_backup,lagrange", [(True, True), (False, True), (False, False)])
-def test_cql_loss(det_backup, lagrange):
+@pytest.mark.parametrize("n", [4, 32])
+def test_cql_loss(det_backup, lagrange, n):
     from tacorl_amd import _lib, ops
 
     dev = _dev()
-    B, n, A = 37, 4, 16
+    B, A = 37, 16
     R = (3 * n + 1) * B
     g = torch.Generator().manual_seed(7)
     q = [torch.randn(R, generator=g).requires_grad_(True) for _ in range(2)]
