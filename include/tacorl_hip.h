@@ -54,6 +54,13 @@ int tacorl_rnn_linear_supported(int M, int K, int N);
 int tacorl_rnn_linear_fwd(const void* x_bf16, const void* w_bf16, const float* bias, const float* addend,
                           int ld_add, float* y, void* y_bf16, int M, int K, int N, int act,
                           tacorl_stream_t stream);
+/* BPTT step of the same RNN: y = (x Wt^T + addend) * [mask_src > 0], x = dZ_t (bf16), Wt = W_hh^T (bf16,
+ * tacorl_transpose_to_bf16), addend = dH_{t-1}, mask_src = h_{t-1}; y fp32 + bf16 copy (next step's x). */
+int tacorl_rnn_linear_bwd_step(const void* x_bf16, const void* wt_bf16, const float* addend, int ld_add,
+                               const float* mask_src, float* y, void* y_bf16, int M, int K, int N,
+                               tacorl_stream_t stream);
+/* dst[c][r] = bf16(src[r][c]); R, C multiples of 32. */
+int tacorl_transpose_to_bf16(const float* src, void* dst, int R, int C, tacorl_stream_t stream);
 
 /* Backward primitives of y = act(x W^T + b):
  *   dgrad: out[m][i] = (sum_o dz[m][o] W[o][i] + addend[m][i]) * act'(src[m][i])

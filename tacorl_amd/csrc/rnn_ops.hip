@@ -26,6 +26,7 @@ struct RnnArgs {
   const __bf16* w;
   const float* bias;
   const float* addend;
+  const float* mask_src;  // optional [M][N]: result kept where mask_src > 0 (ReLU derivative in BPTT)
   float* y;
   __bf16* yb;
   int M, K, N, ld_add, act;
@@ -108,6 +109,11 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnArgs a) {
       if (a.addend) z += *reinterpret_cast<const f32x4*>(a.addend + (long)m * a.ld_add + n);
 #pragma unroll
       for (int r = 0; r < 4; r++) z[r] = act_apply(a.act, z[r]);
+      if (a.mask_src) {
+        const f32x4 ms = *reinterpret_cast<const f32x4*>(a.mask_src + (long)m * a.N + n);
+#pragma unroll
+        for (int r = 0; r < 4; r++) z[r] = ms[r] > 0.f ? z[r] : 0.f;
+      }
       *reinterpret_cast<f32x4*>(a.y + (long)m * a.N + n) = z;
       if (a.yb) *reinterpret_cast<bf16x4*>(a.yb + (long)m * a.N + n) = bf16x4{(__bf16)z[0], (__bf16)z[1], (__bf16)z[2], (__bf16)z[3]};
     }
@@ -137,9 +143,37 @@ extern "C" int tacorl_rnn_linear_fwd(const void* x_bf16, const void* w_bf16, con
   if (!tacorl_rnn_linear_supported(M, K, N) || (addend && ld_add % 4)) return TACORL_EINVAL;
   if (((uintptr_t)x_bf16 | (uintptr_t)w_bf16 | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)addend) & 15) return TACORL_EINVAL;
   if ((uintptr_t)y_bf16 & 7) return TACORL_EINVAL;
-  RnnArgs a{(const __bf16*)x_bf16, (const __bf16*)w_bf16, bias, addend, y, (__bf16*)y_bf16, M, K, N, ld_add, act};
+  RnnArgs a{(const __bf16*)x_bf16, (const __bf16*)w_bf16, bias, addend, nullptr, y, (__bf16*)y_bf16, M, K, N, ld_add, act};
   // a recurrent step (M = batch) wants many small tiles to fill the chip; the sequence-wide input projection
   // (M = batch*T) wants the larger tile (fewer re-reads of W)
   if ((long)M * N >= 256L * 64 * 128 && N % 64 == 0) return launch_ring<128, 64, 3>(a, (hipStream_t)stream);
   return launch_ring<64, 32, 4>(a, (hipStream_t)stream);
+}
+
+/* BPTT step of the ReLU-RNN: y = (x Wt^T + addend) * [mask_src > 0]  with x = dZ_t (bf16 [M][K]), Wt = W_hh^T
+ * (bf16 [N][K], from tacorl_transpose_to_bf16), addend = dH_{t-1}, mask_src = h_{t-1}.  Same kernel. */
+extern "C" int tacorl_rnn_linear_bwd_step(const void* x_bf16, const void* wt_bf16, const float* addend, int ld_add,
+                                          const float* mask_src, float* y, void* y_bf16, int M, int K, int N,
+                                          tacorl_stream_t stream) {
+  if (!tacorl_rnn_linear_supported(M, K, N) || (addend && ld_add % 4)) return TACORL_EINVAL;
+  if (((uintptr_t)x_bf16 | (uintptr_t)wt_bf16 | (uintptr_t)y | (uintptr_t)addend | (uintptr_t)mask_src) & 15) return TACORL_EINVAL;
+  if ((uintptr_t)y_bf16 & 7) return TACORL_EINVAL;
+  RnnArgs a{(const __bf16*)x_bf16, (const __bf16*)wt_bf16, nullptr, addend, mask_src, y, (__bf16*)y_bf16, M, K, N, ld_add, ACT_NONE};
+  return launch_ring<64, 32, 4>(a, (hipStream_t)stream);
+}
+
+// dst[c][r] = bf16(src[r][c]): 32 x 32 tiles through LDS (R, C multiples of 32)
+__global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int R, int C) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; k++) tile[ty + 8 * k][tx] = src[(long)(r0 + ty + 8 * k) * C + c0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) dst[(long)(c0 + ty + 8 * k) * R + r0 + tx] = (__bf16)tile[tx][ty + 8 * k];
+}
+extern "C" int tacorl_transpose_to_bf16(const float* src, void* dst, int R, int C, tacorl_stream_t stream) {
+  if (R % 32 || C % 32 || R < 32 || C < 32) return TACORL_EINVAL;
+  hipLaunchKernelGGL(transpose_to_bf16_kernel, dim3(C / 32, R / 32), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, R, C);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }

@@ -186,14 +186,30 @@ class ActionDecoderLogistic:
         self._wgrad(self.h[L - 1], H, self.d_heads, self.NH, R, H, self.NH, blk.g("mean_fc.weight"),
                     blk.g("mean_fc.bias"), compute)
         self._dgrad(self.d_heads, self.NH, blk.p("mean_fc.weight"), self.dH, H, R, self.NH, H, compute)
+        fast = compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H)) and H % 32 == 0
+        if fast and getattr(self, "_bptt_shape", None) != (B, Tm):
+            bf = lambda *s: torch.zeros(*s, device=self.dev, dtype=torch.bfloat16)  # noqa: E731
+            self.DZb = [bf(R, H) for _ in range(L)]   # bf16 copies of dZ_t: the ring GEMM's operand
+            self.whtb = [bf(H, H) for _ in range(L)]  # W_hh^T
+            self._bptt_shape = (B, Tm)
         for l in reversed(range(L)):
             h, DZ = self.h[l], self.DZ[l]
             last = (Tm - 1) * B * H
             call("tacorl_relu_mask_mul", at(self.dH, last), None, at(h, last), at(DZ, last), B * H, ops.stream())
-            for t in range(Tm - 1, 0, -1):
-                self._dgrad(at(DZ, t * B * H), H, blk.p(f"rnn.weight_hh_l{l}"), at(DZ, (t - 1) * B * H), H, B, H, H,
-                            compute, src=at(h, (t - 1) * B * H), ld_src=H, act=ACT_RELU,
-                            addend=at(self.dH, (t - 1) * B * H), ld_add=H)
+            if fast and Tm > 1:
+                # BPTT steps as one launch each (LDS-DMA ring GEMM on W_hh^T) instead of a 64-workgroup GEMM
+                call("tacorl_transpose_to_bf16", blk.p(f"rnn.weight_hh_l{l}"), ptr(self.whtb[l]), H, H, ops.stream())
+                call("tacorl_to_bf16_batch", 1, ops.ptr_array([at(DZ, last)]),
+                     ops.ptr_array([C.c_void_p(self.DZb[l].data_ptr() + 2 * last)]), (C.c_long * 1)(B * H), ops.stream())
+                for t in range(Tm - 1, 0, -1):
+                    call("tacorl_rnn_linear_bwd_step", C.c_void_p(self.DZb[l].data_ptr() + 2 * t * B * H), ptr(self.whtb[l]),
+                         at(self.dH, (t - 1) * B * H), H, at(h, (t - 1) * B * H), at(DZ, (t - 1) * B * H),
+                         C.c_void_p(self.DZb[l].data_ptr() + 2 * (t - 1) * B * H), B, H, H, ops.stream())
+            else:
+                for t in range(Tm - 1, 0, -1):
+                    self._dgrad(at(DZ, t * B * H), H, blk.p(f"rnn.weight_hh_l{l}"), at(DZ, (t - 1) * B * H), H, B, H, H,
+                                compute, src=at(h, (t - 1) * B * H), ld_src=H, act=ACT_RELU,
+                                addend=at(self.dH, (t - 1) * B * H), ld_add=H)
             if Tm > 1:
                 self._wgrad(h, H, at(DZ, B * H), H, (Tm - 1) * B, H, H, blk.g(f"rnn.weight_hh_l{l}"), None, compute)
             else:

@@ -497,3 +497,26 @@ def test_rnn_linear_bf16(M, K, N, act):
     torch.cuda.synchronize()
     assert relerr(y, ref) < 1e-5, relerr(y, ref)
     assert torch.equal(yb, y.to(torch.bfloat16))
+
+
+def test_rnn_bptt_step_and_transpose():
+    """BPTT step through the ring GEMM: (x Wt^T + addend) * [mask > 0] with Wt from the transpose kernel."""
+    from tacorl_amd import ops
+
+    dev = _dev()
+    M, H = 256, 512
+    dz = rnd(M, H, seed=1).to(torch.bfloat16)
+    W = rnd(H, H, seed=2) / math.sqrt(H)
+    add, hprev = rnd(M, H, seed=3), rnd(M, H, seed=4)
+    ref = (dz.float() @ W.to(torch.bfloat16).float() + add) * (hprev > 0)
+    Wd, wt = W.to(dev), torch.zeros(H, H, device=dev, dtype=torch.bfloat16)
+    ops.call("tacorl_transpose_to_bf16", ops.ptr(Wd), ops.ptr(wt), H, H, ops.stream())
+    y = torch.full((M, H), float("nan"), device=dev)
+    yb = torch.zeros(M, H, device=dev, dtype=torch.bfloat16)
+    dzd, addd, hd = dz.to(dev), add.to(dev), hprev.to(dev)
+    ops.call("tacorl_rnn_linear_bwd_step", ops.ptr(dzd), ops.ptr(wt), ops.ptr(addd), H, ops.ptr(hd), ops.ptr(y), ops.ptr(yb),
+             M, H, H, ops.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(wt.cpu(), W.t().contiguous().to(torch.bfloat16))
+    assert relerr(y, ref) < 1e-5, relerr(y, ref)
+    assert torch.equal(yb, y.to(torch.bfloat16))
