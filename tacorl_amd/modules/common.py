@@ -48,3 +48,51 @@ class LoggerMixin:
         sink = getattr(self, "_log_sink", None)
         if sink is not None:
             sink(name, float(value), **kw)
+
+
+class GraphMixin:
+    """hipGraph replay of the device side of a step, shared by the three module classes.  The host
+    class provides `world_size` and (optionally) `_force_graph_split`."""
+
+    _use_graph = False
+
+    def enable_graph(self, on=True):
+        """Replay the device side of the step from a captured hipGraph (one graph on a single GPU; with
+        several ranks one graph per collective-free segment, the RCCL all-reduces stay eager between them)."""
+        self._use_graph = bool(on)
+        self._graphs = {}
+
+    def _run_segments(self, key, segs, collectives):
+        """Run the device side of a step: `segs` are collective-free kernel sequences over fixed buffers,
+        `collectives[i]` runs between segs[i] and segs[i+1] (RCCL all-reduces; no-ops on one GPU).
+        Eager, or - with enable_graph() - each segment replayed from a captured hipGraph (one graph for
+        the whole step on a single GPU; collectives always stay eager between graphs)."""
+        def eager():
+            for i, f in enumerate(segs):
+                f()
+                if i < len(collectives):
+                    collectives[i]()
+
+        if not self._use_graph:
+            return eager()
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        gs = self._graphs.get(key)
+        if gs is None:
+            eager()  # warm-up: sizes every workspace, so the capture allocates nothing
+            torch.cuda.synchronize()
+            split = getattr(self, "world_size", 1) > 1 or getattr(self, "_force_graph_split", False)
+            parts = [[f] for f in segs] if split else [segs]
+            gs = []
+            for part in parts:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for f in part:
+                        f()
+                gs.append(g)
+            self._graphs[key] = gs
+            return
+        for i, g in enumerate(gs):
+            g.replay()
+            if len(gs) > 1 and i < len(collectives):
+                collectives[i]()

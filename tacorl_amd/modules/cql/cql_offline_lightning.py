@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from ... import _lib
 from ...engine import ACEngine
-from ..common import LoggerMixin, compute_flag, register_views, to_plain
+from ..common import GraphMixin, LoggerMixin, compute_flag, register_views, to_plain
 
 
 class _OptimizerHandle:
@@ -28,7 +28,7 @@ class _OptimizerHandle:
         self.blk.m.copy_(sd["m"]); self.blk.v.copy_(sd["v"]); self.blk.step.copy_(sd["step"])
 
 
-class CQL_Offline(LoggerMixin, nn.Module):
+class CQL_Offline(GraphMixin, LoggerMixin, nn.Module):
     def __init__(self, env={}, actor={}, critic={}, actor_encoder={}, critic_encoder={}, goal_encoder={},
                  transform_manager={}, discount: float = 0.99, tau: float = 0.005, actor_lr: float = 3e-4,
                  critic_lr: float = 3e-4, deterministic_backup: bool = False, reward_scale: float = 1.0,
@@ -157,45 +157,6 @@ class CQL_Offline(LoggerMixin, nn.Module):
             e.load_images(c, obs[c].to(self.dev), goal[c].to(self.dev), nxt[c].to(self.dev), nchw=nchw)
         e.load_transition(action.to(self.dev), reward.to(self.dev), done.to(self.dev))
         e.set_noise(noise)
-
-    def enable_graph(self, on=True):
-        """Replay the device side of the step from a captured hipGraph (single-GPU only: the RCCL
-        all-reduces of the multi-GPU path stay eager)."""
-        self._use_graph = bool(on)
-        self._graphs = {}
-
-    def _run_segments(self, key, segs, collectives):
-        """Run the device side of a step: `segs` are collective-free kernel sequences over fixed buffers,
-        `collectives[i]` runs between segs[i] and segs[i+1] (RCCL all-reduces; no-ops on one GPU).
-        Eager, or - with enable_graph() - each segment replayed from a captured hipGraph (one graph for
-        the whole step on a single GPU; collectives always stay eager between graphs)."""
-        def eager():
-            for i, f in enumerate(segs):
-                f()
-                if i < len(collectives):
-                    collectives[i]()
-
-        if not self._use_graph:
-            return eager()
-        gs = self._graphs.get(key)
-        if gs is None:
-            eager()  # warm-up: sizes every workspace, so the capture allocates nothing
-            torch.cuda.synchronize()
-            split = self.world_size > 1 or getattr(self, "_force_graph_split", False)
-            parts = [[f] for f in segs] if split else [segs]
-            gs = []
-            for part in parts:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    for f in part:
-                        f()
-                gs.append(g)
-            self._graphs[key] = gs
-            return
-        for i, g in enumerate(gs):
-            g.replay()
-            if len(gs) > 1 and i < len(collectives):
-                collectives[i]()
 
     def compute_update(self, batch, optimize: bool = True, log_type: str = "train", noise=None):
         obs, action, nxt, reward, done = batch

@@ -15,10 +15,10 @@ from ...engine import NetBlock
 from ...init import init_views_
 from ...networks.action_decoder import ActionDecoderLogistic
 from ...networks.plan_recognition import PlanRecognition
-from ..common import LoggerMixin, compute_flag, register_views, to_plain
+from ..common import GraphMixin, LoggerMixin, compute_flag, register_views, to_plain
 
 
-class PlayLMP(LoggerMixin, nn.Module):
+class PlayLMP(GraphMixin, LoggerMixin, nn.Module):
     def __init__(self, env={}, actor={}, plan_proposal={}, plan_recognition={}, perceptual_encoder={},
                  goal_encoder={}, action_decoder={}, transform_manager={}, dataloader={}, kl_beta: float = 1e-3,
                  kl_balancing: bool = True, add_random_plan_loss: bool = False, kl_alpha: float = 0.8,
@@ -171,13 +171,67 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
             buf.normal_()
         else:
             buf.uniform_()
-    # ---- forward
-    for j, c in enumerate(cams):
+    # ---- eager staging: frames into the fixed NHWC buffers, actions into a fixed buffer
+    for c in cams:
         H, W = hw[c]
         v = states[c].to(self.dev)
         call("tacorl_pack_images", ptr(v), 3 * H * W, int(nchw), ptr(self.frames[c]), xd, R, 3, H, W, ops.stream())
-        call("tacorl_encoder_fwd", 1, ops.ptr_array([self.frames[c]]), ops.ptr_array([net.enc(c)]),
-             ops.ptr_array([self.f_out[c]]), ops.ptr_array([self.f_act[c]]), ops.int_array([R]), H, W, xd, cd, ops.stream())
+    if getattr(self, "_acts", None) is None or self._acts.shape != batch["actions"].shape:
+        self._acts = torch.zeros(*batch["actions"].shape, device=self.dev)
+    self._acts.copy_(batch["actions"])
+    acts = self._acts
+
+    def fwd_bwd():
+        _playlmp_fwd_bwd(self, B, T, hw, acts, gs)
+
+    def opt():
+        if optimize:
+            ops.adam_step_batch([(blk.param, blk.grad, blk.m, blk.v, self.lr, 0.0, blk.step, None, 0.0)
+                                 for blk in (net, pr.blk, ad.blk)])
+
+    def reduce_grads():
+        if optimize and getattr(self, "world_size", 1) > 1:
+            import torch.distributed as dist
+
+            for blk in (net, pr.blk, ad.blk):
+                dist.all_reduce(blk.grad)
+
+    self._run_segments(("playlmp", B, T, tuple(sorted(hw.items())), optimize), [fwd_bwd, opt], [reduce_grads])
+    lg = self.logs.cpu().tolist()
+    names = ["kl_loss", "kl_loss_scaled", "action_loss", "gripper_accuracy", "random_plan_action_loss",
+             "random_plan_gripper_accuracy"]
+    for k, v in zip(names, lg):
+        self.log(f"{log_type}/{k}", v, on_step=True, on_epoch=True, sync_dist=True)
+    total = lg[1] + lg[2]
+    self.log(f"{log_type}/total_loss", total, on_step=True, on_epoch=True, sync_dist=True)
+    return total
+
+
+
+def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
+    """Device side of the PlayLMP step up to the gradients (fixed buffers only: hipGraph-capturable)."""
+    from ... import ops
+    from ..._lib import BF16, F32, call, ptr
+
+    cams, net, pr, ad = self.plan_proposal_obs_modalities, self.net, self.pr, self.ad
+    R, Ec, A, cd = B * T, 32 * len(cams), pr.A, self.compute
+    xd = BF16 if self.img_dtype == torch.bfloat16 else F32
+    for j, c in enumerate(cams):
+        H, W = hw[c]
+        fused = cd == BF16 and xd == BF16 and bool(ops.L.lib().tacorl_encoder_fused_supported(H, W))
+        if fused:  # one launch for the whole encoder, activations saved for the backward (encoder_fused.hip)
+            if getattr(self, "_wpk", None) is None:
+                self._wpk = {}
+            if c not in self._wpk:
+                self._wpk[c] = torch.empty(ops.L.lib().tacorl_encoder_fused_wpk_bytes(), dtype=torch.uint8, device=self.dev)
+            call("tacorl_encoder_pack_weights", 1, ops.ptr_array([net.enc(c)]), ops.ptr_array([self._wpk[c]]), ops.stream())
+            call("tacorl_encoder_fwd_fused", 1, ops.ptr_array([self.frames[c]]), ops.ptr_array([self._wpk[c]]),
+                 ops.ptr_array([net.enc(c)]), ops.ptr_array([self.f_out[c]]), ops.ptr_array([self.f_act[c]]),
+                 ops.int_array([R]), H, W, ops.stream())
+        else:
+            call("tacorl_encoder_fwd", 1, ops.ptr_array([self.frames[c]]), ops.ptr_array([net.enc(c)]),
+                 ops.ptr_array([self.f_out[c]]), ops.ptr_array([self.f_act[c]]), ops.int_array([R]), H, W, xd, cd,
+                 ops.stream())
         ops.copy_cols(self.f_out[c], 0, 32, self.emb, 32 * j, Ec, R, 32)
     ops.copy_cols(self.emb, (T - 1) * Ec, T * Ec, self.gin, 0, Ec, B, Ec)  # pp_goal input = emb[:, -1]
     ops.mlp_fwd([self.gin], Ec, [net.genc()], [self.gact], [B], net.genc_dims, net.genc_acts, cd)
@@ -189,7 +243,6 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
     call("tacorl_gauss_kl_balanced", ptr(head_pr), ptr(head_pp), ptr(self.d_head_pr), ptr(self.d_head_pp), B, A,
          float(self.kl_alpha), float(self.kl_beta), float(pr.min_std), int(self.kl_balancing), gs, ptr(self.logs),
          ops.stream())
-    acts = batch["actions"].to(self.dev).float().contiguous()
     # logging-only pass with a uniform random plan (reference :243-252) - first, so the real pass's
     # activations are the ones the backward sees
     call("tacorl_uniform_actions", ptr(self.noise["u_plan"]), ptr(self.rplan), A, B, A, 0, ops.stream())
@@ -219,22 +272,9 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
     for j, c in enumerate(cams):
         H, W = hw[c]
         ops.copy_cols(self.d_emb, 32 * j, Ec, self.f_dout[c], 0, 32, R, 32)
-        ops.encoder_bwd([self.frames[c]], [net.enc(c)], [self.f_act[c]], [self.f_dout[c]], [net.enc(c, net.grad)], H, W, cd)
-    if optimize:
-        for blk in (net, pr.blk, ad.blk):
-            if getattr(self, "world_size", 1) > 1:
-                import torch.distributed as dist
-
-                dist.all_reduce(blk.grad)
-            ops.adam_step(blk.param, blk.grad, blk.m, blk.v, self.lr, 0.0, blk.step)
-    lg = self.logs.cpu().tolist()
-    names = ["kl_loss", "kl_loss_scaled", "action_loss", "gripper_accuracy", "random_plan_action_loss",
-             "random_plan_gripper_accuracy"]
-    for k, v in zip(names, lg):
-        self.log(f"{log_type}/{k}", v, on_step=True, on_epoch=True, sync_dist=True)
-    total = lg[1] + lg[2]
-    self.log(f"{log_type}/total_loss", total, on_step=True, on_epoch=True, sync_dist=True)
-    return total
+        fused = cd == BF16 and xd == BF16 and bool(ops.L.lib().tacorl_encoder_fused_supported(H, W))
+        ops.encoder_bwd([self.frames[c]], [net.enc(c)], [self.f_act[c]], [self.f_dout[c]], [net.enc(c, net.grad)], H, W, cd,
+                        fused=fused)
 
 
 def _named_gradients(self):
