@@ -520,3 +520,30 @@ def test_rnn_bptt_step_and_transpose():
     assert torch.equal(wt.cpu(), W.t().contiguous().to(torch.bfloat16))
     assert relerr(y, ref) < 1e-5, relerr(y, ref)
     assert torch.equal(yb, y.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("R", [100, 4096])
+def test_add_layernorm_fwd_bwd(R):
+    """y = LayerNorm(x + res) forward and backward (dv, dw, db) vs torch autograd; R = 4096 exercises the
+    two-level column sums of the weight / bias gradients."""
+    from tacorl_amd import _lib, ops
+
+    dev = _dev()
+    D = 32
+    x, res = rnd(R, D, seed=1).requires_grad_(True), rnd(R, D, seed=2)
+    w, b = (1 + 0.1 * rnd(D, seed=3)).requires_grad_(True), (0.1 * rnd(D, seed=4)).requires_grad_(True)
+    y = F.layer_norm(x + res, (D,), w, b, 1e-5)
+    dy = rnd(R, D, seed=5)
+    (y * dy).sum().backward()
+    xd, rd, wd, bd, dyd = (t.detach().to(dev) for t in (x, res, w, b, dy))
+    yo, stats = torch.empty(R, D, device=dev), torch.empty(R, 2, device=dev)
+    ops.call("tacorl_add_layernorm_fwd", ops.ptr(xd), ops.ptr(rd), ops.ptr(wd), ops.ptr(bd), ops.ptr(yo), ops.ptr(stats), R, D,
+             1e-5, ops.stream())
+    dv, dw, db = torch.empty(R, D, device=dev), torch.empty(D, device=dev), torch.empty(D, device=dev)
+    ws = torch.empty(_lib.lib().tacorl_add_layernorm_bwd_ws_bytes(R, D), dtype=torch.uint8, device=dev)
+    ops.call("tacorl_add_layernorm_bwd", ops.ptr(dyd), ops.ptr(xd), ops.ptr(rd), ops.ptr(wd), ops.ptr(stats), ops.ptr(dv),
+             ops.ptr(dw), ops.ptr(db), R, D, 0, ops.ptr(ws), ws.numel(), ops.stream())
+    torch.cuda.synchronize()
+    assert relerr(yo, y) < 1e-5
+    assert relerr(dv, x.grad) < 1e-4
+    assert relerr(dw, w.grad) < 1e-4 and relerr(db, b.grad) < 1e-4
