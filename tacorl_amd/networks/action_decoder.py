@@ -78,11 +78,6 @@ class ActionDecoderLogistic:
 
     def _lin(self, x, ldx, w, b, y, M, K, N, act, compute):
         # split-K capable entry (skinny outputs with a long K: linear2 2048->32, the 2048->182 heads)
-        import os
-        if os.environ.get("TACORL_NO_SPLITK"):
-            call("tacorl_linear_fwd", 1, ops.ptr_array([x]), ldx, ops.ptr_array([w]), ops.ptr_array([b]),
-                 ops.ptr_array([y]), None, ops.int_array([M]), K, N, act, compute, ops.stream())
-            return
         nb = ops.L.lib().tacorl_linear_add_fwd_ws_bytes(1, ops.int_array([M]), K, N)
         ws = ops.workspace(nb, self.dev, "lin_splitk")
         call("tacorl_linear_add_fwd", 1, ops.ptr_array([x]), ldx, ops.ptr_array([w]), ops.ptr_array([b]), None, 0,
