@@ -62,14 +62,20 @@ class GraphMixin:
         self._use_graph = bool(on)
         self._graphs = {}
 
-    def _run_segments(self, key, segs, collectives):
+    def _run_segments(self, key, segs, collectives, side=None):
         """Run the device side of a step: `segs` are collective-free kernel sequences over fixed buffers,
         `collectives[i]` runs between segs[i] and segs[i+1] (RCCL all-reduces; no-ops on one GPU).
         Eager, or - with enable_graph() - each segment replayed from a captured hipGraph (one graph for
-        the whole step on a single GPU; collectives always stay eager between graphs)."""
+        the whole step on a single GPU; collectives always stay eager between graphs).
+        side = (i, fn): work that depends only on segs[:i+1] and that nothing later in the step reads
+        (TACORL's logging-only action-decoder pass).  In split mode it is its own graph, replayed on a side
+        stream right after segment i and joined at the end of the step, so it overlaps the collectives and
+        the remaining segments; otherwise it simply runs after segment i."""
         def eager():
             for i, f in enumerate(segs):
                 f()
+                if side is not None and side[0] == i:
+                    side[1]()
                 if i < len(collectives):
                     collectives[i]()
 
@@ -82,7 +88,12 @@ class GraphMixin:
             eager()  # warm-up: sizes every workspace, so the capture allocates nothing
             torch.cuda.synchronize()
             split = getattr(self, "world_size", 1) > 1 or getattr(self, "_force_graph_split", False)
-            parts = [[f] for f in segs] if split else [segs]
+            if split:
+                parts = [[f] for f in segs]
+            else:
+                parts = [list(segs)]
+                if side is not None:
+                    parts[0].insert(side[0] + 1, side[1])
             gs = []
             for part in parts:
                 g = torch.cuda.CUDAGraph()
@@ -90,9 +101,24 @@ class GraphMixin:
                     for f in part:
                         f()
                 gs.append(g)
-            self._graphs[key] = gs
+            g_side = None
+            if split and side is not None:
+                g_side = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_side):
+                    side[1]()
+                if getattr(self, "_side_replay_stream", None) is None:
+                    self._side_replay_stream = torch.cuda.Stream(device=self.device)
+            self._graphs[key] = (gs, g_side)
             return
+        gs, g_side = gs
+        cur = torch.cuda.current_stream()
         for i, g in enumerate(gs):
             g.replay()
+            if g_side is not None and side[0] == i:
+                self._side_replay_stream.wait_stream(cur)
+                with torch.cuda.stream(self._side_replay_stream):
+                    g_side.replay()
             if len(gs) > 1 and i < len(collectives):
                 collectives[i]()
+        if g_side is not None:
+            cur.wait_stream(self._side_replay_stream)

@@ -228,9 +228,14 @@ class TACORL(CQL_Offline):
             e.phase_c(optimize)
             self._join_ad()
 
-        self._run_segments(key, [lambda: self._device_front(B, T, hw, optimize, with_ad),
+        # split (multi-GPU) graphs: the frozen, logging-only action-decoder pass leaves the first segment
+        # and runs as a side graph beside the all-reduces and the other segments
+        segmented = self.world_size > 1 or getattr(self, "_force_graph_split", False)
+        ad_side = with_ad and segmented and self._use_graph and not (optimize and self.finetune_action_decoder)
+        side = (0, lambda: self.ad.loss_step(self, self.acts, self.plan, B, T, False)) if ad_side else None
+        self._run_segments(key, [lambda: self._device_front(B, T, hw, optimize, with_ad and not ad_side),
                                  lambda: e.phase_b(bc, optimize), tail],
-                           [e.allreduce_alpha, e.allreduce_grads])
+                           [e.allreduce_alpha, e.allreduce_grads], side=side)
         self._publish_logs(log_type, extra=("action_loss",) if with_ad else ())
 
     def configure_optimizers(self):

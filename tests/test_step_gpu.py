@@ -196,4 +196,6 @@ def test_tacorl_step_hipgraph(split):
     mod.training_step(to_dev(g.batch(1), mod.device), noise=to_dev(g.noise(1), mod.device))
     torch.cuda.synchronize()
     assert torch.isfinite(mod.engine.logs).all() and not torch.equal(before, mod.engine.actor.param)
-    assert len(mod._graphs) == 1 and len(next(iter(mod._graphs.values()))) == (3 if split else 1)
+    gs, g_side = next(iter(mod._graphs.values()))
+    assert len(mod._graphs) == 1 and len(gs) == (3 if split else 1)
+    assert (g_side is not None) == split  # split mode: the frozen action-decoder pass is its own side graph
