@@ -48,18 +48,31 @@ class NetBlock:
         # the fp32 master at the start of every update (ACEngine._refresh_bf16)
         self.param_bf16 = torch.zeros(self.size, device=device, dtype=torch.bfloat16)
         self.step = torch.zeros(1, dtype=torch.int32, device=device)
-        self.views, self.grad_views = {}, {}
-        for flat, dst in ((self.param, self.views), (self.grad, self.grad_views)):
-            for c in self.all_cams:
-                for k, v in blocks.encoder_views(flat, self.enc_off[c]).items():
-                    dst[f"encoder.networks.{c}.{k}"] = v
-            gn = [(f"goal_encoder.mlp.{i}.weight", f"goal_encoder.mlp.{i}.bias") for i in (0, 2, 4)]
-            dst.update(blocks.mlp_views(flat, self.genc_off, self.genc_dims, gn))
-            if head_parts is None:
-                dst.update(blocks.mlp_views(flat, self.head_off, self.head_dims, head_names))
-            else:
-                dst.update(blocks.mlp_views(flat, self.head_off, self.head_dims[:-1], head_names))
-                dst.update(blocks.head_views(flat, self.head_off, self.head_dims, self.head_dims[-2], head_parts))
+        self._head_names, self._head_parts = head_names, head_parts
+        self.views, self.grad_views = self._views_of(self.param), self._views_of(self.grad)
+
+    def _views_of(self, flat):
+        """Reference-named views (logical shapes) into a flat block of this layout."""
+        dst = {}
+        for c in self.all_cams:
+            for k, v in blocks.encoder_views(flat, self.enc_off[c]).items():
+                dst[f"encoder.networks.{c}.{k}"] = v
+        gn = [(f"goal_encoder.mlp.{i}.weight", f"goal_encoder.mlp.{i}.bias") for i in (0, 2, 4)]
+        dst.update(blocks.mlp_views(flat, self.genc_off, self.genc_dims, gn))
+        if self._head_parts is None:
+            dst.update(blocks.mlp_views(flat, self.head_off, self.head_dims, self._head_names))
+        else:
+            dst.update(blocks.mlp_views(flat, self.head_off, self.head_dims[:-1], self._head_names))
+            dst.update(blocks.head_views(flat, self.head_off, self.head_dims, self.head_dims[-2], self._head_parts))
+        return dst
+
+    def rebind_grad(self, flat):
+        """Move the gradient block into caller-provided storage (a slice of one arena, so that a single
+        all-reduce covers several networks)."""
+        assert flat.numel() == self.size and flat.is_contiguous()
+        flat.copy_(self.grad)
+        self.grad = flat
+        self.grad_views = self._views_of(flat)
 
     def enc(self, cam, flat=None):
         flat = self.param if flat is None else flat
@@ -123,6 +136,15 @@ class ACEngine:
         mk = lambda: NetBlock(cams, goal_cams, q_dims, silu_q, qn, device, hidden=hidden)  # noqa: E731
         self.q1, self.q2, self.tq1, self.tq2 = mk(), mk(), mk(), mk()
         self.log_alpha, self.log_alpha_prime = Scalar(device), Scalar(device)
+        # one gradient arena [actor | q1 | q2 | log_alpha'] -> ONE all-reduce per step for the update
+        # (plus the scalar one for log_alpha, which must be stepped before the actor loss)
+        sizes = [self.actor.size, self.q1.size, self.q2.size, 4]
+        self.grad_arena = torch.zeros(sum(sizes), device=device)
+        o = 0
+        for blk, n_ in zip((self.actor, self.q1, self.q2), sizes):
+            blk.rebind_grad(self.grad_arena[o: o + n_])
+            o += n_
+        self.log_alpha_prime.grad = self.grad_arena[o: o + 1]
         self.extra_enc, self._wpk = [], {}
         self.B = None
         if B:
@@ -396,8 +418,7 @@ class ACEngine:
         self._allreduce([self.log_alpha.grad])
 
     def allreduce_grads(self):
-        self._allreduce([self.actor.grad, self.q1.grad, self.q2.grad] +
-                        ([self.log_alpha_prime.grad] if self.with_lagrange else []))
+        self._allreduce([self.grad_arena])
 
     def phase_a(self, encoded=False):
         B, n, A, Ac, hp, nz = self.B, self.n, self.A, self.Ac, self.hp, self.noise
