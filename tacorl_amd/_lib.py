@@ -31,6 +31,8 @@ _SIGS = {
     "tacorl_rnn_linear_fwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "tacorl_rnn_linear_bwd_step": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_transpose_to_bf16": (_i, [_p, _p, _i, _i, _p]),
+    "tacorl_pr_encoder_fused_supported": (_i, [_i, _i, _i, _i, _i]),
+    "tacorl_pr_encoder_fused": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "tacorl_to_bf16_batch": (_i, [_i, _p, _p, _p, _p]),
     "tacorl_mlp_bwd_fused_supported": (_i, [_i, _i, _p, _i, _i]),
     "tacorl_mlp_bwd_fused_ws_bytes": (_sz, [_i, _p, _i, _p]),

@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("dense_ops.hip", "rl_ops.hip", "seq_ops.hip", "encoder_fused.hip", "encoder_bwd_fused.hip", "mlp_fused.hip", "rnn_ops.hip")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("dense_ops.hip", "rl_ops.hip", "seq_ops.hip", "encoder_fused.hip", "encoder_bwd_fused.hip", "mlp_fused.hip", "rnn_ops.hip", "pr_fused.hip")]
 OUT = os.path.join(HERE, "lib", "libtacorl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]

@@ -1,0 +1,237 @@
+// Plan-recognition transformer encoder, inference, in ONE launch (reference
+// networks/plan_encoders/plan_recognition_transformer.py:36-88: learned position embedding + N post-norm
+// nn.TransformerEncoderLayer (ReLU FFN) + mean over time; TACORL runs it frozen / eval, so no dropout and
+// nothing to save for a backward).
+//
+// As separate kernels a layer is 8-9 launches (in-proj, attention, out-proj, add+LayerNorm, FFN1,
+// split-K FFN2 + reduce, add+LayerNorm) of a few microseconds of work each: ~180 us for two layers on the
+// step's longest dependent chain.  With d_model 32 and T = 16 a whole sequence is one 16-row MFMA tile, so
+// here ONE WAVE owns one sequence for all layers: its activations stay in registers (MFMA D layout: lane =
+// row, 4 consecutive features) and a wave-private LDS scratch; no workgroup barrier exists in this kernel.
+// Weights are the MFMA A operand, streamed from global memory (FFN matrices from a bf16 mirror of the
+// parameter block, one phase ahead of their use).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tacorl_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int PR_D = 32, PR_T = 16, PR_H = 8, PR_HD = 4, PR_MAXL = 4, PR_CH = 256;
+constexpr int XB_P = 40;    // bf16 row pitch of the 32-wide MFMA B operand (80 B: conflict-free b128 reads)
+constexpr int HB_P = 264;   // bf16 row pitch of one FFN hidden chunk
+constexpr int QKV_P = 100;  // fp32 row pitch of q|k|v
+
+struct PrLayerOff { long in_w, in_b, out_w, out_b, w1, b1, w2, b2, n1w, n1b, n2w, n2b; };
+struct PrArgs {
+  const float* emb;     // [B*T][ld_emb], first 32 columns used
+  const float* P;       // fp32 parameter block
+  const __bf16* Pb;     // bf16 copy of the block (same element offsets)
+  float* pooled;        // [B][32] mean over time of the last layer's output
+  long pos;             // position_embeddings offset
+  PrLayerOff l[PR_MAXL];
+  int ld_emb, B, FF, L;
+};
+
+__device__ __forceinline__ bf16x8 cvt8(const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  return bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+}
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// LayerNorm over the 32 features of each row; v[nt][r] = feature 16 nt + 4 g + r of row i (lanes i, i+16, i+32, i+48)
+__device__ __forceinline__ void layer_norm32(f32x4 (&v)[2], const float* w, const float* b, int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) s += v[nt][r];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s / 32.f;
+  float q = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const float c = v[nt][r] - mean; q += c * c; }
+  q += __shfl_xor(q, 16, 64);
+  q += __shfl_xor(q, 32, 64);
+  const float rstd = 1.0f / sqrtf(q / 32.f + 1e-5f);
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) {
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(w + 16 * nt + 4 * g), bb = *reinterpret_cast<const f32x4*>(b + 16 * nt + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[nt][r] = (v[nt][r] - mean) * rstd * ww[r] + bb[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 xb_s[4][PR_T * XB_P];
+  __shared__ __attribute__((aligned(16))) unsigned char big_s[4][PR_T * HB_P * 2];  // q|k|v (fp32) or FFN hidden chunk (bf16)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x * 4 + w;
+  if (b >= a.B) return;  // wave-uniform; nothing below synchronises across waves
+  __bf16* xb = xb_s[w];
+  float* qkv = reinterpret_cast<float*>(big_s[w]);
+  __bf16* hb = reinterpret_cast<__bf16*>(big_s[w]);
+  static_assert(PR_T * QKV_P * 4 <= PR_T * HB_P * 2, "q|k|v fits in the hidden-chunk buffer");
+
+  // x = emb + position embedding, in D layout: v[nt][r] = feature 16 nt + 4 g + r of row (time step) i
+  f32x4 x[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) {
+    const int n = 16 * nt + 4 * g;
+    x[nt] = *reinterpret_cast<const f32x4*>(a.emb + ((long)b * PR_T + i) * a.ld_emb + n) +
+            *reinterpret_cast<const f32x4*>(a.P + a.pos + i * PR_D + n);
+  }
+  auto put_xb = [&](const f32x4 (&v)[2]) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+      *reinterpret_cast<bf16x4*>(xb + i * XB_P + 16 * nt + 4 * g) =
+          bf16x4{(__bf16)v[nt][0], (__bf16)v[nt][1], (__bf16)v[nt][2], (__bf16)v[nt][3]};
+  };
+  const int nchunk = a.FF / PR_CH;
+  for (int l = 0; l < a.L; l++) {
+    const PrLayerOff& o = a.l[l];
+    // ---- q|k|v = x Win^T + b  (6 N tiles, K = 32)
+    put_xb(x);
+    lds_sync();
+    {
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + i * XB_P + 8 * g);
+#pragma unroll
+      for (int nt = 0; nt < 6; nt++) {
+        const bf16x8 wf = cvt8(a.P + o.in_w + (long)(16 * nt + i) * PR_D + 8 * g);
+        f32x4 acc = *reinterpret_cast<const f32x4*>(a.P + o.in_b + 16 * nt + 4 * g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc, 0, 0, 0);
+        *reinterpret_cast<f32x4*>(qkv + i * QKV_P + 16 * nt + 4 * g) = acc;
+      }
+    }
+    lds_sync();
+    // ---- attention: 8 heads x 16 queries = 128 (head, query) pairs, two per lane; result -> xb (bf16)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int p = lane + 64 * j, h = p >> 4, qi = p & 15;
+      f32x4 q = *reinterpret_cast<const f32x4*>(qkv + qi * QKV_P + PR_HD * h);
+#pragma unroll
+      for (int e = 0; e < 4; e++) q[e] *= 0.5f;  // 1 / sqrt(head_dim)
+      float s[PR_T], mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < PR_T; t++) {
+        const f32x4 k = *reinterpret_cast<const f32x4*>(qkv + t * QKV_P + PR_D + PR_HD * h);
+        s[t] = ((q[0] * k[0] + q[1] * k[1]) + q[2] * k[2]) + q[3] * k[3];
+        mx = fmaxf(mx, s[t]);
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int t = 0; t < PR_T; t++) { s[t] = expf(s[t] - mx); se += s[t]; }
+      f32x4 ov = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < PR_T; t++) {
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(qkv + t * QKV_P + 2 * PR_D + PR_HD * h);
+        const float pr = s[t] / se;
+#pragma unroll
+        for (int e = 0; e < 4; e++) ov[e] += pr * vv[e];
+      }
+      *reinterpret_cast<bf16x4*>(xb + qi * XB_P + PR_HD * h) = bf16x4{(__bf16)ov[0], (__bf16)ov[1], (__bf16)ov[2], (__bf16)ov[3]};
+    }
+    lds_sync();
+    // ---- out-projection + residual + LayerNorm 1
+    {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(xb + i * XB_P + 8 * g);
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        const bf16x8 wf = cvt8(a.P + o.out_w + (long)(16 * nt + i) * PR_D + 8 * g);
+        f32x4 acc = *reinterpret_cast<const f32x4*>(a.P + o.out_b + 16 * nt + 4 * g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc, 0, 0, 0);
+        x[nt] += acc;
+      }
+      layer_norm32(x, a.P + o.n1w, a.P + o.n1b, g);
+    }
+    lds_sync();  // every lane has read its out-projection operand before xb is overwritten
+    put_xb(x);
+    lds_sync();
+    // ---- FFN: relu(x W1^T + b1) W2^T + b2, hidden processed in chunks of 256 kept in LDS as bf16
+    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + i * XB_P + 8 * g);
+    f32x4 y[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) y[nt] = *reinterpret_cast<const f32x4*>(a.P + o.b2 + 16 * nt + 4 * g);
+    const __bf16* W1 = a.Pb + o.w1;
+    const __bf16* W2 = a.Pb + o.w2;
+    bf16x8 w1f[16], w2f[8][2];
+#pragma unroll
+    for (int nt = 0; nt < 16; nt++) w1f[nt] = *reinterpret_cast<const bf16x8*>(W1 + (long)(16 * nt + i) * PR_D + 8 * g);
+    for (int c = 0; c < nchunk; c++) {
+      // this chunk's W2 fragments travel while FFN1 runs
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+          w2f[ks][nt] = *reinterpret_cast<const bf16x8*>(W2 + (long)(16 * nt + i) * a.FF + PR_CH * c + 32 * ks + 8 * g);
+#pragma unroll
+      for (int nt = 0; nt < 16; nt++) {
+        f32x4 hacc = *reinterpret_cast<const f32x4*>(a.P + o.b1 + PR_CH * c + 16 * nt + 4 * g);
+        hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[nt], xf, hacc, 0, 0, 0);
+        *reinterpret_cast<bf16x4*>(hb + i * HB_P + 16 * nt + 4 * g) =
+            bf16x4{(__bf16)fmaxf(hacc[0], 0.f), (__bf16)fmaxf(hacc[1], 0.f), (__bf16)fmaxf(hacc[2], 0.f), (__bf16)fmaxf(hacc[3], 0.f)};
+      }
+      lds_sync();
+      // the next chunk's W1 fragments travel while FFN2 runs
+      if (c + 1 < nchunk) {
+#pragma unroll
+        for (int nt = 0; nt < 16; nt++)
+          w1f[nt] = *reinterpret_cast<const bf16x8*>(W1 + (long)(PR_CH * (c + 1) + 16 * nt + i) * PR_D + 8 * g);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hb + i * HB_P + 32 * ks + 8 * g);
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) y[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks][nt], hf, y[nt], 0, 0, 0);
+      }
+      lds_sync();  // hidden chunk consumed before the next one overwrites it
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) x[nt] += y[nt];
+    layer_norm32(x, a.P + o.n2w, a.P + o.n2b, g);
+  }
+  // ---- mean over the 16 time steps (lanes i = 0..15 of each g)
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) {
+    f32x4 s = x[nt];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+      for (int r = 0; r < 4; r++) s[r] += __shfl_xor(s[r], off, 64);
+    if (i == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) s[r] *= (1.0f / PR_T);
+      *reinterpret_cast<f32x4*>(a.pooled + (long)b * PR_D + 16 * nt + 4 * g) = s;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tacorl_pr_encoder_fused_supported(int D, int T, int H, int FF, int L) {
+  return D == PR_D && T == PR_T && H == PR_H && FF >= PR_CH && FF % PR_CH == 0 && L >= 1 && L <= PR_MAXL ? 1 : 0;
+}
+// offsets: [position_embeddings, then per layer: in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias,
+// linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias]
+// (element offsets into params / params_bf16, each a multiple of 4).
+extern "C" int tacorl_pr_encoder_fused(const float* emb, int ld_emb, const float* params, const void* params_bf16,
+                                       const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
+                                       tacorl_stream_t stream) {
+  if (!tacorl_pr_encoder_fused_supported(D, T, H, FF, L) || ld_emb % 4 || B < 1) return TACORL_EINVAL;
+  if (((uintptr_t)emb | (uintptr_t)params | (uintptr_t)params_bf16 | (uintptr_t)pooled) & 15) return TACORL_EINVAL;
+  PrArgs a{};
+  a.emb = emb; a.P = params; a.Pb = (const __bf16*)params_bf16; a.pooled = pooled; a.ld_emb = ld_emb; a.B = B; a.FF = FF; a.L = L;
+  a.pos = offsets[0];
+  for (int l = 0; l < L; l++) {
+    const long* q = offsets + 1 + 12 * l;
+    for (int k = 0; k < 12; k++)
+      if (q[k] % 4) return TACORL_EINVAL;
+    a.l[l] = PrLayerOff{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]};
+  }
+  hipLaunchKernelGGL(pr_encoder_fused_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}

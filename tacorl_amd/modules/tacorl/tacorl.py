@@ -162,7 +162,7 @@ class TACORL(CQL_Offline):
         with torch.cuda.stream(self._pr_stream):
             for j, c in enumerate(self.plan_recognition_modalities):
                 ops.copy_cols(self.f_out[c], 0, 32, self.pr_in, 32 * j, self.pr_in.shape[1], B * T, 32)
-            head = self.pr.forward(self.pr_in, self.pr_in.shape[1], B, T, self.compute)
+            head = self.pr.forward(self.pr_in, self.pr_in.shape[1], B, T, self.compute, inference=True)
             call("tacorl_pr_sample", ptr(head), ptr(self.eps_pr), ptr(self.plan), None, None, B, self.action_dim,
                  float(self.pr.min_std), ops.stream())
             e.load_transition(self.plan, self.reward, self.reward)
@@ -205,7 +205,7 @@ class TACORL(CQL_Offline):
                  self.compute, ops.stream())
         for j, c in enumerate(self.plan_recognition_modalities):
             ops.copy_cols(self.f_out[c], 0, 32, self.pr_in, 32 * j, self.pr_in.shape[1], B * T, 32)
-        head = self.pr.forward(self.pr_in, self.pr_in.shape[1], B, T, self.compute)
+        head = self.pr.forward(self.pr_in, self.pr_in.shape[1], B, T, self.compute, inference=True)
         call("tacorl_pr_sample", ptr(head), ptr(self.eps_pr), ptr(self.plan), None, None, B, self.action_dim,
              float(self.pr.min_std), ops.stream())
         return self.plan

@@ -60,21 +60,41 @@ class PlanRecognition:
 
     def _lin(self, x, ldx, w, b, y, M, K, N, act, compute):
         # split-K capable entry (skinny outputs with a long K: linear2 2048->32, the 2048->182 heads)
-        import os
-        if os.environ.get("TACORL_NO_SPLITK"):
-            call("tacorl_linear_fwd", 1, ops.ptr_array([x]), ldx, ops.ptr_array([w]), ops.ptr_array([b]),
-                 ops.ptr_array([y]), None, ops.int_array([M]), K, N, act, compute, ops.stream())
-            return
         nb = ops.L.lib().tacorl_linear_add_fwd_ws_bytes(1, ops.int_array([M]), K, N)
         ws = ops.workspace(nb, self.dev, "lin_splitk")
         call("tacorl_linear_add_fwd", 1, ops.ptr_array([x]), ldx, ops.ptr_array([w]), ops.ptr_array([b]), None, 0,
              ops.ptr_array([y]), N, ops.int_array([M]), K, N, act, compute, ptr(ws), ws.numel(), ops.stream())
 
-    def forward(self, emb, ld_emb, B, T, compute):
+    def _fused_offsets(self):
+        names = ["position_embeddings.weight"]
+        for l in range(self.L):
+            p = f"transformer_encoder.layers.{l}."
+            names += [p + k for k in ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+                                      "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight",
+                                      "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")]
+        return [self.blk.off[n][0] for n in names]
+
+    def forward(self, emb, ld_emb, B, T, compute, inference=False):
         """emb: device tensor/pointer of [B*T][ld_emb] per-frame embeddings (first D_in columns used).
-        Returns the (B, 2A) head buffer [mean | var_raw]."""
+        Returns the (B, 2A) head buffer [mean | var_raw].  inference=True (frozen network, no backward
+        follows): the encoder layers + time pooling run as one launch when the shape qualifies."""
         self._ensure(B, T)
         blk, D, R = self.blk, self.D, B * T
+        if (inference and compute == ops.BF16 and self.pad == 0 and ld_emb % 4 == 0
+                and ops.L.lib().tacorl_pr_encoder_fused_supported(D, T, self.H, self.FF, self.L)):
+            import ctypes as C
+            if getattr(self, "_pb", None) is None:
+                self._pb = torch.zeros(blk.param.numel(), device=self.dev, dtype=torch.bfloat16)
+                self._foff = (C.c_long * (1 + 12 * self.L))(*self._fused_offsets())
+            n4 = blk.param.numel() // 4 * 4
+            call("tacorl_to_bf16_batch", 1, ops.ptr_array([blk.param]), ops.ptr_array([self._pb]), (C.c_long * 1)(n4),
+                 ops.stream())
+            call("tacorl_pr_encoder_fused", ptr(emb), ld_emb, ptr(blk.param), ptr(self._pb), self._foff, ptr(self.pooled),
+                 B, D, T, self.H, self.FF, self.L, ops.stream())
+            self._lin(self.pooled, D, blk.p("fc.weight"), blk.p("fc.bias"), self.fc_out, B, D, self.FC, ACT_NONE, compute)
+            self._lin(self.fc_out, self.FC, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.head, B, self.FC,
+                      2 * self.A, ACT_NONE, compute)
+            return self.head
         call("tacorl_add_rows_bcast", ptr(emb), ld_emb, blk.p("position_embeddings.weight"), ptr(self.x[0]), R, T,
              self.D_in, D, ops.stream())
         for l in range(self.L):

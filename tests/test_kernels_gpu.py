@@ -547,3 +547,45 @@ def test_add_layernorm_fwd_bwd(R):
     assert relerr(yo, y) < 1e-5
     assert relerr(dv, x.grad) < 1e-4
     assert relerr(dw, w.grad) < 1e-4 and relerr(db, b.grad) < 1e-4
+
+
+def test_plan_recognition_fused_encoder():
+    """Single-launch frozen plan-recognition encoder (one wave per sequence) vs the per-kernel bf16 path of
+    the same module (same operand roundings) and vs an fp32 torch restatement at bf16 tolerance."""
+    from tacorl_amd import ops
+    from tacorl_amd.networks.plan_recognition import PlanRecognition
+
+    dev = _dev()
+    B, T, D, A = 37, 16, 32, 16
+    pr = PlanRecognition(state_dim=D, latent_plan_dim=A, device=dev, num_heads=8, num_layers=2, encoder_hidden_size=2048,
+                         fc_hidden_size=4096, max_position_embeddings=T, trainable=False)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for k, v in pr.blk.views.items():
+            if k.endswith("weight") and v.dim() == 2:
+                v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) / math.sqrt(v.shape[1]))
+            elif "norm" in k and k.endswith("weight"):
+                v.copy_(1 + 0.1 * torch.randn(v.shape, generator=g))
+            else:
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+    emb = rnd(B * T, D, seed=9).to(dev)
+    h_ref = pr.forward(emb, D, B, T, 1).clone()
+    pooled_ref = pr.pooled.clone()
+    h_fus = pr.forward(emb, D, B, T, 1, inference=True).clone()
+    torch.cuda.synchronize()
+    assert getattr(pr, "_pb", None) is not None, "fused path not taken"
+    assert relerr(pr.pooled, pooled_ref) < 1e-2, relerr(pr.pooled, pooled_ref)
+    assert relerr(h_fus, h_ref) < 2e-2, relerr(h_fus, h_ref)
+    # fp32 restatement (post-norm encoder layers, ReLU FFN, mean over time)
+    P = {k: v.detach().cpu() for k, v in pr.blk.views.items()}
+    x = emb.cpu().view(B, T, D) + P["position_embeddings.weight"][:T]
+    for l in range(2):
+        p = f"transformer_encoder.layers.{l}."
+        qkv = x @ P[p + "self_attn.in_proj_weight"].t() + P[p + "self_attn.in_proj_bias"]
+        q, k, v = (t.view(B, T, 8, 4).transpose(1, 2) for t in qkv.split(D, dim=-1))
+        att = torch.softmax(q @ k.transpose(-1, -2) / 2.0, dim=-1) @ v
+        att = att.transpose(1, 2).reshape(B, T, D) @ P[p + "self_attn.out_proj.weight"].t() + P[p + "self_attn.out_proj.bias"]
+        x = F.layer_norm(x + att, (D,), P[p + "norm1.weight"], P[p + "norm1.bias"])
+        ff = F.relu(x @ P[p + "linear1.weight"].t() + P[p + "linear1.bias"]) @ P[p + "linear2.weight"].t() + P[p + "linear2.bias"]
+        x = F.layer_norm(x + ff, (D,), P[p + "norm2.weight"], P[p + "norm2.bias"])
+    assert relerr(pr.pooled, x.mean(1)) < TOL_BF16, relerr(pr.pooled, x.mean(1))
