@@ -54,6 +54,13 @@ int tacorl_rnn_linear_supported(int M, int K, int N);
 int tacorl_rnn_linear_fwd(const void* x_bf16, const void* w_bf16, const float* bias, const float* addend,
                           int ld_add, float* y, void* y_bf16, int M, int K, int N, int act,
                           tacorl_stream_t stream);
+/* nprob <= 4 independent y = act(x W^T + b + addend) of one shape (M, K, N) in one launch, one activation per
+ * problem: the wavefront schedule of the stacked RNN (launch s = recurrent step s-2l of every layer l plus
+ * the input projection of step s-2l+1 of layers l >= 1). */
+int tacorl_rnn_linear_fwd_batch(int nprob, const void* const* x_bf16, const void* const* w_bf16,
+                                const float* const* bias, const float* const* addend, int ld_add,
+                                float* const* y, void* const* y_bf16, int M, int K, int N, const int* acts,
+                                tacorl_stream_t stream);
 /* BPTT step of the same RNN: y = (x Wt^T + addend) * [mask_src > 0], x = dZ_t (bf16), Wt = W_hh^T (bf16,
  * tacorl_transpose_to_bf16), addend = dH_{t-1}, mask_src = h_{t-1}; y fp32 + bf16 copy (next step's x). */
 int tacorl_rnn_linear_bwd_step(const void* x_bf16, const void* wt_bf16, const float* addend, int ld_add,

@@ -25,3 +25,13 @@ for M, K, N in [(256, 2048, 2048), (3840, 2048, 2048)]:
                             ops.ptr_array([y]), N, ops.int_array([M]), K, N, 1, 1, ops.ptr(ws), ws.numel(), ops.stream())
     new = lambda: ops.call("tacorl_rnn_linear_fwd", ops.ptr(xb), ops.ptr(wb), ops.ptr(b), ops.ptr(add), N, ops.ptr(y), ops.ptr(yb), M, K, N, 1, ops.stream())
     print(f"M={M}: generic (split-K + reduce) {timeit(base):.2f} us   LDS-DMA ring {timeit(new):.2f} us", flush=True)
+import ctypes as C
+M, K, N = 256, 2048, 2048
+xs = [torch.randn(M, K, device=dev).to(torch.bfloat16) for _ in range(3)]
+wsb = [(torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16) for _ in range(3)]
+bb = [torch.zeros(N, device=dev) for _ in range(3)]; adds = [torch.randn(M, N, device=dev) for _ in range(3)]
+ys = [torch.empty(M, N, device=dev) for _ in range(3)]; ybs = [torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(3)]
+for n in (1, 2, 3):
+    f = lambda: ops.call("tacorl_rnn_linear_fwd_batch", n, ops.ptr_array(xs[:n]), ops.ptr_array(wsb[:n]), ops.ptr_array(bb[:n]),
+                         ops.ptr_array(adds[:n]), N, ops.ptr_array(ys[:n]), ops.ptr_array(ybs[:n]), M, K, N, ops.int_array([1] * n), ops.stream())
+    print(f"batch ring (2-stage) nprob={n}: {timeit(f):.2f} us", flush=True)

@@ -36,8 +36,12 @@ struct RnnArgs {
 // LDS row r keeps its 16-byte chunk c at position c ^ (r & 15): a fragment read (16 lanes = 16 rows, same
 // c) then spreads over all banks.  The DMA writes lane-contiguous, so the swizzle is applied to the
 // *global* chunk each lane fetches.
+#define RNN_MAXP 4
+struct RnnBatch { RnnArgs p[RNN_MAXP]; };
+
 template <int RB_M, int RB_N, int RB_S>
-__global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnArgs a) {
+__global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnBatch ab) {
+  const RnnArgs a = ab.p[blockIdx.z];  // by value: keeps the fields in SGPRs (a reference re-loads them in the K loop)
   constexpr int STAGE_BYTES = (RB_M + RB_N) * ROW_BYTES;
   constexpr int DMA_PER_WAVE = (RB_M + RB_N) / 4 / 4;  // wave-instructions per stage and wave (4 rows each)
   constexpr int MI = RB_M / 64, NI = RB_N / 16;        // 16x16 tiles per wave
@@ -120,15 +124,23 @@ __global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnArgs a) {
   }
 }
 
+// all problems of a batch share (M, K, N)
 template <int RB_M, int RB_N, int RB_S>
-int launch_ring(const RnnArgs& a, hipStream_t st) {
+int launch_ring(const RnnBatch& ab, int nprob, hipStream_t st) {
   constexpr int lds = RB_S * (RB_M + RB_N) * ROW_BYTES;
   auto kern = rnn_gemm_kernel<RB_M, RB_N, RB_S>;
   static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) ==
                             hipSuccess ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3((a.M + RB_M - 1) / RB_M, a.N / RB_N), dim3(256), lds, st, a);
+  const RnnArgs& a = ab.p[0];
+  hipLaunchKernelGGL(kern, dim3((a.M + RB_M - 1) / RB_M, a.N / RB_N, nprob), dim3(256), lds, st, ab);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+template <int RB_M, int RB_N, int RB_S>
+int launch_ring(const RnnArgs& a, hipStream_t st) {
+  RnnBatch ab{};
+  ab.p[0] = a;
+  return launch_ring<RB_M, RB_N, RB_S>(ab, 1, st);
 }
 
 }  // namespace
@@ -176,4 +188,25 @@ extern "C" int tacorl_transpose_to_bf16(const float* src, void* dst, int R, int 
   if (R % 32 || C % 32 || R < 32 || C < 32) return TACORL_EINVAL;
   hipLaunchKernelGGL(transpose_to_bf16_kernel, dim3(C / 32, R / 32), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, R, C);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
+/* nprob <= 4 independent y = act(x W^T + b + addend) of one shape in ONE launch (blockIdx.z = problem), on a
+ * 2-stage ring (48 KB of LDS per workgroup, so the workgroups of three problems are co-resident on a CU):
+ * the wavefront schedule of a stacked RNN - recurrent steps of both layers and the upper layer's input
+ * projection of the next step - as T + 2(L-1) launches instead of L*T + L. */
+extern "C" int tacorl_rnn_linear_fwd_batch(int nprob, const void* const* x_bf16, const void* const* w_bf16,
+                                           const float* const* bias, const float* const* addend, int ld_add,
+                                           float* const* y, void* const* y_bf16, int M, int K, int N, const int* acts,
+                                           tacorl_stream_t stream) {
+  if (nprob < 1 || nprob > RNN_MAXP || !tacorl_rnn_linear_supported(M, K, N) || ld_add % 4) return TACORL_EINVAL;
+  RnnBatch ab{};
+  for (int p = 0; p < nprob; p++) {
+    const float* ad = addend ? addend[p] : nullptr;
+    const float* bi = bias ? bias[p] : nullptr;
+    void* yb = y_bf16 ? y_bf16[p] : nullptr;
+    if (((uintptr_t)x_bf16[p] | (uintptr_t)w_bf16[p] | (uintptr_t)y[p] | (uintptr_t)bi | (uintptr_t)ad) & 15) return TACORL_EINVAL;
+    if ((uintptr_t)yb & 7) return TACORL_EINVAL;
+    ab.p[p] = RnnArgs{(const __bf16*)x_bf16[p], (const __bf16*)w_bf16[p], bi, ad, nullptr, y[p], (__bf16*)yb, M, K, N, ld_add, acts[p]};
+  }
+  return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
 }

@@ -99,20 +99,33 @@ class ActionDecoderLogistic:
             call("tacorl_to_bf16_batch", len(srcs), ops.ptr_array(srcs), ops.ptr_array(dsts),
                  (C.c_long * len(srcs))(*([H * H] * len(srcs))), ops.stream())
         at = ops._at
-        for l in range(self.L):
-            if fast and l > 0:  # sequence-wide input projection from the bf16 hidden states of the layer below
-                call("tacorl_rnn_linear_fwd", ptr(self.hb[l - 1]), ptr(self.wib[l]), blk.p(f"rnn.bias_ih_l{l}"), None, 0,
-                     ptr(self.xin[l]), None, R, H, H, ACT_NONE, ops.stream())
-            else:
-                self._lin(x, K, blk.p(f"rnn.weight_ih_l{l}"), blk.p(f"rnn.bias_ih_l{l}"), self.xin[l], R, K, H, ACT_NONE,
-                          compute)
+        if fast:
+            # Wavefront over (layer, step): launch s holds the recurrent step s-2l of every layer l and the
+            # input projection of step s-2l+1 of layers l >= 1 (operand h_{l-1}[s-2l+1] left launch s-1) as
+            # independent problems of ONE batched ring-GEMM launch whose workgroups are co-resident:
+            # T + 2(L-1) dependent launches instead of L*T + (L-1).
+            self._lin(x, K, blk.p("rnn.weight_ih_l0"), blk.p("rnn.bias_ih_l0"), self.xin[0], R, K, H, ACT_NONE, compute)
+            L = self.L
+            hbp = lambda l, t: C.c_void_p(self.hb[l].data_ptr() + 2 * t * B * H)  # noqa: E731
+            for s_ in range(Tm + 2 * (L - 1)):
+                xs, wt, bs, ad, ys, yb, ac = [], [], [], [], [], [], []
+                for l in range(L):
+                    t = s_ - 2 * l
+                    if 0 <= t < Tm:  # h_l[t] = relu(W_hh h_l[t-1] + b_hh + xin_l[t])
+                        xs.append(ptr(self.h0b) if t == 0 else hbp(l, t - 1)); wt.append(ptr(self.whb[l]))
+                        bs.append(blk.p(f"rnn.bias_hh_l{l}")); ad.append(at(self.xin[l], t * B * H))
+                        ys.append(at(self.h[l], t * B * H)); yb.append(hbp(l, t)); ac.append(ACT_RELU)
+                    t = s_ - 2 * l + 1
+                    if l >= 1 and 0 <= t < Tm:  # xin_l[t] = W_ih h_{l-1}[t] + b_ih
+                        xs.append(hbp(l - 1, t)); wt.append(ptr(self.wib[l])); bs.append(blk.p(f"rnn.bias_ih_l{l}"))
+                        ad.append(None); ys.append(at(self.xin[l], t * B * H)); yb.append(None); ac.append(ACT_NONE)
+                call("tacorl_rnn_linear_fwd_batch", len(xs), ops.ptr_array(xs), ops.ptr_array(wt), ops.ptr_array(bs),
+                     ops.ptr_array(ad), H, ops.ptr_array(ys), ops.ptr_array(yb), B, H, H, ops.int_array(ac), ops.stream())
+            x, K = self.h[L - 1], H
+        for l in range(self.L if fast else 0, self.L):  # exact / generic path: layer by layer, step by step
+            self._lin(x, K, blk.p(f"rnn.weight_ih_l{l}"), blk.p(f"rnn.bias_ih_l{l}"), self.xin[l], R, K, H, ACT_NONE,
+                      compute)
             for t in range(Tm):
-                if fast:
-                    prevb = ptr(self.h0b) if t == 0 else C.c_void_p(self.hb[l].data_ptr() + 2 * (t - 1) * B * H)
-                    call("tacorl_rnn_linear_fwd", prevb, ptr(self.whb[l]), blk.p(f"rnn.bias_hh_l{l}"), at(self.xin[l], t * B * H),
-                         H, at(self.h[l], t * B * H), C.c_void_p(self.hb[l].data_ptr() + 2 * t * B * H), B, H, H, ACT_RELU,
-                         ops.stream())
-                    continue
                 prev = self.h0 if t == 0 else at(self.h[l], (t - 1) * B * H)
                 call("tacorl_linear_add_fwd", 1, ops.ptr_array([prev]), H, ops.ptr_array([blk.p(f"rnn.weight_hh_l{l}")]),
                      ops.ptr_array([blk.p(f"rnn.bias_hh_l{l}")]), ops.ptr_array([at(self.xin[l], t * B * H)]), H,
