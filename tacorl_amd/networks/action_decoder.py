@@ -63,7 +63,8 @@ class ActionDecoderLogistic:
         self.xin = [f(R, H) for _ in range(self.L)]
         self.h = [f(R, H) for _ in range(self.L)]
         self.h0 = f(B, H)
-        self.heads, self.d_heads = f(R, self.NH), f(R, self.NH)
+        self.NHP = (self.NH + 31) // 32 * 32  # row pitch of the head buffers (ring GEMM: N % 32 == 0)
+        self.heads, self.d_heads = f(R, self.NHP), f(R, self.NHP)
         self.ws = torch.empty(max(256, ops.L.lib().tacorl_logistic_mixture_ws_bytes(B, Tm, self.Da)), dtype=torch.uint8,
                               device=self.dev)
         nb = ops.L.lib().tacorl_linear_add_fwd_ws_bytes(1, ops.int_array([B]), H, H)
@@ -74,14 +75,16 @@ class ActionDecoderLogistic:
         self.h0b = bf(B, H)
         self.whb = [bf(H, H) for _ in range(self.L)]
         self.wib = [None] + [bf(H, H) for _ in range(1, self.L)]  # W_ih of layers >= 1 (H x H)
+        self.headw_b, self.headb = bf(self.NHP, H), f(self.NHP)    # output heads, rows padded with zeros
         self._shape = (B, Tm)
 
-    def _lin(self, x, ldx, w, b, y, M, K, N, act, compute):
+    def _lin(self, x, ldx, w, b, y, M, K, N, act, compute, ldy=None):
         # split-K capable entry (skinny outputs with a long K: linear2 2048->32, the 2048->182 heads)
         nb = ops.L.lib().tacorl_linear_add_fwd_ws_bytes(1, ops.int_array([M]), K, N)
         ws = ops.workspace(nb, self.dev, "lin_splitk")
         call("tacorl_linear_add_fwd", 1, ops.ptr_array([x]), ldx, ops.ptr_array([w]), ops.ptr_array([b]), None, 0,
-             ops.ptr_array([y]), N, ops.int_array([M]), K, N, act, compute, ptr(ws), ws.numel(), ops.stream())
+             ops.ptr_array([y]), N if ldy is None else ldy, ops.int_array([M]), K, N, act, compute, ptr(ws), ws.numel(),
+             ops.stream())
 
     def forward(self, plan, emb, ld_emb, B, T, Tm, compute):
         """plan (B,P); emb [B*T][ld_emb] batch-major frame embeddings; uses steps t < Tm.  Fills self.heads."""
@@ -132,12 +135,21 @@ class ActionDecoderLogistic:
                      ops.ptr_array([at(self.h[l], t * B * H)]), H, ops.int_array([B]), H, H, ACT_RELU, compute,
                      ptr(self.rnn_ws), self.rnn_ws.numel(), ops.stream())
             x, K = self.h[l], H
-        self._lin(x, H, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.heads, R, H, self.NH, ACT_NONE, compute)
+        if fast:  # output heads through the ring GEMM (bf16 weights, rows padded to a multiple of 32)
+            call("tacorl_to_bf16_batch", 1, ops.ptr_array([blk.p("mean_fc.weight")]), ops.ptr_array([self.headw_b]),
+                 (C.c_long * 1)(self.NH * H), ops.stream())
+            ob = blk.off["mean_fc.bias"][0]  # the four heads' biases sit back to back
+            self.headb[: self.NH].copy_(blk.param[ob: ob + self.NH])
+            call("tacorl_rnn_linear_fwd", ptr(self.hb[self.L - 1]), ptr(self.headw_b), ptr(self.headb), None, 0,
+                 ptr(self.heads), None, R, H, self.NHP, ACT_NONE, ops.stream())
+        else:
+            self._lin(x, H, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.heads, R, H, self.NH, ACT_NONE, compute,
+                      ldy=self.NHP)
 
     def loss(self, actions, loss_out, B, T, Tm, want_grad, grad_scale=1.0):
         """actions: device [B][T][Da+1]; writes the scalar loss to loss_out (device float) and, if
         want_grad, dL/dheads into self.d_heads."""
-        call("tacorl_logistic_mixture_loss", ptr(self.heads), self.NH, ptr(actions), ptr(self.d_heads) if want_grad else None,
+        call("tacorl_logistic_mixture_loss", ptr(self.heads), self.NHP, ptr(actions), ptr(self.d_heads) if want_grad else None,
              loss_out, B, T, Tm, self.Da, self.K, self.num_classes, float(self.gripper_alpha), float(grad_scale),
              ptr(self.ws), self.ws.numel(), ops.stream())
 
@@ -191,9 +203,9 @@ class ActionDecoderLogistic:
             self.dx_seq = f(R, self.P + self.E)
             self._bshape = (B, Tm)
         at = ops._at
-        self._wgrad(self.h[L - 1], H, self.d_heads, self.NH, R, H, self.NH, blk.g("mean_fc.weight"),
+        self._wgrad(self.h[L - 1], H, self.d_heads, self.NHP, R, H, self.NH, blk.g("mean_fc.weight"),
                     blk.g("mean_fc.bias"), compute)
-        self._dgrad(self.d_heads, self.NH, blk.p("mean_fc.weight"), self.dH, H, R, self.NH, H, compute)
+        self._dgrad(self.d_heads, self.NHP, blk.p("mean_fc.weight"), self.dH, H, R, self.NH, H, compute)
         fast = compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H)) and H % 32 == 0
         if fast and getattr(self, "_bptt_shape", None) != (B, Tm):
             bf = lambda *s: torch.zeros(*s, device=self.dev, dtype=torch.bfloat16)  # noqa: E731
