@@ -27,6 +27,25 @@ struct GemmArgs {
   int R[GEMM_MAXP];  // reduction length per problem
 };
 
+// In-place 4x4 transpose across the 4 lanes of a quad: lane q (= lane & 3) enters with row q of a 4x4
+// block in v[0..3] and leaves with column q.  Two DPP quad_perm exchanges (lane^1, lane^2), no LDS traffic.
+// Used when the reduction index is the slow one in memory ([R][M] operands of the weight gradients): the
+// 4 lanes of a quad load 4 consecutive r for the same 4 m, and after the transpose each lane writes 4
+// consecutive r of one m with a single LDS store (instead of 4 scalar stores with a stride).
+__device__ __forceinline__ float dpp_xor1(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose(float (&v)[4], int q) {
+  const bool o1 = q & 1, o2 = q & 2;
+  const float x0 = dpp_xor1(o1 ? v[0] : v[1]), x1 = dpp_xor1(o1 ? v[2] : v[3]);
+  if (o1) { v[0] = x0; v[2] = x1; } else { v[1] = x0; v[3] = x1; }
+  const float y0 = dpp_xor2(o2 ? v[0] : v[2]), y1 = dpp_xor2(o2 ? v[1] : v[3]);
+  if (o2) { v[0] = y0; v[1] = y1; } else { v[2] = y0; v[3] = y1; }
+}
+
 template <class Atom, class LA, class LB, bool TA, bool TB, class Epi, int BM, int BN, int BKT = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmArgs g) {
   typedef typename Atom::elem T;
@@ -56,14 +75,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmAr
     for (int i = 0; i < ACH; i++) {
       int c = tid + i * 256;
       if (!TA) la.load(p, m0 + c / (BK / 4), r0 + (c % (BK / 4)) * 4, ra[i]);
-      else     la.load(p, r0 + c / (BM / 4), m0 + (c % (BM / 4)) * 4, ra[i]);
+      else     la.load(p, r0 + (c / BM) * 4 + (c & 3), m0 + ((c >> 2) % (BM / 4)) * 4, ra[i]);  // quad = 4 rows r, same 4 m
     }
 #pragma unroll
     for (int i = 0; i < BCH; i++) {
       int c = tid + i * 256;
       if (BN * BK / 4 % 256 != 0 && c >= BN * BK / 4) break;
       if (!TB) lb.load(p, n0 + c / (BK / 4), r0 + (c % (BK / 4)) * 4, rb[i]);
-      else     lb.load(p, r0 + c / (BN / 4), n0 + (c % (BN / 4)) * 4, rb[i]);
+      else     lb.load(p, r0 + (c / BN) * 4 + (c & 3), n0 + ((c >> 2) % (BN / 4)) * 4, rb[i]);
     }
   };
   auto stash = [&]() {
@@ -72,10 +91,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmAr
       int c = tid + i * 256;
       if (!TA) {
         Atom::st4(&As[(c / (BK / 4)) * LD + (c % (BK / 4)) * 4], ra[i]);
-      } else {
-        int r = c / (BM / 4), m = (c % (BM / 4)) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; j++) As[(m + j) * LD + r] = Atom::cvt(ra[i][j]);
+      } else {  // 4x4 transpose inside the lane quad (DPP), then one 4-element store along r
+        quad_transpose(ra[i], tid & 3);
+        Atom::st4(&As[(((c >> 2) % (BM / 4)) * 4 + (c & 3)) * LD + (c / BM) * 4], ra[i]);
       }
     }
 #pragma unroll
@@ -85,9 +103,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmAr
       if (!TB) {
         Atom::st4(&Bs[(c / (BK / 4)) * LD + (c % (BK / 4)) * 4], rb[i]);
       } else {
-        int r = c / (BN / 4), n = (c % (BN / 4)) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; j++) Bs[(n + j) * LD + r] = Atom::cvt(rb[i][j]);
+        quad_transpose(rb[i], tid & 3);
+        Atom::st4(&Bs[(((c >> 2) % (BN / 4)) * 4 + (c & 3)) * LD + (c / BN) * 4], rb[i]);
       }
     }
   };
