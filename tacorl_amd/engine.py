@@ -245,13 +245,18 @@ class ACEngine:
         """obs/goal/nxt: (B,3,H,W) [nchw] or (B,H,W,3) fp32 device tensors (may be strided views with a
         uniform image pitch, e.g. states[:,0])."""
         H, W = self.hw[cam]
+        xd = BF16 if self.img_dtype == torch.bfloat16 else F32
+        esz, img = self.X3[cam].element_size(), H * W * 3
+        jobs = []
         for i, t in enumerate((obs, goal, nxt)):
             assert t.is_cuda and t.dtype == torch.float32 and t[0].is_contiguous()
             pitch = t.stride(0) if t.shape[0] > 1 else 3 * H * W
-            dst_off = i * self.B * H * W * 3
-            dst = self.X3[cam].view(-1)[dst_off:]
-            call("tacorl_pack_images", ptr(t), pitch, int(nchw), ptr(dst),
-                 BF16 if self.img_dtype == torch.bfloat16 else F32, self.B, 3, H, W, ops.stream())
+            jobs.append((t.data_ptr(), pitch, self.X3[cam].data_ptr() + i * self.B * img * esz, self.B))
+        if nchw and (H * W) % 4 == 0 and all(j[0] % 16 == 0 and j[1] % 4 == 0 for j in jobs):
+            ops.pack_images_batch(jobs, xd, H, W)  # one vectorised launch for obs / goal / next
+        else:
+            for src, pitch, dst, n_ in jobs:
+                call("tacorl_pack_images", src, pitch, int(nchw), dst, xd, n_, 3, H, W, ops.stream())
 
     def load_transition(self, action, reward, done):
         self.action.copy_(action.reshape(self.B, self.A).float())

@@ -175,7 +175,10 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
     for c in cams:
         H, W = hw[c]
         v = states[c].to(self.dev)
-        call("tacorl_pack_images", ptr(v), 3 * H * W, int(nchw), ptr(self.frames[c]), xd, R, 3, H, W, ops.stream())
+        if nchw and (H * W) % 4 == 0 and v.data_ptr() % 16 == 0:
+            ops.pack_images_batch([(v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), R)], xd, H, W)
+        else:
+            call("tacorl_pack_images", ptr(v), 3 * H * W, int(nchw), ptr(self.frames[c]), xd, R, 3, H, W, ops.stream())
     if getattr(self, "_acts", None) is None or self._acts.shape != batch["actions"].shape:
         self._acts = torch.zeros(*batch["actions"].shape, device=self.dev)
     self._acts.copy_(batch["actions"])

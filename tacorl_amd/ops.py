@@ -166,6 +166,14 @@ def pack_images(src, img_pitch, src_nchw, dst, n, Cc, H, W, src_offset=0):
          n, Cc, H, W, stream())
 
 
+def pack_images_batch(jobs, dst_dtype_flag, H, W):
+    """jobs: [(src_ptr, image_pitch_elems, dst_ptr, n_images)], NCHW fp32 (C = 3) -> NHWC, one launch
+    (H*W % 4 == 0, 16-byte aligned pointers, pitches % 4 == 0)."""
+    k = len(jobs)
+    call("tacorl_pack_images_batch", k, (C.c_void_p * k)(*[j[0] for j in jobs]), (C.c_long * k)(*[j[1] for j in jobs]),
+         (C.c_void_p * k)(*[j[2] for j in jobs]), int_array([j[3] for j in jobs]), dst_dtype_flag, H, W, stream())
+
+
 def _at(t, off):
     return C.c_void_p(t.data_ptr() + 4 * off)
 
