@@ -30,6 +30,8 @@ enum { TACORL_ACT_NONE = 0, TACORL_ACT_RELU = 1, TACORL_ACT_SILU = 2 };
 int tacorl_hip_version(void);
 int tacorl_hip_init(int device);             /* idempotent; checks the device is gfx950 */
 const char* tacorl_hip_last_error(void);
+/* tracing aid: marks[slot] = device wall clock (100 MHz ticks) when the stream reaches this point */
+int tacorl_time_mark(unsigned long long* marks, int slot, tacorl_stream_t stream);
 
 /* ---- primitives ------------------------------------------------------------------ */
 /* y = act(x W^T + b), optional pre-activation z.  Replaces nn.Linear (+F.silu / nn.ReLU):
@@ -259,6 +261,16 @@ int tacorl_pr_encoder_fused_supported(int D, int T, int H, int FF, int L);
 int tacorl_pr_encoder_fused(const float* emb, int ld_emb, const float* params, const void* params_bf16,
                             const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
                             tacorl_stream_t stream);
+/* The same launch extended by the posterior head and the plan sample: head = Wc pooled + bc with (Wc, bc) the
+ * composition of the two bias-only Linear layers after the pooling (fc, mean_fc: no activation between them;
+ * tacorl_pr_head_compose, weights only, off the dependent chain), std = softplus(var_raw) + min_std,
+ * plan = tanh(mean + eps * std)  (plan_recognition_transformer.py:89-104).  2A <= 64. */
+int tacorl_pr_encoder_fused_sample(const float* emb, int ld_emb, const float* params, const void* params_bf16,
+                                   const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
+                                   const float* Wc, const float* bc, const float* eps, float* head, float* plan,
+                                   int A, float min_std, tacorl_stream_t stream);
+int tacorl_pr_head_compose(const float* w_fc, const float* b_fc, const float* w_head, const float* b_head,
+                           float* Wc, float* bc, int D, int FC, int A2, tacorl_stream_t stream);
 int tacorl_mean_over_t(const float* x, float* out, int B, int T, int D, tacorl_stream_t stream);
 /* head [B][2A] = [mean | var_raw]; std = softplus(var_raw)+min_std; plan = tanh(mean + eps*std). */
 int tacorl_pr_sample(const float* head, const float* eps, float* plan, float* mu_out, float* std_out,

@@ -1,6 +1,7 @@
 import sys, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tacorl_amd import _lib, blocks, ops
+if os.environ.get("TACORL_SCRATCH_LIB"): _lib.LIB_PATH = os.environ["TACORL_SCRATCH_LIB"]
 dev = torch.device('cuda:0')
 H = W = 84
 n = [int(x) for x in (sys.argv[1:] or ["4096", "256", "512", "512"])]
@@ -23,3 +24,15 @@ for _ in range(20): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 print(f"imgs {sum(n)} ms {ms:.4f} TF {sum(n)*13.918e6/ms/1e9:.1f}")
+# phase stamps (only in a -DEF_STAMPS build of the library)
+import ctypes as C
+L = _lib.lib()
+if hasattr(L, "tacorl_ef_stamps_read"):
+    buf = (C.c_ulonglong * 16)()
+    L.tacorl_ef_stamps_read(buf, 1)
+    run(); torch.cuda.synchronize()
+    L.tacorl_ef_stamps_read(buf, 0)
+    names = ["prologue", "dma issue", "conv1", "barrier1", "conv2", "barrier2", "conv3 mfma", "soft-argmax", "fc tail", "img wait+barrier"]
+    tot = sum(buf[:10])
+    for k, nm in enumerate(names): print(f"{nm:18s} {buf[k]:9d} clk  {100.0 * buf[k] / tot:5.1f} %")
+    print("total clk", tot)

@@ -24,6 +24,7 @@ _SIGS = {
     "tacorl_hip_version": (_i, []),
     "tacorl_hip_init": (_i, [_i]),
     "tacorl_hip_last_error": (C.c_char_p, []),
+    "tacorl_time_mark": (_i, [_p, _i, _p]),
     "tacorl_linear_fwd": (_i, [_i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "tacorl_linear_add_fwd_ws_bytes": (_sz, [_i, _p, _i, _i]),
     "tacorl_linear_add_fwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _sz, _p]),
@@ -34,6 +35,8 @@ _SIGS = {
     "tacorl_transpose_to_bf16": (_i, [_p, _p, _i, _i, _p]),
     "tacorl_pr_encoder_fused_supported": (_i, [_i, _i, _i, _i, _i]),
     "tacorl_pr_encoder_fused": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "tacorl_pr_encoder_fused_sample": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _f, _p]),
+    "tacorl_pr_head_compose": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_to_bf16_batch": (_i, [_i, _p, _p, _p, _p]),
     "tacorl_mlp_bwd_fused_supported": (_i, [_i, _i, _p, _i, _i]),
     "tacorl_mlp_bwd_fused_ws_bytes": (_sz, [_i, _p, _i, _p]),

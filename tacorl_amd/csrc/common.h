@@ -16,6 +16,27 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // activation ids shared with the host side (include/tacorl_hip.h)
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
 
+// Reductions over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), result in every lane: quad xor 1, quad
+// xor 2, row_half_mirror, row_mirror - four VALU-side lane exchanges, no LDS crossbar (ds_bpermute) round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float x) {
+  x += dpp_move<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp_move<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp_move<0x141>(x);  // row_half_mirror: the other quad of this half row
+  x += dpp_move<0x140>(x);  // row_mirror: the other half row
+  return x;
+}
+__device__ __forceinline__ float row16_max(float x) {
+  x = fmaxf(x, dpp_move<0xB1>(x));
+  x = fmaxf(x, dpp_move<0x4E>(x));
+  x = fmaxf(x, dpp_move<0x141>(x));
+  x = fmaxf(x, dpp_move<0x140>(x));
+  return x;
+}
+
 __device__ __forceinline__ float act_apply(int act, float z) {
   if (act == ACT_RELU) return z > 0.f ? z : 0.f;
   if (act == ACT_SILU) return z / (1.f + expf(-z));

@@ -33,6 +33,16 @@ extern "C" int tacorl_hip_init(int device) {
   return TACORL_OK;
 }
 
+// Device-side time mark (constant 100 MHz clock): one 1-thread launch that stores the clock into
+// marks[slot].  Placed between the launches of a captured step it gives the branch timeline of a graph
+// replay without a profiler attached (rocprofv3's kernel trace perturbs the branch overlap).
+__global__ void time_mark_kernel(unsigned long long* marks, int slot) { marks[slot] = wall_clock64(); }
+extern "C" int tacorl_time_mark(unsigned long long* marks, int slot, tacorl_stream_t stream) {
+  if (!marks || slot < 0) FAIL(TACORL_EINVAL, "time_mark: bad arguments");
+  hipLaunchKernelGGL(time_mark_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, marks, slot);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
 static inline long al4(long x) { return (x + 3) & ~3L; }
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 

@@ -107,8 +107,12 @@ extern "C" int tacorl_encoder_pack_weights(int nprob, const float* const* params
 // shared destination register).  Inline asm is invisible to hipcc's hazard recogniser, so the chain
 // brackets itself: s_nop before the first MFMA (VALU-written accumulator) and after the last one
 // (MFMA result read by VALU) - cdna_hip_programming.md section 5.7.
+#if EF_VAR == 2
+#define MFMA_AW(acc, wfrag, bfrag) asm volatile("" : "+v"(acc) : "a"(wfrag), "v"(bfrag))
+#else
 #define MFMA_AW(acc, wfrag, bfrag) \
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wfrag), "v"(bfrag))
+#endif
 #define MFMA_CHAIN_BEGIN(acc) asm volatile("s_nop 1" : "+v"(acc))
 #define MFMA_CHAIN_END(acc) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc))
 
@@ -132,6 +136,33 @@ struct EFGeom {
                              OH3 >= 1 && OW3 >= 1;
 };
 
+// Phase timing for kernel work (scratch builds with -DEF_STAMPS only; the product build has no trace of it):
+// wave 0 of block 0 accumulates shader-clock deltas per phase, read back with tacorl_ef_stamps_read.
+#ifndef EF_VAR
+#define EF_VAR 0
+#endif
+#ifdef EF_STAMPS
+__device__ unsigned long long ef_stamps[16];
+#define STAMP(k)                                                    \
+  do {                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                      \
+      const unsigned long long t_ = clock64();                      \
+      atomicAdd(&ef_stamps[k], t_ - t_prev);                        \
+      t_prev = t_;                                                  \
+    }                                                               \
+  } while (0)
+extern "C" int tacorl_ef_stamps_read(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ef_stamps), sizeof(ef_stamps)) != hipSuccess) return TACORL_ELAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ef_stamps), z, sizeof(z)) != hipSuccess) return TACORL_ELAUNCH;
+  }
+  return TACORL_OK;
+}
+#else
+#define STAMP(k)
+#endif
+
 template <int H_, int W_>
 __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
   typedef EFGeom<H_, W_> G;
@@ -147,6 +178,9 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
   const EFProblem P = a_.p[pi];
   const int worker = blockIdx.x - P.first_block, nworkers = P.nblocks;
   if (worker >= P.n_img) return;
+#ifdef EF_STAMPS
+  unsigned long long t_prev = clock64();
+#endif
 
   unsigned char* act1 = lds + 2 * a.lds_img;
   const int npx1 = a.OH1 * a.OW1, npx2 = a.OH2 * a.OW2, npx3 = a.OH3 * a.OW3;
@@ -191,10 +225,19 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     for (int i = 0; i < EF_MAXCH; i++) {
       const int c0 = i * 256 + w * 64;  // first chunk of this wave-instruction (wave-uniform)
       if (c0 < n16) {
-        if (c0 + l < n16)
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(src + (long)(c0 + l) * 16),
-              (__attribute__((address_space(3))) void*)(dstb + c0 * 16), 16, 0, 0);
+        if (c0 + l < n16) {
+          // inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in the loop hipcc degrades every
+          // LDS wait of the conv phases to lgkmcnt(0) (it cannot tell the DMA's LDS writes from the fragment
+          // reads), which exposes the full LDS latency at each tile; the ordering against the readers of this
+          // buffer is explicit anyway (vmcnt(0) + barrier at the end of the image).
+          const unsigned lds_off = __builtin_amdgcn_readfirstlane(
+              (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)(dstb + c0 * 16));  // wave-uniform
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep)
+                       : "v"(src + (long)(c0 + l) * 16), "s"(lds_off)
+                       : "memory");
+        }
       }
     }
   };
@@ -206,12 +249,14 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
   dma_load(cur, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  STAMP(0);  // prologue: weights to registers, first image
 
   while (true) {
     const int slot = it & (EF_CHUNK - 1);
     const long nxt = cur + nworkers;
     const bool has_next = nxt < P.n_img;
     if (has_next) dma_load(nxt, buf ^ 1);  // that buffer was last read by the previous image's conv1
+    STAMP(1);  // DMA issue
 
     // Every conv phase is software-pipelined by hand: the LDS reads of the next half-tile are issued
     // before the MFMA chain of the current one (one wave per SIMD: nothing else hides LDS latency).
@@ -228,9 +273,13 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #pragma unroll
         for (int s = 0; s < 6; s++) {
           const int off = (s / 3) * 4 * G::W * 6 + (s % 3) * 16;  // compile-time immediate
+#if EF_VAR == 1
+          bf[s] = u32x4{(unsigned)(size_t)base, (unsigned)off, 0u, 0u};
+#else
           const u32x2 lo = *reinterpret_cast<const u32x2*>(base + off);
           const u32x2 hi = *reinterpret_cast<const u32x2*>(base + off + 8);
           bf[s] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+#endif
         }
       };
       auto tile1 = [&](int mt, u32x4 (&bf)[6]) {
@@ -266,8 +315,10 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         if (w + 4 * (i + 1) < NT1 && i + 1 < PER1) tile1(w + 4 * (i + 1), fb);
       }
     }
+    STAMP(2);  // conv1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    STAMP(3);  // barrier after conv1
 
     // ------------------------------------------------ conv2: 4x4 stride 2, 32 -> 64 (wave = 16 channels)
     {
@@ -281,7 +332,11 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
           const int s = 8 * h + i, ky = s >> 2, kx = s & 3;
+#if EF_VAR == 1
+          bf[i] = u32x4{(unsigned)(size_t)base, (unsigned)s, 0u, 0u};
+#else
           bf[i] = *reinterpret_cast<const u32x4*>(base + (ky * a.OW1 + kx) * ACT1_STRIDE);
+#endif
         }
       };
       u32x4 fa[8], fb[8];
@@ -306,8 +361,10 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         }
       }
     }
+    STAMP(4);  // conv2
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    STAMP(5);  // barrier after conv2
 
     // ------------------------------------------------ conv3: 3x3 stride 1, 64 -> 64 + soft-argmax in registers
     {
@@ -324,7 +381,11 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #pragma unroll
         for (int i = 0; i < 9; i++) {
           const int s = 9 * h + i, tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
+#if EF_VAR == 1
+          bf[i] = u32x4{(unsigned)(size_t)base, (unsigned)s, 0u, 0u};
+#else
           bf[i] = *reinterpret_cast<const u32x4*>(base + (ky * a.OW2 + kx) * ACT2_STRIDE + 64 * (s & 1));
+#endif
         }
       };
       u32x4 fa[9], fb[9];
@@ -350,6 +411,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #pragma unroll
         for (int q = 0; q < 4; q++) v3[mt][q] = ok ? fmaxf(acc[q], 0.f) * inv_t : -INFINITY;
       }
+      STAMP(6);  // conv3 MFMA part
       // pass 1: per-channel max over the image (tiles in registers, then the 16 pixel lanes)
       float mx[4], se[4], sx[4], sy[4];
 #pragma unroll
@@ -357,9 +419,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         float m = v3[0][q];
 #pragma unroll
         for (int mt = 1; mt < NT3; mt++) m = fmaxf(m, v3[mt][q]);
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        mx[q] = m; se[q] = 0.f; sx[q] = 0.f; sy[q] = 0.f;
+        mx[q] = row16_max(m); se[q] = 0.f; sx[q] = 0.f; sy[q] = 0.f;
       }
       // pass 2: exp and the three sums (exp(-inf) = 0 masks the padded pixels)
 #pragma unroll
@@ -370,11 +430,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
           se[q] += e; sx[q] += e * fx[mt]; sy[q] += e * fy[mt];
         }
 #pragma unroll
-      for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          se[q] += __shfl_xor(se[q], o, 64); sx[q] += __shfl_xor(sx[q], o, 64); sy[q] += __shfl_xor(sy[q], o, 64);
-        }
+      for (int q = 0; q < 4; q++) { se[q] = row16_sum(se[q]); sx[q] = row16_sum(sx[q]); sy[q] = row16_sum(sy[q]); }
       if (r16 == 0) {
         // features interleaved [x_c, y_c]; channels 16 w + 4 g + q
         __bf16* dst = reinterpret_cast<__bf16*>(sa + slot * SA_STRIDE) + 2 * (16 * w + 4 * g);
@@ -390,6 +446,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       }
     }
 
+    STAMP(7);  // soft-argmax
     // ------------------------------------------------ FC tail once per chunk
     const bool chunk_done = (slot == EF_CHUNK - 1) || !has_next;
     if (chunk_done) {
@@ -436,9 +493,11 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         }
       }
     }
+    STAMP(8);  // FC tail (every 8th image)
     if (!has_next) break;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next image has landed
     __syncthreads();                                  // ... and everyone's; sa/h1 free for the next chunk
+    STAMP(9);  // next image landed + end-of-image barrier
     cur = nxt; it++; buf ^= 1;
   }
 }

@@ -63,6 +63,17 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
   const int p = blockIdx.y, m0 = blockIdx.x * BMF, M = a.M[p];
   if (m0 >= M) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int n0 = 64 * w;
+  bf16x8 B[8][4];
+  auto load_layer = [&](int l) {  // every weight fragment of the layer in flight at once (K <= 256)
+    const int K = a.dims[l], N = a.dims[l + 1];
+    const __bf16* Wb = a.pbf[p] + a.woff[l];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) B[ks][nt] = load_w(Wb, K, N, n0 + 16 * nt + i, 32 * ks + 8 * g);
+  };
+  if (n0 < a.dims[1]) load_layer(0);  // travels while the input rows are staged
   // zero both buffers once: padded K columns are multiplied by zero weights and must stay finite
   for (int e = tid; e < 2 * BMF * XP / 8; e += 256) reinterpret_cast<f32x4*>(X)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
@@ -85,25 +96,20 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
   // LDS-only barrier: the fp32 activation rows written for the backward stay in flight across layers
   // (nothing in this kernel reads them back), __syncthreads() would drain them at every layer
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  const int n0 = 64 * w;
-  bf16x8 B[8][4];
-  auto load_layer = [&](int l) {  // every weight fragment of the layer in flight at once (K <= 256)
-    const int K = a.dims[l], N = a.dims[l + 1];
-    const __bf16* Wb = a.pbf[p] + a.woff[l];
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++)
-#pragma unroll
-      for (int nt = 0; nt < 4; nt++) B[ks][nt] = load_w(Wb, K, N, n0 + 16 * nt + i, 32 * ks + 8 * g);
-  };
-  if (n0 < a.dims[1]) load_layer(0);
   int cur = 0;
   for (int l = 0; l < a.L; l++) {
     const int K = a.dims[l], N = a.dims[l + 1], KS = (K + 31) / 32, act = a.acts[l];
     const float* bias = a.params[p] + a.boff[l];
     const __bf16* xin = X + cur * BMF * XP;
     __bf16* xout = X + (cur ^ 1) * BMF * XP;
-    f32x4 acc[MTF][4];
+    f32x4 acc[MTF][4], bvv[4];
+    const bool vec = (N & 3) == 0;
     if (n0 < N) {  // wave-uniform: this wave owns output columns [n0, n0 + 64)
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) {  // bias vectors travel under the MFMA loop (clamped address, masked below)
+        const int col = n0 + 16 * nt + 4 * g;
+        bvv[nt] = *reinterpret_cast<const f32x4*>(bias + (vec && col < N ? col : 0));
+      }
 #pragma unroll
       for (int mt = 0; mt < MTF; mt++)
 #pragma unroll
@@ -129,13 +135,12 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
     if (n0 < N) {
       float* zb = a.zoff[p][l] >= 0 ? a.act[p] + a.zoff[p][l] : nullptr;
       float* yb = a.act[p] + a.yoff[p][l];
-      const bool vec = (N & 3) == 0;
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) {
         const int col = n0 + 16 * nt + 4 * g;  // this lane's 4 consecutive columns
         if (n0 + 16 * nt >= N) continue;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (vec && col < N) bv = *reinterpret_cast<const f32x4*>(bias + col);
+        if (vec && col < N) bv = bvv[nt];
         else {
 #pragma unroll
           for (int r = 0; r < 4; r++) bv[r] = col + r < N ? bias[col + r] : 0.f;
@@ -209,6 +214,18 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
   const int p = blockIdx.y, m0 = blockIdx.x * BMF, M = a.M[p];
   if (m0 >= M) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int n0 = 64 * w;  // this wave's output columns (input features of the layer)
+  bf16x8 B[8][4];
+  auto load_layer = [&](int l) {
+    const int KO = a.dims[l], NP = (a.dims[l + 1] + 7) / 8 * 8;  // outputs, (padded) reduction length
+    const __bf16* T = a.wt[p] + a.wtoff[l];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) B[ks][nt] = load_w(T, NP, KO, n0 + 16 * nt + i, 32 * ks + 8 * g);
+  };
+  const int l_last = a.d_x[p] ? 0 : 1;  // layer 0's dgrad only if the input gradient is wanted
+  if (a.L - 1 >= l_last && n0 < a.dims[a.L - 1]) load_layer(a.L - 1);  // travels while d_out is staged
   for (int e = tid; e < 2 * BMF * XP / 8; e += 256) reinterpret_cast<f32x4*>(X)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   {  // stage dZ of the last layer (= d_out rows) as bf16
@@ -221,25 +238,27 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
   }
   __syncthreads();
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  const int n0 = 64 * w;  // this wave's output columns (input features of the layer)
-  bf16x8 B[8][4];
-  auto load_layer = [&](int l) {
-    const int KO = a.dims[l], NP = (a.dims[l + 1] + 7) / 8 * 8;  // outputs, (padded) reduction length
-    const __bf16* T = a.wt[p] + a.wtoff[l];
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++)
-#pragma unroll
-      for (int nt = 0; nt < 4; nt++) B[ks][nt] = load_w(T, NP, KO, n0 + 16 * nt + i, 32 * ks + 8 * g);
-  };
-  const int l_last = a.d_x[p] ? 0 : 1;  // layer 0's dgrad only if the input gradient is wanted
-  if (a.L - 1 >= l_last && n0 < a.dims[a.L - 1]) load_layer(a.L - 1);
   int cur = 0;
   for (int l = a.L - 1; l >= l_last; l--) {
     const int KO = a.dims[l], NR = a.dims[l + 1], KS = (NR + 31) / 32;
     const __bf16* xin = X + cur * BMF * XP;
     __bf16* xout = X + (cur ^ 1) * BMF * XP;
-    f32x4 acc[MTF][4];
+    f32x4 acc[MTF][4], svv[MTF][4];
+    const int pact = l > 0 ? a.acts[l - 1] : ACT_NONE;
+    const float* src = (l > 0 && a.srcoff[p][l - 1] >= 0) ? a.act[p] + a.srcoff[p][l - 1] : nullptr;
+    const int ldout = l > 0 ? KO : a.ldd;
+    const bool vec = (KO & 3) == 0 && (ldout & 3) == 0;
     if (n0 < KO) {
+      if (src && vec) {  // the activation-derivative sources travel under the MFMA loop (clamped, masked below)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+          for (int mt = 0; mt < MTF; mt++) {
+            const int col = n0 + 16 * nt + 4 * g, row = m0 + 16 * mt + i;
+            const bool ok = row < M && col < KO;
+            svv[mt][nt] = *reinterpret_cast<const f32x4*>(src + (ok ? (long)row * KO + col : 0));
+          }
+      }
 #pragma unroll
       for (int mt = 0; mt < MTF; mt++)
 #pragma unroll
@@ -260,11 +279,7 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
     }
     if (l - 1 >= l_last && n0 < a.dims[l - 1]) load_layer(l - 1);
     if (n0 < KO) {
-      const int pact = l > 0 ? a.acts[l - 1] : ACT_NONE;
-      const float* src = (l > 0 && a.srcoff[p][l - 1] >= 0) ? a.act[p] + a.srcoff[p][l - 1] : nullptr;
       float* out = l > 0 ? a.dz[p] + a.dzoff[p][l - 1] : a.d_x[p];
-      const int ldout = l > 0 ? KO : a.ldd;
-      const bool vec = (KO & 3) == 0 && (ldout & 3) == 0;
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) {
         const int col = n0 + 16 * nt + 4 * g;  // this lane's 4 consecutive columns (D = W^T-frag x dZ-frag)
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
           f32x4 v = acc[mt][nt];
           if (rok && src) {
             if (vec && col < KO) {
-              const f32x4 sv = *reinterpret_cast<const f32x4*>(src + (long)(m0 + row) * KO + col);
+              const f32x4 sv = svv[mt][nt];
 #pragma unroll
               for (int r = 0; r < 4; r++) v[r] *= act_grad_fast(pact, sv[r]);
             } else {

@@ -32,6 +32,14 @@ struct PrArgs {
   long pos;             // position_embeddings offset
   PrLayerOff l[PR_MAXL];
   int ld_emb, B, FF, L;
+  // optional posterior head + sample in the same launch (all null / 0 when unused)
+  const float* Wc;   // [2A][32] composed fc -> mean_fc weight (tacorl_pr_head_compose)
+  const float* bc;   // [2A]
+  const float* eps;  // [B][A]
+  float* head;       // [B][2A]  (mean | var_raw)
+  float* plan;       // [B][A]   tanh(mean + eps * std)
+  int A;
+  float min_std;
 };
 
 __device__ __forceinline__ bf16x8 cvt8(const float* p) {
@@ -206,7 +214,50 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; r++) s[r] *= (1.0f / PR_T);
       *reinterpret_cast<f32x4*>(a.pooled + (long)b * PR_D + 16 * nt + 4 * g) = s;
+      if (a.Wc) *reinterpret_cast<f32x4*>(qkv + 16 * nt + 4 * g) = s;
     }
+  }
+  if (!a.Wc) return;
+  // ---- posterior head on the pooled vector: head = Wc pooled + bc (lane j = output j), then
+  // std = softplus(var_raw) + min_std, plan = tanh(mean + eps * std)  (plan_recognition_transformer.py:89-104)
+  lds_sync();
+  const int A = a.A, j = lane < 2 * A ? lane : 0;
+  float h = a.bc[j];
+#pragma unroll
+  for (int d = 0; d < PR_D; d += 4) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.Wc + j * PR_D + d), pv = *reinterpret_cast<const f32x4*>(qkv + d);
+    h += wv[0] * pv[0] + wv[1] * pv[1] + wv[2] * pv[2] + wv[3] * pv[3];
+  }
+  if (lane < 2 * A) a.head[(long)b * 2 * A + lane] = h;
+  const float vr = __shfl(h, (lane + A) & 63, 64);
+  if (lane < A) {
+    const float sd = (vr > 20.f ? vr : log1pf(expf(vr))) + a.min_std;
+    a.plan[(long)b * A + lane] = tanhf(h + a.eps[(long)b * A + lane] * sd);
+  }
+}
+
+// Wc = W_head W_fc ([2A][D]), bc = W_head b_fc + b_head: the two bias-only Linear layers after the time pooling
+// (fc: D -> FC, mean_fc: FC -> 2A, no activation between them) are one affine map.  Weights only, so it runs off
+// the dependent chain; fixed reduction order (deterministic).  grid = 2A blocks of 256 threads, D = 32.
+__global__ __launch_bounds__(256) void pr_head_compose_kernel(const float* __restrict__ w_fc, const float* __restrict__ b_fc,
+                                                              const float* __restrict__ w_head, const float* __restrict__ b_head,
+                                                              float* __restrict__ Wc, float* __restrict__ bc, int FC) {
+  __shared__ float part[8][PR_D + 1];
+  const int j = blockIdx.x, d = threadIdx.x & 31, fg = threadIdx.x >> 5;
+  float acc = 0.f, accb = 0.f;
+  for (int f = fg; f < FC; f += 8) {
+    const float wh = w_head[(long)j * FC + f];
+    acc += wh * w_fc[(long)f * PR_D + d];
+    if (d == 0) accb += wh * b_fc[f];
+  }
+  part[fg][d] = acc;
+  if (d == 0) part[fg][PR_D] = accb;
+  __syncthreads();
+  if (threadIdx.x <= PR_D) {
+    float t = 0.f;
+    for (int q = 0; q < 8; q++) t += part[q][threadIdx.x];
+    if (threadIdx.x < PR_D) Wc[j * PR_D + threadIdx.x] = t;
+    else bc[j] = t + b_head[j];
   }
 }
 
@@ -218,9 +269,10 @@ extern "C" int tacorl_pr_encoder_fused_supported(int D, int T, int H, int FF, in
 // offsets: [position_embeddings, then per layer: in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias,
 // linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias]
 // (element offsets into params / params_bf16, each a multiple of 4).
-extern "C" int tacorl_pr_encoder_fused(const float* emb, int ld_emb, const float* params, const void* params_bf16,
-                                       const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
-                                       tacorl_stream_t stream) {
+static int pr_encoder_fused_launch(const float* emb, int ld_emb, const float* params, const void* params_bf16,
+                                   const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
+                                   const float* Wc, const float* bc, const float* eps, float* head, float* plan, int A,
+                                   float min_std, tacorl_stream_t stream) {
   if (!tacorl_pr_encoder_fused_supported(D, T, H, FF, L) || ld_emb % 4 || B < 1) return TACORL_EINVAL;
   if (((uintptr_t)emb | (uintptr_t)params | (uintptr_t)params_bf16 | (uintptr_t)pooled) & 15) return TACORL_EINVAL;
   PrArgs a{};
@@ -232,6 +284,31 @@ extern "C" int tacorl_pr_encoder_fused(const float* emb, int ld_emb, const float
       if (q[k] % 4) return TACORL_EINVAL;
     a.l[l] = PrLayerOff{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]};
   }
+  if (Wc) {
+    if (!bc || !eps || !head || !plan || A < 1 || 2 * A > 64 || ((uintptr_t)Wc & 15)) return TACORL_EINVAL;
+    a.Wc = Wc; a.bc = bc; a.eps = eps; a.head = head; a.plan = plan; a.A = A; a.min_std = min_std;
+  }
   hipLaunchKernelGGL(pr_encoder_fused_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+extern "C" int tacorl_pr_encoder_fused(const float* emb, int ld_emb, const float* params, const void* params_bf16,
+                                       const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
+                                       tacorl_stream_t stream) {
+  return pr_encoder_fused_launch(emb, ld_emb, params, params_bf16, offsets, pooled, B, D, T, H, FF, L, nullptr, nullptr,
+                                 nullptr, nullptr, nullptr, 0, 0.f, stream);
+}
+extern "C" int tacorl_pr_encoder_fused_sample(const float* emb, int ld_emb, const float* params, const void* params_bf16,
+                                              const long* offsets, float* pooled, int B, int D, int T, int H, int FF,
+                                              int L, const float* Wc, const float* bc, const float* eps, float* head,
+                                              float* plan, int A, float min_std, tacorl_stream_t stream) {
+  if (!Wc) return TACORL_EINVAL;
+  return pr_encoder_fused_launch(emb, ld_emb, params, params_bf16, offsets, pooled, B, D, T, H, FF, L, Wc, bc, eps, head,
+                                 plan, A, min_std, stream);
+}
+extern "C" int tacorl_pr_head_compose(const float* w_fc, const float* b_fc, const float* w_head, const float* b_head,
+                                      float* Wc, float* bc, int D, int FC, int A2, tacorl_stream_t stream) {
+  if (D != PR_D || FC < 1 || A2 < 1 || !w_fc || !b_fc || !w_head || !b_head || !Wc || !bc) return TACORL_EINVAL;
+  hipLaunchKernelGGL(pr_head_compose_kernel, dim3(A2), dim3(256), 0, (hipStream_t)stream, w_fc, b_fc, w_head, b_head, Wc, bc,
+                     FC);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }

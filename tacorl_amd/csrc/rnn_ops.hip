@@ -40,15 +40,24 @@ struct RnnArgs {
 struct RnnBatch { RnnArgs p[RNN_MAXP]; };
 
 template <int RB_M, int RB_N, int RB_S>
-__global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnBatch ab) {
-  const RnnArgs a = ab.p[blockIdx.z];  // by value: keeps the fields in SGPRs (a reference re-loads them in the K loop)
+__global__ __launch_bounds__(256) void rnn_gemm_kernel(RnnBatch ab, int MT, int NT, int NTX) {
+  // XCD-aware tile map (1-D grid of 8 * MT * NTX * nprob workgroups): blocks b and b + 8 share an XCD and its
+  // 4 MiB L2, so XCD b % 8 owns the N tiles [NTX (b % 8), NTX (b % 8 + 1)) of every problem - one eighth of
+  // each weight matrix (3 x 1 MiB for the three 2048 x 2048 matrices of a wavefront launch), which then stays
+  // L2-resident from one recurrent step's launch to the next instead of being re-fetched from the Infinity
+  // Cache by every XCD.  Inside an XCD the M tiles of one N tile are adjacent (they share the weight rows).
+  // Placement is a speed matter only: any block -> XCD assignment computes the same result.
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int mt = jx % MT, rx = jx / MT, ntile = xcd * NTX + rx % NTX;
+  if (ntile >= NT) return;
+  const RnnArgs a = ab.p[rx / NTX];  // by value: keeps the fields in SGPRs (a reference re-loads them in the K loop)
   constexpr int STAGE_BYTES = (RB_M + RB_N) * ROW_BYTES;
   constexpr int DMA_PER_WAVE = (RB_M + RB_N) / 4 / 4;  // wave-instructions per stage and wave (4 rows each)
   constexpr int MI = RB_M / 64, NI = RB_N / 16;        // 16x16 tiles per wave
   static_assert((RB_M + RB_N) % 16 == 0 && RB_M % 64 == 0 && RB_N % 16 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * RB_M, n0 = blockIdx.y * RB_N;
+  const int m0 = mt * RB_M, n0 = ntile * RB_N;
   const int nk = a.K / RB_K;
 
   auto issue = [&](int kt, int slot) {
@@ -133,7 +142,8 @@ int launch_ring(const RnnBatch& ab, int nprob, hipStream_t st) {
                             hipSuccess ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
   const RnnArgs& a = ab.p[0];
-  hipLaunchKernelGGL(kern, dim3((a.M + RB_M - 1) / RB_M, a.N / RB_N, nprob), dim3(256), lds, st, ab);
+  const int MT = (a.M + RB_M - 1) / RB_M, NT = a.N / RB_N, NTX = (NT + 7) / 8;
+  hipLaunchKernelGGL(kern, dim3(8 * MT * NTX * nprob), dim3(256), lds, st, ab, MT, NT, NTX);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 template <int RB_M, int RB_N, int RB_S>

@@ -430,10 +430,12 @@ class ACEngine:
         gs = 1.0 / self.world
         if not encoded:
             self._encode_all()
+        ops.mark("a:start")
         self._refresh_bf16()
         self._prepack_backward()
         self._assemble_states()
         self._policy_fwd()
+        ops.mark("a:policy_fwd")
         head_cur, head_next = self._head("a"), self._head("a_nx")
         g = (lambda k: nz[k]) if self.dg else (lambda k: None)
         # actor rsample on obs, critic-target sample on next_obs, CQL samples on both
@@ -451,8 +453,10 @@ class ACEngine:
         # alpha: loss, gradient, Adam step (alpha is read post-step below; SURVEY 8a note 2)
         call("tacorl_alpha_loss", ptr(self.logp_pi), B, ptr(self.log_alpha.param), float(hp["target_entropy"]), gs,
              ptr(self.log_alpha.grad), ptr(self.logs), ops.stream())
+        ops.mark("a:alpha")
         if getattr(self, "_prepacked", False):  # the side branch ends inside this phase
             torch.cuda.current_stream().wait_stream(self._pack_stream)
+        ops.mark("a:end")
 
     def phase_b(self, bc_phase, optimize=True):
         B, n, A, Ac, hp, nz = self.B, self.n, self.A, self.Ac, self.hp, self.noise
@@ -466,6 +470,7 @@ class ACEngine:
         if getattr(self, "action_ready", None) is not None:
             torch.cuda.current_stream().wait_event(self.action_ready)
             self.action_ready = None
+        ops.mark("b:start")
         with ops.copy_batch():  # one launch; rows [0,B) of the Q input take the data action straight from its source
             ops.copy_cols(self.action, 0, A, self.acts_main, 0, A, B, A)
             for k in ("q1", "q2"):
@@ -497,6 +502,7 @@ class ACEngine:
              float(hp["discount"]), float(hp["reward_scale"]), float(hp["temp"]), float(hp["cons_w"]),
              float(hp["gap"]), int(hp["deterministic_backup"]), gs, ptr(lap.grad), ptr(self.logs), ptr(self.cql_ws),
              self.cql_ws.numel(), ops.stream())
+        ops.mark("b:q_fwd+cql")
         # ---- actor backward: independent of the critic backward until the goal encoders, so it runs on a
         # side stream (a parallel branch of the captured graph); both are chains of small launches that
         # fill only part of the chip on their own
@@ -506,6 +512,7 @@ class ACEngine:
         self._bwd_stream.wait_stream(main_stream)
         with torch.cuda.stream(self._bwd_stream):
             self._actor_backward(bc_phase, head_cur, q1p, q2p, gs)
+            ops.mark("b:actor_bwd")
         # ---- critic backward through the Q MLPs; sum the broadcast embedding gradient over samples
         self._mlp_backward("q", [self.XQ["q1"], self.XQ["q2"]], self.ldq, [self.q1.head(), self.q2.head()],
                            [self.qact["q1"], self.qact["q2"]], [self.dq["q1"], self.dq["q2"]], 1,
@@ -513,9 +520,12 @@ class ACEngine:
                            self.ldq, [self.R, self.R], qd, qa)
         for k in ("q1", "q2"):
             ops.reduce_rows_mod(self.dXQ[k], 0, self.ldq, self.dS[k], 0, self.lds, B, self.E, 3 * n + 1)
+        ops.mark("b:critic_bwd")
         main_stream.wait_stream(self._bwd_stream)
         self._encoders_backward()
+        ops.mark("b:enc_bwd")
         self._join_wgrads()
+        ops.mark("b:end")
 
     def _mlp_backward(self, tag, xs, ldx, params, acts_buf, d_outs, ldo, grads, d_xs, ldd, M, dims, acts):
         """MLP backward.  bf16 mode: the input-gradient chain is ONE launch on the current stream and the
@@ -625,6 +635,7 @@ class ACEngine:
             for q, t in ((self.q1, self.tq1), (self.q2, self.tq2)):
                 items.append((q.param, q.grad, q.m, q.v, hp["critic_lr"], hp["clip"], q.step, t.param, hp["tau"]))
             ops.adam_step_batch(items)  # three launches for all blocks
+        ops.mark("c:adam")
 
     def _allreduce(self, tensors):
         if self.world > 1:

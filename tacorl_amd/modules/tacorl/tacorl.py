@@ -91,8 +91,11 @@ class TACORL(CQL_Offline):
         self.f_act = {c: torch.zeros(ops.encoder_act_layout(B * T, *hw[c])[1], device=dev) for c in self.all_modalities}
         npr = len(self.plan_recognition_modalities)
         self.pr_in = torch.zeros(B * T, 32 * npr, device=dev)
-        self.plan = torch.zeros(B, self.action_dim, device=dev)
-        self.reward = torch.zeros(B, device=dev)
+        # the sampled plan IS the RL action and the displacement flag IS reward and done (get_rl_batch,
+        # tacorl.py:142-179): alias the engine's transition buffers instead of copying into them every step
+        e = self.engine
+        assert e.action.shape == (B, self.action_dim) and e.action.dtype == torch.float32
+        self.plan, self.reward = e.action, e.reward
         # the frozen LMP encoder over the B*T window frames rides in the engine's encoder launches
         self.engine.extra_enc = [dict(cam=c, img=self.frames[c], net=self.lmp_net, out=self.f_out[c],
                                       act=self.f_act[c], n=B * T) for c in self.all_modalities]
@@ -136,6 +139,7 @@ class TACORL(CQL_Offline):
                 self.acts = torch.zeros(B, T, 7, device=self.dev)
             self.acts.copy_(batch["actions"])
         self.reward.copy_(batch["disp"] == 1)
+        e.done.copy_(self.reward)
         e.set_noise(noise)
         return B, T, hw
 
@@ -147,25 +151,36 @@ class TACORL(CQL_Offline):
         """Graph-capturable: all encoders (frozen LMP + actor/critics/targets) -> plan recognition -> plan ->
         AD loss -> first phase of the CQL update (up to the alpha gradient)."""
         e = self.engine
-        e._encode_all()
-        # Plan recognition -> plan -> (action-decoder loss) only need the frame embeddings; the first phase of
-        # the CQL update does not need the plan.  They run as parallel branches of the step's graph:
-        #   side stream 1: PR transformer -> sampled plan -> RL "action"/reward staged -> event action_ready
-        #   side stream 2 (forked after the plan): frozen action-decoder forward + loss (logging only)
-        #   main stream  : policy / sampling / alpha (phase_a); phase_b waits for action_ready
+        ops.mark("front:start")
         if getattr(self, "_pr_stream", None) is None:
             self._pr_stream, self._side_stream = torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)
         main = torch.cuda.current_stream()
+        mods = self.plan_recognition_modalities
+        # one camera: the frame embeddings are the transformer's input as they stand
+        emb, ld = (self.f_out[mods[0]], 32) if len(mods) == 1 else (self.pr_in, self.pr_in.shape[1])
+        prepared = self.pr.fused_inference_ok(T, ld, self.compute)
+        if prepared:  # weight-only preparation of the frozen plan recognition, beside the image encoders
+            self._pr_stream.wait_stream(main)
+            with torch.cuda.stream(self._pr_stream):
+                self.pr.prepare_inference()
+        e._encode_all()
+        ops.mark("front:encoded")
+        # Plan recognition -> plan -> (action-decoder loss) only need the frame embeddings; the first phase of
+        # the CQL update does not need the plan.  They run as parallel branches of the step's graph:
+        #   side stream 1: PR transformer -> sampled plan (= the RL action, in place) -> event action_ready
+        #   side stream 2 (forked after the plan): frozen action-decoder forward + loss (logging only)
+        #   main stream  : policy / sampling / alpha (phase_a); phase_b waits for action_ready
         self._ad_join = None
         ad_on_side = with_ad and not (optimize and self.finetune_action_decoder)
         self._pr_stream.wait_stream(main)
         with torch.cuda.stream(self._pr_stream):
-            for j, c in enumerate(self.plan_recognition_modalities):
-                ops.copy_cols(self.f_out[c], 0, 32, self.pr_in, 32 * j, self.pr_in.shape[1], B * T, 32)
-            head = self.pr.forward(self.pr_in, self.pr_in.shape[1], B, T, self.compute, inference=True)
-            call("tacorl_pr_sample", ptr(head), ptr(self.eps_pr), ptr(self.plan), None, None, B, self.action_dim,
-                 float(self.pr.min_std), ops.stream())
-            e.load_transition(self.plan, self.reward, self.reward)
+            ops.mark("pr:start")
+            if len(mods) > 1:
+                for j, c in enumerate(mods):
+                    ops.copy_cols(self.f_out[c], 0, 32, self.pr_in, 32 * j, self.pr_in.shape[1], B * T, 32)
+            self.pr.forward(emb, ld, B, T, self.compute, inference=True, sample=(self.eps_pr, self.plan),
+                            prepared=prepared)
+            ops.mark("pr:plan")
             ready = torch.cuda.Event()
             ready.record(self._pr_stream)
             if with_ad and not ad_on_side:
@@ -176,7 +191,9 @@ class TACORL(CQL_Offline):
             # fill a fraction of the chip -> their own branch, joined at the end of the step
             self._side_stream.wait_event(ready)
             with torch.cuda.stream(self._side_stream):
+                ops.mark("ad:start")
                 self.ad.loss_step(self, self.acts, self.plan, B, T, False)
+                ops.mark("ad:end")
             self._ad_join = self._side_stream
         e.action_ready = ready
         e.phase_a(encoded=True)
@@ -227,6 +244,7 @@ class TACORL(CQL_Offline):
         def tail():
             e.phase_c(optimize)
             self._join_ad()
+            ops.mark("step:end")
 
         # split (multi-GPU) graphs: the frozen, logging-only action-decoder pass leaves the first segment
         # and runs as a side graph beside the all-reduces and the other segments

@@ -160,7 +160,9 @@ class ActionDecoderLogistic:
 
         acts = actions
         cams = module.action_decoder_modalities
-        if cams == module.plan_recognition_modalities:
+        if len(cams) == 1:  # one camera: the frame embeddings as the encoder wrote them
+            emb, ld = module.f_out[cams[0]], 32
+        elif cams == module.plan_recognition_modalities:  # already concatenated for the plan recognition
             emb, ld = module.pr_in, module.pr_in.shape[1]
         else:
             if getattr(module, "_ad_in", None) is None or module._ad_in.shape[0] != B * T:

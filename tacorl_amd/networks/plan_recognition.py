@@ -74,21 +74,44 @@ class PlanRecognition:
                                       "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")]
         return [self.blk.off[n][0] for n in names]
 
-    def forward(self, emb, ld_emb, B, T, compute, inference=False):
+    def fused_inference_ok(self, T, ld_emb, compute):
+        return bool(compute == ops.BF16 and self.pad == 0 and ld_emb % 4 == 0 and 2 * self.A <= 64
+                    and ops.L.lib().tacorl_pr_encoder_fused_supported(self.D, T, self.H, self.FF, self.L))
+
+    def prepare_inference(self):
+        """Weight-only preparation of the single-launch inference path: the bf16 mirror of the parameter block
+        and the composed posterior head (fc -> mean_fc is one affine map).  Depends on nothing a step computes,
+        so a caller can issue it beside the image encoders instead of on the plan's dependent chain."""
+        import ctypes as C
+        blk = self.blk
+        if getattr(self, "_pb", None) is None:
+            self._pb = torch.zeros(blk.param.numel(), device=self.dev, dtype=torch.bfloat16)
+            self._foff = (C.c_long * (1 + 12 * self.L))(*self._fused_offsets())
+            self._Wc = torch.zeros(2 * self.A, self.D, device=self.dev)
+            self._bc = torch.zeros(2 * self.A, device=self.dev)
+        n4 = blk.param.numel() // 4 * 4
+        call("tacorl_to_bf16_batch", 1, ops.ptr_array([blk.param]), ops.ptr_array([self._pb]), (C.c_long * 1)(n4),
+             ops.stream())
+        call("tacorl_pr_head_compose", blk.p("fc.weight"), blk.p("fc.bias"), blk.p("mean_fc.weight"), blk.p("mean_fc.bias"),
+             ptr(self._Wc), ptr(self._bc), self.D, self.FC, 2 * self.A, ops.stream())
+
+    def forward(self, emb, ld_emb, B, T, compute, inference=False, sample=None, prepared=False):
         """emb: device tensor/pointer of [B*T][ld_emb] per-frame embeddings (first D_in columns used).
         Returns the (B, 2A) head buffer [mean | var_raw].  inference=True (frozen network, no backward
-        follows): the encoder layers + time pooling run as one launch when the shape qualifies."""
+        follows): the encoder layers + time pooling run as one launch when the shape qualifies; with
+        sample=(eps, plan) the posterior head and plan = tanh(mean + eps * std) ride in that launch too
+        (prepared=True: prepare_inference() was already issued for the current weights)."""
         self._ensure(B, T)
         blk, D, R = self.blk, self.D, B * T
-        if (inference and compute == ops.BF16 and self.pad == 0 and ld_emb % 4 == 0
-                and ops.L.lib().tacorl_pr_encoder_fused_supported(D, T, self.H, self.FF, self.L)):
-            import ctypes as C
-            if getattr(self, "_pb", None) is None:
-                self._pb = torch.zeros(blk.param.numel(), device=self.dev, dtype=torch.bfloat16)
-                self._foff = (C.c_long * (1 + 12 * self.L))(*self._fused_offsets())
-            n4 = blk.param.numel() // 4 * 4
-            call("tacorl_to_bf16_batch", 1, ops.ptr_array([blk.param]), ops.ptr_array([self._pb]), (C.c_long * 1)(n4),
-                 ops.stream())
+        if inference and self.fused_inference_ok(T, ld_emb, compute):
+            if not prepared:
+                self.prepare_inference()
+            if sample is not None:
+                eps, plan = sample
+                call("tacorl_pr_encoder_fused_sample", ptr(emb), ld_emb, ptr(blk.param), ptr(self._pb), self._foff,
+                     ptr(self.pooled), B, D, T, self.H, self.FF, self.L, ptr(self._Wc), ptr(self._bc), ptr(eps),
+                     ptr(self.head), ptr(plan), self.A, float(self.min_std), ops.stream())
+                return self.head
             call("tacorl_pr_encoder_fused", ptr(emb), ld_emb, ptr(blk.param), ptr(self._pb), self._foff, ptr(self.pooled),
                  B, D, T, self.H, self.FF, self.L, ops.stream())
             self._lin(self.pooled, D, blk.p("fc.weight"), blk.p("fc.bias"), self.fc_out, B, D, self.FC, ACT_NONE, compute)
@@ -117,6 +140,10 @@ class PlanRecognition:
         self._lin(self.pooled, D, blk.p("fc.weight"), blk.p("fc.bias"), self.fc_out, B, D, self.FC, ACT_NONE, compute)
         self._lin(self.fc_out, self.FC, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.head, B, self.FC,
                   2 * self.A, ACT_NONE, compute)
+        if sample is not None:
+            eps, plan = sample
+            call("tacorl_pr_sample", ptr(self.head), ptr(eps), ptr(plan), None, None, B, self.A, float(self.min_std),
+                 ops.stream())
         return self.head
 
     # ------------------------------------------------------------------------ backward

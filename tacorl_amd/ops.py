@@ -178,6 +178,37 @@ def _at(t, off):
     return C.c_void_p(t.data_ptr() + 4 * off)
 
 
+# ---- tracing aid: device time marks between the launches of a step (off unless trace_marks() is called)
+_marks = None
+
+
+def trace_marks(device, slots=64):
+    """Switch time marks on: every mark(name) call appends one 1-thread launch that stores the device clock.
+    Returns a reader: reader() -> [(name, microseconds since the first mark)] of the last run / graph replay."""
+    global _marks
+    import torch
+
+    buf = torch.zeros(slots, dtype=torch.int64, device=device)
+    _marks = {"buf": buf, "names": []}
+
+    def reader():
+        t = buf.cpu().tolist()
+        names = _marks["names"]
+        t0 = min(t[: len(names)]) if names else 0
+        return sorted(((n, (t[i] - t0) / 100.0) for i, n in enumerate(names)), key=lambda r: r[1])
+
+    return reader
+
+
+def mark(name):
+    if _marks is None:
+        return
+    names = _marks["names"]
+    if name not in names:
+        names.append(name)
+    call("tacorl_time_mark", ptr(_marks["buf"]), names.index(name), stream())
+
+
 _copy_batch = None
 
 
