@@ -210,6 +210,11 @@ int tacorl_pack_images(const float* src, long img_pitch, int src_nchw, void* dst
  * and the obs / goal / next-obs images of a TACORL step (reference get_rl_batch, tacorl.py:142-179). */
 int tacorl_pack_images_batch(int njobs, const float* const* src, const long* img_pitch, void* const* dst,
                              const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream);
+/* reward = done = float(disp == 1) (done may be NULL) and acts_dst[0:n_acts] = acts_src[0:n_acts], one launch:
+ * the small tensors of TACORL.get_rl_batch (reference modules/tacorl/tacorl.py:142-179).
+ * disp_dtype: 0 float32, 1 int64, 2 int32, 3 uint8 / bool. */
+int tacorl_stage_transition(const void* disp, int disp_dtype, float* reward, float* done, int B,
+                            const float* acts_src, float* acts_dst, long n_acts, tacorl_stream_t stream);
 /* dst[r][0:cols] (+)= src[r % src_row_mod][0:cols]  (src_row_mod <= 0: r).  expand_obs on
  * embeddings instead of images (reference utils/misc.py:132-153) and torch.cat plumbing. */
 int tacorl_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols,

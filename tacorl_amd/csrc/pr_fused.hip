@@ -6,10 +6,13 @@
 // As separate kernels a layer is 8-9 launches (in-proj, attention, out-proj, add+LayerNorm, FFN1,
 // split-K FFN2 + reduce, add+LayerNorm) of a few microseconds of work each: ~180 us for two layers on the
 // step's longest dependent chain.  With d_model 32 and T = 16 a whole sequence is one 16-row MFMA tile, so
-// here ONE WAVE owns one sequence for all layers: its activations stay in registers (MFMA D layout: lane =
-// row, 4 consecutive features) and a wave-private LDS scratch; no workgroup barrier exists in this kernel.
-// Weights are the MFMA A operand, streamed from global memory (FFN matrices from a bf16 mirror of the
-// parameter block, one phase ahead of their use).
+// here one WORKGROUP owns one sequence for all layers: activations stay in registers (MFMA D layout: lane =
+// row, 4 consecutive features) and wave-private LDS scratch.  The four waves run the attention half of a
+// layer redundantly (no synchronisation) and split the FFN by hidden chunks; their partial outputs meet in
+// LDS behind the only workgroup barrier of a layer.  Weights are the MFMA A operand, streamed from global
+// memory (FFN matrices from a bf16 mirror of the parameter block, one phase ahead of their use).
+// Optionally the posterior head (fc -> mean_fc composed into one 2A x 32 affine map) and the plan sample
+// ride in the same launch.  B = 256: 34 us (one wave per sequence on a quarter of the CUs: 81 us).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -78,13 +81,28 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 xb_s[4][PR_T * XB_P];
   __shared__ __attribute__((aligned(16))) unsigned char big_s[4][PR_T * HB_P * 2];  // q|k|v (fp32) or FFN hidden chunk (bf16)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x * 4 + w;
-  if (b >= a.B) return;  // wave-uniform; nothing below synchronises across waves
+  // One workgroup per sequence.  Its four waves each run the (cheap) attention half of a layer redundantly on
+  // private scratch and split the FFN - two thirds of the work, 256 KB of weights per layer - by hidden chunks
+  // (wave w: chunks w, w + 4, ...); the partial FFN outputs meet in LDS once per layer.  B workgroups instead
+  // of B / 4: at B = 256 the launch covers every CU instead of a quarter of them.
+  __shared__ __attribute__((aligned(16))) float ypart[2][4][PR_T * PR_D];  // [layer parity][wave]
+  const int b = blockIdx.x;
+  if (b >= a.B) return;  // block-uniform
   __bf16* xb = xb_s[w];
   float* qkv = reinterpret_cast<float*>(big_s[w]);
   __bf16* hb = reinterpret_cast<__bf16*>(big_s[w]);
   static_assert(PR_T * QKV_P * 4 <= PR_T * HB_P * 2, "q|k|v fits in the hidden-chunk buffer");
 
+  // posterior-head operands of this lane (output j = lane): fetched now, used after the last layer
+  const int A_ = a.A, jh = lane < 2 * A_ ? lane : 0;
+  f32x4 hw[PR_D / 4];
+  float hbias = 0.f, heps = 0.f;
+  if (a.Wc) {
+#pragma unroll
+    for (int d = 0; d < PR_D / 4; d++) hw[d] = *reinterpret_cast<const f32x4*>(a.Wc + jh * PR_D + 4 * d);
+    hbias = a.bc[jh];
+    heps = a.eps[(long)b * A_ + (lane < A_ ? lane : 0)];
+  }
   // x = emb + position embedding, in D layout: v[nt][r] = feature 16 nt + 4 g + r of row (time step) i
   f32x4 x[2];
 #pragma unroll
@@ -163,13 +181,15 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
     const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + i * XB_P + 8 * g);
     f32x4 y[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) y[nt] = *reinterpret_cast<const f32x4*>(a.P + o.b2 + 16 * nt + 4 * g);
+    for (int nt = 0; nt < 2; nt++)
+      y[nt] = w == 0 ? *reinterpret_cast<const f32x4*>(a.P + o.b2 + 16 * nt + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
     const __bf16* W1 = a.Pb + o.w1;
     const __bf16* W2 = a.Pb + o.w2;
     bf16x8 w1f[16], w2f[8][2];
+    const int c0 = w < nchunk ? w : nchunk - 1;  // (a wave without chunks prefetches in bounds and skips the loop)
 #pragma unroll
-    for (int nt = 0; nt < 16; nt++) w1f[nt] = *reinterpret_cast<const bf16x8*>(W1 + (long)(16 * nt + i) * PR_D + 8 * g);
-    for (int c = 0; c < nchunk; c++) {
+    for (int nt = 0; nt < 16; nt++) w1f[nt] = *reinterpret_cast<const bf16x8*>(W1 + (long)(PR_CH * c0 + 16 * nt + i) * PR_D + 8 * g);
+    for (int c = w; c < nchunk; c += 4) {
       // this chunk's W2 fragments travel while FFN1 runs
 #pragma unroll
       for (int ks = 0; ks < 8; ks++)
@@ -185,10 +205,10 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
       }
       lds_sync();
       // the next chunk's W1 fragments travel while FFN2 runs
-      if (c + 1 < nchunk) {
+      if (c + 4 < nchunk) {
 #pragma unroll
         for (int nt = 0; nt < 16; nt++)
-          w1f[nt] = *reinterpret_cast<const bf16x8*>(W1 + (long)(PR_CH * (c + 1) + 16 * nt + i) * PR_D + 8 * g);
+          w1f[nt] = *reinterpret_cast<const bf16x8*>(W1 + (long)(PR_CH * (c + 4) + 16 * nt + i) * PR_D + 8 * g);
       }
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
@@ -198,10 +218,25 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
       }
       lds_sync();  // hidden chunk consumed before the next one overwrites it
     }
+    // the four partial FFN outputs meet in LDS (fixed summation order: every wave ends with the same bits).
+    // One barrier per layer: the buffer alternates with the layer, and a wave can only reach layer l + 2's write
+    // after every wave has passed layer l + 1's barrier, i.e. finished reading layer l's partials.
+    {
+      float* yp = ypart[l & 1][w];
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) x[nt] += y[nt];
+      for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(yp + i * PR_D + 16 * nt + 4 * g) = y[nt];
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(ypart[l & 1][0] + i * PR_D + 16 * nt + 4 * g);
+#pragma unroll
+        for (int ww = 1; ww < 4; ww++) t += *reinterpret_cast<const f32x4*>(ypart[l & 1][ww] + i * PR_D + 16 * nt + 4 * g);
+        x[nt] += t;
+      }
+    }
     layer_norm32(x, a.P + o.n2w, a.P + o.n2b, g);
   }
+  if (w != 0) return;  // every wave holds the same result: wave 0 writes it
   // ---- mean over the 16 time steps (lanes i = 0..15 of each g)
 #pragma unroll
   for (int nt = 0; nt < 2; nt++) {
@@ -221,18 +256,18 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
   // ---- posterior head on the pooled vector: head = Wc pooled + bc (lane j = output j), then
   // std = softplus(var_raw) + min_std, plan = tanh(mean + eps * std)  (plan_recognition_transformer.py:89-104)
   lds_sync();
-  const int A = a.A, j = lane < 2 * A ? lane : 0;
-  float h = a.bc[j];
+  const int A = A_;
+  float h = hbias;
 #pragma unroll
   for (int d = 0; d < PR_D; d += 4) {
-    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.Wc + j * PR_D + d), pv = *reinterpret_cast<const f32x4*>(qkv + d);
+    const f32x4 wv = hw[d / 4], pv = *reinterpret_cast<const f32x4*>(qkv + d);
     h += wv[0] * pv[0] + wv[1] * pv[1] + wv[2] * pv[2] + wv[3] * pv[3];
   }
   if (lane < 2 * A) a.head[(long)b * 2 * A + lane] = h;
   const float vr = __shfl(h, (lane + A) & 63, 64);
   if (lane < A) {
     const float sd = (vr > 20.f ? vr : log1pf(expf(vr))) + a.min_std;
-    a.plan[(long)b * A + lane] = tanhf(h + a.eps[(long)b * A + lane] * sd);
+    a.plan[(long)b * A + lane] = tanhf(h + heps * sd);
   }
 }
 
@@ -245,10 +280,11 @@ __global__ __launch_bounds__(256) void pr_head_compose_kernel(const float* __res
   __shared__ float part[8][PR_D + 1];
   const int j = blockIdx.x, d = threadIdx.x & 31, fg = threadIdx.x >> 5;
   float acc = 0.f, accb = 0.f;
-  for (int f = fg; f < FC; f += 8) {
+#pragma unroll 16
+  for (int f = fg; f < FC; f += 8) {  // independent iterations: 16 x 3 loads in flight per thread
     const float wh = w_head[(long)j * FC + f];
     acc += wh * w_fc[(long)f * PR_D + d];
-    if (d == 0) accb += wh * b_fc[f];
+    accb += wh * b_fc[f];
   }
   part[fg][d] = acc;
   if (d == 0) part[fg][PR_D] = accb;
@@ -288,7 +324,7 @@ static int pr_encoder_fused_launch(const float* emb, int ld_emb, const float* pa
     if (!bc || !eps || !head || !plan || A < 1 || 2 * A > 64 || ((uintptr_t)Wc & 15)) return TACORL_EINVAL;
     a.Wc = Wc; a.bc = bc; a.eps = eps; a.head = head; a.plan = plan; a.A = A; a.min_std = min_std;
   }
-  hipLaunchKernelGGL(pr_encoder_fused_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(pr_encoder_fused_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 extern "C" int tacorl_pr_encoder_fused(const float* emb, int ld_emb, const float* params, const void* params_bf16,

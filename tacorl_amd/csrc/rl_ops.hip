@@ -105,6 +105,36 @@ extern "C" int tacorl_pack_images_batch(int njobs, const float* const* src, cons
   return LAUNCH_OK();
 }
 
+// ===================================================================== small transition tensors
+// reward = done = (disp == 1) as float (TACORL.get_rl_batch, reference tacorl.py:142-179) and the action window
+// copy, in one launch instead of four (compare, two casts, copy) in front of every step.
+// disp_dtype: 0 = float32, 1 = int64, 2 = int32, 3 = uint8 / bool.
+__global__ void stage_transition_kernel(const void* __restrict__ disp, int disp_dtype, float* __restrict__ reward,
+                                        float* __restrict__ done, int B, const float* __restrict__ acts_src,
+                                        float* __restrict__ acts_dst, long n_acts) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) {
+    bool one;
+    if (disp_dtype == 0) one = static_cast<const float*>(disp)[i] == 1.0f;
+    else if (disp_dtype == 1) one = static_cast<const long long*>(disp)[i] == 1;
+    else if (disp_dtype == 2) one = static_cast<const int*>(disp)[i] == 1;
+    else one = static_cast<const unsigned char*>(disp)[i] == 1;
+    const float r = one ? 1.0f : 0.0f;
+    reward[i] = r;
+    if (done) done[i] = r;
+  }
+  for (long k = i; k < n_acts; k += (long)gridDim.x * blockDim.x) acts_dst[k] = acts_src[k];
+}
+extern "C" int tacorl_stage_transition(const void* disp, int disp_dtype, float* reward, float* done, int B,
+                                       const float* acts_src, float* acts_dst, long n_acts, tacorl_stream_t stream) {
+  if (!disp || !reward || B < 1 || disp_dtype < 0 || disp_dtype > 3 || (n_acts > 0 && (!acts_src || !acts_dst))) return TACORL_EINVAL;
+  const long work = n_acts > B ? n_acts : B;
+  const int blocks = (int)((work + 255) / 256 > 1024 ? 1024 : (work + 255) / 256);
+  hipLaunchKernelGGL(stage_transition_kernel, dim3(blocks < (B + 255) / 256 ? (B + 255) / 256 : blocks), dim3(256), 0,
+                     (hipStream_t)stream, disp, disp_dtype, reward, done, B, acts_src, acts_dst, n_acts);
+  return LAUNCH_OK();
+}
+
 // ===================================================================== copy_cols
 __global__ void copy_cols_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
                                  int rows, int cols, int src_row_mod, int accumulate) {

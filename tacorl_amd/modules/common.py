@@ -62,6 +62,14 @@ class GraphMixin:
         self._use_graph = bool(on)
         self._graphs = {}
 
+    def load_state_dict(self, *args, **kwargs):
+        """nn.Module.load_state_dict, then drop the captured graphs: a capture may have skipped weight-only
+        preparation that was already valid at capture time (frozen networks), so new weights need new captures."""
+        out = super().load_state_dict(*args, **kwargs)
+        if getattr(self, "_graphs", None):
+            self._graphs = {}
+        return out
+
     def _run_segments(self, key, segs, collectives, side=None):
         """Run the device side of a step: `segs` are collective-free kernel sequences over fixed buffers,
         `collectives[i]` runs between segs[i] and segs[i+1] (RCCL all-reduces; no-ops on one GPU).

@@ -134,12 +134,22 @@ class TACORL(CQL_Offline):
             else:
                 for src, pitch, dst, n in jobs:
                     call("tacorl_pack_images", src, pitch, int(nchw), dst, xd, n, 3, H, W, ops.stream())
-        if self.ad is not None:
-            if getattr(self, "acts", None) is None or self.acts.shape[:2] != (B, T):
-                self.acts = torch.zeros(B, T, 7, device=self.dev)
-            self.acts.copy_(batch["actions"])
-        self.reward.copy_(batch["disp"] == 1)
-        e.done.copy_(self.reward)
+        if self.ad is not None and (getattr(self, "acts", None) is None or self.acts.shape[:2] != (B, T)):
+            self.acts = torch.zeros(B, T, 7, device=self.dev)
+        disp, acts = batch["disp"], batch["actions"] if self.ad is not None else None
+        dd = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.uint8: 3, torch.bool: 3}.get(disp.dtype)
+        if (dd is not None and disp.is_cuda and disp.is_contiguous() and disp.numel() == B
+                and (acts is None or (acts.is_cuda and acts.is_contiguous() and acts.dtype == torch.float32
+                                      and acts.shape == self.acts.shape))):
+            # reward = done = (disp == 1) and the action window, one launch
+            call("tacorl_stage_transition", ptr(disp), dd, ptr(self.reward), ptr(e.done), B,
+                 ptr(acts) if acts is not None else None, ptr(self.acts) if acts is not None else None,
+                 acts.numel() if acts is not None else 0, ops.stream())
+        else:
+            if acts is not None:
+                self.acts.copy_(acts)
+            self.reward.copy_(disp == 1)
+            e.done.copy_(self.reward)
         e.set_noise(noise)
         return B, T, hw
 
@@ -158,11 +168,6 @@ class TACORL(CQL_Offline):
         mods = self.plan_recognition_modalities
         # one camera: the frame embeddings are the transformer's input as they stand
         emb, ld = (self.f_out[mods[0]], 32) if len(mods) == 1 else (self.pr_in, self.pr_in.shape[1])
-        prepared = self.pr.fused_inference_ok(T, ld, self.compute)
-        if prepared:  # weight-only preparation of the frozen plan recognition, beside the image encoders
-            self._pr_stream.wait_stream(main)
-            with torch.cuda.stream(self._pr_stream):
-                self.pr.prepare_inference()
         e._encode_all()
         ops.mark("front:encoded")
         # Plan recognition -> plan -> (action-decoder loss) only need the frame embeddings; the first phase of
@@ -178,8 +183,8 @@ class TACORL(CQL_Offline):
             if len(mods) > 1:
                 for j, c in enumerate(mods):
                     ops.copy_cols(self.f_out[c], 0, 32, self.pr_in, 32 * j, self.pr_in.shape[1], B * T, 32)
-            self.pr.forward(emb, ld, B, T, self.compute, inference=True, sample=(self.eps_pr, self.plan),
-                            prepared=prepared)
+            # the LMP networks are frozen in TACORL (tacorl.py:52-66): their weight-only preparation is cached
+            self.pr.forward(emb, ld, B, T, self.compute, inference=True, sample=(self.eps_pr, self.plan), frozen=True)
             ops.mark("pr:plan")
             ready = torch.cuda.Event()
             ready.record(self._pr_stream)
@@ -192,7 +197,7 @@ class TACORL(CQL_Offline):
             self._side_stream.wait_event(ready)
             with torch.cuda.stream(self._side_stream):
                 ops.mark("ad:start")
-                self.ad.loss_step(self, self.acts, self.plan, B, T, False)
+                self.ad.loss_step(self, self.acts, self.plan, B, T, False, frozen=not self.finetune_action_decoder)
                 ops.mark("ad:end")
             self._ad_join = self._side_stream
         e.action_ready = ready
@@ -250,7 +255,7 @@ class TACORL(CQL_Offline):
         # and runs as a side graph beside the all-reduces and the other segments
         segmented = self.world_size > 1 or getattr(self, "_force_graph_split", False)
         ad_side = with_ad and segmented and self._use_graph and not (optimize and self.finetune_action_decoder)
-        side = (0, lambda: self.ad.loss_step(self, self.acts, self.plan, B, T, False)) if ad_side else None
+        side = (0, lambda: self.ad.loss_step(self, self.acts, self.plan, B, T, False, frozen=not self.finetune_action_decoder)) if ad_side else None
         self._run_segments(key, [lambda: self._device_front(B, T, hw, optimize, with_ad and not ad_side),
                                  lambda: e.phase_b(bc, optimize), tail],
                            [e.allreduce_alpha, e.allreduce_grads], side=side)

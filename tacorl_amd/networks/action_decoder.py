@@ -86,8 +86,11 @@ class ActionDecoderLogistic:
              ops.ptr_array([y]), N if ldy is None else ldy, ops.int_array([M]), K, N, act, compute, ptr(ws), ws.numel(),
              ops.stream())
 
-    def forward(self, plan, emb, ld_emb, B, T, Tm, compute):
-        """plan (B,P); emb [B*T][ld_emb] batch-major frame embeddings; uses steps t < Tm.  Fills self.heads."""
+    def forward(self, plan, emb, ld_emb, B, T, Tm, compute, frozen=False):
+        """plan (B,P); emb [B*T][ld_emb] batch-major frame embeddings; uses steps t < Tm.  Fills self.heads.
+        frozen=True: the caller never steps these weights with the library's optimiser kernels, so the bf16
+        copies of the weight matrices are refreshed only when the block's torch version counter moved
+        (load_state_dict / copy_)."""
         self._ensure(B, Tm)
         blk, H, R = self.blk, self.hidden, B * Tm
         call("tacorl_build_ad_input", ptr(plan), ptr(emb), ld_emb, ptr(self.x_seq), B, T, Tm, self.P, self.E,
@@ -96,7 +99,11 @@ class ActionDecoderLogistic:
         # bf16 mode: the recurrent step runs as ONE launch (LDS-DMA ring GEMM, rnn_ops.hip) on bf16 copies of
         # W_hh (refreshed here: the weights may have been stepped) and of the previous hidden state
         fast = compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H))
+        ver = blk.param._version
+        fresh = frozen and getattr(self, "_bf16_version", None) == ver  # bf16 weight copies still valid
         if fast:
+            self._bf16_version = ver if frozen else None
+        if fast and not fresh:
             srcs = [blk.p(f"rnn.weight_hh_l{l}") for l in range(self.L)] + [blk.p(f"rnn.weight_ih_l{l}") for l in range(1, self.L)]
             dsts = self.whb + self.wib[1:]
             call("tacorl_to_bf16_batch", len(srcs), ops.ptr_array(srcs), ops.ptr_array(dsts),
@@ -136,10 +143,11 @@ class ActionDecoderLogistic:
                      ptr(self.rnn_ws), self.rnn_ws.numel(), ops.stream())
             x, K = self.h[l], H
         if fast:  # output heads through the ring GEMM (bf16 weights, rows padded to a multiple of 32)
-            call("tacorl_to_bf16_batch", 1, ops.ptr_array([blk.p("mean_fc.weight")]), ops.ptr_array([self.headw_b]),
-                 (C.c_long * 1)(self.NH * H), ops.stream())
-            ob = blk.off["mean_fc.bias"][0]  # the four heads' biases sit back to back
-            self.headb[: self.NH].copy_(blk.param[ob: ob + self.NH])
+            if not fresh:
+                call("tacorl_to_bf16_batch", 1, ops.ptr_array([blk.p("mean_fc.weight")]), ops.ptr_array([self.headw_b]),
+                     (C.c_long * 1)(self.NH * H), ops.stream())
+                ob = blk.off["mean_fc.bias"][0]  # the four heads' biases sit back to back
+                self.headb[: self.NH].copy_(blk.param[ob: ob + self.NH])
             call("tacorl_rnn_linear_fwd", ptr(self.hb[self.L - 1]), ptr(self.headw_b), ptr(self.headb), None, 0,
                  ptr(self.heads), None, R, H, self.NHP, ACT_NONE, ops.stream())
         else:
@@ -153,7 +161,7 @@ class ActionDecoderLogistic:
              loss_out, B, T, Tm, self.Da, self.K, self.num_classes, float(self.gripper_alpha), float(grad_scale),
              ptr(self.ws), self.ws.numel(), ops.stream())
 
-    def loss_step(self, module, actions, plan, B, T, optimize):
+    def loss_step(self, module, actions, plan, B, T, optimize, frozen=False):
         """TACORL.compute_action_decoder_update (reference tacorl.py:206-233): loss on emb[:, :-1],
         actions[:, :-1]; logged always, Adam step when fine-tuning."""
         from .._lib import LOG_SLOTS
@@ -170,7 +178,7 @@ class ActionDecoderLogistic:
             for j, c in enumerate(cams):
                 ops.copy_cols(module.f_out[c], 0, 32, module._ad_in, 32 * j, module._ad_in.shape[1], B * T, 32)
             emb, ld = module._ad_in, module._ad_in.shape[1]
-        self.forward(plan, emb, ld, B, T, T - 1, module.compute)
+        self.forward(plan, emb, ld, B, T, T - 1, module.compute, frozen=frozen and not optimize)
         slot = ops._at(module.engine.logs, LOG_SLOTS.index("action_loss"))
         self.loss(acts, slot, B, T, T - 1, want_grad=optimize, grad_scale=1.0 / module.world_size)
         if optimize:

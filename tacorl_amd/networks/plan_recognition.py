@@ -95,17 +95,22 @@ class PlanRecognition:
         call("tacorl_pr_head_compose", blk.p("fc.weight"), blk.p("fc.bias"), blk.p("mean_fc.weight"), blk.p("mean_fc.bias"),
              ptr(self._Wc), ptr(self._bc), self.D, self.FC, 2 * self.A, ops.stream())
 
-    def forward(self, emb, ld_emb, B, T, compute, inference=False, sample=None, prepared=False):
+    def forward(self, emb, ld_emb, B, T, compute, inference=False, sample=None, prepared=False, frozen=False):
         """emb: device tensor/pointer of [B*T][ld_emb] per-frame embeddings (first D_in columns used).
         Returns the (B, 2A) head buffer [mean | var_raw].  inference=True (frozen network, no backward
         follows): the encoder layers + time pooling run as one launch when the shape qualifies; with
         sample=(eps, plan) the posterior head and plan = tanh(mean + eps * std) ride in that launch too
-        (prepared=True: prepare_inference() was already issued for the current weights)."""
+        (prepared=True: prepare_inference() was already issued for the current weights; frozen=True: the caller
+        never steps these weights with the library's optimiser kernels, so they only change through torch in-place
+        ops - load_state_dict, copy_ - which bump the parameter block's version counter: the preparation is then
+        re-issued only when that counter moved)."""
         self._ensure(B, T)
         blk, D, R = self.blk, self.D, B * T
         if inference and self.fused_inference_ok(T, ld_emb, compute):
-            if not prepared:
+            ver = blk.param._version
+            if not prepared and not (frozen and getattr(self, "_prep_version", None) == ver):
                 self.prepare_inference()
+                self._prep_version = ver if frozen else None
             if sample is not None:
                 eps, plan = sample
                 call("tacorl_pr_encoder_fused_sample", ptr(emb), ld_emb, ptr(blk.param), ptr(self._pb), self._foff,

@@ -549,6 +549,55 @@ def test_add_layernorm_fwd_bwd(R):
     assert relerr(dw, w.grad) < 1e-4 and relerr(db, b.grad) < 1e-4
 
 
+def test_plan_recognition_fused_sample_and_frozen_cache():
+    """The in-launch posterior head + plan sample (fc -> mean_fc composed into one affine map) against the
+    two-GEMM head + tacorl_pr_sample of the same module, and the frozen-weights cache: the weight-only
+    preparation is skipped while the parameter block's version counter stands still and re-issued after a
+    torch in-place update (what load_state_dict does)."""
+    from tacorl_amd._lib import call, ptr, stream as ops_stream
+    from tacorl_amd.networks.plan_recognition import PlanRecognition
+
+    dev = _dev()
+    B, T, D, A = 64, 16, 32, 16
+    pr = PlanRecognition(state_dim=D, latent_plan_dim=A, device=dev, num_heads=8, num_layers=2, encoder_hidden_size=2048,
+                         fc_hidden_size=4096, max_position_embeddings=T, trainable=False)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for k, v in pr.blk.views.items():
+            if k.endswith("weight") and v.dim() == 2:
+                v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) / math.sqrt(v.shape[1]))
+            elif "norm" in k and k.endswith("weight"):
+                v.copy_(1 + 0.1 * torch.randn(v.shape, generator=g))
+            else:
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+    emb, eps = rnd(B * T, D, seed=3).to(dev), rnd(B, A, seed=4).to(dev)
+
+    def reference():
+        head = pr.forward(emb, D, B, T, 1, inference=True).clone()  # fused encoder, two bf16 GEMMs for the head
+        plan = torch.zeros(B, A, device=dev)
+        call("tacorl_pr_sample", ptr(head), ptr(eps), ptr(plan), None, None, B, A, float(pr.min_std), ops_stream())
+        return head, plan
+
+    def fused():
+        plan = torch.zeros(B, A, device=dev)
+        head = pr.forward(emb, D, B, T, 1, inference=True, sample=(eps, plan), frozen=True).clone()
+        return head, plan
+
+    h_ref, p_ref = reference()
+    h_fus, p_fus = fused()
+    torch.cuda.synchronize()
+    assert relerr(h_fus, h_ref) < 2e-2 and relerr(p_fus, p_ref) < 2e-2, (relerr(h_fus, h_ref), relerr(p_fus, p_ref))
+    ver = pr._prep_version
+    h2, p2 = fused()  # cached preparation: same bits
+    assert pr._prep_version == ver and torch.equal(h2, h_fus) and torch.equal(p2, p_fus)
+    with torch.no_grad():
+        pr.blk.views["mean_fc.bias"].add_(0.5)  # in-place update bumps the version counter
+    h3, p3 = fused()
+    torch.cuda.synchronize()
+    assert pr._prep_version != ver
+    assert relerr(h3[:, :A], h_fus[:, :A] + 0.5) < 1e-5, "stale composed head after a weight update"
+
+
 def test_plan_recognition_fused_encoder():
     """Single-launch frozen plan-recognition encoder (one wave per sequence) vs the per-kernel bf16 path of
     the same module (same operand roundings) and vs an fp32 torch restatement at bf16 tolerance."""
