@@ -913,6 +913,10 @@ static MlpBwdWs mlp_bwd_fused_plan(int nprob, const int* M, int L, const int* di
   for (int p = 0; p < nprob; p++) { w.wt_off[p] = b; b += w.wt_bytes_each; }
   w.slab_off = b;
   for (int l = 0; l < L; l++) { size_t s = wgrad_ws_bytes(nprob, dims[l], dims[l + 1], maxM); w.slab_bytes = s > w.slab_bytes ? s : w.slab_bytes; }
+  if (mlp_fused_wgrad_ok(nprob, L, dims)) {  // one-launch weight gradients: a record of every layer per 256-row slice
+    const size_t s = mlp_fused_wgrad_slab_floats(nprob, M, L, dims) * sizeof(float);
+    w.slab_bytes = s > w.slab_bytes ? s : w.slab_bytes;
+  }
   w.total = b + w.slab_bytes;
   return w;
 }
@@ -976,6 +980,20 @@ extern "C" int tacorl_mlp_bwd_fused_wgrad(int nprob, const float* const* x, int 
   long wo[MLP_MAXL], bo[MLP_MAXL];
   tacorl_mlp_param_layout(L, dims, wo, bo);
   void* slab = (unsigned char*)ws + w.slab_off;
+  if (mlp_fused_wgrad_ok(nprob, L, dims)) {  // every layer and network in one launch (+ one reduce)
+    long yoffs[MF_MAXP * MF_MAXL];
+    const float* dzp[MF_MAXP];
+    for (int p = 0; p < nprob; p++) {
+      long zo[MLP_MAXL], yo[MLP_MAXL];
+      tacorl_mlp_act_layout(M[p], L, dims, acts, zo, yo);
+      for (int l = 0; l < L; l++) yoffs[p * MF_MAXL + l] = yo[l];
+      dzp[p] = (const float*)ws;
+    }
+    if (mlp_fused_wgrad(nprob, x, ldx, act, d_out, ldo, dzp, grads, (float*)slab, M, L, dims, yoffs, w.dzoff, wo, bo,
+                        accumulate, st))
+      FAIL(TACORL_ELAUNCH, "mlp_bwd_fused_wgrad: launch failed");
+    return TACORL_OK;
+  }
   for (int l = L - 1; l >= 0; l--) {
     const float *xg[GEMM_MAXP], *dzg[GEMM_MAXP];
     float *dwg[GEMM_MAXP], *dbg[GEMM_MAXP];

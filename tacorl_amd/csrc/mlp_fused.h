@@ -27,3 +27,12 @@ int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act
                   const int* acts, const long* srcoff, const long* dzoff, const long* woff, hipStream_t st, int mode);
 // mode: 0 = transpose the weights, then run the chain; 1 = transpose only (d_out / act / dz unused);
 //       2 = chain only (wt already holds this step's transposed weights)
+
+// Weight / bias gradients of every layer and network of an MLP site in one launch + one reduce launch
+// (dims <= 256).  dz[p] + dzoff[p*MF_MAXL + l]: dZ_l from the dgrad launch (l < L-1); d_out: dZ of the last
+// layer; yoff[p*MF_MAXL + l]: offset of layer l's output in act[p].  slab: mlp_fused_wgrad_slab_floats() floats.
+bool mlp_fused_wgrad_ok(int nprob, int L, const int* dims);
+size_t mlp_fused_wgrad_slab_floats(int nprob, const int* M, int L, const int* dims);
+int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* const* act, const float* const* d_out, int ldo,
+                    const float* const* dz, float* const* grads, float* slab, const int* M, int L, const int* dims,
+                    const long* yoff, const long* dzoff, const long* woff, const long* boff, int accumulate, hipStream_t st);

@@ -321,7 +321,232 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------- weight gradients
+// dW_l = dZ_l^T X_l and db_l = colsum(dZ_l) of EVERY layer and network of an MLP site in one launch (+ one reduce
+// launch).  As per-layer split-K GEMM launches this was 2 launches per layer, each a latency-bound chain of
+// transposed-operand K tiles (a 256 x 256 x 3328 gradient took ~30 us at 2 % of a CU's MFMA rate) - 370 us of
+// kernel time per step that sat beside the encoder backward and the action decoder.
+// Here a workgroup owns a slice of WG_MS batch rows of one (network, layer) and the WHOLE dW (<= 256 x 256):
+// 4 waves x (4 N tiles x 16 K tiles) of 16x16 fp32 accumulators = the full register file, so every operand
+// fragment read from LDS feeds 4 (X) or 16 (dZ) MFMAs.  Both operands have the reduction index (the batch row)
+// as their slow index in memory: the staging loads 4 rows x 4 columns per lane quad, transposes in registers
+// (DPP quad_perm) and writes 4 consecutive rows of one column as bf16 (one 8-byte LDS store), so the MFMA
+// fragments are contiguous 16-byte LDS reads.  X is the MFMA A operand (D rows = K index: a lane ends with 4
+// consecutive k of one n -> 16-byte slab stores); the bias gradient is one more K tile with an all-ones
+// fragment.  Slices are summed by mlp_wgrad_reduce_kernel in slice order (deterministic).
+constexpr int WG_MS = 256;    // batch rows per workgroup
+constexpr int WG_MT = 32;     // rows per staged tile (one MFMA k-step)
+constexpr int WG_TP = 40;     // bf16 pitch of a transposed row [col][32 m] (80 B: 16 cols hit distinct 16-B slots)
+constexpr int WG_OPB = 256 * WG_TP * 2;  // bytes of one staged operand tile
+
+struct MlpWgArgs {
+  const float* x[MF_MAXP];      // layer-0 input [M][ldx]
+  const float* act[MF_MAXP];    // saved activations (layer l >= 1 input = y_{l-1} at yoff[p][l-1])
+  const float* dlast[MF_MAXP];  // gradient of the MLP output [M][ldo] (= dZ of the last layer)
+  const float* dz[MF_MAXP];     // dZ_l, l < L-1, at dzoff[p][l] (from the dgrad launch)
+  float* slab[MF_MAXP];         // partial gradients: [slice][record]
+  int M[MF_MAXP];
+  long yoff[MF_MAXP][MF_MAXL], dzoff[MF_MAXP][MF_MAXL];
+  long sloff[MF_MAXL];          // offset of layer l inside a record: [N][K] then [N]
+  long rec;                     // floats per record
+  int dims[MF_MAXL + 1];
+  int L, ldx, ldo;
+};
+
+__device__ __forceinline__ float wg_dpp1(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wg_dpp2(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+}
+// 4x4 transpose across a lane quad (lane q enters with row q, leaves with column q)
+__device__ __forceinline__ void wg_quad_transpose(f32x4& v, int q) {
+  const bool o1 = q & 1, o2 = q & 2;
+  const float x0 = wg_dpp1(o1 ? v[0] : v[1]), x1 = wg_dpp1(o1 ? v[2] : v[3]);
+  if (o1) { v[0] = x0; v[2] = x1; } else { v[1] = x0; v[3] = x1; }
+  const float y0 = wg_dpp2(o2 ? v[0] : v[2]), y1 = wg_dpp2(o2 ? v[1] : v[3]);
+  if (o2) { v[0] = y0; v[1] = y1; } else { v[2] = y0; v[3] = y1; }
+}
+
+__global__ __launch_bounds__(256) void mlp_wgrad_fused_kernel(MlpWgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 buffers][X^T | dZ^T] tiles
+  const int p = blockIdx.z, l = blockIdx.y, m0 = blockIdx.x * WG_MS, M = a.M[p];
+  if (m0 >= M) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4, q = tid & 3, qd = tid >> 2;
+  const int K = a.dims[l], N = a.dims[l + 1];
+  const float* X = l == 0 ? a.x[p] : a.act[p] + a.yoff[p][l - 1];
+  const int ldX = l == 0 ? a.ldx : K;
+  const float* Z = l == a.L - 1 ? a.dlast[p] : a.dz[p] + a.dzoff[p][l];
+  const int ldZ = l == a.L - 1 ? a.ldo : N;
+  const bool vecX = (ldX & 3) == 0 && (K & 3) == 0 && ((uintptr_t)X & 15) == 0;
+  const bool vecZ = (ldZ & 3) == 0 && (N & 3) == 0 && ((uintptr_t)Z & 15) == 0;
+  const int KT = (K + 15) >> 4, NT = (N + 15) >> 4;
+  const int mend = min(M, m0 + WG_MS), nsteps = (mend - m0 + WG_MT - 1) / WG_MT;
+
+  // staging: quad qd owns columns 4 qd .. 4 qd + 3, lane q of it row 4 j + q of the tile (j = 0..7)
+  f32x4 rx[8], rz[8];
+  auto fetch = [&](const float* S, int ld, int C, bool vec, int mt, f32x4 (&r)[8]) {
+    const int c = 4 * qd;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int m = m0 + mt * WG_MT + 4 * j + q;
+      const bool rok = m < mend;
+      const float* src = S + (long)(rok ? m : m0) * ld;
+      if (vec) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (c < C ? c : 0));
+        const bool ok = rok && c < C;
+        r[j] = f32x4{ok ? v[0] : 0.f, ok ? v[1] : 0.f, ok ? v[2] : 0.f, ok ? v[3] : 0.f};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float v = src[c + e < C ? c + e : 0];
+          r[j][e] = rok && c + e < C ? v : 0.f;
+        }
+      }
+    }
+  };
+  auto stash = [&](f32x4 (&r)[8], unsigned char* T) {  // T: [col][WG_TP] bf16
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      f32x4 v = r[j];
+      wg_quad_transpose(v, q);  // now: column 4 qd + q, rows 4 j .. 4 j + 3
+      *reinterpret_cast<bf16x4*>(T + ((4 * qd + q) * WG_TP + 4 * j) * 2) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+  };
+  f32x4 acc[4][17];
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+    for (int kt = 0; kt < 17; kt++) acc[nt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const __bf16 one = (__bf16)1.0f;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
+
+  fetch(X, ldX, K, vecX, 0, rx);
+  fetch(Z, ldZ, N, vecZ, 0, rz);
+  for (int s = 0; s < nsteps; s++) {
+    unsigned char* TX = smem + (s & 1) * 2 * WG_OPB;
+    unsigned char* TZ = TX + WG_OPB;
+    stash(rx, TX);
+    stash(rz, TZ);
+    __syncthreads();  // (the other buffer is still being read by slower waves: two buffers, one barrier per step)
+    if (s + 1 < nsteps) { fetch(X, ldX, K, vecX, s + 1, rx); fetch(Z, ldZ, N, vecZ, s + 1, rz); }
+    // this wave's N tiles: w, w + 4, w + 8, w + 12
+    bf16x8 zf[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)
+      zf[nt] = *reinterpret_cast<const bf16x8*>(TZ + ((16 * (w + 4 * nt) + i) * WG_TP + 8 * g) * 2);
+#pragma unroll
+    for (int kt = 0; kt < 16; kt++) {
+      if (kt < KT) {  // (wave-uniform; a break would leave acc[][] dynamically indexed, i.e. in scratch)
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(TX + ((16 * kt + i) * WG_TP + 8 * g) * 2);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+          if (w + 4 * nt < NT) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, zf[nt], acc[nt][kt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)  // bias gradient: all-ones X fragment
+      if (w + 4 * nt < NT) acc[nt][16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, zf[nt], acc[nt][16], 0, 0, 0);
+  }
+  // partial dW [N][K] (this lane: n = 16 tile + i, k = 16 kt + 4 g .. + 3) and db [N]
+  float* rec = a.slab[p] + (long)blockIdx.x * a.rec + a.sloff[l];
+  const bool vecK = (K & 3) == 0;
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++) {
+    const int n = 16 * (w + 4 * nt) + i;
+    if (w + 4 * nt >= NT || n >= N) continue;
+#pragma unroll
+    for (int kt = 0; kt < 16; kt++) {
+      const int k = 16 * kt + 4 * g;
+      if (kt < KT) {
+        if (vecK) {
+          if (k < K) *reinterpret_cast<f32x4*>(rec + (long)n * K + k) = acc[nt][kt];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (k + r < K) rec[(long)n * K + k + r] = acc[nt][kt][r];
+        }
+      }
+    }
+    if (g == 0) rec[(long)N * K + n] = acc[nt][16][0];
+  }
+}
+
+struct MlpWgReduceArgs {
+  const float* slab[MF_MAXP];
+  float* grad[MF_MAXP];
+  int nslice[MF_MAXP];
+  long sloff[MF_MAXL], woff[MF_MAXL], boff[MF_MAXL];
+  long rec;
+  int dims[MF_MAXL + 1];
+  int accumulate;
+};
+// grid (blocks, L, nprob): grad[wo_l + e] (+)= sum over slices, in slice order
+__global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(MlpWgReduceArgs a) {
+  const int l = blockIdx.y, p = blockIdx.z, K = a.dims[l], N = a.dims[l + 1], ns = a.nslice[p];
+  const long nw = (long)N * K, tot = nw + N;
+  const float* __restrict__ s0 = a.slab[p] + a.sloff[l];
+  float* __restrict__ gr = a.grad[p];
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    float t = 0.f;
+    for (int s = 0; s < ns; s++) t += s0[(long)s * a.rec + e];
+    float* d = gr + (e < nw ? a.woff[l] + e : a.boff[l] + (e - nw));
+    *d = a.accumulate ? *d + t : t;
+  }
+}
+
 }  // namespace
+
+bool mlp_fused_wgrad_ok(int nprob, int L, const int* dims) {
+  if (nprob < 1 || nprob > MF_MAXP || L < 1 || L > MF_MAXL) return false;
+  for (int l = 0; l <= L; l++)
+    if (dims[l] < 1 || dims[l] > MAXD) return false;
+  return true;
+}
+static long mlp_wgrad_record(int L, const int* dims, long* sloff) {
+  long off = 0;
+  for (int l = 0; l < L; l++) {
+    if (sloff) sloff[l] = off;
+    off += (long)dims[l + 1] * dims[l] + dims[l + 1];
+    off = (off + 3) & ~3L;
+  }
+  return off;
+}
+size_t mlp_fused_wgrad_slab_floats(int nprob, const int* M, int L, const int* dims) {
+  const long rec = mlp_wgrad_record(L, dims, nullptr);
+  size_t tot = 0;
+  for (int p = 0; p < nprob; p++) tot += (size_t)((M[p] + WG_MS - 1) / WG_MS) * rec;
+  return tot;
+}
+int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* const* act, const float* const* d_out, int ldo,
+                    const float* const* dz, float* const* grads, float* slab, const int* M, int L, const int* dims,
+                    const long* yoff, const long* dzoff, const long* woff, const long* boff, int accumulate, hipStream_t st) {
+  MlpWgArgs a{};
+  MlpWgReduceArgs r{};
+  a.rec = r.rec = mlp_wgrad_record(L, dims, a.sloff);
+  a.L = L; a.ldx = ldx; a.ldo = ldo; r.accumulate = accumulate;
+  for (int l = 0; l <= L; l++) a.dims[l] = r.dims[l] = dims[l];
+  for (int l = 0; l < L; l++) { r.sloff[l] = a.sloff[l]; r.woff[l] = woff[l]; r.boff[l] = boff[l]; }
+  int n2 = 0, maxs = 0;
+  float* sp = slab;
+  for (int p = 0; p < nprob; p++) {
+    if (!grads[p] || M[p] <= 0) continue;
+    const int ns = (M[p] + WG_MS - 1) / WG_MS;
+    a.x[n2] = x[p]; a.act[n2] = act[p]; a.dlast[n2] = d_out[p]; a.dz[n2] = dz[p]; a.M[n2] = M[p]; a.slab[n2] = sp;
+    r.slab[n2] = sp; r.grad[n2] = grads[p]; r.nslice[n2] = ns;
+    for (int l = 0; l < L; l++) { a.yoff[n2][l] = yoff[p * MF_MAXL + l]; a.dzoff[n2][l] = dzoff[p * MF_MAXL + l]; }
+    sp += (size_t)ns * a.rec;
+    maxs = ns > maxs ? ns : maxs;
+    n2++;
+  }
+  if (!n2) return 0;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_fused_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_OPB) == hipSuccess ? 0 : -1;
+  if (once) return -1;
+  hipLaunchKernelGGL(mlp_wgrad_fused_kernel, dim3(maxs, L, n2), dim3(256), 4 * WG_OPB, st, a);
+  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(64, L, n2), dim3(256), 0, st, r);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 bool mlp_fused_bwd_ok(int nprob, int L, const int* dims, int ldo, int ldd) {
   if (nprob < 1 || nprob > MF_MAXP || L < 1 || L > MF_MAXL) return false;
