@@ -327,8 +327,9 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
 // transposed-operand K tiles (a 256 x 256 x 3328 gradient took ~30 us at 2 % of a CU's MFMA rate) - 370 us of
 // kernel time per step that sat beside the encoder backward and the action decoder.
 // Here a workgroup owns a slice of WG_MS batch rows of one (network, layer) and the WHOLE dW (<= 256 x 256):
-// 4 waves x (4 N tiles x 16 K tiles) of 16x16 fp32 accumulators = the full register file, so every operand
-// fragment read from LDS feeds 4 (X) or 16 (dZ) MFMAs.  Both operands have the reduction index (the batch row)
+// 8 waves x (2 N tiles x 16 K tiles) of 16x16 fp32 accumulators, so every operand fragment read from LDS feeds
+// 2 (X) or 16 (dZ) MFMAs; two waves per SIMD, so one wave's LDS traffic and global-load waits hide behind the
+// other's MFMAs (with one wave per SIMD they add up: 75 us per launch against 40).  Both operands have the reduction index (the batch row)
 // as their slow index in memory: the staging loads 4 rows x 4 columns per lane quad, transposes in registers
 // (DPP quad_perm) and writes 4 consecutive rows of one column as bf16 (one 8-byte LDS store), so the MFMA
 // fragments are contiguous 16-byte LDS reads.  X is the MFMA A operand (D rows = K index: a lane ends with 4
@@ -368,11 +369,12 @@ __device__ __forceinline__ void wg_quad_transpose(f32x4& v, int q) {
   if (o2) { v[0] = y0; v[1] = y1; } else { v[2] = y0; v[3] = y1; }
 }
 
-__global__ __launch_bounds__(256) void mlp_wgrad_fused_kernel(MlpWgArgs a) {
+__global__ __launch_bounds__(512) void mlp_wgrad_fused_kernel(MlpWgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 buffers][X^T | dZ^T] tiles
   const int p = blockIdx.z, l = blockIdx.y, m0 = blockIdx.x * WG_MS, M = a.M[p];
   if (m0 >= M) return;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4, q = tid & 3, qd = tid >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4, q = tid & 3;
+  const int qd = (tid >> 2) & 63, jh = tid >> 8;  // column quad, row-group parity of this thread in the staging
   const int K = a.dims[l], N = a.dims[l + 1];
   const float* X = l == 0 ? a.x[p] : a.act[p] + a.yoff[p][l - 1];
   const int ldX = l == 0 ? a.ldx : K;
@@ -383,13 +385,13 @@ __global__ __launch_bounds__(256) void mlp_wgrad_fused_kernel(MlpWgArgs a) {
   const int KT = (K + 15) >> 4, NT = (N + 15) >> 4;
   const int mend = min(M, m0 + WG_MS), nsteps = (mend - m0 + WG_MT - 1) / WG_MT;
 
-  // staging: quad qd owns columns 4 qd .. 4 qd + 3, lane q of it row 4 j + q of the tile (j = 0..7)
-  f32x4 rx[8], rz[8];
-  auto fetch = [&](const float* S, int ld, int C, bool vec, int mt, f32x4 (&r)[8]) {
+  // staging: quad qd owns columns 4 qd .. 4 qd + 3, lane q of it row 4 (2 j + jh) + q of the tile (j = 0..3)
+  f32x4 rx[4], rz[4];
+  auto fetch = [&](const float* S, int ld, int C, bool vec, int mt, f32x4 (&r)[4]) {
     const int c = 4 * qd;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int m = m0 + mt * WG_MT + 4 * j + q;
+    for (int j = 0; j < 4; j++) {
+      const int m = m0 + mt * WG_MT + 4 * (2 * j + jh) + q;
       const bool rok = m < mend;
       const float* src = S + (long)(rok ? m : m0) * ld;
       if (vec) {
@@ -405,17 +407,17 @@ __global__ __launch_bounds__(256) void mlp_wgrad_fused_kernel(MlpWgArgs a) {
       }
     }
   };
-  auto stash = [&](f32x4 (&r)[8], unsigned char* T) {  // T: [col][WG_TP] bf16
+  auto stash = [&](f32x4 (&r)[4], unsigned char* T) {  // T: [col][WG_TP] bf16
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < 4; j++) {
       f32x4 v = r[j];
-      wg_quad_transpose(v, q);  // now: column 4 qd + q, rows 4 j .. 4 j + 3
-      *reinterpret_cast<bf16x4*>(T + ((4 * qd + q) * WG_TP + 4 * j) * 2) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      wg_quad_transpose(v, q);  // now: column 4 qd + q, rows 4 (2 j + jh) .. + 3
+      *reinterpret_cast<bf16x4*>(T + ((4 * qd + q) * WG_TP + 4 * (2 * j + jh)) * 2) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
     }
   };
-  f32x4 acc[4][17];
+  f32x4 acc[2][17];
 #pragma unroll
-  for (int nt = 0; nt < 4; nt++)
+  for (int nt = 0; nt < 2; nt++)
 #pragma unroll
     for (int kt = 0; kt < 17; kt++) acc[nt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const __bf16 one = (__bf16)1.0f;
@@ -430,31 +432,31 @@ __global__ __launch_bounds__(256) void mlp_wgrad_fused_kernel(MlpWgArgs a) {
     stash(rz, TZ);
     __syncthreads();  // (the other buffer is still being read by slower waves: two buffers, one barrier per step)
     if (s + 1 < nsteps) { fetch(X, ldX, K, vecX, s + 1, rx); fetch(Z, ldZ, N, vecZ, s + 1, rz); }
-    // this wave's N tiles: w, w + 4, w + 8, w + 12
-    bf16x8 zf[4];
+    // this wave's N tiles: w, w + 8
+    bf16x8 zf[2];
 #pragma unroll
-    for (int nt = 0; nt < 4; nt++)
-      zf[nt] = *reinterpret_cast<const bf16x8*>(TZ + ((16 * (w + 4 * nt) + i) * WG_TP + 8 * g) * 2);
+    for (int nt = 0; nt < 2; nt++)
+      zf[nt] = *reinterpret_cast<const bf16x8*>(TZ + ((16 * (w + 8 * nt) + i) * WG_TP + 8 * g) * 2);
 #pragma unroll
     for (int kt = 0; kt < 16; kt++) {
       if (kt < KT) {  // (wave-uniform; a break would leave acc[][] dynamically indexed, i.e. in scratch)
         const bf16x8 xf = *reinterpret_cast<const bf16x8*>(TX + ((16 * kt + i) * WG_TP + 8 * g) * 2);
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
-          if (w + 4 * nt < NT) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, zf[nt], acc[nt][kt], 0, 0, 0);
+        for (int nt = 0; nt < 2; nt++)
+          if (w + 8 * nt < NT) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, zf[nt], acc[nt][kt], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int nt = 0; nt < 4; nt++)  // bias gradient: all-ones X fragment
-      if (w + 4 * nt < NT) acc[nt][16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, zf[nt], acc[nt][16], 0, 0, 0);
+    for (int nt = 0; nt < 2; nt++)  // bias gradient: all-ones X fragment
+      if (w + 8 * nt < NT) acc[nt][16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, zf[nt], acc[nt][16], 0, 0, 0);
   }
   // partial dW [N][K] (this lane: n = 16 tile + i, k = 16 kt + 4 g .. + 3) and db [N]
   float* rec = a.slab[p] + (long)blockIdx.x * a.rec + a.sloff[l];
   const bool vecK = (K & 3) == 0;
 #pragma unroll
-  for (int nt = 0; nt < 4; nt++) {
-    const int n = 16 * (w + 4 * nt) + i;
-    if (w + 4 * nt >= NT || n >= N) continue;
+  for (int nt = 0; nt < 2; nt++) {
+    const int n = 16 * (w + 8 * nt) + i;
+    if (w + 8 * nt >= NT || n >= N) continue;
 #pragma unroll
     for (int kt = 0; kt < 16; kt++) {
       const int k = 16 * kt + 4 * g;
@@ -489,7 +491,8 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(MlpWgReduceArgs a
   float* __restrict__ gr = a.grad[p];
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
     float t = 0.f;
-    for (int s = 0; s < ns; s++) t += s0[(long)s * a.rec + e];
+#pragma unroll 8
+    for (int s = 0; s < ns; s++) t += s0[(long)s * a.rec + e];  // slice order: deterministic (loads batch, adds stay ordered)
     float* d = gr + (e < nw ? a.woff[l] + e : a.boff[l] + (e - nw));
     *d = a.accumulate ? *d + t : t;
   }
@@ -543,8 +546,8 @@ int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* cons
   static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_fused_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_OPB) == hipSuccess ? 0 : -1;
   if (once) return -1;
-  hipLaunchKernelGGL(mlp_wgrad_fused_kernel, dim3(maxs, L, n2), dim3(256), 4 * WG_OPB, st, a);
-  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(64, L, n2), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(mlp_wgrad_fused_kernel, dim3(maxs, L, n2), dim3(512), 4 * WG_OPB, st, a);
+  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(256, L, n2), dim3(256), 0, st, r);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
