@@ -3,11 +3,13 @@
 // (reference networks/actors/*.py, critics/*.py: nn.Sequential of Linear + SiLU/ReLU).
 //
 // As a chain of per-layer GEMM launches each layer costs ~13-25 us of launch + dependent global
-// round trips for a few microseconds of work.  Here a workgroup keeps a 64-row block of the batch
-// resident: the layer input lives in LDS as bf16, a wave owns 64 output columns (4 N tiles x 4 M
-// tiles of accumulators), streams its weight rows straight from global memory into B fragments
-// (register double buffer) and writes the fp32 pre-activation / activation rows the backward needs
-// plus the bf16 copy that is the next layer's LDS input.
+// round trips for a few microseconds of work.  Here a workgroup keeps a 32-row block of the batch
+// resident: the layer input lives in LDS as bf16, each of the 16 waves owns 16 output columns, streams its
+// weight rows straight from global memory into MFMA fragments (the whole layer in flight at once, the next
+// layer's during the epilogue) and writes the fp32 pre-activation / activation rows the backward needs
+// plus the bf16 copy that is the next layer's LDS input.  Four waves per SIMD: with one (4 waves x 64
+// columns) a wave's LDS reads, fragment waits and epilogue added up with its MFMAs instead of hiding
+// behind another wave's - the 8 launches of these kernels on the step's dependent chain took 30 % longer.
 #include "mlp_fused.h"
 
 #include "common.h"
@@ -19,6 +21,9 @@ constexpr int BMF = 32;   // rows per workgroup (32: twice the workgroups of 64 
 constexpr int MTF = BMF / 16;
 constexpr int XP = 264;   // LDS row pitch (bf16): 528 B -> 16 consecutive rows hit distinct bank groups
 constexpr int MAXD = 256; // widest layer
+// 16 waves per workgroup, 16 output columns each (measured at the bench shapes, ms/step: 4 waves 1.183,
+// 8 waves 1.122, 16 waves 1.106)
+constexpr int MF_NT = 1024, MF_CW = MAXD / (MF_NT / 64), MF_NTW = MF_CW / 16;
 
 struct MlpFwdArgs {
   const float* x[MF_MAXP];
@@ -57,30 +62,30 @@ __device__ __forceinline__ bf16x8 load_w(const __bf16* __restrict__ W, int K, in
   return on ? bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} : bf16x8{z, z, z, z, z, z, z, z};
 }
 
-__global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
+__global__ __launch_bounds__(MF_NT) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* X = reinterpret_cast<__bf16*>(smem);  // [2][BMF][XP]
   const int p = blockIdx.y, m0 = blockIdx.x * BMF, M = a.M[p];
   if (m0 >= M) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
-  const int n0 = 64 * w;
-  bf16x8 B[8][4];
+  const int n0 = MF_CW * w;
+  bf16x8 B[8][MF_NTW];
   auto load_layer = [&](int l) {  // every weight fragment of the layer in flight at once (K <= 256)
     const int K = a.dims[l], N = a.dims[l + 1];
     const __bf16* Wb = a.pbf[p] + a.woff[l];
 #pragma unroll
     for (int ks = 0; ks < 8; ks++)
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) B[ks][nt] = load_w(Wb, K, N, n0 + 16 * nt + i, 32 * ks + 8 * g);
+      for (int nt = 0; nt < MF_NTW; nt++) B[ks][nt] = load_w(Wb, K, N, n0 + 16 * nt + i, 32 * ks + 8 * g);
   };
   if (n0 < a.dims[1]) load_layer(0);  // travels while the input rows are staged
   // zero both buffers once: padded K columns are multiplied by zero weights and must stay finite
-  for (int e = tid; e < 2 * BMF * XP / 8; e += 256) reinterpret_cast<f32x4*>(X)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int e = tid; e < 2 * BMF * XP / 8; e += MF_NT) reinterpret_cast<f32x4*>(X)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   {  // stage the input rows as bf16
     const int K0 = a.dims[0], c8 = K0 / 8;
     const float* x = a.x[p];
-    for (int c = tid; c < BMF * c8; c += 256) {
+    for (int c = tid; c < BMF * c8; c += MF_NT) {
       const int row = c / c8, k = (c - row * c8) * 8;
       if (m0 + row < M) {
         const float* q = x + (long)(m0 + row) * a.ldx + k;
@@ -102,18 +107,18 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
     const float* bias = a.params[p] + a.boff[l];
     const __bf16* xin = X + cur * BMF * XP;
     __bf16* xout = X + (cur ^ 1) * BMF * XP;
-    f32x4 acc[MTF][4], bvv[4];
+    f32x4 acc[MTF][MF_NTW], bvv[MF_NTW];
     const bool vec = (N & 3) == 0;
     if (n0 < N) {  // wave-uniform: this wave owns output columns [n0, n0 + 64)
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) {  // bias vectors travel under the MFMA loop (clamped address, masked below)
+      for (int nt = 0; nt < MF_NTW; nt++) {  // bias vectors travel under the MFMA loop (clamped address, masked below)
         const int col = n0 + 16 * nt + 4 * g;
         bvv[nt] = *reinterpret_cast<const f32x4*>(bias + (vec && col < N ? col : 0));
       }
 #pragma unroll
       for (int mt = 0; mt < MTF; mt++)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < MF_NTW; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
         if (ks >= KS) break;
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MTF; mt++) A[mt] = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
+        for (int nt = 0; nt < MF_NTW; nt++)
           if (n0 + 16 * nt < N) {
 #pragma unroll
             // weights as the A operand: D[n][m] - a lane then holds 4 CONSECUTIVE output columns of one row,
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
       float* zb = a.zoff[p][l] >= 0 ? a.act[p] + a.zoff[p][l] : nullptr;
       float* yb = a.act[p] + a.yoff[p][l];
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) {
+      for (int nt = 0; nt < MF_NTW; nt++) {
         const int col = n0 + 16 * nt + 4 * g;  // this lane's 4 consecutive columns
         if (n0 + 16 * nt >= N) continue;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -208,30 +213,30 @@ __global__ __launch_bounds__(256) void mlp_pack_wt_kernel(WtPackArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
+__global__ __launch_bounds__(MF_NT) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* X = reinterpret_cast<__bf16*>(smem);  // [2][BMF][XP]
   const int p = blockIdx.y, m0 = blockIdx.x * BMF, M = a.M[p];
   if (m0 >= M) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
-  const int n0 = 64 * w;  // this wave's output columns (input features of the layer)
-  bf16x8 B[8][4];
+  const int n0 = MF_CW * w;  // this wave's output columns (input features of the layer)
+  bf16x8 B[8][MF_NTW];
   auto load_layer = [&](int l) {
     const int KO = a.dims[l], NP = (a.dims[l + 1] + 7) / 8 * 8;  // outputs, (padded) reduction length
     const __bf16* T = a.wt[p] + a.wtoff[l];
 #pragma unroll
     for (int ks = 0; ks < 8; ks++)
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) B[ks][nt] = load_w(T, NP, KO, n0 + 16 * nt + i, 32 * ks + 8 * g);
+      for (int nt = 0; nt < MF_NTW; nt++) B[ks][nt] = load_w(T, NP, KO, n0 + 16 * nt + i, 32 * ks + 8 * g);
   };
   const int l_last = a.d_x[p] ? 0 : 1;  // layer 0's dgrad only if the input gradient is wanted
   if (a.L - 1 >= l_last && n0 < a.dims[a.L - 1]) load_layer(a.L - 1);  // travels while d_out is staged
-  for (int e = tid; e < 2 * BMF * XP / 8; e += 256) reinterpret_cast<f32x4*>(X)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int e = tid; e < 2 * BMF * XP / 8; e += MF_NT) reinterpret_cast<f32x4*>(X)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   {  // stage dZ of the last layer (= d_out rows) as bf16
     const int NL = a.dims[a.L];
     const float* d = a.d_out[p];
-    for (int c = tid; c < BMF * NL; c += 256) {
+    for (int c = tid; c < BMF * NL; c += MF_NT) {
       const int row = c / NL, n = c - row * NL;
       if (m0 + row < M) X[row * XP + n] = (__bf16)d[(long)(m0 + row) * a.ldo + n];
     }
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
     const int KO = a.dims[l], NR = a.dims[l + 1], KS = (NR + 31) / 32;
     const __bf16* xin = X + cur * BMF * XP;
     __bf16* xout = X + (cur ^ 1) * BMF * XP;
-    f32x4 acc[MTF][4], svv[MTF][4];
+    f32x4 acc[MTF][MF_NTW], svv[MTF][MF_NTW];
     const int pact = l > 0 ? a.acts[l - 1] : ACT_NONE;
     const float* src = (l > 0 && a.srcoff[p][l - 1] >= 0) ? a.act[p] + a.srcoff[p][l - 1] : nullptr;
     const int ldout = l > 0 ? KO : a.ldd;
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
     if (n0 < KO) {
       if (src && vec) {  // the activation-derivative sources travel under the MFMA loop (clamped, masked below)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
+        for (int nt = 0; nt < MF_NTW; nt++)
 #pragma unroll
           for (int mt = 0; mt < MTF; mt++) {
             const int col = n0 + 16 * nt + 4 * g, row = m0 + 16 * mt + i;
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
 #pragma unroll
       for (int mt = 0; mt < MTF; mt++)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < MF_NTW; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
         if (ks >= KS) break;
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MTF; mt++) A[mt] = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
+        for (int nt = 0; nt < MF_NTW; nt++)
           if (n0 + 16 * nt < KO) {
 #pragma unroll
             for (int mt = 0; mt < MTF; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nt], A[mt], acc[mt][nt], 0, 0, 0);
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
     if (n0 < KO) {
       float* out = l > 0 ? a.dz[p] + a.dzoff[p][l - 1] : a.d_x[p];
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) {
+      for (int nt = 0; nt < MF_NTW; nt++) {
         const int col = n0 + 16 * nt + 4 * g;  // this lane's 4 consecutive columns (D = W^T-frag x dZ-frag)
         if (n0 + 16 * nt >= KO) continue;
 #pragma unroll
@@ -592,7 +597,7 @@ int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act
   static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_bwd_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
-  hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3((maxM + BMF - 1) / BMF, nprob), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3((maxM + BMF - 1) / BMF, nprob), dim3(MF_NT), lds, st, a);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
@@ -626,6 +631,6 @@ int mlp_fused_fwd(int nprob, const float* const* x, int ldx, const float* const*
   static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_fwd_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
-  hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3((maxM + BMF - 1) / BMF, nprob), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3((maxM + BMF - 1) / BMF, nprob), dim3(MF_NT), lds, st, a);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
