@@ -643,9 +643,14 @@ extern "C" int tacorl_encoder_bwd(int nprob, const void* const* img, const float
 
 // ---- bf16 / bf16-image / templated-geometry variant: FC tail and soft-argmax as above, the three
 // convolutions' backward through the per-image LDS-resident kernels of encoder_bwd_fused.hip.
+static const int kFcDims[3] = {128, 256, 32};
 static size_t enc_fc_slab_bytes(int nprob, long maxn) {
   size_t a = wgrad_ws_bytes(nprob, 256, 32, maxn), b = wgrad_ws_bytes(nprob, 128, 256, maxn);
-  return ((a > b ? a : b) + 255) & ~(size_t)255;
+  int Mx[EBW_MAXP];  // the one-launch weight gradients of the FC tail (mlp_fused_wgrad): a record per slice
+  for (int p = 0; p < nprob && p < EBW_MAXP; p++) Mx[p] = (int)maxn;
+  const size_t c = mlp_fused_wgrad_slab_floats(nprob, Mx, 2, kFcDims) * sizeof(float);
+  a = a > b ? a : b;
+  return ((a > c ? a : c) + 255) & ~(size_t)255;
 }
 // Workspace of the fused encoder backward: [per-problem scratch d_h1 | d_sa | dz3 | .. | dtemp][FC W^T (bf16)]
 // [FC wgrad slabs][conv backward workspace (ebw_ws_bytes)].
@@ -656,7 +661,6 @@ struct EncBwdPlan {
   long so[EBW_MAXP][6], ao[EBW_MAXP][5], sbase[EBW_MAXP];  // scratch / activation offsets (floats)
   long maxn;
 };
-static const int kFcDims[3] = {128, 256, 32};
 static const int kFcActs[2] = {ACT_RELU, ACT_NONE};
 static bool enc_bwd_plan(int nprob, const int* n_img, int H, int W, EncBwdPlan& pl) {
   if (!enc_dims(H, W, pl.d) || !ebw_supported(H, W) || nprob < 1 || nprob > EBW_MAXP) return false;
@@ -764,6 +768,22 @@ extern "C" int tacorl_encoder_bwd_fused_fc_wgrad(int nprob, const float* const* 
     g_fw1[p] = G + pl.po[E_FW1]; g_fb1[p] = G + pl.po[E_FB1]; g_fw2[p] = G + pl.po[E_FW2]; g_fb2[p] = G + pl.po[E_FB2];
   }
   void* slab = (unsigned char*)ws + pl.slab_off;
+  if (mlp_fused_wgrad_ok(nprob, 2, kFcDims) &&
+      mlp_fused_wgrad_slab_floats(nprob, n_img, 2, kFcDims) * sizeof(float) <= pl.slab_bytes) {
+    // both FC layers of every network in one launch + one reduce (they sit on the backward's dependent chain)
+    long yoffs[MF_MAXP * MF_MAXL] = {}, dzoffs[MF_MAXP * MF_MAXL] = {};
+    const float* dzb[EBW_MAXP];
+    for (int p = 0; p < nprob; p++) {
+      yoffs[p * MF_MAXL] = pl.ao[p][4];                 // fc1 output h1 inside act[p]
+      dzoffs[p * MF_MAXL] = pl.sbase[p] + pl.so[p][0];  // d_h1 inside the workspace
+      dzb[p] = (const float*)ws;
+    }
+    const long wo[2] = {pl.po[E_FW1], pl.po[E_FW2]}, bo[2] = {pl.po[E_FB1], pl.po[E_FB2]};
+    if (mlp_fused_wgrad(nprob, sa, 128, act, d_out, 32, dzb, grads, (float*)slab, n_img, 2, kFcDims, yoffs, dzoffs, wo, bo,
+                        accumulate, st))
+      FAIL(TACORL_ELAUNCH, "encoder_bwd_fused_fc_wgrad: launch failed");
+    return TACORL_OK;
+  }
   CHECK(k_linear_wgrad(nprob, h1, 256, d_out, 32, n_img, 256, 32, g_fw2, g_fb2, accumulate, slab, pl.slab_bytes, TACORL_BF16, st));
   CHECK(k_linear_wgrad(nprob, sa, 128, d_h1, 256, n_img, 128, 256, g_fw1, g_fb1, accumulate, slab, pl.slab_bytes, TACORL_BF16, st));
   return TACORL_OK;

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(MF_NT) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
 // fragments are contiguous 16-byte LDS reads.  X is the MFMA A operand (D rows = K index: a lane ends with 4
 // consecutive k of one n -> 16-byte slab stores); the bias gradient is one more K tile with an all-ones
 // fragment.  Slices are summed by mlp_wgrad_reduce_kernel in slice order (deterministic).
-constexpr int WG_MS = 256;    // batch rows per workgroup
+constexpr int WG_MS = 256;    // most batch rows per workgroup (a.ms: chosen per call, a multiple of WG_MT)
 constexpr int WG_MT = 32;     // rows per staged tile (one MFMA k-step)
 constexpr int WG_TP = 40;     // bf16 pitch of a transposed row [col][32 m] (80 B: 16 cols hit distinct 16-B slots)
 constexpr int WG_OPB = 256 * WG_TP * 2;  // bytes of one staged operand tile
@@ -356,7 +356,7 @@ struct MlpWgArgs {
   long sloff[MF_MAXL];          // offset of layer l inside a record: [N][K] then [N]
   long rec;                     // floats per record
   int dims[MF_MAXL + 1];
-  int L, ldx, ldo;
+  int L, ldx, ldo, ms;
 };
 
 __device__ __forceinline__ float wg_dpp1(float x) {
@@ -376,7 +376,7 @@ __device__ __forceinline__ void wg_quad_transpose(f32x4& v, int q) {
 
 __global__ __launch_bounds__(512) void mlp_wgrad_fused_kernel(MlpWgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 buffers][X^T | dZ^T] tiles
-  const int p = blockIdx.z, l = blockIdx.y, m0 = blockIdx.x * WG_MS, M = a.M[p];
+  const int p = blockIdx.z, l = blockIdx.y, m0 = blockIdx.x * a.ms, M = a.M[p];
   if (m0 >= M) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4, q = tid & 3;
   const int qd = (tid >> 2) & 63, jh = tid >> 8;  // column quad, row-group parity of this thread in the staging
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(512) void mlp_wgrad_fused_kernel(MlpWgArgs a) {
   const bool vecX = (ldX & 3) == 0 && (K & 3) == 0 && ((uintptr_t)X & 15) == 0;
   const bool vecZ = (ldZ & 3) == 0 && (N & 3) == 0 && ((uintptr_t)Z & 15) == 0;
   const int KT = (K + 15) >> 4, NT = (N + 15) >> 4;
-  const int mend = min(M, m0 + WG_MS), nsteps = (mend - m0 + WG_MT - 1) / WG_MT;
+  const int mend = min(M, m0 + a.ms), nsteps = (mend - m0 + WG_MT - 1) / WG_MT;
 
   // staging: quad qd owns columns 4 qd .. 4 qd + 3, lane q of it row 4 (2 j + jh) + q of the tile (j = 0..3)
   f32x4 rx[4], rz[4];
@@ -520,10 +520,20 @@ static long mlp_wgrad_record(int L, const int* dims, long* sloff) {
   }
   return off;
 }
+// Rows per slice: enough slices that the launch has ~128+ workgroups (a 256-row problem as ONE 8-step workgroup
+// per layer takes as long as a 3328-row one), at most WG_MS rows, at least one staged tile.
+static int mlp_wgrad_rows(int nprob, const int* M, int L) {
+  long rows = 0;
+  for (int p = 0; p < nprob; p++) rows += M[p] > 0 ? M[p] : 0;
+  long ms = rows * L / 128;
+  ms = (ms + WG_MT - 1) / WG_MT * WG_MT;
+  return (int)(ms < WG_MT ? WG_MT : ms > WG_MS ? WG_MS : ms);
+}
 size_t mlp_fused_wgrad_slab_floats(int nprob, const int* M, int L, const int* dims) {
   const long rec = mlp_wgrad_record(L, dims, nullptr);
+  const int ms = mlp_wgrad_rows(nprob, M, L);
   size_t tot = 0;
-  for (int p = 0; p < nprob; p++) tot += (size_t)((M[p] + WG_MS - 1) / WG_MS) * rec;
+  for (int p = 0; p < nprob; p++) tot += (size_t)((M[p] + ms - 1) / ms) * rec;
   return tot;
 }
 int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* const* act, const float* const* d_out, int ldo,
@@ -533,13 +543,18 @@ int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* cons
   MlpWgReduceArgs r{};
   a.rec = r.rec = mlp_wgrad_record(L, dims, a.sloff);
   a.L = L; a.ldx = ldx; a.ldo = ldo; r.accumulate = accumulate;
+  {
+    int Mg[MF_MAXP], n = 0;  // only the problems that take part (same rule as the slab size query when all do)
+    for (int p = 0; p < nprob; p++) Mg[n++] = M[p];
+    a.ms = mlp_wgrad_rows(n, Mg, L);
+  }
   for (int l = 0; l <= L; l++) a.dims[l] = r.dims[l] = dims[l];
   for (int l = 0; l < L; l++) { r.sloff[l] = a.sloff[l]; r.woff[l] = woff[l]; r.boff[l] = boff[l]; }
   int n2 = 0, maxs = 0;
   float* sp = slab;
   for (int p = 0; p < nprob; p++) {
     if (!grads[p] || M[p] <= 0) continue;
-    const int ns = (M[p] + WG_MS - 1) / WG_MS;
+    const int ns = (M[p] + a.ms - 1) / a.ms;
     a.x[n2] = x[p]; a.act[n2] = act[p]; a.dlast[n2] = d_out[p]; a.dz[n2] = dz[p]; a.M[n2] = M[p]; a.slab[n2] = sp;
     r.slab[n2] = sp; r.grad[n2] = grads[p]; r.nslice[n2] = ns;
     for (int l = 0; l < L; l++) { a.yoff[n2][l] = yoff[p * MF_MAXL + l]; a.dzoff[n2][l] = dzoff[p * MF_MAXL + l]; }
