@@ -394,7 +394,8 @@ __global__ __launch_bounds__(256) void ebw_reduce_kernel(RdArgs a) {
   float sum = 0.f;
   if (e < per) {
     const float* s = a.slab[l] + (long)p * a.wpp * per + e;
-    for (int k = kg; k < a.wpp; k += 4) sum += s[(long)k * per];
+#pragma unroll 8
+    for (int k = kg; k < a.wpp; k += 4) sum += s[(long)k * per];  // (loads batch, the adds keep their order)
   }
   sh[kg][threadIdx.x & 63] = sum;
   __syncthreads();

@@ -119,6 +119,10 @@ class GraphMixin:
             self._graphs[key] = (gs, g_side)
             return
         gs, g_side = gs
+        stepped = getattr(self, "_stepped_blocks", None)
+        if stepped is not None:  # a replay runs no python: the optimiser kernels' writes are announced here
+            from .. import ops
+            ops.touched(*stepped())
         cur = torch.cuda.current_stream()
         for i, g in enumerate(gs):
             g.replay()

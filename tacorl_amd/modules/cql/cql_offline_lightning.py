@@ -130,6 +130,15 @@ class CQL_Offline(GraphMixin, LoggerMixin, nn.Module):
     def device(self):
         return self.dev
 
+    def _stepped_blocks(self):
+        """Parameter blocks the step's optimiser kernels write (see ops.touched / GraphMixin._run_segments)."""
+        e = self.engine
+        out = [e.actor.param, e.q1.param, e.q2.param, e.tq1.param, e.tq2.param, e.log_alpha.param, e.log_alpha_prime.param]
+        ad = getattr(self, "ad", None)
+        if ad is not None and getattr(self, "finetune_action_decoder", False):
+            out.append(ad.blk.param)
+        return out
+
     def named_gradients(self):
         e = self.engine
         out = {}

@@ -199,6 +199,8 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
             for blk in (net, pr.blk, ad.blk):
                 dist.all_reduce(blk.grad)
 
+    # (a graph replay runs no python: announce the optimiser's writes to torch's version counters - ops.touched)
+    self._stepped_blocks = (lambda: [net.param, pr.blk.param, ad.blk.param]) if optimize else None
     self._run_segments(("playlmp", B, T, tuple(sorted(hw.items())), optimize), [fwd_bwd, opt], [reduce_grads])
     lg = self.logs.cpu().tolist()
     names = ["kl_loss", "kl_loss_scaled", "action_loss", "gripper_accuracy", "random_plan_action_loss",

@@ -269,6 +269,15 @@ def adam_step_batch(items):
          (C.c_float * k)(*[float(i[4]) for i in items]), (C.c_float * k)(*[float(i[5]) for i in items]),
          ptr_array([i[6] for i in items]), ptr_array([i[7] for i in items]), (C.c_float * k)(*[float(i[8]) for i in items]),
          ptr(ws), ws.numel(), stream())
+    touched(*[i[0] for i in items], *[i[7] for i in items if i[7] is not None])
+
+
+def touched(*tensors):
+    """The library's kernels write parameter blocks through raw pointers, which torch's version counters do not see;
+    bump them by hand (host-side, no launch) so that caches keyed on `tensor._version` - the frozen-network weight
+    preparation - also notice optimiser steps.  Views share their base's counter."""
+    for t in tensors:
+        torch.autograd.graph.increment_version(t)
 
 
 def adam_step(param, grad, m, v, lr, max_norm, step_counter, target=None, tau=0.0):
@@ -277,3 +286,4 @@ def adam_step(param, grad, m, v, lr, max_norm, step_counter, target=None, tau=0.
     ws = workspace(nb, param.device, "adam")
     call("tacorl_adam_step", ptr(param), ptr(grad), ptr(m), ptr(v), n, float(lr), float(max_norm), ptr(step_counter),
          ptr(target), float(tau), ptr(ws), ws.numel(), stream())
+    touched(param, *([target] if target is not None else []))

@@ -596,6 +596,15 @@ def test_plan_recognition_fused_sample_and_frozen_cache():
     torch.cuda.synchronize()
     assert pr._prep_version != ver
     assert relerr(h3[:, :A], h_fus[:, :A] + 0.5) < 1e-5, "stale composed head after a weight update"
+    # the library's own optimiser writes through raw pointers: ops.adam_step announces it to the version counter
+    from tacorl_amd import ops
+    ver = pr._prep_version
+    blk = pr.blk
+    g_, m_, v_ = torch.ones_like(blk.param), torch.zeros_like(blk.param), torch.zeros_like(blk.param)
+    ops.adam_step(blk.param, g_, m_, v_, 1e-2, 0.0, torch.zeros(1, dtype=torch.int32, device=dev))
+    h4, _ = fused()
+    torch.cuda.synchronize()
+    assert pr._prep_version != ver and not torch.equal(h4, h3)
 
 
 def test_plan_recognition_fused_encoder():
