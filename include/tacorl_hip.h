@@ -226,6 +226,9 @@ int tacorl_copy_cols_batch(int n, const float* const* src, const int* ld_src, fl
 /* out[b][c] = sum_{j<reps} in[j*B+b][c] : gradient of that broadcast. */
 int tacorl_reduce_rows_mod(const float* in, int ld_in, float* out, int ld_out, int B, int cols,
                            int reps, tacorl_stream_t stream);
+/* n <= 4 such reductions of one shape in one launch. */
+int tacorl_reduce_rows_mod_batch(int n, const float* const* in, int ld_in, float* const* out, int ld_out, int B,
+                                 int cols, int reps, tacorl_stream_t stream);
 /* dst[r][0:A] = 2u-1 (last dim snapped to +-1 for a discrete gripper);
  * reference modules/cql/cql_offline_lightning.py:243-250. */
 int tacorl_uniform_actions(const float* u01, float* dst, int ld_dst, int rows, int A,

@@ -91,6 +91,7 @@ _SIGS = {
     "tacorl_copy_cols": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "tacorl_copy_cols_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "tacorl_reduce_rows_mod": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "tacorl_reduce_rows_mod_batch": (_i, [_i, _p, _i, _p, _i, _i, _i, _i, _p]),
     "tacorl_uniform_actions": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "tacorl_tanh_normal_sample": (_i, [_p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _p]),
     "tacorl_tanh_normal_sample_batch": (_i, [_i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p]),

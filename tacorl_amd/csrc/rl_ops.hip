@@ -220,6 +220,32 @@ extern "C" int tacorl_reduce_rows_mod(const float* in, int ld_in, float* out, in
   return LAUNCH_OK();
 }
 
+// the same for up to 4 (in, out) pairs of one shape in one launch (blockIdx.y = pair): the critics' state gradients
+struct RrmTbl { const float* in[4]; float* out[4]; };
+__global__ void reduce_rows_mod_batch_kernel(RrmTbl t, int ld_in, int ld_out, int B, int cols, int reps) {
+  const float* __restrict__ in = t.in[blockIdx.y];
+  float* __restrict__ out = t.out[blockIdx.y];
+  const long total = (long)B * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / cols), c = (int)(i - (long)b * cols);
+    float s = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < reps; j++) s += in[((long)j * B + b) * ld_in + c];  // loads batch, adds keep their order
+    out[(long)b * ld_out + c] = s;
+  }
+}
+extern "C" int tacorl_reduce_rows_mod_batch(int n, const float* const* in, int ld_in, float* const* out, int ld_out, int B,
+                                            int cols, int reps, tacorl_stream_t stream) {
+  if (n < 1 || n > 4) return TACORL_EINVAL;
+  if (B <= 0) return TACORL_OK;
+  RrmTbl t{};
+  for (int k = 0; k < n; k++) { t.in[k] = in[k]; t.out[k] = out[k]; }
+  const long total = (long)B * cols;
+  hipLaunchKernelGGL(reduce_rows_mod_batch_kernel, dim3((int)((total + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, t,
+                     ld_in, ld_out, B, cols, reps);
+  return LAUNCH_OK();
+}
+
 // uniform random actions: dst[r][0:A] = 2u - 1 (last dim snapped to +-1 if discrete gripper)
 // reference cql_offline_lightning.py:243-250
 __global__ void uniform_actions_kernel(const float* __restrict__ u01, float* __restrict__ dst, int ld_dst, int rows,

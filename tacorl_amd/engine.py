@@ -518,8 +518,8 @@ class ACEngine:
                            [self.qact["q1"], self.qact["q2"]], [self.dq["q1"], self.dq["q2"]], 1,
                            [self.q1.head(self.q1.grad), self.q2.head(self.q2.grad)], [self.dXQ["q1"], self.dXQ["q2"]],
                            self.ldq, [self.R, self.R], qd, qa)
-        for k in ("q1", "q2"):
-            ops.reduce_rows_mod(self.dXQ[k], 0, self.ldq, self.dS[k], 0, self.lds, B, self.E, 3 * n + 1)
+        call("tacorl_reduce_rows_mod_batch", 2, ops.ptr_array([self.dXQ["q1"], self.dXQ["q2"]]), self.ldq,
+             ops.ptr_array([self.dS["q1"], self.dS["q2"]]), self.lds, B, self.E, 3 * n + 1, ops.stream())
         ops.mark("b:critic_bwd")
         main_stream.wait_stream(self._bwd_stream)
         self._encoders_backward()
