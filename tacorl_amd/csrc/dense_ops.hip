@@ -426,10 +426,12 @@ struct SabArgs {
   int n[EBW_MAXP];
 };
 __global__ __launch_bounds__(256) void softargmax_bwd_batch_kernel(SabArgs a, int P, int OW) {
+  // lane = channel (a pixel's 64 channels are one 256-byte row: every load / store instruction moves whole rows),
+  // wave w takes pixels w, w + 4, ...; the per-channel max / sum meet across the four waves in LDS
   const int p = blockIdx.y, img = blockIdx.x;
   if (img >= a.n[p]) return;
-  __shared__ float sh[4];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = 16 * w + (lane & 15), g = lane >> 4;
+  __shared__ float shm[4][64], shs[4][64], sh[4];
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float t = a.temp[p][0];
   const float* q = a.y3[p] + (long)img * P * 64 + c;
   float* o = a.dz3[p] + (long)img * P * 64 + c;
@@ -437,24 +439,26 @@ __global__ __launch_bounds__(256) void softargmax_bwd_batch_kernel(SabArgs a, in
   float mx = -INFINITY;
 #pragma unroll
   for (int k = 0; k < SAB_MAXI; k++) {
-    const int i = g + 4 * k;
+    const int i = w + 4 * k;
     v[k] = i < P ? q[i * 64] : 0.f;
     if (i < P) mx = fmaxf(mx, v[k] / t);
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  shm[w][c] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(shm[0][c], shm[1][c]), fmaxf(shm[2][c], shm[3][c]));
   float se = 0.f;
 #pragma unroll
   for (int k = 0; k < SAB_MAXI; k++)
-    if (g + 4 * k < P) se += expf(v[k] / t - mx);
-  se += __shfl_xor(se, 16, 64);
-  se += __shfl_xor(se, 32, 64);
+    if (w + 4 * k < P) se += expf(v[k] / t - mx);
+  shs[w][c] = se;
+  __syncthreads();
+  se = ((shs[0][c] + shs[1][c]) + shs[2][c]) + shs[3][c];
   const float gx = a.d_sa[p][(long)img * 128 + 2 * c], gy = a.d_sa[p][(long)img * 128 + 2 * c + 1];
   const float dot = gx * a.sa[p][(long)img * 128 + 2 * c] + gy * a.sa[p][(long)img * 128 + 2 * c + 1];
   float dt = 0.f;
 #pragma unroll
   for (int k = 0; k < SAB_MAXI; k++) {
-    const int i = g + 4 * k;
+    const int i = w + 4 * k;
     if (i < P) {
       const float s = v[k] / t, pr = expf(s - mx) / se;
       const float ds = pr * (gx * (float)(i % OW) + gy * (float)(i / OW) - dot);
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(256) void softargmax_bwd_batch_kernel(SabArgs a, in
     }
   }
   dt = wave_sum(dt);
-  if (lane == 0) sh[w] = dt;
+  if (c == 0) sh[w] = dt;
   __syncthreads();
   if (threadIdx.x == 0) a.dtp[p][img] = sh[0] + sh[1] + sh[2] + sh[3];
 }
