@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--ad-every", type=int, default=1,
                     help="evaluate the (logging-only, frozen) action-decoder loss every k-th step; 1 = every step "
                          "as the reference does")
+    ap.add_argument("--frames", default="f32", choices=["f32", "u8"],
+                    help="f32: the reference's batch schema (transformed fp32 CHW frames; the contract of `value`); "
+                         "u8: the dataset's uint8 HWC frames, normalised on the GPU (SURVEY 8f N2; reported in DESIGN.md)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,6 +172,10 @@ def main():
     B, T, H, W = a.batch, 16, 84, 84
     mod = build_module(dev, a.dtype, T, world, a.ad_every)
     batch = synth_batch(B, T, H, W, dev, 1234 + rank)
+    if a.frames == "u8":  # the same frames quantised back to the dataset's format
+        q = lambda x, perm: ((x.permute(*perm) * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8).contiguous()  # noqa: E731
+        batch = dict(batch, states={k: q(v, (0, 1, 3, 4, 2)) for k, v in batch["states"].items()},
+                     goal={k: q(v, (0, 2, 3, 1)) for k, v in batch["goal"].items()})
     use_graph = (not a.no_graph) and hasattr(mod, "enable_graph")
     if use_graph:
         mod.enable_graph()
@@ -217,6 +224,7 @@ def main():
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "tacorl actor-critic training_step, frozen LMP (BASELINE configs[1])",
                        "per_gpu_batch": B, "global_batch": B * world, "window": T, "image": f"{H}x{W}x3",
+                       "frames": "fp32 CHW (reference batch schema)" if a.frames == "f32" else "uint8 HWC, normalised on the GPU",
                        "latent_plan": 16, "n_action_samples": 4, "phase": "Q (epoch>=bc_epochs)",
                        "action_decoder_loss": ("every step (reference behaviour)" if a.ad_every <= 1 else
                                                f"every {a.ad_every} steps (logging cadence)"), "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
@@ -231,7 +239,7 @@ def main():
                                    "LMPVisionEncoder forward, per-layer kernels (tacorl_encoder_fwd)",
                          "images_per_launch": n_img, "avg_ms": round(enc_ms, 4)},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.frames == "f32":
             from tacorl_amd import synth  # noqa: F401
 
             bc = {"states": {"rgb_static": batch["states"]["rgb_static"].cpu()},

@@ -210,6 +210,12 @@ int tacorl_pack_images(const float* src, long img_pitch, int src_nchw, void* dst
  * and the obs / goal / next-obs images of a TACORL step (reference get_rl_batch, tacorl.py:142-179). */
 int tacorl_pack_images_batch(int njobs, const float* const* src, const long* img_pitch, void* const* dst,
                              const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream);
+/* The dataset's own frame format: uint8 HWC (reference datamodule/dataset/play_dataset.py) -> NHWC fp32 / bf16 with the
+ * reference's transform pipeline applied on the way, ToTensor (x / 255) and Normalize(0.5, 0.5) ((t - 0.5) / 0.5) in
+ * fp32 (config .../rl_train.yaml:12-14): bit-identical to packing the transformed fp32 frames, a quarter of the
+ * bytes read.  Jobs as in tacorl_pack_images_batch; pitches in bytes; H*W*3 % 16 == 0, 16-byte aligned. */
+int tacorl_pack_images_u8_batch(int njobs, const void* const* src, const long* img_pitch_bytes, void* const* dst,
+                                const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream);
 /* reward = done = float(disp == 1) (done may be NULL) and acts_dst[0:n_acts] = acts_src[0:n_acts], one launch:
  * the small tensors of TACORL.get_rl_batch (reference modules/tacorl/tacorl.py:142-179).
  * disp_dtype: 0 float32, 1 int64, 2 int32, 3 uint8 / bool. */

@@ -105,6 +105,71 @@ extern "C" int tacorl_pack_images_batch(int njobs, const float* const* src, cons
   return LAUNCH_OK();
 }
 
+// ===================================================================== uint8 frames (dataset format)
+// The play dataset stores frames as uint8 HWC (reference datamodule/dataset/play_dataset.py, one .npz per frame);
+// the reference's CPU transform pipeline turns them into fp32 CHW with ToTensor (x / 255) and Normalize(0.5, 0.5)
+// ((t - 0.5) / 0.5) before the batch reaches the module (config/.../rl_train.yaml:12-14).  Shipping the uint8
+// frames and normalising here - the same two fp32 operations, then the cast to the image dtype - reads a quarter
+// of the bytes (and a quarter of the host link) and needs no layout change: the source is already NHWC.
+// 16 bytes per thread; H*W*3 % 16 == 0, pitches % 16 == 0, 16-byte aligned pointers.
+struct PackU8Tbl {
+  const unsigned char* src[PACK_MAXJ];
+  void* dst[PACK_MAXJ];
+  long pitch[PACK_MAXJ];  // bytes between images
+  int n[PACK_MAXJ];
+};
+typedef unsigned int pk_u32x4 __attribute__((ext_vector_type(4)));
+template <typename OutT>
+__global__ void pack_u8_batch_kernel(PackU8Tbl t, int chunks) {  // chunks = H*W*3 / 16
+  const int j = blockIdx.y;
+  const long total = (long)t.n[j] * chunks;
+  const unsigned char* __restrict__ src = t.src[j];
+  OutT* __restrict__ dst = reinterpret_cast<OutT*>(t.dst[j]);
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const long img = q / chunks;
+    const int c = (int)(q - img * chunks);
+    const pk_u32x4 v = *reinterpret_cast<const pk_u32x4*>(src + img * t.pitch[j] + (long)c * 16);
+    float f[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const float x = (float)((v[e >> 2] >> (8 * (e & 3))) & 0xffu);
+      f[e] = (x / 255.0f - 0.5f) / 0.5f;  // ToTensor, Normalize(0.5, 0.5): the reference's fp32 operations
+    }
+    OutT* d = dst + (img * chunks + c) * 16;
+    if constexpr (sizeof(OutT) == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        *reinterpret_cast<bf16x4*>(d + 4 * k) = bf16x4{(__bf16)f[4 * k], (__bf16)f[4 * k + 1], (__bf16)f[4 * k + 2], (__bf16)f[4 * k + 3]};
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) *reinterpret_cast<f32x4*>(d + 4 * k) = f32x4{f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]};
+    }
+  }
+}
+extern "C" int tacorl_pack_images_u8_batch(int njobs, const void* const* src, const long* img_pitch_bytes, void* const* dst,
+                                           const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream) {
+  const long bytes = (long)H * W * 3;
+  if (njobs < 1 || njobs > PACK_MAXJ || bytes % 16) return TACORL_EINVAL;
+  PackU8Tbl t{};
+  long mx = 0;
+  int m = 0;
+  for (int j = 0; j < njobs; j++) {
+    if (n_img[j] <= 0) continue;
+    if (((uintptr_t)src[j] & 15) || ((uintptr_t)dst[j] & 15) || img_pitch_bytes[j] % 16) return TACORL_EINVAL;
+    t.src[m] = (const unsigned char*)src[j]; t.dst[m] = dst[j]; t.pitch[m] = img_pitch_bytes[j]; t.n[m] = n_img[j];
+    const long tot = (long)n_img[j] * (bytes / 16);
+    mx = tot > mx ? tot : mx;
+    m++;
+  }
+  if (m == 0) return TACORL_OK;
+  const int blocks = (int)((mx + 255) / 256 > 8192 ? 8192 : (mx + 255) / 256);
+  if (dst_dtype == TACORL_BF16)
+    hipLaunchKernelGGL(pack_u8_batch_kernel<__bf16>, dim3(blocks, m), dim3(256), 0, (hipStream_t)stream, t, (int)(bytes / 16));
+  else
+    hipLaunchKernelGGL(pack_u8_batch_kernel<float>, dim3(blocks, m), dim3(256), 0, (hipStream_t)stream, t, (int)(bytes / 16));
+  return LAUNCH_OK();
+}
+
 // ===================================================================== small transition tensors
 // reward = done = (disp == 1) as float (TACORL.get_rl_batch, reference tacorl.py:142-179) and the action window
 // copy, in one launch instead of four (compare, two casts, copy) in front of every step.

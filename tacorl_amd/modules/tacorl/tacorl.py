@@ -103,8 +103,13 @@ class TACORL(CQL_Offline):
 
     def _stage_frames(self, batch, noise, nchw=True):
         """Eager part of the step: pack the window frames (reference NCHW fp32 -> NHWC image dtype) into
-        fixed buffers, copy the small tensors, draw / copy the noise."""
+        fixed buffers, copy the small tensors, draw / copy the noise.
+        uint8 frames - the dataset's own format, (B, T, H, W, 3) with goal (B, H, W, 3) - are taken as they are
+        and normalised on the way (ToTensor + Normalize(0.5, 0.5), bit-identical to the transformed fp32 frames)."""
         states = batch["states"]
+        u8 = next(iter(states.values())).dtype == torch.uint8
+        if u8:
+            nchw = False
         B, T = next(iter(states.values())).shape[:2]
         hw = {c: (tuple(v.shape[-2:]) if nchw else tuple(v.shape[-3:-1])) for c, v in states.items()}
         self.engine.extra_normal = {"eps_pr": (B, self.action_dim)}  # drawn with the engine's noise (one launch)
@@ -117,16 +122,21 @@ class TACORL(CQL_Offline):
         for c in sorted(set(self.all_modalities) | set(e.cams)):
             H, W = hw[c]
             v = states[c]
-            assert v.is_cuda and v.is_contiguous() and v.dtype == torch.float32
+            sz = 1 if u8 else 4  # bytes per source element
+            assert v.is_cuda and v.is_contiguous() and v.dtype == (torch.uint8 if u8 else torch.float32)
             jobs = [(v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), B * T)] if c in self.all_modalities else []
             if c in e.cams:
                 g = batch["goal"][c]
-                assert g.is_cuda and g.is_contiguous() and g.dtype == torch.float32
+                assert g.is_cuda and g.is_contiguous() and g.dtype == v.dtype
                 esz, img = e.X3[c].element_size(), H * W * 3
                 x3 = e.X3[c].data_ptr()
                 jobs += [(v.data_ptr(), T * 3 * H * W, x3, B), (g.data_ptr(), 3 * H * W, x3 + B * img * esz, B),
-                         (v.data_ptr() + 4 * (T - 1) * 3 * H * W, T * 3 * H * W, x3 + 2 * B * img * esz, B)]
-            if nchw and (H * W) % 4 == 0:  # one launch for the window frames and the obs / goal / next images
+                         (v.data_ptr() + sz * (T - 1) * 3 * H * W, T * 3 * H * W, x3 + 2 * B * img * esz, B)]
+            if u8:
+                if (H * W * 3) % 16 or any(j[0] % 16 for j in jobs):
+                    raise ValueError("uint8 frames: H*W*3 must be a multiple of 16 and the tensors 16-byte aligned")
+                ops.pack_images_u8_batch(jobs, xd, H, W)  # pitches are in bytes = elements
+            elif nchw and (H * W) % 4 == 0:  # one launch for the window frames and the obs / goal / next images
                 import ctypes as C
                 call("tacorl_pack_images_batch", len(jobs), (C.c_void_p * len(jobs))(*[j[0] for j in jobs]),
                      (C.c_long * len(jobs))(*[j[1] for j in jobs]), (C.c_void_p * len(jobs))(*[j[2] for j in jobs]),

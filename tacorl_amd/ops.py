@@ -174,6 +174,13 @@ def pack_images_batch(jobs, dst_dtype_flag, H, W):
          (C.c_void_p * k)(*[j[2] for j in jobs]), int_array([j[3] for j in jobs]), dst_dtype_flag, H, W, stream())
 
 
+def pack_images_u8_batch(jobs, dst_dtype_flag, H, W):
+    """jobs: [(src_ptr, image_pitch_bytes, dst_ptr, n_images)], uint8 HWC frames -> normalised NHWC, one launch."""
+    k = len(jobs)
+    call("tacorl_pack_images_u8_batch", k, (C.c_void_p * k)(*[j[0] for j in jobs]), (C.c_long * k)(*[j[1] for j in jobs]),
+         (C.c_void_p * k)(*[j[2] for j in jobs]), int_array([j[3] for j in jobs]), dst_dtype_flag, H, W, stream())
+
+
 def _at(t, off):
     return C.c_void_p(t.data_ptr() + 4 * off)
 

@@ -191,3 +191,33 @@ def test_fullsize_cql_baseline_c5():
     logs = mod.engine.metrics()
     assert all(v == v and abs(v) < 1e30 for v in logs.values()), logs
     assert not torch.equal(before, mod.engine.q1.param)
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f32"])
+def test_uint8_frames_equal_transformed_fp32_frames(compute):
+    """the dataset's uint8 HWC frames handed to the step as they are (normalised on the GPU:
+    ToTensor + Normalize(0.5, 0.5)) must give bit-identical image buffers, and so an identical step, to the
+    reference route (the same frames transformed to fp32 CHW on the host side)."""
+    dev = torch.device("cuda:0")
+    n = 32
+    g = torch.Generator(device=dev).manual_seed(5)
+    s8 = torch.randint(0, 256, (n, T, H, W, 3), device=dev, dtype=torch.uint8, generator=g)
+    g8 = torch.randint(0, 256, (n, H, W, 3), device=dev, dtype=torch.uint8, generator=g)
+    base = _batch(n)
+    # torchvision ToTensor (x.div(255)) + Normalize(0.5, 0.5) ((t - 0.5) / 0.5), on the CPU as the dataloader workers
+    # run them (a GPU tensor / python scalar is computed as x * (1 / 255) by torch: 1 ulp off the true quotient)
+    tf = lambda x: ((x.cpu().float().div(255) - 0.5) / 0.5).to(dev)  # noqa: E731
+    b32 = dict(base, states={"rgb_static": tf(s8).permute(0, 1, 4, 2, 3).contiguous()},
+               goal={"rgb_static": tf(g8).permute(0, 3, 1, 2).contiguous()})
+    b8 = dict(base, states={"rgb_static": s8}, goal={"rgb_static": g8})
+    ma, mb = _mod(compute), _mod(compute)
+    ma.training_step(b32)
+    nz = _noise(ma)
+    mb.training_step(b8, noise=nz)
+    torch.cuda.synchronize()
+    assert torch.equal(ma.frames["rgb_static"], mb.frames["rgb_static"])
+    assert torch.equal(ma.engine.X3["rgb_static"], mb.engine.X3["rgb_static"])
+    la, lb = _logs(ma), _logs(mb)
+    assert la == lb, (la, lb)
+    for (ka, va), (kb, vb) in zip(sorted(ma.state_dict().items()), sorted(mb.state_dict().items())):
+        assert ka == kb and torch.equal(va, vb), ka
