@@ -248,6 +248,17 @@ class ACEngine:
         xd = BF16 if self.img_dtype == torch.bfloat16 else F32
         esz, img = self.X3[cam].element_size(), H * W * 3
         jobs = []
+        if obs.dtype == torch.uint8:
+            # the dataset's uint8 HWC frames: ToTensor + Normalize(0.5, 0.5) applied by the pack (bit-identical to the
+            # host-transformed fp32 route, a quarter of the bytes)
+            for i, t in enumerate((obs, goal, nxt)):
+                assert t.is_cuda and t.dtype == torch.uint8 and t[0].is_contiguous() and tuple(t.shape[-3:]) == (H, W, 3)
+                pitch = t.stride(0) if t.shape[0] > 1 else img
+                jobs.append((t.data_ptr(), pitch, self.X3[cam].data_ptr() + i * self.B * img * esz, self.B))
+            if img % 16 or any(j[0] % 16 or j[1] % 16 for j in jobs):
+                raise ValueError("uint8 frames: H*W*3 and the image pitch must be multiples of 16, tensors 16-byte aligned")
+            ops.pack_images_u8_batch(jobs, xd, H, W)
+            return
         for i, t in enumerate((obs, goal, nxt)):
             assert t.is_cuda and t.dtype == torch.float32 and t[0].is_contiguous()
             pitch = t.stride(0) if t.shape[0] > 1 else 3 * H * W

@@ -158,6 +158,8 @@ class CQL_Offline(GraphMixin, LoggerMixin, nn.Module):
         e = self.engine
         B = action.shape[0]
         hw = {}
+        if obs[e.cams[0]].dtype == torch.uint8:  # the dataset's uint8 HWC frames: normalised on the GPU (engine.load_images)
+            nchw = False
         for c in e.cams:
             t = obs[c]
             hw[c] = tuple(t.shape[-2:]) if nchw else tuple(t.shape[-3:-1])

@@ -159,6 +159,9 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
     states = batch["states"]
     cams, net, pr, ad = self.plan_proposal_obs_modalities, self.net, self.pr, self.ad
     B, T = next(iter(states.values())).shape[:2]
+    u8 = next(iter(states.values())).dtype == torch.uint8  # the dataset's uint8 HWC frames: normalised by the pack
+    if u8:
+        nchw = False
     hw = {c: (tuple(v.shape[-2:]) if nchw else tuple(v.shape[-3:-1])) for c, v in states.items()}
     _playlmp_ensure(self, B, T, hw)
     R, Ec, A, cd = B * T, 32 * len(cams), pr.A, self.compute
@@ -175,7 +178,11 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
     for c in cams:
         H, W = hw[c]
         v = states[c].to(self.dev)
-        if nchw and (H * W) % 4 == 0 and v.data_ptr() % 16 == 0:
+        if u8:
+            if (H * W * 3) % 16 or v.data_ptr() % 16 or not v.is_contiguous():
+                raise ValueError("uint8 frames: contiguous, 16-byte aligned, H*W*3 a multiple of 16")
+            ops.pack_images_u8_batch([(v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), R)], xd, H, W)
+        elif nchw and (H * W) % 4 == 0 and v.data_ptr() % 16 == 0:
             ops.pack_images_batch([(v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), R)], xd, H, W)
         else:
             call("tacorl_pack_images", ptr(v), 3 * H * W, int(nchw), ptr(self.frames[c]), xd, R, 3, H, W, ops.stream())

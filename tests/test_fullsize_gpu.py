@@ -221,3 +221,55 @@ def test_uint8_frames_equal_transformed_fp32_frames(compute):
     assert la == lb, (la, lb)
     for (ka, va), (kb, vb) in zip(sorted(ma.state_dict().items()), sorted(mb.state_dict().items())):
         assert ka == kb and torch.equal(va, vb), ka
+
+
+def test_uint8_frames_cql_offline_and_playlmp():
+    """The same equality for the other two module classes' staging: CQL_Offline (engine.load_images) and
+    PlayLMP (window frames): uint8 HWC frames vs the host-transformed fp32 CHW route -> identical image buffers."""
+    from tacorl_amd.modules.cql.cql_offline_lightning import CQL_Offline
+    from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(9)
+    tf = lambda x: ((x.cpu().float().div(255) - 0.5) / 0.5).to(dev)  # noqa: E731  ToTensor + Normalize(0.5, 0.5) on the CPU
+    u8 = lambda *s: torch.randint(0, 256, s, device=dev, dtype=torch.uint8, generator=g)  # noqa: E731
+    # ---- CQL_Offline
+    n = 16
+    mk = lambda: CQL_Offline(actor={"policy": {"num_layers": 3, "hidden_dim": 256}, "discrete_gripper": True},  # noqa: E731
+                             critic={"q_network": {"num_layers": 3, "hidden_dim": 256, "last_layer_activation": "Identity"}},
+                             real_world=True, obs_modalities=["rgb_static"], goal_modalities=["rgb_static"], action_dim=7,
+                             device="cuda:0", compute_dtype="bf16", image_dtype="bf16", n_action_samples=4)
+    o8, g8, x8 = u8(n, H, W, 3), u8(n, H, W, 3), u8(n, H, W, 3)
+    act = torch.rand(n, 7, device=dev) * 2 - 1
+    rew, done = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    chw = lambda x: tf(x).permute(0, 3, 1, 2).contiguous()  # noqa: E731
+    mkb = lambda f: {"observations": {"observation": {"rgb_static": f(o8)}, "goal": {"rgb_static": f(g8)}}, "actions": act,  # noqa: E731
+                     "next_observations": {"observation": {"rgb_static": f(x8)}, "goal": {"rgb_static": f(g8)}},
+                     "rewards": rew, "terminals": done}
+    b8, b32 = mkb(lambda x: x), mkb(chw)
+    torch.manual_seed(0); ma = mk()
+    torch.manual_seed(0); mb = mk()
+    ma.training_step(b32, 0)
+    mb.training_step(b8, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(ma.engine.X3["rgb_static"], mb.engine.X3["rgb_static"])
+    # ---- PlayLMP
+    pr = dict(num_heads=8, num_layers=2, encoder_hidden_size=2048, fc_hidden_size=4096, latent_plan_dim=16, min_std=1e-4,
+              dropout_p=0.0, max_position_embeddings=T)
+    ad = dict(n_mixtures=10, num_layers=2, hidden_size=2048, out_features=7, num_classes=10, latent_plan_dim=16,
+              rnn_model="rnn_decoder", include_goal=False)
+    cams = ["rgb_static"]
+    mkp = lambda: PlayLMP(plan_proposal={"policy": {"num_layers": 3, "hidden_dim": 256}}, plan_recognition=pr,  # noqa: E731
+                          action_decoder=ad, plan_proposal_obs_modalities=cams, plan_proposal_goal_modalities=cams,
+                          plan_recognition_modalities=cams, action_decoder_modalities=cams, real_world=True, device=dev,
+                          compute_dtype="bf16", image_dtype="bf16")
+    s8 = u8(8, T, H, W, 3)
+    base = _batch(8)
+    p32 = dict(base, states={"rgb_static": tf(s8).permute(0, 1, 4, 2, 3).contiguous()})
+    p8 = dict(base, states={"rgb_static": s8})
+    torch.manual_seed(0); pa = mkp()
+    torch.manual_seed(0); pb = mkp()
+    pa.training_step(p32, 0)
+    pb.training_step(p8, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(pa.frames["rgb_static"], pb.frames["rgb_static"])
