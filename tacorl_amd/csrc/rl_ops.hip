@@ -791,6 +791,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     coef = fminf(max_norm / (sqrtf(s) + 1e-6f), 1.0f);
   }
   const int t = step_counter[0] + 1;
+  if (gridDim.x == 1) {  // a one-block launch (log_alpha) bumps its own counter: one launch less on the dependent chain
+    __syncthreads();     // every thread has read the counter
+    if (threadIdx.x == 0) step_counter[0] = t;
+  }
   const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
   const float step_size = (float)((double)lr / bc1), rsq_bc2 = (float)sqrt(bc2);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -806,7 +810,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 __global__ void bump_step_kernel(int* step_counter) { step_counter[0] += 1; }
 
-// Several parameter blocks in three launches (norms, updates, step counters) instead of three each:
+// Several parameter blocks in two launches (norms + step counters, updates) instead of three each:
 // the optimiser phase is the tail of the step's dependent chain.  Same per-block partitioning as
 // tacorl_adam_step, so results are bit-identical to it.
 #define ADAM_MAXB 8
@@ -825,6 +829,8 @@ struct AdamTbl {
 __global__ __launch_bounds__(256) void sqnorm_partial_batch_kernel(AdamTbl t) {
   __shared__ float sh[4];
   const int b = blockIdx.y;
+  // the step counters advance here, one launch ahead of the update that reads them (no bump launch behind it)
+  if (blockIdx.x == 0 && threadIdx.x == 0) t.step[b][0] += 1;
   if ((int)blockIdx.x >= t.blocks[b] || !(t.max_norm[b] > 0.f)) return;
   const float* __restrict__ g = t.g[b];
   float s = 0.f;
@@ -843,7 +849,7 @@ __global__ __launch_bounds__(256) void adam_batch_kernel(AdamTbl t) {
     s = block_sum_256(s, sh);
     coef = fminf(t.max_norm[b] / (sqrtf(s) + 1e-6f), 1.0f);
   }
-  const int st = t.step[b][0] + 1;
+  const int st = t.step[b][0];  // already advanced by the norm launch
   const double bc1 = 1.0 - pow(0.9, (double)st), bc2 = 1.0 - pow(0.999, (double)st);
   const float step_size = (float)((double)t.lr[b] / bc1), rsq_bc2 = (float)sqrt(bc2);
   float* __restrict__ p = t.p[b];
@@ -862,9 +868,6 @@ __global__ __launch_bounds__(256) void adam_batch_kernel(AdamTbl t) {
     p[i] = pn;
     if (target) target[i] = target[i] * (1.0f - tau) + pn * tau;
   }
-}
-__global__ void bump_step_batch_kernel(AdamTbl t, int nb) {
-  if ((int)threadIdx.x < nb) t.step[threadIdx.x][0] += 1;
 }
 extern "C" size_t tacorl_adam_batch_ws_bytes(int nb) { return (size_t)nb * 1024 * sizeof(float); }
 extern "C" int tacorl_adam_step_batch(int nb, float* const* param, const float* const* grad, float* const* m,
@@ -886,9 +889,9 @@ extern "C" int tacorl_adam_step_batch(int nb, float* const* param, const float* 
     maxb = (int)blocks > maxb ? (int)blocks : maxb;
     any_clip |= max_norm[b] > 0.f;
   }
-  if (any_clip) hipLaunchKernelGGL(sqnorm_partial_batch_kernel, dim3(maxb, nb), dim3(256), 0, st, t);
+  (void)any_clip;  // the norm launch also advances the step counters, so it always runs
+  hipLaunchKernelGGL(sqnorm_partial_batch_kernel, dim3(maxb, nb), dim3(256), 0, st, t);
   hipLaunchKernelGGL(adam_batch_kernel, dim3(maxb, nb), dim3(256), 0, st, t);
-  hipLaunchKernelGGL(bump_step_batch_kernel, dim3(1), dim3(64), 0, st, t, nb);
   return LAUNCH_OK();
 }
 
@@ -909,6 +912,6 @@ extern "C" int tacorl_adam_step(float* param, const float* grad, float* m, float
   }
   hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, st, param, grad, m, v, n, lr, (const float*)ws,
                      (int)blocks, max_norm, step_counter, target, tau);
-  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, step_counter);
+  if (blocks > 1) hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, step_counter);
   return LAUNCH_OK();
 }

@@ -267,7 +267,7 @@ def tanh_normal_sample(head, ld_head, eps, gumbel_u, hard, act_out, act_off, ld_
 
 def adam_step_batch(items):
     """items: list of (param, grad, m, v, lr, max_norm, step_counter, target_or_None, tau) - one
-    norm launch, one update launch, one counter launch for all of them."""
+    norm (+ step counter) launch and one update launch for all of them."""
     k = len(items)
     nb = L.lib().tacorl_adam_batch_ws_bytes(k)
     ws = workspace(nb, items[0][0].device, "adam_batch")
