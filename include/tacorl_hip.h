@@ -361,7 +361,7 @@ int tacorl_adam_step(float* param, const float* grad, float* m, float* v, long n
                      float max_norm, int* step_counter, float* target, float tau, void* ws,
                      size_t ws_bytes, tacorl_stream_t stream);
 /* nb <= 8 parameter blocks (each with its own lr / max_norm / step counter / optional Polyak target) in
- * three launches; results bit-identical to nb tacorl_adam_step calls. */
+ * two launches (norms + step counters, updates); results bit-identical to nb tacorl_adam_step calls. */
 size_t tacorl_adam_batch_ws_bytes(int nb);
 int tacorl_adam_step_batch(int nb, float* const* param, const float* const* grad, float* const* m,
                            float* const* v, const long* n, const float* lr, const float* max_norm,

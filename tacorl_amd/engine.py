@@ -645,7 +645,7 @@ class ACEngine:
             items.append((a.param, a.grad, a.m, a.v, hp["actor_lr"], hp["clip"], a.step, None, 0.0))
             for q, t in ((self.q1, self.tq1), (self.q2, self.tq2)):
                 items.append((q.param, q.grad, q.m, q.v, hp["critic_lr"], hp["clip"], q.step, t.param, hp["tau"]))
-            ops.adam_step_batch(items)  # three launches for all blocks
+            ops.adam_step_batch(items)  # two launches for all blocks
         ops.mark("c:adam")
 
     def _allreduce(self, tensors):
