@@ -485,16 +485,16 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
     const int Y = m / L::PW, X = m - Y * L::PW;
     abase[t] = ((Y + L::HA) * L::C + X + L::HB) * L::PP + 8 * g;
   }
-  // output element (relative to the image) of accumulator register r of tile t, -1 = padding
-  int oidx[MTW][4];
+  // W^T is the MFMA A operand (D rows = input channels): a lane ends with 4 CONSECUTIVE channels of one pixel,
+  // i.e. one 8-byte store and one mask nibble per tile instead of four 2-byte stores and four mask bytes.
+  // First output element (relative to the image) of tile t's accumulator, -1 = padding:
+  int oidx[MTW];
 #pragma unroll
-  for (int t = 0; t < MTW; t++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int m = 16 * (mpart + t * MPARTS) + 4 * g + r, Y = m / L::PW, X = m - Y * L::PW;
-      const int y = L::S * Y + py, x = L::S * X + px;
-      oidx[t][r] = (m < L::PH * L::PW && y < L::IH && x < L::IW) ? (y * L::IW + x) * L::CI + 16 * nt + i : -1;
-    }
+  for (int t = 0; t < MTW; t++) {
+    const int m = 16 * (mpart + t * MPARTS) + i, Y = m / L::PW, X = m - Y * L::PW;
+    const int y = L::S * Y + py, x = L::S * X + px;
+    oidx[t] = (m < L::PH * L::PW && y < L::IH && x < L::IW) ? (y * L::IW + x) * L::CI + 16 * nt + 4 * g : -1;
+  }
   const DzT* dz = reinterpret_cast<const DzT*>(a.dz[p]);
   const float* yin = a.yin[p];
   __bf16* dx = a.dx[p];
@@ -551,14 +551,14 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
       for (int ks = 0; ks < L::KS; ks++) {
         const int tp = ks / (L::CO / 32), hf = ks % (L::CO / 32), ta = tp / L::KB, tb = tp % L::KB;
         const bf16x8 A = *reinterpret_cast<const bf16x8*>(buf + abase[t] - (ta * L::C + tb) * L::PP + 32 * hf);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bf[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[ks], A, acc, 0, 0, 0);
       }
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-        if (oidx[t][r] >= 0) {
-          const bool on = (mb[oidx[t][r] >> 3] >> (oidx[t][r] & 7)) & 1;
-          dx[ibase + oidx[t][r]] = (__bf16)(on ? acc[r] : 0.f);
-        }
+      if (oidx[t] >= 0) {
+        const unsigned bits = (unsigned)mb[oidx[t] >> 3] >> (oidx[t] & 7);  // 4 channels: one nibble (CI % 8 == 0)
+        *reinterpret_cast<bf16x4*>(dx + ibase + oidx[t]) =
+            bf16x4{(__bf16)((bits & 1) ? acc[0] : 0.f), (__bf16)((bits & 2) ? acc[1] : 0.f),
+                   (__bf16)((bits & 4) ? acc[2] : 0.f), (__bf16)((bits & 8) ? acc[3] : 0.f)};
+      }
     }
     if (nxt < n_img) put(dzh + (k ^ 1) * BUF, mkb + (k ^ 1) * MKB);
     __syncthreads();
