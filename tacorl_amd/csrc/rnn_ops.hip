@@ -4,11 +4,13 @@
 //
 // The generic GEMM needs split-K plus a reduce launch for this shape ([256 x 2048] x [2048 x 2048]:
 // 16 us + 7.6 us per step, 31 dependent steps per forward) and exposes one global round trip per K tile.
-// Here operands are bf16 in HBM and stream through a 4-stage LDS ring filled by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, three K tiles in flight per workgroup), one
-// 64 x 32 output tile per workgroup over the whole K - no split, no second launch; bias, the
-// input-projection addend and the activation are applied in the epilogue, which also writes the bf16
-// copy that is the next step's operand.
+// Here operands are bf16 in HBM and stream through an LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers), one output tile per workgroup over the whole K -
+// no split, no second launch; bias, the input-projection addend and the activation are applied in the
+// epilogue, which also writes the bf16 copy that is the next step's operand.  Tile shapes in use:
+// 64 x 32 / 4 stages / 4 waves (single recurrent step, BPTT step), 128 x 64 / 3 stages / 4 waves
+// (sequence-wide projections), 128 x 64 / 2 stages / 8 waves (the wavefront batches of up to 4 problems:
+// a quarter of the workgroups of the 64 x 32 variant at the same launch time).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
