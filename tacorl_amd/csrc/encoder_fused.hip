@@ -433,15 +433,19 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       for (int q = 0; q < 4; q++) { se[q] = row16_sum(se[q]); sx[q] = row16_sum(sx[q]); sy[q] = row16_sum(sy[q]); }
       if (r16 == 0) {
         // features interleaved [x_c, y_c]; channels 16 w + 4 g + q
-        __bf16* dst = reinterpret_cast<__bf16*>(sa + slot * SA_STRIDE) + 2 * (16 * w + 4 * g);
+        float fx_[4], fy_[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const float r = 1.0f / se[q];
-          dst[2 * q] = (__bf16)(sx[q] * r); dst[2 * q + 1] = (__bf16)(sy[q] * r);
-          if (P.act) {
-            float* f = P.act + P.a_sa + (long)cur * 128 + 2 * (16 * w + 4 * g + q);
-            f[0] = sx[q] * r; f[1] = sy[q] * r;
-          }
+          fx_[q] = sx[q] * r; fy_[q] = sy[q] * r;
+        }
+        // the lane's 8 features are adjacent: one 16-byte LDS store (and two 16-byte global ones), not eight 2-byte ones
+        const u32x2 lo = pack4_bf16(fx_[0], fy_[0], fx_[1], fy_[1]), hi = pack4_bf16(fx_[2], fy_[2], fx_[3], fy_[3]);
+        *reinterpret_cast<u32x4*>(sa + slot * SA_STRIDE + 4 * (16 * w + 4 * g)) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        if (P.act) {
+          float* f = P.act + P.a_sa + (long)cur * 128 + 2 * (16 * w + 4 * g);
+          *reinterpret_cast<f32x4*>(f) = f32x4{fx_[0], fy_[0], fx_[1], fy_[1]};
+          *reinterpret_cast<f32x4*>(f + 4) = f32x4{fx_[2], fy_[2], fx_[3], fy_[3]};
         }
       }
     }
@@ -450,6 +454,13 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     // ------------------------------------------------ FC tail once per chunk
     const bool chunk_done = (slot == EF_CHUNK - 1) || !has_next;
     if (chunk_done) {
+      // fc1's 16 weight fragments travel while the slower waves finish their soft-argmax (the conv fragment
+      // registers are free here); issued after the barrier their L2 round trip was exposed once per chunk
+      u32x4 wf1[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) wf1[j][s] = P.wpk[WP_F1 + ((4 * w + j) * 4 + s) * 64 + l];
       __syncthreads();  // soft-argmax features of the whole chunk are in LDS
       const int n_in_chunk = slot + 1;
       {
@@ -457,9 +468,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          u32x4 wf[4];
-#pragma unroll
-          for (int s = 0; s < 4; s++) wf[s] = P.wpk[WP_F1 + ((4 * w + j) * 4 + s) * 64 + l];
+          const u32x4 (&wf)[4] = wf1[j];
           const float* bb = P.params + po[8] + 16 * (4 * w + j) + 4 * g;
           const float c0 = bb[0], c1 = bb[1], c2 = bb[2], c3 = bb[3];
 #pragma unroll
