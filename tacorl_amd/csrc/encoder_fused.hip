@@ -82,7 +82,11 @@ __global__ void ef_pack_kernel(EFPackArgs a, long o_w1, long o_w2, long o_w3, lo
   else if (f < WP_F2 / 64) { int r = f - WP_F1 / 64; W = params + o_f1; K = 128; j = r / 4; s = r % 4; }
   else { int r = f - WP_F2 / 64; W = params + o_f2; K = 256; j = r / 8; s = r % 8; }
   const float* src = W + (long)(16 * j + (l & 15)) * K + 32 * s + 8 * (l >> 4);
-  if (f < WP_C2 / 64) src = W + (long)(16 * j + (l & 15)) * K + (4 * (s / 3) + (l >> 4)) * 24 + 8 * (s % 3);
+  // conv1 also permutes the output channels between its two tiles: row 4 a + r of tile j is channel 8 a + 4 j + r,
+  // so that a lane's accumulators (rows 4 g .. 4 g + 3 of both tiles) are the 8 ADJACENT channels 8 g .. 8 g + 7
+  // (one 16-byte activation store per pixel tile instead of two 8-byte ones)
+  if (f < WP_C2 / 64)
+    src = W + (long)(8 * ((l & 15) >> 2) + 4 * j + (l & 3)) * K + (4 * (s / 3) + (l >> 4)) * 24 + 8 * (s % 3);
   bf16x8 v;
 #pragma unroll
   for (int e = 0; e < 8; e++) v[e] = (__bf16)src[e];
@@ -205,8 +209,8 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
   float b1[2][4], b2[4], b3[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    b1[0][q] = P.params[po[1] + 4 * g + q];
-    b1[1][q] = P.params[po[1] + 16 + 4 * g + q];
+    b1[0][q] = P.params[po[1] + 8 * g + q];  // conv1 tile j, row 4 g + q  <->  channel 8 g + 4 j + q (ef_pack_kernel)
+    b1[1][q] = P.params[po[1] + 8 * g + 4 + q];
     b2[q] = P.params[po[3] + 16 * w + 4 * g + q];
     b3[q] = P.params[po[5] + 16 * w + 4 * g + q];
   }
@@ -296,12 +300,12 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         if (pm < npx1) {
           const f32x4 r0 = {fmaxf(acc0[0], 0.f), fmaxf(acc0[1], 0.f), fmaxf(acc0[2], 0.f), fmaxf(acc0[3], 0.f)};
           const f32x4 r1 = {fmaxf(acc1[0], 0.f), fmaxf(acc1[1], 0.f), fmaxf(acc1[2], 0.f), fmaxf(acc1[3], 0.f)};
-          *reinterpret_cast<u32x2*>(act1 + pm * ACT1_STRIDE + (4 * g) * 2) = pack4_bf16(r0[0], r0[1], r0[2], r0[3]);
-          *reinterpret_cast<u32x2*>(act1 + pm * ACT1_STRIDE + (16 + 4 * g) * 2) = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
+          const u32x2 lo = pack4_bf16(r0[0], r0[1], r0[2], r0[3]), hi = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
+          *reinterpret_cast<u32x4*>(act1 + pm * ACT1_STRIDE + (8 * g) * 2) = u32x4{lo[0], lo[1], hi[0], hi[1]};  // channels 8 g .. 8 g + 7
           if (P.act) {
-            float* y = P.act + ((long)cur * npx1 + pm) * 32 + 4 * g;
+            float* y = P.act + ((long)cur * npx1 + pm) * 32 + 8 * g;
             *reinterpret_cast<f32x4*>(y) = r0;
-            *reinterpret_cast<f32x4*>(y + 16) = r1;
+            *reinterpret_cast<f32x4*>(y + 4) = r1;
           }
         }
       };
