@@ -118,7 +118,9 @@ extern "C" int tacorl_encoder_pack_weights(int nprob, const float* const* params
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wfrag), "v"(bfrag))
 #endif
 #define MFMA_CHAIN_BEGIN(acc) asm volatile("s_nop 1" : "+v"(acc))
-#define MFMA_CHAIN_END(acc) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc))
+// (12 wait states: what an 8-pass XDL result needs before a non-MFMA reader, cdna_hip_programming.md section 5.7 item 2;
+// v_mfma_f32_16x16x32_bf16 issues every ~17 clk in a dependent chain, i.e. is a 4-pass op - 20 states were used before)
+#define MFMA_CHAIN_END(acc) asm volatile("s_nop 11" : "+v"(acc))
 
 // ------------------------------------------------------------------------- kernel
 #define ACT1_STRIDE 80   // bytes per conv1-output pixel (32 ch bf16 + 16 pad)
