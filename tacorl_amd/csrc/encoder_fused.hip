@@ -57,6 +57,13 @@ struct EFArgs {
 #define WP_TOTAL (WP_F2 + 2 * 8 * 64)
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+// max(x, 0) as ONE v_max_f32: fmaxf() costs two (hipcc first canonicalises x with v_max x, x - signalling-NaN
+// quieting the accumulators here cannot need); 20 of them per 16-pixel tile add up at one wave per SIMD
+__device__ __forceinline__ float relu1(float x) {
+  float r;
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 __device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d) {
   bf16x4 t = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
   return __builtin_bit_cast(u32x2, t);
@@ -300,8 +307,8 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         MFMA_CHAIN_END(acc1);
         const int pm = mt * 16 + r16;
         if (pm < npx1) {
-          const f32x4 r0 = {fmaxf(acc0[0], 0.f), fmaxf(acc0[1], 0.f), fmaxf(acc0[2], 0.f), fmaxf(acc0[3], 0.f)};
-          const f32x4 r1 = {fmaxf(acc1[0], 0.f), fmaxf(acc1[1], 0.f), fmaxf(acc1[2], 0.f), fmaxf(acc1[3], 0.f)};
+          const f32x4 r0 = {relu1(acc0[0]), relu1(acc0[1]), relu1(acc0[2]), relu1(acc0[3])};
+          const f32x4 r1 = {relu1(acc1[0]), relu1(acc1[1]), relu1(acc1[2]), relu1(acc1[3])};
           const u32x2 lo = pack4_bf16(r0[0], r0[1], r0[2], r0[3]), hi = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
           *reinterpret_cast<u32x4*>(act1 + pm * ACT1_STRIDE + (8 * g) * 2) = u32x4{lo[0], lo[1], hi[0], hi[1]};  // channels 8 g .. 8 g + 7
           if (P.act) {
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         MFMA_CHAIN_END(acc);
         const int pm = mt * 16 + r16;
         if (pm < npx2) {
-          const f32x4 r = {fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f)};
+          const f32x4 r = {relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3])};
           *reinterpret_cast<u32x2*>(act2 + pm * ACT2_STRIDE + (16 * w + 4 * g) * 2) = pack4_bf16(r[0], r[1], r[2], r[3]);
           if (P.act) *reinterpret_cast<f32x4*>(P.act + P.a_y2 + ((long)cur * npx2 + pm) * 64 + 16 * w + 4 * g) = r;
         }
@@ -413,9 +420,9 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         const bool ok = mt * 16 + r16 < npx3;
         if (P.act && ok)
           *reinterpret_cast<f32x4*>(P.act + P.a_y3 + ((long)cur * npx3 + mt * 16 + r16) * 64 + 16 * w + 4 * g) =
-              f32x4{fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f)};
+              f32x4{relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3])};
 #pragma unroll
-        for (int q = 0; q < 4; q++) v3[mt][q] = ok ? fmaxf(acc[q], 0.f) * inv_t : -INFINITY;
+        for (int q = 0; q < 4; q++) v3[mt][q] = ok ? relu1(acc[q]) * inv_t : -INFINITY;
       }
       STAMP(6);  // conv3 MFMA part
       // pass 1: per-channel max over the image (tiles in registers, then the 16 pixel lanes)
