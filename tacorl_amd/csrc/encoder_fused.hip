@@ -125,6 +125,15 @@ extern "C" int tacorl_encoder_pack_weights(int nprob, const float* const* params
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wfrag), "v"(bfrag))
 #endif
 #define MFMA_CHAIN_BEGIN(acc) asm volatile("s_nop 1" : "+v"(acc))
+// First MFMA of a chain: the bias registers are its C operand and the accumulator only its destination - no four
+// v_mov per chain to seed the accumulator (22 chains per image), and no VALU-write -> MFMA-read wait either: the
+// bias registers were written once, before the image loop.
+#if EF_VAR == 2
+#define MFMA_FIRST_AW(acc, wfrag, bfrag, bias) asm volatile("v_mov_b32 %0, %0" : "=v"(acc) : "a"(wfrag), "v"(bfrag), "v"(bias))
+#else
+#define MFMA_FIRST_AW(acc, wfrag, bfrag, bias) \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc) : "a"(wfrag), "v"(bfrag), "v"(bias))
+#endif
 // (12 wait states: what an 8-pass XDL result needs before a non-MFMA reader, cdna_hip_programming.md section 5.7 item 2;
 // v_mfma_f32_16x16x32_bf16 issues every ~17 clk in a dependent chain, i.e. is a 4-pass op - 20 states were used before)
 #define MFMA_CHAIN_END(acc) asm volatile("s_nop 11" : "+v"(acc))
@@ -223,6 +232,8 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     b2[q] = P.params[po[3] + 16 * w + 4 * g + q];
     b3[q] = P.params[po[5] + 16 * w + 4 * g + q];
   }
+  const f32x4 bias1a = {b1[0][0], b1[0][1], b1[0][2], b1[0][3]}, bias1b = {b1[1][0], b1[1][1], b1[1][2], b1[1][3]},
+              bias2 = {b2[0], b2[1], b2[2], b2[3]}, bias3 = {b3[0], b3[1], b3[2], b3[3]};
   const float temp = P.params[po[6]];
 
   // conv1 k offsets (bytes): lane group g reads image row 4 (s / 3) + g, 8-element group s % 3 of the 24-run
@@ -296,14 +307,14 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         }
       };
       auto tile1 = [&](int mt, u32x4 (&bf)[6]) {
-        f32x4 acc0 = {b1[0][0], b1[0][1], b1[0][2], b1[0][3]}, acc1 = {b1[1][0], b1[1][1], b1[1][2], b1[1][3]};
-        MFMA_CHAIN_BEGIN(acc0);
+        f32x4 acc0, acc1;
+        MFMA_FIRST_AW(acc0, wc1a[0], bf[0], bias1a);
 #pragma unroll
-        for (int s = 0; s < 6; s++) MFMA_AW(acc0, wc1a[s], bf[s]);
+        for (int s = 1; s < 6; s++) MFMA_AW(acc0, wc1a[s], bf[s]);
         MFMA_CHAIN_END(acc0);    // the compiler may schedule acc0's epilogue right here: cover the hazard
-        MFMA_CHAIN_BEGIN(acc1);  // each accumulator chain stays strictly back-to-back (asm MFMAs get no
-#pragma unroll                   // compiler hazard handling: interleaving two chains returned wrong sums)
-        for (int s = 0; s < 6; s++) MFMA_AW(acc1, wc1b[s], bf[s]);
+        MFMA_FIRST_AW(acc1, wc1b[0], bf[0], bias1b);  // each accumulator chain stays strictly back-to-back (asm
+#pragma unroll                   // MFMAs get no compiler hazard handling: interleaving two chains returned wrong sums)
+        for (int s = 1; s < 6; s++) MFMA_AW(acc1, wc1b[s], bf[s]);
         MFMA_CHAIN_END(acc1);
         const int pm = mt * 16 + r16;
         if (pm < npx1) {
@@ -357,11 +368,11 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       ld2(bcur, 0, fa);
 #pragma unroll
       for (int mt = 0; mt < NT2; mt++) {
-        f32x4 acc = {b2[0], b2[1], b2[2], b2[3]};
+        f32x4 acc;
         ld2(bcur, 1, fb);
-        MFMA_CHAIN_BEGIN(acc);
+        MFMA_FIRST_AW(acc, wc2[0], fa[0], bias2);
 #pragma unroll
-        for (int i = 0; i < 8; i++) MFMA_AW(acc, wc2[i], fa[i]);
+        for (int i = 1; i < 8; i++) MFMA_AW(acc, wc2[i], fa[i]);
         if (mt + 1 < NT2) { bcur = base2(mt + 1); ld2(bcur, 0, fa); }
 #pragma unroll
         for (int i = 0; i < 8; i++) MFMA_AW(acc, wc2[8 + i], fb[i]);
@@ -407,12 +418,12 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       ld3(bcur, 0, fa);
 #pragma unroll
       for (int mt = 0; mt < NT3; mt++) {
-        f32x4 acc = {b3[0], b3[1], b3[2], b3[3]};
+        f32x4 acc;
         fx[mt] = (float)ox; fy[mt] = (float)oy;
         ld3(bcur, 1, fb);
-        MFMA_CHAIN_BEGIN(acc);
+        MFMA_FIRST_AW(acc, wc3[0], fa[0], bias3);
 #pragma unroll
-        for (int i = 0; i < 9; i++) MFMA_AW(acc, wc3[i], fa[i]);
+        for (int i = 1; i < 9; i++) MFMA_AW(acc, wc3[i], fa[i]);
         if (mt + 1 < NT3) { bcur = base3(mt + 1, ox, oy); ld3(bcur, 0, fa); }
 #pragma unroll
         for (int i = 0; i < 9; i++) MFMA_AW(acc, wc3[9 + i], fb[i]);
