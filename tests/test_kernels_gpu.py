@@ -647,3 +647,64 @@ def test_plan_recognition_fused_encoder():
         ff = F.relu(x @ P[p + "linear1.weight"].t() + P[p + "linear1.bias"]) @ P[p + "linear2.weight"].t() + P[p + "linear2.bias"]
         x = F.layer_norm(x + ff, (D,), P[p + "norm2.weight"], P[p + "norm2.bias"])
     assert relerr(pr.pooled, x.mean(1)) < TOL_BF16, relerr(pr.pooled, x.mean(1))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.int64, torch.int32, torch.uint8, torch.bool])
+def test_stage_transition_dtypes(dt):
+    """reward = done = float(disp == 1) for every disp dtype a dataloader may deliver, plus the action-window copy
+    (TACORL.get_rl_batch, reference tacorl.py:142-179), one launch."""
+    from tacorl_amd._lib import call, ptr, stream
+
+    dev = _dev()
+    B = 300
+    g = torch.Generator().manual_seed(3)
+    base = torch.randint(-1, 4, (B,), generator=g)
+    disp = (base == 1).to(dev) if dt == torch.bool else base.clamp_min(0).to(dt).to(dev) if dt == torch.uint8 else base.to(dt).to(dev)
+    acts = rnd(B, 16, 7, seed=1).to(dev)
+    reward, done, out = torch.zeros(B, device=dev), torch.zeros(B, device=dev), torch.zeros(B, 16, 7, device=dev)
+    code = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.uint8: 3, torch.bool: 3}[dt]
+    call("tacorl_stage_transition", ptr(disp), code, ptr(reward), ptr(done), B, ptr(acts), ptr(out), acts.numel(), stream())
+    torch.cuda.synchronize()
+    ref = (disp == 1).float()
+    assert torch.equal(reward, ref) and torch.equal(done, ref) and torch.equal(out, acts)
+
+
+def test_reduce_rows_mod_batch():
+    """out[b][c] = sum_j in[j*B + b][c] for several (in, out) pairs in one launch, summed in j order (bit-exact
+    against the same order in torch)."""
+    from tacorl_amd import ops
+    from tacorl_amd._lib import call, stream
+
+    dev = _dev()
+    B, cols, reps, ld_in, ld_out = 256, 64, 13, 72, 64
+    ins = [rnd(reps * B, ld_in, seed=5 + k).to(dev) for k in range(2)]
+    outs = [torch.zeros(B, ld_out, device=dev) for _ in range(2)]
+    call("tacorl_reduce_rows_mod_batch", 2, ops.ptr_array(ins), ld_in, ops.ptr_array(outs), ld_out, B, cols, reps, stream())
+    torch.cuda.synchronize()
+    for x, o in zip(ins, outs):
+        ref = torch.zeros(B, cols, device=dev)
+        for j in range(reps):
+            ref = ref + x[j * B:(j + 1) * B, :cols]
+        assert torch.equal(o[:, :cols], ref)
+
+
+@pytest.mark.parametrize("flag,dt", [(1, torch.bfloat16), (0, torch.float32)])
+def test_pack_images_u8(flag, dt):
+    """uint8 HWC frames -> normalised NHWC (ToTensor x/255, Normalize (t-0.5)/0.5 in fp32, as the reference's CPU
+    transform pipeline computes them), strided jobs included: bit-exact."""
+    from tacorl_amd import ops
+
+    dev = _dev()
+    n, T, H, W = 6, 4, 44, 60
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(0, 256, (n, T, H, W, 3), dtype=torch.uint8, generator=g)
+    ref = ((x.float().div(255) - 0.5) / 0.5).to(dt)
+    xd = x.to(dev)
+    img = H * W * 3
+    all_ = torch.zeros(n * T, H, W, 3, device=dev, dtype=dt)
+    first = torch.zeros(n, H, W, 3, device=dev, dtype=dt)
+    ops.pack_images_u8_batch([(xd.data_ptr(), img, all_.data_ptr(), n * T), (xd.data_ptr(), T * img, first.data_ptr(), n)],
+                             flag, H, W)
+    torch.cuda.synchronize()
+    assert torch.equal(all_.cpu().view(n, T, H, W, 3), ref)
+    assert torch.equal(first.cpu(), ref[:, 0])
