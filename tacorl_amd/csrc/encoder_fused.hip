@@ -94,6 +94,10 @@ __global__ void ef_pack_kernel(EFPackArgs a, long o_w1, long o_w2, long o_w3, lo
   // (one 16-byte activation store per pixel tile instead of two 8-byte ones)
   if (f < WP_C2 / 64)
     src = W + (long)(8 * ((l & 15) >> 2) + 4 * j + (l & 3)) * K + (4 * (s / 3) + (l >> 4)) * 24 + 8 * (s % 3);
+  // conv2: a wave owns the fragment pair (2 cg, 2 cg + 1) = channels 32 cg .. 32 cg + 31, permuted the same way:
+  // row 4 a + r of fragment 2 cg + ct is channel 32 cg + 8 a + 4 ct + r
+  else if (f < WP_C3 / 64)
+    src = W + (long)(32 * (j >> 1) + 8 * ((l & 15) >> 2) + 4 * (j & 1) + (l & 3)) * K + 32 * s + 8 * (l >> 4);
   bf16x8 v;
 #pragma unroll
   for (int e = 0; e < 8; e++) v[e] = (__bf16)src[e];
@@ -217,23 +221,34 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     long off = 0;
     for (int i = 0; i < 11; i++) { po[i] = off; off = (off + sz[i] + 3) & ~3L; }
   }
-  u32x4 wc1a[6], wc1b[6], wc2[16], wc3[18];  // all AGPR-resident (184 AGPRs)
+  // conv2 work split: wave = (channel half cg, pixel-tile parity ph).  It owns 32 output channels (two MFMA tiles)
+  // and every second 16-pixel tile, so each im2col fragment read from LDS feeds TWO MFMAs: with one wave per SIMD an
+  // LDS read costs the wave ~32 clk and adds to its MFMA time, and conv2 sat at its read count (96 per image).
+  // conv3 keeps 16 channels per wave (its second fragment set would not fit the register file: 248 of 256 AGPRs
+  // are weights now).
+  const int cg = w & 1, ph = w >> 1;
+  u32x4 wc1a[6], wc1b[6], wc2a[16], wc2b[16], wc3[18];  // all AGPR-resident (248 AGPRs)
 #pragma unroll
   for (int s = 0; s < 6; s++) { wc1a[s] = P.wpk[WP_C1 + s * 64 + l]; wc1b[s] = P.wpk[WP_C1 + (6 + s) * 64 + l]; }
 #pragma unroll
-  for (int s = 0; s < 16; s++) wc2[s] = P.wpk[WP_C2 + (w * 16 + s) * 64 + l];
+  for (int s = 0; s < 16; s++) {
+    wc2a[s] = P.wpk[WP_C2 + ((2 * cg) * 16 + s) * 64 + l];
+    wc2b[s] = P.wpk[WP_C2 + ((2 * cg + 1) * 16 + s) * 64 + l];
+  }
 #pragma unroll
   for (int s = 0; s < 18; s++) wc3[s] = P.wpk[WP_C3 + (w * 18 + s) * 64 + l];
-  float b1[2][4], b2[4], b3[4];
+  float b1[2][4], b2[2][4], b3[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     b1[0][q] = P.params[po[1] + 8 * g + q];  // conv1 tile j, row 4 g + q  <->  channel 8 g + 4 j + q (ef_pack_kernel)
     b1[1][q] = P.params[po[1] + 8 * g + 4 + q];
-    b2[q] = P.params[po[3] + 16 * w + 4 * g + q];
+    b2[0][q] = P.params[po[3] + 32 * cg + 8 * g + q];  // fragment 2 cg + ct, row 4 g + q <-> channel 32 cg + 8 g + 4 ct + q
+    b2[1][q] = P.params[po[3] + 32 * cg + 8 * g + 4 + q];
     b3[q] = P.params[po[5] + 16 * w + 4 * g + q];
   }
   const f32x4 bias1a = {b1[0][0], b1[0][1], b1[0][2], b1[0][3]}, bias1b = {b1[1][0], b1[1][1], b1[1][2], b1[1][3]},
-              bias2 = {b2[0], b2[1], b2[2], b2[3]}, bias3 = {b3[0], b3[1], b3[2], b3[3]};
+              bias2a = {b2[0][0], b2[0][1], b2[0][2], b2[0][3]}, bias2b = {b2[1][0], b2[1][1], b2[1][2], b2[1][3]},
+              bias3 = {b3[0], b3[1], b3[2], b3[3]};
   const float temp = P.params[po[6]];
 
   // conv1 k offsets (bytes): lane group g reads image row 4 (s / 3) + g, 8-element group s % 3 of the 24-run
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     __builtin_amdgcn_s_barrier();
     STAMP(3);  // barrier after conv1
 
-    // ------------------------------------------------ conv2: 4x4 stride 2, 32 -> 64 (wave = 16 channels)
+    // ------------------------------------------------ conv2: 4x4 stride 2, 32 -> 64 (wave = 32 channels x half the tiles)
     {
       constexpr int NT2 = (G::NPX2 + 15) >> 4;
       auto base2 = [&](int mt) {
@@ -364,24 +379,52 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         }
       };
       u32x4 fa[8], fb[8];
-      const unsigned char* bcur = base2(0);
-      ld2(bcur, 0, fa);
+      // Two accumulator chains per tile (fragments 2 cg and 2 cg + 1) in blocks of 8 back-to-back MFMAs: inside a
+      // block every MFMA takes the previous one's result as its C (forwarded); a chain is resumed only after the
+      // other chain's 8 MFMAs - far beyond the wait states a non-adjacent dependent MFMA needs (hipcc pads
+      // nothing for inline asm).
+      if (ph < NT2) {
+        const unsigned char* bcur = base2(ph);
+        ld2(bcur, 0, fa);
 #pragma unroll
-      for (int mt = 0; mt < NT2; mt++) {
-        f32x4 acc;
-        ld2(bcur, 1, fb);
-        MFMA_FIRST_AW(acc, wc2[0], fa[0], bias2);
+        for (int t2 = 0; t2 < (NT2 + 1) / 2; t2++) {
+          const int mt = ph + 2 * t2;
+          if (mt < NT2) {
+            f32x4 acc0, acc1;
+            ld2(bcur, 1, fb);
+            MFMA_FIRST_AW(acc0, wc2a[0], fa[0], bias2a);
 #pragma unroll
-        for (int i = 1; i < 8; i++) MFMA_AW(acc, wc2[i], fa[i]);
-        if (mt + 1 < NT2) { bcur = base2(mt + 1); ld2(bcur, 0, fa); }
+            for (int i = 1; i < 8; i++) MFMA_AW(acc0, wc2a[i], fa[i]);
+            MFMA_FIRST_AW(acc1, wc2b[0], fa[0], bias2b);
 #pragma unroll
-        for (int i = 0; i < 8; i++) MFMA_AW(acc, wc2[8 + i], fb[i]);
-        MFMA_CHAIN_END(acc);
-        const int pm = mt * 16 + r16;
-        if (pm < npx2) {
-          const f32x4 r = {relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3])};
-          *reinterpret_cast<u32x2*>(act2 + pm * ACT2_STRIDE + (16 * w + 4 * g) * 2) = pack4_bf16(r[0], r[1], r[2], r[3]);
-          if (P.act) *reinterpret_cast<f32x4*>(P.act + P.a_y2 + ((long)cur * npx2 + pm) * 64 + 16 * w + 4 * g) = r;
+            for (int i = 1; i < 8; i++) MFMA_AW(acc1, wc2b[i], fa[i]);
+            // next tile's first half (the last tile re-reads its own: a conditional load would push fa[] to scratch)
+            bcur = base2(mt + 2 < NT2 ? mt + 2 : mt);
+#pragma unroll
+            for (int i = 0; i < 8; i++) MFMA_AW(acc0, wc2a[8 + i], fb[i]);
+#pragma unroll
+            for (int i = 0; i < 8; i++) MFMA_AW(acc1, wc2b[8 + i], fb[i]);
+            ld2(bcur, 0, fa);
+            MFMA_CHAIN_END(acc1);             // (acc0's last MFMA is 8 MFMAs older: covered)
+            asm volatile("" : "+v"(acc0));
+            // (store addresses re-derived behind an opaque zero: hoisted out of the image loop they are spilled, and a
+            // scratch reload inside the loop waits on vmcnt, i.e. on the next image's DMA)
+            int oz;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+            const int pm = mt * 16 + r16 + oz;
+            if (pm < npx2) {
+              const f32x4 r0 = {relu1(acc0[0]), relu1(acc0[1]), relu1(acc0[2]), relu1(acc0[3])};
+              const f32x4 r1 = {relu1(acc1[0]), relu1(acc1[1]), relu1(acc1[2]), relu1(acc1[3])};
+              const u32x2 lo = pack4_bf16(r0[0], r0[1], r0[2], r0[3]), hi = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
+              *reinterpret_cast<u32x4*>(act2 + pm * ACT2_STRIDE + (32 * cg + 8 * g) * 2) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+              if (P.act) {
+                // wave-uniform base + 32-bit lane offset (a 64-bit per-lane address would be hoisted and spilled)
+                float* y = P.act + (P.a_y2 + (long)cur * (npx2 * 64)) + (unsigned)(pm * 64 + 32 * cg + 8 * g);
+                *reinterpret_cast<f32x4*>(y) = r0;
+                *reinterpret_cast<f32x4*>(y + 4) = r1;
+              }
+            }
+          }
         }
       }
     }
