@@ -4,9 +4,11 @@
 // utils.py:39-65).
 //
 // Design (MI355X_MICROARCH / cdna_hip_programming guides):
-//  * weights are REGISTER-stationary: each of the 4 waves of a workgroup owns 16 output channels of
-//    conv2/conv3 (a quarter of fc1, half of conv1/fc2) as pre-packed MFMA fragments (~256 VGPRs, one
-//    wave per SIMD); they are loaded once per workgroup and reused for every image it processes;
+//  * weights are REGISTER-stationary (248 AGPRs, fed to the MFMAs by inline asm, loaded once per workgroup and
+//    reused for every image it processes): conv1 - all 32 channels in every wave, the waves split the pixel
+//    tiles; conv2 - a wave owns 32 output channels and every second pixel tile, so each im2col fragment read
+//    from LDS feeds two MFMAs; conv3 - a wave owns 16 channels and reads every pixel tile (a quarter of fc1,
+//    half of fc2 from global memory per chunk of 8 images).  One wave per SIMD: that is what bounds the kernel;
 //  * activations live in LDS: the raw NHWC bf16 image (double-buffered, next image prefetched through
 //    registers while the current one is computed), conv1 output [pixel][32ch] with an 80-byte pixel
 //    stride and conv2 output [pixel][64ch] with a 160-byte stride - strides chosen so that the
