@@ -341,7 +341,8 @@ __global__ __launch_bounds__(MF_NT) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
 // fragments are contiguous 16-byte LDS reads.  X is the MFMA A operand (D rows = K index: a lane ends with 4
 // consecutive k of one n -> 16-byte slab stores); the bias gradient is one more K tile with an all-ones
 // fragment.  Slices are summed by mlp_wgrad_reduce_kernel in slice order (deterministic).
-constexpr int WG_MS = 256;    // most batch rows per workgroup (a.ms: chosen per call, a multiple of WG_MT)
+constexpr int WG_MS = 2048;   // most batch rows per workgroup (a.ms: chosen per call, a multiple of WG_MT; 256 at the bench
+                              // shapes - the cap only matters for 100 k-row problems, where it keeps the slab count down)
 constexpr int WG_MT = 32;     // rows per staged tile (one MFMA k-step)
 constexpr int WG_TP = 40;     // bf16 pitch of a transposed row [col][32 m] (80 B: 16 cols hit distinct 16-B slots)
 constexpr int WG_OPB = 256 * WG_TP * 2;  // bytes of one staged operand tile
