@@ -5,7 +5,7 @@
 #define MF_MAXP 8  // problems per launch
 #define MF_MAXL 4  // layers
 
-// bf16 compute only: every layer input width a multiple of 8 and <= 256, output widths <= 256.
+// bf16 compute only: hidden widths multiples of 8, every width <= 256 (the input width may be ragged, e.g. 64 + 7).
 bool mlp_fused_fwd_ok(int nprob, int L, const int* dims, int ldx);
 // zoff / yoff: [nprob][MF_MAXL] offsets (floats) into act[p] (tacorl_mlp_act_layout; zoff < 0 = not saved);
 // woff / boff: [L] offsets into params[p] (tacorl_mlp_param_layout).

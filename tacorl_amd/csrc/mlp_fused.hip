@@ -56,6 +56,17 @@ __device__ __forceinline__ float act_grad_fast(int act, float zy) {
 
 // 8 consecutive bf16 weights of output row n (zeros outside the matrix); rows are 8-byte aligned
 __device__ __forceinline__ bf16x8 load_w(const __bf16* __restrict__ W, int K, int N, int n, int k) {
+  if (K & 7) {  // rows not 8-byte aligned (a first layer of width 64 + 7): element loads, masked at the row end
+    const __bf16 z0 = (__bf16)0.f;
+    bf16x8 v = {z0, z0, z0, z0, z0, z0, z0, z0};
+    if (n < N) {
+      const __bf16* q = W + (long)n * K;
+#pragma unroll
+      for (int e = 0; e < 8; e++)
+        if (k + e < K) v[e] = q[k + e];
+    }
+    return v;
+  }
   const bool on = n < N && k < K;  // K % 8 == 0: a fragment is inside the row or entirely outside
   const __bf16* q = W + (long)(on ? n : 0) * K + (on ? k : 0);
   const bf16x4 lo = *reinterpret_cast<const bf16x4*>(q), hi = *reinterpret_cast<const bf16x4*>(q + 4);
@@ -83,17 +94,22 @@ __global__ __launch_bounds__(MF_NT) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
   // zero both buffers once: padded K columns are multiplied by zero weights and must stay finite
   for (int e = tid; e < 2 * BMF * XP / 8; e += MF_NT) reinterpret_cast<f32x4*>(X)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  {  // stage the input rows as bf16
-    const int K0 = a.dims[0], c8 = K0 / 8;
+  {  // stage the input rows as bf16 (chunks of 8 columns; a ragged last chunk - K0 % 8 != 0 - element by element)
+    const int K0 = a.dims[0], c8 = (K0 + 7) / 8;
     const float* x = a.x[p];
     for (int c = tid; c < BMF * c8; c += MF_NT) {
       const int row = c / c8, k = (c - row * c8) * 8;
       if (m0 + row < M) {
         const float* q = x + (long)(m0 + row) * a.ldx + k;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(q), hi = *reinterpret_cast<const f32x4*>(q + 4);
         bf16x8 v;
+        if (k + 8 <= K0) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(q), hi = *reinterpret_cast<const f32x4*>(q + 4);
 #pragma unroll
-        for (int j = 0; j < 4; j++) { v[j] = (__bf16)lo[j]; v[4 + j] = (__bf16)hi[j]; }
+          for (int j = 0; j < 4; j++) { v[j] = (__bf16)lo[j]; v[4 + j] = (__bf16)hi[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] = (__bf16)(k + j < K0 ? q[j] : 0.f);
+        }
         *reinterpret_cast<bf16x8*>(X + row * XP + k) = v;
       }
     }
@@ -620,8 +636,8 @@ int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act
 
 bool mlp_fused_fwd_ok(int nprob, int L, const int* dims, int ldx) {
   if (nprob < 1 || nprob > MF_MAXP || L < 1 || L > MF_MAXL || ldx % 4) return false;
-  for (int l = 0; l < L; l++)
-    if (dims[l] % 8 || dims[l] > MAXD || dims[l] < 8) return false;
+  for (int l = 0; l < L; l++)  // hidden widths: multiples of 8; the input width: any (a ragged row end is handled)
+    if ((l > 0 && dims[l] % 8) || dims[l] > MAXD || dims[l] < 8) return false;
   return dims[L] >= 1 && dims[L] <= MAXD;
 }
 

@@ -433,6 +433,35 @@ def test_mlp_fused_forward(dims, acts):
         assert relerr(y, refs[i]) < TOL_BF16
 
 
+def test_mlp_fused_forward_ragged_input_width():
+    """The Q head of a 7-dim-action critic: input width 64 + 7 = 71 (rows of the first weight matrix are not
+    8-byte aligned in the bf16 mirror, the last 8-column chunk of the input is ragged), row pitch 72."""
+    from tacorl_amd import _lib, blocks, ops
+
+    dev = _dev()
+    dims, acts, Ms, ld = [71, 256, 256, 256, 1], [2, 2, 2, 0], [70, 9, 300], 72
+    L = len(dims) - 1
+    assert _lib.lib().tacorl_mlp_fwd_fused_supported(len(Ms), L, ops.int_array(dims), ld) == 1
+    xs, flats, fb, a_f, a_g = [], [], [], [], []
+    for i, M in enumerate(Ms):
+        flat = torch.zeros(blocks.mlp_size(dims), device=dev)
+        v = blocks.mlp_views(flat, 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+        for l in range(L):
+            v[f"l{l}.w"].copy_(rnd(dims[l + 1], dims[l], seed=350 + i + l, scale=1 / math.sqrt(dims[l])))
+            v[f"l{l}.b"].copy_(rnd(dims[l + 1], seed=360 + i + l, scale=0.1))
+        xp = torch.full((M, ld), 7.0, device=dev)  # the pad column holds garbage: it must not reach the result
+        xp[:, :dims[0]] = rnd(M, dims[0], seed=370 + i).to(dev)
+        xs.append(xp); flats.append(flat); fb.append(flat.to(torch.bfloat16))
+        n_act = ops.mlp_act_layout(M, dims, acts)[2]
+        a_f.append(torch.zeros(n_act, device=dev)); a_g.append(torch.zeros(n_act, device=dev))
+    ops.mlp_fwd(xs, ld, flats, a_g, Ms, dims, acts, 1)
+    ops.mlp_fwd(xs, ld, flats, a_f, Ms, dims, acts, 1, params_bf16=fb)
+    torch.cuda.synchronize()
+    for i in range(len(Ms)):
+        assert torch.isfinite(a_f[i]).all()
+        assert relerr(a_f[i], a_g[i]) < 2e-3, relerr(a_f[i], a_g[i])
+
+
 @pytest.mark.parametrize("dims,acts", [([64, 256, 256, 256, 32], [2, 2, 2, 0]), ([80, 256, 256, 256, 1], [2, 2, 2, 0]),
                                        ([71, 256, 256, 256, 1], [2, 2, 2, 0]), ([32, 256, 256, 32], [1, 1, 0])])
 @pytest.mark.parametrize("want_dx", [True, False])
