@@ -160,6 +160,7 @@ class ACEngine:
 
     def _alloc(self):
         B, n, dev = self.B, self.n, self.dev
+        ops.note_alloc()
         f = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
         self.X3 = {c: torch.zeros(3 * B, *self.hw[c], 3, device=dev, dtype=self.img_dtype) for c in self.cams}
         # encoder problems: (net, first image row in X3, n images, keep activations for backward)
@@ -296,6 +297,7 @@ class ACEngine:
     def _packed(self, net, c):
         key = (id(net), c)
         if key not in self._wpk:
+            ops.note_alloc()
             self._wpk[key] = torch.empty(ops.L.lib().tacorl_encoder_fused_wpk_bytes(), dtype=torch.uint8, device=self.dev)
         return self._wpk[key]
 

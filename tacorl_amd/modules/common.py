@@ -91,7 +91,14 @@ class GraphMixin:
             return eager()
         if not hasattr(self, "_graphs"):
             self._graphs = {}
+        from .. import ops
         gs = self._graphs.get(key)
+        if gs is not None and gs[2] != ops.alloc_epoch():
+            # some step buffer or workspace was (re)allocated since the capture (another batch shape came
+            # through - the last, partial batch of an epoch - or another module grew a shared workspace): every
+            # capture of this module may hold freed addresses.  Drop them all and capture again.
+            self._graphs = {}
+            gs = None
         if gs is None:
             eager()  # warm-up: sizes every workspace, so the capture allocates nothing
             torch.cuda.synchronize()
@@ -116,12 +123,11 @@ class GraphMixin:
                     side[1]()
                 if getattr(self, "_side_replay_stream", None) is None:
                     self._side_replay_stream = torch.cuda.Stream(device=self.device)
-            self._graphs[key] = (gs, g_side)
+            self._graphs[key] = (gs, g_side, ops.alloc_epoch())
             return
-        gs, g_side = gs
+        gs, g_side, _ = gs
         stepped = getattr(self, "_stepped_blocks", None)
         if stepped is not None:  # a replay runs no python: the optimiser kernels' writes are announced here
-            from .. import ops
             ops.touched(*stepped())
         cur = torch.cuda.current_stream()
         for i, g in enumerate(gs):

@@ -129,6 +129,7 @@ def _playlmp_ensure(self, B, T, hw):
         return
     from ... import ops
 
+    ops.note_alloc()
     dev, cams, net = self.dev, self.plan_proposal_obs_modalities, self.net
     f = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
     R, Ec = B * T, 32 * len(cams)
@@ -187,6 +188,7 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
         else:
             call("tacorl_pack_images", ptr(v), 3 * H * W, int(nchw), ptr(self.frames[c]), xd, R, 3, H, W, ops.stream())
     if getattr(self, "_acts", None) is None or self._acts.shape != batch["actions"].shape:
+        ops.note_alloc()
         self._acts = torch.zeros(*batch["actions"].shape, device=self.dev)
     self._acts.copy_(batch["actions"])
     acts = self._acts
@@ -235,6 +237,7 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
             if getattr(self, "_wpk", None) is None:
                 self._wpk = {}
             if c not in self._wpk:
+                ops.note_alloc()
                 self._wpk[c] = torch.empty(ops.L.lib().tacorl_encoder_fused_wpk_bytes(), dtype=torch.uint8, device=self.dev)
             call("tacorl_encoder_pack_weights", 1, ops.ptr_array([net.enc(c)]), ops.ptr_array([self._wpk[c]]), ops.stream())
             call("tacorl_encoder_fwd_fused", 1, ops.ptr_array([self.frames[c]]), ops.ptr_array([self._wpk[c]]),

@@ -85,6 +85,7 @@ class TACORL(CQL_Offline):
     def _ensure_seq(self, B, T, hw):
         if self._T == (B, T, tuple(sorted(hw.items()))):
             return
+        ops.note_alloc()
         dev = self.dev
         self.frames = {c: torch.zeros(B * T, *hw[c], 3, device=dev, dtype=self.img_dtype) for c in self.all_modalities}
         self.f_out = {c: torch.zeros(B * T, 32, device=dev) for c in self.all_modalities}
@@ -145,6 +146,7 @@ class TACORL(CQL_Offline):
                 for src, pitch, dst, n in jobs:
                     call("tacorl_pack_images", src, pitch, int(nchw), dst, xd, n, 3, H, W, ops.stream())
         if self.ad is not None and (getattr(self, "acts", None) is None or self.acts.shape[:2] != (B, T)):
+            ops.note_alloc()
             self.acts = torch.zeros(B, T, 7, device=self.dev)
         disp, acts = batch["disp"], batch["actions"] if self.ad is not None else None
         dd = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.uint8: 3, torch.bool: 3}.get(disp.dtype)

@@ -57,6 +57,7 @@ class ActionDecoderLogistic:
     def _ensure(self, B, Tm):
         if self._shape == (B, Tm):
             return
+        ops.note_alloc()
         f = lambda *s: torch.zeros(*s, device=self.dev)  # noqa: E731
         R, H = B * Tm, self.hidden
         self.x_seq = f(R, self.P + self.E)
@@ -174,6 +175,7 @@ class ActionDecoderLogistic:
             emb, ld = module.pr_in, module.pr_in.shape[1]
         else:
             if getattr(module, "_ad_in", None) is None or module._ad_in.shape[0] != B * T:
+                ops.note_alloc()
                 module._ad_in = torch.zeros(B * T, 32 * len(cams), device=self.dev)
             for j, c in enumerate(cams):
                 ops.copy_cols(module.f_out[c], 0, 32, module._ad_in, 32 * j, module._ad_in.shape[1], B * T, 32)
@@ -207,6 +209,7 @@ class ActionDecoderLogistic:
         d(x_seq) into self.dx_seq.  ReLU-RNN BPTT: dz_{t-1} = (dz_t W_hh + dH_{t-1}) * [h_{t-1} > 0]."""
         blk, H, R, L = self.blk, self.hidden, B * Tm, self.L
         if getattr(self, "_bshape", None) != (B, Tm):
+            ops.note_alloc()
             f = lambda *s: torch.zeros(*s, device=self.dev)  # noqa: E731
             self.dH = f(R, H)
             self.DZ = [f(R, H) for _ in range(L)]
@@ -218,6 +221,7 @@ class ActionDecoderLogistic:
         self._dgrad(self.d_heads, self.NHP, blk.p("mean_fc.weight"), self.dH, H, R, self.NH, H, compute)
         fast = compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H)) and H % 32 == 0
         if fast and getattr(self, "_bptt_shape", None) != (B, Tm):
+            ops.note_alloc()
             bf = lambda *s: torch.zeros(*s, device=self.dev, dtype=torch.bfloat16)  # noqa: E731
             self.DZb = [bf(R, H) for _ in range(L)]   # bf16 copies of dZ_t: the ring GEMM's operand
             self.whtb = [bf(H, H) for _ in range(L)]  # W_hh^T

@@ -46,6 +46,7 @@ class PlanRecognition:
             return
         if T > self.T_max:
             raise ValueError(f"sequence length {T} > max_position_embeddings {self.T_max}")
+        ops.note_alloc()
         f = lambda *s: torch.zeros(*s, device=self.dev)  # noqa: E731
         R, D = B * T, self.D
         self.x = [f(R, D) for _ in range(2 * self.L + 1)]  # layer inputs / post-norm1 / post-norm2
@@ -85,6 +86,7 @@ class PlanRecognition:
         import ctypes as C
         blk = self.blk
         if getattr(self, "_pb", None) is None:
+            ops.note_alloc()
             self._pb = torch.zeros(blk.param.numel(), device=self.dev, dtype=torch.bfloat16)
             self._foff = (C.c_long * (1 + 12 * self.L))(*self._fused_offsets())
             self._Wc = torch.zeros(2 * self.A, self.D, device=self.dev)
@@ -176,6 +178,7 @@ class PlanRecognition:
         (B*T, D) gradient w.r.t. the (padded) input embeddings."""
         blk, D, R, FF, FC, A2 = self.blk, self.D, B * T, self.FF, self.FC, 2 * self.A
         if getattr(self, "_bshape", None) != (B, T):
+            ops.note_alloc()
             f = lambda *s: torch.zeros(*s, device=self.dev)  # noqa: E731
             self.d_fc, self.d_pool = f(B, FC), f(B, D)
             self.dx, self.dv, self.d_ff1, self.d_x1, self.d_att, self.d_qkv = f(R, D), f(R, D), f(R, FF), f(R, D), f(R, D), f(R, 3 * D)

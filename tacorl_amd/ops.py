@@ -8,16 +8,31 @@ from . import _lib as L
 from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, BF16, F32, call, int_array, ptr, ptr_array, stream  # noqa: F401
 
 _ws_cache = {}
+_alloc_epoch = 0
+
+
+def note_alloc():
+    """Every (re)allocation of a buffer that a captured hipGraph may hold a raw pointer to - step buffers
+    of a new batch shape, a regrown workspace - bumps this epoch.  GraphMixin._run_segments stamps its
+    captures with the epoch and drops any capture whose stamp is stale, so a graph is never replayed
+    against freed memory (the reference DataLoader has no drop_last: B goes 256 -> r -> 256 every epoch)."""
+    global _alloc_epoch
+    _alloc_epoch += 1
+
+
+def alloc_epoch():
+    return _alloc_epoch
 
 
 def workspace(nbytes, device, tag="default"):
-    """Grow-only scratch buffer per (device, tag); stable address once grown (graph-safe
-    after the warm-up step)."""
+    """Grow-only scratch buffer per (device, tag); its address is stable until it has to grow, and
+    growing bumps the allocation epoch (captured graphs that point at the old buffer are dropped)."""
     key = (str(device), tag)
     t = _ws_cache.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = t
+        note_alloc()
     return t
 
 
