@@ -5,15 +5,23 @@ Workload (BASELINE.json configs[1] / SURVEY 8d "C2"): TACORL.training_step, froz
 (finetune_action_decoder=False), batch 256 per GPU, T=16 window, 84x84x3 frames, latent plan 16,
 n_action_samples=4, Q phase (epoch >= bc_epochs), bf16 MFMA operands with fp32 accumulation and
 fp32 master weights.  Synthetic data (U(-1,1) frames, reference initialisers, random-init LMP).
-One process per GPU; for N>1 start with torch.distributed.run (RCCL all-reduce of the flat
-gradient blocks).  Prints ONE JSON line on rank 0.
+
+One process per GPU over RCCL.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the
+environment starts the N rank processes itself (child processes, created before this process has made
+any GPU call); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one
+of the ranks.  Rank 0 prints ONE JSON line.
 
 "step" = one full training_step on one 256-sample batch per GPU (weak scaling);
-value = batch-256 grad steps per second summed over GPUs (= global samples/s / 256).
+value = batch-256 grad steps per second summed over GPUs (= global samples/s / 256).  For N > 1 the
+line also carries a `strong` block: the same global batch of 256 split over the ranks (256/N samples
+per GPU), i.e. true optimiser steps per second.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +33,7 @@ sys.path.insert(0, ROOT)
 ENC_FLOP_PER_IMG_84 = 13.918e6  # 2 * 6 959 104 MAC
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+DATA_SEED, PARAM_SEED = 1234, 0
 
 
 def synth_batch(B, T, H, W, dev, seed):
@@ -49,7 +58,7 @@ def build_module(dev, compute, T, world, ad_every=1):
               min_std=1e-4, dropout_p=0.0, max_position_embeddings=T)
     ad = dict(n_mixtures=10, num_layers=2, hidden_size=2048, out_features=7, num_classes=10, latent_plan_dim=16,
               rnn_model="rnn_decoder", include_goal=False)
-    torch.manual_seed(0)
+    torch.manual_seed(PARAM_SEED)
     lmp = PlayLMP(plan_proposal=actor, plan_recognition=pr, action_decoder=ad, plan_proposal_obs_modalities=cams,
                   plan_proposal_goal_modalities=cams, plan_recognition_modalities=cams, action_decoder_modalities=cams,
                   real_world=True, device=dev, compute_dtype=compute, image_dtype=compute)
@@ -128,15 +137,85 @@ def cpu_baseline(mod, batch_cpu, noise_cpu, B, budget_s=25.0):
             "s_per_step": round(dt, 3)}
 
 
+def launch_ranks(n, argv):
+    """Self-launcher: one child process per GPU, rendezvous on 127.0.0.1.  Nothing in this (parent) process has
+    touched the GPU - it only waits for the children and passes rank 0's JSON line through its own stdout."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:  # a rank died: the others would wait in a collective for ever
+                rc = code
+                for q in live:
+                    q.terminate()
+    return rc
+
+
+def launch_check(world, rank):
+    """`--launch-check`: rendezvous + one all-reduce on host tensors, no GPU work (the CPU test of the launcher)."""
+    import torch.distributed as dist
+
+    dist.init_process_group(os.environ.get("TACORL_DIST_BACKEND", "gloo"))
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": dist.get_world_size(), "sum": t.item()}), flush=True)
+    dist.destroy_process_group()
+
+
+def timed_steps(mod, batch, steps, barrier):
+    """Contract region: exactly `steps` training steps between barrier + synchronize on both sides."""
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        mod.training_step(batch)
+    barrier()
+    return time.perf_counter() - t0
+
+
+def step_time_distribution(mod, batch, ms_guess, min_seconds=1.0, max_steps=4000):
+    """Per-step device times from HIP events (one event after every step on the stream the step runs on),
+    over at least `min_seconds` of steps: median / p10 / p90 next to the contract region's wall-clock mean."""
+    n = int(min(max_steps, max(50, math.ceil(min_seconds * 1e3 / max(ms_guess, 1e-3)))))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    torch.cuda.synchronize()
+    evs[0].record()
+    for i in range(n):
+        mod.training_step(batch)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
+    q = lambda f: ts[min(n - 1, int(f * n))]  # noqa: E731
+    return {"n": n, "median_ms": round(q(0.5), 4), "p10_ms": round(q(0.1), 4), "p90_ms": round(q(0.9), 4),
+            "mean_ms": round(sum(ts) / n, 4), "max_ms": round(ts[-1], 4),
+            "how": "hipEvent after every training_step on torch's current stream"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-distribution", action="store_true", help="skip the per-step HIP-event statistics")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous + one host all-reduce only (launcher test)")
     ap.add_argument("--ad-every", type=int, default=1,
                     help="evaluate the (logging-only, frozen) action-decoder loss every k-th step; 1 = every step "
                          "as the reference does")
@@ -145,11 +224,16 @@ def main():
                          "u8: the dataset's uint8 HWC frames, normalised on the GPU (SURVEY 8f N2; reported in DESIGN.md)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))  # no GPU call has happened in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        sys.exit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    if a.gpus != world:
+        sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start with --nproc-per-node {a.gpus}, or without "
+                 f"torch.distributed.run (bench.py then starts its own rank processes)")
+    if a.launch_check:
+        return launch_check(world, rank)
     # Test hooks (never set by the driver): run the N-rank code path on a 1-GPU box - every rank on
     # cuda:0 and gloo instead of RCCL (which refuses two ranks on one device).
     if os.environ.get("TACORL_BENCH_SINGLE_DEVICE"):
@@ -161,7 +245,7 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        if backend == "nccl":  # = RCCL on ROCm
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
@@ -170,8 +254,13 @@ def main():
 
     _lib.call("tacorl_hip_init", local)
     B, T, H, W = a.batch, 16, 84, 84
+    # identical parameters on every rank: same PARAM_SEED, and the constructor broadcasts rank 0's blocks
+    # (what DDP's wrap does for the reference module)
     mod = build_module(dev, a.dtype, T, world, a.ad_every)
-    batch = synth_batch(B, T, H, W, dev, 1234 + rank)
+    # every rank draws its own noise for its own shard of the global batch
+    torch.manual_seed(DATA_SEED + rank)
+    torch.cuda.manual_seed(DATA_SEED + rank)
+    batch = synth_batch(B, T, H, W, dev, DATA_SEED + rank)
     if a.frames == "u8":  # the same frames quantised back to the dataset's format
         q = lambda x, perm: ((x.permute(*perm) * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8).contiguous()  # noqa: E731
         batch = dict(batch, states={k: q(v, (0, 1, 3, 4, 2)) for k, v in batch["states"].items()},
@@ -186,29 +275,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.item()
+        return x
+
     for _ in range(a.warmup):
         mod.training_step(batch)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        mod.training_step(batch)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt = max_over_ranks(timed_steps(mod, batch, a.steps, barrier))
     ms_step = dt / a.steps * 1e3
     logs = mod.engine.metrics()
     finite = all(v == v and abs(v) < 1e30 for v in logs.values())
-    in_sync = None
-    if world > 1:  # replicas must hold identical parameters after the timed steps (same all-reduced grads)
+    dist_stats = None if a.no_distribution else step_time_distribution(mod, batch, ms_step)
+
+    def replicas_in_sync():
         e = mod.engine
         cs = torch.stack([x.param.double().sum() for x in (e.actor, e.q1, e.q2)]).to(dev)
         lo, hi = cs.clone(), cs.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        in_sync = bool(torch.equal(lo, hi))
+        return bool(torch.equal(lo, hi))
+
+    in_sync, strong = None, None
+    if world > 1:  # replicas must hold identical parameters after the timed steps (same all-reduced grads)
+        in_sync = replicas_in_sync()
+        # strong scaling: the SAME global batch of 256, 256/N samples per GPU -> true optimiser steps per second
+        if B % world == 0:
+            sb = synth_batch(B // world, T, H, W, dev, DATA_SEED + 100 + rank)
+            for _ in range(a.warmup):
+                mod.training_step(sb)
+            sdt = max_over_ranks(timed_steps(mod, sb, a.steps, barrier))
+            strong = {"global_batch": B, "per_gpu_batch": B // world, "ms_per_step": round(sdt / a.steps * 1e3, 4),
+                      "value": round(a.steps / sdt, 3), "unit": "optimiser steps/s at global batch 256",
+                      "replicas_in_sync": replicas_in_sync()}
+            for _ in range(3):  # back to the bench shape for the roofline probe below
+                mod.training_step(batch)
 
     out = None
     if rank == 0:
@@ -227,9 +330,13 @@ def main():
                        "frames": "fp32 CHW (reference batch schema)" if a.frames == "f32" else "uint8 HWC, normalised on the GPU",
                        "latent_plan": 16, "n_action_samples": 4, "phase": "Q (epoch>=bc_epochs)",
                        "action_decoder_loss": ("every step (reference behaviour)" if a.ad_every <= 1 else
-                                               f"every {a.ad_every} steps (logging cadence)"), "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                                               f"every {a.ad_every} steps (logging cadence)"), "parallelism": f"dp{world}",
+                       "collective_backend": None if world == 1 else ("rccl" if backend == "nccl" else backend),
+                       "hip_graph": bool(use_graph),
                        "samples_per_s": round(world * B / (ms_step * 1e-3), 1), "losses_finite": finite,
                        "replicas_in_sync": in_sync},
+            "step_time": dist_stats,
+            "strong": strong,
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tflops / peak, 4), "traffic": measured_traffic(n_img, fused, a.dtype),
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
@@ -240,8 +347,6 @@ def main():
                          "images_per_launch": n_img, "avg_ms": round(enc_ms, 4)},
         }
         if world == 1 and not a.no_cpu_baseline and a.frames == "f32":
-            from tacorl_amd import synth  # noqa: F401
-
             bc = {"states": {"rgb_static": batch["states"]["rgb_static"].cpu()},
                   "goal": {"rgb_static": batch["goal"]["rgb_static"].cpu()}, "actions": batch["actions"].cpu(),
                   "disp": batch["disp"].cpu()}
@@ -250,6 +355,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(mod, bc, nz, B)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -35,8 +35,18 @@ CASES = {
     "tacorl_dualcam": dict(kind="tacorl", B=2, T=8, latent=32, epoch=5, finetune_ad=False,
                            cams={"rgb_static": (128, 128), "rgb_gripper": (84, 84)},
                            steps=1, seed=13, overrides=dict(deterministic_backup=False)),
+    # BASELINE config 4 as stated: both cameras 128x128, window 32 (config/datamodule/play_lmp_real_world.yaml:17-18),
+    # latent plan 32 (config/experiment/play_lmp_real_world.yaml:10), real-world entropy backup
+    "tacorl_c4": dict(kind="tacorl", B=2, T=32, latent=32, epoch=5, finetune_ad=False,
+                      cams={"rgb_static": (128, 128), "rgb_gripper": (128, 128)}, steps=2, seed=17),
+    # BASELINE config 3 as stated: the full default TACORL step - Q phase WITH action-decoder fine-tuning
+    "tacorl_q_ad": dict(kind="tacorl", B=2, T=16, cams={"rgb_static": (84, 84)}, latent=16,
+                        epoch=5, finetune_ad=True, steps=2, seed=18),
     # flat CQL baseline, discrete gripper (BASELINE config 5 shape)
     "cql_q": dict(kind="cql", B=3, cams={"rgb_static": (84, 84)}, epoch=5, steps=2, seed=14),
+    # BASELINE config 5 as stated: 32 action samples in the logsumexp
+    "cql_n32": dict(kind="cql", B=3, cams={"rgb_static": (84, 84)}, epoch=5, steps=2, seed=19,
+                    overrides=dict(n_action_samples=32)),
     "cql_bc": dict(kind="cql", B=3, cams={"rgb_static": (84, 84)}, epoch=0, steps=1, seed=15,
                    overrides=dict(n_action_samples=2)),
     # PlayLMP seq-VAE step (BASELINE config 1 shape)

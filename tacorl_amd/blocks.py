@@ -91,6 +91,10 @@ class TensorBlock:
             self.step = torch.zeros(1, dtype=torch.int32, device=device)
             self.grad_views = {k: self.grad[o: o + n].view(*shp) for k, (o, shp, n) in self.off.items()}
 
+    def views_of(self, flat):
+        """Reference-named views into another flat buffer of this layout (Adam moments, ...)."""
+        return {k: flat[o: o + n].view(*shp) for k, (o, shp, n) in self.off.items()}
+
     def p(self, name, flat=None):
         """Raw device address of tensor `name` inside `flat` (default: the parameter block)."""
         return (self.param if flat is None else flat).data_ptr() + 4 * self.off[name][0]

@@ -66,6 +66,9 @@ class NetBlock:
             dst.update(blocks.head_views(flat, self.head_off, self.head_dims, self.head_dims[-2], self._head_parts))
         return dst
 
+    def views_of(self, flat):
+        return self._views_of(flat)
+
     def rebind_grad(self, flat):
         """Move the gradient block into caller-provided storage (a slice of one arena, so that a single
         all-reduce covers several networks)."""

@@ -1,5 +1,6 @@
 """Shared plumbing for the reference-shaped module classes (no arithmetic here)."""
 import copy
+import re
 
 import torch
 import torch.nn as nn
@@ -19,6 +20,71 @@ def to_plain(cfg):
     return copy.deepcopy(dict(cfg)) if isinstance(cfg, dict) else copy.deepcopy(cfg)
 
 
+_INTERP = re.compile(r"\$\{([^${}]+)\}")
+
+
+def load_resolved_yaml(path):
+    """OmegaConf.load(path) + OmegaConf.to_container(cfg, resolve=True) (reference utils/networks.py:142): the saved
+    run config keeps `${latent_plan_dim}` / `${datamodule.dataset.max_window_size}` style interpolations
+    (config/networks/plan_recognition/transformer.yaml:7,13).  With omegaconf installed it does the work; without it
+    the absolute-key `${a.b.c}` interpolations those configs use are resolved here (resolvers such as `${oc.env:..}`
+    are not supported and raise)."""
+    try:
+        from omegaconf import OmegaConf  # noqa: WPS433
+
+        return OmegaConf.to_container(OmegaConf.load(path), resolve=True)
+    except ImportError:
+        pass
+    import yaml
+
+    with open(path) as f:
+        root = yaml.safe_load(f)
+
+    def lookup(key, stack):
+        if ":" in key or key.startswith("."):
+            raise NotImplementedError(f"{path}: interpolation ${{{key}}} needs omegaconf")
+        if key in stack:
+            raise ValueError(f"{path}: interpolation cycle at ${{{key}}}")
+        node = root
+        for part in key.split("."):
+            node = node[int(part)] if isinstance(node, list) else node[part]
+        return walk(node, stack + (key,))
+
+    def walk(node, stack=()):
+        if isinstance(node, dict):
+            return {k: walk(v, stack) for k, v in node.items()}
+        if isinstance(node, list):
+            return [walk(v, stack) for v in node]
+        if isinstance(node, str):
+            m = _INTERP.fullmatch(node)
+            if m:
+                return lookup(m.group(1).strip(), stack)
+            while _INTERP.search(node):
+                node = _INTERP.sub(lambda mm: str(lookup(mm.group(1).strip(), stack)), node)
+        return node
+
+    return walk(root)
+
+
+def find_checkpoint(run_dir, epoch=-1):
+    """get_checkpoint_i_from_dir (reference utils/networks.py:120-136): `last.ckpt` for epoch -1, else the checkpoint
+    whose file name carries exactly `epoch_<N>` / `epoch=<N>`; otherwise the `epoch`-th checkpoint by modification time
+    (the reference sorts by mtime and discards the result - an unsorted rglob order; here the sort is kept)."""
+    from pathlib import Path
+
+    cks = sorted(Path(run_dir).rglob("*.ckpt"), key=lambda f: f.stat().st_mtime)
+    if not cks:
+        raise FileNotFoundError(f"no .ckpt under {run_dir}")
+    if epoch == -1:
+        for c in cks:
+            if c.stem == "last":
+                return c
+    for c in cks:
+        if any(int(n) == epoch for n in re.findall(r"epoch[_=](\d+)", c.name)):
+            return c
+    return cks[epoch]
+
+
 def compute_flag(compute_dtype):
     if compute_dtype in (F32, "f32", "fp32", torch.float32, 32, "32"):
         return F32
@@ -28,7 +94,9 @@ def compute_flag(compute_dtype):
 
 
 def register_views(root, prefix, views, requires_grad=True):
-    """Expose flat-block views as nn.Parameters under the reference's dotted names."""
+    """Expose flat-block views as nn.Parameters under the reference's dotted names.
+    Returns {view name: Parameter} (what BlockAdam is built from)."""
+    made = {}
     for name, t in views.items():
         parts = (prefix + name).split(".")
         mod = root
@@ -36,18 +104,106 @@ def register_views(root, prefix, views, requires_grad=True):
             if not hasattr(mod, p) or not isinstance(getattr(mod, p), nn.Module):
                 mod.add_module(p, nn.Module())
             mod = getattr(mod, p)
-        mod.register_parameter(parts[-1], nn.Parameter(t, requires_grad=requires_grad))
+        made[name] = nn.Parameter(t, requires_grad=requires_grad)
+        mod.register_parameter(parts[-1], made[name])
+    return made
 
 
-class LoggerMixin:
-    """`self.log(name, value, ...)` as LightningModule offers it; values are kept in
-    `self.logged` (and forwarded to a trainer-provided sink when one is attached)."""
+def broadcast_blocks(blocks, src=0):
+    """Make every rank's parameter blocks and optimiser state equal to rank `src`'s (what DDP does when it wraps
+    the reference module, so callers that seed per rank still start from one model).  No-op without a
+    process group."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    for blk in blocks:
+        for name in ("param", "m", "v", "step"):
+            t = getattr(blk, name, None)
+            if t is not None:
+                dist.broadcast(t, src)
+
+
+class ModuleMixin:
+    """What the three module classes share on top of LightningModuleBase (pl.LightningModule when
+    pytorch_lightning is importable, tacorl_amd.lightning._MiniLightningModule otherwise): the parameter
+    blocks live on ONE device chosen at construction, `self.log` also keeps the last value in `self.logged`,
+    `current_epoch` can be pinned by hand (tests / scripts without a trainer), optimisers are BlockAdams."""
+
+    def _init_runtime(self, device, compute_dtype, image_dtype, world_size):
+        from .. import _lib
+        from ..lightning import default_device
+
+        _lib.lib()  # fail loudly, now, if the HIP extension is missing (no CPU / eager fallback)
+        self.dev = torch.device(device) if device is not None else default_device()
+        self.logged = {}
+        self.compute = compute_flag(compute_dtype)
+        self.img_dtype = torch.bfloat16 if compute_flag(image_dtype) == BF16 else torch.float32
+        self.world_size = int(world_size)
+        self.log_every_n_steps = 1  # PL Trainer(log_every_n_steps=...) semantics: metrics are read back (one D2H
+        self._step_count = 0        # sync) only on these steps
+        self._graphs, self._use_graph = {}, False
+
+    # -- trainer-owned state, overridable without a trainer
+    def _attached_trainer(self):
+        tr = self.__dict__.get("_trainer")
+        if tr is None:
+            tr = getattr(self, "_trainer", None)
+        return tr
+
+    @property
+    def current_epoch(self):
+        ov = self.__dict__.get("_epoch_override")
+        if ov is not None:
+            return ov
+        tr = self._attached_trainer()
+        return int(tr.current_epoch) if tr is not None else 0
+
+    @current_epoch.setter
+    def current_epoch(self, v):
+        self.__dict__["_epoch_override"] = v
+
+    @property
+    def device(self):
+        return self.dev
 
     def log(self, name, value, **kw):
         self.logged[name] = float(value)
-        sink = getattr(self, "_log_sink", None)
-        if sink is not None:
-            sink(name, float(value), **kw)
+        if self._attached_trainer() is not None:
+            super().log(name, float(value), **kw)
+
+    def _apply(self, fn, *args, **kwargs):
+        """nn.Module.to / .cuda / .float land here.  The parameters are views into flat device blocks that the
+        kernels address by raw pointer, so the module cannot be moved or cast after construction; a call that
+        would not change anything (what Trainer.fit does to a module that is already on its GPU) is accepted."""
+        probe = fn(torch.empty(0, device=self.dev))
+        if probe.device != self.dev or probe.dtype != torch.float32:
+            raise RuntimeError(
+                f"{type(self).__name__} lives on {self.dev} as fp32 blocks (views, raw pointers): build it on its GPU "
+                "(device=..., default cuda:$LOCAL_RANK) and select precision with compute_dtype / image_dtype; "
+                f".to({probe.device}, {probe.dtype}) cannot move or cast it")
+        return self
+
+    def on_fit_start(self):
+        """Adopt the trainer's world size (PL DDP: one process per GPU; the gradient blocks are all-reduced
+        through torch.distributed's default group - RCCL with backend nccl)."""
+        tr = self._attached_trainer()
+        ws = int(getattr(tr, "world_size", 1) or 1)
+        if ws != self.world_size:
+            self._set_world_size(ws)
+
+    def _set_world_size(self, ws):
+        self.world_size = ws
+        if getattr(self, "engine", None) is not None:
+            self.engine.world = ws
+        self._graphs = {}
+        if ws > 1:
+            self.sync_from_rank0()
+
+    def _make_adam(self, name, entries, lr):
+        from ..lightning import BlockAdam
+
+        return BlockAdam(name, entries, lr)
 
 
 class GraphMixin:

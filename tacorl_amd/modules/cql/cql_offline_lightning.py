@@ -12,23 +12,11 @@ import torch.nn as nn
 
 from ... import _lib
 from ...engine import ACEngine
-from ..common import GraphMixin, LoggerMixin, compute_flag, register_views, to_plain
+from ...lightning import LightningModuleBase
+from ..common import GraphMixin, ModuleMixin, broadcast_blocks, register_views, to_plain
 
 
-class _OptimizerHandle:
-    """What `configure_optimizers()` returns: the state lives in the engine's flat blocks."""
-
-    def __init__(self, name, blk, lr):
-        self.name, self.blk, self.lr = name, blk, lr
-
-    def state_dict(self):
-        return {"m": self.blk.m.clone(), "v": self.blk.v.clone(), "step": self.blk.step.clone(), "lr": self.lr}
-
-    def load_state_dict(self, sd):
-        self.blk.m.copy_(sd["m"]); self.blk.v.copy_(sd["v"]); self.blk.step.copy_(sd["step"])
-
-
-class CQL_Offline(GraphMixin, LoggerMixin, nn.Module):
+class CQL_Offline(GraphMixin, ModuleMixin, LightningModuleBase):
     def __init__(self, env={}, actor={}, critic={}, actor_encoder={}, critic_encoder={}, goal_encoder={},
                  transform_manager={}, discount: float = 0.99, tau: float = 0.005, actor_lr: float = 3e-4,
                  critic_lr: float = 3e-4, deterministic_backup: bool = False, reward_scale: float = 1.0,
@@ -42,11 +30,9 @@ class CQL_Offline(GraphMixin, LoggerMixin, nn.Module):
         super().__init__()
         if with_dr3 or with_vib:
             raise NotImplementedError("DR3 / VIB regularisers are off in every in-scope config (SURVEY 8a A9)")
-        _lib.lib()  # fail loudly, now, if the HIP extension is missing
-        self.dev = torch.device(device if device is not None else "cuda:0")
-        self.logged = {}
-        self.current_epoch = 0
-        self.automatic_optimization = False
+        self._init_runtime(device, compute_dtype, image_dtype, world_size)
+        self.automatic_optimization = False  # reference :115
+        self.save_hyperparameters(ignore=["play_lmp"])  # reference :116
         self.real_world = real_world
         self.env = None
         self.transform_manager = transform_manager
@@ -54,18 +40,14 @@ class CQL_Offline(GraphMixin, LoggerMixin, nn.Module):
         self.actor_lr, self.critic_lr = actor_lr, critic_lr
         self.with_lagrange = with_lagrange
         self.n_action_samples = n_action_samples
-        self.compute = compute_flag(compute_dtype)
-        self.img_dtype = torch.bfloat16 if compute_flag(image_dtype) == _lib.BF16 else torch.float32
-        self.world_size = world_size
-        self.log_every_n_steps = 1  # PL Trainer(log_every_n_steps=...) semantics: metrics are read back (one D2H
-        self._step_count = 0        # sync) only on these steps
-        self._graphs, self._use_graph = {}, False
         self._hp = dict(discount=discount, tau=tau, actor_lr=actor_lr, critic_lr=critic_lr,
                         deterministic_backup=deterministic_backup, reward_scale=reward_scale,
                         clip_grad_val=float(clip_grad_val) if clip_grad else 0.0,
                         conservative_weight=conservative_weight, lagrange_thresh=lagrange_thresh, temp=temp,
                         with_lagrange=with_lagrange, n=n_action_samples)
         self.actor_cfg, self.critic_cfg = to_plain(actor), to_plain(critic)
+        self.actor_encoder_cfg, self.critic_encoder_cfg = to_plain(actor_encoder), to_plain(critic_encoder)
+        self.goal_encoder_cfg = to_plain(goal_encoder)
         if not real_world:
             # the reference builds the pybullet env here to read modalities / action space
             # (cql_offline_lightning.py:65-67,155-158); the simulator is out of scope, so the same
@@ -78,15 +60,15 @@ class CQL_Offline(GraphMixin, LoggerMixin, nn.Module):
         # target entropy: -action_dim (real world, :93-94) or -prod(env.action_space.shape) = -7 (:96-98)
         self.target_entropy = -float(action_dim) if real_world else -7.0
         self.build_networks()
+        if world_size > 1:
+            self.sync_from_rank0()
 
     # ------------------------------------------------------------------ construction
     def _arch(self):
-        pol = self.actor_cfg.get("policy", {}) if self.actor_cfg else {}
-        qn = self.critic_cfg.get("q_network", {}) if self.critic_cfg else {}
-        for cfg, ok in ((pol, "MLPPolicy"), (qn, "MLPQNetwork")):
-            t = cfg.get("_target_", ok)
-            if not t.endswith(ok):
-                raise NotImplementedError(f"{t}: only the default {ok} is on the hot path (SURVEY section 2 row 8)")
+        from .. import cfgcheck
+
+        pol = cfgcheck.check_actor(self.actor_cfg, "actor")
+        qn = cfgcheck.check_critic(self.critic_cfg, "critic")
         return dict(policy_layers=pol.get("num_layers", 2), q_layers=qn.get("num_layers", 2),
                     hidden=pol.get("hidden_dim", 256),
                     discrete_gripper=bool(self.actor_cfg.get("discrete_gripper", False)))
@@ -94,9 +76,14 @@ class CQL_Offline(GraphMixin, LoggerMixin, nn.Module):
     def build_networks(self):
         if not self.obs_modalities:
             raise ValueError("obs_modalities / goal_modalities are required (real_world=True style construction)")
+        from .. import cfgcheck
+
         a = self._arch()
-        if a["hidden"] != self.critic_cfg.get("q_network", {}).get("hidden_dim", 256):
+        if a["hidden"] != (self.critic_cfg or {}).get("q_network", {}).get("hidden_dim", 256):
             raise NotImplementedError("actor and critic hidden sizes must match")
+        cfgcheck.check_representation(self.actor_encoder_cfg, "actor_encoder", self.obs_modalities)
+        cfgcheck.check_representation(self.critic_encoder_cfg, "critic_encoder", self.obs_modalities)
+        cfgcheck.check_goal_encoder(self.goal_encoder_cfg, "goal_encoder", a["hidden"])
         self._make_engine(self.obs_modalities, self.goal_modalities, self.action_dim, a)
         self._register()
 
@@ -113,13 +100,31 @@ class CQL_Offline(GraphMixin, LoggerMixin, nn.Module):
 
     def _register(self):
         e = self.engine
+        self._pv = {}  # block name -> {view name: Parameter}: what the BlockAdams are built from
         for name, blk in (("actor", e.actor), ("q1", e.q1), ("q2", e.q2), ("target_q1", e.tq1), ("target_q2", e.tq2)):
-            register_views(self, name + ".", blk.views)
+            self._pv[name] = register_views(self, name + ".", blk.views)
         self.log_alpha = nn.Parameter(e.log_alpha.param)
         if self.with_lagrange:
             self.log_alpha_prime = nn.Parameter(e.log_alpha_prime.param)
         self.actor.action_dim = self.action_dim
         self.actor.discrete_gripper = e.dg
+
+    def _all_blocks(self):
+        e = self.engine
+        out = [e.actor, e.q1, e.q2, e.tq1, e.tq2, e.log_alpha, e.log_alpha_prime]
+        for extra in ("lmp_net",):
+            if getattr(self, extra, None) is not None:
+                out.append(getattr(self, extra))
+        for extra in ("pr", "ad"):
+            if getattr(self, extra, None) is not None:
+                out.append(getattr(self, extra).blk)
+        return out
+
+    def sync_from_rank0(self):
+        """Broadcast rank 0's parameters and optimiser state (PL's DDP wrap does this for the reference module)."""
+        broadcast_blocks(self._all_blocks())
+        from ... import ops
+        ops.touched(*[b.param for b in self._all_blocks()])
 
     def sync_targets(self):
         """target.load_state_dict(q.state_dict()) (reference :226-227)."""
@@ -171,6 +176,7 @@ class CQL_Offline(GraphMixin, LoggerMixin, nn.Module):
 
     def compute_update(self, batch, optimize: bool = True, log_type: str = "train", noise=None):
         obs, action, nxt, reward, done = batch
+        self._sync_lrs()
         self._stage(obs["observation"], obs["goal"], nxt["observation"], action, reward, done, noise)
         bc = self.current_epoch < self.bc_epochs
         e = self.engine
@@ -195,11 +201,36 @@ class CQL_Offline(GraphMixin, LoggerMixin, nn.Module):
     def validation_step(self, batch, *args, noise=None, **kwargs):
         self.compute_update(self.overwrite_batch(batch), optimize=False, log_type="validation", noise=noise)
 
+    def _net_adam(self, name, blk, key, lr):
+        return self._make_adam(name, [(blk, self._pv[key], blk.views_of(blk.m), blk.views_of(blk.v))], lr)
+
+    def _scalar_adam(self, name, sc, param, lr):
+        return self._make_adam(name, [(sc, {"v": param}, {"v": sc.m}, {"v": sc.v})], lr)
+
     def configure_optimizers(self):
-        """Order [alpha, actor, q1, q2, (alpha')] as the reference (:553-574)."""
+        """Order [alpha, actor, q1, q2, (alpha')] as the reference (:553-574).  torch.optim.Optimizer subclasses whose
+        state is the engine's Adam blocks; the update itself runs inside training_step (manual optimisation)."""
         e = self.engine
-        o = [_OptimizerHandle("alpha", e.log_alpha, self.actor_lr), _OptimizerHandle("actor", e.actor, self.actor_lr),
-             _OptimizerHandle("q1", e.q1, self.critic_lr), _OptimizerHandle("q2", e.q2, self.critic_lr)]
+        o = [self._scalar_adam("alpha", e.log_alpha, self.log_alpha, self.actor_lr),
+             self._net_adam("actor", e.actor, "actor", self.actor_lr),
+             self._net_adam("q1", e.q1, "q1", self.critic_lr), self._net_adam("q2", e.q2, "q2", self.critic_lr)]
         if self.with_lagrange:
-            o.append(_OptimizerHandle("alpha_prime", e.log_alpha_prime, self.critic_lr))
+            o.append(self._scalar_adam("alpha_prime", e.log_alpha_prime, self.log_alpha_prime, self.critic_lr))
+        self._optimizers = o
         return o
+
+    def _sync_lrs(self):
+        """Learning rates edited on the optimisers' param_groups (schedulers, hand edits) reach the kernels: they are
+        launch arguments, so a change also drops the captured graphs."""
+        opts = getattr(self, "_optimizers", None)
+        if not opts:
+            return
+        hp, by = self.engine.hp, {o.name: o.lr for o in opts}
+        new = dict(actor_lr=by["actor"], critic_lr=by["q1"])
+        if by["alpha"] != by["actor"] or by["q2"] != by["q1"] or by.get("alpha_prime", by["q1"]) != by["q1"]:
+            raise NotImplementedError("alpha/actor share actor_lr and q1/q2/alpha' share critic_lr (reference :553-574)")
+        if "action_decoder" in by and by["action_decoder"] != self.action_decoder_lr:
+            self.action_decoder_lr, self._graphs = by["action_decoder"], {}
+        if any(hp[k] != v for k, v in new.items()):
+            hp.update(new)
+            self.actor_lr, self.critic_lr, self._graphs = new["actor_lr"], new["critic_lr"], {}

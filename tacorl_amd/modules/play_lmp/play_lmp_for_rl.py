@@ -15,22 +15,27 @@ from ...engine import NetBlock
 from ...init import init_views_
 from ...networks.action_decoder import ActionDecoderLogistic
 from ...networks.plan_recognition import PlanRecognition
-from ..common import GraphMixin, LoggerMixin, compute_flag, register_views, to_plain
+from ...lightning import LightningModuleBase
+from .. import cfgcheck
+from ..common import GraphMixin, ModuleMixin, register_views, to_plain
 
 
-class PlayLMP(GraphMixin, LoggerMixin, nn.Module):
+class PlayLMP(GraphMixin, ModuleMixin, LightningModuleBase):
     def __init__(self, env={}, actor={}, plan_proposal={}, plan_recognition={}, perceptual_encoder={},
                  goal_encoder={}, action_decoder={}, transform_manager={}, dataloader={}, kl_beta: float = 1e-3,
                  kl_balancing: bool = True, add_random_plan_loss: bool = False, kl_alpha: float = 0.8,
                  lr: float = 1e-4, plan_proposal_obs_modalities: List[str] = [],
                  plan_proposal_goal_modalities: List[str] = [], plan_recognition_modalities: List[str] = [],
                  action_decoder_modalities: List[str] = [], real_world: bool = False, *args, device=None,
-                 compute_dtype="f32", image_dtype="f32", **kwargs):
+                 compute_dtype="f32", image_dtype="f32", world_size=1, **kwargs):
         super().__init__()
-        _lib.lib()
-        self.dev = torch.device(device if device is not None else "cuda:0")
-        self.logged, self.current_epoch = {}, 0
+        self._init_runtime(device, compute_dtype, image_dtype, world_size)
+        # The reference leaves optimisation to PL (one Adam over everything, :362-368).  Here forward, backward and
+        # the fused Adam are one kernel sequence inside training_step, i.e. manual optimisation in PL's terms.
+        self.automatic_optimization = False
+        self.save_hyperparameters()  # reference :79
         self.real_world, self.env, self.transform_manager = real_world, None, transform_manager
+        self.dataloader = dataloader
         self.add_random_plan_loss = add_random_plan_loss
         self.plan_proposal_obs_modalities = list(plan_proposal_obs_modalities)
         self.plan_proposal_goal_modalities = list(plan_proposal_goal_modalities)
@@ -41,19 +46,22 @@ class PlayLMP(GraphMixin, LoggerMixin, nn.Module):
         if not self.all_modalities:
             raise ValueError("PlayLMP needs its *_modalities lists")
         self.lr, self.kl_beta, self.kl_balancing, self.kl_alpha = lr, kl_beta, kl_balancing, kl_alpha
-        self.compute = compute_flag(compute_dtype)
-        self.img_dtype = torch.bfloat16 if compute_flag(image_dtype) == _lib.BF16 else torch.float32
         self.pp_cfg, self.pr_cfg, self.ad_cfg = to_plain(plan_proposal), to_plain(plan_recognition), to_plain(action_decoder)
+        self.pe_cfg, self.ge_cfg = to_plain(perceptual_encoder), to_plain(goal_encoder)
         self.build_networks()
+        if self.world_size > 1:
+            self.sync_from_rank0()
 
     def build_networks(self):
         """reference play_lmp_for_rl.py:80-130."""
         cams = self.plan_proposal_obs_modalities
         if sorted(self.all_modalities) != sorted(set(cams)) or sorted(cams) != sorted(self.plan_proposal_goal_modalities):
             raise NotImplementedError("all PlayLMP modality lists must name the same cameras (in-scope configs)")
-        pol = self.pp_cfg.get("policy", {})
+        pol = cfgcheck.check_actor(self.pp_cfg, "plan_proposal")
         self.policy_layers, self.hidden = pol.get("num_layers", 2), pol.get("hidden_dim", 256)
-        prc = {k: v for k, v in self.pr_cfg.items() if not k.startswith("_")}
+        cfgcheck.check_representation(self.pe_cfg, "perceptual_encoder", cams)
+        cfgcheck.check_goal_encoder(self.ge_cfg, "goal_encoder", self.hidden)
+        prc = cfgcheck.check_plan_recognition(self.pr_cfg, "plan_recognition")
         state_dim = 32 * len(self.plan_recognition_modalities)
         prc["state_dim"] = state_dim
         self.pr = PlanRecognition(device=self.dev, **prc)
@@ -64,7 +72,7 @@ class PlayLMP(GraphMixin, LoggerMixin, nn.Module):
         parts = [("actor.policy.fc_mean", A), ("actor.policy.fc_log_std", A)]
         self.net = NetBlock(cams, cams, pdims, [ACT_SILU] * self.policy_layers + [ACT_NONE], pn, self.dev,
                             head_parts=parts, hidden=self.hidden)
-        adc = {k: v for k, v in self.ad_cfg.items() if not k.startswith("_")}
+        adc = cfgcheck.check_action_decoder(self.ad_cfg, "action_decoder")
         adc["state_dim"] = 32 * len(self.action_decoder_modalities)
         adc["goal_dim"] = 32 * len(cams)
         self.ad = ActionDecoderLogistic(device=self.dev, **adc)
@@ -79,45 +87,59 @@ class PlayLMP(GraphMixin, LoggerMixin, nn.Module):
                 ren["plan_proposal.policy." + k[len("actor.policy."):]] = v
             else:
                 ren[k] = v
-        register_views(self, "", ren)
-        register_views(self, "plan_recognition.", self.pr.blk.views)
-        register_views(self, "action_decoder.", self.ad.blk.views)
+        pv = register_views(self, "", ren)
+        back = {v_: k_ for k_, v_ in zip(self.net.views, ren)}  # renamed -> block view name
+        self._pv = {"net": {back[k]: p for k, p in pv.items()},
+                    "pr": register_views(self, "plan_recognition.", self.pr.blk.views),
+                    "ad": register_views(self, "action_decoder.", self.ad.blk.views)}
         for k, v in self.ad.buffers.items():
             self.action_decoder.register_buffer(k, v)
 
-    @property
-    def device(self):
-        return self.dev
+    def sync_from_rank0(self):
+        """Broadcast rank 0's parameters and optimiser state (PL's DDP wrap does this for the reference module)."""
+        from ... import ops
+        from ..common import broadcast_blocks
+
+        blocks = [self.net, self.pr.blk, self.ad.blk]
+        broadcast_blocks(blocks)
+        ops.touched(*[b.param for b in blocks])
 
     def set_kl_beta(self, kl_beta):
         """reference :303-305."""
         self.kl_beta = kl_beta
 
 
-def load_play_lmp(play_lmp_dir, epoch=-1, overwrite_cfg=None, device=None, compute_dtype="f32", image_dtype="f32"):
-    """utils/networks.py:90-142 load_pl_module_from_checkpoint: first `*config.yaml` + `last.ckpt`
-    (or `..._epoch_N...ckpt`) under `play_lmp_dir`."""
-    import yaml
+def load_play_lmp(play_lmp_dir, epoch=-1, overwrite_cfg=None, device=None, compute_dtype="f32", image_dtype="f32",
+                  unsafe_pickle=False):
+    """utils/networks.py:90-117 load_pl_module_from_checkpoint: the run directory's first `*config.yaml` (loaded as
+    a whole and resolved, so `${latent_plan_dim}`-style interpolations arrive as values) + `last.ckpt` or the
+    checkpoint of epoch N.  The checkpoint is read with weights_only=True (a state_dict needs nothing else);
+    unsafe_pickle=True opts into a full unpickle for checkpoints that carry arbitrary objects."""
+    from ..common import find_checkpoint, load_resolved_yaml
 
     d = Path(play_lmp_dir).expanduser()
     if d.is_file():
+        if d.suffix != ".ckpt":
+            raise ValueError("File must have .ckpt extension")
         ckpt, d = d, d.parent
+    elif d.is_dir():
+        ckpt = find_checkpoint(d, epoch)
     else:
-        cks = list(d.rglob("*.ckpt"))
-        if not cks:
-            raise FileNotFoundError(f"no .ckpt under {d}")
-        ckpt = next((c for c in cks if c.stem == "last"), None) if epoch == -1 else None
-        if ckpt is None:
-            ckpt = next((c for c in cks if f"epoch_{epoch}" in c.stem or f"epoch={epoch}" in c.stem), cks[-1])
+        raise ValueError(f"not valid file path: {d}")
     cfgs = list(d.rglob("*config.yaml"))
     if not cfgs:
         raise FileNotFoundError(f"no *config.yaml under {d}")
-    cfg = yaml.safe_load(open(cfgs[0]))["module"]
+    cfg = load_resolved_yaml(cfgs[0])["module"]
     cfg = {k: v for k, v in cfg.items() if k not in ("_target_", "_recursive_")}
     cfg.update(overwrite_cfg or {})
     cfg.setdefault("real_world", True)
     mod = PlayLMP(device=device, compute_dtype=compute_dtype, image_dtype=image_dtype, **cfg)
-    sd = torch.load(ckpt, map_location="cpu", weights_only=False)
+    try:
+        sd = torch.load(ckpt, map_location="cpu", weights_only=True)
+    except Exception:
+        if not unsafe_pickle:
+            raise
+        sd = torch.load(ckpt, map_location="cpu", weights_only=False)
     mod.load_state_dict(sd.get("state_dict", sd))
     return mod
 
@@ -159,6 +181,9 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
 
     states = batch["states"]
     cams, net, pr, ad = self.plan_proposal_obs_modalities, self.net, self.pr, self.ad
+    opts = getattr(self, "_optimizers", None)
+    if opts and opts[0].lr != self.lr:  # lr edited on the optimiser (scheduler): a launch argument -> new captures
+        self.lr, self._graphs = opts[0].lr, {}
     B, T = next(iter(states.values())).shape[:2]
     u8 = next(iter(states.values())).dtype == torch.uint8  # the dataset's uint8 HWC frames: normalised by the pack
     if u8:
@@ -306,7 +331,24 @@ def _named_gradients(self):
     return out
 
 
-PlayLMP.training_step = lambda self, batch, batch_idx=0, noise=None: _playlmp_step(self, batch, noise, True, "train")
-PlayLMP.validation_step = lambda self, batch, batch_idx=0, noise=None: _playlmp_step(self, batch, noise, False, "validation")
+def _training_step(self, batch, batch_idx=0, noise=None):
+    """reference :307-317 (returns the total loss; the optimiser step has already run - manual optimisation)."""
+    return _playlmp_step(self, batch, noise, True, "train")
+
+
+def _validation_step(self, batch, batch_idx=0, noise=None):
+    return _playlmp_step(self, batch, noise, False, "validation")
+
+
+def _configure_optimizers(self):
+    """reference :362-368: ONE Adam over every parameter.  A BlockAdam spanning the three flat blocks."""
+    ent = [(blk, self._pv[k], blk.views_of(blk.m), blk.views_of(blk.v))
+           for k, blk in (("net", self.net), ("pr", self.pr.blk), ("ad", self.ad.blk))]
+    self._optimizers = [self._make_adam("adam", ent, self.lr)]
+    return self._optimizers[0]
+
+
+PlayLMP.training_step = _training_step
+PlayLMP.validation_step = _validation_step
 PlayLMP.named_gradients = _named_gradients
-PlayLMP.configure_optimizers = lambda self: [self.net, self.pr.blk, self.ad.blk]
+PlayLMP.configure_optimizers = _configure_optimizers

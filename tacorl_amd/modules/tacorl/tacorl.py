@@ -13,7 +13,7 @@ import torch.nn as nn
 from ... import ops
 from ..._lib import BF16, F32, call, ptr
 from ..common import register_views
-from ..cql.cql_offline_lightning import CQL_Offline, _OptimizerHandle
+from ..cql.cql_offline_lightning import CQL_Offline
 
 
 class TACORL(CQL_Offline):
@@ -43,6 +43,10 @@ class TACORL(CQL_Offline):
             lmp = load_play_lmp(self.play_lmp_dir, self.lmp_epoch_to_load, self.overwrite_lmp_cfg, device=self.dev,
                                 compute_dtype=self.compute, image_dtype=self.img_dtype)
         assert isinstance(lmp, PlayLMP)
+        from .. import cfgcheck
+
+        cfgcheck.check_critic(self.critic_cfg, "critic")  # layers / hidden mirror the actor's (tacorl.py:72-73)
+        cfgcheck.check_representation(self.critic_encoder_cfg, "critic_encoder", lmp.plan_proposal_obs_modalities)
         self.action_decoder_modalities = list(lmp.action_decoder_modalities)
         self.plan_recognition_modalities = list(lmp.plan_recognition_modalities)
         self.all_modalities = sorted(set(self.action_decoder_modalities + self.plan_recognition_modalities))
@@ -70,7 +74,7 @@ class TACORL(CQL_Offline):
         register_views(self, "perceptual_encoder.", enc_views, requires_grad=False)
         register_views(self, "plan_recognition.", lmp.pr.blk.views, requires_grad=False)
         if self.ad is not None:
-            register_views(self, "action_decoder.", self.ad.blk.views)
+            self._pv["action_decoder"] = register_views(self, "action_decoder.", self.ad.blk.views)
             for k, v in self.ad.buffers.items():
                 self.action_decoder.register_buffer(k, v)
         self._T = None
@@ -275,6 +279,8 @@ class TACORL(CQL_Offline):
 
     def configure_optimizers(self):
         o = super().configure_optimizers()
-        if self.finetune_action_decoder and self.ad is not None:
-            o.append(_OptimizerHandle("action_decoder", self.ad.blk, self.action_decoder_lr))
+        if self.finetune_action_decoder and self.ad is not None:  # reference tacorl.py:289-300
+            blk = self.ad.blk
+            o.append(self._make_adam("action_decoder", [(blk, self._pv["action_decoder"], blk.views_of(blk.m),
+                                                         blk.views_of(blk.v))], self.action_decoder_lr))
         return o

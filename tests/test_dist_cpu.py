@@ -64,3 +64,26 @@ def test_sharded_gradients_equal_full_batch():
     for p in procs:
         p.join(timeout=60)
     assert err < 5e-5, err
+
+
+def test_bench_self_launcher_rendezvous():
+    """bench.py's own launcher (python bench.py --gpus 2, no torch.distributed.run): two child ranks rendezvous on
+    127.0.0.1 and all-reduce once through gloo on host tensors.  `--launch-check` stops before any GPU work, so
+    this runs here; the full 2-rank step through the same launcher is tests/test_dist_gpu.py."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["TACORL_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res == {"launch_check": True, "world": 2, "sum": 3.0}
+    # a rank that fails takes the launch down with a non-zero exit code instead of hanging the others
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=dict(env, TACORL_DIST_BACKEND="no-such-backend"), cwd=root, capture_output=True, text=True,
+                         timeout=300)
+    assert bad.returncode != 0

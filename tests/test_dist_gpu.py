@@ -25,3 +25,19 @@ def test_two_ranks_stay_in_sync():
     assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2"
     assert res["config"]["losses_finite"] is True
     assert res["config"]["replicas_in_sync"] is True
+
+
+def test_bench_self_launcher_two_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts its own rank processes
+    (the command the driver's scaling run would use if it were not under torch.distributed.run), reports the
+    weak-scaling value and the strong-scaling block, noise differs per rank, replicas stay in sync."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TACORL_DIST_BACKEND="gloo", TACORL_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "64",
+           "--no-cpu-baseline", "--no-distribution"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["replicas_in_sync"] is True
+    st = res["strong"]
+    assert st["per_gpu_batch"] == 32 and st["global_batch"] == 64 and st["value"] > 0 and st["replicas_in_sync"] is True
