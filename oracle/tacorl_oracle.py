@@ -16,6 +16,12 @@ Conventions
   ((24+12n)B + 16B encoder images per TACORL step) - used for the CPU-baseline
   timing; ``faithful=False`` encodes each unique (encoder, image set) once.
   Both give the same numbers.
+* ``operand_rounding(torch.bfloat16)`` (context manager) evaluates the SAME algorithm with the operand
+  rounding of the GPU's bf16 MFMA mode: both operands of every Linear / Conv2d contraction - forward,
+  input-gradient and weight-gradient - are rounded to bf16, accumulation and everything else stay fp32
+  (master weights, activations, reductions, transcendental functions).  That is the yardstick for the bf16
+  kernels (tests hold them to it far tighter than to the fp32 reference); without the context the oracle is
+  the exact fp32 restatement that the goldens pin.
 """
 import math
 
@@ -25,6 +31,71 @@ import torch.nn.functional as F
 LOG_SIG_MAX, LOG_SIG_MIN = 2.0, -5.0  # reference networks/actor_critic/actor.py:12-15
 MEAN_MIN, MEAN_MAX = -9.0, 9.0
 LOG2 = math.log(2.0)
+
+
+# ------------------------------------------------------------- contractions (exact / bf16 operands)
+_OPERAND_DTYPE = None
+
+
+class operand_rounding:
+    """with operand_rounding(torch.bfloat16): ... - see the module docstring."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _OPERAND_DTYPE
+        self.prev, _OPERAND_DTYPE = _OPERAND_DTYPE, self.dtype
+
+    def __exit__(self, *exc):
+        global _OPERAND_DTYPE
+        _OPERAND_DTYPE = self.prev
+        return False
+
+
+def _r(t):
+    return t.to(_OPERAND_DTYPE).to(torch.float32)
+
+
+class _RoundedLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xr, wr = _r(x), _r(w)
+        ctx.save_for_backward(xr, wr)
+        ctx.has_b = b is not None
+        return F.linear(xr, wr, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        dyr = _r(dy)
+        d2, x2 = dyr.reshape(-1, dyr.shape[-1]), xr.reshape(-1, xr.shape[-1])
+        return dyr @ wr, d2.t() @ x2, (d2.sum(0) if ctx.has_b else None)
+
+
+class _RoundedConv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride):
+        xr, wr = _r(x), _r(w)
+        ctx.save_for_backward(xr, wr)
+        ctx.stride, ctx.has_b = stride, b is not None
+        return F.conv2d(xr, wr, b, stride=stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        dyr = _r(dy)
+        dx = torch.nn.grad.conv2d_input(xr.shape, wr, dyr, stride=ctx.stride)
+        dw = torch.nn.grad.conv2d_weight(xr, wr.shape, dyr, stride=ctx.stride)
+        return dx, dw, (dyr.sum(dim=(0, 2, 3)) if ctx.has_b else None), None
+
+
+def _linear(x, w, b=None):
+    return F.linear(x, w, b) if _OPERAND_DTYPE is None else _RoundedLinear.apply(x, w, b)
+
+
+def _conv2d(x, w, b=None, stride=1):
+    return F.conv2d(x, w, b, stride=stride) if _OPERAND_DTYPE is None else _RoundedConv2d.apply(x, w, b, stride)
 
 
 # ----------------------------------------------------------------------------- A1/A2
@@ -43,12 +114,12 @@ def spatial_softargmax(x, temperature):
 def encoder_fwd(P, pre, img):
     """LMPVisionEncoder.forward, reference networks/visual_encoders/encoder.py:369-419.
     img (N,3,H,W) -> (N,32)."""
-    x = F.relu(F.conv2d(img, P[pre + "model.0.weight"], P[pre + "model.0.bias"], stride=4))
-    x = F.relu(F.conv2d(x, P[pre + "model.2.weight"], P[pre + "model.2.bias"], stride=2))
-    x = F.relu(F.conv2d(x, P[pre + "model.4.weight"], P[pre + "model.4.bias"], stride=1))
+    x = F.relu(_conv2d(img, P[pre + "model.0.weight"], P[pre + "model.0.bias"], stride=4))
+    x = F.relu(_conv2d(x, P[pre + "model.2.weight"], P[pre + "model.2.bias"], stride=2))
+    x = F.relu(_conv2d(x, P[pre + "model.4.weight"], P[pre + "model.4.bias"], stride=1))
     x = spatial_softargmax(x, P[pre + "model.6.temperature"])
-    x = F.relu(F.linear(x, P[pre + "fc_layers.0.weight"], P[pre + "fc_layers.0.bias"]))
-    return F.linear(x, P[pre + "fc_layers.3.weight"], P[pre + "fc_layers.3.bias"])
+    x = F.relu(_linear(x, P[pre + "fc_layers.0.weight"], P[pre + "fc_layers.0.bias"]))
+    return _linear(x, P[pre + "fc_layers.3.weight"], P[pre + "fc_layers.3.bias"])
 
 
 def late_fusion(P, pre, obs, cams):
@@ -60,9 +131,9 @@ def late_fusion(P, pre, obs, cams):
 # -------------------------------------------------------------------------------- A3
 def goal_encoder(P, pre, x):
     """VisualGoalEncoder.forward, reference visual_encoders/goal_encoder.py:17-33."""
-    x = F.relu(F.linear(x, P[pre + "mlp.0.weight"], P[pre + "mlp.0.bias"]))
-    x = F.relu(F.linear(x, P[pre + "mlp.2.weight"], P[pre + "mlp.2.bias"]))
-    return F.linear(x, P[pre + "mlp.4.weight"], P[pre + "mlp.4.bias"])
+    x = F.relu(_linear(x, P[pre + "mlp.0.weight"], P[pre + "mlp.0.bias"]))
+    x = F.relu(_linear(x, P[pre + "mlp.2.weight"], P[pre + "mlp.2.bias"]))
+    return _linear(x, P[pre + "mlp.4.weight"], P[pre + "mlp.4.bias"])
 
 
 # -------------------------------------------------------------------------------- A6
@@ -70,12 +141,12 @@ def policy(P, pre, s, n_layers=3, discrete_gripper=False):
     """MLPPolicy.forward, reference actor_critic/actor.py:252-270."""
     x = s
     for i in range(n_layers):
-        x = F.silu(F.linear(x, P[f"{pre}fc_layers.{i}.weight"], P[f"{pre}fc_layers.{i}.bias"]))
-    mean = torch.clamp(F.linear(x, P[pre + "fc_mean.weight"], P[pre + "fc_mean.bias"]), MEAN_MIN, MEAN_MAX)
-    log_std = torch.clamp(F.linear(x, P[pre + "fc_log_std.weight"], P[pre + "fc_log_std.bias"]),
+        x = F.silu(_linear(x, P[f"{pre}fc_layers.{i}.weight"], P[f"{pre}fc_layers.{i}.bias"]))
+    mean = torch.clamp(_linear(x, P[pre + "fc_mean.weight"], P[pre + "fc_mean.bias"]), MEAN_MIN, MEAN_MAX)
+    log_std = torch.clamp(_linear(x, P[pre + "fc_log_std.weight"], P[pre + "fc_log_std.bias"]),
                           LOG_SIG_MIN, LOG_SIG_MAX)
     if discrete_gripper:
-        logits = F.linear(x, P[pre + "gripper_action.weight"], P[pre + "gripper_action.bias"])
+        logits = _linear(x, P[pre + "gripper_action.weight"], P[pre + "gripper_action.bias"])
         return mean, log_std.exp(), logits
     return mean, log_std.exp()
 
@@ -85,8 +156,8 @@ def qnet(P, pre, s, a, n_layers=3):
     """Critic.forward + MLPQNetwork.forward, reference actor_critic/critic.py:24-30,92-97."""
     x = torch.cat([s, a], dim=-1)
     for i in range(n_layers):
-        x = F.silu(F.linear(x, P[f"{pre}fc_layers.{i}.weight"], P[f"{pre}fc_layers.{i}.bias"]))
-    return F.linear(x, P[pre + "out.weight"], P[pre + "out.bias"])
+        x = F.silu(_linear(x, P[f"{pre}fc_layers.{i}.weight"], P[f"{pre}fc_layers.{i}.bias"]))
+    return _linear(x, P[pre + "out.weight"], P[pre + "out.bias"])
 
 
 # -------------------------------------------------------------------------------- A7
@@ -152,20 +223,20 @@ def plan_recognition(P, pre, emb, n_heads=8, n_layers=2, min_std=1e-4):
     hd = D // n_heads
     for l in range(n_layers):
         lp = f"{pre}transformer_encoder.layers.{l}."
-        qkv = F.linear(x, P[lp + "self_attn.in_proj_weight"], P[lp + "self_attn.in_proj_bias"])
+        qkv = _linear(x, P[lp + "self_attn.in_proj_weight"], P[lp + "self_attn.in_proj_bias"])
         q, k, v = qkv.split(D, dim=-1)
         sh = lambda t: t.reshape(B, T, n_heads, hd).permute(0, 2, 1, 3)  # noqa: E731
         q, k, v = sh(q), sh(k), sh(v)
         att = torch.softmax((q / math.sqrt(hd)) @ k.transpose(-1, -2), dim=-1)
         o = (att @ v).permute(0, 2, 1, 3).reshape(B, T, D)
-        o = F.linear(o, P[lp + "self_attn.out_proj.weight"], P[lp + "self_attn.out_proj.bias"])
+        o = _linear(o, P[lp + "self_attn.out_proj.weight"], P[lp + "self_attn.out_proj.bias"])
         x = _layer_norm(x + o, P[lp + "norm1.weight"], P[lp + "norm1.bias"])
-        f = F.linear(F.relu(F.linear(x, P[lp + "linear1.weight"], P[lp + "linear1.bias"])),
+        f = _linear(F.relu(_linear(x, P[lp + "linear1.weight"], P[lp + "linear1.bias"])),
                      P[lp + "linear2.weight"], P[lp + "linear2.bias"])
         x = _layer_norm(x + f, P[lp + "norm2.weight"], P[lp + "norm2.bias"])
-    x = F.linear(x, P[pre + "fc.weight"], P[pre + "fc.bias"]).mean(dim=1)
-    mean = F.linear(x, P[pre + "mean_fc.weight"], P[pre + "mean_fc.bias"])
-    std = F.softplus(F.linear(x, P[pre + "variance_fc.weight"], P[pre + "variance_fc.bias"])) + min_std
+    x = _linear(x, P[pre + "fc.weight"], P[pre + "fc.bias"]).mean(dim=1)
+    mean = _linear(x, P[pre + "mean_fc.weight"], P[pre + "mean_fc.bias"])
+    std = F.softplus(_linear(x, P[pre + "variance_fc.weight"], P[pre + "variance_fc.bias"])) + min_std
     return mean, std
 
 
@@ -179,17 +250,17 @@ def action_decoder_fwd(P, pre, plan, emb, n_mix=10, n_layers=2):
         wi, wh = P[f"{pre}rnn.weight_ih_l{l}"], P[f"{pre}rnn.weight_hh_l{l}"]
         bi, bh = P[f"{pre}rnn.bias_ih_l{l}"], P[f"{pre}rnn.bias_hh_l{l}"]
         h = torch.zeros(B, wh.shape[0], dtype=emb.dtype)
-        xin = F.linear(x, wi, bi)
+        xin = _linear(x, wi, bi)
         outs = []
         for t in range(T):
-            h = F.relu(xin[:, t] + F.linear(h, wh, bh))
+            h = F.relu(xin[:, t] + _linear(h, wh, bh))
             outs.append(h)
         x = torch.stack(outs, dim=1)
-    probs = F.linear(x, P[pre + "prob_fc.weight"], P[pre + "prob_fc.bias"])
-    means = F.linear(x, P[pre + "mean_fc.weight"], P[pre + "mean_fc.bias"])
-    log_scales = torch.clamp(F.linear(x, P[pre + "log_scale_fc.weight"], P[pre + "log_scale_fc.bias"]),
+    probs = _linear(x, P[pre + "prob_fc.weight"], P[pre + "prob_fc.bias"])
+    means = _linear(x, P[pre + "mean_fc.weight"], P[pre + "mean_fc.bias"])
+    log_scales = torch.clamp(_linear(x, P[pre + "log_scale_fc.weight"], P[pre + "log_scale_fc.bias"]),
                              min=LOG_SIG_MIN)
-    grip = F.linear(x, P[pre + "gripper_fc.weight"], P[pre + "gripper_fc.bias"])
+    grip = _linear(x, P[pre + "gripper_fc.weight"], P[pre + "gripper_fc.bias"])
     v = lambda t: t.reshape(B, T, -1, n_mix)  # noqa: E731
     return v(probs), v(log_scales), v(means), grip
 

@@ -193,6 +193,60 @@ def test_fullsize_cql_baseline_c5():
     assert not torch.equal(before, mod.engine.q1.param)
 
 
+def test_fullsize_cql_baseline_c5_f32_matches_oracle():
+    """BASELINE configs C5 at its stated size (CQL_Offline, discrete gripper, A=7, n=32 action samples in the
+    logsumexp, B=1024, 84x84) in exact-fp32 mode against the CPU oracle on the same parameters, batch and noise:
+    every logged loss within 1e-4 rel (north-star tolerance), gradients within 1e-3."""
+    from oracle import tacorl_oracle as O
+    from tacorl_amd import synth
+    from tacorl_amd.modules.cql.cql_offline_lightning import CQL_Offline
+
+    dev = torch.device("cuda:0")
+    Bc, n = 1024, 32
+    torch.manual_seed(3)
+    mod = CQL_Offline(actor={"policy": {"num_layers": 3, "hidden_dim": 256}, "discrete_gripper": True},
+                      critic={"q_network": {"num_layers": 3, "hidden_dim": 256, "last_layer_activation": "Identity"}},
+                      real_world=True, obs_modalities=["rgb_static"], goal_modalities=["rgb_static"], action_dim=7, device="cuda:0",
+                      compute_dtype="f32", image_dtype="f32", discount=0.99, actor_lr=1e-4, critic_lr=3e-4,
+                      conservative_weight=1.0, n_action_samples=n, with_lagrange=True, reward_scale=10.0,
+                      deterministic_backup=False, bc_epochs=5)
+    mod.current_epoch = 5
+    from tacorl_amd.init import init_views_
+    for blk in (mod.engine.actor, mod.engine.q1, mod.engine.q2):
+        init_views_(blk.views)
+    mod.sync_targets()
+    cams = ["rgb_static"]
+    spec = O.ACSpec(cams=cams, goal_cams=cams, action_dim=7, n=n, discount=0.99, actor_lr=1e-4, critic_lr=3e-4,
+                    deterministic_backup=False, reward_scale=10.0, bc_epochs=5, with_lagrange=True,
+                    discrete_gripper=True, target_entropy=-7.0)
+    P = {k: v.detach().cpu().clone().contiguous() for k, v in mod.state_dict().items()}
+    O.require_grad_(P)
+    opts = O.make_opts(P, spec)
+    batch = synth.make_transition_batch(7, Bc, {"rgb_static": (84, 84)})
+    mod.logged = {}
+    mod.training_step(_to_dev(batch, dev), 0)
+    torch.cuda.synchronize()
+    got = {k.split("/", 1)[1]: float(v) for k, v in mod.logged.items()}
+    nz = {k: v.detach().cpu().clone() for k, v in mod.engine.noise.items()}
+    ologs, ograds = O.cql_step(P, opts, spec, batch, nz, 5)
+    bad = [f"{k}: hip {got[k]:.8g} oracle {float(v):.8g}" for k, v in ologs.items()
+           if k in got and abs(got[k] - float(v)) > 1e-4 * max(abs(float(v)), 1e-3)]
+    assert len(set(ologs) & set(got)) >= 8, (sorted(ologs), sorted(got))
+    grads = mod.named_gradients()
+    for k, g in ograds.items():
+        if k in grads and g is not None and g.norm() > 1e-6:
+            d = (grads[k].cpu().reshape(g.shape) - g).norm() / g.norm()
+            if d > 1e-3:
+                bad.append(f"grad {k}: relerr {d:.3g}")
+    assert not bad, "\n".join(bad[:30])
+
+
+def _to_dev(x, dev):
+    if isinstance(x, dict):
+        return {k: _to_dev(v, dev) for k, v in x.items()}
+    return x.to(dev) if torch.is_tensor(x) else x
+
+
 @pytest.mark.parametrize("compute", ["bf16", "f32"])
 def test_uint8_frames_equal_transformed_fp32_frames(compute):
     """the dataset's uint8 HWC frames handed to the step as they are (normalised on the GPU:

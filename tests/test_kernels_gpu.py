@@ -12,6 +12,11 @@ pytestmark = pytest.mark.gpu
 
 TOL_F32 = 1e-4
 TOL_BF16 = 3e-2  # bf16 operands (8-bit mantissa), fp32 accumulate
+# bf16 kernels vs the oracle evaluated with the same operand rounding (oracle.operand_rounding): what is left is
+# fp32 summation order, transcendental-function differences and the few places where a kernel rounds one step
+# earlier or later than "at the operand" (e.g. a bias gradient summed from unrounded dZ)
+FWD_BF16_ROUNDED = 2e-3
+GRAD_BF16_ROUNDED = 1e-2
 
 
 def _dev():
@@ -103,9 +108,11 @@ def test_encoder_fwd_bwd(compute, tol, H, W):
     for i, k in enumerate(n):
         P = {kk: v.clone().requires_grad_(True) for kk, v in _enc_params(20 + i).items()}
         img = rnd(k, 3, H, W, seed=30 + i)
-        out = O.encoder_fwd(P, "", img)
-        dout = rnd(k, 32, seed=40 + i)
-        (out * dout).sum().backward()
+        # bf16 mode is held to the oracle evaluated with the MFMA's operand rounding (bf16 operands, fp32 accumulate)
+        with O.operand_rounding(torch.bfloat16 if compute == 1 else None):
+            out = O.encoder_fwd(P, "", img)
+            dout = rnd(k, 32, seed=40 + i)
+            (out * dout).sum().backward()
         flat = torch.zeros(blocks.encoder_size(), device=dev)
         blocks.load_named(blocks.encoder_views(flat), {kk: v.detach() for kk, v in P.items()})
         flats.append(flat)
@@ -118,19 +125,13 @@ def test_encoder_fwd_bwd(compute, tol, H, W):
     ops.encoder_fwd(imgs_d, flats, outs, acts, H, W, compute)
     ops.encoder_bwd(imgs_d, flats, acts, douts, grads, H, W, compute)
     torch.cuda.synchronize()
+    ftol, gtol = (tol, tol) if compute == 0 else (FWD_BF16_ROUNDED, GRAD_BF16_ROUNDED)
     for i in range(len(n)):
-        assert relerr(outs[i], refs[i][0]) < tol, "forward"
+        assert relerr(outs[i], refs[i][0]) < ftol, ("forward", relerr(outs[i], refs[i][0]))
         gv = blocks.encoder_views(grads[i])
         for name, g in refs[i][1].items():
             e = relerr(gv[name], g)
-            if compute == 0:
-                assert e < tol, (name, e)
-            else:
-                # bf16 operands through 5 chained layers + the soft-argmax's (dp - <p,dp>) cancellation:
-                # direction must agree (cosine), magnitude within 20 %
-                a, b = gv[name].reshape(-1).double().cpu(), g.reshape(-1).double()
-                cos = (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
-                assert cos > 0.99 and e < (0.35 if name.endswith("temperature") else 0.2), (name, e, cos)
+            assert e < gtol, (name, e)
 
 
 @pytest.mark.parametrize("compute,tol", [(0, TOL_F32), (1, TOL_BF16)])
@@ -314,11 +315,13 @@ def test_encoder_fused_forward(H, W):
     dev = _dev()
     assert _lib.lib().tacorl_encoder_fused_supported(H, W) == 1
     n = [19, 8, 1]
-    flats, imgs, outs_f, outs_g, acts, packed, refs = [], [], [], [], [], [], []
+    flats, imgs, outs_f, outs_g, acts, packed, refs, refs_r = [], [], [], [], [], [], [], []
     for i, k in enumerate(n):
         P = _enc_params(70 + i)
         img = rnd(k, 3, H, W, seed=80 + i)
         refs.append(O.encoder_fwd(P, "", img.to(torch.bfloat16).float()))
+        with O.operand_rounding(torch.bfloat16):
+            refs_r.append(O.encoder_fwd(P, "", img))
         flat = torch.zeros(blocks.encoder_size(), device=dev)
         blocks.load_named(blocks.encoder_views(flat), P)
         flats.append(flat)
@@ -337,6 +340,8 @@ def test_encoder_fused_forward(H, W):
         assert torch.isfinite(outs_f[i]).all()
         assert relerr(outs_f[i], outs_g[i]) < 1e-2, ("vs generic bf16", relerr(outs_f[i], outs_g[i]))
         assert relerr(outs_f[i], refs[i]) < TOL_BF16, ("vs oracle", relerr(outs_f[i], refs[i]))
+        e = relerr(outs_f[i], refs_r[i])
+        assert e < FWD_BF16_ROUNDED, ("vs oracle with bf16 operand rounding", e)
     for i in (0, 2):  # saved activations (what tacorl_encoder_bwd reads) equal the per-layer path's
         offs, tot = ops.encoder_act_layout(n[i], H, W)
         for j, name in enumerate(["y1", "y2", "y3", "softargmax", "fc1"]):
@@ -351,7 +356,7 @@ def test_encoder_fused_forward(H, W):
 def test_encoder_fused_backward(H, W, accumulate):
     """Per-image LDS-resident conv backward (tacorl_encoder_bwd_fused) vs the generic bf16 path on the
     same saved activations (same bf16 operand rounding, different fp32 summation order only), and vs
-    fp32 autograd of the oracle (bf16 tolerance: cosine)."""
+    autograd of the oracle evaluated with the MFMA's operand rounding (relative error, not cosine)."""
     from oracle import tacorl_oracle as O
     from tacorl_amd import _lib, blocks, ops
 
@@ -362,9 +367,9 @@ def test_encoder_fused_backward(H, W, accumulate):
     for i, k in enumerate(n):
         P = {kk: v.clone().requires_grad_(True) for kk, v in _enc_params(120 + i).items()}
         img = rnd(k, 3, H, W, seed=130 + i).to(torch.bfloat16).float()
-        out = O.encoder_fwd(P, "", img)
         dout = rnd(k, 32, seed=140 + i)
-        (out * dout).sum().backward()
+        with O.operand_rounding(torch.bfloat16):  # same algorithm, the MFMA's operand rounding
+            (O.encoder_fwd(P, "", img) * dout).sum().backward()
         flat = torch.zeros(blocks.encoder_size(), device=dev)
         blocks.load_named(blocks.encoder_views(flat), {kk: v.detach() for kk, v in P.items()})
         flats.append(flat)
@@ -386,11 +391,8 @@ def test_encoder_fused_backward(H, W, accumulate):
             assert torch.isfinite(vf[name]).all(), name
             e = relerr(vf[name] - (0.25 if accumulate else 0.0), vg[name] - (0.25 if accumulate else 0.0))
             assert e < 2e-3, ("vs generic bf16", name, e)
-            a, b = (vf[name] - (0.25 if accumulate else 0.0)).reshape(-1).double().cpu(), g.reshape(-1).double()
-            cos = (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
-            c = (vg[name] - (0.25 if accumulate else 0.0)).reshape(-1).double().cpu()
-            cos_gen = (c @ b / (c.norm() * b.norm()).clamp_min(1e-30)).item()
-            assert cos > 0.97 and cos > cos_gen - 0.005, ("vs fp32 autograd", name, cos, cos_gen)
+            e = relerr(vf[name] - (0.25 if accumulate else 0.0), g)
+            assert e < GRAD_BF16_ROUNDED, ("vs oracle autograd with bf16 operand rounding", name, e)
 
 
 @pytest.mark.parametrize("dims,acts", [([64, 256, 256, 256, 32], [2, 2, 2, 0]), ([80, 256, 256, 256, 1], [2, 2, 2, 0]),
@@ -398,17 +400,19 @@ def test_encoder_fused_backward(H, W, accumulate):
 def test_mlp_fused_forward(dims, acts):
     """Single-launch MLP forward vs the per-layer bf16 path (same operand rounding) - outputs and every
     saved activation - and vs fp32 torch at bf16 tolerance; ragged row counts, several problems."""
+    from oracle import tacorl_oracle as O
     from tacorl_amd import _lib, blocks, ops
 
     dev = _dev()
     Ms = [70, 9, 300]
     L = len(dims) - 1
     assert _lib.lib().tacorl_mlp_fwd_fused_supported(len(Ms), L, ops.int_array(dims), dims[0]) == 1
-    xs, flats, fb, a_f, a_g, refs = [], [], [], [], [], []
+    xs, flats, fb, a_f, a_g, refs, refs_r = [], [], [], [], [], [], []
     for i, M in enumerate(Ms):
         flat = torch.zeros(blocks.mlp_size(dims), device=dev)
         v = blocks.mlp_views(flat, 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
         h = rnd(M, dims[0], seed=170 + i)
+        hr = h
         xs.append(h.to(dev).contiguous())
         for l in range(L):
             W = rnd(dims[l + 1], dims[l], seed=150 + i + l, scale=1 / math.sqrt(dims[l]))
@@ -416,7 +420,11 @@ def test_mlp_fused_forward(dims, acts):
             v[f"l{l}.w"].copy_(W); v[f"l{l}.b"].copy_(b)
             h = F.linear(h, W, b)
             h = [h, F.relu(h), F.silu(h)][acts[l]]
+            with O.operand_rounding(torch.bfloat16):
+                hr = O._linear(hr, W, b)
+            hr = [hr, F.relu(hr), F.silu(hr)][acts[l]]
         refs.append(h)
+        refs_r.append(hr)
         flats.append(flat)
         fb.append(flat.to(torch.bfloat16))
         n_act = ops.mlp_act_layout(M, dims, acts)[2]
@@ -431,6 +439,7 @@ def test_mlp_fused_forward(dims, acts):
         yo = ops.mlp_act_layout(M, dims, acts)[1][-1]
         y = a_f[i][yo: yo + M * dims[-1]].view(M, dims[-1])
         assert relerr(y, refs[i]) < TOL_BF16
+        assert relerr(y, refs_r[i]) < FWD_BF16_ROUNDED, ("vs torch with bf16 operand rounding", relerr(y, refs_r[i]))
 
 
 def test_mlp_fused_forward_ragged_input_width():
@@ -497,12 +506,32 @@ def test_mlp_fused_backward(dims, acts, want_dx):
     g_fus[1] = None  # a problem without parameter gradients (the actor's pass through the Q networks)
     ops.mlp_bwd_fused_wgrad(xs, ld, actb, douts, dims[-1], g_fus, Ms, dims, acts, "t_mlp_fused")
     torch.cuda.synchronize()
+    from oracle import tacorl_oracle as O
+
     for i in range(len(Ms)):
         if want_dx:
             assert relerr(dx_fus[i], dx_ref[i]) < 3e-3, ("dx", i, relerr(dx_fus[i], dx_ref[i]))
         if g_fus[i] is not None:
             assert torch.isfinite(g_fus[i]).all()
             assert relerr(g_fus[i], g_ref[i]) < 3e-3, ("grads", i, relerr(g_fus[i], g_ref[i]))
+        # ... and not only against the repo's own per-layer path: torch autograd with the MFMA's operand rounding
+        v = blocks.mlp_views(flats[i], 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+        Pw = {k: t.detach().cpu().clone().requires_grad_(True) for k, t in v.items()}
+        x0 = xs[i][:, :dims[0]].cpu().clone().requires_grad_(True)
+        h = x0
+        with O.operand_rounding(torch.bfloat16):
+            for l in range(L):
+                h = O._linear(h, Pw[f"l{l}.w"], Pw[f"l{l}.b"])
+                h = [h, F.relu(h), F.silu(h)][acts[l]]
+            (h * douts[i].cpu()).sum().backward()
+        if want_dx:
+            e = relerr(dx_fus[i][:, :dims[0]], x0.grad)
+            assert e < GRAD_BF16_ROUNDED, ("dx vs rounded autograd", i, e)
+        if g_fus[i] is not None:
+            gv = blocks.mlp_views(g_fus[i], 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+            for k, t in Pw.items():
+                e = relerr(gv[k], t.grad)
+                assert e < GRAD_BF16_ROUNDED, ("grad vs rounded autograd", i, k, e)
 
 
 @pytest.mark.parametrize("M,K,N,act", [(256, 2048, 2048, 1), (100, 256, 64, 0), (3840, 2048, 2048, 0), (64, 128, 32, 1)])
@@ -676,6 +705,14 @@ def test_plan_recognition_fused_encoder():
         ff = F.relu(x @ P[p + "linear1.weight"].t() + P[p + "linear1.bias"]) @ P[p + "linear2.weight"].t() + P[p + "linear2.bias"]
         x = F.layer_norm(x + ff, (D,), P[p + "norm2.weight"], P[p + "norm2.bias"])
     assert relerr(pr.pooled, x.mean(1)) < TOL_BF16, relerr(pr.pooled, x.mean(1))
+    # the oracle's plan recognition with the MFMA's operand rounding: posterior mean and std of the fused launch
+    from oracle import tacorl_oracle as O
+
+    with O.operand_rounding(torch.bfloat16):
+        mu, std = O.plan_recognition(P, "", emb.cpu().view(B, T, D), min_std=pr.min_std)
+    e_mu = relerr(h_fus[:, :A], mu)
+    e_sd = relerr(F.softplus(h_fus[:, A:]) + pr.min_std, std)
+    assert e_mu < 5e-3 and e_sd < 5e-3, ("posterior vs oracle with bf16 operand rounding", e_mu, e_sd)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.int64, torch.int32, torch.uint8, torch.bool])

@@ -21,7 +21,7 @@ def _check_logs(got, exp, rtol=RTOL):
     return bad
 
 
-@pytest.mark.parametrize("name", ["tacorl_q", "tacorl_bc_ad", "tacorl_dualcam"])
+@pytest.mark.parametrize("name", ["tacorl_q", "tacorl_bc_ad", "tacorl_dualcam", "tacorl_c4", "tacorl_q_ad"])
 @pytest.mark.parametrize("faithful", [False, True])
 def test_tacorl_step_matches_reference(name, faithful):
     if faithful and name != "tacorl_q":
@@ -42,7 +42,7 @@ def test_tacorl_step_matches_reference(name, faithful):
         assert not bad, "\n".join(bad[:20])
 
 
-@pytest.mark.parametrize("name", ["cql_q", "cql_bc"])
+@pytest.mark.parametrize("name", ["cql_q", "cql_bc", "cql_n32"])
 def test_cql_step_matches_reference(name):
     g = Golden(name)
     spec = spec_for(g)

@@ -53,7 +53,7 @@ def compare_with_oracle_grads(mod, oracle_grads, rtol):
     return bad
 
 
-@pytest.mark.parametrize("name", ["cql_q", "cql_bc"])
+@pytest.mark.parametrize("name", ["cql_q", "cql_bc", "cql_n32"])
 def test_cql_offline_step(name):
     from oracle import tacorl_oracle as O
     from tacorl_amd.modules.cql.cql_offline_lightning import CQL_Offline
@@ -104,7 +104,7 @@ def build_tacorl(g, compute="f32", **over):
                   device="cuda:0", compute_dtype=compute, image_dtype=compute, **kw)
 
 
-@pytest.mark.parametrize("name", ["tacorl_q", "tacorl_dualcam", "tacorl_bc_ad"])
+@pytest.mark.parametrize("name", ["tacorl_q", "tacorl_dualcam", "tacorl_bc_ad", "tacorl_c4", "tacorl_q_ad"])
 def test_tacorl_step(name):
     from oracle import tacorl_oracle as O
 
@@ -289,3 +289,113 @@ def test_tacorl_step_bf16_mode(name):
     if e > 2e-2:
         bad.append(f"latent plan relerr {e:.3g}")
     assert not bad, "\n".join(bad)
+
+
+# ---------------------------------------------------------------------------------------------- bf16 mode
+# The benchmark's compute mode (bf16 MFMA operands, fp32 accumulate / master weights, every fused fast path) cannot
+# meet 1e-4 against the fp32 reference (8-bit mantissa).  It is held instead to the oracle evaluated with the SAME
+# operand rounding (oracle.operand_rounding(bf16): both operands of every Linear / Conv contraction rounded to bf16 in
+# forward, input-gradient and weight-gradient; everything else fp32): losses and latent plans 2e-3, every gradient
+# 1e-2 relative (norm-wise), post-step parameters like the f32 tests (+ a few % of one Adam update) - over TWO
+# optimiser steps, for the configurations BASELINE names (C2 tacorl_q, C3 tacorl_q_ad, C4 tacorl_c4, C5 cql_n32, C1 playlmp).
+BF16_LOG_RTOL, BF16_PLAN_RTOL, BF16_GRAD_RTOL, BF16_PARAM_ATOL = 2e-3, 2e-3, 1e-2, 3e-5
+
+
+def _bf16_compare(mod, got, ologs, ograds, P, step, plan=None, oplan=None, skip_logs=()):
+    bad = []
+    for k, v in ologs.items():
+        if k in got and k not in skip_logs and abs(got[k] - float(v)) > BF16_LOG_RTOL * max(abs(float(v)), 1e-2):
+            bad.append(f"{k}: {got[k]:.7g} vs rounded oracle {float(v):.7g}")
+    if plan is not None:
+        e = relerr(plan, oplan)
+        if e > BF16_PLAN_RTOL:
+            bad.append(f"latent plan relerr {e:.3g}")
+    bad += compare_with_oracle_grads(mod, ograds, BF16_GRAD_RTOL)
+    sd = mod.state_dict()
+    for k, v in P.items():
+        if k in sd and sd[k].dtype == torch.float32:
+            d = (sd[k].detach().cpu().double() - v.detach().double()).abs().max().item()
+            if d > BF16_PARAM_ATOL + 1e-4 * v.detach().abs().max().item():
+                bad.append(f"param {k}: max|d| {d:.3g}")
+    return [f"step {step}: {b}" for b in bad]
+
+
+@pytest.mark.parametrize("name", ["tacorl_q", "tacorl_q_ad", "tacorl_c4", "tacorl_bc_ad"])
+def test_tacorl_step_bf16_vs_rounded_oracle(name):
+    from oracle import tacorl_oracle as O
+
+    g = Golden(name)
+    mod = build_tacorl(g, compute="bf16")
+    mod.load_state_dict(g.params(), strict=False)
+    mod.current_epoch = g.cfg["epoch"]
+    spec = spec_for(g)
+    P = O.require_grad_(g.params(), frozen_prefixes=("perceptual_encoder.", "plan_recognition."))
+    opts = O.make_opts(P, spec)
+    bad = []
+    for step in range(g.cfg["steps"]):
+        batch, noise = g.batch(step), g.noise(step)
+        mod.logged = {}
+        mod.training_step(to_dev(batch, mod.device), noise=to_dev(noise, mod.device))
+        torch.cuda.synchronize()
+        got = {k.split("/", 1)[1]: v for k, v in mod.logged.items()}
+        with O.operand_rounding(torch.bfloat16):
+            ologs, oplan, ograds = O.tacorl_step(P, opts, spec, batch, noise, g.cfg["epoch"])
+        bad += _bf16_compare(mod, got, ologs, ograds, P, step, mod.plan, oplan)
+    assert not bad, "\n".join(bad[:30])
+
+
+def test_cql_step_bf16_vs_rounded_oracle():
+    from oracle import tacorl_oracle as O
+    from tacorl_amd.modules.cql.cql_offline_lightning import CQL_Offline
+
+    g = Golden("cql_n32")
+    cams = sorted(g.cams)
+    kw = dict(CQL_YAML)
+    kw.update(g.cfg.get("overrides", {}))
+    mod = CQL_Offline(actor=dict(ACTOR, discrete_gripper=True), critic=CRITIC, real_world=True, obs_modalities=cams,
+                      goal_modalities=cams, action_dim=7, device="cuda:0", compute_dtype="bf16", image_dtype="bf16", **kw)
+    mod.load_state_dict(g.params())
+    mod.current_epoch = g.cfg["epoch"]
+    spec = spec_for(g)
+    P = O.require_grad_(g.params())
+    opts = O.make_opts(P, spec)
+    bad = []
+    for step in range(g.cfg["steps"]):
+        batch, noise = g.batch(step), g.noise(step)
+        mod.logged = {}
+        mod.training_step(to_dev(batch, mod.device), 0, noise=to_dev(noise, mod.device))
+        torch.cuda.synchronize()
+        got = {k.split("/", 1)[1]: v for k, v in mod.logged.items()}
+        with O.operand_rounding(torch.bfloat16):
+            ologs, ograds = O.cql_step(P, opts, spec, batch, noise, g.cfg["epoch"])
+        bad += _bf16_compare(mod, got, ologs, ograds, P, step)
+    assert not bad, "\n".join(bad[:30])
+
+
+def test_playlmp_step_bf16_vs_rounded_oracle():
+    from oracle import tacorl_oracle as O
+    from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
+
+    g = Golden("playlmp")
+    cams, c = sorted(g.cams), g.cfg
+    pr = dict(num_heads=8, num_layers=2, encoder_hidden_size=2048, fc_hidden_size=4096, latent_plan_dim=c["latent"],
+              min_std=1e-4, dropout_p=0.0, max_position_embeddings=c["T"])
+    ad = dict(n_mixtures=10, num_layers=2, hidden_size=2048, out_features=7, num_classes=10,
+              latent_plan_dim=c["latent"], rnn_model="rnn_decoder", include_goal=False)
+    mod = PlayLMP(plan_proposal=ACTOR, plan_recognition=pr, action_decoder=ad, plan_proposal_obs_modalities=cams,
+                  plan_proposal_goal_modalities=cams, plan_recognition_modalities=cams, action_decoder_modalities=cams,
+                  real_world=True, lr=1e-4, kl_beta=1e-3, device="cuda:0", compute_dtype="bf16", image_dtype="bf16")
+    mod.load_state_dict(g.params(), strict=False)
+    P = O.require_grad_(g.params())
+    opt = O.Adam([n for n in P], 1e-4)
+    bad = []
+    for step in range(c["steps"]):
+        batch, nz = g.batch(step), g.noise(step)
+        mod.logged = {}
+        mod.training_step(to_dev(batch, mod.device), 0, noise=to_dev({k: nz[k] for k in ("eps_plan", "u_plan")}, mod.device))
+        torch.cuda.synchronize()
+        got = {k.split("/", 1)[1]: v for k, v in mod.logged.items()}
+        with O.operand_rounding(torch.bfloat16):
+            ologs, ograds = O.playlmp_step(P, opt, batch, nz, cams)
+        bad += _bf16_compare(mod, got, ologs, ograds, P, step)
+    assert not bad, "\n".join(bad[:30])
