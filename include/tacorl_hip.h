@@ -262,6 +262,16 @@ int tacorl_add_rows_bcast(const float* x, int ldx, const float* add, float* out,
                           int Dp, tacorl_stream_t stream);
 /* softmax(q k^T / sqrt(hd)) v per (batch, head); qkv [B*T][3D], out [B*T][D]; T <= 64, hd <= 16. */
 int tacorl_attention_fwd(const float* qkv, float* out, int B, int T, int D, int H, tacorl_stream_t stream);
+/* Train mode of the same (reference plan_recognition_transformer.py:49-54: nn.TransformerEncoderLayer(dropout=p);
+ * nn.MultiheadAttention drops attention probabilities): keep = uint8 [B][H][T][T] keep flags (an explicit input:
+ * the caller draws them), kept probabilities are scaled by keep_scale = 1/(1-p). */
+int tacorl_attention_dropout_fwd(const float* qkv, float* out, const unsigned char* keep, float keep_scale, int B,
+                                 int T, int D, int H, tacorl_stream_t stream);
+int tacorl_attention_dropout_bwd(const float* qkv, const float* d_out, float* d_qkv, const unsigned char* keep,
+                                 float keep_scale, int B, int T, int D, int H, tacorl_stream_t stream);
+/* nn.Dropout in train mode with an explicit keep mask, in place: x[i] = keep[i] ? x[i] * keep_scale : 0
+ * (an activation in the forward, its gradient in the backward; :60,87 and the encoder layers' dropout1/2/ffn). */
+int tacorl_dropout_mul(float* x, const unsigned char* keep, float keep_scale, long n, tacorl_stream_t stream);
 /* y = LayerNorm(x + res); stats[r] = {mean, rstd} (may be NULL). D <= 256. */
 int tacorl_add_layernorm_fwd(const float* x, const float* res, const float* w, const float* b, float* y,
                              float* stats, int R, int D, float eps, tacorl_stream_t stream);

@@ -47,6 +47,9 @@ _SIGS = {
     "tacorl_mlp_fwd_fused": (_i, [_i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p]),
     "tacorl_add_rows_bcast": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "tacorl_attention_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "tacorl_attention_dropout_fwd": (_i, [_p, _p, _p, _f, _i, _i, _i, _i, _p]),
+    "tacorl_attention_dropout_bwd": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _i, _p]),
+    "tacorl_dropout_mul": (_i, [_p, _p, _f, _l, _p]),
     "tacorl_add_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "tacorl_mean_over_t": (_i, [_p, _p, _i, _i, _i, _p]),
     "tacorl_pr_sample": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p]),

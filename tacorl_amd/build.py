@@ -1,33 +1,53 @@
-"""Build libtacorl_hip.so (gfx950) in-tree with hipcc.  `python -m tacorl_amd.build`."""
+"""Build libtacorl_hip.so (gfx950) in-tree with hipcc.  `python -m tacorl_amd.build [--force]`.
+Each csrc/*.hip is compiled to its own object (only when it or a header changed, up to 4 at a time), then linked."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("dense_ops.hip", "rl_ops.hip", "seq_ops.hip", "encoder_fused.hip", "encoder_bwd_fused.hip", "mlp_fused.hip", "rnn_ops.hip", "pr_fused.hip")]
+CSRC = os.path.join(HERE, "csrc")
+NAMES = ("dense_ops", "rl_ops", "seq_ops", "encoder_fused", "encoder_bwd_fused", "mlp_fused", "rnn_ops", "pr_fused",
+         "data_ops")
+SRC = [os.path.join(CSRC, f + ".hip") for f in NAMES]
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
 OUT = os.path.join(HERE, "lib", "libtacorl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17"]
 
 
-def _stale():
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))]
-    deps.append(os.path.join(os.path.dirname(HERE), "include", "tacorl_hip.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+def _headers_mtime():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "tacorl_hip.h"))
+    return max(os.path.getmtime(h) for h in hs)
 
 
 def build(force=False, verbose=True):
     srcs = [s for s in SRC if os.path.exists(s)]
-    if not force and not _stale():
-        return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [HIPCC, *FLAGS, "-o", OUT, *srcs]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hm = _headers_mtime()
+    todo = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(OBJ_DIR, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hm):
+            todo.append((s, o))
+
+    def cc(so):
+        cmd = [HIPCC, *FLAGS, "-c", so[0], "-o", so[1]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            list(ex.map(cc, todo))
+    if todo or not os.path.exists(OUT) or any(os.path.getmtime(o) > os.path.getmtime(OUT) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     return OUT
 
 

@@ -32,7 +32,10 @@ extern "C" int tacorl_add_rows_bcast(const float* x, int ldx, const float* add, 
 // One thread per (b, head, query): scores = (q/sqrt(hd)) . k, softmax over keys, weighted sum of v.
 #define ATT_MAX_T 64
 #define ATT_MAX_HD 16
-__global__ void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int T, int D, int H) {
+// keep (may be NULL): attention-probability dropout of nn.MultiheadAttention in train mode, uint8 [B][H][T][T]
+// keep flags; a kept probability is scaled by ks = 1/(1-p)  (out = (softmax(..) o keep * ks) v).
+__global__ void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int T, int D, int H,
+                                     const unsigned char* __restrict__ keep, float ks) {
   const int hd = D / H;
   const long total = (long)B * H * T;
   const float scale = 1.0f / sqrtf((float)hd);
@@ -49,19 +52,43 @@ __global__ void attention_fwd_kernel(const float* __restrict__ qkv, float* __res
     }
     float se = 0.f;
     for (int j = 0; j < T; j++) { s[j] = expf(s[j] - mx); se += s[j]; }
+    const unsigned char* kp = keep ? keep + (((long)b * H + h) * T + t) * T : nullptr;
     for (int j = 0; j < T; j++) {
-      const float p = s[j] / se;
+      const float p = s[j] / se * (kp ? (kp[j] ? ks : 0.f) : 1.f);
       for (int e = 0; e < hd; e++) o[e] += p * base[(long)j * 3 * D + 2 * D + h * hd + e];
     }
     for (int e = 0; e < hd; e++) out[((long)b * T + t) * D + h * hd + e] = o[e];
   }
 }
-extern "C" int tacorl_attention_fwd(const float* qkv, float* out, int B, int T, int D, int H, tacorl_stream_t stream) {
+static int attention_fwd_launch(const float* qkv, float* out, int B, int T, int D, int H, const unsigned char* keep, float ks,
+                                tacorl_stream_t stream) {
   if (T > ATT_MAX_T || D % H || D / H > ATT_MAX_HD) return TACORL_EINVAL;
   const long total = (long)B * H * T;
   if (total <= 0) return TACORL_OK;
   hipLaunchKernelGGL(attention_fwd_kernel, dim3((int)((total + 127) / 128)), dim3(128), 0, (hipStream_t)stream, qkv, out,
-                     B, T, D, H);
+                     B, T, D, H, keep, ks);
+  return LAUNCH_OK();
+}
+extern "C" int tacorl_attention_fwd(const float* qkv, float* out, int B, int T, int D, int H, tacorl_stream_t stream) {
+  return attention_fwd_launch(qkv, out, B, T, D, H, nullptr, 1.f, stream);
+}
+extern "C" int tacorl_attention_dropout_fwd(const float* qkv, float* out, const unsigned char* keep, float keep_scale, int B,
+                                            int T, int D, int H, tacorl_stream_t stream) {
+  if (!keep) return TACORL_EINVAL;
+  return attention_fwd_launch(qkv, out, B, T, D, H, keep, keep_scale, stream);
+}
+
+// x[i] = keep[i] ? x[i] * keep_scale : 0 in place: nn.Dropout in train mode with the keep mask as an explicit input
+// (applied to an activation in the forward and to its gradient in the backward).
+__global__ void dropout_mul_kernel(float* __restrict__ x, const unsigned char* __restrict__ keep, float ks, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    x[i] = keep[i] ? x[i] * ks : 0.f;
+}
+extern "C" int tacorl_dropout_mul(float* x, const unsigned char* keep, float keep_scale, long n, tacorl_stream_t stream) {
+  if (n <= 0) return TACORL_OK;
+  const long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(dropout_mul_kernel, dim3((int)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, x, keep,
+                     keep_scale, n);
   return LAUNCH_OK();
 }
 
@@ -364,8 +391,10 @@ extern "C" int tacorl_bcast_over_t(const float* src, float* dst, int B, int T, i
 }
 
 // Attention backward, one block of T threads per (batch, head); probabilities are recomputed.
+// keep / ks as in the forward: out_i = sum_j p_ij w_ij v_j with w_ij = keep_ij * ks, so dP_ij = w_ij (dO_i . v_j).
 __global__ void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ d_out,
-                                     float* __restrict__ d_qkv, int B, int T, int D, int H) {
+                                     float* __restrict__ d_qkv, int B, int T, int D, int H,
+                                     const unsigned char* __restrict__ keep, float ks) {
   __shared__ float s_m[ATT_MAX_T], s_l[ATT_MAX_T], s_dd[ATT_MAX_T];
   const int hd = D / H, b = blockIdx.x / H, h = blockIdx.x % H, i = threadIdx.x;
   const float scale = 1.0f / sqrtf((float)hd);
@@ -373,6 +402,8 @@ __global__ void attention_bwd_kernel(const float* __restrict__ qkv, const float*
   const float* dob = d_out + (long)b * T * D;
   float* dqb = d_qkv + (long)b * T * 3 * D;
   float q[ATT_MAX_HD], dO[ATT_MAX_HD], acc[ATT_MAX_HD];
+  const unsigned char* kb = keep ? keep + ((long)b * H + h) * T * T : nullptr;
+#define ATT_W(r, j) (kb ? (kb[(r) * T + (j)] ? ks : 0.f) : 1.f)
   if (i < T) {
     for (int e = 0; e < hd; e++) { q[e] = base[(long)i * 3 * D + h * hd + e] * scale; dO[e] = dob[(long)i * D + h * hd + e]; }
     float mx = -INFINITY;
@@ -389,7 +420,7 @@ __global__ void attention_bwd_kernel(const float* __restrict__ qkv, const float*
         dp += dO[e] * base[(long)j * 3 * D + 2 * D + h * hd + e];
       }
       const float w = expf(a - mx);
-      l += w; dd += w * dp;
+      l += w; dd += w * dp * ATT_W(i, j);
     }
     dd /= l;
     s_m[i] = mx; s_l[i] = l; s_dd[i] = dd;
@@ -401,7 +432,7 @@ __global__ void attention_bwd_kernel(const float* __restrict__ qkv, const float*
         a += q[e] * base[(long)j * 3 * D + D + h * hd + e];
         dp += dO[e] * base[(long)j * 3 * D + 2 * D + h * hd + e];
       }
-      const float ds = expf(a - mx) / l * (dp - dd);
+      const float ds = expf(a - mx) / l * (dp * ATT_W(i, j) - dd);
       for (int e = 0; e < hd; e++) acc[e] += ds * base[(long)j * 3 * D + D + h * hd + e];
     }
     for (int e = 0; e < hd; e++) dqb[(long)i * 3 * D + h * hd + e] = acc[e] * scale;
@@ -421,10 +452,11 @@ __global__ void attention_bwd_kernel(const float* __restrict__ qkv, const float*
         dp += dob[(long)r * D + h * hd + e] * v[e];
       }
       const float p = expf(a - s_m[r]) / s_l[r];
-      const float ds = p * (dp - s_dd[r]);
+      const float wr = ATT_W(r, i);
+      const float ds = p * (dp * wr - s_dd[r]);
       for (int e = 0; e < hd; e++) {
         dk[e] += ds * base[(long)r * 3 * D + h * hd + e] * scale;
-        dv[e] += p * dob[(long)r * D + h * hd + e];
+        dv[e] += p * wr * dob[(long)r * D + h * hd + e];
       }
     }
     for (int e = 0; e < hd; e++) {
@@ -433,12 +465,23 @@ __global__ void attention_bwd_kernel(const float* __restrict__ qkv, const float*
     }
   }
 }
-extern "C" int tacorl_attention_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int D, int H,
-                                    tacorl_stream_t stream) {
+#undef ATT_W
+static int attention_bwd_launch(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int D, int H,
+                                const unsigned char* keep, float ks, tacorl_stream_t stream) {
   if (T > ATT_MAX_T || D % H || D / H > ATT_MAX_HD) return TACORL_EINVAL;
   if (B <= 0) return TACORL_OK;
-  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, qkv, d_out, d_qkv, B, T, D, H);
+  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, qkv, d_out, d_qkv, B, T, D, H, keep,
+                     ks);
   return LAUNCH_OK();
+}
+extern "C" int tacorl_attention_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int D, int H,
+                                    tacorl_stream_t stream) {
+  return attention_bwd_launch(qkv, d_out, d_qkv, B, T, D, H, nullptr, 1.f, stream);
+}
+extern "C" int tacorl_attention_dropout_bwd(const float* qkv, const float* d_out, float* d_qkv, const unsigned char* keep,
+                                            float keep_scale, int B, int T, int D, int H, tacorl_stream_t stream) {
+  if (!keep) return TACORL_EINVAL;
+  return attention_bwd_launch(qkv, d_out, d_qkv, B, T, D, H, keep, keep_scale, stream);
 }
 
 // LayerNorm(x + res) backward.  dv (gradient of x + res) and per-block partial sums of dw, db.

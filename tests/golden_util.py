@@ -114,3 +114,53 @@ def check_stats(got_named, expected_stats, rtol, atol=0.0, what=""):
         elif np.max(np.abs(got[2:] - exp[2:])) > rtol * max(np.max(np.abs(exp[2:])), scale / np.sqrt(n)) + atol + 1e-12:
             bad.append(f"{what}{name}: samples max|d|={np.max(np.abs(got[2:] - exp[2:])):.3g}")
     return bad
+
+
+def resync_oracle(mod, P, opts):
+    """Copy the module's parameters and Adam state (moments, step counters) into the oracle's.
+
+    Multi-step comparisons restart the oracle from the module's own state before every step after the first:
+    after ONE Adam step two implementations that agree to 1e-7 on a gradient can differ by 2*lr in the elements
+    whose gradient is ~0 (the first update is lr * sign(g)), and such a difference can flip a ReLU gate in the
+    next step - a 1e-3..1e-2 event in a small-batch gradient that says nothing about either implementation
+    (the fp32 and fp64 evaluations of the oracle differ by as much, scratch/dbg_c4.py).  `opts`: the oracle's
+    optimisers by name (make_opts) or a single oracle Adam (PlayLMP)."""
+    import torch
+
+    sd = mod.state_dict()
+    with torch.no_grad():
+        for k, v in P.items():
+            if k in sd and sd[k].dtype == torch.float32:
+                v.copy_(sd[k].detach().cpu())
+    name_of = {id(p): n for n, p in mod.named_parameters()}
+    mopts = mod.configure_optimizers()
+    mopts = list(mopts) if isinstance(mopts, (list, tuple)) else [mopts]
+    for o in mopts:
+        tgt = opts[o.name] if isinstance(opts, dict) else opts
+        for blk, p, m, v in o._triples():
+            n = name_of[id(p)]
+            tgt.m[n], tgt.v[n] = m.detach().cpu().clone().contiguous(), v.detach().cpu().clone().contiguous()
+            tgt.t = int(blk.step.item())
+
+
+def gradient_floor(grad_fn, P, ref_grads, runs=2, eps=1e-7):
+    """Per-tensor reproducibility of a gradient evaluated with bf16 operand rounding: re-evaluate it with every
+    parameter perturbed by a relative N(0, eps) noise (eps = 1e-7: one fp32 ulp, what a different summation order
+    does upstream of a rounding point) and return {name: worst relative change}.  A rounding to bf16 is a step
+    function, so a 1-ulp change that crosses a boundary moves that operand by 2^-8; through the 30 sequential layers
+    of the RNN's BPTT, or the (dp - <p, dp>) cancellation of the soft-argmax temperature, this is a 1-2.5 % effect
+    on small-batch gradients (scratch/chaos_floor.py).  No bf16 kernel can be held tighter than this floor.
+    grad_fn(P_perturbed) -> {name: grad}; it must not modify its argument's originals."""
+    import torch
+
+    floor = {}
+    for r in range(runs):
+        gen = torch.Generator().manual_seed(1000 + r)
+        Pp = {k: (v.detach() * (1 + eps * torch.randn(v.shape, generator=gen))).requires_grad_(v.requires_grad)
+              for k, v in P.items()}
+        got = grad_fn(Pp)
+        for k, g0 in ref_grads.items():
+            if k in got and g0 is not None and g0.norm() > 0:
+                e = ((got[k] - g0).norm() / g0.norm()).item()
+                floor[k] = max(floor.get(k, 0.0), e)
+    return floor

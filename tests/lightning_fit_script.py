@@ -77,7 +77,8 @@ for kind in ("tacorl", "cql", "playlmp"):
         with torch.no_grad():  # make sure the values really come from the checkpoint
             for p in resumed.parameters():
                 p.mul_(0.5)
-        t2 = Trainer(max_epochs=1, max_steps=4, log_every_n_steps=1, **tkw)
+        # (the checkpoint was written after t1's epoch counter moved on: give the resumed run epochs to spend)
+        t2 = Trainer(max_epochs=10, max_steps=4, log_every_n_steps=1, **tkw)
         t2.fit(resumed, train_dataloaders=data[2:], ckpt_path=path)
     torch.cuda.synchronize()
     assert t2.global_step == 4

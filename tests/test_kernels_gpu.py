@@ -362,14 +362,24 @@ def test_encoder_fused_backward(H, W, accumulate):
 
     dev = _dev()
     assert _lib.lib().tacorl_encoder_fused_supported(H, W) == 1
+    from tests.golden_util import gradient_floor
+
     n = [7, 13, 2]
-    flats, imgs, outs, acts, douts, refs = [], [], [], [], [], []
+    flats, imgs, outs, acts, douts, refs, floors = [], [], [], [], [], [], []
     for i, k in enumerate(n):
         P = {kk: v.clone().requires_grad_(True) for kk, v in _enc_params(120 + i).items()}
         img = rnd(k, 3, H, W, seed=130 + i).to(torch.bfloat16).float()
         dout = rnd(k, 32, seed=140 + i)
         with O.operand_rounding(torch.bfloat16):  # same algorithm, the MFMA's operand rounding
             (O.encoder_fwd(P, "", img) * dout).sum().backward()
+
+            def regrad(Pp, img=img, dout=dout):
+                gs = torch.autograd.grad((O.encoder_fwd(Pp, "", img) * dout).sum(), list(Pp.values()))
+                return dict(zip(Pp, gs))
+
+            # the soft-argmax temperature gradient is one global (dp - <p, dp>) cancellation: its reproducibility
+            # under a 1-ulp perturbation of the weights bounds what a kernel can be held to (golden_util.gradient_floor)
+            floors.append(gradient_floor(regrad, P, {kk: v.grad for kk, v in P.items()}))
         flat = torch.zeros(blocks.encoder_size(), device=dev)
         blocks.load_named(blocks.encoder_views(flat), {kk: v.detach() for kk, v in P.items()})
         flats.append(flat)
@@ -392,7 +402,8 @@ def test_encoder_fused_backward(H, W, accumulate):
             e = relerr(vf[name] - (0.25 if accumulate else 0.0), vg[name] - (0.25 if accumulate else 0.0))
             assert e < 2e-3, ("vs generic bf16", name, e)
             e = relerr(vf[name] - (0.25 if accumulate else 0.0), g)
-            assert e < GRAD_BF16_ROUNDED, ("vs oracle autograd with bf16 operand rounding", name, e)
+            assert e < max(GRAD_BF16_ROUNDED, 3 * floors[i].get(name, 0.0)), (
+                "vs oracle autograd with bf16 operand rounding", name, e, floors[i].get(name))
 
 
 @pytest.mark.parametrize("dims,acts", [([64, 256, 256, 256, 32], [2, 2, 2, 0]), ([80, 256, 256, 256, 1], [2, 2, 2, 0]),
