@@ -52,6 +52,10 @@ CASES = {
     # PlayLMP seq-VAE step (BASELINE config 1 shape)
     "playlmp": dict(kind="playlmp", B=3, T=16, cams={"rgb_static": (84, 84)}, latent=16,
                     steps=2, seed=16),
+    # PlayLMP as the reference trains it: plan-recognition dropout 0.1 in train mode
+    # (config/networks/plan_recognition/transformer.yaml:9); the keep masks are part of the noise tape
+    "playlmp_dropout": dict(kind="playlmp", B=3, T=16, cams={"rgb_static": (84, 84)}, latent=16,
+                            steps=2, seed=20, dropout_p=0.1),
 }
 
 
@@ -75,7 +79,8 @@ def run_case(name, c):
     out = {}
     cams = c["cams"]
     if c["kind"] in ("tacorl", "playlmp"):
-        lmp = H.build_play_lmp(cams=tuple(sorted(cams)), latent_plan_dim=c["latent"], seq_len=c["T"])
+        lmp = H.build_play_lmp(cams=tuple(sorted(cams)), latent_plan_dim=c["latent"], seq_len=c["T"],
+                               dropout_p=c.get("dropout_p", 0.0))
     if c["kind"] == "tacorl":
         mod = H.build_tacorl(lmp, finetune_action_decoder=c["finetune_ad"], **c.get("overrides", {}))
     elif c["kind"] == "cql":
@@ -147,6 +152,7 @@ def run_case(name, c):
 
 
 if __name__ == "__main__":
+    assert H.check_sdpa_standin() < 1e-6, "recording stand-in for scaled_dot_product_attention drifted from torch's"
     which = sys.argv[1:] or list(CASES)
     for n in which:
         run_case(n, CASES[n])

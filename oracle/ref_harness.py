@@ -21,6 +21,8 @@ import types
 from contextlib import contextmanager
 
 import numpy as np
+import math
+
 import torch
 import torch.nn as nn
 
@@ -198,13 +200,52 @@ def record_noise(tape: NoiseTape):
         tape.add("rand", u)
         return u
 
+    import torch.nn.functional as F
+
+    o_dropout, o_sdpa = F.dropout, F.scaled_dot_product_attention
+
+    def dropout(input, p=0.5, training=True, inplace=False):
+        """F.dropout with the keep mask recorded (what nn.Dropout calls; torch's own kernel hides the mask).
+        Same distribution and arithmetic as torch: keep ~ Bernoulli(1 - p), kept values scaled by 1 / (1 - p)."""
+        if not training or p == 0.0:
+            return input
+        keep = torch.bernoulli(torch.full(input.shape, 1.0 - p))
+        tape.add("dropout", keep.to(torch.uint8))
+        return input * keep * (1.0 / (1.0 - p))
+
+    def sdpa(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, **kw):
+        """torch's scaled_dot_product_attention, written out so that its internal dropout on the attention
+        probabilities goes through the recorded F.dropout above (nn.MultiheadAttention in train mode, need_weights=
+        False, takes this route; its math path is softmax(q k^T * scale + mask) -> dropout -> @ v).
+        check_sdpa_standin() pins it against torch's own implementation with dropout off."""
+        assert attn_mask is None and not is_causal and not kw, "stand-in covers the plan-recognition use only"
+        sc = (1.0 / math.sqrt(query.shape[-1])) if scale is None else scale
+        att = torch.softmax((query * sc) @ key.transpose(-1, -2), dim=-1)
+        att = dropout(att, dropout_p, True)
+        return att @ value
+
     Normal.sample, Normal.rsample = sample, rsample
     torch.Tensor.uniform_, torch.rand = uniform_, rand
+    F.dropout, F.scaled_dot_product_attention = dropout, sdpa
     try:
         yield tape
     finally:
         Normal.sample, Normal.rsample = o_sample, o_rsample
         torch.Tensor.uniform_, torch.rand = o_uniform, o_rand
+        F.dropout, F.scaled_dot_product_attention = o_dropout, o_sdpa
+
+
+def check_sdpa_standin():
+    """The written-out attention used while recording equals torch's scaled_dot_product_attention (dropout off) and,
+    through nn.MultiheadAttention in train mode, changes nothing: max abs difference of an encoder layer's output."""
+    torch.manual_seed(0)
+    layer = torch.nn.TransformerEncoderLayer(32, 8, dim_feedforward=64, dropout=0.0)
+    layer.train()
+    x = torch.randn(16, 3, 32)
+    ref = layer(x)
+    with record_noise(NoiseTape()):
+        got = layer(x)
+    return (got - ref).abs().max().item()
 
 
 # ------------------------------------------------------------------ config dicts

@@ -210,29 +210,49 @@ def _layer_norm(x, w, b):
     return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
 
 
-def plan_recognition(P, pre, emb, n_heads=8, n_layers=2, min_std=1e-4):
-    """PlanRecognitionTransformersNetwork.forward (dropout off),
+def plan_recognition(P, pre, emb, n_heads=8, n_layers=2, min_std=1e-4, dropout=None):
+    """PlanRecognitionTransformersNetwork.forward,
     reference plan_encoders/plan_recognition_transformer.py:70-105 with torch's
-    nn.TransformerEncoderLayer defaults (post-norm, ReLU).  emb (B,T,D) -> mu,std (B,A)."""
+    nn.TransformerEncoderLayer defaults (post-norm, ReLU).  emb (B,T,D) -> mu,std (B,A).
+    dropout = (p, masks): train mode; masks = the 1 + 4 * n_layers keep masks in the reference's draw order and
+    layouts - embedding (T,B,D) (:87), then per layer attention probabilities (B,H,T,T), dropout1 (T,B,D), FFN
+    dropout (T,B,FF), dropout2 (T,B,D) (torch nn.TransformerEncoderLayer._sa_block / _ff_block)."""
+    p_drop, masks = dropout if dropout is not None else (0.0, None)
+    ks = 1.0 / (1.0 - p_drop)
+
+    def drop_tbd(x, m):  # x batch-major (B,T,*), mask sequence-major (T,B,*)
+        return x * m.to(x.dtype).permute(1, 0, 2) * ks
+
     B, T, D = emb.shape
     pad = (-D) % n_heads
     if pad:
         emb = torch.cat([emb, torch.zeros(B, T, pad, dtype=emb.dtype)], dim=-1)
         D += pad
     x = emb + P[pre + "position_embeddings.weight"][:T].unsqueeze(0)
+    if masks is not None:
+        x = drop_tbd(x, masks[0])
     hd = D // n_heads
     for l in range(n_layers):
         lp = f"{pre}transformer_encoder.layers.{l}."
+        mk = masks[1 + 4 * l: 5 + 4 * l] if masks is not None else None
         qkv = _linear(x, P[lp + "self_attn.in_proj_weight"], P[lp + "self_attn.in_proj_bias"])
         q, k, v = qkv.split(D, dim=-1)
         sh = lambda t: t.reshape(B, T, n_heads, hd).permute(0, 2, 1, 3)  # noqa: E731
         q, k, v = sh(q), sh(k), sh(v)
         att = torch.softmax((q / math.sqrt(hd)) @ k.transpose(-1, -2), dim=-1)
+        if mk is not None:
+            att = att * mk[0].to(att.dtype) * ks
         o = (att @ v).permute(0, 2, 1, 3).reshape(B, T, D)
         o = _linear(o, P[lp + "self_attn.out_proj.weight"], P[lp + "self_attn.out_proj.bias"])
+        if mk is not None:
+            o = drop_tbd(o, mk[1])
         x = _layer_norm(x + o, P[lp + "norm1.weight"], P[lp + "norm1.bias"])
-        f = _linear(F.relu(_linear(x, P[lp + "linear1.weight"], P[lp + "linear1.bias"])),
-                     P[lp + "linear2.weight"], P[lp + "linear2.bias"])
+        hdn = F.relu(_linear(x, P[lp + "linear1.weight"], P[lp + "linear1.bias"]))
+        if mk is not None:
+            hdn = drop_tbd(hdn, mk[2])
+        f = _linear(hdn, P[lp + "linear2.weight"], P[lp + "linear2.bias"])
+        if mk is not None:
+            f = drop_tbd(f, mk[3])
         x = _layer_norm(x + f, P[lp + "norm2.weight"], P[lp + "norm2.bias"])
     x = _linear(x, P[pre + "fc.weight"], P[pre + "fc.bias"]).mean(dim=1)
     mean = _linear(x, P[pre + "mean_fc.weight"], P[pre + "mean_fc.bias"])
@@ -617,8 +637,9 @@ def balanced_kl(mu_q, std_q, mu_p, std_p, kl_alpha=0.8):
             + (1 - kl_alpha) * kl(mu_q, std_q, mu_p.detach(), std_p.detach()).mean())
 
 
-def playlmp_step(P, opt, batch, noise, cams, kl_beta=1e-3, kl_alpha=0.8, step=True):
-    """PlayLMP.training_step + Adam (play_lmp_for_rl.py:200-257,307-317,362-368), dropout 0.
+def playlmp_step(P, opt, batch, noise, cams, kl_beta=1e-3, kl_alpha=0.8, step=True, dropout_p=0.0):
+    """PlayLMP.training_step + Adam (play_lmp_for_rl.py:200-257,307-317,362-368); with dropout_p > 0 the
+    plan recognition runs in train mode with the keep masks noise['dropout'] (see plan_recognition).
     noise: 'eps_plan' (B,A) rsample; 'rand' list of 4 U(0,1) (B,T-1,6[,10]) for the two
     logging-only _sample calls; 'u_plan' (B,A), 'u_goal' (B,G) U(0,1)."""
     logs = {}
@@ -630,7 +651,8 @@ def playlmp_step(P, opt, batch, noise, cams, kl_beta=1e-3, kl_alpha=0.8, step=Tr
     cat = torch.cat([emb[c] for c in cams], dim=-1)
     pp_goal = goal_encoder(P, "goal_encoder.", cat[:, -1])
     mu_p, std_p = policy(P, "plan_proposal.policy.", torch.cat([cat[:, 0], pp_goal], dim=-1))
-    mu_q, std_q = plan_recognition(P, "plan_recognition.", cat)
+    mu_q, std_q = plan_recognition(P, "plan_recognition.", cat,
+                                   dropout=(dropout_p, noise["dropout"]) if dropout_p > 0 else None)
     kl = balanced_kl(mu_q, std_q, mu_p, std_p, kl_alpha)
     logs["kl_loss"], logs["kl_loss_scaled"] = kl.item(), (kl * kl_beta).item()
     plan = torch.tanh(mu_q + noise["eps_plan"] * std_q)

@@ -85,6 +85,14 @@ class CQL_Offline(GraphMixin, ModuleMixin, LightningModuleBase):
         cfgcheck.check_representation(self.critic_encoder_cfg, "critic_encoder", self.obs_modalities)
         cfgcheck.check_goal_encoder(self.goal_encoder_cfg, "goal_encoder", a["hidden"])
         self._make_engine(self.obs_modalities, self.goal_modalities, self.action_dim, a)
+        # fresh networks start from the reference modules' torch initialisers (tacorl_amd/init.py); targets are
+        # copies of the critics (reference :226-227)
+        from ...init import init_views_
+
+        e = self.engine
+        for blk in (e.actor, e.q1, e.q2):
+            init_views_(blk.views)
+        self.sync_targets()
         self._register()
 
     def _make_engine(self, cams, goal_cams, action_dim, a):

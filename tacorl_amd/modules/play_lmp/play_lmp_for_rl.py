@@ -200,6 +200,11 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
             buf.normal_()
         else:
             buf.uniform_()
+    # plan-recognition dropout is live in train mode (reference transformer.yaml:9, nn.Module.training): its keep masks
+    # are drawn (or injected: noise["dropout"]) here, with the step's other noise
+    self._pr_train = bool(self.training and pr.dropout_p > 0)
+    if self._pr_train:
+        pr.stage_dropout(B, T, noise.get("dropout") if noise is not None else None)
     # ---- eager staging: frames into the fixed NHWC buffers, actions into a fixed buffer
     for c in cams:
         H, W = hw[c]
@@ -235,7 +240,7 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
 
     # (a graph replay runs no python: announce the optimiser's writes to torch's version counters - ops.touched)
     self._stepped_blocks = (lambda: [net.param, pr.blk.param, ad.blk.param]) if optimize else None
-    self._run_segments(("playlmp", B, T, tuple(sorted(hw.items())), optimize), [fwd_bwd, opt], [reduce_grads])
+    self._run_segments(("playlmp", B, T, tuple(sorted(hw.items())), optimize, self._pr_train), [fwd_bwd, opt], [reduce_grads])
     lg = self.logs.cpu().tolist()
     names = ["kl_loss", "kl_loss_scaled", "action_loss", "gripper_accuracy", "random_plan_action_loss",
              "random_plan_gripper_accuracy"]
@@ -279,7 +284,7 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     ops.copy_cols(self.gact, self.g_yoff, Ec, self.S, Ec, 2 * Ec, B, Ec)
     ops.mlp_fwd([self.S], 2 * Ec, [net.head()], [self.pact], [B], net.head_dims, net.head_acts, cd)
     head_pp = self.pact[self.p_yoff: self.p_yoff + B * 2 * A]
-    head_pr = pr.forward(self.emb, Ec, B, T, cd)
+    head_pr = pr.forward(self.emb, Ec, B, T, cd, train=getattr(self, "_pr_train", False))
     call("tacorl_gauss_kl_balanced", ptr(head_pr), ptr(head_pp), ptr(self.d_head_pr), ptr(self.d_head_pp), B, A,
          float(self.kl_alpha), float(self.kl_beta), float(pr.min_std), int(self.kl_balancing), gs, ptr(self.logs),
          ops.stream())

@@ -6,6 +6,12 @@ transformer_encoder.layers.N.{self_attn.in_proj_*, self_attn.out_proj.*, linear1
 fc, mean_fc, variance_fc).  mean_fc and variance_fc are stored back to back so the two heads
 are one GEMM.  `fc` is applied after the mean over time (fc is affine, so
 mean_t(fc(x_t)) == fc(mean_t(x_t)); saves 16x of the 32->4096 GEMM).
+
+Train mode (`forward(train=True)` with dropout_p > 0, reference :49-54,60,87 and
+config/networks/plan_recognition/transformer.yaml:9): the 1 + 4 * num_layers dropout sites of the reference -
+embeddings, and per encoder layer attention probabilities, dropout1, FFN dropout, dropout2 - take their keep
+masks as explicit inputs (`stage_dropout`: injected masks in the reference's layouts, or fresh Bernoulli draws),
+applied in the forward and to the matching gradients in the backward.
 """
 import torch
 
@@ -57,7 +63,34 @@ class PlanRecognition:
         self.ff2 = [f(R, D) for _ in range(self.L)]
         self.stats = [f(R, 2) for _ in range(2 * self.L)]
         self.pooled, self.fc_out, self.head = f(B, D), f(B, self.FC), f(B, 2 * self.A)
+        self.keep = None
+        if self.dropout_p > 0:  # keep masks (uint8): [embedding] + per layer [attention probs, dropout1, ffn, dropout2]
+            u8 = lambda n: torch.ones(n, dtype=torch.uint8, device=self.dev)  # noqa: E731
+            self.keep = [u8(R * D)]
+            for _ in range(self.L):
+                self.keep += [u8(B * self.H * T * T), u8(R * D), u8(R * self.FF), u8(R * D)]
         self._shape = (B, T)
+
+    def stage_dropout(self, B, T, masks=None):
+        """Fill the keep masks of the next train-mode forward (eager, before a graph replay - like the step's other
+        noise).  masks: the reference's draws in its order and layouts (sequence-major (T,B,*) for the activations,
+        (B,H,T,T) for the attention probabilities); None: fresh Bernoulli(1 - p) draws from torch's device generator."""
+        self._ensure(B, T)
+        if self.keep is None:
+            return
+        if masks is None:
+            for k in self.keep:
+                k.bernoulli_(1.0 - self.dropout_p)
+            return
+        assert len(masks) == len(self.keep), (len(masks), len(self.keep))
+        for i, (k, m) in enumerate(zip(self.keep, masks)):
+            m = m.to(self.dev)
+            if (i - 1) % 4 != 0 or i == 0:  # activation masks arrive as (T, B, *): batch-major here
+                m = m.permute(1, 0, 2)
+            k.copy_(m.reshape(-1).to(torch.uint8))
+
+    def _drop(self, x, i, n):
+        call("tacorl_dropout_mul", ptr(x), ptr(self.keep[i]), 1.0 / (1.0 - self.dropout_p), n, ops.stream())
 
     def _lin(self, x, ldx, w, b, y, M, K, N, act, compute):
         # split-K capable entry (skinny outputs with a long K: linear2 2048->32, the 2048->182 heads)
@@ -97,7 +130,7 @@ class PlanRecognition:
         call("tacorl_pr_head_compose", blk.p("fc.weight"), blk.p("fc.bias"), blk.p("mean_fc.weight"), blk.p("mean_fc.bias"),
              ptr(self._Wc), ptr(self._bc), self.D, self.FC, 2 * self.A, ops.stream())
 
-    def forward(self, emb, ld_emb, B, T, compute, inference=False, sample=None, prepared=False, frozen=False):
+    def forward(self, emb, ld_emb, B, T, compute, inference=False, sample=None, prepared=False, frozen=False, train=False):
         """emb: device tensor/pointer of [B*T][ld_emb] per-frame embeddings (first D_in columns used).
         Returns the (B, 2A) head buffer [mean | var_raw].  inference=True (frozen network, no backward
         follows): the encoder layers + time pooling run as one launch when the shape qualifies; with
@@ -108,6 +141,8 @@ class PlanRecognition:
         re-issued only when that counter moved)."""
         self._ensure(B, T)
         blk, D, R = self.blk, self.D, B * T
+        drop = self._dropping = bool(train and not inference and self.dropout_p > 0)
+        ks = 1.0 / (1.0 - self.dropout_p) if drop else 1.0
         if inference and self.fused_inference_ok(T, ld_emb, compute):
             ver = blk.param._version
             if not prepared and not (frozen and getattr(self, "_prep_version", None) == ver):
@@ -127,20 +162,32 @@ class PlanRecognition:
             return self.head
         call("tacorl_add_rows_bcast", ptr(emb), ld_emb, blk.p("position_embeddings.weight"), ptr(self.x[0]), R, T,
              self.D_in, D, ops.stream())
+        if drop:
+            self._drop(self.x[0], 0, R * D)
         for l in range(self.L):
             p = f"transformer_encoder.layers.{l}."
             xin, x1, x2 = self.x[2 * l], self.x[2 * l + 1], self.x[2 * l + 2]
             self._lin(xin, D, blk.p(p + "self_attn.in_proj_weight"), blk.p(p + "self_attn.in_proj_bias"), self.qkv[l],
                       R, D, 3 * D, ACT_NONE, compute)
-            call("tacorl_attention_fwd", ptr(self.qkv[l]), ptr(self.att[l]), B, T, D, self.H, ops.stream())
+            if drop:
+                call("tacorl_attention_dropout_fwd", ptr(self.qkv[l]), ptr(self.att[l]), ptr(self.keep[1 + 4 * l]), ks, B, T,
+                     D, self.H, ops.stream())
+            else:
+                call("tacorl_attention_fwd", ptr(self.qkv[l]), ptr(self.att[l]), B, T, D, self.H, ops.stream())
             self._lin(self.att[l], D, blk.p(p + "self_attn.out_proj.weight"), blk.p(p + "self_attn.out_proj.bias"),
                       self.proj[l], R, D, D, ACT_NONE, compute)
+            if drop:
+                self._drop(self.proj[l], 2 + 4 * l, R * D)
             call("tacorl_add_layernorm_fwd", ptr(xin), ptr(self.proj[l]), blk.p(p + "norm1.weight"),
                  blk.p(p + "norm1.bias"), ptr(x1), ptr(self.stats[2 * l]), R, D, 1e-5, ops.stream())
             self._lin(x1, D, blk.p(p + "linear1.weight"), blk.p(p + "linear1.bias"), self.ff1[l], R, D, self.FF,
                       ACT_RELU, compute)
+            if drop:
+                self._drop(self.ff1[l], 3 + 4 * l, R * self.FF)
             self._lin(self.ff1[l], self.FF, blk.p(p + "linear2.weight"), blk.p(p + "linear2.bias"), self.ff2[l], R,
                       self.FF, D, ACT_NONE, compute)
+            if drop:
+                self._drop(self.ff2[l], 4 + 4 * l, R * D)
             call("tacorl_add_layernorm_fwd", ptr(x1), ptr(self.ff2[l]), blk.p(p + "norm2.weight"),
                  blk.p(p + "norm2.bias"), ptr(x2), ptr(self.stats[2 * l + 1]), R, D, 1e-5, ops.stream())
         call("tacorl_mean_over_t", ptr(self.x[2 * self.L]), ptr(self.pooled), B, T, D, ops.stream())
@@ -183,33 +230,57 @@ class PlanRecognition:
             self.d_fc, self.d_pool = f(B, FC), f(B, D)
             self.dx, self.dv, self.d_ff1, self.d_x1, self.d_att, self.d_qkv = f(R, D), f(R, D), f(R, FF), f(R, D), f(R, D), f(R, 3 * D)
             self.dv1 = f(R, D)
+            self.dvb, self.dv1b = f(R, D), f(R, D)  # branch gradients behind dropout2 / dropout1 (train mode)
             self._bshape = (B, T)
         self._wgrad(self.fc_out, FC, d_head, A2, B, FC, A2, blk.g("mean_fc.weight"), blk.g("mean_fc.bias"), compute)
         self._dgrad(d_head, A2, blk.p("mean_fc.weight"), self.d_fc, FC, B, A2, FC, compute)
         self._wgrad(self.pooled, D, self.d_fc, FC, B, D, FC, blk.g("fc.weight"), blk.g("fc.bias"), compute)
         self._dgrad(self.d_fc, FC, blk.p("fc.weight"), self.d_pool, D, B, FC, D, compute)
         call("tacorl_bcast_over_t", ptr(self.d_pool), ptr(self.dx), B, T, D, 1.0 / T, 0, ops.stream())
+        # train mode: the forward dropped ff2 / ff1 / proj / attention probabilities / embeddings in place (the saved
+        # buffers ARE the dropped values, so the weight gradients and the fused ReLU mask see what the next layer saw);
+        # a branch's gradient takes the same keep mask and scale, the residual path takes the unmasked one
+        drop = getattr(self, "_dropping", False)
+        ks = 1.0 / (1.0 - self.dropout_p) if drop else 1.0
         for l in reversed(range(self.L)):
             p = f"transformer_encoder.layers.{l}."
             xin, x1 = self.x[2 * l], self.x[2 * l + 1]
             self._ln_bwd(self.dx, x1, self.ff2[l], blk.p(p + "norm2.weight"), self.stats[2 * l + 1], self.dv,
                          blk.g(p + "norm2.weight"), blk.g(p + "norm2.bias"), R, D)
-            self._wgrad(self.ff1[l], FF, self.dv, D, R, FF, D, blk.g(p + "linear2.weight"), blk.g(p + "linear2.bias"), compute)
-            self._dgrad(self.dv, D, blk.p(p + "linear2.weight"), self.d_ff1, FF, R, D, FF, compute, src=self.ff1[l],
+            dvb = self.dv
+            if drop:
+                dvb = self.dvb
+                ops.copy_cols(self.dv, 0, D, dvb, 0, D, R, D)
+                self._drop(dvb, 4 + 4 * l, R * D)
+            self._wgrad(self.ff1[l], FF, dvb, D, R, FF, D, blk.g(p + "linear2.weight"), blk.g(p + "linear2.bias"), compute)
+            self._dgrad(dvb, D, blk.p(p + "linear2.weight"), self.d_ff1, FF, R, D, FF, compute, src=self.ff1[l],
                         ld_src=FF, act=ACT_RELU)
+            if drop:  # (the ReLU mask taken from the dropped ff1 already zeroed the dropped units: this adds the scale)
+                self._drop(self.d_ff1, 3 + 4 * l, R * FF)
             self._wgrad(x1, D, self.d_ff1, FF, R, D, FF, blk.g(p + "linear1.weight"), blk.g(p + "linear1.bias"), compute)
             self._dgrad(self.d_ff1, FF, blk.p(p + "linear1.weight"), self.d_x1, D, R, FF, D, compute, addend=self.dv,
                         ld_add=D)
             self._ln_bwd(self.d_x1, xin, self.proj[l], blk.p(p + "norm1.weight"), self.stats[2 * l], self.dv1,
                          blk.g(p + "norm1.weight"), blk.g(p + "norm1.bias"), R, D)
-            self._wgrad(self.att[l], D, self.dv1, D, R, D, D, blk.g(p + "self_attn.out_proj.weight"),
+            dv1b = self.dv1
+            if drop:
+                dv1b = self.dv1b
+                ops.copy_cols(self.dv1, 0, D, dv1b, 0, D, R, D)
+                self._drop(dv1b, 2 + 4 * l, R * D)
+            self._wgrad(self.att[l], D, dv1b, D, R, D, D, blk.g(p + "self_attn.out_proj.weight"),
                         blk.g(p + "self_attn.out_proj.bias"), compute)
-            self._dgrad(self.dv1, D, blk.p(p + "self_attn.out_proj.weight"), self.d_att, D, R, D, D, compute)
-            call("tacorl_attention_bwd", ptr(self.qkv[l]), ptr(self.d_att), ptr(self.d_qkv), B, T, D, self.H, ops.stream())
+            self._dgrad(dv1b, D, blk.p(p + "self_attn.out_proj.weight"), self.d_att, D, R, D, D, compute)
+            if drop:
+                call("tacorl_attention_dropout_bwd", ptr(self.qkv[l]), ptr(self.d_att), ptr(self.d_qkv),
+                     ptr(self.keep[1 + 4 * l]), ks, B, T, D, self.H, ops.stream())
+            else:
+                call("tacorl_attention_bwd", ptr(self.qkv[l]), ptr(self.d_att), ptr(self.d_qkv), B, T, D, self.H, ops.stream())
             self._wgrad(xin, D, self.d_qkv, 3 * D, R, D, 3 * D, blk.g(p + "self_attn.in_proj_weight"),
                         blk.g(p + "self_attn.in_proj_bias"), compute)
             self._dgrad(self.d_qkv, 3 * D, blk.p(p + "self_attn.in_proj_weight"), self.dx, D, R, 3 * D, D, compute,
                         addend=self.dv1, ld_add=D)
+        if drop:
+            self._drop(self.dx, 0, R * D)
         # position embeddings: sum over the batch of rows with the same t
         call("tacorl_reduce_rows_mod", ptr(self.dx), D, blk.g("position_embeddings.weight"), D, T, D, B, ops.stream())
         if self.T_max > T:

@@ -43,8 +43,15 @@ class Golden:
         kind = self.cfg["kind"]
         nz = {}
         if kind == "playlmp":
+            # train-mode dropout masks of the plan recognition come first (1 embedding mask + 4 per encoder layer:
+            # attention probabilities, dropout1, FFN dropout, dropout2 - reference plan_recognition_transformer.py:87-88)
+            nd = sum(1 for k, _ in t if k == "dropout")
+            assert all(k == "dropout" for k, _ in t[:nd])
+            drop, t = [m for _, m in t[:nd]], t[nd:]
             assert [k for k, _ in t] == ["normal", "rand", "rand", "uniform01", "uniform01", "rand", "rand"]
             nz = dict(eps_plan=t[0][1], rand=[t[1][1], t[2][1], t[5][1], t[6][1]], u_plan=t[3][1], u_goal=t[4][1])
+            if drop:
+                nz["dropout"] = drop
             return nz
         i = 0
         if kind == "tacorl":
@@ -143,7 +150,7 @@ def resync_oracle(mod, P, opts):
             tgt.t = int(blk.step.item())
 
 
-def gradient_floor(grad_fn, P, ref_grads, runs=2, eps=1e-7):
+def gradient_floor(grad_fn, P, ref_grads, runs=4, eps=1e-7):
     """Per-tensor reproducibility of a gradient evaluated with bf16 operand rounding: re-evaluate it with every
     parameter perturbed by a relative N(0, eps) noise (eps = 1e-7: one fp32 ulp, what a different summation order
     does upstream of a rounding point) and return {name: worst relative change}.  A rounding to bf16 is a step

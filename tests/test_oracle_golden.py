@@ -56,12 +56,14 @@ def test_cql_step_matches_reference(name):
         assert not bad, "\n".join(bad[:20])
 
 
-def test_playlmp_step_matches_reference():
-    g = Golden("playlmp")
+@pytest.mark.parametrize("name", ["playlmp", "playlmp_dropout"])
+def test_playlmp_step_matches_reference(name):
+    g = Golden(name)
     P = O.require_grad_(g.params())
     opt = O.Adam([n for n in P], 1e-4)
     for step in range(g.cfg["steps"]):
-        logs, grads = O.playlmp_step(P, opt, g.batch(step), g.noise(step), sorted(g.cams))
+        logs, grads = O.playlmp_step(P, opt, g.batch(step), g.noise(step), sorted(g.cams),
+                                     dropout_p=g.cfg.get("dropout_p", 0.0))
         bad = _check_logs(logs, g.logged(step))
         bad += check_stats(grads, g.stats(step, "grad"), rtol=5e-5, what="grad ")
         bad += check_stats(P, g.stats(step, "param"), rtol=RTOL, atol=PARAM_ATOL, what="param ")

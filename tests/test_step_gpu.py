@@ -2,6 +2,8 @@
 unmodified reference and (b) the CPU oracle run on the same inputs with full tensors.
 Tolerance: 1e-4 relative on every logged loss and on the sampled latent plans (north star),
 f32 MFMA mode.  The bf16 MFMA mode is checked separately at a stated, looser tolerance."""
+import copy
+
 import pytest
 import torch
 
@@ -10,7 +12,12 @@ from tests.golden_util import Golden, check_stats, gradient_floor, resync_oracle
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-4
-GRAD_RTOL = 3e-4  # gradients: sums of ~1e5 fp32 products re-associated by the split-R wgrad
+# gradients: sums of ~1e5 fp32 products re-associated by the split-R wgrad.  Where the reference's OWN fp32 arithmetic is
+# less reproducible than this - a branch of the discretised-logistic NLL or a ReLU gate decided by the last bit: one
+# of 270 terms switching moves every upstream gradient by 0.4 % (scratch/dbg_plmp.py: torch-fp32 sits that far from
+# torch-fp64 while the HIP step sits 3e-6 from torch-fp32) - the tolerance of that tensor is three times its measured
+# reproducibility under a 1-ulp perturbation of the parameters (golden_util.gradient_floor).
+GRAD_RTOL = 3e-4
 PARAM_ATOL = 1.5e-5  # Adam g/(|g|+eps) amplification on near-zero grads (a few % of one lr update)
 
 ACTOR = {"policy": {"num_layers": 3, "hidden_dim": 256}}
@@ -35,6 +42,10 @@ def check_logs(got, exp, rtol=RTOL):
         elif abs(got[k] - v) > rtol * max(abs(v), 1e-2):
             bad.append(f"{k}: {got[k]:.8g} vs {v:.8g}")
     return bad
+
+
+def _snap(P):
+    return {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in P.items()}
 
 
 def relerr(a, b):
@@ -81,9 +92,11 @@ def test_cql_offline_step(name):
         mod.training_step(to_dev(batch, mod.device), 0, noise=to_dev(noise, mod.device))
         torch.cuda.synchronize()
         got = {k.split("/", 1)[1]: v for k, v in mod.logged.items()}
+        before, opts0 = _snap(P), copy.deepcopy(opts)
         _, ograds = O.cql_step(P, opts, spec, batch, noise, g.cfg["epoch"])
+        floor = gradient_floor(lambda Pp: O.cql_step(Pp, copy.deepcopy(opts0), spec, batch, noise, g.cfg["epoch"])[1], before, ograds)
         bad = check_logs(got, g.logged(step))
-        bad += compare_with_oracle_grads(mod, ograds, GRAD_RTOL)
+        bad += compare_with_oracle_grads(mod, ograds, GRAD_RTOL, floor)
         if step == 0:
             bad += check_stats(mod.named_gradients(), g.stats(step, "grad"), rtol=GRAD_RTOL, what="golden grad ")
         bad += check_stats(mod.state_dict(), g.stats(step, "param"), rtol=RTOL, atol=PARAM_ATOL, what="golden param ")
@@ -133,26 +146,33 @@ def test_tacorl_step(name):
         mod.training_step(to_dev(batch, mod.device), noise=to_dev(noise, mod.device))
         torch.cuda.synchronize()
         got = {k.split("/", 1)[1]: v for k, v in mod.logged.items()}
+        before, opts0 = _snap(P), copy.deepcopy(opts)
         _, oplan, ograds = O.tacorl_step(P, opts, spec, batch, noise, g.cfg["epoch"])
+        floor = gradient_floor(lambda Pp: O.tacorl_step(Pp, copy.deepcopy(opts0), spec, batch, noise, g.cfg["epoch"])[2], before, ograds)
         bad = check_logs(got, g.logged(step))
         e = relerr(mod.plan, g.latent_plan(step))
         if e > RTOL:
             bad.append(f"latent plan relerr {e:.3g} (oracle {relerr(mod.plan, oplan):.3g})")
-        bad += compare_with_oracle_grads(mod, ograds, GRAD_RTOL)
+        bad += compare_with_oracle_grads(mod, ograds, GRAD_RTOL, floor)
         if step == 0:  # (fingerprints of later steps' gradients belong to the reference's own parameter trajectory)
             bad += check_stats(mod.named_gradients(), g.stats(step, "grad"), rtol=GRAD_RTOL, what="golden grad ")
         bad += check_stats(mod.state_dict(), g.stats(step, "param"), rtol=RTOL, atol=PARAM_ATOL, what="golden param ")
         assert not bad, f"step {step}:\n" + "\n".join(bad[:25])
 
 
-def test_playlmp_step():
+@pytest.mark.parametrize("name", ["playlmp", "playlmp_dropout"])
+def test_playlmp_step(name):
+    """PlayLMP.training_step vs the reference goldens; `playlmp_dropout` is the reference's own training
+    configuration (plan-recognition dropout 0.1 live in train mode, config/networks/plan_recognition/transformer.yaml:9)
+    with the recorded keep masks injected."""
     from oracle import tacorl_oracle as O
     from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
 
-    g = Golden("playlmp")
+    g = Golden(name)
     cams, c = sorted(g.cams), g.cfg
+    dp = c.get("dropout_p", 0.0)
     pr = dict(num_heads=8, num_layers=2, encoder_hidden_size=2048, fc_hidden_size=4096, latent_plan_dim=c["latent"],
-              min_std=1e-4, dropout_p=0.0, max_position_embeddings=c["T"])
+              min_std=1e-4, dropout_p=dp, max_position_embeddings=c["T"])
     ad = dict(n_mixtures=10, num_layers=2, hidden_size=2048, out_features=7, num_classes=10,
               latent_plan_dim=c["latent"], rnn_model="rnn_decoder", include_goal=False)
     mod = PlayLMP(plan_proposal=ACTOR, plan_recognition=pr, action_decoder=ad, plan_proposal_obs_modalities=cams,
@@ -170,12 +190,15 @@ def test_playlmp_step():
             # oracle restarts from the module's own parameters (golden_util.resync_oracle) and is held to GRAD_RTOL there
             resync_oracle(mod, P, opt)
         mod.logged = {}
-        mod.training_step(to_dev(batch, mod.device), 0, noise=to_dev({k: nz[k] for k in ("eps_plan", "u_plan")}, mod.device))
+        inj = {k: nz[k] for k in ("eps_plan", "u_plan", "dropout") if k in nz}
+        mod.training_step(to_dev(batch, mod.device), 0, noise=inj)
         torch.cuda.synchronize()
         got = {k.split("/", 1)[1]: v for k, v in mod.logged.items()}
-        _, ograds = O.playlmp_step(P, opt, batch, nz, cams)
+        before, opt0 = _snap(P), copy.deepcopy(opt)
+        _, ograds = O.playlmp_step(P, opt, batch, nz, cams, dropout_p=dp)
+        floor = gradient_floor(lambda Pp: O.playlmp_step(Pp, copy.deepcopy(opt0), batch, nz, cams, dropout_p=dp)[1], before, ograds)
         bad = check_logs(got, g.logged(step))
-        bad += compare_with_oracle_grads(mod, ograds, GRAD_RTOL)
+        bad += compare_with_oracle_grads(mod, ograds, GRAD_RTOL, floor)
         if step == 0:
             bad += check_stats(mod.named_gradients(), g.stats(step, "grad"), rtol=GRAD_RTOL, what="golden grad ")
         bad += check_stats(mod.state_dict(), g.stats(step, "param"), rtol=RTOL, atol=PARAM_ATOL if step == 0 else 2e-4,
@@ -312,9 +335,11 @@ def test_tacorl_step_bf16_mode(name):
 # for the configurations BASELINE names (C2 tacorl_q, C3 tacorl_q_ad, C4 tacorl_c4, C5 cql_n32, C1 playlmp).
 BF16_LOG_RTOL, BF16_PLAN_RTOL, BF16_GRAD_RTOL = 2e-3, 2e-3, 1e-2
 # Post-step parameters: Adam's update is lr * m / (sqrt(v) + eps) - after the first step exactly lr * sign(g) - so an
-# element whose gradient is below the bf16 noise floor may step the other way (2 * lr apart) although the gradient
-# tensors agree to 1e-2.  What is held: at most 3 % of the elements of any tensor take a different step (more than a
-# quarter of the oracle's largest), and the rest agree.
+# element whose gradient is below the bf16 noise floor steps in a random direction (2 * lr apart) although the
+# gradient tensors agree to 1e-2; e.g. the key third of a MultiheadAttention in_proj_bias has an exactly zero true
+# gradient (softmax is invariant to a key bias).  What is held: of the elements whose oracle gradient is significant
+# (>= 10 % of the tensor's rms), at most 3 % take a different step (by more than a quarter of the oracle's largest
+# step); tensors with fewer than 64 such elements are left to the gradient check above.
 BF16_STEP_FLIP_FRACTION = 0.03
 
 
@@ -336,16 +361,16 @@ def _bf16_compare(mod, got, ologs, ograds, P_before, P_after, step, plan=None, o
             d_or = (v.detach() - P_before[k]).double()
             d_hip = (sd[k].detach().cpu() - P_before[k]).double()
             big = d_or.abs().max().item()
-            if big == 0.0:
+            g = ograds.get(k)
+            if big == 0.0 or g is None:
                 continue
-            frac = ((d_hip - d_or).abs() > 0.25 * big).double().mean().item()
+            sig = g.detach().abs().double() >= 0.1 * g.detach().double().pow(2).mean().sqrt()
+            if int(sig.sum()) < 64:
+                continue
+            frac = ((d_hip - d_or).abs() > 0.25 * big)[sig].double().mean().item()
             if frac > BF16_STEP_FLIP_FRACTION:
-                bad.append(f"param {k}: {100 * frac:.1f} % of the elements step differently")
+                bad.append(f"param {k}: {100 * frac:.1f} % of the significant elements step differently")
     return [f"step {step}: {b}" for b in bad]
-
-
-def _snap(P):
-    return {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in P.items()}
 
 
 @pytest.mark.parametrize("name", ["tacorl_q", "tacorl_q_ad", "tacorl_c4", "tacorl_bc_ad"])
@@ -369,8 +394,6 @@ def test_tacorl_step_bf16_vs_rounded_oracle(name):
         mod.training_step(to_dev(batch, mod.device), noise=to_dev(noise, mod.device))
         torch.cuda.synchronize()
         got = {k.split("/", 1)[1]: v for k, v in mod.logged.items()}
-        import copy
-
         opts0 = copy.deepcopy(opts)
         with O.operand_rounding(torch.bfloat16):
             ologs, oplan, ograds = O.tacorl_step(P, opts, spec, batch, noise, g.cfg["epoch"])
@@ -405,8 +428,6 @@ def test_cql_step_bf16_vs_rounded_oracle():
         mod.training_step(to_dev(batch, mod.device), 0, noise=to_dev(noise, mod.device))
         torch.cuda.synchronize()
         got = {k.split("/", 1)[1]: v for k, v in mod.logged.items()}
-        import copy
-
         opts0 = copy.deepcopy(opts)
         with O.operand_rounding(torch.bfloat16):
             ologs, ograds = O.cql_step(P, opts, spec, batch, noise, g.cfg["epoch"])
@@ -442,8 +463,6 @@ def test_playlmp_step_bf16_vs_rounded_oracle():
         mod.training_step(to_dev(batch, mod.device), 0, noise=to_dev({k: nz[k] for k in ("eps_plan", "u_plan")}, mod.device))
         torch.cuda.synchronize()
         got = {k.split("/", 1)[1]: v for k, v in mod.logged.items()}
-        import copy
-
         opt0 = copy.deepcopy(opt)
         with O.operand_rounding(torch.bfloat16):
             ologs, ograds = O.playlmp_step(P, opt, batch, nz, cams)
