@@ -58,10 +58,19 @@ def compare_with_oracle_grads(mod, oracle_grads, rtol, floor=None):
     max(rtol, 3 * floor)."""
     bad = []
     got = mod.named_gradients()
+    # A soft-argmax temperature gradient is ONE scalar: a signed sum over images x 64 channels x pixels whose absolute
+    # rounding noise is the same for every encoder of the step, while its value can be a small residue (the actor's in
+    # the BC phase: 1.4 % of the critics').  The scalars are therefore held relative to the largest of them.
+    t_scale = max([v.abs().max().item() for k, v in oracle_grads.items() if k.endswith(".temperature") and v is not None] or [0.0])
     for k, v in oracle_grads.items():
         if k in got:
-            e = relerr(got[k].reshape(v.shape), v)
             tol = max(rtol, 3.0 * (floor or {}).get(k, 0.0))
+            if k.endswith(".temperature"):
+                d = (got[k].reshape(v.shape).detach().cpu().double() - v.detach().double()).abs().max().item()
+                if d > tol * max(v.abs().max().item(), t_scale):
+                    bad.append(f"grad {k}: {got[k].item():.6g} vs {v.item():.6g} (tolerance {tol:.3g} of {t_scale:.3g})")
+                continue
+            e = relerr(got[k].reshape(v.shape), v)
             if e > tol and v.norm() > 1e-12:
                 bad.append(f"grad {k}: relerr {e:.3g} (tolerance {tol:.3g})")
     return bad
@@ -343,6 +352,22 @@ BF16_LOG_RTOL, BF16_PLAN_RTOL, BF16_GRAD_RTOL = 2e-3, 2e-3, 1e-2
 BF16_STEP_FLIP_FRACTION = 0.03
 
 
+def _with_bf16_sensitivity(floor, g_rounded, g_fp32):
+    """A second bound on how tightly a bf16 kernel can be pinned: how much the tensor's gradient moves when operands
+    are rounded to bf16 AT ALL (rounded oracle vs fp32 oracle; 0.5 % for most tensors, tens of % for the gradients that
+    are differences of nearly equal terms - the CQL logsumexp against the data Q at initialisation, a soft-argmax
+    temperature).  A kernel that rounds a dZ one step earlier than the oracle emulates moves such a gradient by a
+    comparable amount, so the per-tensor tolerance (3 * floor, compare_with_oracle_grads) is at least half of that
+    sensitivity; a kernel must land much nearer to the rounded oracle than the fp32 value does."""
+    out = dict(floor)
+    for k, gr in g_rounded.items():
+        g32 = g_fp32.get(k)
+        if g32 is not None and gr is not None and gr.norm() > 0:
+            sens = ((gr - g32).norm() / gr.norm()).item()
+            out[k] = max(out.get(k, 0.0), sens / 6.0)  # x3 in compare_with_oracle_grads -> half the sensitivity
+    return out
+
+
 def _bf16_compare(mod, got, ologs, ograds, P_before, P_after, step, plan=None, oplan=None, floor=None):
     bad = []
     for k, v in ologs.items():
@@ -399,6 +424,8 @@ def test_tacorl_step_bf16_vs_rounded_oracle(name):
             ologs, oplan, ograds = O.tacorl_step(P, opts, spec, batch, noise, g.cfg["epoch"])
             floor = gradient_floor(lambda Pp: O.tacorl_step(Pp, copy.deepcopy(opts0), spec, batch, noise, g.cfg["epoch"])[2],
                                    before, ograds)
+        floor = _with_bf16_sensitivity(floor, ograds, O.tacorl_step(_snap(before), copy.deepcopy(opts0), spec, batch, noise,
+                                                                    g.cfg["epoch"])[2])
         bad += _bf16_compare(mod, got, ologs, ograds, before, P, step, mod.plan, oplan, floor)
     assert not bad, "\n".join(bad[:30])
 
@@ -433,6 +460,8 @@ def test_cql_step_bf16_vs_rounded_oracle():
             ologs, ograds = O.cql_step(P, opts, spec, batch, noise, g.cfg["epoch"])
             floor = gradient_floor(lambda Pp: O.cql_step(Pp, copy.deepcopy(opts0), spec, batch, noise, g.cfg["epoch"])[1],
                                    before, ograds)
+        floor = _with_bf16_sensitivity(floor, ograds, O.cql_step(_snap(before), copy.deepcopy(opts0), spec, batch, noise,
+                                                                 g.cfg["epoch"])[1])
         bad += _bf16_compare(mod, got, ologs, ograds, before, P, step, floor=floor)
     assert not bad, "\n".join(bad[:30])
 
@@ -467,5 +496,6 @@ def test_playlmp_step_bf16_vs_rounded_oracle():
         with O.operand_rounding(torch.bfloat16):
             ologs, ograds = O.playlmp_step(P, opt, batch, nz, cams)
             floor = gradient_floor(lambda Pp: O.playlmp_step(Pp, copy.deepcopy(opt0), batch, nz, cams)[1], before, ograds)
+        floor = _with_bf16_sensitivity(floor, ograds, O.playlmp_step(_snap(before), copy.deepcopy(opt0), batch, nz, cams)[1])
         bad += _bf16_compare(mod, got, ologs, ograds, before, P, step, floor=floor)
     assert not bad, "\n".join(bad[:30])
