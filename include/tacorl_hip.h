@@ -312,6 +312,11 @@ int tacorl_logistic_mixture_loss(const float* heads, int ldh, const float* actio
                                  float* loss_out, int B, int T, int Tm, int Da, int K, int num_classes,
                                  float gripper_alpha, float grad_scale, void* ws, size_t ws_bytes,
                                  tacorl_stream_t stream);
+/* ActionDecoderLogistic._sample (:238-266), the action of `act` at rollout time: Gumbel-max mixture component,
+ * inversion sampling of the chosen logistic, argmax gripper class.  rand_a [R][Da][K], rand_b [R][Da]: the
+ * caller's U(0,1) draws in the heads' row order; out [R][Da+1] = [actions | gripper -1/+1]. */
+int tacorl_logistic_mixture_sample(const float* heads, int ldh, const float* rand_a, const float* rand_b,
+                                   float* out, int R, int Da, int K, tacorl_stream_t stream);
 
 /* ---- backward glue: ReLU-RNN BPTT, transformer, seq-VAE KL ---------------------------------- */
 int tacorl_relu_mask_mul(const float* dy, const float* add, const float* h, float* out, long n,

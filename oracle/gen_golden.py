@@ -54,6 +54,11 @@ CASES = {
                     steps=2, seed=16),
     # PlayLMP as the reference trains it: plan-recognition dropout 0.1 in train mode
     # (config/networks/plan_recognition/transformer.yaml:9); the keep masks are part of the noise tape
+    # Rollout-time surface (evaluation/rollout_manager.py:310-431): deterministic and sampled
+    # actor.get_actions, perceptual_encoder.get_state_from_observation, three action_decoder.act steps with the
+    # carried hidden state
+    "rollout_tacorl": dict(kind="rollout", B=2, T=4, cams={"rgb_static": (84, 84)}, latent=16, seed=21),
+    "rollout_cql": dict(kind="rollout_cql", B=3, cams={"rgb_static": (84, 84)}, seed=22),
     "playlmp_dropout": dict(kind="playlmp", B=3, T=16, cams={"rgb_static": (84, 84)}, latent=16,
                             steps=2, seed=20, dropout_p=0.1),
 }
@@ -73,7 +78,58 @@ def _group_of(name):
     return None
 
 
+def run_rollout(name, c):
+    """Inference goldens: no optimiser, modules in eval mode, under no_grad."""
+    torch.manual_seed(c["seed"])
+    out, cams = {}, c["cams"]
+    names = tuple(sorted(cams))
+    tape = H.NoiseTape()
+    if c["kind"] == "rollout":
+        lmp = H.build_play_lmp(cams=names, latent_plan_dim=c["latent"], seq_len=16)
+        mod = H.build_tacorl(lmp, finetune_action_decoder=False)
+        synth.fill_params_(mod, c["seed"])
+        mod.eval()
+        batch = synth.make_play_batch(c["seed"] * 100, c["B"], c["T"], cams)
+        obs0 = {"observation": {k: v[:, 0] for k, v in batch["states"].items()}, "goal": batch["goal"]}
+        with torch.no_grad(), H.record_noise(tape):
+            plan, lp0 = mod.actor.get_actions(obs0, deterministic=True, reparameterize=False)
+            plan_s, lp_s = mod.actor.get_actions(obs0, deterministic=False, reparameterize=False)
+            mod.action_decoder.clear_hidden_state()
+            acts, embs = [], []
+            for t in range(3):
+                ad_state = mod.perceptual_encoder.get_state_from_observation(
+                    observation={k: v[:, t] for k, v in batch["states"].items()}, modalities=mod.action_decoder_modalities)
+                embs.append(ad_state.clone())
+                acts.append(mod.action_decoder.act(latent_plan=plan, perceptual_emb=ad_state.unsqueeze(1)).clone())
+            hidden = mod.action_decoder.hidden_state
+        assert float(lp0.abs().max()) == 0.0 and lp0.shape == plan.shape
+        out.update(plan=plan.numpy(), plan_sampled=plan_s.numpy(), logpi_sampled=lp_s.numpy(),
+                   ad_state=torch.stack(embs).numpy(), actions=torch.stack(acts).numpy(), hidden=hidden.numpy())
+    else:
+        mod = H.build_cql(cams=names)
+        synth.fill_params_(mod, c["seed"])
+        mod.eval()
+        batch = synth.make_transition_batch(c["seed"] * 100, c["B"], cams)
+        obs = batch["observations"]
+        with torch.no_grad(), H.record_noise(tape):
+            a_det, lp0 = mod.actor.get_actions(obs, deterministic=True, reparameterize=False)
+            a_smp, lp_smp = mod.actor.get_actions(obs, deterministic=False, reparameterize=False)
+            a_rsm, lp_rsm = mod.actor.get_actions(obs, deterministic=False, reparameterize=True)
+        out.update(act_det=a_det.numpy(), act_sample=a_smp.numpy(), logpi_sample=lp_smp.numpy(), act_rsample=a_rsm.numpy(),
+                   logpi_rsample=lp_rsm.numpy())
+    for i, (kind, t) in enumerate(tape.draws):
+        out[f"s0/noise/{i:02d}_{kind}"] = t.numpy()
+    out["param_names"] = np.array([n for n, _ in mod.named_parameters()])
+    out["param_shapes"] = np.array(json.dumps([list(p.shape) for _, p in mod.named_parameters()]))
+    out["param_requires_grad"] = np.array([p.requires_grad for _, p in mod.named_parameters()])
+    out["config"] = np.array(json.dumps(dict(c)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"[{name}] wrote {os.path.getsize(os.path.join(OUT, name + '.npz')) / 1e3:.1f} kB; draws: {[k for k, _ in tape.draws]}")
+
+
 def run_case(name, c):
+    if c["kind"].startswith("rollout"):
+        return run_rollout(name, c)
     torch.manual_seed(c["seed"])
     torch.set_num_threads(8)
     out = {}

@@ -261,20 +261,23 @@ def plan_recognition(P, pre, emb, n_heads=8, n_layers=2, min_std=1e-4, dropout=N
 
 
 # ------------------------------------------------------------------------------- A12
-def action_decoder_fwd(P, pre, plan, emb, n_mix=10, n_layers=2):
+def action_decoder_fwd(P, pre, plan, emb, n_mix=10, n_layers=2, h0=None, return_hidden=False):
     """ActionDecoderLogistic.forward (rnn_decoder = 2-layer ReLU nn.RNN, batch_first),
-    reference action_decoders/action_decoder_logistic.py:268-300, rnn_models.py:5-16."""
+    reference action_decoders/action_decoder_logistic.py:268-300, rnn_models.py:5-16.
+    h0 (n_layers,B,H): initial hidden state (the `act` path, :87-97); return_hidden appends h_n."""
     B, T, _ = emb.shape
     x = torch.cat([plan.unsqueeze(1).expand(-1, T, -1), emb], dim=-1)
+    hn = []
     for l in range(n_layers):
         wi, wh = P[f"{pre}rnn.weight_ih_l{l}"], P[f"{pre}rnn.weight_hh_l{l}"]
         bi, bh = P[f"{pre}rnn.bias_ih_l{l}"], P[f"{pre}rnn.bias_hh_l{l}"]
-        h = torch.zeros(B, wh.shape[0], dtype=emb.dtype)
+        h = torch.zeros(B, wh.shape[0], dtype=emb.dtype) if h0 is None else h0[l]
         xin = _linear(x, wi, bi)
         outs = []
         for t in range(T):
             h = F.relu(xin[:, t] + _linear(h, wh, bh))
             outs.append(h)
+        hn.append(h)
         x = torch.stack(outs, dim=1)
     probs = _linear(x, P[pre + "prob_fc.weight"], P[pre + "prob_fc.bias"])
     means = _linear(x, P[pre + "mean_fc.weight"], P[pre + "mean_fc.bias"])
@@ -282,7 +285,37 @@ def action_decoder_fwd(P, pre, plan, emb, n_mix=10, n_layers=2):
                              min=LOG_SIG_MIN)
     grip = _linear(x, P[pre + "gripper_fc.weight"], P[pre + "gripper_fc.bias"])
     v = lambda t: t.reshape(B, T, -1, n_mix)  # noqa: E731
+    if return_hidden:
+        return v(probs), v(log_scales), v(means), grip, torch.stack(hn)
     return v(probs), v(log_scales), v(means), grip
+
+
+def action_decoder_act(P, pre, plan, emb, h0, rand_a, rand_b):
+    """ActionDecoderLogistic.act (:87-97): one decoder step, hidden state in / out, sampled action (B,1,7)."""
+    lp, ls, mm, gr, hn = action_decoder_fwd(P, pre, plan, emb, h0=h0, return_hidden=True)
+    return logistic_sample(lp, ls, mm, gr, rand_a, rand_b), hn
+
+
+def actor_get_actions(P, net, obs, goal, spec, deterministic=False, reparameterize=False, noise=None):
+    """VisualActorWrapper.get_actions -> Actor.get_actions (visual_actor_wrapper.py:64-66, actor.py:65-111).
+    noise: 'eps' (B,Ac) and, for the discrete gripper, 'gumbel_u' (B,2) U(0,1)."""
+    s = _emb(P, net, obs, goal, spec)
+    po = policy(P, net + "actor.policy.", s, discrete_gripper=spec.discrete_gripper)
+    mu, std = po[0], po[1]
+    if deterministic:
+        a = torch.tanh(mu)
+        if spec.discrete_gripper:
+            gi = torch.argmax(torch.softmax(po[2], dim=-1), dim=-1)
+            a = torch.cat([a, gi.unsqueeze(-1) * 2.0 - 1], dim=-1)
+        return a, torch.zeros_like(a)
+    z = mu + noise["eps"] * std
+    a, log_pi = torch.tanh(z), tanh_logprob(z, mu, std)
+    if spec.discrete_gripper:
+        nl = po[2] - po[2].logsumexp(dim=-1, keepdim=True)
+        gi = gumbel_rsample_hard_index(nl, noise["gumbel_u"]) if reparameterize else gumbel_argmax(nl, noise["gumbel_u"])
+        log_pi = log_pi + gripper_logprob(po[2], gi)
+        a = torch.cat([a, gi.unsqueeze(-1) * 2.0 - 1], dim=-1)
+    return a, log_pi
 
 
 def logistic_mixture_loss(logit_probs, log_scales, means, grip, actions, num_classes=10,

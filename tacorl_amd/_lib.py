@@ -56,6 +56,7 @@ _SIGS = {
     "tacorl_build_ad_input": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "tacorl_logistic_mixture_ws_bytes": (_sz, [_i, _i, _i]),
     "tacorl_logistic_mixture_loss": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p]),
+    "tacorl_logistic_mixture_sample": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_linear_dgrad": (_i, [_i, _p, _i, _p, _p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p]),
     "tacorl_linear_wgrad_ws_bytes": (_sz, [_i, _p, _i, _i]),
     "tacorl_linear_wgrad": (_i, [_i, _p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _p, _sz, _p]),

@@ -324,6 +324,46 @@ extern "C" int tacorl_logistic_mixture_loss(const float* heads, int ldh, const f
   return LAUNCH_OK();
 }
 
+// ActionDecoderLogistic._sample (reference action_decoder_logistic.py:238-266): Gumbel-max choice of the mixture
+// component, inversion sampling of that logistic, argmax gripper class.  One thread per (row, action dim).
+// heads as in logistic_mixture_kernel; rand_a [R][Da][K], rand_b [R][Da] U(0,1) draws in the heads' row order;
+// out [R][Da+1] = [actions | gripper command -1/+1].
+__global__ void logistic_mixture_sample_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ rand_a,
+                                               const float* __restrict__ rand_b, float* __restrict__ out, int R, int Da, int K) {
+  const long total = (long)R * Da;
+  const float r1 = 1e-5f, r2 = 1.0f - 1e-5f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(i % Da);
+    const long r = i / Da;
+    const float* h = heads + r * ldh;
+    const float* mean = h + a * K;
+    const float* lsc = h + (Da + a) * K;
+    const float* lg = h + (2 * Da + a) * K;
+    float best = -INFINITY;
+    int arg = 0;
+    for (int k = 0; k < K; k++) {
+      const float u = (r1 - r2) * rand_a[i * K + k] + r2;
+      const float t = lg[k] - logf(-logf(u));
+      if (t > best) { best = t; arg = k; }  // first maximum, as torch.argmax
+    }
+    const float ls = fmaxf(lsc[arg], -5.0f);  // LOG_SIG_MIN (:18,292)
+    const float u = (r1 - r2) * rand_b[i] + r2;
+    out[r * (Da + 1) + a] = mean[arg] + expf(ls) * (logf(u) - logf(1.0f - u));
+    if (a == 0) out[r * (Da + 1) + Da] = h[3 * Da * K + 1] > h[3 * Da * K] ? 1.0f : -1.0f;
+  }
+}
+extern "C" int tacorl_logistic_mixture_sample(const float* heads, int ldh, const float* rand_a, const float* rand_b,
+                                              float* out, int R, int Da, int K, tacorl_stream_t stream) {
+  if (K > LM_MAXK || R < 0) return TACORL_EINVAL;
+  const long total = (long)R * Da;
+  if (total <= 0) return TACORL_OK;
+  long blocks = (total + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(logistic_mixture_sample_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, heads, ldh, rand_a,
+                     rand_b, out, R, Da, K);
+  return LAUNCH_OK();
+}
+
 // ====================================================================== backward glue
 // out = (dy (+ add)) * [h > 0]    (ReLU-RNN: last BPTT step, no recurrent term yet)
 __global__ void relu_mask_mul_kernel(const float* __restrict__ dy, const float* __restrict__ add,

@@ -114,8 +114,9 @@ class CQL_Offline(GraphMixin, ModuleMixin, LightningModuleBase):
         self.log_alpha = nn.Parameter(e.log_alpha.param)
         if self.with_lagrange:
             self.log_alpha_prime = nn.Parameter(e.log_alpha_prime.param)
-        self.actor.action_dim = self.action_dim
-        self.actor.discrete_gripper = e.dg
+        from ..inference import attach_rollout_surface
+
+        attach_rollout_surface(self, e.actor, e.cams, self.goal_modalities, self.action_dim, e.dg)
 
     def _all_blocks(self):
         e = self.engine

@@ -94,6 +94,21 @@ class PlayLMP(GraphMixin, ModuleMixin, LightningModuleBase):
                     "ad": register_views(self, "action_decoder.", self.ad.blk.views)}
         for k, v in self.ad.buffers.items():
             self.action_decoder.register_buffer(k, v)
+        # rollout surface (evaluation/rollout_manager.py PlayLMP manager: plan_proposal.get_actions, action_decoder.act)
+        from ..inference import ActorSurface, EncoderRunner, state_from_observation
+
+        surf = ActorSurface(self, self.net, cams, cams, A, False)
+        self.__dict__["_actor_surface"] = surf
+        self.plan_proposal.get_actions = surf.get_actions
+        self.plan_proposal.action_dim = A
+        runner = EncoderRunner(self)
+        self.__dict__["_pe_runner"] = runner
+        self.perceptual_encoder.get_state_from_observation = (
+            lambda observation, modalities=None: state_from_observation(self, runner, self.net, observation,
+                                                                        list(modalities or cams)))
+        self.action_decoder.clear_hidden_state = self.ad.clear_hidden_state
+        self.action_decoder.act = lambda latent_plan, perceptual_emb, latent_goal=None, noise=None: self.ad.act(
+            latent_plan, perceptual_emb, latent_goal, noise=noise, compute=self.compute)
 
     def sync_from_rank0(self):
         """Broadcast rank 0's parameters and optimiser state (PL's DDP wrap does this for the reference module)."""
@@ -127,6 +142,8 @@ def load_play_lmp(play_lmp_dir, epoch=-1, overwrite_cfg=None, device=None, compu
     else:
         raise ValueError(f"not valid file path: {d}")
     cfgs = list(d.rglob("*config.yaml"))
+    if not cfgs and ckpt.parent == d:  # a checkpoint file was named: the run's .hydra/ sits beside its model_ckpts/
+        cfgs = list(d.parent.rglob("*config.yaml"))
     if not cfgs:
         raise FileNotFoundError(f"no *config.yaml under {d}")
     cfg = load_resolved_yaml(cfgs[0])["module"]

@@ -78,6 +78,12 @@ class TACORL(CQL_Offline):
             for k, v in self.ad.buffers.items():
                 self.action_decoder.register_buffer(k, v)
         self._T = None
+        # rollout surface (evaluation/rollout_manager.py:330-386): the frozen LMP encoder for the action decoder's state,
+        # the decoder's one-step `act` with its carried hidden state
+        from ..inference import attach_rollout_surface
+
+        attach_rollout_surface(self, e.actor, cams, goal_cams, self.action_dim, False, lmp_net=self.lmp_net,
+                               lmp_cams=self.action_decoder_modalities, ad=self.ad)
 
     def named_gradients(self):
         out = super().named_gradients()

@@ -52,7 +52,59 @@ class ActionDecoderLogistic:
         self.hidden_state = None
 
     def clear_hidden_state(self):
+        """reference :73-74."""
         self.hidden_state = None
+
+    def act(self, latent_plan, perceptual_emb, latent_goal=None, noise=None, compute=None):
+        """ActionDecoderLogistic.act (reference :87-97): ONE decoder step per call with the RNN's hidden state carried
+        between calls (rollout: evaluation/rollout_manager.py:375-386).  latent_plan (B,P); perceptual_emb (B,1,E);
+        returns the sampled action (B,1,7).  noise = (rand_a (B,1,6,K), rand_b (B,1,6)) injects the two U(0,1) draws
+        of `_sample` (:247,258)."""
+        if latent_goal is not None:
+            raise NotImplementedError("include_goal=False is the configured decoder")
+        compute = ops.F32 if compute is None else compute
+        B, H, L = latent_plan.shape[0], self.hidden, self.L
+        assert perceptual_emb.shape[0] == B and perceptual_emb.shape[1] == 1, "act decodes one step per call"
+        f = lambda *s: torch.zeros(*s, device=self.dev)  # noqa: E731
+        if getattr(self, "_act_B", None) != B:
+            ops.note_alloc()
+            self._act_x, self._act_xin = f(B, self.P + self.E), f(B, H)
+            self._act_h = [[f(B, H) for _ in range(L)] for _ in range(2)]  # ping-pong: previous / new hidden state
+            self._act_heads, self._act_out = f(B, (self.NH + 31) // 32 * 32), f(B, self.Da + 1)
+            self._act_ra, self._act_rb = f(B, self.Da, self.K), f(B, self.Da)
+            nb = ops.L.lib().tacorl_linear_add_fwd_ws_bytes(1, ops.int_array([B]), H, H)
+            self._act_ws = torch.empty(max(256, nb), dtype=torch.uint8, device=self.dev)
+            self._act_B, self._act_flip = B, 0
+            self.hidden_state = None
+        blk = self.blk
+        plan = latent_plan.to(self.dev, torch.float32).contiguous()
+        emb = perceptual_emb.to(self.dev, torch.float32).reshape(B, self.E).contiguous()
+        call("tacorl_build_ad_input", ptr(plan), ptr(emb), self.E, ptr(self._act_x), B, 1, 1, self.P, self.E, ops.stream())
+        prev = self._act_h[self._act_flip]
+        new = self._act_h[self._act_flip ^ 1]
+        if self.hidden_state is None:  # h_0 = 0 (nn.RNN default)
+            for t in prev:
+                t.zero_()
+        x, K = self._act_x, self.P + self.E
+        for l in range(L):
+            self._lin(x, K, blk.p(f"rnn.weight_ih_l{l}"), blk.p(f"rnn.bias_ih_l{l}"), self._act_xin, B, K, H, ACT_NONE, compute)
+            call("tacorl_linear_add_fwd", 1, ops.ptr_array([prev[l]]), H, ops.ptr_array([blk.p(f"rnn.weight_hh_l{l}")]),
+                 ops.ptr_array([blk.p(f"rnn.bias_hh_l{l}")]), ops.ptr_array([self._act_xin]), H, ops.ptr_array([new[l]]), H,
+                 ops.int_array([B]), H, H, ACT_RELU, compute, ptr(self._act_ws), self._act_ws.numel(), ops.stream())
+            x, K = new[l], H
+        self._lin(x, H, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self._act_heads, B, H, self.NH, ACT_NONE, compute,
+                  ldy=self._act_heads.shape[1])
+        if noise is not None:
+            self._act_ra.copy_(noise[0].reshape(self._act_ra.shape))
+            self._act_rb.copy_(noise[1].reshape(self._act_rb.shape))
+        else:
+            self._act_ra.uniform_()
+            self._act_rb.uniform_()
+        call("tacorl_logistic_mixture_sample", ptr(self._act_heads), self._act_heads.shape[1], ptr(self._act_ra),
+             ptr(self._act_rb), ptr(self._act_out), B, self.Da, self.K, ops.stream())
+        self._act_flip ^= 1
+        self.hidden_state = torch.stack(new)  # (num_layers, B, H) as nn.RNN's h_n
+        return self._act_out.view(B, 1, self.Da + 1).clone()
 
     def _ensure(self, B, Tm):
         if self._shape == (B, Tm):

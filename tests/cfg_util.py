@@ -68,3 +68,59 @@ def tacorl_cfg(cams=("rgb_static",), device="cpu", **over):
            "dr3_coefficient": 0.03, "with_vib": False, "vib_coefficient": 0.03, "real_world": True, "device": device}
     cfg.update(over)
     return cfg
+
+
+def write_reference_run_dir(root, lmp_state_dict, latent=16, T=16, cams=("rgb_static",), extra_ckpts=()):
+    """A PlayLMP run directory as the reference's training leaves it (Hydra's `.hydra/config.yaml` with its
+    interpolations unresolved - `${latent_plan_dim}`, `${datamodule.dataset.max_window_size}`,
+    config/networks/plan_recognition/transformer.yaml:7,13 - and PL checkpoints under model_ckpts/): what
+    `load_pl_module_from_checkpoint` (utils/networks.py:90-142) and TACORL(play_lmp_dir=...) consume."""
+    import os
+
+    import torch
+    import yaml
+
+    cams = list(cams)
+    pr = dict(plan_recognition(latent, T), latent_plan_dim="${latent_plan_dim}",
+              max_position_embeddings="${datamodule.dataset.max_window_size}")
+    ad = dict(action_decoder(latent), latent_plan_dim="${latent_plan_dim}")
+    cfg = {
+        "latent_plan_dim": latent, "seed": 42,
+        "datamodule": {"dataset": {"max_window_size": T, "min_window_size": T}},
+        "module": {"_target_": "tacorl.modules.play_lmp.play_lmp_for_rl.PlayLMP", "_recursive_": False,
+                   "plan_proposal": ACTOR, "plan_recognition": pr, "goal_encoder": GOAL_ENC,
+                   "perceptual_encoder": representation(cams), "action_decoder": ad, "lr": 1e-4, "kl_beta": 1e-3,
+                   "plan_proposal_obs_modalities": cams, "plan_proposal_goal_modalities": cams,
+                   "plan_recognition_modalities": cams, "action_decoder_modalities": cams, "real_world": True},
+    }
+    os.makedirs(os.path.join(root, ".hydra"), exist_ok=True)
+    os.makedirs(os.path.join(root, "model_ckpts"), exist_ok=True)
+    with open(os.path.join(root, ".hydra", "config.yaml"), "w") as f:
+        yaml.safe_dump(cfg, f)
+    ck = {"epoch": 3, "global_step": 30, "pytorch-lightning_version": "1.6.5", "state_dict": dict(lmp_state_dict),
+          "hyper_parameters": {"lr": 1e-4}}
+    torch.save(ck, os.path.join(root, "model_ckpts", "last.ckpt"))
+    for name, sd in extra_ckpts:
+        torch.save(dict(ck, state_dict=dict(sd)), os.path.join(root, "model_ckpts", name))
+    return root
+
+
+def lmp_state_dict_from_tacorl(params):
+    """PlayLMP state-dict keys (SURVEY 8a note 9) out of a TACORL parameter dict: the LMP's frozen pieces plus the
+    actor's head / goal encoder standing in for plan_proposal / goal_encoder."""
+    sd = {}
+    for k, v in params.items():
+        if k.startswith(("perceptual_encoder.", "plan_recognition.", "action_decoder.")):
+            sd[k] = v
+        elif k.startswith("actor.actor.policy."):
+            sd["plan_proposal.policy." + k[len("actor.actor.policy."):]] = v
+        elif k.startswith("actor.goal_encoder."):
+            sd[k[len("actor."):]] = v
+    import torch
+
+    # buffers the reference registers (action_decoder_logistic.py:60-62, action_decoder.py:22-40): part of its checkpoints
+    sd.update({"action_decoder.one_hot_embedding_eye": torch.eye(10), "action_decoder.ones": torch.ones(1, 1, 10),
+               "action_decoder.gripper_bounds": torch.tensor([-1.0, 1.0]),
+               "action_decoder.action_max_bound": torch.ones(1, 1, 6, 10),
+               "action_decoder.action_min_bound": -torch.ones(1, 1, 6, 10)})
+    return sd

@@ -28,7 +28,7 @@ class Golden:
 
     def batch(self, step):
         bseed = self.cfg["seed"] * 100 + step
-        if self.cfg["kind"] == "cql":
+        if self.cfg["kind"] in ("cql", "rollout_cql"):
             return synth.make_transition_batch(bseed, self.cfg["B"], self.cams)
         return synth.make_play_batch(bseed, self.cfg["B"], self.cfg["T"], self.cams)
 

@@ -81,3 +81,46 @@ def test_golden_param_layout_is_reference_layout():
               "log_alpha", "log_alpha_prime"):
         assert k in names, k
     assert sum(int(np.prod(s)) for n, s in zip(g.names, g.shapes) if n.startswith("q1.")) == 352226
+
+
+def test_rollout_surface_matches_reference():
+    """actor.get_actions (deterministic / sampled), the frozen LMP encoder's state and three
+    action_decoder.act steps with the carried hidden state, as the reference's rollout manager calls them."""
+    g = Golden("rollout_tacorl")
+    z, P, cams = g.z, g.params(), sorted(g.cams)
+    spec = O.ACSpec(cams=cams, goal_cams=cams, action_dim=g.cfg["latent"], discrete_gripper=False, target_entropy=-7.0,
+                    ac_cams=cams, pr_cams=cams)
+    batch, tape = g.batch(0), g.tape(0)
+    assert [k for k, _ in tape] == ["normal"] + ["rand"] * 6
+    obs0 = {c: v[:, 0] for c, v in batch["states"].items()}
+    with torch.no_grad():
+        plan, lp = O.actor_get_actions(P, "actor.", obs0, batch["goal"], spec, deterministic=True)
+        assert torch.allclose(plan, torch.from_numpy(z["plan"]), rtol=1e-5, atol=1e-6) and float(lp.abs().max()) == 0.0
+        ps, lps = O.actor_get_actions(P, "actor.", obs0, batch["goal"], spec, noise={"eps": tape[0][1]})
+        assert torch.allclose(ps, torch.from_numpy(z["plan_sampled"]), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(lps, torch.from_numpy(z["logpi_sampled"]), rtol=1e-5, atol=1e-5)
+        h = None
+        for t in range(3):
+            emb = O.late_fusion(P, "perceptual_encoder.", {c: v[:, t] for c, v in batch["states"].items()}, cams)
+            assert torch.allclose(emb, torch.from_numpy(z["ad_state"][t]), rtol=1e-5, atol=1e-6)
+            a, h = O.action_decoder_act(P, "action_decoder.", plan, emb.unsqueeze(1), h, tape[1 + 2 * t][1], tape[2 + 2 * t][1])
+            assert torch.allclose(a, torch.from_numpy(z["actions"][t]), rtol=1e-4, atol=1e-5), t
+        assert torch.allclose(h, torch.from_numpy(z["hidden"]), rtol=1e-5, atol=1e-6)
+
+
+def test_rollout_discrete_gripper_actions_match_reference():
+    g = Golden("rollout_cql")
+    z, P, cams = g.z, g.params(), sorted(g.cams)
+    spec = O.ACSpec(cams=cams, goal_cams=cams, action_dim=7, discrete_gripper=True, target_entropy=-7.0)
+    o, tape = g.batch(0)["observations"], g.tape(0)
+    assert [k for k, _ in tape] == ["normal", "uniform01", "normal", "rand"]
+    with torch.no_grad():
+        a, _ = O.actor_get_actions(P, "actor.", o["observation"], o["goal"], spec, deterministic=True)
+        assert torch.allclose(a, torch.from_numpy(z["act_det"]), rtol=1e-5, atol=1e-6)
+        a, lp = O.actor_get_actions(P, "actor.", o["observation"], o["goal"], spec, noise={"eps": tape[0][1], "gumbel_u": tape[1][1]})
+        assert torch.allclose(a, torch.from_numpy(z["act_sample"]), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(lp, torch.from_numpy(z["logpi_sample"]), rtol=1e-5, atol=1e-5)
+        a, lp = O.actor_get_actions(P, "actor.", o["observation"], o["goal"], spec, reparameterize=True,
+                                    noise={"eps": tape[2][1], "gumbel_u": tape[3][1]})
+        assert torch.allclose(a, torch.from_numpy(z["act_rsample"]), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(lp, torch.from_numpy(z["logpi_rsample"]), rtol=1e-5, atol=1e-5)
