@@ -205,6 +205,50 @@ def step_time_distribution(mod, batch, ms_guess, min_seconds=1.0, max_steps=4000
             "how": "hipEvent after every training_step on torch's current stream"}
 
 
+def time_feeder(mod, a, B, T, H, W, dev, barrier, max_over_ranks, n_frames=40000):
+    """The step fed by the replay data path instead of a resident batch: per step the host samples window / goal
+    indices (PlayIndex, the reference's PlayDataset logic), the frames come out of the uint8 dataset (HBM gather, or
+    pinned host memory -> staging ring -> H2D on a copy stream, one batch ahead) and are normalised (optionally
+    augmented) on the way into the encoder's buffers."""
+    import numpy as np
+
+    from tacorl_amd.data.augment import AugmentSpec, draw_play_batch_augmentation
+    from tacorl_amd.data.replay import HbmReplay, PinnedReplay, PlayIndex
+
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (n_frames, H, W, 3), dtype=torch.uint8, generator=g)
+    acts = np.random.RandomState(6).uniform(-1, 1, size=(n_frames, 7)).astype(np.float32)
+    ix = PlayIndex([[i, i + 1999] for i in range(0, n_frames, 2000)], T, T, goal_sampling_prob=0.3)
+    rng = np.random.default_rng(7)
+    spec = {"rgb_static": AugmentSpec(pad=4)} if a.augment else None
+    rep = (HbmReplay if a.feeder == "hbm" else PinnedReplay)({"rgb_static": frames}, acts, ix, dev)
+
+    def draw():
+        return rng.integers(len(ix), size=B), ix.draw(B, rng), (draw_play_batch_augmentation(spec, B, T, dev) if spec else None)
+
+    def run(steps):
+        if a.feeder == "pinned":
+            rep.prefetch(*draw())
+        for _ in range(steps):
+            if a.feeder == "pinned":
+                b = rep.next()
+                rep.prefetch(*draw())  # host gather + H2D of the next batch overlap this step
+            else:
+                b = rep.batch(*draw())
+            mod.training_step(b)
+
+    run(max(a.warmup, 3))
+    barrier()
+    t0 = time.perf_counter()
+    run(a.steps)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    return {"kind": a.feeder, "augment": bool(a.augment), "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "steps_per_s": round(a.steps / dt, 2), "dataset_frames": n_frames,
+            "bytes_per_step_uint8": int(B * (T + 1) * H * W * 3),
+            "note": "hbm: nothing but indices/actions crosses PCIe; pinned: PCIe-inclusive (host gather + H2D, one batch ahead)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +263,11 @@ def main():
     ap.add_argument("--ad-every", type=int, default=1,
                     help="evaluate the (logging-only, frozen) action-decoder loss every k-th step; 1 = every step "
                          "as the reference does")
+    ap.add_argument("--feeder", default="none", choices=["none", "hbm", "pinned"],
+                    help="also time the step fed by the replay data path (SURVEY 8f N2/N3): hbm = uint8 dataset resident in HBM, "
+                         "windows gathered on the GPU; pinned = dataset in pinned host memory, host gather + H2D on a copy stream "
+                         "one batch ahead (the PCIe-inclusive number).  Reported in a `feeder` block; `value` is unchanged")
+    ap.add_argument("--augment", action="store_true", help="with --feeder: RandomShiftsAug + ColorJitter on the way in")
     ap.add_argument("--frames", default="f32", choices=["f32", "u8"],
                     help="f32: the reference's batch schema (transformed fp32 CHW frames; the contract of `value`); "
                          "u8: the dataset's uint8 HWC frames, normalised on the GPU (SURVEY 8f N2; reported in DESIGN.md)")
@@ -313,6 +362,12 @@ def main():
             for _ in range(3):  # back to the bench shape for the roofline probe below
                 mod.training_step(batch)
 
+    feeder = None
+    if a.feeder != "none":
+        feeder = time_feeder(mod, a, B, T, H, W, dev, barrier, max_over_ranks)
+        for _ in range(3):
+            mod.training_step(batch)
+
     out = None
     if rank == 0:
         enc_ms, n_img, fused = time_encoder_fwd(mod, B, H, W)
@@ -337,6 +392,7 @@ def main():
                        "replicas_in_sync": in_sync},
             "step_time": dist_stats,
             "strong": strong,
+            "feeder": feeder,
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tflops / peak, 4), "traffic": measured_traffic(n_img, fused, a.dtype),
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",

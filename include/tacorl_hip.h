@@ -216,6 +216,22 @@ int tacorl_pack_images_batch(int njobs, const float* const* src, const long* img
  * bytes read.  Jobs as in tacorl_pack_images_batch; pitches in bytes; H*W*3 % 16 == 0, 16-byte aligned. */
 int tacorl_pack_images_u8_batch(int njobs, const void* const* src, const long* img_pitch_bytes, void* const* dst,
                                 const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream);
+/* Replay data path on the GPU.
+ * tacorl_gather_frames_u8: dst[i] = frames[index[i]] - a step's window / goal frames out of the uint8 HWC dataset
+ * resident in HBM (reference datamodule/dataset/play_dataset.py:357-419 loads them from per-frame .npz files);
+ * frame_bytes % 16 == 0, index: device int64[n].
+ * tacorl_pack_images_u8_aug_batch: the reference's train-time image pipeline on the way into the NHWC image
+ * buffers (config/datamodule/transform_manager/transforms/rl_train.yaml): RandomShiftsAug (utils/transforms.py:
+ * 265-299; shift[i] = (sx, sy) in [0, 2*pad], the reference's randint draw - an integer shift of the replicate-padded
+ * frame), x/255, torchvision ColorJitter (utils/transforms.py:302-330; jitter[i] = {brightness factor, contrast
+ * factor, hue shift, the 4 drawn positions of fn_idx (0 brightness, 1 contrast, 2 saturation = unused, 3 hue),
+ * apply flag}), Normalize(0.5, 0.5).  shift / jitter: device tables per job, NULL (array or entry) = that stage off. */
+int tacorl_gather_frames_u8(const void* frames, long frame_bytes, const long* index, void* dst, long n,
+                            tacorl_stream_t stream);
+int tacorl_pack_images_u8_aug_batch(int njobs, const void* const* src, const long* img_pitch_bytes,
+                                    void* const* dst, const int* const* shift, const float* const* jitter,
+                                    const int* n_img, int dst_dtype, int H, int W, int pad,
+                                    tacorl_stream_t stream);
 /* reward = done = float(disp == 1) (done may be NULL) and acts_dst[0:n_acts] = acts_src[0:n_acts], one launch:
  * the small tensors of TACORL.get_rl_batch (reference modules/tacorl/tacorl.py:142-179).
  * disp_dtype: 0 float32, 1 int64, 2 int32, 3 uint8 / bool. */

@@ -1,0 +1,184 @@
+"""Play-data replay for the offline step: the window / hindsight-goal sampling of the reference's
+PlayDataset (datamodule/dataset/play_dataset.py:115-169,258-310,452-473) as index arithmetic over frame ids, and two
+frame stores that turn the ids into the module's uint8 batch:
+
+* HbmReplay    - MI355X-first: the whole uint8 dataset lives in HBM (84x84x3 = 21 KB per frame; 2.4 M CALVIN frames
+                 = 50 GB of 288 GB), a step's frames are gathered on the GPU (`tacorl_gather_frames_u8`), nothing
+                 crosses PCIe per step but a few KB of indices and actions;
+* PinnedReplay - the dataset in pinned host memory, gathered by the host into a double-buffered pinned staging
+                 ring and copied H2D on a copy stream one batch ahead (the PCIe-inclusive path).
+
+Every random draw is explicit (`PlayIndex.draw`), so the sampling is a deterministic function that
+tests/golden/play_sampler.npz (recorded from the reference class) pins.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+
+GEOMETRIC, SIMILAR = 0, 1
+
+
+class PlayIndex:
+    def __init__(self, ep_start_end_ids, min_window_size=16, max_window_size=16, goal_sampling_prob=0.3,
+                 goal_strategy_prob=None, goal_augmentation=False, nn_steps_from_step=None, train=True):
+        if min_window_size > max_window_size:
+            raise ValueError(f"min_window_size {min_window_size} > max_window_size {max_window_size}")  # :133-137
+        self.ep = np.asarray(ep_start_end_ids, dtype=np.int64).reshape(-1, 2)
+        self.min_ws, self.max_ws, self.train = int(min_window_size), int(max_window_size), train
+        self.p_geom_goal = float(goal_sampling_prob)
+        gs = goal_strategy_prob or {"geometric": 0.5, "similar_robot_obs": 0.5}
+        if not np.isclose(sum(gs.values()), 1.0):
+            raise ValueError("Goal strategy probability must sum to 1")  # :93-96
+        self.p_strategy = np.array([gs.get("geometric", 0.0), gs.get("similar_robot_obs", 0.0)])
+        self.goal_augmentation = bool(goal_augmentation)
+        self.nn = {int(k): np.asarray(v, dtype=np.int64) for k, v in (nn_steps_from_step or {}).items()}
+        # load_file_indices (:452-473): every start frame that leaves room for a max-size window
+        look = []
+        for s, e in self.ep:
+            assert e > self.max_ws
+            look.append(np.arange(s, e + 1 - self.max_ws))
+        self.episode_lookup = np.concatenate(look) if look else np.zeros(0, np.int64)
+
+    def __len__(self):
+        return len(self.episode_lookup)
+
+    def draw(self, n, rng):
+        """The random quantities one batch of n items consumes, as the reference draws them per item:
+        window size ~ randint(min, max+1) (:121-124), strategy ~ choice(p) (:171-174), disp ~ geometric(p) (:270),
+        noise_step ~ randint(3)-1 (:273), and two uniforms that pick the similar-robot-obs goal / the random state."""
+        return {"window_size": rng.integers(self.min_ws, self.max_ws + 1, size=n),
+                "strategy": (rng.random(n) >= self.p_strategy[0]).astype(np.int64),
+                "disp": rng.geometric(self.p_geom_goal, size=n), "noise_step": rng.integers(0, 3, size=n) - 1,
+                "u_choice": rng.random(n), "u_random_state": rng.random(n)}
+
+    def episode_end(self, step):
+        """find_episode_end (:238-242): end (inclusive) of the first episode with start <= step <= end, -1 if none."""
+        step = np.asarray(step)
+        k = np.searchsorted(self.ep[:, 0], step, side="right") - 1
+        ok = (k >= 0) & (step <= self.ep[np.maximum(k, 0), 1])
+        return np.where(ok, self.ep[np.maximum(k, 0), 1], -1)
+
+    def sample(self, idx, d):
+        """idx (n,) dataset indices; d = draw(...).  Returns frame ids (n, max_ws) padded by repetition of the last
+        frame (:300-306), the pad mask, window sizes, the goal frame id and `disp` (geometric k, or -1)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        n = len(idx)
+        ws = np.full(n, self.max_ws) if self.min_ws == self.max_ws else np.asarray(d["window_size"])
+        start = self.episode_lookup[idx]
+        t = np.arange(self.max_ws)[None, :]
+        frames = start[:, None] + np.minimum(t, ws[:, None] - 1)
+        padded = t >= ws[:, None]
+        # goal (:159-169): geometric future state of the same episode, or a frame with a similar robot state
+        strat = np.asarray(d["strategy"])
+        disp = np.asarray(d["disp"]).astype(np.int64)
+        end = self.episode_end(start)
+        goal_step = start + (ws - 1) * disp
+        if self.goal_augmentation:
+            goal_step = goal_step + np.asarray(d["noise_step"])
+        random_state = self.episode_lookup[np.minimum((np.asarray(d["u_random_state"]) * len(self)).astype(np.int64), len(self) - 1)]
+        goal = np.where(end >= 0, np.minimum(end, goal_step), random_state)
+        out_disp = np.where(strat == GEOMETRIC, disp, -1)
+        sim = np.nonzero(strat == SIMILAR)[0]
+        for i in sim:  # ragged neighbour lists: a short host loop over the similar-robot-obs share of the batch
+            opts = self.nn.get(int(start[i] + ws[i] - 1), ())
+            goal[i] = opts[min(int(d["u_choice"][i] * len(opts)), len(opts) - 1)] if len(opts) else random_state[i]
+        return {"frames": frames, "padded": padded, "window_size": ws, "goal": goal, "disp": out_disp, "idx": idx}
+
+
+def pad_actions(actions, frames, padded):
+    """pad_sequence for the relative actions (:289-297): padded steps are zero except the gripper action, which
+    repeats the last real step's.  actions (N,7) host array -> (n, T, 7) float32."""
+    a = np.asarray(actions, dtype=np.float32)[frames]
+    a[..., :-1][padded] = 0.0
+    return a
+
+
+class HbmReplay:
+    """uint8 HWC frames of every camera resident in HBM: frames[cam] = (N,H,W,3) uint8 device tensor."""
+
+    def __init__(self, frames, actions, index, device=None):
+        self.dev = torch.device(device) if device is not None else next(iter(frames.values())).device
+        self.frames = {c: v.to(self.dev).contiguous() for c, v in frames.items()}
+        self.actions = np.asarray(actions, dtype=np.float32)
+        self.index = index
+        self._buf = {}
+
+    def _out(self, key, shape):
+        t = self._buf.get(key)
+        if t is None or t.shape != shape:
+            ops.note_alloc()
+            t = self._buf[key] = torch.empty(shape, dtype=torch.uint8, device=self.dev)
+        return t
+
+    def batch(self, idx, draws, aug=None):
+        s = self.index.sample(idx, draws)
+        n, T = s["frames"].shape
+        ids = torch.from_numpy(np.concatenate([s["frames"].reshape(-1), s["goal"]])).to(self.dev, non_blocking=True)
+        states, goal = {}, {}
+        for c, fr in self.frames.items():
+            H, W = fr.shape[1:3]
+            states[c] = ops.gather_frames_u8(fr, ids[: n * T], self._out(("s", c), (n, T, H, W, 3)))
+            goal[c] = ops.gather_frames_u8(fr, ids[n * T:], self._out(("g", c), (n, H, W, 3)))
+        b = {"states": states, "goal": goal,
+             "actions": torch.from_numpy(pad_actions(self.actions, s["frames"], s["padded"])).to(self.dev, non_blocking=True),
+             "disp": torch.from_numpy(s["disp"]).to(self.dev, non_blocking=True), "idx": torch.from_numpy(s["idx"]),
+             "window_size": torch.from_numpy(s["window_size"])}
+        if aug is not None:
+            b["aug"] = aug
+        return b
+
+
+class PinnedReplay:
+    """The dataset in pinned host memory; a batch is gathered by the host into one of two pinned staging buffers and
+    copied to the device on a copy stream, so the copy of batch k+1 overlaps the step on batch k."""
+
+    def __init__(self, frames, actions, index, device):
+        self.dev = torch.device(device)
+        self.frames = {c: v.contiguous().pin_memory() for c, v in frames.items()}
+        self.actions = np.asarray(actions, dtype=np.float32)
+        self.index = index
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self._slot, self._host, self._dev_buf = 0, [{}, {}], [{}, {}]
+        self._pending = None
+
+    def _stage(self, slot, key, src, ids):
+        shape = (len(ids),) + tuple(src.shape[1:])
+        h = self._host[slot].get(key)
+        if h is None or h.shape != shape:
+            h = self._host[slot][key] = torch.empty(shape, dtype=torch.uint8).pin_memory()
+            ops.note_alloc()
+            self._dev_buf[slot][key] = torch.empty(shape, dtype=torch.uint8, device=self.dev)
+        torch.index_select(src, 0, torch.from_numpy(ids), out=h)
+        return h, self._dev_buf[slot][key]
+
+    def prefetch(self, idx, draws, aug=None):
+        s = self.index.sample(idx, draws)
+        n, T = s["frames"].shape
+        slot = self._slot
+        self._slot ^= 1
+        pairs = []
+        for c, fr in self.frames.items():
+            pairs.append(("states", c, (n, T)) + self._stage(slot, ("s", c), fr, s["frames"].reshape(-1)))
+            pairs.append(("goal", c, (n,)) + self._stage(slot, ("g", c), fr, s["goal"]))
+        acts = torch.from_numpy(pad_actions(self.actions, s["frames"], s["padded"])).pin_memory()
+        b = {"states": {}, "goal": {}}
+        with torch.cuda.stream(self.stream):
+            for kind, c, lead, h, d in pairs:
+                d.copy_(h, non_blocking=True)
+                b[kind][c] = d.view(*lead, *d.shape[1:])
+            b["actions"] = acts.to(self.dev, non_blocking=True)
+            b["disp"] = torch.from_numpy(s["disp"]).pin_memory().to(self.dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        b.update(idx=torch.from_numpy(s["idx"]), window_size=torch.from_numpy(s["window_size"]))
+        if aug is not None:
+            b["aug"] = aug
+        self._pending = (b, ev)
+
+    def next(self):
+        """The prefetched batch; the compute stream waits for its copy."""
+        b, ev = self._pending
+        torch.cuda.current_stream().wait_event(ev)
+        self._pending = None
+        return b

@@ -226,7 +226,13 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
     for c in cams:
         H, W = hw[c]
         v = states[c].to(self.dev)
-        if u8:
+        aug = batch.get("aug") if u8 else None
+        if aug is not None:  # train-time augmentations on the way in, draws as device tables
+            st = aug["states"][c]
+            flat = lambda t: None if t is None else t.reshape(R, t.shape[-1]).contiguous()  # noqa: E731
+            ops.pack_images_u8_aug_batch([(v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), R, flat(st.get("shift")),
+                                           flat(st.get("jitter")))], xd, H, W, aug["pad"][c])
+        elif u8:
             if (H * W * 3) % 16 or v.data_ptr() % 16 or not v.is_contiguous():
                 raise ValueError("uint8 frames: contiguous, 16-byte aligned, H*W*3 a multiple of 16")
             ops.pack_images_u8_batch([(v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), R)], xd, H, W)

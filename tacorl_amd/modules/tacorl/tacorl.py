@@ -143,7 +143,20 @@ class TACORL(CQL_Offline):
                 x3 = e.X3[c].data_ptr()
                 jobs += [(v.data_ptr(), T * 3 * H * W, x3, B), (g.data_ptr(), 3 * H * W, x3 + B * img * esz, B),
                          (v.data_ptr() + sz * (T - 1) * 3 * H * W, T * 3 * H * W, x3 + 2 * B * img * esz, B)]
-            if u8:
+            aug = batch.get("aug") if u8 else None
+            if aug is not None:
+                # train-time augmentations on the way in: the draws arrive as device tables; the obs / next
+                # frames of the transition take the draws of window frames 0 / T-1, as in the reference, where the
+                # transform ran once per window in the dataset
+                st, gl = aug["states"][c], aug["goal"][c]
+                sh, ji = st.get("shift"), st.get("jitter")
+                row = lambda t, k: None if t is None else t[:, k].contiguous()  # noqa: E731
+                flat = lambda t: None if t is None else t.reshape(B * T, t.shape[-1]).contiguous()  # noqa: E731
+                tabs = [(flat(sh), flat(ji))] if c in self.all_modalities else []
+                if c in e.cams:
+                    tabs += [(row(sh, 0), row(ji, 0)), (gl.get("shift"), gl.get("jitter")), (row(sh, T - 1), row(ji, T - 1))]
+                ops.pack_images_u8_aug_batch([j + t for j, t in zip(jobs, tabs)], xd, H, W, aug["pad"][c])
+            elif u8:
                 if (H * W * 3) % 16 or any(j[0] % 16 for j in jobs):
                     raise ValueError("uint8 frames: H*W*3 must be a multiple of 16 and the tensors 16-byte aligned")
                 ops.pack_images_u8_batch(jobs, xd, H, W)  # pitches are in bytes = elements

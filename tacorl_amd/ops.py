@@ -196,6 +196,27 @@ def pack_images_u8_batch(jobs, dst_dtype_flag, H, W):
          (C.c_void_p * k)(*[j[2] for j in jobs]), int_array([j[3] for j in jobs]), dst_dtype_flag, H, W, stream())
 
 
+def pack_images_u8_aug_batch(jobs, dst_dtype_flag, H, W, pad):
+    """jobs: [(src_ptr, image_pitch_bytes, dst_ptr, n_images, shift int32 (n,2) or None, jitter f32 (n,8) or None)]:
+    uint8 HWC frames -> RandomShiftsAug -> /255 -> ColorJitter -> Normalize -> NHWC, one launch."""
+    k = len(jobs)
+    for j in jobs:
+        for t, dt in ((j[4], torch.int32), (j[5], torch.float32)):
+            assert t is None or (t.is_cuda and t.is_contiguous() and t.dtype == dt and t.shape[0] == j[3])
+    call("tacorl_pack_images_u8_aug_batch", k, (C.c_void_p * k)(*[j[0] for j in jobs]), (C.c_long * k)(*[j[1] for j in jobs]),
+         (C.c_void_p * k)(*[j[2] for j in jobs]), ptr_array([j[4] for j in jobs]), ptr_array([j[5] for j in jobs]),
+         int_array([j[3] for j in jobs]), dst_dtype_flag, H, W, int(pad), stream())
+
+
+def gather_frames_u8(frames, index, out):
+    """out[i] = frames[index[i]] (uint8 frames resident in HBM, device int64 index)."""
+    fb = frames[0].numel()
+    assert frames.dtype == torch.uint8 and frames.is_contiguous() and index.dtype == torch.int64 and index.is_cuda
+    assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() == index.numel() * fb
+    call("tacorl_gather_frames_u8", ptr(frames), fb, ptr(index), ptr(out), index.numel(), stream())
+    return out
+
+
 def _at(t, off):
     return C.c_void_p(t.data_ptr() + 4 * off)
 

@@ -1,0 +1,116 @@
+"""SURVEY 8f N2 / N3 on the GPU: the augmenting pack kernel against the CPU restatement of the reference's train
+pipeline (and, for RandomShiftsAug, against the reference class's own recorded outputs), the HBM-resident replay's
+gather, the pinned-host feeder, and a TACORL step fed by them."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pack(frames, shift, jitter, pad, dtype):
+    from tacorl_amd import _lib, ops
+
+    n, H, W, _ = frames.shape
+    out = torch.full((n, H, W, 3), float("nan"), device=DEV, dtype=dtype)
+    ops.pack_images_u8_aug_batch([(frames.data_ptr(), H * W * 3, out.data_ptr(), n, shift, jitter)],
+                                 _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, H, W, pad)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("hw,pad", [(84, 4), (128, 6), (20, 2)])
+def test_augment_pack_matches_oracle(hw, pad):
+    from oracle import augment_oracle as A
+    from tacorl_amd import _lib
+    from tacorl_amd.data.augment import AugmentSpec
+
+    _lib.call("tacorl_hip_init", 0)
+    g = torch.Generator(device=DEV).manual_seed(hw)
+    n = 9
+    frames = torch.randint(0, 256, (n, hw, hw, 3), device=DEV, dtype=torch.uint8, generator=g)
+    frames[1] = 200  # a constant grey frame: hue undefined, contrast mean = the value
+    shift, jitter = AugmentSpec(pad=pad, brightness=0.3, contrast=0.3, hue=0.3).draw(n, DEV, g)
+    jitter[2, 7] = 0.0  # ColorTransform(prob<1): an image that keeps its colours
+    ref = A.train_pipeline(frames.cpu(), shift.cpu(), jitter.cpu(), pad)
+    got = _pack(frames, shift, jitter, pad, torch.float32)
+    assert torch.isfinite(got).all()
+    # hue runs through a piecewise (sextant) map: an image value that lands exactly on a sextant border may take the
+    # neighbouring branch under 1-ulp differences - both branches agree there, so the error stays at rounding level
+    assert (got.cpu() - ref).abs().max().item() < 2e-5, (got.cpu() - ref).abs().max().item()
+    got16 = _pack(frames, shift, jitter, pad, torch.bfloat16)
+    assert (got16.float().cpu() - ref.to(torch.bfloat16).float()).abs().max().item() <= 2.0 ** -7  # one bf16 ulp below 1
+    # stages off: shift only / nothing = the plain normalising pack
+    plain = _pack(frames, None, None, pad, torch.float32)
+    assert torch.equal(plain.cpu(), A.train_pipeline(frames.cpu()))
+    only_shift = _pack(frames, shift, None, pad, torch.float32)
+    assert torch.equal(only_shift.cpu(), A.train_pipeline(frames.cpu(), shift.cpu(), None, pad))
+
+
+def test_random_shift_kernel_matches_reference_outputs():
+    """RandomShiftsAug of the reference itself (tests/golden/augment.npz) -> /255 -> Normalize."""
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment.npz"))
+    for tag in ("a", "b", "c"):
+        n, hw, pad, seed = (int(v) for v in G[f"{tag}/cfg"])
+        frames = torch.from_numpy(np.random.RandomState(seed).randint(0, 256, size=(n, hw, hw, 3)).astype(np.uint8)).to(DEV)
+        got = _pack(frames, torch.from_numpy(G[f"{tag}/shift"]).to(DEV), None, pad, torch.float32)
+        ref = (torch.from_numpy(G[f"{tag}/out"]) / 255.0 - 0.5) / 0.5
+        assert (got.cpu() - ref).abs().max().item() < 2e-4  # the reference's bilinear grid weights (~1e-6 of 255)
+
+
+def _dataset(N=400, hw=84):
+    g = torch.Generator().manual_seed(3)
+    frames = torch.randint(0, 256, (N, hw, hw, 3), dtype=torch.uint8, generator=g)
+    acts = np.random.RandomState(4).uniform(-1, 1, size=(N, 7)).astype(np.float32)
+    acts[:, -1] = np.where(acts[:, -1] >= 0, 1.0, -1.0)
+    return frames, acts
+
+
+def test_hbm_and_pinned_replay_feed_the_step():
+    from tacorl_amd.data.augment import AugmentSpec, draw_play_batch_augmentation
+    from tacorl_amd.data.replay import HbmReplay, PinnedReplay, PlayIndex, pad_actions
+    from tests.test_fullsize_gpu import _mod
+
+    frames, acts = _dataset()
+    ix = PlayIndex([[0, 199], [200, 399]], 16, 16, goal_sampling_prob=0.3)
+    rng = np.random.default_rng(0)
+    B, T = 16, 16
+    idx = rng.integers(len(ix), size=B)
+    draws = ix.draw(B, rng)
+    s = ix.sample(idx, draws)
+    hbm = HbmReplay({"rgb_static": frames}, acts, ix, device=DEV)
+    b = hbm.batch(idx, draws)
+    torch.cuda.synchronize()
+    assert torch.equal(b["states"]["rgb_static"].cpu(), frames[torch.from_numpy(s["frames"])])
+    assert torch.equal(b["goal"]["rgb_static"].cpu(), frames[torch.from_numpy(s["goal"])])
+    assert np.array_equal(b["actions"].cpu().numpy(), pad_actions(acts, s["frames"], s["padded"]))
+    assert np.array_equal(b["disp"].cpu().numpy(), s["disp"])
+    pin = PinnedReplay({"rgb_static": frames}, acts, ix, DEV)
+    pin.prefetch(idx, draws)
+    bp = pin.next()
+    torch.cuda.synchronize()
+    for k in ("states", "goal"):
+        assert torch.equal(bp[k]["rgb_static"], b[k]["rgb_static"])
+    assert torch.equal(bp["actions"], b["actions"]) and torch.equal(bp["disp"], b["disp"])
+    # the step takes the feeder's batch as it is; without augmentation it is the plain uint8 route bit for bit
+    ma, mb = _mod("bf16"), _mod("bf16")
+    torch.manual_seed(7); torch.cuda.manual_seed(7)
+    ma.training_step(b)
+    torch.manual_seed(7); torch.cuda.manual_seed(7)
+    mb.training_step({k: ({c: t.clone() for c, t in v.items()} if isinstance(v, dict) else v) for k, v in bp.items()})
+    torch.cuda.synchronize()
+    assert ma.logged == mb.logged and all(v == v for v in ma.logged.values())
+    # with augmentation: finite, different from the plain step, reproducible for the same draws
+    g = torch.Generator(device=DEV).manual_seed(11)
+    aug = draw_play_batch_augmentation({"rgb_static": AugmentSpec(pad=4)}, B, T, DEV, g)
+    outs = []
+    for _ in range(2):
+        m = _mod("bf16")
+        torch.manual_seed(7); torch.cuda.manual_seed(7)
+        m.training_step(dict(b, aug=aug))
+        torch.cuda.synchronize()
+        outs.append(dict(m.logged))
+    assert outs[0] == outs[1] and all(v == v for v in outs[0].values()) and outs[0] != ma.logged
