@@ -82,12 +82,18 @@ __global__ __launch_bounds__(256) void pack_u8_aug_kernel(AugTbl t, int H, int W
   OutT* __restrict__ dst = reinterpret_cast<OutT*>(jb.dst) + (long)img * H * W * 3;
   const int sx = jb.shift ? jb.shift[2 * img] - pad : 0, sy = jb.shift ? jb.shift[2 * img + 1] - pad : 0;
   float bf = 1.f, cf = 1.f, hf = 0.f;
-  int order[4] = {0, 1, 2, 3};
+  unsigned ord = 0u;  // the drawn order, 2 bits per position: op k = (ord >> 2k) & 3
+  int cpos = 4;       // position of the contrast operation
   bool jit = false;
   if (jb.jitter) {
     const float* p = jb.jitter + 8L * img;
     bf = p[0]; cf = p[1]; hf = p[2];
-    for (int k = 0; k < 4; k++) order[k] = (int)p[3 + k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned op = (unsigned)(int)p[3 + k] & 3u;
+      ord |= op << (2 * k);
+      if (op == 1u) cpos = k;
+    }
     jit = p[7] != 0.f;
   }
   const int npx = H * W;
@@ -97,21 +103,17 @@ __global__ __launch_bounds__(256) void pack_u8_aug_kernel(AugTbl t, int H, int W
     const unsigned char* s = src + ((long)ys * W + xs) * 3;
     r = (float)s[0] / 255.0f; g = (float)s[1] / 255.0f; b = (float)s[2] / 255.0f;  // ScaleImageTensor / ToTensor
   };
-  auto ops_before_contrast = [&](float& r, float& g, float& b, int upto) {
-    for (int k = 0; k < upto; k++) {
-      if (order[k] == 0) { r = clamp01(bf * r); g = clamp01(bf * g); b = clamp01(bf * b); }
-      else if (order[k] == 3) adjust_hue(r, g, b, hf);
-    }
-  };
-  int cpos = 4;
   float mean = 0.f;
   if (jit) {
-    for (int k = 0; k < 4; k++) if (order[k] == 1) cpos = k;
     float part = 0.f;
     for (int px = threadIdx.x; px < npx; px += 256) {
       float r, g, b;
       load(px, r, g, b);
-      ops_before_contrast(r, g, b, cpos);
+      for (int k = 0; k < cpos; k++) {  // the operations drawn before the contrast adjustment
+        const unsigned op = (ord >> (2 * k)) & 3u;
+        if (op == 0u) { r = clamp01(bf * r); g = clamp01(bf * g); b = clamp01(bf * b); }
+        else if (op == 3u) adjust_hue(r, g, b, hf);
+      }
       part += gray_of(r, g, b);
     }
     part = wave_sum(part);
@@ -124,10 +126,10 @@ __global__ __launch_bounds__(256) void pack_u8_aug_kernel(AugTbl t, int H, int W
     load(px, r, g, b);
     if (jit) {
       for (int k = 0; k < 4; k++) {
-        const int op = order[k];
-        if (op == 0) { r = clamp01(bf * r); g = clamp01(bf * g); b = clamp01(bf * b); }
-        else if (op == 1) { r = clamp01(cf * r + (1.f - cf) * mean); g = clamp01(cf * g + (1.f - cf) * mean); b = clamp01(cf * b + (1.f - cf) * mean); }
-        else if (op == 3) adjust_hue(r, g, b, hf);
+        const unsigned op = (ord >> (2 * k)) & 3u;
+        if (op == 0u) { r = clamp01(bf * r); g = clamp01(bf * g); b = clamp01(bf * b); }
+        else if (op == 1u) { r = clamp01(cf * r + (1.f - cf) * mean); g = clamp01(cf * g + (1.f - cf) * mean); b = clamp01(cf * b + (1.f - cf) * mean); }
+        else if (op == 3u) adjust_hue(r, g, b, hf);
       }
     }
     r = (r - 0.5f) / 0.5f; g = (g - 0.5f) / 0.5f; b = (b - 0.5f) / 0.5f;  // Normalize(0.5, 0.5)
