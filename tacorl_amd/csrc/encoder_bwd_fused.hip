@@ -20,6 +20,8 @@
 //   The bias gradient rides on the same MFMAs with an all-ones B fragment.
 #include "enc_bwd_fused.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -414,6 +416,237 @@ __global__ __launch_bounds__(256) void ebw_reduce_kernel(RdArgs a) {
   }
 }
 
+
+// ===================================================================== wgrad, transposing LDS reads
+// Same contraction as ebw_wgrad_kernel - dW[co][tap] = sum_pix dZ[pix][co] * im2col[pix][tap] - without any
+// re-layout of the operands: dZ and the layer input sit in LDS in their natural NHWC order (a coalesced 16-byte
+// copy with a padded pixel pitch; the bf16 image verbatim) and the MFMA fragments, whose reduction index is the
+// PIXEL, come out of gfx950's transposing read (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns of
+// 16-bit elements and each lane receives one COLUMN; every lane supplies the address of its own row, so the "rows" of
+// the im2col operand are simply the input pixels of four consecutive output pixels).  One read gives a lane 4 of its
+// 8 k-values; the pixel order inside a 32-pixel k-step is permuted identically for both operands (group g takes pixels
+// 4g..4g+3 and 16+4g..16+4g+3), which a sum does not see, so that a 32-lane half reads 8 CONSECUTIVE pixels whose
+// padded pitches (160 B) spread over all 64 banks.
+// Replaces: per image ~700 VALU + 180 LDS instructions per wave of plane building (2-byte LDS->LDS moves, 57 % bank
+// conflict cycles) in front of 60 MFMAs.
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+#define LDS_BF4(p) ((__attribute__((address_space(3))) bf16x4v*)(p))
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* lo, const __bf16* hi) {
+  const bf16x4v a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_BF4(lo));
+  const bf16x4v b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_BF4(hi));
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// wave tiling of a layer: MGRP x NGRP x KGRP = 8 waves; a wave owns MT/MGRP m-tiles (16 output channels each) x
+// NTL/NGRP n-tiles (16 taps each) and the k-steps s with s % KGRP == its k group
+template <class L> struct TrTile;
+template <int H, int W> struct TrTile<ConvL<3, 1, 64, 64, H, W>> { static constexpr int MGRP = 2, NGRP = 4, KGRP = 1, NBUF = 2, CIP = 80; };
+template <int H, int W> struct TrTile<ConvL<4, 2, 32, 64, H, W>> { static constexpr int MGRP = 2, NGRP = 4, KGRP = 1, NBUF = 2, CIP = 40; };
+template <int H, int W> struct TrTile<ConvL<8, 4, 3, 32, H, W>> { static constexpr int MGRP = 1, NGRP = 4, KGRP = 2, NBUF = 1, CIP = 3; };
+
+template <class L>
+struct TrGeo {
+  using T = TrTile<L>;
+  static constexpr int NPIX = L::OH * L::OW, KS = (NPIX + 31) / 32, KQ = KS * 32;
+  static constexpr int DZR = L::CO + 16;                       // dZ row pitch (elements): 160 B / 96 B
+  static constexpr int CIP = T::CIP;                           // input pixel pitch (elements)
+  static constexpr int DZ_EL = KQ * DZR;
+  static constexpr int IN_EL = (L::IH * L::IW * CIP + 7) / 8 * 8;
+  static constexpr int BUF_EL = DZ_EL + IN_EL;
+  static constexpr int MPW = L::MT / T::MGRP, NPW = L::NTL / T::NGRP, TPW = MPW * NPW;
+  static constexpr size_t lds_bytes = (size_t)T::NBUF * BUF_EL * 2;
+  static constexpr int SLABF = T::KGRP * (L::CO * L::TAPS + L::CO);  // floats per workgroup slab
+  static_assert(L::MT % T::MGRP == 0 && L::NTL % T::NGRP == 0 && T::MGRP * T::NGRP * T::KGRP == NW, "wave tiling");
+};
+
+template <class L, class InT, class DzT>
+__global__ __launch_bounds__(NT) void ebw_wgrad_tr_kernel(WgArgs a) {
+  using G = TrGeo<L>;
+  using T = TrTile<L>;
+  constexpr bool IMG = sizeof(InT) == 2;  // conv1: the bf16 NHWC image, copied verbatim
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* lds = reinterpret_cast<__bf16*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l16 = lane & 15, q = l16 >> 2, pc = l16 & 3;
+  const int p = blockIdx.x / a.wpp, j0 = blockIdx.x - p * a.wpp;
+  const int n_img = a.n[p];
+  const int ng = w % T::NGRP, mg = (w / T::NGRP) % T::MGRP, kg = w / (T::NGRP * T::MGRP);
+  // zero once: the dZ rows of the padded pixels (never written again) - and everything else, so that no lane ever
+  // feeds an MFMA from uninitialised LDS
+  for (int e = tid; e < (int)(G::lds_bytes / 4); e += NT) reinterpret_cast<uint32_t*>(lds)[e] = 0u;
+  // per-lane tap offsets of the wave's n-tiles (elements, relative to the pixel's first input element)
+  int toff[G::NPW];
+#pragma unroll
+  for (int j = 0; j < G::NPW; j++) {
+    const int nt = ng * G::NPW + j;
+    if constexpr (IMG) {
+      const int tap = 16 * nt + 4 * pc, ky = tap / (L::KW * L::CI), rem = tap - ky * (L::KW * L::CI);
+      toff[j] = ky * L::IW * L::CI + rem;
+    } else {
+      constexpr int CPT16 = L::CI / 16;
+      const int kk = nt / CPT16, c0 = 16 * (nt - kk * CPT16), ky = kk / L::KW, kx = kk - ky * L::KW;
+      toff[j] = (ky * L::IW + kx) * G::CIP + c0 + 4 * pc;
+    }
+  }
+  f32x4 acc[G::MPW][G::NPW], bacc[G::MPW];
+#pragma unroll
+  for (int i = 0; i < G::MPW; i++) {
+    bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < G::NPW; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; j++) ones[j] = (__bf16)1.0f;
+  const InT* in = reinterpret_cast<const InT*>(a.in[p]);
+  const DzT* dz = reinterpret_cast<const DzT*>(a.dz[p]);
+  // ---- staging: 8-element chunks, global -> registers (in flight during the MFMAs) -> LDS
+  constexpr int DCG = L::CO / 8, DCH = G::NPIX * DCG, DCPT = (DCH + NT - 1) / NT;
+  constexpr int ICH = IMG ? L::IH * L::IW * L::CI / 8 : L::IH * L::IW * (L::CI / 8), ICPT = (ICH + NT - 1) / NT;
+  static_assert(!IMG || (L::IH * L::IW * L::CI) % 8 == 0, "image bytes");
+  bf16x8 dpre[DCPT], ipre[ICPT];
+  auto fetch = [&](int img) {
+    const DzT* d = dz + (long)img * G::NPIX * L::CO;
+#pragma unroll
+    for (int r = 0; r < DCPT; r++) {
+      const int c = tid + r * NT;
+      dpre[r] = load8v(d + 8 * (c < DCH ? c : DCH - 1));  // unconditional (clamped): keeps dpre in registers
+    }
+    const InT* s = in + (long)img * L::IH * L::IW * L::CI;
+#pragma unroll
+    for (int r = 0; r < ICPT; r++) {
+      const int c = tid + r * NT;
+      ipre[r] = load8v(s + 8 * (c < ICH ? c : ICH - 1));
+    }
+  };
+  auto put = [&](__bf16* buf) {
+#pragma unroll
+    for (int r = 0; r < DCPT; r++) {
+      const int c = tid + r * NT;
+      if (c < DCH) *reinterpret_cast<bf16x8*>(buf + (c / DCG) * G::DZR + 8 * (c % DCG)) = dpre[r];
+    }
+    __bf16* ib = buf + G::DZ_EL;
+#pragma unroll
+    for (int r = 0; r < ICPT; r++) {
+      const int c = tid + r * NT;
+      if (c < ICH) {
+        if constexpr (IMG) *reinterpret_cast<bf16x8*>(ib + 8 * c) = ipre[r];
+        else *reinterpret_cast<bf16x8*>(ib + (c / (L::CI / 8)) * G::CIP + 8 * (c % (L::CI / 8))) = ipre[r];
+      }
+    }
+  };
+  auto compute = [&](const __bf16* buf) {
+    const __bf16* dzs = buf;
+    const __bf16* ins = buf + G::DZ_EL;
+#pragma unroll
+    for (int s = 0; s < G::KS; s++) {
+      if (T::KGRP > 1 && (s % T::KGRP) != kg) continue;
+      // this lane's two pixels of the k-step (dZ rows of padded pixels are zero; their input address is clamped)
+      const int P0 = 32 * s + 4 * g + q, P1 = P0 + 16;
+      const int Q0 = P0 < G::NPIX ? P0 : G::NPIX - 1, Q1 = P1 < G::NPIX ? P1 : G::NPIX - 1;
+      const int b0 = ((Q0 / L::OW) * L::S * L::IW + (Q0 % L::OW) * L::S) * G::CIP;
+      const int b1 = ((Q1 / L::OW) * L::S * L::IW + (Q1 % L::OW) * L::S) * G::CIP;
+      bf16x8 A[G::MPW];
+#pragma unroll
+      for (int i = 0; i < G::MPW; i++) {
+        const int col = 16 * (mg * G::MPW + i) + 4 * pc;
+        A[i] = tr_frag(dzs + P0 * G::DZR + col, dzs + P1 * G::DZR + col);
+      }
+#pragma unroll
+      for (int j = 0; j < G::NPW; j++) {
+        const bf16x8 B = tr_frag(ins + b0 + toff[j], ins + b1 + toff[j]);
+#pragma unroll
+        for (int i = 0; i < G::MPW; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i], B, acc[i][j], 0, 0, 0);
+      }
+      if (ng == 0) {
+#pragma unroll
+        for (int i = 0; i < G::MPW; i++) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i], ones, bacc[i], 0, 0, 0);
+      }
+    }
+  };
+  __syncthreads();  // zero fill done
+  if constexpr (T::NBUF == 2) {
+    if (j0 < n_img) { fetch(j0); put(lds); }
+    __syncthreads();
+    int k = 0;
+    for (int img = j0; img < n_img; img += a.wpp, k ^= 1) {
+      const int nxt = img + a.wpp;
+      if (nxt < n_img) fetch(nxt);
+      compute(lds + k * G::BUF_EL);
+      if (nxt < n_img) put(lds + (k ^ 1) * G::BUF_EL);
+      __syncthreads();
+    }
+  } else {
+    if (j0 < n_img) fetch(j0);
+    for (int img = j0; img < n_img; img += a.wpp) {
+      __syncthreads();  // the previous image's fragments are consumed
+      put(lds);
+      __syncthreads();
+      if (img + a.wpp < n_img) fetch(img + a.wpp);
+      compute(lds);
+    }
+  }
+  // partial slab in accumulator order: dW tiles [wave][mi][nj][lane][4], then db [KGRP][CO]
+  float* sl = a.slab + (long)blockIdx.x * G::SLABF;
+#pragma unroll
+  for (int i = 0; i < G::MPW; i++)
+#pragma unroll
+    for (int j = 0; j < G::NPW; j++)
+      *reinterpret_cast<f32x4*>(sl + (((w * G::MPW + i) * G::NPW + j) * 64 + lane) * 4) = acc[i][j];
+  if (ng == 0 && l16 == 0) {
+#pragma unroll
+    for (int i = 0; i < G::MPW; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        sl[T::KGRP * L::CO * L::TAPS + kg * L::CO + 16 * (mg * G::MPW + i) + 4 * g + r] = bacc[i][r];
+  }
+}
+
+// Fixed-order sum of the transposing-read kernels' slabs (all three layers, all problems, one launch): one thread per
+// OUTPUT element, over the k groups and then the workgroups.
+struct RdTrArgs {
+  const float* slab[3];
+  float* gw[3][EBW_MAXP];
+  float* gb[3][EBW_MAXP];
+  int co[3], taps[3], mpw[3], npw[3], mgrp[3], ngrp[3], kgrp[3], slabf[3];
+  int wpp, accumulate;
+};
+__global__ __launch_bounds__(256) void ebw_reduce_tr_kernel(RdTrArgs a) {
+  // slab order (coalesced reads): 64 consecutive slab floats per block, the 4 waves take every 4th workgroup slab,
+  // partial sums added 0..3 (fixed order); the k groups of a layer are summed by the same thread
+  __shared__ float sh[4][64];
+  const int l = blockIdx.y % 3, p = blockIdx.y / 3;
+  const int nW = a.co[l] * a.taps[l], per = nW + a.co[l], KG = a.kgrp[l];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), kq = threadIdx.x >> 6;
+  if (blockIdx.x * 64 >= per) return;
+  float sum = 0.f;
+  if (e < per) {
+    const float* s0 = a.slab[l] + (long)p * a.wpp * a.slabf[l];
+    for (int kg = 0; kg < KG; kg++) {
+      // element e of k group kg: dW tiles of the group's waves are contiguous (wave index = kg * MGRP * NGRP + ...)
+      const float* s = s0 + (e < nW ? (long)kg * nW + e : (long)KG * nW + kg * a.co[l] + (e - nW));
+#pragma unroll 8
+      for (int k = kq; k < a.wpp; k += 4) sum += s[(long)k * a.slabf[l]];
+    }
+  }
+  sh[kq][threadIdx.x & 63] = sum;
+  __syncthreads();
+  if (kq == 0 && e < per) {
+    const int t = threadIdx.x;
+    const float v = ((sh[0][t] + sh[1][t]) + sh[2][t]) + sh[3][t];
+    float* o;
+    if (e < nW) {  // slab element (wave-in-group, mi, nj, lane, r) -> dW[co][tap]
+      const int r = e & 3, lane = (e >> 2) & 63, tt = e >> 8;
+      const int nj = tt % a.npw[l], mi = (tt / a.npw[l]) % a.mpw[l], wg = tt / (a.npw[l] * a.mpw[l]);
+      const int ng = wg % a.ngrp[l], mg = wg / a.ngrp[l];
+      const int co = 16 * (mg * a.mpw[l] + mi) + 4 * (lane >> 4) + r, tap = 16 * (ng * a.npw[l] + nj) + (lane & 15);
+      o = a.gw[l][p] + (long)co * a.taps[l] + tap;
+    } else {
+      o = a.gb[l][p] + (e - nW);
+    }
+    *o = a.accumulate ? *o + v : v;
+  }
+}
+
 // ===================================================================== dgrad
 struct DgArgs {
   const void* dz[EBW_MAXP];    // [n][OH*OW][CO]
@@ -589,9 +822,9 @@ WsPlan plan(int nprob, const int* n) {
     w.dz1[p] = off; off += al256((size_t)n[p] * G::L2::IH * G::L2::IW * 32 * 2);
   }
   const size_t nwg = (size_t)nprob * w.wpp;
-  w.slab1 = off; off += al256(nwg * G::L1::SLABF * 4);
-  w.slab2 = off; off += al256(nwg * G::L2::SLABF * 4);
-  w.slab3 = off; off += al256(nwg * G::L3::SLABF * 4);
+  w.slab1 = off; off += al256(nwg * cmax(G::L1::SLABF, TrGeo<typename G::L1>::SLABF) * 4);
+  w.slab2 = off; off += al256(nwg * cmax(G::L2::SLABF, TrGeo<typename G::L2>::SLABF) * 4);
+  w.slab3 = off; off += al256(nwg * cmax(G::L3::SLABF, TrGeo<typename G::L3>::SLABF) * 4);
   w.total = off;
   return w;
 }
@@ -610,6 +843,20 @@ int launch_wgrad(const WgArgs& a, int nwg, hipStream_t st) {
   if (once) return TACORL_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, st, a);
   return TACORL_OK;
+}
+template <class L, class InT, class DzT>
+int launch_wgrad_tr(const WgArgs& a, int nwg, hipStream_t st) {
+  auto kern = ebw_wgrad_tr_kernel<L, InT, DzT>;
+  constexpr size_t lds = TrGeo<L>::lds_bytes;
+  static int once = set_lds(kern, lds);
+  if (once) return TACORL_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, st, a);
+  return TACORL_OK;
+}
+// TACORL_EBW_TR=0 selects the plane-building weight-gradient kernels (A/B measurements); default: transposing reads
+inline bool use_tr() {
+  static const int v = [] { const char* e = getenv("TACORL_EBW_TR"); return e ? atoi(e) : 1; }();
+  return v != 0;
 }
 template <class L, class DzT>
 int launch_dgrad(const DgArgs& a, int nwg, hipStream_t st) {
@@ -657,6 +904,29 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
   d3.wpp = d2.wpp = g3.wpp = g2.wpp = g1.wpp = w.wpp;
   g1.slab = (float*)(base + w.slab1); g2.slab = (float*)(base + w.slab2); g3.slab = (float*)(base + w.slab3);
   int rc;
+  if (use_tr()) {
+    if ((rc = launch_dgrad<L3, float>(d3, nwg, st))) return rc;
+    if ((rc = launch_wgrad_tr<L3, float, float>(g3, nwg, st))) return rc;
+    if ((rc = launch_dgrad<L2, __bf16>(d2, nwg, st))) return rc;
+    if ((rc = launch_wgrad_tr<L2, float, __bf16>(g2, nwg, st))) return rc;
+    if ((rc = launch_wgrad_tr<L1, __bf16, __bf16>(g1, nwg, st))) return rc;
+    RdTrArgs t{};
+    t.slab[0] = g1.slab; t.slab[1] = g2.slab; t.slab[2] = g3.slab;
+    auto fill = [&](int l, auto geo, int co, int taps) {
+      using TG = decltype(geo);
+      t.co[l] = co; t.taps[l] = taps; t.mpw[l] = TG::MPW; t.npw[l] = TG::NPW; t.mgrp[l] = TG::T::MGRP;
+      t.ngrp[l] = TG::T::NGRP; t.kgrp[l] = TG::T::KGRP; t.slabf[l] = TG::SLABF;
+    };
+    fill(0, TrGeo<L1>{}, L1::CO, L1::TAPS); fill(1, TrGeo<L2>{}, L2::CO, L2::TAPS); fill(2, TrGeo<L3>{}, L3::CO, L3::TAPS);
+    t.wpp = w.wpp; t.accumulate = accumulate;
+    for (int p = 0; p < nprob; p++) {
+      t.gw[0][p] = gw1[p]; t.gb[0][p] = gb1[p]; t.gw[1][p] = gw2[p]; t.gb[1][p] = gb2[p];
+      t.gw[2][p] = gw3[p]; t.gb[2][p] = gb3[p];
+    }
+    constexpr int maxper_t = cmax(L1::SLABF, cmax(L2::SLABF, L3::SLABF));
+    hipLaunchKernelGGL(ebw_reduce_tr_kernel, dim3(cdivi(maxper_t, 64), 3 * nprob), dim3(256), 0, st, t);
+    return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+  }
   if ((rc = launch_dgrad<L3, float>(d3, nwg, st))) return rc;
   if ((rc = launch_wgrad<L3, float, float, 2>(g3, nwg, st))) return rc;
   if ((rc = launch_dgrad<L2, __bf16>(d2, nwg, st))) return rc;
