@@ -148,6 +148,14 @@ int tacorl_encoder_bwd_fused_conv(int nprob, const void* const* img, const float
                                   const float* const* act, float* const* grads, const int* n_img, int H,
                                   int W, int accumulate, int prepacked, void* ws, size_t ws_bytes,
                                   tacorl_stream_t stream);
+/* The same, a subset of its launches (parts, a bit mask: 1 soft-argmax backward, 2 dgrad3, 4 wgrad3, 8 dgrad2,
+ * 16 wgrad2, 32 wgrad1, 64 slab reduce; 127 = all), so that a caller can put the weight gradients of conv3 / conv2 on a
+ * second stream beside the dgrad3 -> dgrad2 -> wgrad1 chain.  The caller orders the streams: dgrad2 and wgrad2 read
+ * dgrad3's output, wgrad1 reads dgrad2's, the reduce reads every wgrad's slabs.  Partial calls need prepacked = 1. */
+int tacorl_encoder_bwd_fused_conv_parts(int nprob, const void* const* img, const float* const* params,
+                                        const float* const* act, float* const* grads, const int* n_img, int H,
+                                        int W, int accumulate, int prepacked, int parts, void* ws,
+                                        size_t ws_bytes, tacorl_stream_t stream);
 
 /* ---- MLP = chain of Linear(dims[l] -> dims[l+1]) + acts[l]  ------------------------ */
 /* Parameter block: for each layer W[out][in] then b[out], each 4-float aligned. */

@@ -84,6 +84,7 @@ _SIGS = {
     "tacorl_encoder_bwd_fused_head": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "tacorl_encoder_bwd_fused_fc_wgrad": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "tacorl_encoder_bwd_fused_conv": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "tacorl_encoder_bwd_fused_conv_parts": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "tacorl_mlp_param_layout": (_l, [_i, _p, _p, _p]),
     "tacorl_mlp_act_layout": (_l, [_i, _i, _p, _p, _p, _p]),
     "tacorl_mlp_fwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _p, _i, _p]),

@@ -797,6 +797,13 @@ extern "C" int tacorl_encoder_bwd_fused_conv(int nprob, const void* const* img, 
                                              const float* const* act, float* const* grads, const int* n_img, int H, int W,
                                              int accumulate, int prepacked, void* ws, size_t ws_bytes,
                                              tacorl_stream_t stream) {
+  return tacorl_encoder_bwd_fused_conv_parts(nprob, img, params, act, grads, n_img, H, W, accumulate, prepacked, 127, ws,
+                                             ws_bytes, stream);
+}
+extern "C" int tacorl_encoder_bwd_fused_conv_parts(int nprob, const void* const* img, const float* const* params,
+                                                   const float* const* act, float* const* grads, const int* n_img, int H,
+                                                   int W, int accumulate, int prepacked, int parts, void* ws,
+                                                   size_t ws_bytes, tacorl_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   EncBwdPlan pl;
   if (!enc_bwd_plan(nprob, n_img, H, W, pl)) FAIL(TACORL_EINVAL, "encoder_bwd_fused_conv: geometry %dx%d / nprob %d", H, W, nprob);
@@ -811,11 +818,14 @@ extern "C" int tacorl_encoder_bwd_fused_conv(int nprob, const void* const* img, 
     sb.d_sa[p] = sc + pl.so[p][1]; sb.dz3[p] = sc + pl.so[p][2]; sb.dtp[p] = sc + pl.so[p][5];
     sb.gtemp[p] = grads[p] + pl.po[E_T]; sb.n[p] = n_img[p];
   }
-  if (pl.maxn > 0) {
+  if (pl.maxn > 0 && (parts & 1)) {
     hipLaunchKernelGGL(softargmax_bwd_batch_kernel, dim3((unsigned)pl.maxn, nprob), dim3(256), 0, st, sb, pl.d.c3.OH * pl.d.c3.OW, pl.d.c3.OW);
     hipLaunchKernelGGL(sum_to_scalar_batch_kernel, dim3(nprob), dim3(256), 0, st, sb, accumulate);
   }
-  const int rc = ebw_conv_backward(nprob, pr, H, W, accumulate, (unsigned char*)ws + pl.conv_off, pl.total - pl.conv_off, st, prepacked ? 2 : 0);
+  if (!(parts & EBW_ALL)) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+  // (a partial call must not re-pack the W^T fragments behind a dgrad that is reading them: prepacked or EBW_ALL)
+  if ((parts & EBW_ALL) != EBW_ALL && !prepacked) FAIL(TACORL_EINVAL, "encoder_bwd_fused_conv_parts: partial calls need prepacked fragments");
+  const int rc = ebw_conv_backward(nprob, pr, H, W, accumulate, (unsigned char*)ws + pl.conv_off, pl.total - pl.conv_off, st, prepacked ? 2 : 0, parts & EBW_ALL);
   if (rc != TACORL_OK) FAIL(rc, "encoder_bwd_fused_conv: conv backward launch failed (%d)", rc);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }

@@ -22,5 +22,9 @@ size_t ebw_ws_bytes(int nprob, const int* n_img, int H, int W);
 // dW1,db1,dW2,db2,dW3,db3 (+)= conv backward of every problem; deterministic (fixed reduction order).
 // mode: 0 = pack the W^T fragments, then run; 1 = pack only (needs pr[].w2 / w3 / n only); 2 = run with the
 // fragments already packed in ws for this step's weights.
+// parts: which launches of the conv backward to issue on `st` (all of them = EBW_ALL); a caller that spreads them
+// over two streams orders them with events (dgrad2 and wgrad2 read dgrad3's output, wgrad1 reads dgrad2's, the
+// reduce reads every wgrad's slabs).
+enum { EBW_DGRAD3 = 2, EBW_WGRAD3 = 4, EBW_DGRAD2 = 8, EBW_WGRAD2 = 16, EBW_WGRAD1 = 32, EBW_REDUCE = 64, EBW_ALL = 126 };
 int ebw_conv_backward(int nprob, const EbwProblem* pr, int H, int W, int accumulate, void* ws, size_t ws_bytes,
-                      hipStream_t st, int mode);
+                      hipStream_t st, int mode, int parts = EBW_ALL);

@@ -868,7 +868,7 @@ int launch_dgrad(const DgArgs& a, int nwg, hipStream_t st) {
   return TACORL_OK;
 }
 template <class G>
-int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int mode) {
+int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int mode, int parts) {
   using L1 = typename G::L1; using L2 = typename G::L2; using L3 = typename G::L3;
   int n[EBW_MAXP];
   for (int p = 0; p < nprob; p++) n[p] = pr[p].n;
@@ -905,11 +905,12 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
   g1.slab = (float*)(base + w.slab1); g2.slab = (float*)(base + w.slab2); g3.slab = (float*)(base + w.slab3);
   int rc;
   if (use_tr()) {
-    if ((rc = launch_dgrad<L3, float>(d3, nwg, st))) return rc;
-    if ((rc = launch_wgrad_tr<L3, float, float>(g3, nwg, st))) return rc;
-    if ((rc = launch_dgrad<L2, __bf16>(d2, nwg, st))) return rc;
-    if ((rc = launch_wgrad_tr<L2, float, __bf16>(g2, nwg, st))) return rc;
-    if ((rc = launch_wgrad_tr<L1, __bf16, __bf16>(g1, nwg, st))) return rc;
+    if ((parts & EBW_DGRAD3) && (rc = launch_dgrad<L3, float>(d3, nwg, st))) return rc;
+    if ((parts & EBW_WGRAD3) && (rc = launch_wgrad_tr<L3, float, float>(g3, nwg, st))) return rc;
+    if ((parts & EBW_DGRAD2) && (rc = launch_dgrad<L2, __bf16>(d2, nwg, st))) return rc;
+    if ((parts & EBW_WGRAD2) && (rc = launch_wgrad_tr<L2, float, __bf16>(g2, nwg, st))) return rc;
+    if ((parts & EBW_WGRAD1) && (rc = launch_wgrad_tr<L1, __bf16, __bf16>(g1, nwg, st))) return rc;
+    if (!(parts & EBW_REDUCE)) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
     RdTrArgs t{};
     t.slab[0] = g1.slab; t.slab[1] = g2.slab; t.slab[2] = g3.slab;
     auto fill = [&](int l, auto geo, int co, int taps) {
@@ -927,6 +928,7 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
     hipLaunchKernelGGL(ebw_reduce_tr_kernel, dim3(cdivi(maxper_t, 64), 3 * nprob), dim3(256), 0, st, t);
     return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
   }
+  if (parts != EBW_ALL) return TACORL_EINVAL;  // the plane-building kernels run as one sequence
   if ((rc = launch_dgrad<L3, float>(d3, nwg, st))) return rc;
   if ((rc = launch_wgrad<L3, float, float, 2>(g3, nwg, st))) return rc;
   if ((rc = launch_dgrad<L2, __bf16>(d2, nwg, st))) return rc;
@@ -970,9 +972,9 @@ size_t ebw_ws_bytes(int nprob, const int* n_img, int H, int W) {
   return 0;
 }
 int ebw_conv_backward(int nprob, const EbwProblem* pr, int H, int W, int accumulate, void* ws, size_t ws_bytes,
-                      hipStream_t st, int mode) {
+                      hipStream_t st, int mode, int parts) {
   if (nprob < 1 || nprob > EBW_MAXP) return TACORL_EINVAL;
-#define X(h, w) if (H == h && W == w) return run<Geo<h, w>>(nprob, pr, accumulate, ws, ws_bytes, st, mode);
+#define X(h, w) if (H == h && W == w) return run<Geo<h, w>>(nprob, pr, accumulate, ws, ws_bytes, st, mode, parts);
   EBW_GEOMS(X)
 #undef X
   return TACORL_EINVAL;

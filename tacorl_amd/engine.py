@@ -291,6 +291,7 @@ class ACEngine:
     # MLP weight gradients on side streams (parallel graph branches): they are needed only by Adam, so
     # they leave the dependent chain of the update (1.70 -> 1.60 ms/step at the bench shapes)
     wgrad_side_streams = True
+    conv_wgrad_side_stream = False  # measured: 0.97 -> 1.12 ms/step when on (co-resident workgroups slow the chain); conv3 / conv2 weight gradients beside the dgrad chain (see _encoders_backward)
 
     def _fused_ok(self, c):
         if not self.use_fused or self.compute != BF16 or self.img_dtype != torch.bfloat16:
@@ -626,8 +627,30 @@ class ACEngine:
                 img_p, par_p, act_p, dout_p, grad_p, n_p = pa[:6]
                 # dependent chain: FC-tail input gradients (one launch) -> soft-argmax + conv backward
                 call("tacorl_encoder_bwd_fused_head", 3, par_p, act_p, dout_p, n_p, H, W, pk, ptr(ws), ws.numel(), ops.stream())
-                call("tacorl_encoder_bwd_fused_conv", 3, img_p, par_p, act_p, grad_p, n_p, H, W, 0, pk, ptr(ws), ws.numel(),
-                     ops.stream())
+                if pk and self.conv_wgrad_side_stream:
+                    # conv backward on two streams (two graph branches): the chain dgrad3 -> dgrad2 -> wgrad1 on this one,
+                    # the weight gradients of conv3 / conv2 - which nothing on the chain reads - beside it
+                    conv = lambda parts: call("tacorl_encoder_bwd_fused_conv_parts", 3, img_p, par_p, act_p, grad_p, n_p, H, W, 0,  # noqa: E731
+                                              1, parts, ptr(ws), ws.numel(), ops.stream())
+                    if getattr(self, "_cw_stream", None) is None:
+                        self._cw_stream = torch.cuda.Stream(device=self.dev)
+                    main, side = torch.cuda.current_stream(), self._cw_stream
+                    conv(1)                      # soft-argmax backward: dz3
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        conv(4)                  # wgrad3 (dz3, y2)
+                    conv(2)                      # dgrad3 -> dz2
+                    e1 = torch.cuda.Event()
+                    e1.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(e1)
+                        conv(16)                 # wgrad2 (dz2, y1)
+                    conv(8 | 32)                 # dgrad2 -> dz1, wgrad1 (dz1, image)
+                    main.wait_stream(side)
+                    conv(64)                     # slabs -> gradients
+                else:
+                    call("tacorl_encoder_bwd_fused_conv", 3, img_p, par_p, act_p, grad_p, n_p, H, W, 0, pk, ptr(ws), ws.numel(),
+                         ops.stream())
                 # FC weight gradients last and in line: on a side branch they ran beside the conv-backward
                 # kernels, whose 255 one-per-CU workgroups then no longer fit in one round (+0.13 ms/step)
                 call("tacorl_encoder_bwd_fused_fc_wgrad", 3, act_p, dout_p, grad_p, n_p, H, W, 0, ptr(ws), ws.numel(),
