@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/tacorl_hip.h"
 #include "common.h"
@@ -223,6 +224,9 @@ extern "C" int tacorl_rnn_linear_fwd_batch(int nprob, const void* const* x_bf16,
   // 128 x 64 tiles, 8 waves (two per SIMD): the launch itself takes as long as with 64 x 32 tiles and 4 waves
   // (20 us for three problems; a third stage changes nothing), but it is 192 workgroups instead of 768 and the
   // step's other branches get through beside it: 1.106 -> 1.089 ms/step
+  static const int tile = [] { const char* e = getenv("TACORL_RNN_TILE"); return e ? atoi(e) : 0; }();  // A/B switch
+  if (tile == 1 && M % 128 == 0 && N % 128 == 0) return launch_ring<128, 128, 2, 8>(ab, nprob, (hipStream_t)stream);
+  if (tile == 3 && M % 64 == 0 && N % 128 == 0) return launch_ring<64, 128, 2, 4>(ab, nprob, (hipStream_t)stream);
   if (M % 128 == 0 && N % 64 == 0) return launch_ring<128, 64, 2, 8>(ab, nprob, (hipStream_t)stream);
   return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
 }
