@@ -116,7 +116,9 @@ int tacorl_encoder_fused_supported(int H, int W);
 int tacorl_encoder_pack_weights(int nprob, const float* const* params, void* const* packed,
                                 tacorl_stream_t stream);
 /* act: NULL, or per-problem pointers (NULL entries allowed) to tacorl_encoder_act_layout blocks that
- * receive the fp32 activations tacorl_encoder_bwd needs. */
+ * receive the fp32 activations tacorl_encoder_bwd needs.  Saved activations (act[p] != NULL, layout of
+ * tacorl_encoder_act_layout): y3, the soft-argmax features and fc1 as fp32; y1 and y2 as **bf16** at the start of their
+ * fp32-sized slots - the values the next layer consumed - which is what tacorl_encoder_bwd_fused* read. */
 int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const void* const* packed,
                              const float* const* params, float* const* out, float* const* act,
                              const int* n_img, int H, int W, tacorl_stream_t stream);

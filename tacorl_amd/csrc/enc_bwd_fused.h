@@ -8,8 +8,8 @@
 
 struct EbwProblem {
   const void* img;   // [n][H][W][3] bf16
-  const float* y1;   // [n][OH1*OW1][32] saved conv1 output (post-ReLU, fp32)
-  const float* y2;   // [n][OH2*OW2][64]
+  const void* y1;    // [n][OH1*OW1][32] saved conv1 output (post-ReLU), bf16 (tacorl_encoder_fwd_fused's format)
+  const void* y2;    // [n][OH2*OW2][64] bf16
   const float* dz3;  // [n][OH3*OW3][64] gradient of conv3's pre-activation (fp32)
   const float* w2;   // [64][4][4][32] fp32
   const float* w3;   // [64][3][3][64] fp32

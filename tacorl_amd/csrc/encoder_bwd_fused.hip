@@ -10,13 +10,13 @@
 //          dZ of one image lives in LDS as NHWC with a zero halo, so every A fragment is one aligned
 //          ds_read_b128 at a compile-time offset; W^T fragments stay in registers for the whole kernel.
 //   wgrad  dW[co][tap] = sum_pixels dZ[pixel][co] * im2col[pixel][tap].  The reduction index of an MFMA is
-//          the lane-contiguous one, and it is the *pixel* here, so both operands are re-laid in LDS
-//          pixel-contiguous: dZ as planes [co][q], the input as space-to-depth planes
-//          [(y%S, x%S, ci)][Y*PWP + X]; with q = oy*PWP + ox (rows padded to a multiple of 8) the 8 pixels
-//          a lane needs for tap (ky,kx,ci) are 8 consecutive plane elements at offset (ky/S)*PWP + kx/S.
-//          One plane copy per kx/S, pre-shifted, makes that an aligned ds_read_b128.  Padded q carry dZ = 0.
+//          the lane-contiguous one, and it is the *pixel* here: both operands stay in LDS in their natural NHWC
+//          order and the fragments come out of gfx950's transposing read (see ebw_wgrad_tr_kernel; round 1 re-laid
+//          both operands as pixel-major planes with 2-byte LDS->LDS moves, 2x slower per kernel).
 //          dW accumulates in registers across the images of a workgroup; one partial slab per workgroup,
-//          summed in fixed order by ebw_reduce_kernel (deterministic, no atomics).
+//          summed in fixed order by ebw_reduce_tr_kernel (deterministic, no atomics).
+//   The conv1 / conv2 activations (ReLU mask of the dgrads, im2col operand of the wgrads) arrive as bf16 - the
+//   fused forward saves them that way - dZ3 as fp32 (soft-argmax backward), dZ2 / dZ1 as bf16 (written here).
 //   The bias gradient rides on the same MFMAs with an all-ones B fragment.
 #include "enc_bwd_fused.h"
 
@@ -101,322 +101,6 @@ struct WgArgs {
   int wpp;  // workgroups per problem
 };
 
-// Staging maps are image-independent, so each thread resolves its chunks once per kernel (the index
-// arithmetic - divisions by the plane pitch - would otherwise dominate the per-image work).
-// A chunk = 8 channels x 2 adjacent plane positions: two 8-element source vectors (offset -1 = zeros),
-// eight dword stores (one per channel plane) at dst + j * pitch.
-struct Chunk { int s0, s1, dst; };
-
-// dZ of one image, [OH*OW][CO] -> planes [CO][q = oy*PW + ox] (bf16 pairs), zero at padded q
-template <class L>
-struct DzMap {
-  static constexpr int ND = L::KQ / 2, NCG = L::CO / 8, NCH = ND * NCG, CPT = (NCH + NT - 1) / NT;
-  Chunk ch[CPT];
-  __device__ __forceinline__ void init(int tid) {
-#pragma unroll
-    for (int r = 0; r < CPT; r++) {
-      const int c = tid + r * NT, cg = c / ND, d = c - cg * ND;
-      int so[2];
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int q = 2 * d + h, oy = q / L::PWP, ox = q - oy * L::PWP;
-        so[h] = (oy < L::OH && ox < L::OW) ? (oy * L::OW + ox) * L::CO + 8 * cg : -1;
-      }
-      ch[r] = Chunk{so[0], so[1], c < NCH ? (8 * cg) * (L::DZP / 2) + d : -1};
-    }
-  }
-};
-// layer input of one image, NHWC fp32 [IH][IW][CI] -> space-to-depth planes (bf16 pairs)
-template <class L>
-struct PlMap {
-  static constexpr int NDP = L::PH * L::PWP / 2, NCG = L::CI / 8, NCH = L::S * L::S * NCG * NDP,
-                       CPT = (NCH + NT - 1) / NT;
-  Chunk ch[CPT];
-  __device__ __forceinline__ void init(int tid) {
-#pragma unroll
-    for (int r = 0; r < CPT; r++) {
-      const int c = tid + r * NT, d = c % NDP, t = c / NDP, cg = t % NCG, ph = t / NCG, sy = ph / L::S, sx = ph % L::S;
-      int so[2];
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int pos = 2 * d + h, Y = pos / L::PWP, X = pos - Y * L::PWP, y = L::S * Y + sy, x = L::S * X + sx;
-        so[h] = (X < L::PW && y < L::IH && x < L::IW) ? (y * L::IW + x) * L::CI + 8 * cg : -1;
-      }
-      ch[r] = Chunk{so[0], so[1], c < NCH ? (ph * L::CI + 8 * cg) * (L::PLP / 2) + d : -1};
-    }
-  }
-};
-// Staging is split so that the global loads of image i+1 are in flight during the MFMAs of image i:
-// fetch_chunks = global -> registers (raw bits), put_chunks = registers -> LDS planes (bf16 pairs).
-template <class T> struct RawVec;  // 8 source elements as loaded
-template <> struct RawVec<float> { uint4 q[2]; };
-template <> struct RawVec<__bf16> { uint4 q[1]; };
-// loads are unconditional (callers clamp the address) and masked afterwards: a conditional load would
-// keep the register array in scratch
-__device__ __forceinline__ uint4 mask4(uint4 v, bool on) {
-  const uint32_t m = on ? 0xffffffffu : 0u;
-  return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
-}
-__device__ __forceinline__ void raw_load(RawVec<float>& v, const float* p, bool on) {
-  v.q[0] = mask4(reinterpret_cast<const uint4*>(p)[0], on);
-  v.q[1] = mask4(reinterpret_cast<const uint4*>(p)[1], on);
-}
-__device__ __forceinline__ void raw_load(RawVec<__bf16>& v, const __bf16* p, bool on) {
-  v.q[0] = mask4(reinterpret_cast<const uint4*>(p)[0], on);
-}
-// dword j of the result = {bf16(a[j]) low, bf16(b[j]) high}
-__device__ __forceinline__ void raw_pair(const RawVec<float>& a, const RawVec<float>& b, uint32_t (&o)[8]) {
-  const uint32_t aw[8] = {a.q[0].x, a.q[0].y, a.q[0].z, a.q[0].w, a.q[1].x, a.q[1].y, a.q[1].z, a.q[1].w};
-  const uint32_t bw[8] = {b.q[0].x, b.q[0].y, b.q[0].z, b.q[0].w, b.q[1].x, b.q[1].y, b.q[1].z, b.q[1].w};
-#pragma unroll
-  for (int j = 0; j < 8; j++) o[j] = pack2(__builtin_bit_cast(float, aw[j]), __builtin_bit_cast(float, bw[j]));
-}
-__device__ __forceinline__ void raw_pair(const RawVec<__bf16>& a, const RawVec<__bf16>& b, uint32_t (&o)[8]) {
-  const uint32_t aw[4] = {a.q[0].x, a.q[0].y, a.q[0].z, a.q[0].w}, bw[4] = {b.q[0].x, b.q[0].y, b.q[0].z, b.q[0].w};
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    o[2 * k] = (aw[k] & 0xffffu) | (bw[k] << 16);
-    o[2 * k + 1] = (aw[k] >> 16) | (bw[k] & 0xffff0000u);
-  }
-}
-template <int CPT, class T>
-__device__ __forceinline__ void fetch_chunks(const Chunk (&ch)[CPT], const T* __restrict__ src, RawVec<T> (&v)[CPT][2]) {
-#pragma unroll
-  for (int r = 0; r < CPT; r++) {
-    raw_load(v[r][0], src + (ch[r].s0 >= 0 ? ch[r].s0 : 0), ch[r].dst >= 0 && ch[r].s0 >= 0);
-    raw_load(v[r][1], src + (ch[r].s1 >= 0 ? ch[r].s1 : 0), ch[r].dst >= 0 && ch[r].s1 >= 0);
-  }
-}
-template <int CPT, int PITCH2, class T>
-__device__ __forceinline__ void put_chunks(const Chunk (&ch)[CPT], const RawVec<T> (&v)[CPT][2], uint32_t* dst32) {
-#pragma unroll
-  for (int r = 0; r < CPT; r++) {
-    if (ch[r].dst < 0) continue;
-    uint32_t o[8];
-    raw_pair(v[r][0], v[r][1], o);
-#pragma unroll
-    for (int j = 0; j < 8; j++) dst32[ch[r].dst + j * PITCH2] = o[j];
-  }
-}
-
-// bf16 NHWC image (CI = 3): coalesced raw copy into LDS, then LDS -> planes.  A wave takes every 8th
-// plane; a lane owns the same plane positions in every plane, so their raw offsets are resolved once.
-template <class L>
-struct ImgMap {
-  static constexpr int NDP = L::PH * L::PWP / 2, NJ = (NDP + 63) / 64;
-  static_assert(L::NCOPY == 2, "the image path builds the two plane copies of the stride-4 8x8 convolution");
-  int o[NJ][3];  // raw element offsets of (Y, X), (Y, X+1), (Y, X+2) relative to the plane origin, -1 = outside
-  __device__ __forceinline__ void init(int lane) {
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      const int d = lane + 64 * j, pos = 2 * d, Y = pos / L::PWP, X = pos - Y * L::PWP;
-      // phases (sy, sx) < S never leave the image when IH, IW are multiples of S (asserted below)
-#pragma unroll
-      for (int h = 0; h < 3; h++)
-        o[j][h] = (d < NDP && X + h < L::PW) ? (L::S * Y * L::IW + L::S * (X + h)) * L::CI : -1;
-    }
-  }
-};
-template <class L>
-struct ImgRaw {
-  static constexpr int NCHUNK = L::IH * L::IW * L::CI * 2 / 16, NR = (NCHUNK + NT - 1) / NT;
-  static_assert(L::IH * L::IW * L::CI * 2 % 16 == 0, "image bytes must be a multiple of 16");
-  static_assert(L::IH % L::S == 0 && L::IW % L::S == 0, "image size must be a multiple of the conv1 stride");
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 q[NR];
-  __device__ __forceinline__ void fetch(const __bf16* __restrict__ in, int tid) {
-#pragma unroll
-    for (int r = 0; r < NR; r++) {  // unconditional (clamped) so that q stays in registers
-      const int c = tid + r * NT;
-      q[r] = reinterpret_cast<const u32x4*>(in)[c < NCHUNK ? c : NCHUNK - 1];
-    }
-  }
-  __device__ __forceinline__ void put(__bf16* raw, int tid) const {
-#pragma unroll
-    for (int r = 0; r < NR; r++)
-      if (tid + r * NT < NCHUNK) reinterpret_cast<u32x4*>(raw)[tid + r * NT] = q[r];
-  }
-};
-template <class L>
-__device__ __forceinline__ void transpose_image(const ImgMap<L>& m, uint32_t* pl32, const __bf16* raw, int tid) {
-  const unsigned short* r16 = reinterpret_cast<const unsigned short*>(raw);
-  const int lane = tid & 63, w = tid >> 6;
-  for (int pln = w; pln < L::NPL; pln += NW) {
-    const int ci = pln % L::CI, ph = pln / L::CI, base = ((ph / L::S) * L::IW + ph % L::S) * L::CI + ci;
-#pragma unroll
-    for (int j = 0; j < ImgMap<L>::NJ; j++) {
-      if (lane + 64 * j < ImgMap<L>::NDP) {
-        uint32_t v[3];
-#pragma unroll
-        for (int h = 0; h < 3; h++) v[h] = m.o[j][h] >= 0 ? r16[base + m.o[j][h]] : 0u;
-        pl32[pln * (L::PLP / 2) + lane + 64 * j] = v[0] | (v[1] << 16);                // copy 0: plane[Y][X]
-        pl32[(L::NPL + pln) * (L::PLP / 2) + lane + 64 * j] = v[1] | (v[2] << 16);     // copy 1: plane[Y][X + 1]
-      }
-    }
-  }
-}
-// fp32-activation layers: copy 0 was staged from global memory; copy b = copy 0 shifted by b elements
-// (aligned 16-byte LDS reads, funnel shift by a compile-time amount, aligned writes)
-template <class L>
-__device__ __forceinline__ void shift_copies(__bf16* pl, int tid) {
-  constexpr int C8 = L::PLP / 8;
-  static_assert(L::PLP % 8 == 0 && L::NCOPY <= 3, "plane pitch / tap offsets");
-  for (int c = tid; c < L::NPL * C8; c += NT) {
-    const int pln = c / C8, k8 = (c - pln * C8) * 8;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(pl + pln * L::PLP + k8);
-    const uint4 lo = *reinterpret_cast<const uint4*>(src);
-    const uint32_t w[6] = {lo.x, lo.y, lo.z, lo.w, k8 + 8 < L::PLP ? src[4] : 0u, 0u};
-#pragma unroll
-    for (int b = 1; b < L::NCOPY; b++) {
-      uint32_t o[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) o[k] = b == 1 ? (w[k] >> 16) | (w[k + 1] << 16) : w[k + 1];
-      *reinterpret_cast<uint4*>(pl + (b * L::NPL + pln) * L::PLP + k8) = make_uint4(o[0], o[1], o[2], o[3]);
-    }
-  }
-}
-
-template <class L, class InT>
-constexpr size_t wgrad_lds_bytes() {
-  // bf16-image layers: the raw NHWC image and the dZ planes share one region (raw is dead once the planes
-  // are built; dZ is staged after that)
-  const size_t dz = (size_t)L::CO * L::DZP, raw = sizeof(InT) == 2 ? (size_t)L::IH * L::IW * L::CI : 0;
-  return ((size_t)L::NCOPY * L::NPL * L::PLP + (dz > raw ? dz : raw)) * 2;
-}
-
-// MG = M tiles (16 output channels each) per wave
-template <class L, class InT, class DzT, int MG>
-__global__ __launch_bounds__(NT) void ebw_wgrad_kernel(WgArgs a) {
-  constexpr int NGR = L::MT / MG, WPG = NW / NGR, UPW = L::NTL / WPG;
-  static_assert(L::MT % MG == 0 && NW % NGR == 0 && L::NTL % WPG == 0, "wave tiling");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __bf16* pl = reinterpret_cast<__bf16*>(smem);  // [NCOPY][NPL][PLP]
-  __bf16* dzp = pl + L::NCOPY * L::NPL * L::PLP;  // [CO][DZP]
-  __bf16* raw = dzp;                              // bf16-image layers: raw NHWC image, aliases dzp
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
-  const int p = blockIdx.x / a.wpp, j0 = blockIdx.x - p * a.wpp;
-  for (int e = tid; e < L::NCOPY * L::NPL * L::PLP / 2; e += NT) reinterpret_cast<uint32_t*>(pl)[e] = 0u;
-  const int mgrp = w % NGR, nslot = w / NGR;
-  int poff[UPW];
-#pragma unroll
-  for (int u = 0; u < UPW; u++) {
-    const int n = 16 * (nslot + u * WPG) + i, ky = n / (L::KW * L::CI), kx = (n / L::CI) % L::KW, ci = n % L::CI;
-    poff[u] = ((kx / L::S) * L::NPL + ((ky % L::S) * L::S + (kx % L::S)) * L::CI + ci) * L::PLP + (ky / L::S) * L::PWP + 8 * g;
-  }
-  f32x4 acc[UPW][MG], bacc[MG];
-#pragma unroll
-  for (int j = 0; j < MG; j++) {
-    bacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < UPW; u++) acc[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  bf16x8 ones;
-#pragma unroll
-  for (int j = 0; j < 8; j++) ones[j] = (__bf16)1.0f;
-  const int n_img = a.n[p];
-  const InT* in = reinterpret_cast<const InT*>(a.in[p]);
-  const DzT* dz = reinterpret_cast<const DzT*>(a.dz[p]);
-  const __bf16* arow = dzp + (16 * (mgrp * MG) + i) * L::DZP + 8 * g;
-  constexpr bool IMG = sizeof(InT) == 2;  // bf16 NHWC image (conv1) vs fp32 activations
-  DzMap<L> dmap;
-  dmap.init(tid);
-  typename std::conditional<IMG, ImgMap<L>, PlMap<L>>::type imap;
-  imap.init(IMG ? lane : tid);
-  RawVec<DzT> dzr[DzMap<L>::CPT][2];
-  typename std::conditional<IMG, ImgRaw<L>, RawVec<InT>[std::conditional<IMG, DzMap<L>, PlMap<L>>::type::CPT][2]>::type inr;
-  auto fetch = [&](int img) {
-    fetch_chunks<DzMap<L>::CPT>(dmap.ch, dz + (long)img * L::OH * L::OW * L::CO, dzr);
-    if constexpr (IMG) inr.fetch(in + (long)img * L::IH * L::IW * L::CI, tid);
-    else fetch_chunks<PlMap<L>::CPT>(imap.ch, in + (long)img * L::IH * L::IW * L::CI, inr);
-  };
-  if (j0 < n_img) fetch(j0);
-  for (int img = j0; img < n_img; img += a.wpp) {
-    __syncthreads();  // previous image's fragments consumed (first pass: zero fill visible)
-    if constexpr (IMG) {
-      inr.put(raw, tid);
-      __syncthreads();
-      transpose_image<L>(imap, reinterpret_cast<uint32_t*>(pl), raw, tid);
-      __syncthreads();  // raw is dead: its region now takes the dZ planes
-      put_chunks<DzMap<L>::CPT, L::DZP / 2>(dmap.ch, dzr, reinterpret_cast<uint32_t*>(dzp));
-    } else {
-      put_chunks<DzMap<L>::CPT, L::DZP / 2>(dmap.ch, dzr, reinterpret_cast<uint32_t*>(dzp));
-      put_chunks<PlMap<L>::CPT, L::PLP / 2>(imap.ch, inr, reinterpret_cast<uint32_t*>(pl));
-      __syncthreads();
-      shift_copies<L>(pl, tid);
-    }
-    __syncthreads();
-    if (img + a.wpp < n_img) fetch(img + a.wpp);  // in flight during the MFMAs below
-#pragma unroll
-    for (int s = 0; s < L::KQ / 32; s++) {
-      bf16x8 A[MG];
-#pragma unroll
-      for (int j = 0; j < MG; j++) A[j] = *reinterpret_cast<const bf16x8*>(arow + 16 * j * L::DZP + 32 * s);
-#pragma unroll
-      for (int u = 0; u < UPW; u++) {
-        const bf16x8 B = *reinterpret_cast<const bf16x8*>(pl + poff[u] + 32 * s);
-#pragma unroll
-        for (int j = 0; j < MG; j++) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], B, acc[u][j], 0, 0, 0);
-      }
-      if (nslot == 0) {
-#pragma unroll
-        for (int j = 0; j < MG; j++) bacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], ones, bacc[j], 0, 0, 0);
-      }
-    }
-  }
-  // partial slab in accumulator order (one coalesced 16 B store per tile and lane):
-  //   dW: [wave][u][j][lane][4]   db: [CO] after the CO*TAPS tile floats
-  float* sl = a.slab + (long)blockIdx.x * L::SLABF;
-#pragma unroll
-  for (int u = 0; u < UPW; u++)
-#pragma unroll
-    for (int j = 0; j < MG; j++)
-      *reinterpret_cast<f32x4*>(sl + (((w * UPW + u) * MG + j) * 64 + lane) * 4) = acc[u][j];
-  if (nslot == 0 && i == 0) {
-#pragma unroll
-    for (int j = 0; j < MG; j++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) sl[L::CO * L::TAPS + 16 * (mgrp * MG + j) + 4 * g + r] = bacc[j][r];
-  }
-}
-
-// Sum of the per-workgroup slabs of all three layers and all problems in one launch, fixed order:
-// 4 waves take every 4th slab for 64 consecutive elements, then the four partial sums are added 0..3.
-struct RdArgs {
-  const float* slab[3];
-  float* gw[3][EBW_MAXP];
-  float* gb[3][EBW_MAXP];
-  int nW[3], nB[3], taps[3], mg[3], upw[3], ngr[3];  // wave tiling of each layer's wgrad kernel
-  int wpp, accumulate;
-};
-__global__ __launch_bounds__(256) void ebw_reduce_kernel(RdArgs a) {
-  __shared__ float sh[4][64];
-  const int l = blockIdx.y % 3, p = blockIdx.y / 3, per = a.nW[l] + a.nB[l];
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63), kg = threadIdx.x >> 6;
-  if (blockIdx.x * 64 >= per) return;
-  float sum = 0.f;
-  if (e < per) {
-    const float* s = a.slab[l] + (long)p * a.wpp * per + e;
-#pragma unroll 8
-    for (int k = kg; k < a.wpp; k += 4) sum += s[(long)k * per];  // (loads batch, the adds keep their order)
-  }
-  sh[kg][threadIdx.x & 63] = sum;
-  __syncthreads();
-  if (kg == 0 && e < per) {
-    const float v = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
-    float* o;
-    if (e < a.nW[l]) {  // slab element (wave, u, j, lane, r) -> dW[co][tap]
-      const int r = e & 3, lane = (e >> 2) & 63, t = e >> 8, MG = a.mg[l], UPW = a.upw[l], NGR = a.ngr[l];
-      const int j = t % MG, u = (t / MG) % UPW, w = t / (MG * UPW), mgrp = w % NGR, nslot = w / NGR, WPG = NW / NGR;
-      const int co = 16 * (mgrp * MG + j) + 4 * (lane >> 4) + r, tap = 16 * (nslot + u * WPG) + (lane & 15);
-      o = a.gw[l][p] + (long)co * a.taps[l] + tap;
-    } else {
-      o = a.gb[l][p] + (e - a.nW[l]);
-    }
-    *o = a.accumulate ? *o + v : v;
-  }
-}
-
-
 // ===================================================================== wgrad, transposing LDS reads
 // Same contraction as ebw_wgrad_kernel - dW[co][tap] = sum_pix dZ[pix][co] * im2col[pix][tap] - without any
 // re-layout of the operands: dZ and the layer input sit in LDS in their natural NHWC order (a coalesced 16-byte
@@ -463,7 +147,7 @@ template <class L, class InT, class DzT>
 __global__ __launch_bounds__(NT) void ebw_wgrad_tr_kernel(WgArgs a) {
   using G = TrGeo<L>;
   using T = TrTile<L>;
-  constexpr bool IMG = sizeof(InT) == 2;  // conv1: the bf16 NHWC image, copied verbatim
+  constexpr bool IMG = L::CI < 8;  // conv1: the bf16 NHWC image (3 channels), copied verbatim
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* lds = reinterpret_cast<__bf16*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l16 = lane & 15, q = l16 >> 2, pc = l16 & 3;
@@ -650,7 +334,7 @@ __global__ __launch_bounds__(256) void ebw_reduce_tr_kernel(RdTrArgs a) {
 // ===================================================================== dgrad
 struct DgArgs {
   const void* dz[EBW_MAXP];    // [n][OH*OW][CO]
-  const float* yin[EBW_MAXP];  // [n][IH*IW][CI] layer input (post-ReLU): mask
+  const __bf16* yin[EBW_MAXP];  // [n][IH*IW][CI] layer input (post-ReLU, bf16 as the fused forward saved it): mask
   const uint4* wpk[EBW_MAXP];  // packed W^T fragments
   __bf16* dx[EBW_MAXP];        // [n][IH*IW][CI] masked input gradient = dZ of the previous layer
   int n[EBW_MAXP];
@@ -729,7 +413,7 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
     oidx[t] = (m < L::PH * L::PW && y < L::IH && x < L::IW) ? (y * L::IW + x) * L::CI + 16 * nt + 4 * g : -1;
   }
   const DzT* dz = reinterpret_cast<const DzT*>(a.dz[p]);
-  const float* yin = a.yin[p];
+  const __bf16* yin = a.yin[p];
   __bf16* dx = a.dx[p];
   bf16x8 pre[CPT];
   float ypre[CPY][8];
@@ -822,9 +506,9 @@ WsPlan plan(int nprob, const int* n) {
     w.dz1[p] = off; off += al256((size_t)n[p] * G::L2::IH * G::L2::IW * 32 * 2);
   }
   const size_t nwg = (size_t)nprob * w.wpp;
-  w.slab1 = off; off += al256(nwg * cmax(G::L1::SLABF, TrGeo<typename G::L1>::SLABF) * 4);
-  w.slab2 = off; off += al256(nwg * cmax(G::L2::SLABF, TrGeo<typename G::L2>::SLABF) * 4);
-  w.slab3 = off; off += al256(nwg * cmax(G::L3::SLABF, TrGeo<typename G::L3>::SLABF) * 4);
+  w.slab1 = off; off += al256(nwg * TrGeo<typename G::L1>::SLABF * 4);
+  w.slab2 = off; off += al256(nwg * TrGeo<typename G::L2>::SLABF * 4);
+  w.slab3 = off; off += al256(nwg * TrGeo<typename G::L3>::SLABF * 4);
   w.total = off;
   return w;
 }
@@ -835,15 +519,6 @@ int set_lds(K kern, size_t bytes) {
                  hipSuccess ? 0 : -1;
 }
 
-template <class L, class InT, class DzT, int MG>
-int launch_wgrad(const WgArgs& a, int nwg, hipStream_t st) {
-  auto kern = ebw_wgrad_kernel<L, InT, DzT, MG>;
-  constexpr size_t lds = wgrad_lds_bytes<L, InT>();
-  static int once = set_lds(kern, lds);
-  if (once) return TACORL_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, st, a);
-  return TACORL_OK;
-}
 template <class L, class InT, class DzT>
 int launch_wgrad_tr(const WgArgs& a, int nwg, hipStream_t st) {
   auto kern = ebw_wgrad_tr_kernel<L, InT, DzT>;
@@ -852,11 +527,6 @@ int launch_wgrad_tr(const WgArgs& a, int nwg, hipStream_t st) {
   if (once) return TACORL_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, st, a);
   return TACORL_OK;
-}
-// TACORL_EBW_TR=0 selects the plane-building weight-gradient kernels (A/B measurements); default: transposing reads
-inline bool use_tr() {
-  static const int v = [] { const char* e = getenv("TACORL_EBW_TR"); return e ? atoi(e) : 1; }();
-  return v != 0;
 }
 template <class L, class DzT>
 int launch_dgrad(const DgArgs& a, int nwg, hipStream_t st) {
@@ -893,8 +563,8 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
   for (int p = 0; p < nprob; p++) {
     __bf16* dz2 = (__bf16*)(base + w.dz2[p]);
     __bf16* dz1 = (__bf16*)(base + w.dz1[p]);
-    d3.dz[p] = pr[p].dz3; d3.yin[p] = pr[p].y2; d3.wpk[p] = k3.out[p]; d3.dx[p] = dz2; d3.n[p] = n[p];
-    d2.dz[p] = dz2; d2.yin[p] = pr[p].y1; d2.wpk[p] = k2.out[p]; d2.dx[p] = dz1; d2.n[p] = n[p];
+    d3.dz[p] = pr[p].dz3; d3.yin[p] = (const __bf16*)pr[p].y2; d3.wpk[p] = k3.out[p]; d3.dx[p] = dz2; d3.n[p] = n[p];
+    d2.dz[p] = dz2; d2.yin[p] = (const __bf16*)pr[p].y1; d2.wpk[p] = k2.out[p]; d2.dx[p] = dz1; d2.n[p] = n[p];
     g3.in[p] = pr[p].y2; g3.dz[p] = pr[p].dz3; g3.n[p] = n[p];
     g2.in[p] = pr[p].y1; g2.dz[p] = dz2; g2.n[p] = n[p];
     g1.in[p] = pr[p].img; g1.dz[p] = dz1; g1.n[p] = n[p];
@@ -904,11 +574,11 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
   d3.wpp = d2.wpp = g3.wpp = g2.wpp = g1.wpp = w.wpp;
   g1.slab = (float*)(base + w.slab1); g2.slab = (float*)(base + w.slab2); g3.slab = (float*)(base + w.slab3);
   int rc;
-  if (use_tr()) {
+  {
     if ((parts & EBW_DGRAD3) && (rc = launch_dgrad<L3, float>(d3, nwg, st))) return rc;
-    if ((parts & EBW_WGRAD3) && (rc = launch_wgrad_tr<L3, float, float>(g3, nwg, st))) return rc;
+    if ((parts & EBW_WGRAD3) && (rc = launch_wgrad_tr<L3, __bf16, float>(g3, nwg, st))) return rc;
     if ((parts & EBW_DGRAD2) && (rc = launch_dgrad<L2, __bf16>(d2, nwg, st))) return rc;
-    if ((parts & EBW_WGRAD2) && (rc = launch_wgrad_tr<L2, float, __bf16>(g2, nwg, st))) return rc;
+    if ((parts & EBW_WGRAD2) && (rc = launch_wgrad_tr<L2, __bf16, __bf16>(g2, nwg, st))) return rc;
     if ((parts & EBW_WGRAD1) && (rc = launch_wgrad_tr<L1, __bf16, __bf16>(g1, nwg, st))) return rc;
     if (!(parts & EBW_REDUCE)) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
     RdTrArgs t{};
@@ -928,29 +598,6 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
     hipLaunchKernelGGL(ebw_reduce_tr_kernel, dim3(cdivi(maxper_t, 64), 3 * nprob), dim3(256), 0, st, t);
     return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
   }
-  if (parts != EBW_ALL) return TACORL_EINVAL;  // the plane-building kernels run as one sequence
-  if ((rc = launch_dgrad<L3, float>(d3, nwg, st))) return rc;
-  if ((rc = launch_wgrad<L3, float, float, 2>(g3, nwg, st))) return rc;
-  if ((rc = launch_dgrad<L2, __bf16>(d2, nwg, st))) return rc;
-  if ((rc = launch_wgrad<L2, float, __bf16, 4>(g2, nwg, st))) return rc;
-  if ((rc = launch_wgrad<L1, __bf16, __bf16, 1>(g1, nwg, st))) return rc;
-  RdArgs r{};
-  r.slab[0] = g1.slab; r.slab[1] = g2.slab; r.slab[2] = g3.slab;
-  r.nW[0] = L1::CO * L1::TAPS; r.nW[1] = L2::CO * L2::TAPS; r.nW[2] = L3::CO * L3::TAPS;
-  r.nB[0] = L1::CO; r.nB[1] = L2::CO; r.nB[2] = L3::CO;
-  r.taps[0] = L1::TAPS; r.taps[1] = L2::TAPS; r.taps[2] = L3::TAPS;
-  constexpr int MG1 = 1, MG2 = 4, MG3 = 2;  // must match the launch_wgrad instantiations above
-  r.mg[0] = MG1; r.mg[1] = MG2; r.mg[2] = MG3;
-  r.ngr[0] = L1::MT / MG1; r.ngr[1] = L2::MT / MG2; r.ngr[2] = L3::MT / MG3;
-  r.upw[0] = L1::NTL / (NW / r.ngr[0]); r.upw[1] = L2::NTL / (NW / r.ngr[1]); r.upw[2] = L3::NTL / (NW / r.ngr[2]);
-  r.wpp = w.wpp; r.accumulate = accumulate;
-  for (int p = 0; p < nprob; p++) {
-    r.gw[0][p] = gw1[p]; r.gb[0][p] = gb1[p]; r.gw[1][p] = gw2[p]; r.gb[1][p] = gb2[p];
-    r.gw[2][p] = gw3[p]; r.gb[2][p] = gb3[p];
-  }
-  constexpr int maxper = cmax(L1::SLABF, cmax(L2::SLABF, L3::SLABF));
-  hipLaunchKernelGGL(ebw_reduce_kernel, dim3(cdivi(maxper, 64), 3 * nprob), dim3(256), 0, st, r);
-  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
 }  // namespace

@@ -338,12 +338,11 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
           const f32x4 r0 = {relu1(acc0[0]), relu1(acc0[1]), relu1(acc0[2]), relu1(acc0[3])};
           const f32x4 r1 = {relu1(acc1[0]), relu1(acc1[1]), relu1(acc1[2]), relu1(acc1[3])};
           const u32x2 lo = pack4_bf16(r0[0], r0[1], r0[2], r0[3]), hi = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
-          *reinterpret_cast<u32x4*>(act1 + pm * ACT1_STRIDE + (8 * g) * 2) = u32x4{lo[0], lo[1], hi[0], hi[1]};  // channels 8 g .. 8 g + 7
-          if (P.act) {
-            float* y = P.act + ((long)cur * npx1 + pm) * 32 + 8 * g;
-            *reinterpret_cast<f32x4*>(y) = r0;
-            *reinterpret_cast<f32x4*>(y + 4) = r1;
-          }
+          const u32x4 pk = {lo[0], lo[1], hi[0], hi[1]};
+          *reinterpret_cast<u32x4*>(act1 + pm * ACT1_STRIDE + (8 * g) * 2) = pk;  // channels 8 g .. 8 g + 7
+          // saved for the backward as bf16 - the very value the next layer consumes (ReLU mask of the dgrad, im2col operand
+          // of the wgrad) - at the start of y1's fp32-sized slot: one 16-byte store, half the bytes of the fp32 copy
+          if (P.act) *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(P.act) + ((long)cur * npx1 + pm) * 32 + 8 * g) = pk;
         }
       };
       u32x4 fa[6], fb[6];
@@ -418,12 +417,13 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
               const f32x4 r0 = {relu1(acc0[0]), relu1(acc0[1]), relu1(acc0[2]), relu1(acc0[3])};
               const f32x4 r1 = {relu1(acc1[0]), relu1(acc1[1]), relu1(acc1[2]), relu1(acc1[3])};
               const u32x2 lo = pack4_bf16(r0[0], r0[1], r0[2], r0[3]), hi = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
-              *reinterpret_cast<u32x4*>(act2 + pm * ACT2_STRIDE + (32 * cg + 8 * g) * 2) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+              const u32x4 pk = {lo[0], lo[1], hi[0], hi[1]};
+              *reinterpret_cast<u32x4*>(act2 + pm * ACT2_STRIDE + (32 * cg + 8 * g) * 2) = pk;
               if (P.act) {
-                // wave-uniform base + 32-bit lane offset (a 64-bit per-lane address would be hoisted and spilled)
-                float* y = P.act + (P.a_y2 + (long)cur * (npx2 * 64)) + (unsigned)(pm * 64 + 32 * cg + 8 * g);
-                *reinterpret_cast<f32x4*>(y) = r0;
-                *reinterpret_cast<f32x4*>(y + 4) = r1;
+                // bf16 at the start of y2's slot; wave-uniform base + 32-bit lane offset (a 64-bit per-lane address would be
+                // hoisted and spilled)
+                __bf16* y = reinterpret_cast<__bf16*>(P.act + P.a_y2) + (long)cur * (npx2 * 64) + (unsigned)(pm * 64 + 32 * cg + 8 * g);
+                *reinterpret_cast<u32x4*>(y) = pk;
               }
             }
           }
