@@ -54,7 +54,9 @@ struct ConvL {
   static constexpr int MT = CO / 16, NTL = TAPS / 16;
   static constexpr int SLABF = CO * TAPS + CO;  // floats per partial slab (dW | db)
   // dgrad
-  static constexpr int HA = KA - 1, HB = KB - 1, R = PH + HA, C = PW + HB, PP = CO + 8;
+  // PP: dZ pixel pitch in the dgrad's halo image: 160 B for CO = 64 - with ds_read_b128's lane groups ({0-3,12-15,20-27}, ...)
+  // the 16 (pixel, k-group) pairs of a group then hit 16 distinct 16-byte slots; CO + 8 (144 B) cost 59 % conflict cycles
+  static constexpr int HA = KA - 1, HB = KB - 1, R = PH + HA, C = PW + HB, PP = CO + 16;
   static constexpr int KS = KA * KB * CO / 32;
   static constexpr int NCLS = S * S, NTI = CI / 16;
   static constexpr int MTC = (PH * PW + 15) / 16;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
   const __bf16* yin = a.yin[p];
   __bf16* dx = a.dx[p];
   bf16x8 pre[CPT];
-  float ypre[CPY][8];
+  uint4 ypre[CPY];  // 8 bf16 activations per chunk, raw bits
   auto fetch = [&](int img) {
 #pragma unroll
     for (int r = 0; r < CPT; r++) {
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
 #pragma unroll
     for (int r = 0; r < CPY; r++) {
       const int c = tid + r * NT;
-      if (c < NYC) load8(yin + (long)img * L::IH * L::IW * L::CI + 8 * c, ypre[r]);
+      ypre[r] = *reinterpret_cast<const uint4*>(yin + (long)img * L::IH * L::IW * L::CI + 8 * (c < NYC ? c : NYC - 1));
     }
   };
   auto put = [&](__bf16* buf, unsigned char* mb) {
@@ -434,9 +436,14 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
     for (int r = 0; r < CPY; r++) {
       const int c = tid + r * NT;
       if (c < NYC) {
+        // y > 0 on the bf16 bit pattern: 0x0001 .. 0x7fff (post-ReLU values: no negatives, no NaN)
+        const uint32_t d[4] = {ypre[r].x, ypre[r].y, ypre[r].z, ypre[r].w};
         unsigned b = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) b |= (ypre[r][j] > 0.f ? 1u : 0u) << j;
+        for (int j = 0; j < 4; j++) {
+          b |= ((((d[j] & 0xffffu) - 1u) & 0xffffu) < 0x7fffu ? 1u : 0u) << (2 * j);
+          b |= ((((d[j] >> 16) - 1u) & 0xffffu) < 0x7fffu ? 1u : 0u) << (2 * j + 1);
+        }
         mb[c] = (unsigned char)b;
       }
     }
@@ -572,12 +579,20 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
     gw3[p] = pr[p].g_w3; gb3[p] = pr[p].g_b3;
   }
   d3.wpp = d2.wpp = g3.wpp = g2.wpp = g1.wpp = w.wpp;
+  // the dgrads need < 40 KB of LDS and ~70 registers: two of their workgroups fit on a CU and hide each other's global
+  // latency (a workgroup's image loop waits for the next image's loads every iteration).  TACORL_EBW_DG2=0: one per CU
+  static const int dg2 = [] { const char* e = getenv("TACORL_EBW_DG2"); return e ? atoi(e) : 2; }();
+  long maxn = 1;
+  for (int p = 0; p < nprob; p++) maxn = n[p] > maxn ? n[p] : maxn;
+  const int wpp_d = dg2 > 1 ? (int)((long)dg2 * w.wpp < maxn ? (long)dg2 * w.wpp : maxn) : w.wpp;
+  d3.wpp = d2.wpp = wpp_d;
+  const int nwg_d = nprob * wpp_d;
   g1.slab = (float*)(base + w.slab1); g2.slab = (float*)(base + w.slab2); g3.slab = (float*)(base + w.slab3);
   int rc;
   {
-    if ((parts & EBW_DGRAD3) && (rc = launch_dgrad<L3, float>(d3, nwg, st))) return rc;
+    if ((parts & EBW_DGRAD3) && (rc = launch_dgrad<L3, float>(d3, nwg_d, st))) return rc;
     if ((parts & EBW_WGRAD3) && (rc = launch_wgrad_tr<L3, __bf16, float>(g3, nwg, st))) return rc;
-    if ((parts & EBW_DGRAD2) && (rc = launch_dgrad<L2, __bf16>(d2, nwg, st))) return rc;
+    if ((parts & EBW_DGRAD2) && (rc = launch_dgrad<L2, __bf16>(d2, nwg_d, st))) return rc;
     if ((parts & EBW_WGRAD2) && (rc = launch_wgrad_tr<L2, __bf16, __bf16>(g2, nwg, st))) return rc;
     if ((parts & EBW_WGRAD1) && (rc = launch_wgrad_tr<L1, __bf16, __bf16>(g1, nwg, st))) return rc;
     if (!(parts & EBW_REDUCE)) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
