@@ -96,10 +96,10 @@ def time_encoder_fwd(mod, B, H, W, iters=20):
 
 def measured_traffic(n_img, fused, dtype):
     """HBM bytes per launch of the roofline kernel from the committed PMC passes
-    (profiles/r01_fused_traffic.json: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of this
+    (profiles/r02_fused_traffic.json: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of this
     very command, gfx950 correction applied).  null when this run's launch is not the measured one."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_fused_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_fused_traffic.json")) as f:
             m = json.load(f)["bench_launch"]
     except (OSError, KeyError, ValueError):
         return None
