@@ -74,7 +74,7 @@ __device__ __forceinline__ bf16x8 load_w(const __bf16* __restrict__ W, int K, in
   return on ? bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} : bf16x8{z, z, z, z, z, z, z, z};
 }
 
-__global__ __launch_bounds__(MF_NT) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
+__global__ __launch_bounds__(MF_NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* X = reinterpret_cast<__bf16*>(smem);  // [2][BMF][XP]
   const int p = blockIdx.y, m0 = blockIdx.x * BMF, M = a.M[p];
