@@ -35,3 +35,8 @@ for n in (1, 2, 3):
     f = lambda: ops.call("tacorl_rnn_linear_fwd_batch", n, ops.ptr_array(xs[:n]), ops.ptr_array(wsb[:n]), ops.ptr_array(bb[:n]),
                          ops.ptr_array(adds[:n]), N, ops.ptr_array(ys[:n]), ops.ptr_array(ybs[:n]), M, K, N, ops.int_array([1] * n), ops.stream())
     print(f"batch ring (2-stage) nprob={n}: {timeit(f):.2f} us", flush=True)
+f(); torch.cuda.synchronize()
+for p in range(3):
+    ref = torch.relu(xs[p].float() @ wsb[p].float().T + bb[p] + adds[p])
+    err = (ys[p] - ref).abs().max().item(); errb = (ybs[p].float() - ref).abs().max().item()
+    print(f"problem {p}: max |y - ref| = {err:.3e} (bf16 copy {errb:.3e}), ref max {ref.abs().max().item():.2f}", flush=True)
