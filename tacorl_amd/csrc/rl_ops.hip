@@ -557,64 +557,77 @@ extern "C" int tacorl_actor_qmin(const float* q1, const float* q2, const float* 
 //   L = (1/B) sum_b [ alpha*logpi_b  - Qmin_b            ]   (Q phase:  g_act = dL/da from the critics)
 //   L = (1/B) sum_b [ alpha*logpi_b  - logp_data_b       ]   (BC phase: value = dataset action)
 // d logpi/d mu_j = 2 a_j, d logpi/d logsd_j = -1 + 2 a_j eps_j sd_j (the Normal terms cancel through
-// z = mu + sd*eps), d a_j/d mu_j = 1 - a_j^2, clamp masks as torch.clamp.  One thread per row.
+// z = mu + sd*eps), d a_j/d mu_j = 1 - a_j^2, clamp masks as torch.clamp.
 // bc: also accumulates mean(alpha*logpi - logp_data) into logs (single block when bc).
-__global__ __launch_bounds__(256) void actor_head_bwd_kernel(
+// One workgroup of 1024 threads, one thread per (row, action dim) element (consecutive lanes = consecutive dims: the
+// head / eps / gradient loads coalesce and are independent of each other; with a thread per row and a serial loop over
+// the dims this was 21 us of dependent, strided round trips on the update's chain), then one thread per row for the
+// gripper logits and the per-row loss term.
+__global__ __launch_bounds__(1024) void actor_head_bwd_kernel(
     const float* __restrict__ head, int ld_head, const float* __restrict__ eps, const float* __restrict__ logp,
     const float* __restrict__ g_act1, const float* __restrict__ g_act2, int ld_g, const float* __restrict__ value,
     int ld_value, const int* __restrict__ grip_idx, const float* log_alpha, float grad_scale,
     float* __restrict__ d_head, int B, int Ac, int has_grip, float* logs) {
-  __shared__ float sh[4];
+  __shared__ float sh[16];
   const float alpha = expf(log_alpha[0]);
   const float gl = alpha * grad_scale / (float)B;  // dL/dlogpi
+  const float c = -grad_scale / (float)B;
   float loss = 0.f;
-  for (int b = threadIdx.x + blockIdx.x * 256; b < B; b += 256 * gridDim.x) {
+  const int total = B * Ac;
+#pragma unroll 2
+  for (int e0 = threadIdx.x; e0 < total; e0 += 1024) {
+    const int b = e0 / Ac, j = e0 - b * Ac;
     const float* h = head + (long)b * ld_head;
     float* dh = d_head + (long)b * ld_head;
-    float lpd = 0.f;
-    for (int j = 0; j < Ac; j++) {
-      float mu, sd;
-      head_stats(h, j, Ac, mu, sd);
-      const float e = eps[(long)b * Ac + j];
-      const float a = tanhf(mu + e * sd);
-      float gm = gl * 2.f * a, gs = gl * (-1.f + 2.f * a * e * sd);
-      if (g_act1) {
-        float ga = g_act1[(long)b * ld_g + j] + (g_act2 ? g_act2[(long)b * ld_g + j] : 0.f);
-        gm += ga * (1.f - a * a);
-        gs += ga * (1.f - a * a) * e * sd;
-      }
-      if (value) {  // - (1/B) d logp_data: TanhNormal.log_prob(value), distributions.py:98-109
-        float v = fminf(fmaxf(value[(long)b * ld_value + j], -0.999f), 0.999f);
-        const float zd = 0.5f * logf(fmaxf(1.f + v, 1e-6f) / fmaxf(1.f - v, 1e-6f));
-        const float d = zd - mu, var = sd * sd;
-        lpd += normal_lp(zd, mu, sd) + tanh_corr(zd);
-        const float c = -grad_scale / (float)B;
-        gm += c * (d / var);
-        gs += c * ((d * d) / var - 1.f);
-      }
-      const float mr = h[j], lr = h[Ac + j];
-      dh[j] = (mr >= -9.f && mr <= 9.f) ? gm : 0.f;
-      dh[Ac + j] = (lr >= -5.f && lr <= 2.f) ? gs : 0.f;
+    float mu, sd;
+    head_stats(h, j, Ac, mu, sd);
+    const float e = eps[(long)b * Ac + j];
+    const float a = tanhf(mu + e * sd);
+    float gm = gl * 2.f * a, gs = gl * (-1.f + 2.f * a * e * sd);
+    if (g_act1) {
+      float ga = g_act1[(long)b * ld_g + j] + (g_act2 ? g_act2[(long)b * ld_g + j] : 0.f);
+      gm += ga * (1.f - a * a);
+      gs += ga * (1.f - a * a) * e * sd;
     }
+    if (value) {  // - (1/B) d logp_data: TanhNormal.log_prob(value), distributions.py:98-109
+      float v = fminf(fmaxf(value[(long)b * ld_value + j], -0.999f), 0.999f);
+      const float zd = 0.5f * logf(fmaxf(1.f + v, 1e-6f) / fmaxf(1.f - v, 1e-6f));
+      const float d = zd - mu, var = sd * sd;
+      loss -= normal_lp(zd, mu, sd) + tanh_corr(zd);
+      gm += c * (d / var);
+      gs += c * ((d * d) / var - 1.f);
+    }
+    const float mr = h[j], lr = h[Ac + j];
+    dh[j] = (mr >= -9.f && mr <= 9.f) ? gm : 0.f;
+    dh[Ac + j] = (lr >= -5.f && lr <= 2.f) ? gs : 0.f;
+  }
+  for (int b = threadIdx.x; b < B; b += 1024) {
     if (has_grip) {
       // log pi (and, in BC, log p_data) contain log_softmax(logits)[idx]: d/dlogits = onehot - softmax
+      const float* h = head + (long)b * ld_head;
+      float* dh = d_head + (long)b * ld_head;
       const float l0 = h[2 * Ac], l1 = h[2 * Ac + 1], mx = fmaxf(l0, l1);
       const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
       const int idx = grip_idx[b];
       float g0 = gl * ((idx == 0 ? 1.f : 0.f) - p0), g1 = gl * ((idx == 1 ? 1.f : 0.f) - p1);
       if (value) {
         const int vi = (int)(value[(long)b * ld_value + Ac] / 2.f + 0.5f);
-        const float c = -grad_scale / (float)B;
         g0 += c * ((vi == 0 ? 1.f : 0.f) - p0); g1 += c * ((vi == 1 ? 1.f : 0.f) - p1);
-        lpd += (vi ? l1 : l0) - (mx + logf(e0 + e1));
+        loss -= (vi ? l1 : l0) - (mx + logf(e0 + e1));
       }
       dh[2 * Ac] = g0; dh[2 * Ac + 1] = g1;
     }
-    if (value) loss += alpha * logp[b] - lpd;
+    if (value) loss += alpha * logp[b];
   }
-  if (value && gridDim.x == 1) {
-    loss = block_sum_256(loss, sh);
-    if (threadIdx.x == 0) { logs[LG_ACTOR_LOSS] = loss / (float)B; logs[LG_ALPHA] = alpha; }
+  if (value) {
+    loss = wave_sum(loss);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int i = 0; i < 16; i++) t += sh[i];
+      logs[LG_ACTOR_LOSS] = t / (float)B; logs[LG_ALPHA] = alpha;
+    }
   }
 }
 extern "C" int tacorl_actor_head_bwd(const float* head, int ld_head, const float* eps, const float* logp,
@@ -622,7 +635,7 @@ extern "C" int tacorl_actor_head_bwd(const float* head, int ld_head, const float
                                      int ld_value, const int* grip_idx, const float* log_alpha, float grad_scale,
                                      float* d_head, int B, int Ac, int has_grip, float* logs,
                                      tacorl_stream_t stream) {
-  hipLaunchKernelGGL(actor_head_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, head, ld_head, eps, logp,
+  hipLaunchKernelGGL(actor_head_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, head, ld_head, eps, logp,
                      g_act1, g_act2, ld_g, value, ld_value, grip_idx, log_alpha, grad_scale, d_head, B, Ac, has_grip,
                      logs);
   return LAUNCH_OK();
