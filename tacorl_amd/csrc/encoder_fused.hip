@@ -156,12 +156,21 @@ struct EFGeom {
   static constexpr int OH1 = (H - 8) / 4 + 1, OW1 = (W - 8) / 4 + 1;
   static constexpr int OH2 = (OH1 - 4) / 2 + 1, OW2 = (OW1 - 4) / 2 + 1;
   static constexpr int OH3 = OH2 - 2, OW3 = OW2 - 2;
-  static constexpr int IMG_BYTES = H * W * 6, LDS_IMG = (IMG_BYTES + 15) & ~15;
+  static constexpr int IMG_BYTES = H * W * 6;
   static constexpr int NPX1 = OH1 * OW1, NPX2 = OH2 * OW2, NPX3 = OH3 * OW3;
   static constexpr int ACT1_BYTES = (NPX1 * 80 + 15) & ~15, ACT2_BYTES = (NPX2 * 160 + 15) & ~15;
-  static constexpr int LDS_BYTES = 2 * LDS_IMG + ACT1_BYTES + ACT2_BYTES + EF_CHUNK * (272 + 528);
-  static constexpr bool OK = IMG_BYTES % 16 == 0 && IMG_BYTES <= EF_MAXCH * 256 * 16 && LDS_BYTES <= 160 * 1024 &&
-                             OH3 >= 1 && OW3 >= 1;
+  static constexpr int FIXED_BYTES = ACT1_BYTES + ACT2_BYTES + EF_CHUNK * (272 + 528);
+  // The image buffer is double: two whole images when they fit beside the activations (84 x 84: 2 x 42 KB); otherwise
+  // conv1 runs over BANDS of BR output rows = 4 BR + 4 image rows (128 x 128: 8 bands of 20 rows, 2 x 15 KB; the 4
+  // rows two bands share are fetched twice - from L2), the next band streaming in while the current one is computed.
+  static constexpr bool WHOLE = 2 * ((IMG_BYTES + 15) & ~15) + FIXED_BYTES <= 160 * 1024;
+  static constexpr int BR = WHOLE ? OH1 : 4, NB = (OH1 + BR - 1) / BR;
+  static constexpr int BAND_ROWS = WHOLE ? H : 4 * BR + 4;
+  static constexpr int BAND_BYTES = BAND_ROWS * W * 6, LDS_IMG = (BAND_BYTES + 15) & ~15;
+  static constexpr int NPXB = BR * OW1;  // conv1 output pixels of a full band
+  static constexpr int LDS_BYTES = 2 * LDS_IMG + FIXED_BYTES;
+  static constexpr bool OK = (WHOLE ? IMG_BYTES % 16 == 0 : (W * 6) % 16 == 0) && BAND_BYTES <= EF_MAXCH * 256 * 16 &&
+                             LDS_BYTES <= 160 * 1024 && OH3 >= 1 && OW3 >= 1;
 };
 
 // Phase timing for kernel work (scratch builds with -DEF_STAMPS only; the product build has no trace of it):
@@ -258,9 +267,11 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 
   // ---- image streaming: LDS-DMA (global_load_lds_dwordx4: no staging registers).  One wave-instruction
   // moves 64 x 16 B = 1 KiB from a contiguous global span to a contiguous LDS span (wave-uniform LDS base).
-  const int n16 = a.img_bytes >> 4;  // 16-byte chunks per image
-  auto dma_load = [&](long img_idx, int buf) {
-    const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img) + img_idx * a.img_bytes;
+  auto dma_load = [&](long img_idx, int band, int buf) {
+    const int row0 = G::WHOLE ? 0 : 4 * G::BR * band;                                // first image row of the band
+    const int rows = G::WHOLE ? G::H : min(G::BAND_ROWS, G::H - row0);
+    const int n16 = G::WHOLE ? (G::IMG_BYTES >> 4) : (rows * G::W * 6) >> 4;          // 16-byte chunks to move
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img) + img_idx * G::IMG_BYTES + row0 * (G::W * 6);
     unsigned char* dstb = lds + buf * a.lds_img;
 #pragma unroll
     for (int i = 0; i < EF_MAXCH; i++) {
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
           // inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in the loop hipcc degrades every
           // LDS wait of the conv phases to lgkmcnt(0) (it cannot tell the DMA's LDS writes from the fragment
           // reads), which exposes the full LDS latency at each tile; the ordering against the readers of this
-          // buffer is explicit anyway (vmcnt(0) + barrier at the end of the image).
+          // buffer is explicit anyway (vmcnt(0) + barrier at the end of the image / band).
           const unsigned lds_off = __builtin_amdgcn_readfirstlane(
               (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)(dstb + c0 * 16));  // wave-uniform
           unsigned keep;
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
   // of imbalance); the FC tail runs after every EF_CHUNK processed images (slots) or at the end.
   long cur = worker;
   int it = 0, buf = 0;
-  dma_load(cur, 0);
+  dma_load(cur, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   STAMP(0);  // prologue: weights to registers, first image
@@ -296,17 +307,21 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     const int slot = it & (EF_CHUNK - 1);
     const long nxt = cur + nworkers;
     const bool has_next = nxt < P.n_img;
-    if (has_next) dma_load(nxt, buf ^ 1);  // that buffer was last read by the previous image's conv1
-    STAMP(1);  // DMA issue
-
     // Every conv phase is software-pipelined by hand: the LDS reads of the next half-tile are issued
     // before the MFMA chain of the current one (one wave per SIMD: nothing else hides LDS latency).
-    // ------------------------------------------------ conv1: 8x8 stride 4, 3 -> 32
-    {
+    // ------------------------------------------------ conv1: 8x8 stride 4, 3 -> 32, band by band
+#pragma unroll 1
+    for (int band = 0; band < G::NB; band++) {
+      // the other buffer was last read by the previous band's (or image's) conv1, a barrier ago
+      if (band + 1 < G::NB) dma_load(cur, band + 1, buf ^ 1);
+      else if (has_next) dma_load(nxt, 0, buf ^ 1);
+      STAMP(1);  // DMA issue
       const unsigned char* ib = lds + buf * a.lds_img;
-      constexpr int NT1 = (G::NPX1 + 15) >> 4, PER1 = (NT1 + 3) >> 2;
+      constexpr int NT1 = (G::NPXB + 15) >> 4, PER1 = (NT1 + 3) >> 2;
+      const int npxb = G::WHOLE ? npx1 : min(G::BR, a.OH1 - band * G::BR) * a.OW1;  // output pixels of this band
+      const int nt1 = G::WHOLE ? NT1 : (npxb + 15) >> 4, px0 = band * G::NPXB;
       auto base1 = [&](int mt) {
-        const int pc = min(mt * 16 + r16, npx1 - 1);
+        const int pc = min(mt * 16 + r16, npxb - 1);
         const int oy = pc / a.OW1, ox = pc - oy * a.OW1;
         return ib + ((4 * oy * a.W + 4 * ox) * 3) * 2 + k1g;
       };
@@ -333,8 +348,9 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #pragma unroll                   // MFMAs get no compiler hazard handling: interleaving two chains returned wrong sums)
         for (int s = 1; s < 6; s++) MFMA_AW(acc1, wc1b[s], bf[s]);
         MFMA_CHAIN_END(acc1);
-        const int pm = mt * 16 + r16;
-        if (pm < npx1) {
+        const int pb = mt * 16 + r16;
+        if (pb < npxb) {
+          const int pm = px0 + pb;
           const f32x4 r0 = {relu1(acc0[0]), relu1(acc0[1]), relu1(acc0[2]), relu1(acc0[3])};
           const f32x4 r1 = {relu1(acc1[0]), relu1(acc1[1]), relu1(acc1[2]), relu1(acc1[3])};
           const u32x2 lo = pack4_bf16(r0[0], r0[1], r0[2], r0[3]), hi = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
@@ -349,10 +365,15 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       ld1(base1(w), fa);
 #pragma unroll
       for (int i = 0; i < PER1; i += 2) {
-        if (w + 4 * (i + 1) < NT1 && i + 1 < PER1) ld1(base1(w + 4 * (i + 1)), fb);
-        if (w + 4 * i < NT1) tile1(w + 4 * i, fa);
-        if (w + 4 * (i + 2) < NT1 && i + 2 < PER1) ld1(base1(w + 4 * (i + 2)), fa);
-        if (w + 4 * (i + 1) < NT1 && i + 1 < PER1) tile1(w + 4 * (i + 1), fb);
+        if (w + 4 * (i + 1) < nt1 && i + 1 < PER1) ld1(base1(w + 4 * (i + 1)), fb);
+        if (w + 4 * i < nt1) tile1(w + 4 * i, fa);
+        if (w + 4 * (i + 2) < nt1 && i + 2 < PER1) ld1(base1(w + 4 * (i + 2)), fa);
+        if (w + 4 * (i + 1) < nt1 && i + 1 < PER1) tile1(w + 4 * (i + 1), fb);
+      }
+      if (band + 1 < G::NB) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next band has landed
+        __syncthreads();                                  // ... everyone's, and everyone is done reading this band
+        buf ^= 1;
       }
     }
     STAMP(2);  // conv1
@@ -580,7 +601,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
   }
 }
 
-#define EF_GEOMS(X) X(84, 84) X(64, 64) X(44, 60)
+#define EF_GEOMS(X) X(84, 84) X(64, 64) X(44, 60) X(128, 128)
 
 extern "C" int tacorl_encoder_fused_supported(int H, int W) {
 #define X(h, w) if (H == h && W == w) return EFGeom<h, w>::OK ? 1 : 0;

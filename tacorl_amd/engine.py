@@ -298,6 +298,12 @@ class ACEngine:
             return False
         return bool(ops.L.lib().tacorl_encoder_fused_supported(*self.hw[c]))
 
+    def _fused_bwd_ok(self, c):
+        """The per-image LDS-resident conv backward exists for fewer geometries than the fused forward (128 x 128: forward
+        only); where it does not, the problems that have a backward take the per-layer forward (fp32 activations)."""
+        return self._fused_ok(c) and ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(
+            3, ops.int_array([2 * self.B] * 3), *self.hw[c]) > 0
+
     def _packed(self, net, c):
         key = (id(net), c)
         if key not in self._wpk:
@@ -338,11 +344,14 @@ class ACEngine:
             H, W = self.hw[c]
             pr = self._all_problems(c)
             if self._fused_ok(c):
+                slow = [] if self._fused_bwd_ok(c) else [x for x in pr if x[5]]
+                pr = [x for x in pr if not (slow and x[5])]
                 nets = {id(x[1]): x[1] for x in pr}
                 call("tacorl_encoder_pack_weights", len(nets), ops.ptr_array([n_.enc(c) for n_ in nets.values()]),
                      ops.ptr_array([self._packed(n_, c) for n_ in nets.values()]), ops.stream())
                 self._launch_fused(c, pr)
-            else:
+                pr = slow
+            if pr:
                 call("tacorl_encoder_fwd", len(pr), ops.ptr_array([x[0] for x in pr]),
                      ops.ptr_array([x[1].enc(c) for x in pr]), ops.ptr_array([x[2] for x in pr]),
                      ops.ptr_array([x[3] for x in pr]), ops.int_array([x[4] for x in pr]), H, W, xd, self.compute,
@@ -382,7 +391,7 @@ class ACEngine:
                 ops.mlp_bwd_fused_pack(params, M, dims, "mlp_bwdf_" + tag, self.dev)
             nets = [self.actor, self.q1, self.q2]
             for c in self.cams:
-                if self._fused_ok(c):
+                if self._fused_bwd_ok(c):
                     H, W = self.hw[c]
                     n3 = ops.int_array([2 * self.B] * 3)
                     nb = ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(3, n3, H, W)
@@ -620,7 +629,7 @@ class ACEngine:
                   ops.ptr_array([self.enc_act[(ek[k], c)] for k in ks]),
                   ops.ptr_array([self.enc_dout[(ek[k], c)] for k in ks]),
                   ops.ptr_array([nets[k].enc(c, nets[k].grad) for k in ks]), ops.int_array(ops_n), H, W]
-            if self._fused_ok(c):  # per-image LDS-resident conv backward (encoder_bwd_fused.hip)
+            if self._fused_bwd_ok(c):  # per-image LDS-resident conv backward (encoder_bwd_fused.hip)
                 nb = ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(3, ops.int_array(ops_n), H, W)
                 ws = ops.workspace(nb, self.dev, "enc_bwd_fused_" + c)
                 pk = int(getattr(self, "_prepacked", False))

@@ -285,7 +285,8 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     xd = BF16 if self.img_dtype == torch.bfloat16 else F32
     for j, c in enumerate(cams):
         H, W = hw[c]
-        fused = cd == BF16 and xd == BF16 and bool(ops.L.lib().tacorl_encoder_fused_supported(H, W))
+        fused = (cd == BF16 and xd == BF16 and bool(ops.L.lib().tacorl_encoder_fused_supported(H, W))
+                 and ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(1, ops.int_array([R]), H, W) > 0)  # forward and backward
         if fused:  # one launch for the whole encoder, activations saved for the backward (encoder_fused.hip)
             if getattr(self, "_wpk", None) is None:
                 self._wpk = {}
@@ -340,7 +341,8 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     for j, c in enumerate(cams):
         H, W = hw[c]
         ops.copy_cols(self.d_emb, 32 * j, Ec, self.f_dout[c], 0, 32, R, 32)
-        fused = cd == BF16 and xd == BF16 and bool(ops.L.lib().tacorl_encoder_fused_supported(H, W))
+        fused = (cd == BF16 and xd == BF16 and bool(ops.L.lib().tacorl_encoder_fused_supported(H, W))
+                 and ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(1, ops.int_array([R]), H, W) > 0)  # forward and backward
         ops.encoder_bwd([self.frames[c]], [net.enc(c)], [self.f_act[c]], [self.f_dout[c]], [net.enc(c, net.grad)], H, W, cd,
                         fused=fused)
 

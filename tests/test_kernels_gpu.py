@@ -306,7 +306,7 @@ def test_cql_loss(det_backup, lagrange, n):
         assert abs(g_lap.item() - glap.item()) < 1e-4 * abs(glap.item())
 
 
-@pytest.mark.parametrize("H,W", [(84, 84), (44, 60)])
+@pytest.mark.parametrize("H,W", [(84, 84), (44, 60), (128, 128)])  # 128 x 128: conv1 over row bands
 def test_encoder_fused_forward(H, W):
     """Fused bf16 inference kernel vs the CPU oracle (bf16 tolerance) and vs the generic bf16 path."""
     from oracle import tacorl_oracle as O
