@@ -221,18 +221,20 @@ def time_feeder(mod, a, B, T, H, W, dev, barrier, max_over_ranks, n_frames=40000
     ix = PlayIndex([[i, i + 1999] for i in range(0, n_frames, 2000)], T, T, goal_sampling_prob=0.3)
     rng = np.random.default_rng(7)
     spec = {"rgb_static": AugmentSpec(pad=4)} if a.augment else None
-    rep = (HbmReplay if a.feeder == "hbm" else PinnedReplay)({"rgb_static": frames}, acts, ix, dev)
+    pinned = a.feeder.startswith("pinned")
+    rep = (PinnedReplay({"rgb_static": frames}, acts, ix, dev, gather="host" if a.feeder == "pinned-host" else "device")
+           if pinned else HbmReplay({"rgb_static": frames}, acts, ix, dev))
 
     def draw():
         return rng.integers(len(ix), size=B), ix.draw(B, rng), (draw_play_batch_augmentation(spec, B, T, dev) if spec else None)
 
     def run(steps):
-        if a.feeder == "pinned":
+        if pinned:
             rep.prefetch(*draw())
         for _ in range(steps):
-            if a.feeder == "pinned":
+            if pinned:
                 b = rep.next()
-                rep.prefetch(*draw())  # host gather + H2D of the next batch overlap this step
+                rep.prefetch(*draw())  # the gather of the next batch (over PCIe) overlaps this step
             else:
                 b = rep.batch(*draw())
             mod.training_step(b)
@@ -246,7 +248,8 @@ def time_feeder(mod, a, B, T, H, W, dev, barrier, max_over_ranks, n_frames=40000
     return {"kind": a.feeder, "augment": bool(a.augment), "ms_per_step": round(dt / a.steps * 1e3, 4),
             "steps_per_s": round(a.steps / dt, 2), "dataset_frames": n_frames,
             "bytes_per_step_uint8": int(B * (T + 1) * H * W * 3),
-            "note": "hbm: nothing but indices/actions crosses PCIe; pinned: PCIe-inclusive (host gather + H2D, one batch ahead)"}
+            "note": "hbm: nothing but indices/actions crosses PCIe; pinned: PCIe-inclusive, the GPU gathers the frames out of pinned "
+                    "host memory one batch ahead; pinned-host: host gather into a staging ring + H2D copy"}
 
 
 def main():
@@ -263,10 +266,11 @@ def main():
     ap.add_argument("--ad-every", type=int, default=1,
                     help="evaluate the (logging-only, frozen) action-decoder loss every k-th step; 1 = every step "
                          "as the reference does")
-    ap.add_argument("--feeder", default="none", choices=["none", "hbm", "pinned"],
+    ap.add_argument("--feeder", default="none", choices=["none", "hbm", "pinned", "pinned-host"],
                     help="also time the step fed by the replay data path (SURVEY 8f N2/N3): hbm = uint8 dataset resident in HBM, "
-                         "windows gathered on the GPU; pinned = dataset in pinned host memory, host gather + H2D on a copy stream "
-                         "one batch ahead (the PCIe-inclusive number).  Reported in a `feeder` block; `value` is unchanged")
+                         "windows gathered on the GPU; pinned = dataset in pinned host memory, the GPU gathers the windows out of it over "
+                         "PCIe on a copy stream one batch ahead (the PCIe-inclusive number); pinned-host = host gather into a staging "
+                         "ring + H2D copy.  Reported in a `feeder` block; `value` is unchanged")
     ap.add_argument("--augment", action="store_true", help="with --feeder: RandomShiftsAug + ColorJitter on the way in")
     ap.add_argument("--frames", default="f32", choices=["f32", "u8"],
                     help="f32: the reference's batch schema (transformed fp32 CHW frames; the contract of `value`); "

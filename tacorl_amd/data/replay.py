@@ -130,42 +130,58 @@ class HbmReplay:
 
 
 class PinnedReplay:
-    """The dataset in pinned host memory; a batch is gathered by the host into one of two pinned staging buffers and
-    copied to the device on a copy stream, so the copy of batch k+1 overlaps the step on batch k."""
+    """The dataset in pinned host memory (datasets larger than HBM).  gather="device" (default): the GPU gathers the
+    batch's frames straight out of the pinned pages over PCIe - the same gather kernel as HbmReplay, reading mapped host
+    memory - on a copy stream, one batch ahead of the step; the host only draws indices.  gather="host": the host gathers
+    into one of two pinned staging buffers and the copy stream moves them (single-threaded index_select: 16 ms per 92 MB
+    batch - kept for comparison)."""
 
-    def __init__(self, frames, actions, index, device):
+    def __init__(self, frames, actions, index, device, gather="device"):
+        assert gather in ("device", "host")
         self.dev = torch.device(device)
         self.frames = {c: v.contiguous().pin_memory() for c, v in frames.items()}
         self.actions = np.asarray(actions, dtype=np.float32)
         self.index = index
+        self.gather = gather
         self.stream = torch.cuda.Stream(device=self.dev)
         self._slot, self._host, self._dev_buf = 0, [{}, {}], [{}, {}]
         self._pending = None
+
+    def _dev_out(self, slot, key, shape):
+        d = self._dev_buf[slot].get(key)
+        if d is None or d.shape != shape:
+            ops.note_alloc()
+            d = self._dev_buf[slot][key] = torch.empty(shape, dtype=torch.uint8, device=self.dev)
+        return d
 
     def _stage(self, slot, key, src, ids):
         shape = (len(ids),) + tuple(src.shape[1:])
         h = self._host[slot].get(key)
         if h is None or h.shape != shape:
             h = self._host[slot][key] = torch.empty(shape, dtype=torch.uint8).pin_memory()
-            ops.note_alloc()
-            self._dev_buf[slot][key] = torch.empty(shape, dtype=torch.uint8, device=self.dev)
         torch.index_select(src, 0, torch.from_numpy(ids), out=h)
-        return h, self._dev_buf[slot][key]
+        return h, self._dev_out(slot, key, shape)
 
     def prefetch(self, idx, draws, aug=None):
         s = self.index.sample(idx, draws)
         n, T = s["frames"].shape
         slot = self._slot
         self._slot ^= 1
-        pairs = []
-        for c, fr in self.frames.items():
-            pairs.append(("states", c, (n, T)) + self._stage(slot, ("s", c), fr, s["frames"].reshape(-1)))
-            pairs.append(("goal", c, (n,)) + self._stage(slot, ("g", c), fr, s["goal"]))
+        jobs = [("states", c, (n, T), ("s", c), fr, s["frames"].reshape(-1)) for c, fr in self.frames.items()]
+        jobs += [("goal", c, (n,), ("g", c), fr, s["goal"]) for c, fr in self.frames.items()]
         acts = torch.from_numpy(pad_actions(self.actions, s["frames"], s["padded"])).pin_memory()
         b = {"states": {}, "goal": {}}
+        if self.gather == "host":
+            staged = [self._stage(slot, key, fr, ids) for _, _, _, key, fr, ids in jobs]
         with torch.cuda.stream(self.stream):
-            for kind, c, lead, h, d in pairs:
-                d.copy_(h, non_blocking=True)
+            for j, (kind, c, lead, key, fr, ids) in enumerate(jobs):
+                if self.gather == "host":
+                    h, d = staged[j]
+                    d.copy_(h, non_blocking=True)
+                else:
+                    d = self._dev_out(slot, key, (len(ids),) + tuple(fr.shape[1:]))
+                    ids_d = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).pin_memory().to(self.dev, non_blocking=True)
+                    ops.gather_frames_u8(fr, ids_d, d)  # fr is mapped host memory: the reads cross PCIe
                 b[kind][c] = d.view(*lead, *d.shape[1:])
             b["actions"] = acts.to(self.dev, non_blocking=True)
             b["disp"] = torch.from_numpy(s["disp"]).pin_memory().to(self.dev, non_blocking=True)

@@ -88,13 +88,14 @@ def test_hbm_and_pinned_replay_feed_the_step():
     assert torch.equal(b["goal"]["rgb_static"].cpu(), frames[torch.from_numpy(s["goal"])])
     assert np.array_equal(b["actions"].cpu().numpy(), pad_actions(acts, s["frames"], s["padded"]))
     assert np.array_equal(b["disp"].cpu().numpy(), s["disp"])
-    pin = PinnedReplay({"rgb_static": frames}, acts, ix, DEV)
-    pin.prefetch(idx, draws)
-    bp = pin.next()
-    torch.cuda.synchronize()
-    for k in ("states", "goal"):
-        assert torch.equal(bp[k]["rgb_static"], b[k]["rgb_static"])
-    assert torch.equal(bp["actions"], b["actions"]) and torch.equal(bp["disp"], b["disp"])
+    for how in ("host", "device"):  # host gather + H2D copy / GPU gather out of the pinned pages over PCIe
+        pin = PinnedReplay({"rgb_static": frames}, acts, ix, DEV, gather=how)
+        pin.prefetch(idx, draws)
+        bp = pin.next()
+        torch.cuda.synchronize()
+        for k in ("states", "goal"):
+            assert torch.equal(bp[k]["rgb_static"], b[k]["rgb_static"]), how
+        assert torch.equal(bp["actions"], b["actions"]) and torch.equal(bp["disp"], b["disp"])
     # the step takes the feeder's batch as it is; without augmentation it is the plain uint8 route bit for bit
     ma, mb = _mod("bf16"), _mod("bf16")
     torch.manual_seed(7); torch.cuda.manual_seed(7)
