@@ -68,6 +68,13 @@ int tacorl_rnn_linear_fwd_batch(int nprob, const void* const* x_bf16, const void
 int tacorl_rnn_linear_bwd_step(const void* x_bf16, const void* wt_bf16, const float* addend, int ld_add,
                                const float* mask_src, float* y, void* y_bf16, int M, int K, int N,
                                tacorl_stream_t stream);
+/* Weight gradient of the RNN's square matrices from the bf16 copies the ring GEMMs leave behind (replaces, for this
+ * shape, tacorl_linear_wgrad's split-R slabs + reduce; reference: autograd of nn.RNN's weight_hh / weight_ih,
+ * networks/action_decoders/rnn_models.py:5-16): dw[M][N] (+)= dz^T x, db[M] (+)= column sums of dz (db may be NULL).
+ * dz bf16 [R][ld_dz], x bf16 [R][ld_x]; R % 64 == 0, M % 128 == 0, N % 128 == 0. */
+int tacorl_rnn_wgrad_supported(int R, int M, int N);
+int tacorl_rnn_wgrad(const void* dz_bf16, int ld_dz, const void* x_bf16, int ld_x, int R, int M, int N, float* dw,
+                     float* db, int accumulate, tacorl_stream_t stream);
 /* dst[c][r] = bf16(src[r][c]); R, C multiples of 32. */
 int tacorl_transpose_to_bf16(const float* src, void* dst, int R, int C, tacorl_stream_t stream);
 

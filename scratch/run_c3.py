@@ -26,6 +26,7 @@ mod = TACORL(play_lmp=lmp(), finetune_action_decoder=True, critic=critic, real_w
              n_action_samples=4, with_lagrange=True, deterministic_backup=True, bc_epochs=5)
 mod.current_epoch = 5; mod.enable_graph(); mod.log_every_n_steps = 50
 print(f"C3 TACORL finetune_action_decoder=True B={B}: {timeit(lambda: mod.training_step(batch)):.3f} ms/step", flush=True)
+if os.environ.get('ONLY') == 'c3': sys.exit(0)
 p = lmp(); p.log_every_n_steps = 50
 try:
     p.enable_graph()

@@ -187,6 +187,142 @@ extern "C" int tacorl_rnn_linear_bwd_step(const void* x_bf16, const void* wt_bf1
   return launch_ring<64, 32, 4>(a, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients of the RNN's 2048 x 2048 matrices: dW[o][k] = sum_r dZ[r][o] * x[r][k] over r = (time, batch)
+// rows (reference: autograd of torch nn.RNN's W_hh / W_ih, rnn_models.py:5-16).  Both operands exist as bf16 row-major
+// [R][2048] (the ring GEMMs write those copies) and the reduction index r is the SLOW one of both, so no operand has
+// the layout an MFMA fragment wants - the generic wgrad GEMM re-lays them through registers (DPP quad transposes),
+// splits R into slabs and reduces them: 151 + 26 us per matrix.  Here: one 128 x 128 tile of dW per workgroup (256
+// workgroups for 2048 x 2048: one per CU, whole R, no slabs), 64 rows of both operands per stage streamed into a
+// 3-stage LDS ring by LDS-DMA in their natural order (a row's 16-byte chunks XOR-swizzled through the choice of which
+// global chunk a lane fetches), fragments by gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group
+// reads 4 rows x 16 columns, each lane receives a column - see encoder_bwd_fused.hip).  x as the MFMA's A operand:
+// a lane ends with 4 consecutive k of one dW row (16-byte stores).  The bias gradient rides along as one more MFMA
+// against a fragment of ones.  Bound by the per-CU LDS-DMA ingest (32 KB per 64 rows), not by MFMA or LDS.
+typedef __bf16 bf16x4t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_frag8(const unsigned char* lo, const unsigned char* hi) {
+  const bf16x4t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4t*)(lo));
+  const bf16x4t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4t*)(hi));
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+constexpr int WG_T = 128, WG_R = 64, WG_S = 3, WG_NW = 8;  // tile edge, rows per stage, stages, waves
+constexpr int WG_OP_BYTES = WG_R * WG_T * 2, WG_STAGE_BYTES = 2 * WG_OP_BYTES;
+
+__global__ __launch_bounds__(64 * WG_NW) void rnn_wgrad_kernel(const __bf16* __restrict__ dz, int ld_dz, const __bf16* __restrict__ x,
+                                                               int ld_x, int R, int MT, int NT, float* __restrict__ dw, int ld_w,
+                                                               float* __restrict__ db, int accumulate) {
+  // tile map: XCD b % 8 owns a block of m tiles x n tiles (its operand columns stay in its L2 while all of its
+  // workgroups walk down r together); any assignment computes the same result
+  int mt, nt;
+  {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    if ((MT & 3) == 0 && (NT & 1) == 0) {
+      const int mb = MT / 4, nb = NT / 2;  // block shape of an XCD: mb x nb tiles
+      mt = (xcd >> 1) * mb + j / nb; nt = (xcd & 1) * nb + j % nb;
+    } else {
+      const int b = blockIdx.x; mt = b / NT; nt = b % NT;
+    }
+  }
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l16 = lane & 15, q = l16 >> 2, pc = l16 & 3;
+  const int wm = w >> 2, wn = w & 3;  // wave grid 2 (m: 64 rows of dW each) x 4 (n: 32 columns each)
+  const int m0 = mt * WG_T, n0 = nt * WG_T;
+  const int nk = R / WG_R;
+  constexpr int DPW = 2 * WG_R / 4 / WG_NW;  // DMA wave-instructions per stage and wave (4 rows of one operand each)
+
+  auto issue = [&](int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < DPW; i++) {
+      const int id = w + WG_NW * i;            // 0 .. 31: operand (id >> 4), row group (id & 15)
+      const int op = id >> 4, row4 = (id & 15) * 4;
+      const int r = row4 + (lane >> 4), cpos = lane & 15, c = cpos ^ (2 * (r & 7));
+      const __bf16* src = (op ? x + (long)(kt * WG_R + r) * ld_x + n0 : dz + (long)(kt * WG_R + r) * ld_dz + m0) + c * 8;
+      const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)(
+          lds + slot * WG_STAGE_BYTES + op * WG_OP_BYTES + row4 * 256));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(src), "s"(lds_off)
+                   : "memory");
+    }
+  };
+
+  f32x4 acc[2][4], bacc[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++) {
+    bacc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; j++) ones[j] = (__bf16)1.0f;
+#pragma unroll
+  for (int s = 0; s < WG_S - 1; s++)
+    if (s < nk) issue(s, s);
+  // this lane's fragment addresses inside a stage: row 4 g + q (+16), chunk (2 tile + pc / 2) ^ swizzle, half pc % 2
+  const int row = 4 * g + q, sw = 2 * (row & 7), half = 8 * (pc & 1);
+  int offA[4], offB[2];
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++) offA[mi] = row * 256 + (((2 * (4 * wm + mi) + (pc >> 1)) ^ sw) << 4) + half;
+#pragma unroll
+  for (int ni = 0; ni < 2; ni++) offB[ni] = WG_OP_BYTES + row * 256 + (((2 * (2 * wn + ni) + (pc >> 1)) ^ sw) << 4) + half;
+
+  for (int kt = 0; kt < nk; kt++) {
+    if (kt + WG_S - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (WG_S - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + WG_S - 1 < nk) issue(kt + WG_S - 1, (kt + WG_S - 1) % WG_S);
+    const unsigned char* st = lds + (kt % WG_S) * WG_STAGE_BYTES;
+#pragma unroll
+    for (int sub = 0; sub < WG_R / 32; sub++) {
+      const unsigned char* sb = st + sub * 32 * 256;
+      bf16x8 A[4], B[2];
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++) A[mi] = tr_frag8(sb + offA[mi], sb + offA[mi] + 16 * 256);
+#pragma unroll
+      for (int ni = 0; ni < 2; ni++) B[ni] = tr_frag8(sb + offB[ni], sb + offB[ni] + 16 * 256);
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ni], A[mi], acc[ni][mi], 0, 0, 0);
+        if (db && wn == 0 && nt == 0) bacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, A[mi], bacc[mi], 0, 0, 0);
+      }
+    }
+  }
+  // D[i][j]: i = x column inside the n tile (rows 4 g .. 4 g + 3 of the lane), j = dZ column (lane l16)
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++) {
+    const int m = m0 + 16 * (4 * wm + mi) + l16;
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++) {
+      float* o = dw + (long)m * ld_w + n0 + 16 * (2 * wn + ni) + 4 * g;
+      f32x4 v = acc[ni][mi];
+      if (accumulate) v += *reinterpret_cast<const f32x4*>(o);
+      *reinterpret_cast<f32x4*>(o) = v;
+    }
+    if (db && wn == 0 && nt == 0 && g == 0) db[m] = (accumulate ? db[m] : 0.f) + bacc[mi][0];
+  }
+}
+
+extern "C" int tacorl_rnn_wgrad_supported(int R, int M, int N) {
+  return R >= WG_R && R % WG_R == 0 && M >= WG_T && M % WG_T == 0 && N >= WG_T && N % WG_T == 0 ? 1 : 0;
+}
+/* dw[M][N] (+)= dz^T x, db[M] (+)= column sums of dz;  dz bf16 [R][ld_dz] (M columns used), x bf16 [R][ld_x] (N columns) */
+extern "C" int tacorl_rnn_wgrad(const void* dz_bf16, int ld_dz, const void* x_bf16, int ld_x, int R, int M, int N, float* dw,
+                                float* db, int accumulate, tacorl_stream_t stream) {
+  if (!tacorl_rnn_wgrad_supported(R, M, N) || ld_dz % 8 || ld_x % 8 || ld_dz < M || ld_x < N) return TACORL_EINVAL;
+  if (((uintptr_t)dz_bf16 | (uintptr_t)x_bf16 | (uintptr_t)dw) & 15) return TACORL_EINVAL;
+  constexpr int lds = WG_S * WG_STAGE_BYTES;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) ==
+                            hipSuccess ? 0 : -1;
+  if (once) return TACORL_ELAUNCH;
+  const int MT = M / WG_T, NT = N / WG_T;
+  hipLaunchKernelGGL(rnn_wgrad_kernel, dim3(MT * NT), dim3(64 * WG_NW), lds, (hipStream_t)stream, (const __bf16*)dz_bf16, ld_dz,
+                     (const __bf16*)x_bf16, ld_x, R, MT, NT, dw, N, db, accumulate);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
 // dst[c][r] = bf16(src[r][c]): 32 x 32 tiles through LDS (R, C multiples of 32)
 __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int R, int C) {
   __shared__ float tile[32][33];

@@ -296,12 +296,23 @@ class ActionDecoderLogistic:
                     self._dgrad(at(DZ, t * B * H), H, blk.p(f"rnn.weight_hh_l{l}"), at(DZ, (t - 1) * B * H), H, B, H, H,
                                 compute, src=at(h, (t - 1) * B * H), ld_src=H, act=ACT_RELU,
                                 addend=at(self.dH, (t - 1) * B * H), ld_add=H)
-            if Tm > 1:
+            # the square matrices' gradients straight from the bf16 copies the ring GEMMs left (hb: forward, DZb: BPTT):
+            # one launch per matrix, no slabs (rnn_ops.hip rnn_wgrad_kernel); other shapes: the generic split-R GEMM
+            tr = lambda rows: fast and bool(ops.L.lib().tacorl_rnn_wgrad_supported(rows, H, H))  # noqa: E731
+            bfp = lambda t, off: C.c_void_p(t.data_ptr() + 2 * off)  # noqa: E731
+            if Tm > 1 and tr((Tm - 1) * B):
+                call("tacorl_rnn_wgrad", bfp(self.DZb[l], B * H), H, ptr(self.hb[l]), H, (Tm - 1) * B, H, H,
+                     blk.g(f"rnn.weight_hh_l{l}"), None, 0, ops.stream())
+            elif Tm > 1:
                 self._wgrad(h, H, at(DZ, B * H), H, (Tm - 1) * B, H, H, blk.g(f"rnn.weight_hh_l{l}"), None, compute)
             else:
                 blk.grad_views[f"rnn.weight_hh_l{l}"].zero_()
             xin, K = (self.x_seq, self.P + self.E) if l == 0 else (self.h[l - 1], H)
-            self._wgrad(xin, K, DZ, H, R, K, H, blk.g(f"rnn.weight_ih_l{l}"), blk.g(f"rnn.bias_ih_l{l}"), compute)
+            if l > 0 and Tm > 1 and tr(R):
+                call("tacorl_rnn_wgrad", ptr(self.DZb[l]), H, ptr(self.hb[l - 1]), H, R, H, H, blk.g(f"rnn.weight_ih_l{l}"),
+                     blk.g(f"rnn.bias_ih_l{l}"), 0, ops.stream())
+            else:
+                self._wgrad(xin, K, DZ, H, R, K, H, blk.g(f"rnn.weight_ih_l{l}"), blk.g(f"rnn.bias_ih_l{l}"), compute)
             call("tacorl_copy_cols", blk.g(f"rnn.bias_ih_l{l}"), H, blk.g(f"rnn.bias_hh_l{l}"), H, 1, H, 0, 0,
                  ops.stream())
             if l > 0:

@@ -602,6 +602,31 @@ def test_rnn_bptt_step_and_transpose():
     assert torch.equal(yb, y.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("R,M,N,ld", [(64, 128, 128, 128), (192, 256, 384, 512), (1024, 512, 256, 512)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_rnn_wgrad(R, M, N, ld, accumulate):
+    """dW = dz^T x, db = column sums of dz from bf16 row-major operands (transposing LDS reads, LDS-DMA ring) vs fp32
+    torch on the same bf16 values: only the fp32 summation order differs."""
+    from tacorl_amd import _lib, ops
+
+    dev = _dev()
+    assert _lib.lib().tacorl_rnn_wgrad_supported(R, M, N) == 1 and _lib.lib().tacorl_rnn_wgrad_supported(R + 32, M, N) == 0
+    dz, x = rnd(R, ld, seed=1).to(torch.bfloat16), rnd(R, ld, seed=2).to(torch.bfloat16)
+    ref_w = dz[:, :M].float().t() @ x[:, :N].float()
+    ref_b = dz[:, :M].float().sum(0)
+    base = 0.5 if accumulate else float("nan")
+    dw, db = torch.full((M, N), base, device=dev), torch.full((M,), base, device=dev)
+    dzd, xd = dz.to(dev), x.to(dev)
+    ops.call("tacorl_rnn_wgrad", ops.ptr(dzd), ld, ops.ptr(xd), ld, R, M, N, ops.ptr(dw), ops.ptr(db), int(accumulate), ops.stream())
+    dw2 = torch.full((M, N), base, device=dev)
+    ops.call("tacorl_rnn_wgrad", ops.ptr(dzd), ld, ops.ptr(xd), ld, R, M, N, ops.ptr(dw2), None, int(accumulate), ops.stream())
+    torch.cuda.synchronize()
+    off = 0.5 if accumulate else 0.0
+    assert relerr(dw - off, ref_w) < 1e-5, relerr(dw - off, ref_w)
+    assert relerr(db - off, ref_b) < 1e-5, relerr(db - off, ref_b)
+    assert torch.equal(dw, dw2)
+
+
 @pytest.mark.parametrize("R", [100, 4096])
 def test_add_layernorm_fwd_bwd(R):
     """y = LayerNorm(x + res) forward and backward (dv, dw, db) vs torch autograd; R = 4096 exercises the
