@@ -21,11 +21,12 @@ def timeit(f, steps=20, warm=5):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / steps * 1e3
-mod = TACORL(play_lmp=lmp(), finetune_action_decoder=True, critic=critic, real_world=True, device=dev, compute_dtype="bf16", image_dtype="bf16",
-             action_decoder_lr=3e-4, actor_lr=1e-4, critic_lr=3e-4, discount=0.95, conservative_weight=1.0, reward_scale=10.0,
-             n_action_samples=4, with_lagrange=True, deterministic_backup=True, bc_epochs=5)
-mod.current_epoch = 5; mod.enable_graph(); mod.log_every_n_steps = 50
-print(f"C3 TACORL finetune_action_decoder=True B={B}: {timeit(lambda: mod.training_step(batch)):.3f} ms/step", flush=True)
+if os.environ.get('ONLY') != 'plmp':
+  mod = TACORL(play_lmp=lmp(), finetune_action_decoder=True, critic=critic, real_world=True, device=dev, compute_dtype="bf16", image_dtype="bf16",
+               action_decoder_lr=3e-4, actor_lr=1e-4, critic_lr=3e-4, discount=0.95, conservative_weight=1.0, reward_scale=10.0,
+               n_action_samples=4, with_lagrange=True, deterministic_backup=True, bc_epochs=5)
+  mod.current_epoch = 5; mod.enable_graph(); mod.log_every_n_steps = 50
+  print(f"C3 TACORL finetune_action_decoder=True B={B}: {timeit(lambda: mod.training_step(batch)):.3f} ms/step", flush=True)
 if os.environ.get('ONLY') == 'c3': sys.exit(0)
 p = lmp(); p.log_every_n_steps = 50
 try:
