@@ -782,23 +782,33 @@ def test_stage_transition_dtypes(dt):
     assert torch.equal(reward, ref) and torch.equal(done, ref) and torch.equal(out, acts)
 
 
-def test_reduce_rows_mod_batch():
-    """out[b][c] = sum_j in[j*B + b][c] for several (in, out) pairs in one launch, summed in j order (bit-exact
-    against the same order in torch)."""
+@pytest.mark.parametrize("B,cols,reps,ld_in,ld_out", [(256, 64, 13, 72, 64), (96, 71, 97, 80, 71), (5, 3, 2, 4, 3)])
+def test_reduce_rows_mod_batch(B, cols, reps, ld_in, ld_out):
+    """out[b][c] = sum_j in[j*B + b][c] for several (in, out) pairs in one launch.  The four waves of a workgroup take
+    j = w, w + 4, ... each and meet in wave order: bit-exact against the same order in torch (and within fp32 rounding
+    of the plain sum)."""
     from tacorl_amd import ops
     from tacorl_amd._lib import call, stream
 
     dev = _dev()
-    B, cols, reps, ld_in, ld_out = 256, 64, 13, 72, 64
     ins = [rnd(reps * B, ld_in, seed=5 + k).to(dev) for k in range(2)]
     outs = [torch.zeros(B, ld_out, device=dev) for _ in range(2)]
     call("tacorl_reduce_rows_mod_batch", 2, ops.ptr_array(ins), ld_in, ops.ptr_array(outs), ld_out, B, cols, reps, stream())
+    single = torch.zeros(B, ld_out, device=dev)
+    call("tacorl_reduce_rows_mod", ops.ptr(ins[0]), ld_in, ops.ptr(single), ld_out, B, cols, reps, stream())
     torch.cuda.synchronize()
     for x, o in zip(ins, outs):
-        ref = torch.zeros(B, cols, device=dev)
-        for j in range(reps):
-            ref = ref + x[j * B:(j + 1) * B, :cols]
+        part = []
+        for w in range(4):
+            acc = torch.zeros(B, cols, device=dev)
+            for j in range(w, reps, 4):
+                acc = acc + x[j * B:(j + 1) * B, :cols]
+            part.append(acc)
+        ref = ((part[0] + part[1]) + part[2]) + part[3]
         assert torch.equal(o[:, :cols], ref)
+        plain = x.view(reps, B, ld_in)[:, :, :cols].double().sum(0)
+        assert relerr(o[:, :cols], plain) < 1e-6
+    assert torch.equal(single, outs[0])
 
 
 @pytest.mark.parametrize("flag,dt", [(1, torch.bfloat16), (0, torch.float32)])
