@@ -302,6 +302,21 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
                  ops.ptr_array([self.f_out[c]]), ops.ptr_array([self.f_act[c]]), ops.int_array([R]), H, W, xd, cd,
                  ops.stream())
         ops.copy_cols(self.f_out[c], 0, 32, self.emb, 32 * j, Ec, R, 32)
+    # Branches (torch streams: branches of the captured graph).  The step is a long chain of small kernels; what does not
+    # depend on each other runs side by side: the logging-only random-plan decoder pass beside the plan proposal /
+    # recognition forward, the plan proposal's backward beside the decoder's, the decoder's weight gradients beside its
+    # BPTT and the plan recognition's backward.  (Scratch buffers are per network - "ad_*" tags - so branches do not share any.)
+    if getattr(self, "_branch", None) is None:
+        self._branch = [torch.cuda.Stream(device=self.dev) for _ in range(3)]
+    main = torch.cuda.current_stream()
+    s_rand, s_pp, s_wg = self._branch if getattr(self, "branches", True) else [main] * 3  # tests switch the branches off
+    # logging-only pass with a uniform random plan (reference :243-252) - before the real pass, whose activations
+    # are the ones the backward sees (the decoder's buffers are shared: the real pass waits for this branch)
+    s_rand.wait_stream(main)
+    with torch.cuda.stream(s_rand):
+        call("tacorl_uniform_actions", ptr(self.noise["u_plan"]), ptr(self.rplan), A, B, A, 0, ops.stream())
+        ad.forward(self.rplan, self.emb, Ec, B, T, T - 1, cd)
+        ad.loss(acts, ops._at(self.logs, 4), B, T, T - 1, want_grad=False)
     ops.copy_cols(self.emb, (T - 1) * Ec, T * Ec, self.gin, 0, Ec, B, Ec)  # pp_goal input = emb[:, -1]
     ops.mlp_fwd([self.gin], Ec, [net.genc()], [self.gact], [B], net.genc_dims, net.genc_acts, cd)
     ops.copy_cols(self.emb, 0, T * Ec, self.S, 0, 2 * Ec, B, Ec)  # pp_state = emb[:, 0]
@@ -312,19 +327,22 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     call("tacorl_gauss_kl_balanced", ptr(head_pr), ptr(head_pp), ptr(self.d_head_pr), ptr(self.d_head_pp), B, A,
          float(self.kl_alpha), float(self.kl_beta), float(pr.min_std), int(self.kl_balancing), gs, ptr(self.logs),
          ops.stream())
-    # logging-only pass with a uniform random plan (reference :243-252) - first, so the real pass's
-    # activations are the ones the backward sees
-    call("tacorl_uniform_actions", ptr(self.noise["u_plan"]), ptr(self.rplan), A, B, A, 0, ops.stream())
-    ad.forward(self.rplan, self.emb, Ec, B, T, T - 1, cd)
-    ad.loss(acts, ops._at(self.logs, 4), B, T, T - 1, want_grad=False)
+    # plan proposal backward (needs only the KL's gradient): its own branch; d_emb gets its share after the join
+    s_pp.wait_stream(main)
+    with torch.cuda.stream(s_pp):
+        ops.mlp_bwd([self.S], 2 * Ec, [net.head()], [self.pact], [self.d_head_pp], 2 * A, [net.head(net.grad)], [self.dS],
+                    2 * Ec, [B], net.head_dims, net.head_acts, cd)
+        ops.mlp_bwd([self.gin], Ec, [net.genc()], [self.gact], [ops._at(self.dS, Ec)], 2 * Ec, [net.genc(net.grad)],
+                    [self.dgin], Ec, [B], net.genc_dims, net.genc_acts, cd)
     call("tacorl_pr_sample", ptr(head_pr), ptr(self.noise["eps_plan"]), ptr(self.plan), None, None, B, A,
          float(pr.min_std), ops.stream())
+    main.wait_stream(s_rand)
     ad.forward(self.plan, self.emb, Ec, B, T, T - 1, cd)
     ad.loss(acts, ops._at(self.logs, 2), B, T, T - 1, want_grad=True, grad_scale=gs)
     if self.add_random_plan_loss:
         raise NotImplementedError("add_random_plan_loss=True is not used by any in-scope config")
     # ---- backward
-    ad.backward(B, T - 1, cd, need_input_grad=True)
+    ad.backward(B, T - 1, cd, need_input_grad=True, wgrad_stream=s_wg, join=False)
     self.d_emb.zero_()
     call("tacorl_ad_input_bwd", ptr(ad.dx_seq), ptr(self.d_plan), ptr(self.d_emb), Ec, B, T, T - 1, ad.P, ad.E, 1,
          ops.stream())
@@ -332,11 +350,8 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
          float(pr.min_std), ops.stream())
     dx = pr.backward(self.d_head_pr, B, T, cd)
     ops.copy_cols(dx, 0, pr.D, self.d_emb, 0, Ec, R, pr.D_in, accumulate=True)
-    ops.mlp_bwd([self.S], 2 * Ec, [net.head()], [self.pact], [self.d_head_pp], 2 * A, [net.head(net.grad)], [self.dS],
-                2 * Ec, [B], net.head_dims, net.head_acts, cd)
+    main.wait_stream(s_pp)
     ops.copy_cols(self.dS, 0, 2 * Ec, self.d_emb, 0, T * Ec, B, Ec, accumulate=True)
-    ops.mlp_bwd([self.gin], Ec, [net.genc()], [self.gact], [ops._at(self.dS, Ec)], 2 * Ec, [net.genc(net.grad)],
-                [self.dgin], Ec, [B], net.genc_dims, net.genc_acts, cd)
     ops.copy_cols(self.dgin, 0, Ec, self.d_emb, (T - 1) * Ec, T * Ec, B, Ec, accumulate=True)
     for j, c in enumerate(cams):
         H, W = hw[c]
@@ -345,6 +360,7 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
                  and ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(1, ops.int_array([R]), H, W) > 0)  # forward and backward
         ops.encoder_bwd([self.frames[c]], [net.enc(c)], [self.f_act[c]], [self.f_dout[c]], [net.enc(c, net.grad)], H, W, cd,
                         fused=fused)
+    main.wait_stream(s_wg)
 
 
 def _named_gradients(self):

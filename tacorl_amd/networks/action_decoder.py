@@ -134,7 +134,7 @@ class ActionDecoderLogistic:
     def _lin(self, x, ldx, w, b, y, M, K, N, act, compute, ldy=None):
         # split-K capable entry (skinny outputs with a long K: linear2 2048->32, the 2048->182 heads)
         nb = ops.L.lib().tacorl_linear_add_fwd_ws_bytes(1, ops.int_array([M]), K, N)
-        ws = ops.workspace(nb, self.dev, "lin_splitk")
+        ws = ops.workspace(nb, self.dev, "ad_splitk")  # own scratch: runs beside the plan recognition's linears
         call("tacorl_linear_add_fwd", 1, ops.ptr_array([x]), ldx, ops.ptr_array([w]), ops.ptr_array([b]), None, 0,
              ops.ptr_array([y]), N if ldy is None else ldy, ops.int_array([M]), K, N, act, compute, ptr(ws), ws.numel(),
              ops.stream())
@@ -236,6 +236,8 @@ class ActionDecoderLogistic:
         slot = ops._at(module.engine.logs, LOG_SLOTS.index("action_loss"))
         self.loss(acts, slot, B, T, T - 1, want_grad=optimize, grad_scale=1.0 / module.world_size)
         if optimize:
+            # (no wgrad_stream here: this call already runs on a branch of the step's graph, and a branch forked from a
+            # branch crashed hipStreamEndCapture on ROCm 7.2)
             self.backward(B, T - 1, module.compute, need_input_grad=False)
             module.engine._allreduce([self.blk.grad])
             ops.adam_step(self.blk.param, self.blk.grad, self.blk.m, self.blk.v, module.action_decoder_lr, 0.0,
@@ -244,7 +246,7 @@ class ActionDecoderLogistic:
     # ------------------------------------------------------------------ backward (BPTT)
     def _wgrad(self, x, ldx, dz, ld_dz, M, K, O, dw, db, compute):
         nb = ops.L.lib().tacorl_linear_wgrad_ws_bytes(1, ops.int_array([M]), K, O)
-        ws = ops.workspace(nb, self.dev, "lin_wgrad")
+        ws = ops.workspace(nb, self.dev, "ad_wgrad")  # own scratch (see _lin)
         call("tacorl_linear_wgrad", 1, ops.ptr_array([x]), ldx, ops.ptr_array([dz]), ld_dz, ops.int_array([M]), K, O,
              ops.ptr_array([dw]), ops.ptr_array([db]) if db is not None else None, 0, compute, ptr(ws), ws.numel(),
              ops.stream())
@@ -256,9 +258,36 @@ class ActionDecoderLogistic:
              ops.ptr_array([addend]) if addend is not None else None, ld_add, ops.int_array([M]), O, I, compute,
              ops.stream())
 
-    def backward(self, B, Tm, compute, need_input_grad=False):
+    def _layer_wgrads(self, l, B, Tm, compute, fast):
+        """W_hh / W_ih / bias gradients of layer l (its BPTT has been issued)."""
+        blk, H, R = self.blk, self.hidden, B * Tm
+        h, DZ, at = self.h[l], self.DZ[l], ops._at
+        # the square matrices' gradients straight from the bf16 copies the ring GEMMs left (hb: forward, DZb: BPTT):
+        # one launch per matrix, no slabs (rnn_ops.hip rnn_wgrad_kernel); other shapes: the generic split-R GEMM
+        tr = lambda rows: fast and bool(ops.L.lib().tacorl_rnn_wgrad_supported(rows, H, H))  # noqa: E731
+        bfp = lambda t, off: C.c_void_p(t.data_ptr() + 2 * off)  # noqa: E731
+        if Tm > 1 and tr((Tm - 1) * B):
+            call("tacorl_rnn_wgrad", bfp(self.DZb[l], B * H), H, ptr(self.hb[l]), H, (Tm - 1) * B, H, H,
+                 blk.g(f"rnn.weight_hh_l{l}"), None, 0, ops.stream())
+        elif Tm > 1:
+            self._wgrad(h, H, at(DZ, B * H), H, (Tm - 1) * B, H, H, blk.g(f"rnn.weight_hh_l{l}"), None, compute)
+        else:
+            blk.grad_views[f"rnn.weight_hh_l{l}"].zero_()
+        xin, K = (self.x_seq, self.P + self.E) if l == 0 else (self.h[l - 1], H)
+        if l > 0 and Tm > 1 and tr(R):
+            call("tacorl_rnn_wgrad", ptr(self.DZb[l]), H, ptr(self.hb[l - 1]), H, R, H, H, blk.g(f"rnn.weight_ih_l{l}"),
+                 blk.g(f"rnn.bias_ih_l{l}"), 0, ops.stream())
+        else:
+            self._wgrad(xin, K, DZ, H, R, K, H, blk.g(f"rnn.weight_ih_l{l}"), blk.g(f"rnn.bias_ih_l{l}"), compute)
+        call("tacorl_copy_cols", blk.g(f"rnn.bias_ih_l{l}"), H, blk.g(f"rnn.bias_hh_l{l}"), H, 1, H, 0, 0,
+             ops.stream())
+
+    def backward(self, B, Tm, compute, need_input_grad=False, wgrad_stream=None, join=True):
         """Gradients of the loss (dL/dheads in self.d_heads) into self.blk.grad; optionally
-        d(x_seq) into self.dx_seq.  ReLU-RNN BPTT: dz_{t-1} = (dz_t W_hh + dH_{t-1}) * [h_{t-1} > 0]."""
+        d(x_seq) into self.dx_seq.  ReLU-RNN BPTT: dz_{t-1} = (dz_t W_hh + dH_{t-1}) * [h_{t-1} > 0].
+        wgrad_stream: the weight gradients - which only the optimiser reads - go to that stream (a branch of a
+        captured graph) beside the dependent chain heads -> BPTT -> input gradient; join=False leaves the join
+        (`current.wait_stream(wgrad_stream)`) to the caller, who may put more work in front of it."""
         blk, H, R, L = self.blk, self.hidden, B * Tm, self.L
         if getattr(self, "_bshape", None) != (B, Tm):
             ops.note_alloc()
@@ -268,8 +297,16 @@ class ActionDecoderLogistic:
             self.dx_seq = f(R, self.P + self.E)
             self._bshape = (B, Tm)
         at = ops._at
-        self._wgrad(self.h[L - 1], H, self.d_heads, self.NHP, R, H, self.NH, blk.g("mean_fc.weight"),
-                    blk.g("mean_fc.bias"), compute)
+
+        def side(fn):  # everything fn reads has been issued on the current stream; nothing on that stream reads fn's outputs
+            if wgrad_stream is None:
+                return fn()
+            wgrad_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(wgrad_stream):
+                fn()
+
+        side(lambda: self._wgrad(self.h[L - 1], H, self.d_heads, self.NHP, R, H, self.NH, blk.g("mean_fc.weight"),
+                                 blk.g("mean_fc.bias"), compute))
         self._dgrad(self.d_heads, self.NHP, blk.p("mean_fc.weight"), self.dH, H, R, self.NH, H, compute)
         fast = compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H)) and H % 32 == 0
         if fast and getattr(self, "_bptt_shape", None) != (B, Tm):
@@ -296,26 +333,12 @@ class ActionDecoderLogistic:
                     self._dgrad(at(DZ, t * B * H), H, blk.p(f"rnn.weight_hh_l{l}"), at(DZ, (t - 1) * B * H), H, B, H, H,
                                 compute, src=at(h, (t - 1) * B * H), ld_src=H, act=ACT_RELU,
                                 addend=at(self.dH, (t - 1) * B * H), ld_add=H)
-            # the square matrices' gradients straight from the bf16 copies the ring GEMMs left (hb: forward, DZb: BPTT):
-            # one launch per matrix, no slabs (rnn_ops.hip rnn_wgrad_kernel); other shapes: the generic split-R GEMM
-            tr = lambda rows: fast and bool(ops.L.lib().tacorl_rnn_wgrad_supported(rows, H, H))  # noqa: E731
-            bfp = lambda t, off: C.c_void_p(t.data_ptr() + 2 * off)  # noqa: E731
-            if Tm > 1 and tr((Tm - 1) * B):
-                call("tacorl_rnn_wgrad", bfp(self.DZb[l], B * H), H, ptr(self.hb[l]), H, (Tm - 1) * B, H, H,
-                     blk.g(f"rnn.weight_hh_l{l}"), None, 0, ops.stream())
-            elif Tm > 1:
-                self._wgrad(h, H, at(DZ, B * H), H, (Tm - 1) * B, H, H, blk.g(f"rnn.weight_hh_l{l}"), None, compute)
-            else:
-                blk.grad_views[f"rnn.weight_hh_l{l}"].zero_()
-            xin, K = (self.x_seq, self.P + self.E) if l == 0 else (self.h[l - 1], H)
-            if l > 0 and Tm > 1 and tr(R):
-                call("tacorl_rnn_wgrad", ptr(self.DZb[l]), H, ptr(self.hb[l - 1]), H, R, H, H, blk.g(f"rnn.weight_ih_l{l}"),
-                     blk.g(f"rnn.bias_ih_l{l}"), 0, ops.stream())
-            else:
-                self._wgrad(xin, K, DZ, H, R, K, H, blk.g(f"rnn.weight_ih_l{l}"), blk.g(f"rnn.bias_ih_l{l}"), compute)
-            call("tacorl_copy_cols", blk.g(f"rnn.bias_ih_l{l}"), H, blk.g(f"rnn.bias_hh_l{l}"), H, 1, H, 0, 0,
-                 ops.stream())
+            side(lambda l=l: self._layer_wgrads(l, B, Tm, compute, fast))
             if l > 0:
+                # (overwrites dH, which the side stream's mean_fc / layer-l weight gradients do not read)
                 self._dgrad(DZ, H, blk.p(f"rnn.weight_ih_l{l}"), self.dH, H, R, H, H, compute)
             elif need_input_grad:
+                K = self.P + self.E
                 self._dgrad(DZ, H, blk.p("rnn.weight_ih_l0"), self.dx_seq, K, R, H, K, compute)
+        if wgrad_stream is not None and join:
+            torch.cuda.current_stream().wait_stream(wgrad_stream)

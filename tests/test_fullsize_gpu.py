@@ -327,3 +327,42 @@ def test_uint8_frames_cql_offline_and_playlmp():
     pb.training_step(p8, 0)
     torch.cuda.synchronize()
     assert torch.equal(pa.frames["rgb_static"], pb.frames["rgb_static"])
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_playlmp_branches_equal_serial(graph):
+    """PlayLMP.training_step at bench shapes (bf16: ring GEMMs, fused encoder, one-launch RNN weight gradients) with its
+    graph branches - random-plan decoder pass, plan-proposal backward, decoder weight gradients on side streams - and
+    without: the same kernels on the same inputs, so logs and every gradient agree bit for bit (a race would show)."""
+    import bench
+    from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
+
+    dev = torch.device("cuda:0")
+    B, T, cams = 64, 16, ["rgb_static"]
+    actor = {"policy": {"num_layers": 3, "hidden_dim": 256}}
+    pr = dict(num_heads=8, num_layers=2, encoder_hidden_size=2048, fc_hidden_size=4096, latent_plan_dim=16, min_std=1e-4,
+              dropout_p=0.0, max_position_embeddings=T)
+    ad = dict(n_mixtures=10, num_layers=2, hidden_size=2048, out_features=7, num_classes=10, latent_plan_dim=16,
+              rnn_model="rnn_decoder", include_goal=False)
+    batch = bench.synth_batch(B, T, 84, 84, dev, 1)
+    res = []
+    for branches in (True, False):
+        torch.manual_seed(0)
+        m = PlayLMP(plan_proposal=actor, plan_recognition=pr, action_decoder=ad, plan_proposal_obs_modalities=cams,
+                    plan_proposal_goal_modalities=cams, plan_recognition_modalities=cams, action_decoder_modalities=cams,
+                    real_world=True, device=dev, compute_dtype="bf16", image_dtype="bf16")
+        m.branches = branches
+        if graph:
+            m.enable_graph()
+        torch.manual_seed(5); torch.cuda.manual_seed(5)
+        for _ in range(3):
+            m.training_step(batch, 0)
+        torch.cuda.synchronize()
+        res.append((dict(m.logged), {k: v.clone() for k, v in m.named_gradients().items()},
+                    {k: v.clone() for k, v in m.state_dict().items()}))
+    (la, ga, pa), (lb, gb, pb) = res
+    assert la == lb and all(v == v for v in la.values()), (la, lb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
