@@ -304,8 +304,8 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
         ops.copy_cols(self.f_out[c], 0, 32, self.emb, 32 * j, Ec, R, 32)
     # Branches (torch streams: branches of the captured graph).  The step is a long chain of small kernels; what does not
     # depend on each other runs side by side: the logging-only random-plan decoder pass beside the plan proposal /
-    # recognition forward, the plan proposal's backward beside the decoder's, the decoder's weight gradients beside its
-    # BPTT and the plan recognition's backward.  (Scratch buffers are per network - "ad_*" tags - so branches do not share any.)
+    # recognition forward, the plan proposal's backward beside the decoder's, the decoder's and the plan recognition's
+    # weight gradients beside the BPTT / input-gradient chains and the encoder backward.  (Scratch buffers are per network - "ad_*" tags - so branches do not share any.)
     if getattr(self, "_branch", None) is None:
         self._branch = [torch.cuda.Stream(device=self.dev) for _ in range(3)]
     main = torch.cuda.current_stream()
@@ -348,7 +348,7 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
          ops.stream())
     call("tacorl_pr_sample_bwd", ptr(head_pr), ptr(self.noise["eps_plan"]), ptr(self.d_plan), ptr(self.d_head_pr), B, A,
          float(pr.min_std), ops.stream())
-    dx = pr.backward(self.d_head_pr, B, T, cd)
+    dx = pr.backward(self.d_head_pr, B, T, cd, wgrad_stream=s_wg)
     ops.copy_cols(dx, 0, pr.D, self.d_emb, 0, Ec, R, pr.D_in, accumulate=True)
     main.wait_stream(s_pp)
     ops.copy_cols(self.dS, 0, 2 * Ec, self.d_emb, 0, T * Ec, B, Ec, accumulate=True)

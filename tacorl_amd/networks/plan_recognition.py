@@ -220,21 +220,33 @@ class PlanRecognition:
         call("tacorl_add_layernorm_bwd", ptr(dy), ptr(x), ptr(res), w, ptr(stats), ptr(dv), dw, db, R, D, 0, ptr(ws),
              ws.numel(), ops.stream())
 
-    def backward(self, d_head, B, T, compute):
+    def backward(self, d_head, B, T, compute, wgrad_stream=None):
         """d_head: (B, 2A) gradient w.r.t. [mean | var_raw].  Fills self.blk.grad and returns the
-        (B*T, D) gradient w.r.t. the (padded) input embeddings."""
+        (B*T, D) gradient w.r.t. the (padded) input embeddings.
+        wgrad_stream: the Linear weight gradients - read only by the optimiser - are issued on that stream (a branch
+        of a captured graph) beside the dependent input-gradient chain; the caller joins it.  The gradient buffers
+        those launches read are per layer, so the chain never overwrites what a pending weight gradient still needs."""
         blk, D, R, FF, FC, A2 = self.blk, self.D, B * T, self.FF, self.FC, 2 * self.A
         if getattr(self, "_bshape", None) != (B, T):
             ops.note_alloc()
             f = lambda *s: torch.zeros(*s, device=self.dev)  # noqa: E731
+            per = lambda *s: [f(*s) for _ in range(self.L)]  # noqa: E731
             self.d_fc, self.d_pool = f(B, FC), f(B, D)
-            self.dx, self.dv, self.d_ff1, self.d_x1, self.d_att, self.d_qkv = f(R, D), f(R, D), f(R, FF), f(R, D), f(R, D), f(R, 3 * D)
-            self.dv1 = f(R, D)
-            self.dvb, self.dv1b = f(R, D), f(R, D)  # branch gradients behind dropout2 / dropout1 (train mode)
+            self.dx, self.d_x1, self.d_att = f(R, D), f(R, D), f(R, D)
+            self.dv, self.dv1, self.d_ff1, self.d_qkv = per(R, D), per(R, D), per(R, FF), per(R, 3 * D)
+            self.dvb, self.dv1b = per(R, D), per(R, D)  # branch gradients behind dropout2 / dropout1 (train mode)
             self._bshape = (B, T)
-        self._wgrad(self.fc_out, FC, d_head, A2, B, FC, A2, blk.g("mean_fc.weight"), blk.g("mean_fc.bias"), compute)
+
+        def side(fn):
+            if wgrad_stream is None:
+                return fn()
+            wgrad_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(wgrad_stream):
+                fn()
+
+        side(lambda: self._wgrad(self.fc_out, FC, d_head, A2, B, FC, A2, blk.g("mean_fc.weight"), blk.g("mean_fc.bias"), compute))
         self._dgrad(d_head, A2, blk.p("mean_fc.weight"), self.d_fc, FC, B, A2, FC, compute)
-        self._wgrad(self.pooled, D, self.d_fc, FC, B, D, FC, blk.g("fc.weight"), blk.g("fc.bias"), compute)
+        side(lambda: self._wgrad(self.pooled, D, self.d_fc, FC, B, D, FC, blk.g("fc.weight"), blk.g("fc.bias"), compute))
         self._dgrad(self.d_fc, FC, blk.p("fc.weight"), self.d_pool, D, B, FC, D, compute)
         call("tacorl_bcast_over_t", ptr(self.d_pool), ptr(self.dx), B, T, D, 1.0 / T, 0, ops.stream())
         # train mode: the forward dropped ff2 / ff1 / proj / attention probabilities / embeddings in place (the saved
@@ -245,40 +257,41 @@ class PlanRecognition:
         for l in reversed(range(self.L)):
             p = f"transformer_encoder.layers.{l}."
             xin, x1 = self.x[2 * l], self.x[2 * l + 1]
-            self._ln_bwd(self.dx, x1, self.ff2[l], blk.p(p + "norm2.weight"), self.stats[2 * l + 1], self.dv,
+            dv, dv1, d_ff1, d_qkv = self.dv[l], self.dv1[l], self.d_ff1[l], self.d_qkv[l]
+            self._ln_bwd(self.dx, x1, self.ff2[l], blk.p(p + "norm2.weight"), self.stats[2 * l + 1], dv,
                          blk.g(p + "norm2.weight"), blk.g(p + "norm2.bias"), R, D)
-            dvb = self.dv
+            dvb = dv
             if drop:
-                dvb = self.dvb
-                ops.copy_cols(self.dv, 0, D, dvb, 0, D, R, D)
+                dvb = self.dvb[l]
+                ops.copy_cols(dv, 0, D, dvb, 0, D, R, D)
                 self._drop(dvb, 4 + 4 * l, R * D)
-            self._wgrad(self.ff1[l], FF, dvb, D, R, FF, D, blk.g(p + "linear2.weight"), blk.g(p + "linear2.bias"), compute)
-            self._dgrad(dvb, D, blk.p(p + "linear2.weight"), self.d_ff1, FF, R, D, FF, compute, src=self.ff1[l],
+            side(lambda: self._wgrad(self.ff1[l], FF, dvb, D, R, FF, D, blk.g(p + "linear2.weight"), blk.g(p + "linear2.bias"),
+                                     compute))
+            self._dgrad(dvb, D, blk.p(p + "linear2.weight"), d_ff1, FF, R, D, FF, compute, src=self.ff1[l],
                         ld_src=FF, act=ACT_RELU)
             if drop:  # (the ReLU mask taken from the dropped ff1 already zeroed the dropped units: this adds the scale)
-                self._drop(self.d_ff1, 3 + 4 * l, R * FF)
-            self._wgrad(x1, D, self.d_ff1, FF, R, D, FF, blk.g(p + "linear1.weight"), blk.g(p + "linear1.bias"), compute)
-            self._dgrad(self.d_ff1, FF, blk.p(p + "linear1.weight"), self.d_x1, D, R, FF, D, compute, addend=self.dv,
-                        ld_add=D)
-            self._ln_bwd(self.d_x1, xin, self.proj[l], blk.p(p + "norm1.weight"), self.stats[2 * l], self.dv1,
+                self._drop(d_ff1, 3 + 4 * l, R * FF)
+            side(lambda: self._wgrad(x1, D, d_ff1, FF, R, D, FF, blk.g(p + "linear1.weight"), blk.g(p + "linear1.bias"), compute))
+            self._dgrad(d_ff1, FF, blk.p(p + "linear1.weight"), self.d_x1, D, R, FF, D, compute, addend=dv, ld_add=D)
+            self._ln_bwd(self.d_x1, xin, self.proj[l], blk.p(p + "norm1.weight"), self.stats[2 * l], dv1,
                          blk.g(p + "norm1.weight"), blk.g(p + "norm1.bias"), R, D)
-            dv1b = self.dv1
+            dv1b = dv1
             if drop:
-                dv1b = self.dv1b
-                ops.copy_cols(self.dv1, 0, D, dv1b, 0, D, R, D)
+                dv1b = self.dv1b[l]
+                ops.copy_cols(dv1, 0, D, dv1b, 0, D, R, D)
                 self._drop(dv1b, 2 + 4 * l, R * D)
-            self._wgrad(self.att[l], D, dv1b, D, R, D, D, blk.g(p + "self_attn.out_proj.weight"),
-                        blk.g(p + "self_attn.out_proj.bias"), compute)
+            side(lambda: self._wgrad(self.att[l], D, dv1b, D, R, D, D, blk.g(p + "self_attn.out_proj.weight"),
+                                     blk.g(p + "self_attn.out_proj.bias"), compute))
             self._dgrad(dv1b, D, blk.p(p + "self_attn.out_proj.weight"), self.d_att, D, R, D, D, compute)
             if drop:
-                call("tacorl_attention_dropout_bwd", ptr(self.qkv[l]), ptr(self.d_att), ptr(self.d_qkv),
+                call("tacorl_attention_dropout_bwd", ptr(self.qkv[l]), ptr(self.d_att), ptr(d_qkv),
                      ptr(self.keep[1 + 4 * l]), ks, B, T, D, self.H, ops.stream())
             else:
-                call("tacorl_attention_bwd", ptr(self.qkv[l]), ptr(self.d_att), ptr(self.d_qkv), B, T, D, self.H, ops.stream())
-            self._wgrad(xin, D, self.d_qkv, 3 * D, R, D, 3 * D, blk.g(p + "self_attn.in_proj_weight"),
-                        blk.g(p + "self_attn.in_proj_bias"), compute)
-            self._dgrad(self.d_qkv, 3 * D, blk.p(p + "self_attn.in_proj_weight"), self.dx, D, R, 3 * D, D, compute,
-                        addend=self.dv1, ld_add=D)
+                call("tacorl_attention_bwd", ptr(self.qkv[l]), ptr(self.d_att), ptr(d_qkv), B, T, D, self.H, ops.stream())
+            side(lambda: self._wgrad(xin, D, d_qkv, 3 * D, R, D, 3 * D, blk.g(p + "self_attn.in_proj_weight"),
+                                     blk.g(p + "self_attn.in_proj_bias"), compute))
+            self._dgrad(d_qkv, 3 * D, blk.p(p + "self_attn.in_proj_weight"), self.dx, D, R, 3 * D, D, compute,
+                        addend=dv1, ld_add=D)
         if drop:
             self._drop(self.dx, 0, R * D)
         # position embeddings: sum over the batch of rows with the same t
