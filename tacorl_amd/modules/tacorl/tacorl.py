@@ -239,7 +239,12 @@ class TACORL(CQL_Offline):
         e.phase_a(encoded=True)
         segmented = self.world_size > 1 or getattr(self, "_force_graph_split", False) or not self._use_graph
         if with_ad and not ad_on_side:
-            main.wait_stream(self._pr_stream)
+            if segmented:
+                main.wait_stream(self._pr_stream)
+            else:
+                # one graph for the whole step: the fine-tuning chain (loss, BPTT, weight gradients, Adam - 1.4 ms, touching
+                # nothing but the decoder's own buffers) stays a branch beside the CQL update and joins at the end of the step
+                self._ad_join = self._pr_stream
         if segmented:
             # every segment must be self-contained (its graph is replayed on its own)
             main.wait_stream(self._pr_stream)

@@ -19,3 +19,21 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_objects(request):
+    """After every GPU test: drop the dead modules' captured hipGraphs, streams and buffers now, not whenever the
+    garbage collector gets to them - a long session otherwise accumulates dozens of instantiated graphs (observed on
+    ROCm 7.2: with test_step_gpu.py run BEFORE test_fullsize_gpu.py, the C5 test's graph replay segfaulted in
+    hipGraphLaunch; with the dead captures released after each test every order passes)."""
+    yield
+    if "gpu" in request.keywords:
+        import gc
+
+        import torch
+
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
