@@ -236,8 +236,10 @@ class ActionDecoderLogistic:
         slot = ops._at(module.engine.logs, LOG_SLOTS.index("action_loss"))
         self.loss(acts, slot, B, T, T - 1, want_grad=optimize, grad_scale=1.0 / module.world_size)
         if optimize:
-            # (no wgrad_stream here: this call already runs on a branch of the step's graph, and a branch forked from a
-            # branch crashed hipStreamEndCapture on ROCm 7.2)
+            # (no wgrad_stream here.  This call already runs on a branch of the step's graph: a side stream joined back INTO
+            # that branch crashed hipStreamEndCapture on ROCm 7.2; forked from and joined into the main stream instead - with
+            # the Adam step moved behind the join - it captured, and the step went 1.82 -> 2.10 ms: three concurrent
+            # chains of chip-wide kernels slow each other more than the overlap returns)
             self.backward(B, T - 1, module.compute, need_input_grad=False)
             module.engine._allreduce([self.blk.grad])
             ops.adam_step(self.blk.param, self.blk.grad, self.blk.m, self.blk.v, module.action_decoder_lr, 0.0,
