@@ -59,11 +59,13 @@ static int k_linear_fwd(int nprob, const float* const* x, int ldx, const float* 
   la.cols = K; la.ld = ldx; la.vec = (ldx % 4 == 0); la.ones_col = 0;
   lb.cols = K; lb.ld = K; lb.vec = (K % 4 == 0); lb.ones_col = 0;
   ep.ld = ldy; ep.act = act; ep.ld_add = ld_add;
+  ep.vec = ldy % 4 == 0 && ld_add % 4 == 0;
   for (int p = 0; p < nprob; p++) {
     la.ptr[p] = x[p]; la.rows[p] = M[p]; la.vec &= aligned16(x[p]);
     lb.ptr[p] = w[p]; lb.rows[p] = N; lb.vec &= aligned16(w[p]);
     ep.bias[p] = b ? b[p] : nullptr; ep.y[p] = y[p]; ep.z[p] = z ? z[p] : nullptr;
     ep.addend[p] = addend ? addend[p] : nullptr;
+    ep.vec &= aligned16(ep.bias[p]) && aligned16(y[p]) && aligned16(ep.z[p]) && aligned16(ep.addend[p]);
     g.M[p] = M[p]; g.R[p] = K;
   }
   return gemm_launch<RowMajorLoader, RowMajorLoader, false, false, BiasActStore>(la, lb, ep, g, cd, st);
@@ -120,6 +122,7 @@ static int k_linear_fwd_splitk(int nprob, const float* const* x, int ldx, const 
   la.cols = K; la.ld = ldx; la.vec = (ldx % 4 == 0); la.ones_col = 0;
   lb.cols = K; lb.ld = K; lb.vec = (K % 4 == 0); lb.ones_col = 0;
   ep.N = N;
+  ep.vec = N % 4 == 0 && aligned16(ws);  // slab offsets are multiples of N
   float* cur = (float*)ws;
   int maxM = 0;
   for (int p = 0; p < nprob; p++) {
@@ -179,10 +182,12 @@ static int k_conv_fwd(int nprob, const void* const* x, const float* const* w, co
   la.g = cg; la.vec = conv_vec_ok(cg); la.ones_col = 0;
   lb.cols = K; lb.ld = K; lb.vec = 1; lb.ones_col = 0;
   ep.ld = cg.CO; ep.act = ACT_RELU;
+  ep.vec = cg.CO % 4 == 0;
   for (int p = 0; p < nprob; p++) {
     la.ptr[p] = (const InT*)x[p]; la.rows[p] = n_img[p] * cg.OH * cg.OW; la.vec &= aligned16(x[p]);
     lb.ptr[p] = w[p]; lb.rows[p] = cg.CO; lb.vec &= aligned16(w[p]);
     ep.bias[p] = b[p]; ep.y[p] = y[p]; ep.z[p] = nullptr;
+    ep.vec &= aligned16(b[p]) && aligned16(y[p]);
     g.M[p] = la.rows[p]; g.R[p] = K;
   }
   return gemm_launch<ConvColLoader<InT>, RowMajorLoader, false, false, BiasActStore>(la, lb, ep, g, cd, st);
@@ -217,10 +222,12 @@ static int k_linear_dgrad(int nprob, const float* const* dz, int ld_dz, const fl
   la.cols = O; la.ld = ld_dz; la.vec = (O % 4 == 0 && ld_dz % 4 == 0); la.ones_col = 0;
   lb.cols = I; lb.ld = I; lb.vec = (I % 4 == 0); lb.ones_col = 0;
   ep.ld = ld_out; ep.act = act_src; ep.ld_add = ld_add; ep.ld_src = ld_src < 0 ? ld_out : ld_src;
+  ep.vec = ep.ld % 4 == 0 && ep.ld_add % 4 == 0 && ep.ld_src % 4 == 0;
   for (int p = 0; p < nprob; p++) {
     la.ptr[p] = dz[p]; la.rows[p] = M[p]; la.vec &= aligned16(dz[p]);
     lb.ptr[p] = w[p]; lb.rows[p] = O; lb.vec &= aligned16(w[p]);
     ep.out[p] = out[p]; ep.src[p] = src ? src[p] : nullptr; ep.addend[p] = addend ? addend[p] : nullptr;
+    ep.vec &= aligned16(out[p]) && aligned16(ep.src[p]) && aligned16(ep.addend[p]);
     g.M[p] = M[p]; g.R[p] = O;
   }
   return gemm_launch<RowMajorLoader, RowMajorLoader, false, true, DgradStore>(la, lb, ep, g, cd, st);

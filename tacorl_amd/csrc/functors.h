@@ -92,6 +92,8 @@ struct BiasActStore {
   float* y[GEMM_MAXP];
   float* z[GEMM_MAXP];
   int ld, act, ld_add;
+  int vec;  // host-set: every pointer 16-byte aligned and every leading dimension a multiple of 4 -> store4 is legal
+  static constexpr bool VEC = true;  // contiguous along n: the kernel hands a lane 4 consecutive columns of one row
   __device__ __forceinline__ void store(int p, int, int m, int n, float acc) const {
     float zz = acc + (bias[p] ? bias[p][n] : 0.f);
     if (addend[p]) zz += addend[p][(long)m * ld_add + n];
@@ -99,14 +101,27 @@ struct BiasActStore {
     if (z[p]) z[p][o] = zz;
     y[p][o] = act_apply(act, zz);
   }
+  __device__ __forceinline__ void store4(int p, int, int m, int n, f32x4 acc) const {
+    f32x4 zz = acc;
+    if (bias[p]) zz += *reinterpret_cast<const f32x4*>(bias[p] + n);
+    if (addend[p]) zz += *reinterpret_cast<const f32x4*>(addend[p] + (long)m * ld_add + n);
+    const long o = (long)m * ld + n;
+    if (z[p]) *reinterpret_cast<f32x4*>(z[p] + o) = zz;
+    *reinterpret_cast<f32x4*>(y[p] + o) = f32x4{act_apply(act, zz[0]), act_apply(act, zz[1]), act_apply(act, zz[2]), act_apply(act, zz[3])};
+  }
 };
 // split-R forward: partial sums into slab[(s*M + m)*N + n]; finished by bias_act_reduce_kernel
 struct SplitStore {
   float* slab[GEMM_MAXP];
   int M[GEMM_MAXP];
   int N;
+  int vec;
+  static constexpr bool VEC = true;
   __device__ __forceinline__ void store(int p, int s, int m, int n, float acc) const {
     slab[p][((long)s * M[p] + m) * N + n] = acc;
+  }
+  __device__ __forceinline__ void store4(int p, int s, int m, int n, f32x4 acc) const {
+    *reinterpret_cast<f32x4*>(slab[p] + ((long)s * M[p] + m) * N + n) = acc;
   }
 };
 // out = acc * act'(src)   (src = pre-activation for SiLU, output for ReLU; NULL = identity)
@@ -115,10 +130,20 @@ struct DgradStore {
   const float* src[GEMM_MAXP];
   const float* addend[GEMM_MAXP];  // optional [M][N] added before the mask (BPTT: dH_{t-1})
   int ld, act, ld_add, ld_src;
+  int vec;
+  static constexpr bool VEC = true;
   __device__ __forceinline__ void store(int p, int, int m, int n, float acc) const {
     long o = (long)m * ld + n;
     if (addend[p]) acc += addend[p][(long)m * ld_add + n];
     out[p][o] = src[p] ? acc * act_grad(act, src[p][(long)m * ld_src + n]) : acc;
+  }
+  __device__ __forceinline__ void store4(int p, int, int m, int n, f32x4 acc) const {
+    if (addend[p]) acc += *reinterpret_cast<const f32x4*>(addend[p] + (long)m * ld_add + n);
+    if (src[p]) {
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(src[p] + (long)m * ld_src + n);
+      acc = f32x4{acc[0] * act_grad(act, sv[0]), acc[1] * act_grad(act, sv[1]), acc[2] * act_grad(act, sv[2]), acc[3] * act_grad(act, sv[3])};
+    }
+    *reinterpret_cast<f32x4*>(out[p] + (long)m * ld + n) = acc;
   }
 };
 // conv dgrad: row m of parity class -> NHWC input position; masks with ReLU of the input.
@@ -126,6 +151,7 @@ struct ConvDgradStore {
   float* out[GEMM_MAXP];
   const float* src[GEMM_MAXP];  // the conv input activation (post-ReLU) or NULL
   ConvGeom g;
+  static constexpr bool VEC = false;
   __device__ __forceinline__ void store(int p, int, int m, int n, float acc) const {
     const int S = g.S, cls = p % (S * S), py = cls / S, px = cls % S;
     const int nh = (g.H - py + S - 1) / S, nw = (g.W - px + S - 1) / S;
@@ -139,6 +165,7 @@ struct ConvDgradStore {
 struct WgradStore {
   float* slab[GEMM_MAXP];
   int K, O, nsplit;
+  static constexpr bool VEC = false;  // contiguous along the GEMM row (k): the row-per-lane layout is the right one
   __device__ __forceinline__ void store(int p, int s, int k, int o, float acc) const {
     slab[p][((long)s * O + o) * (K + 1) + k] = acc;
   }

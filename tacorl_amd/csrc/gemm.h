@@ -132,21 +132,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmAr
 #pragma unroll
       for (int i = 0; i < MI; i++)
 #pragma unroll
-        for (int j = 0; j < NI; j++) acc[i][j] = Atom::mma(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < NI; j++) {
+          // epilogues whose output is contiguous along n take the B tile as the MFMA's first operand: D^T, i.e. a lane
+          // ends with 4 consecutive columns of ONE row (a 16-byte store / mask load / addend load instead of four
+          // scalar ones with 64-bit address arithmetic each).  Same products, same accumulation order over k.
+          if constexpr (Epi::VEC) acc[i][j] = Atom::mma(b[j], a[i], acc[i][j]);
+          else acc[i][j] = Atom::mma(a[i], b[j], acc[i][j]);
+        }
     }
     __syncthreads();
   }
+  if constexpr (Epi::VEC) {
 #pragma unroll
-  for (int i = 0; i < MI; i++)
+    for (int i = 0; i < MI; i++) {
+      const int m = m0 + wave * MI * 16 + i * 16 + (lane & 15);
 #pragma unroll
-    for (int j = 0; j < NI; j++) {
-      int n = n0 + j * 16 + (lane & 15);
+      for (int j = 0; j < NI; j++) {
+        const int n = n0 + j * 16 + (lane >> 4) * 4;
+        if (m >= M) continue;
+        if (epi.vec && n + 3 < N) {
+          epi.store4(p, s, m, n, acc[i][j]);
+        } else {
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        int m = m0 + wave * MI * 16 + i * 16 + (lane >> 4) * 4 + q;
-        if (m < M && n < N) epi.store(p, s, m, n, acc[i][j][q]);
+          for (int q = 0; q < 4; q++)
+            if (n + q < N) epi.store(p, s, m, n + q, acc[i][j][q]);
+        }
       }
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < NI; j++) {
+        int n = n0 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          int m = m0 + wave * MI * 16 + i * 16 + (lane >> 4) * 4 + q;
+          if (m < M && n < N) epi.store(p, s, m, n, acc[i][j][q]);
+        }
+      }
+  }
 }
 
 // Host-side launcher: picks the tile for N and the atom for the compute dtype.
