@@ -85,6 +85,13 @@ int tacorl_linear_dgrad(int nprob, const float* const* dz, int ld_dz, const floa
                         float* const* out, int ld_out, const float* const* src, int ld_src, int act_src,
                         const float* const* addend, int ld_add, const int* M, int O, int I,
                         int compute_dtype, tacorl_stream_t stream);
+/* tacorl_linear_dgrad with the reduction split over workgroups (+ a reduce pass) when the output is skinny and O long;
+ * falls back to the single-pass form when a src mask is given or ws is too small (tacorl_linear_dgrad_ws_bytes). */
+size_t tacorl_linear_dgrad_ws_bytes(int nprob, const int* M, int O, int I);
+int tacorl_linear_dgrad_splitk(int nprob, const float* const* dz, int ld_dz, const float* const* w,
+                               float* const* out, int ld_out, const float* const* src, int ld_src, int act_src,
+                               const float* const* addend, int ld_add, const int* M, int O, int I,
+                               int compute_dtype, void* ws, size_t ws_bytes, tacorl_stream_t stream);
 size_t tacorl_linear_wgrad_ws_bytes(int nprob, const int* M, int K, int O);
 int tacorl_linear_wgrad(int nprob, const float* const* x, int ldx, const float* const* dz, int ld_dz,
                         const int* M, int K, int O, float* const* dw, float* const* db, int accumulate,

@@ -60,6 +60,8 @@ _SIGS = {
     "tacorl_logistic_mixture_loss": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p]),
     "tacorl_logistic_mixture_sample": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_linear_dgrad": (_i, [_i, _p, _i, _p, _p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p]),
+    "tacorl_linear_dgrad_ws_bytes": (_sz, [_i, _p, _i, _i]),
+    "tacorl_linear_dgrad_splitk": (_i, [_i, _p, _i, _p, _p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p, _sz, _p]),
     "tacorl_linear_wgrad_ws_bytes": (_sz, [_i, _p, _i, _i]),
     "tacorl_linear_wgrad": (_i, [_i, _p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _p, _sz, _p]),
     "tacorl_relu_mask_mul": (_i, [_p, _p, _p, _p, _l, _p]),

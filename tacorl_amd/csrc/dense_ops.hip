@@ -244,6 +244,52 @@ extern "C" int tacorl_linear_dgrad(int nprob, const float* const* dz, int ld_dz,
                         addend, ld_add, ld_src);
 }
 
+// The same with the reduction split over workgroups when the output is skinny and the reduction long (e.g. the
+// transformer FFN's first Linear: [4096 x 2048] . [2048 x 32] is 32 output tiles - 32 CUs streaming 33 MB - 42 us;
+// 16-way split + reduce: the whole chip).  Only without an activation-derivative source (the reduce pass adds the addend).
+extern "C" size_t tacorl_linear_dgrad_ws_bytes(int nprob, const int* M, int O, int I) {
+  return tacorl_linear_add_fwd_ws_bytes(nprob, M, O, I);
+}
+extern "C" int tacorl_linear_dgrad_splitk(int nprob, const float* const* dz, int ld_dz, const float* const* w,
+                                          float* const* out, int ld_out, const float* const* src, int ld_src, int act_src,
+                                          const float* const* addend, int ld_add, const int* M, int O, int I,
+                                          int compute_dtype, void* ws, size_t ws_bytes, tacorl_stream_t stream) {
+  if (nprob < 1 || nprob > GEMM_MAXP) FAIL(TACORL_EINVAL, "linear_dgrad: nprob %d", nprob);
+  hipStream_t st = (hipStream_t)stream;
+  const int ns = splitk_choice(nprob, M, O, I);
+  long need = 0;
+  for (int p = 0; p < nprob; p++) need += (long)ns * M[p] * I;
+  bool masked = false;
+  for (int p = 0; p < nprob; p++) masked |= src && src[p];
+  if (ns == 1 || masked || ws == nullptr || (size_t)need * sizeof(float) > ws_bytes)
+    return k_linear_dgrad(nprob, dz, ld_dz, w, out, ld_out, src, act_src, M, O, I, compute_dtype, st, addend, ld_add, ld_src);
+  RowMajorLoader la{}, lb{};
+  SplitStore ep{};
+  GemmArgs g{};
+  ReduceTbl t{};
+  g.nprob = nprob; g.nsplit = ns; g.N = I;
+  la.cols = O; la.ld = ld_dz; la.vec = (O % 4 == 0 && ld_dz % 4 == 0); la.ones_col = 0;
+  lb.cols = I; lb.ld = I; lb.vec = (I % 4 == 0); lb.ones_col = 0;
+  ep.N = I;
+  ep.vec = I % 4 == 0 && aligned16(ws);
+  float* cur = (float*)ws;
+  int maxM = 0;
+  for (int p = 0; p < nprob; p++) {
+    la.ptr[p] = dz[p]; la.rows[p] = M[p]; la.vec &= aligned16(dz[p]);
+    lb.ptr[p] = w[p]; lb.rows[p] = O; lb.vec &= aligned16(w[p]);
+    ep.slab[p] = cur; ep.M[p] = M[p];
+    t.slab[p] = cur; t.bias[p] = nullptr; t.addend[p] = addend ? addend[p] : nullptr; t.y[p] = out[p]; t.M[p] = M[p];
+    cur += (long)ns * M[p] * I;
+    g.M[p] = M[p]; g.R[p] = O;
+    maxM = M[p] > maxM ? M[p] : maxM;
+  }
+  CHECK((gemm_launch<RowMajorLoader, RowMajorLoader, false, true, SplitStore>(la, lb, ep, g, compute_dtype, st)));
+  const long total = (long)maxM * I;
+  dim3 grid((unsigned)(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), nprob);
+  hipLaunchKernelGGL(bias_act_reduce_kernel, grid, dim3(256), 0, st, t, ns, I, ld_out, ld_add, ACT_NONE);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
 // conv: gather form, one GEMM per input-pixel parity class (S*S classes per net).
 static int k_conv_dgrad(int nnets, const float* const* dout, const float* const* w, float* const* din,
                         const float* const* src, const int* n_img, const ConvGeom& cg, int cd,

@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmAr
   const int p = blockIdx.z / g.nsplit;
   const int s = blockIdx.z % g.nsplit;
   const int M = g.M[p], N = g.N, R = g.R[p];
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // n tiles are the fast grid index: workgroups that run together write neighbouring column blocks of the SAME rows
+  // (whole output rows per DRAM page instead of 256-byte pieces 128 rows apart) and share the A tile in L2
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   if (m0 >= M) return;
   constexpr int RQ = BK > 64 ? BK : 64;  // split boundaries: multiple of every tile depth in use
   int rs = ((R + g.nsplit - 1) / g.nsplit + RQ - 1) / RQ * RQ;
@@ -190,7 +192,7 @@ static int gemm_launch(const LA& la, const LB& lb, const Epi& epi, const GemmArg
     if (compute_dtype == DT_BF16 && (maxR + g.nsplit - 1) / g.nsplit >= 96) {
 #define GEMM_GO_DEEP(BN_)                                                                                  \
   do {                                                                                                     \
-    dim3 grid(cdiv(maxM, 128), cdiv(g.N, BN_), g.nprob * g.nsplit);                                        \
+    dim3 grid(cdiv(g.N, BN_), cdiv(maxM, 128), g.nprob * g.nsplit);                                        \
     hipLaunchKernelGGL((gemm_kernel<AtomBF16, LA, LB, TA, TB, Epi, 128, BN_, 128>), grid, dim3(256), 0, st, \
                        la, lb, epi, g);                                                                    \
   } while (0)
@@ -203,7 +205,7 @@ static int gemm_launch(const LA& la, const LB& lb, const Epi& epi, const GemmArg
   }
 #define GEMM_GO(ATOM, BM_, BN_)                                                              \
   do {                                                                                       \
-    dim3 grid(cdiv(maxM, BM_), cdiv(g.N, BN_), g.nprob * g.nsplit);                          \
+    dim3 grid(cdiv(g.N, BN_), cdiv(maxM, BM_), g.nprob * g.nsplit);                          \
     hipLaunchKernelGGL((gemm_kernel<ATOM, LA, LB, TA, TB, Epi, BM_, BN_>), grid, dim3(256), \
                        0, st, la, lb, epi, g);                                               \
   } while (0)

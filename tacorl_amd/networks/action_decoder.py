@@ -255,10 +255,12 @@ class ActionDecoderLogistic:
 
     def _dgrad(self, dz, ld_dz, w, out, ld_out, M, O, I, compute, src=None, ld_src=0, act=ACT_NONE, addend=None,
                ld_add=0):
-        call("tacorl_linear_dgrad", 1, ops.ptr_array([dz]), ld_dz, ops.ptr_array([w]), ops.ptr_array([out]), ld_out,
+        nb = ops.L.lib().tacorl_linear_dgrad_ws_bytes(1, ops.int_array([M]), O, I)  # split reduction for skinny outputs
+        ws = ops.workspace(nb, self.dev, "ad_dgrad")
+        call("tacorl_linear_dgrad_splitk", 1, ops.ptr_array([dz]), ld_dz, ops.ptr_array([w]), ops.ptr_array([out]), ld_out,
              ops.ptr_array([src]) if src is not None else None, ld_src, act,
              ops.ptr_array([addend]) if addend is not None else None, ld_add, ops.int_array([M]), O, I, compute,
-             ops.stream())
+             ptr(ws), ws.numel(), ops.stream())
 
     def _layer_wgrads(self, l, B, Tm, compute, fast):
         """W_hh / W_ih / bias gradients of layer l (its BPTT has been issued)."""

@@ -209,10 +209,12 @@ class PlanRecognition:
 
     def _dgrad(self, dz, ld_dz, w, out, ld_out, M, O, I, compute, src=None, ld_src=0, act=ACT_NONE, addend=None,
                ld_add=0):
-        call("tacorl_linear_dgrad", 1, ops.ptr_array([dz]), ld_dz, ops.ptr_array([w]), ops.ptr_array([out]), ld_out,
+        nb = ops.L.lib().tacorl_linear_dgrad_ws_bytes(1, ops.int_array([M]), O, I)  # split reduction for skinny outputs
+        ws = ops.workspace(nb, self.dev, "lin_dgrad")
+        call("tacorl_linear_dgrad_splitk", 1, ops.ptr_array([dz]), ld_dz, ops.ptr_array([w]), ops.ptr_array([out]), ld_out,
              ops.ptr_array([src]) if src is not None else None, ld_src, act,
              ops.ptr_array([addend]) if addend is not None else None, ld_add, ops.int_array([M]), O, I, compute,
-             ops.stream())
+             ptr(ws), ws.numel(), ops.stream())
 
     def _ln_bwd(self, dy, x, res, w, stats, dv, dw, db, R, D):
         nb = ops.L.lib().tacorl_add_layernorm_bwd_ws_bytes(R, D)

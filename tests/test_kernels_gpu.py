@@ -602,6 +602,38 @@ def test_rnn_bptt_step_and_transpose():
     assert torch.equal(yb, y.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("compute,tol", [(0, TOL_F32), (1, TOL_BF16)])
+@pytest.mark.parametrize("M,O,I,masked", [(512, 2048, 32, False), (256, 4096, 32, False), (300, 96, 32, False), (512, 2048, 32, True)])
+def test_linear_dgrad_splitk(compute, tol, M, O, I, masked):
+    """dX = dZ W (+ addend) (* act'(src)): the split-reduction entry vs the single-pass one and vs torch; with a mask
+    source (or a short reduction) it must fall back to the single pass and still be right."""
+    from tacorl_amd import _lib, ops
+
+    dev = _dev()
+    dz, w, add, src = rnd(M, O, seed=1), rnd(O, I, seed=2) / math.sqrt(O), rnd(M, I, seed=3), rnd(M, I, seed=4)
+    ref = dz @ w + add
+    if masked:
+        ref = ref * (src > 0)
+    dzd, wd, addd, srcd = dz.to(dev), w.to(dev), add.to(dev), src.to(dev)
+    outs = []
+    for split in (False, True):
+        out = torch.full((M, I), float("nan"), device=dev)
+        args = [1, ops.ptr_array([dzd]), O, ops.ptr_array([wd]), ops.ptr_array([out]), I,
+                ops.ptr_array([srcd]) if masked else None, I, 1 if masked else 0, ops.ptr_array([addd]), I, ops.int_array([M]), O, I,
+                compute]
+        if split:
+            nb = _lib.lib().tacorl_linear_dgrad_ws_bytes(1, ops.int_array([M]), O, I)
+            assert (nb > 0) == (O >= 512)
+            ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
+            ops.call("tacorl_linear_dgrad_splitk", *args, ops.ptr(ws), ws.numel(), ops.stream())
+        else:
+            ops.call("tacorl_linear_dgrad", *args, ops.stream())
+        torch.cuda.synchronize()
+        assert relerr(out, ref) < tol, (split, relerr(out, ref))
+        outs.append(out)
+    assert relerr(outs[1], outs[0]) < (1e-6 if compute == 0 else 1e-5)
+
+
 @pytest.mark.parametrize("R,M,N,ld", [(64, 128, 128, 128), (192, 256, 384, 512), (1024, 512, 256, 512)])
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_rnn_wgrad(R, M, N, ld, accumulate):
