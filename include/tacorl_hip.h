@@ -75,6 +75,12 @@ int tacorl_rnn_linear_bwd_step(const void* x_bf16, const void* wt_bf16, const fl
 int tacorl_rnn_wgrad_supported(int R, int M, int N);
 int tacorl_rnn_wgrad(const void* dz_bf16, int ld_dz, const void* x_bf16, int ld_x, int R, int M, int N, float* dw,
                      float* db, int accumulate, tacorl_stream_t stream);
+/* The BPTT wavefront launch: nprob <= 4 problems y[p] = (x[p] Wt[p]^T + addend[p]) * [mask_src[p] > 0] (addend / mask
+ * entries may be NULL) of one shape, fp32 y + optional bf16 copy: recurrent gradient steps of all layers and the
+ * projection dH_{l-1}[t] = dZ_l[t] W_ih_l (Wt = W_ih_l^T) side by side (reference: autograd of nn.RNN, rnn_models.py:5-16). */
+int tacorl_rnn_linear_bwd_batch(int nprob, const void* const* x_bf16, const void* const* wt_bf16,
+                                const float* const* addend, int ld_add, const float* const* mask_src,
+                                float* const* y, void* const* y_bf16, int M, int K, int N, tacorl_stream_t stream);
 /* dst[c][r] = bf16(src[r][c]); R, C multiples of 32. */
 int tacorl_transpose_to_bf16(const float* src, void* dst, int R, int C, tacorl_stream_t stream);
 

@@ -29,6 +29,8 @@ if os.environ.get('ONLY') != 'plmp':
   print(f"C3 TACORL finetune_action_decoder=True B={B}: {timeit(lambda: mod.training_step(batch)):.3f} ms/step", flush=True)
 if os.environ.get('ONLY') == 'c3': sys.exit(0)
 p = lmp(); p.log_every_n_steps = 50
+if os.environ.get('WAVEFRONT') is not None: p.ad.bptt_wavefront = bool(int(os.environ['WAVEFRONT']))
+if os.environ.get('BRANCHES') is not None: p.branches = bool(int(os.environ['BRANCHES']))
 try:
     p.enable_graph()
 except Exception as e:

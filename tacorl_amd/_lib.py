@@ -32,6 +32,7 @@ _SIGS = {
     "tacorl_rnn_linear_fwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "tacorl_rnn_linear_fwd_batch": (_i, [_i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p]),
     "tacorl_rnn_linear_bwd_step": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p]),
+    "tacorl_rnn_linear_bwd_batch": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_rnn_wgrad_supported": (_i, [_i, _i, _i]),
     "tacorl_rnn_wgrad": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _i, _p]),
     "tacorl_transpose_to_bf16": (_i, [_p, _p, _i, _i, _p]),

@@ -187,6 +187,26 @@ extern "C" int tacorl_rnn_linear_bwd_step(const void* x_bf16, const void* wt_bf1
   return launch_ring<64, 32, 4>(a, (hipStream_t)stream);
 }
 
+/* BPTT as a wavefront: nprob <= 4 independent y = (x Wt^T + addend) * [mask_src > 0] of one shape in ONE launch - the
+ * recurrent gradient step of every layer plus the projection of the upper layer's dZ onto the lower layer's hidden
+ * state (dH_{l-1}[t] = dZ_l[t] W_ih_l: Wt = W_ih_l^T, no mask) - T + 1 launches instead of L (T - 1) + a projection GEMM. */
+extern "C" int tacorl_rnn_linear_bwd_batch(int nprob, const void* const* x_bf16, const void* const* wt_bf16,
+                                           const float* const* addend, int ld_add, const float* const* mask_src,
+                                           float* const* y, void* const* y_bf16, int M, int K, int N, tacorl_stream_t stream) {
+  if (nprob < 1 || nprob > RNN_MAXP || !tacorl_rnn_linear_supported(M, K, N) || ld_add % 4) return TACORL_EINVAL;
+  RnnBatch ab{};
+  for (int p = 0; p < nprob; p++) {
+    const float* ad = addend ? addend[p] : nullptr;
+    const float* ms = mask_src ? mask_src[p] : nullptr;
+    void* yb = y_bf16 ? y_bf16[p] : nullptr;
+    if (((uintptr_t)x_bf16[p] | (uintptr_t)wt_bf16[p] | (uintptr_t)y[p] | (uintptr_t)ad | (uintptr_t)ms) & 15) return TACORL_EINVAL;
+    if ((uintptr_t)yb & 7) return TACORL_EINVAL;
+    ab.p[p] = RnnArgs{(const __bf16*)x_bf16[p], (const __bf16*)wt_bf16[p], nullptr, ad, ms, y[p], (__bf16*)yb, M, K, N, ld_add, ACT_NONE};
+  }
+  if (M % 128 == 0 && N % 64 == 0) return launch_ring<128, 64, 2, 8>(ab, nprob, (hipStream_t)stream);
+  return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients of the RNN's 2048 x 2048 matrices: dW[o][k] = sum_r dZ[r][o] * x[r][k] over r = (time, batch)
 // rows (reference: autograd of torch nn.RNN's W_hh / W_ih, rnn_models.py:5-16).  Both operands exist as bf16 row-major

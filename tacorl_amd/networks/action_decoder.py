@@ -240,7 +240,7 @@ class ActionDecoderLogistic:
             # that branch crashed hipStreamEndCapture on ROCm 7.2; forked from and joined into the main stream instead - with
             # the Adam step moved behind the join - it captured, and the step went 1.82 -> 2.10 ms: three concurrent
             # chains of chip-wide kernels slow each other more than the overlap returns)
-            self.backward(B, T - 1, module.compute, need_input_grad=False)
+            self.backward(B, T - 1, module.compute, need_input_grad=False, wavefront=False)
             module.engine._allreduce([self.blk.grad])
             ops.adam_step(self.blk.param, self.blk.grad, self.blk.m, self.blk.v, module.action_decoder_lr, 0.0,
                           self.blk.step)
@@ -286,17 +286,60 @@ class ActionDecoderLogistic:
         call("tacorl_copy_cols", blk.g(f"rnn.bias_ih_l{l}"), H, blk.g(f"rnn.bias_hh_l{l}"), H, 1, H, 0, 0,
              ops.stream())
 
-    def backward(self, B, Tm, compute, need_input_grad=False, wgrad_stream=None, join=True):
+    def _bptt_wavefront(self, B, Tm):
+        """BPTT of all layers as a wavefront of batched ring-GEMM launches (rnn_ops.hip tacorl_rnn_linear_bwd_batch).
+        With k = L-1-l the depth of layer l below the top, launch s holds
+          step(l, u), u = Tm-2-(s-2k):  dZ_l[u] = (dZ_l[u+1] W_hh_l + dH_l[u]) * [h_l[u] > 0]
+          proj(l, t), t = Tm-1-(s-2k):  dH_{l-1}[t] = dZ_l[t] W_ih_l  (t = Tm-1: masked by h_{l-1}[t], i.e. dZ_{l-1}[Tm-1] itself)
+        whose operands all left launch s-1: Tm-1 + 2(L-1) launches instead of L(Tm-1) + (L-1) projection GEMMs."""
+        blk, H, L = self.blk, self.hidden, self.L
+        at = ops._at
+        bfp = lambda t, off: C.c_void_p(t.data_ptr() + 2 * off)  # noqa: E731
+        row = lambda t: t * B * H  # noqa: E731
+        for l in range(L):
+            call("tacorl_transpose_to_bf16", blk.p(f"rnn.weight_hh_l{l}"), ptr(self.whtb[l]), H, H, ops.stream())
+            if l >= 1:
+                call("tacorl_transpose_to_bf16", blk.p(f"rnn.weight_ih_l{l}"), ptr(self.wihtb[l]), H, H, ops.stream())
+        top, last = L - 1, row(Tm - 1)
+        call("tacorl_relu_mask_mul", at(self.dHs[top], last), None, at(self.h[top], last), at(self.DZ[top], last), B * H, ops.stream())
+        call("tacorl_to_bf16_batch", 1, ops.ptr_array([at(self.DZ[top], last)]), ops.ptr_array([bfp(self.DZb[top], last)]),
+             (C.c_long * 1)(B * H), ops.stream())
+        for s_ in range(Tm - 1 + 2 * (L - 1)):
+            xs, wt, ad, ms, ys, yb = [], [], [], [], [], []
+            for l in range(L):
+                j = s_ - 2 * (L - 1 - l)
+                if j < 0:
+                    continue
+                u = Tm - 2 - j
+                if u >= 0:
+                    xs.append(bfp(self.DZb[l], row(u + 1))); wt.append(ptr(self.whtb[l])); ad.append(at(self.dHs[l], row(u)))
+                    ms.append(at(self.h[l], row(u))); ys.append(at(self.DZ[l], row(u))); yb.append(bfp(self.DZb[l], row(u)))
+                t = Tm - 1 - j
+                if l >= 1 and t >= 0:
+                    xs.append(bfp(self.DZb[l], row(t))); wt.append(ptr(self.wihtb[l])); ad.append(None)
+                    if t == Tm - 1:
+                        ms.append(at(self.h[l - 1], row(t))); ys.append(at(self.DZ[l - 1], row(t))); yb.append(bfp(self.DZb[l - 1], row(t)))
+                    else:
+                        ms.append(None); ys.append(at(self.dHs[l - 1], row(t))); yb.append(None)
+            if xs:
+                call("tacorl_rnn_linear_bwd_batch", len(xs), ops.ptr_array(xs), ops.ptr_array(wt), ops.ptr_array(ad), H,
+                     ops.ptr_array(ms), ops.ptr_array(ys), ops.ptr_array(yb), B, H, H, ops.stream())
+
+    def backward(self, B, Tm, compute, need_input_grad=False, wgrad_stream=None, join=True, wavefront=True):
         """Gradients of the loss (dL/dheads in self.d_heads) into self.blk.grad; optionally
         d(x_seq) into self.dx_seq.  ReLU-RNN BPTT: dz_{t-1} = (dz_t W_hh + dH_{t-1}) * [h_{t-1} > 0].
         wgrad_stream: the weight gradients - which only the optimiser reads - go to that stream (a branch of a
         captured graph) beside the dependent chain heads -> BPTT -> input gradient; join=False leaves the join
-        (`current.wait_stream(wgrad_stream)`) to the caller, who may put more work in front of it."""
+        (`current.wait_stream(wgrad_stream)`) to the caller, who may put more work in front of it.
+        wavefront: BPTT as Tm+1 batched launches (_bptt_wavefront) - right when this backward has the chip to itself
+        (PlayLMP: 3.06 -> 2.98 ms/step); beside another chain (TACORL fine-tuning: a branch beside the CQL update) the
+        chip-wide batched launches cost more than they save (1.80 -> 2.43 ms/step), there one launch per step stays."""
         blk, H, R, L = self.blk, self.hidden, B * Tm, self.L
         if getattr(self, "_bshape", None) != (B, Tm):
             ops.note_alloc()
             f = lambda *s: torch.zeros(*s, device=self.dev)  # noqa: E731
-            self.dH = f(R, H)
+            self.dHs = [f(R, H) for _ in range(L)]  # dL/dh_l before the ReLU mask, per layer (the wavefront needs them side by side)
+            self.dH = self.dHs[L - 1]
             self.DZ = [f(R, H) for _ in range(L)]
             self.dx_seq = f(R, self.P + self.E)
             self._bshape = (B, Tm)
@@ -318,11 +361,22 @@ class ActionDecoderLogistic:
             bf = lambda *s: torch.zeros(*s, device=self.dev, dtype=torch.bfloat16)  # noqa: E731
             self.DZb = [bf(R, H) for _ in range(L)]   # bf16 copies of dZ_t: the ring GEMM's operand
             self.whtb = [bf(H, H) for _ in range(L)]  # W_hh^T
+            self.wihtb = [None] + [bf(H, H) for _ in range(1, L)]  # W_ih^T of layers >= 1 (wavefront projections)
             self._bptt_shape = (B, Tm)
+        if fast and Tm > 1 and 2 * L - 1 <= 4 and wavefront and getattr(self, "bptt_wavefront", True):
+            self._bptt_wavefront(B, Tm)
+            for l in reversed(range(L)):
+                side(lambda l=l: self._layer_wgrads(l, B, Tm, compute, fast))
+            if need_input_grad:
+                K = self.P + self.E
+                self._dgrad(self.DZ[0], H, blk.p("rnn.weight_ih_l0"), self.dx_seq, K, R, H, K, compute)
+            if wgrad_stream is not None and join:
+                torch.cuda.current_stream().wait_stream(wgrad_stream)
+            return
         for l in reversed(range(L)):
             h, DZ = self.h[l], self.DZ[l]
             last = (Tm - 1) * B * H
-            call("tacorl_relu_mask_mul", at(self.dH, last), None, at(h, last), at(DZ, last), B * H, ops.stream())
+            call("tacorl_relu_mask_mul", at(self.dHs[l], last), None, at(h, last), at(DZ, last), B * H, ops.stream())
             if fast and Tm > 1:
                 # BPTT steps as one launch each (LDS-DMA ring GEMM on W_hh^T) instead of a 64-workgroup GEMM
                 call("tacorl_transpose_to_bf16", blk.p(f"rnn.weight_hh_l{l}"), ptr(self.whtb[l]), H, H, ops.stream())
@@ -330,17 +384,16 @@ class ActionDecoderLogistic:
                      ops.ptr_array([C.c_void_p(self.DZb[l].data_ptr() + 2 * last)]), (C.c_long * 1)(B * H), ops.stream())
                 for t in range(Tm - 1, 0, -1):
                     call("tacorl_rnn_linear_bwd_step", C.c_void_p(self.DZb[l].data_ptr() + 2 * t * B * H), ptr(self.whtb[l]),
-                         at(self.dH, (t - 1) * B * H), H, at(h, (t - 1) * B * H), at(DZ, (t - 1) * B * H),
+                         at(self.dHs[l], (t - 1) * B * H), H, at(h, (t - 1) * B * H), at(DZ, (t - 1) * B * H),
                          C.c_void_p(self.DZb[l].data_ptr() + 2 * (t - 1) * B * H), B, H, H, ops.stream())
             else:
                 for t in range(Tm - 1, 0, -1):
                     self._dgrad(at(DZ, t * B * H), H, blk.p(f"rnn.weight_hh_l{l}"), at(DZ, (t - 1) * B * H), H, B, H, H,
                                 compute, src=at(h, (t - 1) * B * H), ld_src=H, act=ACT_RELU,
-                                addend=at(self.dH, (t - 1) * B * H), ld_add=H)
+                                addend=at(self.dHs[l], (t - 1) * B * H), ld_add=H)
             side(lambda l=l: self._layer_wgrads(l, B, Tm, compute, fast))
             if l > 0:
-                # (overwrites dH, which the side stream's mean_fc / layer-l weight gradients do not read)
-                self._dgrad(DZ, H, blk.p(f"rnn.weight_ih_l{l}"), self.dH, H, R, H, H, compute)
+                self._dgrad(DZ, H, blk.p(f"rnn.weight_ih_l{l}"), self.dHs[l - 1], H, R, H, H, compute)
             elif need_input_grad:
                 K = self.P + self.E
                 self._dgrad(DZ, H, blk.p("rnn.weight_ih_l0"), self.dx_seq, K, R, H, K, compute)
