@@ -112,6 +112,24 @@ class TACORL(CQL_Offline):
                                       act=self.f_act[c], n=B * T) for c in self.all_modalities]
         self._T = (B, T, tuple(sorted(hw.items())))
 
+    def _stage_small(self, batch, noise, B, T):
+        e = self.engine
+        disp, acts = batch["disp"], batch["actions"] if self.ad is not None else None
+        dd = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.uint8: 3, torch.bool: 3}.get(disp.dtype)
+        if (dd is not None and disp.is_cuda and disp.is_contiguous() and disp.numel() == B
+                and (acts is None or (acts.is_cuda and acts.is_contiguous() and acts.dtype == torch.float32
+                                      and acts.shape == self.acts.shape))):
+            # reward = done = (disp == 1) and the action window, one launch
+            call("tacorl_stage_transition", ptr(disp), dd, ptr(self.reward), ptr(e.done), B,
+                 ptr(acts) if acts is not None else None, ptr(self.acts) if acts is not None else None,
+                 acts.numel() if acts is not None else 0, ops.stream())
+        else:
+            if acts is not None:
+                self.acts.copy_(acts)
+            self.reward.copy_(disp == 1)
+            e.done.copy_(self.reward)
+        e.set_noise(noise)
+
     def _stage_frames(self, batch, noise, nchw=True):
         """Eager part of the step: pack the window frames (reference NCHW fp32 -> NHWC image dtype) into
         fixed buffers, copy the small tensors, draw / copy the noise.
@@ -129,6 +147,18 @@ class TACORL(CQL_Offline):
         self._ensure_seq(B, T, hw)
         xd = BF16 if self.img_dtype == torch.bfloat16 else F32
         e = self.engine
+        if self.ad is not None and (getattr(self, "acts", None) is None or self.acts.shape[:2] != (B, T)):
+            ops.note_alloc()
+            self.acts = torch.zeros(B, T, 7, device=self.dev)
+        # the small launches of the eager part (reward / done / action window, the two noise generators) go beside the
+        # HBM-bound image pack on a second stream instead of behind it
+        if getattr(self, "_stage_stream", None) is None:
+            self._stage_stream = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream()
+        side = self._stage_stream if getattr(self, "stage_side", True) else main
+        side.wait_stream(main)  # the previous step's graph read these buffers
+        with torch.cuda.stream(side):
+            self._stage_small(batch, noise, B, T)
         # get_rl_batch (tacorl.py:142-179) as strided views: s = states[:,0], s' = states[:,-1]
         for c in sorted(set(self.all_modalities) | set(e.cams)):
             H, W = hw[c]
@@ -168,24 +198,7 @@ class TACORL(CQL_Offline):
             else:
                 for src, pitch, dst, n in jobs:
                     call("tacorl_pack_images", src, pitch, int(nchw), dst, xd, n, 3, H, W, ops.stream())
-        if self.ad is not None and (getattr(self, "acts", None) is None or self.acts.shape[:2] != (B, T)):
-            ops.note_alloc()
-            self.acts = torch.zeros(B, T, 7, device=self.dev)
-        disp, acts = batch["disp"], batch["actions"] if self.ad is not None else None
-        dd = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.uint8: 3, torch.bool: 3}.get(disp.dtype)
-        if (dd is not None and disp.is_cuda and disp.is_contiguous() and disp.numel() == B
-                and (acts is None or (acts.is_cuda and acts.is_contiguous() and acts.dtype == torch.float32
-                                      and acts.shape == self.acts.shape))):
-            # reward = done = (disp == 1) and the action window, one launch
-            call("tacorl_stage_transition", ptr(disp), dd, ptr(self.reward), ptr(e.done), B,
-                 ptr(acts) if acts is not None else None, ptr(self.acts) if acts is not None else None,
-                 acts.numel() if acts is not None else 0, ops.stream())
-        else:
-            if acts is not None:
-                self.acts.copy_(acts)
-            self.reward.copy_(disp == 1)
-            e.done.copy_(self.reward)
-        e.set_noise(noise)
+        main.wait_stream(side)
         return B, T, hw
 
     def _ad_due(self):
