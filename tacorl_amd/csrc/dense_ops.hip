@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void softargmax_bwd_kernel(SaArgs a, int OH, i
 }
 // Same math, all problems of the fused backward in one launch: one workgroup per image, a wave owns 16
 // channels x 4 pixel groups, every activation is read once and kept in registers.
-#define SAB_MAXI 13  // pixels per lane: conv3 output <= 52 pixels (the fused geometries have 49 / 16 / 8)
+#define SAB_MAXI_BIG 36  // pixels per lane: conv3 output <= 52 pixels (49 / 16 / 8 at 84 / 64 / 44x60) with 13, <= 144 (128 x 128) with 36
 struct SabArgs {
   const float* y3[EBW_MAXP];
   const float* temp[EBW_MAXP];
@@ -508,6 +508,7 @@ struct SabArgs {
   float* gtemp[EBW_MAXP];
   int n[EBW_MAXP];
 };
+template <int SAB_MAXI>
 __global__ __launch_bounds__(256) void softargmax_bwd_batch_kernel(SabArgs a, int P, int OW) {
   // lane = channel (a pixel's 64 channels are one 256-byte row: every load / store instruction moves whole rows),
   // wave w takes pixels w, w + 4, ...; the per-channel max / sum meet across the four waves in LDS
@@ -902,7 +903,7 @@ extern "C" int tacorl_encoder_bwd_fused_conv_parts(int nprob, const void* const*
   EncBwdPlan pl;
   if (!enc_bwd_plan(nprob, n_img, H, W, pl)) FAIL(TACORL_EINVAL, "encoder_bwd_fused_conv: geometry %dx%d / nprob %d", H, W, nprob);
   if (ws_bytes < pl.total) FAIL(TACORL_ENOMEM, "encoder_bwd_fused_conv: workspace too small");
-  if (pl.d.c3.OH * pl.d.c3.OW > 4 * SAB_MAXI) FAIL(TACORL_EINVAL, "encoder_bwd_fused: conv3 output too large");
+  if (pl.d.c3.OH * pl.d.c3.OW > 4 * SAB_MAXI_BIG) FAIL(TACORL_EINVAL, "encoder_bwd_fused: conv3 output too large");
   EbwProblem pr[EBW_MAXP];
   enc_bwd_conv_problems(nprob, img, params, act, grads, n_img, pl, ws, pr);
   SabArgs sb{};
@@ -913,7 +914,9 @@ extern "C" int tacorl_encoder_bwd_fused_conv_parts(int nprob, const void* const*
     sb.gtemp[p] = grads[p] + pl.po[E_T]; sb.n[p] = n_img[p];
   }
   if (pl.maxn > 0 && (parts & 1)) {
-    hipLaunchKernelGGL(softargmax_bwd_batch_kernel, dim3((unsigned)pl.maxn, nprob), dim3(256), 0, st, sb, pl.d.c3.OH * pl.d.c3.OW, pl.d.c3.OW);
+    const int P3 = pl.d.c3.OH * pl.d.c3.OW;
+    if (P3 <= 4 * 13) hipLaunchKernelGGL(softargmax_bwd_batch_kernel<13>, dim3((unsigned)pl.maxn, nprob), dim3(256), 0, st, sb, P3, pl.d.c3.OW);
+    else hipLaunchKernelGGL(softargmax_bwd_batch_kernel<SAB_MAXI_BIG>, dim3((unsigned)pl.maxn, nprob), dim3(256), 0, st, sb, P3, pl.d.c3.OW);
     hipLaunchKernelGGL(sum_to_scalar_batch_kernel, dim3(nprob), dim3(256), 0, st, sb, accumulate);
   }
   if (!(parts & EBW_ALL)) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;

@@ -133,16 +133,26 @@ template <int H, int W> struct TrTile<ConvL<8, 4, 3, 32, H, W>> { static constex
 template <class L>
 struct TrGeo {
   using T = TrTile<L>;
-  static constexpr int NPIX = L::OH * L::OW, KS = (NPIX + 31) / 32, KQ = KS * 32;
+  static constexpr bool IMG = L::CI < 8;
   static constexpr int DZR = L::CO + 16;                       // dZ row pitch (elements): 160 B / 96 B
   static constexpr int CIP = T::CIP;                           // input pixel pitch (elements)
+  static constexpr int NPIX_ALL = L::OH * L::OW;
+  // conv1 of a large camera (128 x 128: 95 KB of dZ1 + the 98 KB image) does not fit LDS even single-buffered: the image
+  // is then processed in NBAND bands of BR output rows = (BR - 1) S + KH input rows; dW simply keeps accumulating
+  static constexpr size_t WHOLE_BYTES = ((size_t)((NPIX_ALL + 31) / 32 * 32) * DZR + (size_t)(L::IH * L::IW * CIP + 7) / 8 * 8) * 2;
+  static constexpr int NBAND = (IMG && WHOLE_BYTES > 160 * 1024) ? 2 : 1;
+  static constexpr int BR = (L::OH + NBAND - 1) / NBAND;       // output rows per band (the last band may have fewer)
+  static constexpr int BROWS = NBAND == 1 ? L::IH : (BR - 1) * L::S + L::KH;  // input rows staged per band
+  static constexpr int NPIX = BR * L::OW, KS = (NPIX + 31) / 32, KQ = KS * 32;
   static constexpr int DZ_EL = KQ * DZR;
-  static constexpr int IN_EL = (L::IH * L::IW * CIP + 7) / 8 * 8;
+  static constexpr int IN_EL = (BROWS * L::IW * CIP + 7) / 8 * 8;
   static constexpr int BUF_EL = DZ_EL + IN_EL;
+  static constexpr int NBUF = (T::NBUF == 2 && (size_t)2 * BUF_EL * 2 <= 160 * 1024 && NBAND == 1) ? 2 : 1;
   static constexpr int MPW = L::MT / T::MGRP, NPW = L::NTL / T::NGRP, TPW = MPW * NPW;
-  static constexpr size_t lds_bytes = (size_t)T::NBUF * BUF_EL * 2;
+  static constexpr size_t lds_bytes = (size_t)NBUF * BUF_EL * 2;
   static constexpr int SLABF = T::KGRP * (L::CO * L::TAPS + L::CO);  // floats per workgroup slab
   static_assert(L::MT % T::MGRP == 0 && L::NTL % T::NGRP == 0 && T::MGRP * T::NGRP * T::KGRP == NW, "wave tiling");
+  static_assert(lds_bytes <= 160 * 1024, "wgrad tile does not fit LDS");
 };
 
 template <class L, class InT, class DzT>
@@ -187,48 +197,56 @@ __global__ __launch_bounds__(NT) void ebw_wgrad_tr_kernel(WgArgs a) {
   const DzT* dz = reinterpret_cast<const DzT*>(a.dz[p]);
   // ---- staging: 8-element chunks, global -> registers (in flight during the MFMAs) -> LDS
   constexpr int DCG = L::CO / 8, DCH = G::NPIX * DCG, DCPT = (DCH + NT - 1) / NT;
-  constexpr int ICH = IMG ? L::IH * L::IW * L::CI / 8 : L::IH * L::IW * (L::CI / 8), ICPT = (ICH + NT - 1) / NT;
-  static_assert(!IMG || (L::IH * L::IW * L::CI) % 8 == 0, "image bytes");
+  constexpr int ICH = IMG ? G::BROWS * L::IW * L::CI / 8 : L::IH * L::IW * (L::CI / 8), ICPT = (ICH + NT - 1) / NT;
+  static_assert(!IMG || ((G::BROWS * L::IW * L::CI) % 8 == 0 && (G::BR * L::S * L::IW * L::CI) % 8 == 0), "image / band bytes");
   bf16x8 dpre[DCPT], ipre[ICPT];
-  auto fetch = [&](int img) {
-    const DzT* d = dz + (long)img * G::NPIX * L::CO;
+  // band b of an image: output rows [b BR, ...), dZ chunks [0, dch), input chunks [0, ich) from input row b BR S
+  auto band_rows = [&](int b) { return G::NBAND == 1 ? L::OH : (L::OH - b * G::BR < G::BR ? L::OH - b * G::BR : G::BR); };
+  auto fetch = [&](int img, int b) {
+    const int dch = G::NBAND == 1 ? DCH : band_rows(b) * L::OW * DCG;
+    const DzT* d = dz + ((long)img * G::NPIX_ALL + (long)b * G::BR * L::OW) * L::CO;
 #pragma unroll
     for (int r = 0; r < DCPT; r++) {
       const int c = tid + r * NT;
-      dpre[r] = load8v(d + 8 * (c < DCH ? c : DCH - 1));  // unconditional (clamped): keeps dpre in registers
+      dpre[r] = load8v(d + 8 * (c < dch ? c : dch - 1));  // unconditional (clamped): keeps dpre in registers
     }
-    const InT* s = in + (long)img * L::IH * L::IW * L::CI;
+    const int ich = G::NBAND == 1 ? ICH : ((band_rows(b) - 1) * L::S + L::KH) * L::IW * L::CI / 8;
+    const InT* s = in + (long)img * L::IH * L::IW * L::CI + (long)b * G::BR * L::S * L::IW * L::CI;
 #pragma unroll
     for (int r = 0; r < ICPT; r++) {
       const int c = tid + r * NT;
-      ipre[r] = load8v(s + 8 * (c < ICH ? c : ICH - 1));
+      ipre[r] = load8v(s + 8 * (c < ich ? c : ich - 1));
     }
   };
-  auto put = [&](__bf16* buf) {
+  auto put = [&](__bf16* buf, int b) {
+    const int dch = G::NBAND == 1 ? DCH : band_rows(b) * L::OW * DCG;
 #pragma unroll
     for (int r = 0; r < DCPT; r++) {
       const int c = tid + r * NT;
-      if (c < DCH) *reinterpret_cast<bf16x8*>(buf + (c / DCG) * G::DZR + 8 * (c % DCG)) = dpre[r];
+      if (c < dch) *reinterpret_cast<bf16x8*>(buf + (c / DCG) * G::DZR + 8 * (c % DCG)) = dpre[r];
+      else if (G::NBAND > 1 && c < DCH) *reinterpret_cast<bf16x8*>(buf + (c / DCG) * G::DZR + 8 * (c % DCG)) = bf16x8{};  // a shorter band: its missing rows are zero
     }
     __bf16* ib = buf + G::DZ_EL;
+    const int ich = G::NBAND == 1 ? ICH : ((band_rows(b) - 1) * L::S + L::KH) * L::IW * L::CI / 8;
 #pragma unroll
     for (int r = 0; r < ICPT; r++) {
       const int c = tid + r * NT;
-      if (c < ICH) {
+      if (c < ich) {
         if constexpr (IMG) *reinterpret_cast<bf16x8*>(ib + 8 * c) = ipre[r];
         else *reinterpret_cast<bf16x8*>(ib + (c / (L::CI / 8)) * G::CIP + 8 * (c % (L::CI / 8))) = ipre[r];
       }
     }
   };
-  auto compute = [&](const __bf16* buf) {
+  auto compute = [&](const __bf16* buf, int b) {
     const __bf16* dzs = buf;
     const __bf16* ins = buf + G::DZ_EL;
+    const int npix = G::NBAND == 1 ? G::NPIX : band_rows(b) * L::OW;
 #pragma unroll
     for (int s = 0; s < G::KS; s++) {
       if (T::KGRP > 1 && (s % T::KGRP) != kg) continue;
       // this lane's two pixels of the k-step (dZ rows of padded pixels are zero; their input address is clamped)
       const int P0 = 32 * s + 4 * g + q, P1 = P0 + 16;
-      const int Q0 = P0 < G::NPIX ? P0 : G::NPIX - 1, Q1 = P1 < G::NPIX ? P1 : G::NPIX - 1;
+      const int Q0 = P0 < npix ? P0 : npix - 1, Q1 = P1 < npix ? P1 : npix - 1;
       const int b0 = ((Q0 / L::OW) * L::S * L::IW + (Q0 % L::OW) * L::S) * G::CIP;
       const int b1 = ((Q1 / L::OW) * L::S * L::IW + (Q1 % L::OW) * L::S) * G::CIP;
       bf16x8 A[G::MPW];
@@ -250,25 +268,29 @@ __global__ __launch_bounds__(NT) void ebw_wgrad_tr_kernel(WgArgs a) {
     }
   };
   __syncthreads();  // zero fill done
-  if constexpr (T::NBUF == 2) {
-    if (j0 < n_img) { fetch(j0); put(lds); }
+  if constexpr (G::NBUF == 2) {
+    if (j0 < n_img) { fetch(j0, 0); put(lds, 0); }
     __syncthreads();
     int k = 0;
     for (int img = j0; img < n_img; img += a.wpp, k ^= 1) {
       const int nxt = img + a.wpp;
-      if (nxt < n_img) fetch(nxt);
-      compute(lds + k * G::BUF_EL);
-      if (nxt < n_img) put(lds + (k ^ 1) * G::BUF_EL);
+      if (nxt < n_img) fetch(nxt, 0);
+      compute(lds + k * G::BUF_EL, 0);
+      if (nxt < n_img) put(lds + (k ^ 1) * G::BUF_EL, 0);
       __syncthreads();
     }
   } else {
-    if (j0 < n_img) fetch(j0);
+    if (j0 < n_img) fetch(j0, 0);
     for (int img = j0; img < n_img; img += a.wpp) {
-      __syncthreads();  // the previous image's fragments are consumed
-      put(lds);
-      __syncthreads();
-      if (img + a.wpp < n_img) fetch(img + a.wpp);
-      compute(lds);
+#pragma unroll 1
+      for (int b = 0; b < G::NBAND; b++) {
+        __syncthreads();  // the previous unit's fragments are consumed
+        put(lds, b);
+        __syncthreads();
+        if (b + 1 < G::NBAND) fetch(img, b + 1);
+        else if (img + a.wpp < n_img) fetch(img + a.wpp, 0);
+        compute(lds, b);
+      }
     }
   }
   // partial slab in accumulator order: dW tiles [wave][mi][nj][lane][4], then db [KGRP][CO]
@@ -584,15 +606,16 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
   static const int dg2 = [] { const char* e = getenv("TACORL_EBW_DG2"); return e ? atoi(e) : 2; }();
   long maxn = 1;
   for (int p = 0; p < nprob; p++) maxn = n[p] > maxn ? n[p] : maxn;
-  const int wpp_d = dg2 > 1 ? (int)((long)dg2 * w.wpp < maxn ? (long)dg2 * w.wpp : maxn) : w.wpp;
-  d3.wpp = d2.wpp = wpp_d;
-  const int nwg_d = nprob * wpp_d;
+  auto per_cu = [&](size_t lds) { return dg2 > 1 && (size_t)dg2 * lds <= 160 * 1024 ? dg2 : 1; };  // 128 x 128: one
+  const int k3w = per_cu(dgrad_lds_bytes<L3>()), k2w = per_cu(dgrad_lds_bytes<L2>());
+  d3.wpp = (int)((long)k3w * w.wpp < maxn ? (long)k3w * w.wpp : maxn);
+  d2.wpp = (int)((long)k2w * w.wpp < maxn ? (long)k2w * w.wpp : maxn);
   g1.slab = (float*)(base + w.slab1); g2.slab = (float*)(base + w.slab2); g3.slab = (float*)(base + w.slab3);
   int rc;
   {
-    if ((parts & EBW_DGRAD3) && (rc = launch_dgrad<L3, float>(d3, nwg_d, st))) return rc;
+    if ((parts & EBW_DGRAD3) && (rc = launch_dgrad<L3, float>(d3, nprob * d3.wpp, st))) return rc;
     if ((parts & EBW_WGRAD3) && (rc = launch_wgrad_tr<L3, __bf16, float>(g3, nwg, st))) return rc;
-    if ((parts & EBW_DGRAD2) && (rc = launch_dgrad<L2, __bf16>(d2, nwg_d, st))) return rc;
+    if ((parts & EBW_DGRAD2) && (rc = launch_dgrad<L2, __bf16>(d2, nprob * d2.wpp, st))) return rc;
     if ((parts & EBW_WGRAD2) && (rc = launch_wgrad_tr<L2, __bf16, __bf16>(g2, nwg, st))) return rc;
     if ((parts & EBW_WGRAD1) && (rc = launch_wgrad_tr<L1, __bf16, __bf16>(g1, nwg, st))) return rc;
     if (!(parts & EBW_REDUCE)) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
@@ -618,7 +641,7 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
 }  // namespace
 
 // the geometries encoder_fused.hip is instantiated for (the cameras of the reference's configs)
-#define EBW_GEOMS(X) X(84, 84) X(64, 64) X(44, 60)
+#define EBW_GEOMS(X) X(84, 84) X(64, 64) X(44, 60) X(128, 128)
 
 bool ebw_supported(int H, int W) {
 #define X(h, w) if (H == h && W == w) return true;

@@ -299,8 +299,8 @@ class ACEngine:
         return bool(ops.L.lib().tacorl_encoder_fused_supported(*self.hw[c]))
 
     def _fused_bwd_ok(self, c):
-        """The per-image LDS-resident conv backward exists for fewer geometries than the fused forward (128 x 128: forward
-        only); where it does not, the problems that have a backward take the per-layer forward (fp32 activations)."""
+        """The per-image LDS-resident conv backward may exist for fewer geometries than the fused forward; where it does
+        not, the problems that have a backward take the per-layer forward (fp32 activations)."""
         return self._fused_ok(c) and ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(
             3, ops.int_array([2 * self.B] * 3), *self.hw[c]) > 0
 

@@ -353,7 +353,7 @@ def test_encoder_fused_forward(H, W):
             assert relerr(a, b) < 1e-2, (name, relerr(a, b))
 
 
-@pytest.mark.parametrize("H,W", [(84, 84), (64, 64), (44, 60)])
+@pytest.mark.parametrize("H,W", [(84, 84), (64, 64), (44, 60), (128, 128)])  # 128 x 128: conv1 weight gradient in 2 bands
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_encoder_fused_backward(H, W, accumulate):
     """Per-image LDS-resident conv backward (tacorl_encoder_bwd_fused) vs the generic bf16 path on the
