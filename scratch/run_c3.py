@@ -25,14 +25,14 @@ if os.environ.get('ONLY') != 'plmp':
   mod = TACORL(play_lmp=lmp(), finetune_action_decoder=True, critic=critic, real_world=True, device=dev, compute_dtype="bf16", image_dtype="bf16",
                action_decoder_lr=3e-4, actor_lr=1e-4, critic_lr=3e-4, discount=0.95, conservative_weight=1.0, reward_scale=10.0,
                n_action_samples=4, with_lagrange=True, deterministic_backup=True, bc_epochs=5)
-  mod.current_epoch = 5; mod.enable_graph(); mod.log_every_n_steps = 50
+  mod.current_epoch = 5; (None if os.environ.get('NOGRAPH') else mod.enable_graph()); mod.log_every_n_steps = 50
   print(f"C3 TACORL finetune_action_decoder=True B={B}: {timeit(lambda: mod.training_step(batch)):.3f} ms/step", flush=True)
 if os.environ.get('ONLY') == 'c3': sys.exit(0)
 p = lmp(); p.log_every_n_steps = 50
 if os.environ.get('WAVEFRONT') is not None: p.ad.bptt_wavefront = bool(int(os.environ['WAVEFRONT']))
 if os.environ.get('BRANCHES') is not None: p.branches = bool(int(os.environ['BRANCHES']))
 try:
-    p.enable_graph()
+    (None if os.environ.get('NOGRAPH') else p.enable_graph())
 except Exception as e:
     print("playlmp graph:", e)
 print(f"PlayLMP.training_step B={B} T={T}: {timeit(lambda: p.training_step(batch, 0)):.3f} ms/step", flush=True)

@@ -25,7 +25,7 @@ if which == "c5":
                       with_lagrange=True, reward_scale=10.0, deterministic_backup=False, bc_epochs=5)
     mod.current_epoch = 5
     batch = to_dev(synth.make_transition_batch(7, B, {"rgb_static": (84, 84)}))
-    mod.enable_graph(); mod.log_every_n_steps = 50
+    (None if os.environ.get('NOGRAPH') else mod.enable_graph()); mod.log_every_n_steps = 50
     ms = timeit(mod, batch, (0,))
     logs = mod.engine.metrics()
     print(f"C5 CQL_Offline B={B} n=32 bf16: {ms:.3f} ms/step = {B / ms * 1e3:.0f} samples/s; finite={all(v == v for v in logs.values())}")
@@ -49,7 +49,7 @@ else:
     acts = u(B, T, 7); acts[..., -1] = torch.where(acts[..., -1] >= 0, 1.0, -1.0)
     disp = torch.ones(B, device=dev).long()
     batch = {"states": {c: u(B, T, 3, 128, 128) for c in cams}, "goal": {c: u(B, 3, 128, 128) for c in cams}, "actions": acts, "disp": disp}
-    mod.enable_graph(); mod.log_every_n_steps = 50
+    (None if os.environ.get('NOGRAPH') else mod.enable_graph()); mod.log_every_n_steps = 50
     ms = timeit(mod, batch, steps=10, warm=3)
     logs = mod.engine.metrics()
     print(f"C4-like TACORL dual-cam 128x128 A=32 T=32 B={B} bf16: {ms:.3f} ms/step = {B / ms * 1e3:.0f} samples/s; finite={all(v == v for v in logs.values())}")
