@@ -193,9 +193,13 @@ int tacorl_mlp_fwd(int nprob, const float* const* x, int ldx, const float* const
  * copy of params[p] at the same element offsets (tacorl_to_bf16_batch); the caller refreshes it
  * whenever the fp32 block changes.  Saved activations are identical in layout to tacorl_mlp_fwd's. */
 int tacorl_mlp_fwd_fused_supported(int nprob, int n_layers, const int* dims, int ldx);
+/* lean != 0: hidden-layer outputs whose pre-activation is saved are not written; the fused weight-gradient launch
+ * (same flag) recomputes them.  Only where tacorl_mlp_lean_supported() - forward, input-gradient chain and one-launch
+ * weight gradients all fused - and nothing else reads those hidden outputs. */
+int tacorl_mlp_lean_supported(int nprob, int n_layers, const int* dims, int ldx, int ldo, int ldd);
 int tacorl_mlp_fwd_fused(int nprob, const float* const* x, int ldx, const float* const* params,
                          const void* const* params_bf16, float* const* act, const int* M,
-                         int n_layers, const int* dims, const int* acts, tacorl_stream_t stream);
+                         int n_layers, const int* dims, const int* acts, int lean, tacorl_stream_t stream);
 /* dst[i][:] = bf16(src[i][:]) for n <= 16 buffers in one launch (count[i] % 4 == 0). */
 int tacorl_to_bf16_batch(int n, const float* const* src, void* const* dst, const long* count,
                          tacorl_stream_t stream);
@@ -227,7 +231,7 @@ int tacorl_mlp_bwd_fused_pack(int nprob, const float* const* params, const int* 
                               const int* dims, void* ws, size_t ws_bytes, tacorl_stream_t stream);
 int tacorl_mlp_bwd_fused_wgrad(int nprob, const float* const* x, int ldx, const float* const* act,
                                const float* const* d_out, int ldo, float* const* grads, const int* M,
-                               int n_layers, const int* dims, const int* acts, int accumulate,
+                               int n_layers, const int* dims, const int* acts, int accumulate, int lean,
                                void* ws, size_t ws_bytes, tacorl_stream_t stream);
 
 /* ---- data movement ----------------------------------------------------------------- */

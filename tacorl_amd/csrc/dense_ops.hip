@@ -987,9 +987,16 @@ extern "C" int tacorl_mlp_fwd(int nprob, const float* const* x, int ldx, const f
 extern "C" int tacorl_mlp_fwd_fused_supported(int nprob, int L, const int* dims, int ldx) {
   return mlp_fused_fwd_ok(nprob, L, dims, ldx) ? 1 : 0;
 }
+// lean != 0: the output of a hidden layer whose pre-activation is saved (SiLU) is NOT written - the fused weight-gradient
+// launch recomputes it from the pre-activation while staging (tacorl_mlp_bwd_fused_wgrad with the same flag; bit-identical
+// operands): at 99 k rows the forward is bound by exactly these stores.  Only for callers whose backward is the fused
+// pair (tacorl_mlp_lean_supported).
+extern "C" int tacorl_mlp_lean_supported(int nprob, int L, const int* dims, int ldx, int ldo, int ldd) {
+  return mlp_fused_fwd_ok(nprob, L, dims, ldx) && mlp_fused_bwd_ok(nprob, L, dims, ldo, ldd) && mlp_fused_wgrad_ok(nprob, L, dims) ? 1 : 0;
+}
 extern "C" int tacorl_mlp_fwd_fused(int nprob, const float* const* x, int ldx, const float* const* params,
                                     const void* const* params_bf16, float* const* act, const int* M, int L,
-                                    const int* dims, const int* acts, tacorl_stream_t stream) {
+                                    const int* dims, const int* acts, int lean, tacorl_stream_t stream) {
   if (!mlp_fused_fwd_ok(nprob, L, dims, ldx)) FAIL(TACORL_EINVAL, "mlp_fwd_fused: shapes not supported");
   long wo[MLP_MAXL], bo[MLP_MAXL];
   tacorl_mlp_param_layout(L, dims, wo, bo);
@@ -997,7 +1004,10 @@ extern "C" int tacorl_mlp_fwd_fused(int nprob, const float* const* x, int ldx, c
   for (int p = 0; p < nprob; p++) {
     long z1[MLP_MAXL], y1[MLP_MAXL];
     tacorl_mlp_act_layout(M[p], L, dims, acts, z1, y1);
-    for (int l = 0; l < L; l++) { zo[p * MF_MAXL + l] = z1[l]; yo[p * MF_MAXL + l] = y1[l]; }
+    for (int l = 0; l < L; l++) {
+      zo[p * MF_MAXL + l] = z1[l];
+      yo[p * MF_MAXL + l] = (lean && l + 1 < L && z1[l] >= 0) ? -1 : y1[l];
+    }
   }
   const int rc = mlp_fused_fwd(nprob, x, ldx, params, params_bf16, act, M, L, dims, acts, zo, yo, wo, bo, (hipStream_t)stream);
   if (rc != TACORL_OK) FAIL(rc, "mlp_fwd_fused: launch failed (%d)", rc);
@@ -1102,7 +1112,7 @@ extern "C" int tacorl_mlp_bwd_fused_pack(int nprob, const float* const* params, 
 }
 extern "C" int tacorl_mlp_bwd_fused_wgrad(int nprob, const float* const* x, int ldx, const float* const* act,
                                           const float* const* d_out, int ldo, float* const* grads, const int* M, int L,
-                                          const int* dims, const int* acts, int accumulate, void* ws, size_t ws_bytes,
+                                          const int* dims, const int* acts, int accumulate, int lean, void* ws, size_t ws_bytes,
                                           tacorl_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (nprob < 1 || nprob > MF_MAXP || L < 1 || L > MF_MAXL) FAIL(TACORL_EINVAL, "mlp_bwd_fused_wgrad: bad L/nprob");
@@ -1117,14 +1127,15 @@ extern "C" int tacorl_mlp_bwd_fused_wgrad(int nprob, const float* const* x, int 
     for (int p = 0; p < nprob; p++) {
       long zo[MLP_MAXL], yo[MLP_MAXL];
       tacorl_mlp_act_layout(M[p], L, dims, acts, zo, yo);
-      for (int l = 0; l < L; l++) yoffs[p * MF_MAXL + l] = yo[l];
+      for (int l = 0; l < L; l++) yoffs[p * MF_MAXL + l] = (lean && l + 1 < L && zo[l] >= 0) ? -(zo[l] + 1) : yo[l];
       dzp[p] = (const float*)ws;
     }
     if (mlp_fused_wgrad(nprob, x, ldx, act, d_out, ldo, dzp, grads, (float*)slab, M, L, dims, yoffs, w.dzoff, wo, bo,
-                        accumulate, st))
+                        accumulate, st, acts))
       FAIL(TACORL_ELAUNCH, "mlp_bwd_fused_wgrad: launch failed");
     return TACORL_OK;
   }
+  if (lean) FAIL(TACORL_EINVAL, "mlp_bwd_fused_wgrad: lean activations need the one-launch form (tacorl_mlp_lean_supported)");
   for (int l = L - 1; l >= 0; l--) {
     const float *xg[GEMM_MAXP], *dzg[GEMM_MAXP];
     float *dwg[GEMM_MAXP], *dbg[GEMM_MAXP];

@@ -35,4 +35,6 @@ bool mlp_fused_wgrad_ok(int nprob, int L, const int* dims);
 size_t mlp_fused_wgrad_slab_floats(int nprob, const int* M, int L, const int* dims);
 int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* const* act, const float* const* d_out, int ldo,
                     const float* const* dz, float* const* grads, float* slab, const int* M, int L, const int* dims,
-                    const long* yoff, const long* dzoff, const long* woff, const long* boff, int accumulate, hipStream_t st);
+                    const long* yoff, const long* dzoff, const long* woff, const long* boff, int accumulate, hipStream_t st,
+                    const int* acts = nullptr);
+// yoff[...] < 0 (forward: do not save that layer's output; wgrad: -(zoff + 1), recompute it from the pre-activation with acts[l])

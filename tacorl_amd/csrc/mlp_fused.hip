@@ -12,6 +12,8 @@
 // behind another wave's - the 8 launches of these kernels on the step's dependent chain took 30 % longer.
 #include "mlp_fused.h"
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -74,7 +76,12 @@ __device__ __forceinline__ bf16x8 load_w(const __bf16* __restrict__ W, int K, in
   return on ? bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} : bf16x8{z, z, z, z, z, z, z, z};
 }
 
-__global__ __launch_bounds__(MF_NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
+// Rows per workgroup BMF_: 32 for the step's small batches (latency: more workgroups), 128 for tens of thousands of rows
+// (C5's Q networks, 99 k rows each: a workgroup re-streams every layer's weights from L2, 330 KB per 32 rows - 2 GB per
+// launch - so four times the rows per weight load; 135 KB of LDS, one workgroup per CU).
+template <int BMF_>
+__device__ __forceinline__ void mlp_fused_fwd_body(const MlpFwdArgs& a) {
+  constexpr int BMF = BMF_, MTF = BMF_ / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* X = reinterpret_cast<__bf16*>(smem);  // [2][BMF][XP]
   const int p = blockIdx.y, m0 = blockIdx.x * BMF, M = a.M[p];
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(MF_NT) __attribute__((amdgpu_waves_per_eu(5, 8))) v
     if (l + 1 < a.L && n0 < a.dims[l + 2]) load_layer(l + 1);
     if (n0 < N) {
       float* zb = a.zoff[p][l] >= 0 ? a.act[p] + a.zoff[p][l] : nullptr;
-      float* yb = a.act[p] + a.yoff[p][l];
+      float* yb = a.yoff[p][l] >= 0 ? a.act[p] + a.yoff[p][l] : nullptr;  // lean mode: a hidden SiLU layer's output is not saved
 #pragma unroll
       for (int nt = 0; nt < MF_NTW; nt++) {
         const int col = n0 + 16 * nt + 4 * g;  // this lane's 4 consecutive columns
@@ -177,11 +184,11 @@ __global__ __launch_bounds__(MF_NT) __attribute__((amdgpu_waves_per_eu(5, 8))) v
             const long o = (long)(m0 + row) * N + col;
             if (vec && col < N) {
               if (zb) *reinterpret_cast<f32x4*>(zb + o) = z;
-              *reinterpret_cast<f32x4*>(yb + o) = y;
+              if (yb) *reinterpret_cast<f32x4*>(yb + o) = y;
             } else {
 #pragma unroll
               for (int r = 0; r < 4; r++)
-                if (col + r < N) { if (zb) zb[o + r] = z[r]; yb[o + r] = y[r]; }
+                if (col + r < N) { if (zb) zb[o + r] = z[r]; if (yb) yb[o + r] = y[r]; }
             }
           }
           *reinterpret_cast<bf16x4*>(xout + row * XP + col) = bf16x4{(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
@@ -192,6 +199,11 @@ __global__ __launch_bounds__(MF_NT) __attribute__((amdgpu_waves_per_eu(5, 8))) v
     cur ^= 1;
   }
 }
+
+__global__ __launch_bounds__(MF_NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void mlp_fused_fwd_kernel(MlpFwdArgs a) {
+  mlp_fused_fwd_body<32>(a);
+}
+__global__ __launch_bounds__(MF_NT) void mlp_fused_fwd_big_kernel(MlpFwdArgs a) { mlp_fused_fwd_body<128>(a); }
 
 // ---------------------------------------------------------------------------------- backward
 // The input-gradient chain dZ_{l-1} = (dZ_l W_l) * act'_{l-1} of the whole MLP in one launch: the same
@@ -370,7 +382,9 @@ struct MlpWgArgs {
   const float* dz[MF_MAXP];     // dZ_l, l < L-1, at dzoff[p][l] (from the dgrad launch)
   float* slab[MF_MAXP];         // partial gradients: [slice][record]
   int M[MF_MAXP];
-  long yoff[MF_MAXP][MF_MAXL], dzoff[MF_MAXP][MF_MAXL];
+  long yoff[MF_MAXP][MF_MAXL], dzoff[MF_MAXP][MF_MAXL];  // yoff < 0: -(zoff + 1) - the layer's output was not saved (lean
+                                                          // mode): read its pre-activation there and apply acts[l]
+  int acts[MF_MAXL];
   long sloff[MF_MAXL];          // offset of layer l inside a record: [N][K] then [N]
   long rec;                     // floats per record
   int dims[MF_MAXL + 1];
@@ -399,7 +413,9 @@ __global__ __launch_bounds__(512) void mlp_wgrad_fused_kernel(MlpWgArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4, q = tid & 3;
   const int qd = (tid >> 2) & 63, jh = tid >> 8;  // column quad, row-group parity of this thread in the staging
   const int K = a.dims[l], N = a.dims[l + 1];
-  const float* X = l == 0 ? a.x[p] : a.act[p] + a.yoff[p][l - 1];
+  const long yo = l == 0 ? 0 : a.yoff[p][l - 1];
+  const float* X = l == 0 ? a.x[p] : a.act[p] + (yo < 0 ? -(yo + 1) : yo);
+  const int actX = l > 0 && yo < 0 ? a.acts[l - 1] : ACT_NONE;  // recompute y = act(z) while staging (bit-identical to the saved y)
   const int ldX = l == 0 ? a.ldx : K;
   const float* Z = l == a.L - 1 ? a.dlast[p] : a.dz[p] + a.dzoff[p][l];
   const int ldZ = l == a.L - 1 ? a.ldo : N;
@@ -430,10 +446,11 @@ __global__ __launch_bounds__(512) void mlp_wgrad_fused_kernel(MlpWgArgs a) {
       }
     }
   };
-  auto stash = [&](f32x4 (&r)[4], unsigned char* T) {  // T: [col][WG_TP] bf16
+  auto stash = [&](f32x4 (&r)[4], unsigned char* T, int act) {  // T: [col][WG_TP] bf16
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       f32x4 v = r[j];
+      if (act != ACT_NONE) v = f32x4{act_fast(act, v[0]), act_fast(act, v[1]), act_fast(act, v[2]), act_fast(act, v[3])};
       wg_quad_transpose(v, q);  // now: column 4 qd + q, rows 4 (2 j + jh) .. + 3
       *reinterpret_cast<bf16x4*>(T + ((4 * qd + q) * WG_TP + 4 * (2 * j + jh)) * 2) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
     }
@@ -451,8 +468,8 @@ __global__ __launch_bounds__(512) void mlp_wgrad_fused_kernel(MlpWgArgs a) {
   for (int s = 0; s < nsteps; s++) {
     unsigned char* TX = smem + (s & 1) * 2 * WG_OPB;
     unsigned char* TZ = TX + WG_OPB;
-    stash(rx, TX);
-    stash(rz, TZ);
+    stash(rx, TX, actX);
+    stash(rz, TZ, ACT_NONE);
     __syncthreads();  // (the other buffer is still being read by slower waves: two buffers, one barrier per step)
     if (s + 1 < nsteps) { fetch(X, ldX, K, vecX, s + 1, rx); fetch(Z, ldZ, N, vecZ, s + 1, rz); }
     // this wave's N tiles: w, w + 8
@@ -556,7 +573,8 @@ size_t mlp_fused_wgrad_slab_floats(int nprob, const int* M, int L, const int* di
 }
 int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* const* act, const float* const* d_out, int ldo,
                     const float* const* dz, float* const* grads, float* slab, const int* M, int L, const int* dims,
-                    const long* yoff, const long* dzoff, const long* woff, const long* boff, int accumulate, hipStream_t st) {
+                    const long* yoff, const long* dzoff, const long* woff, const long* boff, int accumulate, hipStream_t st,
+                    const int* acts) {
   MlpWgArgs a{};
   MlpWgReduceArgs r{};
   a.rec = r.rec = mlp_wgrad_record(L, dims, a.sloff);
@@ -567,7 +585,7 @@ int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* cons
     a.ms = mlp_wgrad_rows(n, Mg, L);
   }
   for (int l = 0; l <= L; l++) a.dims[l] = r.dims[l] = dims[l];
-  for (int l = 0; l < L; l++) { r.sloff[l] = a.sloff[l]; r.woff[l] = woff[l]; r.boff[l] = boff[l]; }
+  for (int l = 0; l < L; l++) { r.sloff[l] = a.sloff[l]; r.woff[l] = woff[l]; r.boff[l] = boff[l]; a.acts[l] = acts ? acts[l] : ACT_NONE; }
   int n2 = 0, maxs = 0;
   float* sp = slab;
   for (int p = 0; p < nprob; p++) {
@@ -660,10 +678,16 @@ int mlp_fused_fwd(int nprob, const float* const* x, int ldx, const float* const*
   }
   a.dims[L] = dims[L]; a.L = L; a.ldx = ldx;
   if (maxM == 0) return TACORL_OK;
-  constexpr size_t lds = (size_t)2 * BMF * XP * 2;
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_fwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
+  constexpr size_t lds = (size_t)2 * BMF * XP * 2, lds_big = (size_t)2 * 128 * XP * 2;
+  static int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_fwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_fwd_big_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big) == hipSuccess) ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
-  hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3((maxM + BMF - 1) / BMF, nprob), dim3(MF_NT), lds, st, a);
+  static const int big_rows = [] { const char* e = getenv("TACORL_MLP_BIG_ROWS"); return e ? atoi(e) : 16384; }();
+  if (maxM >= big_rows)
+    hipLaunchKernelGGL(mlp_fused_fwd_big_kernel, dim3((maxM + 127) / 128, nprob), dim3(MF_NT), lds_big, st, a);
+  else
+    hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3((maxM + BMF - 1) / BMF, nprob), dim3(MF_NT), lds, st, a);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }

@@ -412,7 +412,7 @@ class ACEngine:
         ks = ["a", "q1", "q2", "tq1", "tq2"]
         ops.mlp_fwd([self.gin[k] for k in ks], self.G, [nets[k].genc() for k in ks], [self.gact[k] for k in ks],
                     [B] * 5, self.actor.genc_dims, self.actor.genc_acts, self.compute,
-                    params_bf16=[nets[k].genc_bf16() for k in ks])
+                    params_bf16=[nets[k].genc_bf16() for k in ks], lean=self._lean("genc"))
         # S = [enc(obs or next) | goal_enc(enc(goal))]
         obs_src = {"a": ("a_og", 0, "a"), "a_nx": ("a_nx", 0, "a"), "q1": ("q1", 0, "q1"), "q2": ("q2", 0, "q2"),
                    "tq1": ("tq1", B, "tq1"), "tq2": ("tq2", B, "tq2")}
@@ -426,7 +426,7 @@ class ACEngine:
         ks = ["a", "a_nx"]
         ops.mlp_fwd([self.S[k] for k in ks], self.lds, [self.actor.head()] * 2, [self.pact[k] for k in ks],
                     [self.B] * 2, self.actor.head_dims, self.actor.head_acts, self.compute,
-                    params_bf16=[self.actor.head_bf16()] * 2)
+                    params_bf16=[self.actor.head_bf16()] * 2, lean=self._lean("pi"))
 
     def _head(self, k):
         return self.pact[k][self.p_yoff: self.p_yoff + self.B * self.HD]
@@ -515,7 +515,7 @@ class ACEngine:
               self.qact_t["tq2"]]
         pb = [self.q1.head_bf16(), self.q2.head_bf16(), self.q1.head_bf16(), self.q2.head_bf16(), self.tq1.head_bf16(),
               self.tq2.head_bf16()]
-        ops.mlp_fwd(xs, self.ldq, ps, ac, [self.R, self.R, B, B, B, B], qd, qa, self.compute, params_bf16=pb)
+        ops.mlp_fwd(xs, self.ldq, ps, ac, [self.R, self.R, B, B, B, B], qd, qa, self.compute, params_bf16=pb, lean=self._lean("q"))
         qout = lambda buf, off, rows: buf[off: off + rows]  # noqa: E731
         q1m, q2m = qout(self.qact["q1"], self.q_yoff_R, self.R), qout(self.qact["q2"], self.q_yoff_R, self.R)
         q1p, q2p = qout(self.qact_pi["q1"], self.q_yoff_B, B), qout(self.qact_pi["q2"], self.q_yoff_B, B)
@@ -553,6 +553,22 @@ class ACEngine:
         self._join_wgrads()
         ops.mark("b:end")
 
+    lean_mlp_acts = True  # hidden-layer outputs of the fused MLPs are recomputed by the weight-gradient launch, not saved
+
+    def _lean(self, tag):
+        """True when the MLP site's forward may skip its hidden-layer outputs: its whole backward is the fused pair
+        (input-gradient chain + one-launch weight gradients), the only reader of those outputs."""
+        if self.compute != BF16 or not self.lean_mlp_acts:
+            return False
+        tag = {"qpi": "q"}.get(tag, tag)
+        cache = self.__dict__.setdefault("_lean_cache", {})
+        if tag not in cache:
+            n, dims, ldx, ldo, ldd = {"genc": (5, self.actor.genc_dims, self.G, self.lds, self.G),
+                                      "pi": (2, self.actor.head_dims, self.lds, self.HD, self.lds),
+                                      "q": (6, self.q1.head_dims, self.ldq, 1, self.ldq)}[tag]
+            cache[tag] = ops.mlp_lean_ok(n, dims, ldx, ldo, ldd, self.compute) and ops.mlp_bwd_fused_ok(n, dims, ldo, ldd, self.compute)
+        return cache[tag]
+
     def _mlp_backward(self, tag, xs, ldx, params, acts_buf, d_outs, ldo, grads, d_xs, ldd, M, dims, acts):
         """MLP backward.  bf16 mode: the input-gradient chain is ONE launch on the current stream and the
         weight gradients go to a side stream of their own (a parallel graph branch joined before the
@@ -568,7 +584,7 @@ class ACEngine:
         if all(g is None for g in grads):
             return
         if not self.wgrad_side_streams:
-            ops.mlp_bwd_fused_wgrad(xs, ldx, acts_buf, d_outs, ldo, grads, M, dims, acts, "mlp_bwdf_" + tag)
+            ops.mlp_bwd_fused_wgrad(xs, ldx, acts_buf, d_outs, ldo, grads, M, dims, acts, "mlp_bwdf_" + tag, lean=self._lean(tag))
             return
         if not hasattr(self, "_wg_streams"):
             self._wg_streams, self._wg_pending = {}, []
@@ -577,7 +593,7 @@ class ACEngine:
         ws_ = self._wg_streams[tag]
         ws_.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(ws_):
-            ops.mlp_bwd_fused_wgrad(xs, ldx, acts_buf, d_outs, ldo, grads, M, dims, acts, "mlp_bwdf_" + tag)
+            ops.mlp_bwd_fused_wgrad(xs, ldx, acts_buf, d_outs, ldo, grads, M, dims, acts, "mlp_bwdf_" + tag, lean=self._lean(tag))
         self._wg_pending.append(ws_)
 
     def _join_wgrads(self):

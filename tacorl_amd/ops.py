@@ -122,14 +122,22 @@ def encoder_bwd(imgs, params, acts, d_outs, grads, H, W, compute=F32, accumulate
 
 
 # ------------------------------------------------------------------------------- MLP
-def mlp_fwd(xs, ldx, params, acts_buf, M, dims, acts, compute=F32, params_bf16=None):
+def mlp_lean_ok(n, dims, ldx, ldo, ldd, compute):
+    """Forward, input-gradient chain and weight gradients of this MLP site all run as the fused launches: the forward
+    may then skip the hidden layers' outputs (mlp_fwd / mlp_bwd_fused_wgrad lean=True on BOTH)."""
+    return compute == BF16 and bool(L.lib().tacorl_mlp_lean_supported(n, len(dims) - 1, int_array(dims), ldx, ldo, ldd))
+
+
+def mlp_fwd(xs, ldx, params, acts_buf, M, dims, acts, compute=F32, params_bf16=None, lean=False):
     """params_bf16: bf16 copies of the parameter blocks -> the whole MLP runs as one launch when the
-    shapes qualify (bf16 mode only); otherwise one GEMM launch per layer."""
+    shapes qualify (bf16 mode only); otherwise one GEMM launch per layer.
+    lean: do not save hidden-layer outputs whose pre-activation is saved (see mlp_lean_ok)."""
     if (params_bf16 is not None and compute == BF16
             and L.lib().tacorl_mlp_fwd_fused_supported(len(xs), len(dims) - 1, int_array(dims), ldx)):
         call("tacorl_mlp_fwd_fused", len(xs), ptr_array(xs), ldx, ptr_array(params), ptr_array(params_bf16),
-             ptr_array(acts_buf), int_array(M), len(dims) - 1, int_array(dims), int_array(acts), stream())
+             ptr_array(acts_buf), int_array(M), len(dims) - 1, int_array(dims), int_array(acts), int(lean), stream())
         return
+    assert not lean, "lean activations need the fused forward"
     call("tacorl_mlp_fwd", len(xs), ptr_array(xs), ldx, ptr_array(params), ptr_array(acts_buf), int_array(M),
          len(dims) - 1, int_array(dims), int_array(acts), compute, stream())
 
@@ -166,11 +174,11 @@ def mlp_bwd_fused_dgrad(params, acts_buf, d_outs, ldo, d_xs, ldd, M, dims, acts,
          int_array(dims), int_array(acts), int(prepacked), ptr(ws), ws.numel(), stream())
 
 
-def mlp_bwd_fused_wgrad(xs, ldx, acts_buf, d_outs, ldo, grads, M, dims, acts, ws_tag, accumulate=False):
+def mlp_bwd_fused_wgrad(xs, ldx, acts_buf, d_outs, ldo, grads, M, dims, acts, ws_tag, accumulate=False, lean=False):
     nb = L.lib().tacorl_mlp_bwd_fused_ws_bytes(len(xs), int_array(M), len(dims) - 1, int_array(dims))
     ws = workspace(nb, acts_buf[0].device, ws_tag)
     call("tacorl_mlp_bwd_fused_wgrad", len(xs), ptr_array(xs), ldx, ptr_array(acts_buf), ptr_array(d_outs), ldo,
-         ptr_array(grads), int_array(M), len(dims) - 1, int_array(dims), int_array(acts), int(accumulate), ptr(ws),
+         ptr_array(grads), int_array(M), len(dims) - 1, int_array(dims), int_array(acts), int(accumulate), int(lean), ptr(ws),
          ws.numel(), stream())
 
 

@@ -493,6 +493,87 @@ def test_mlp_fused_forward_ragged_input_width():
         assert relerr(a_f[i], a_g[i]) < 2e-3, relerr(a_f[i], a_g[i])
 
 
+@pytest.mark.parametrize("lean", [False, True])
+def test_mlp_fused_forward_many_rows(lean):
+    """>= 16384 rows take the 128-rows-per-workgroup instantiation (C5's Q networks: 99 k rows): against the per-layer
+    bf16 path on the same inputs, ragged last block included; in lean mode the final output must agree as well."""
+    from tacorl_amd import blocks, ops
+
+    dev = _dev()
+    dims, acts, Ms, ld = [71, 256, 256, 256, 1], [2, 2, 2, 0], [16384 + 77, 300], 72
+    L = len(dims) - 1
+    xs, flats, fb, a_f, a_g = [], [], [], [], []
+    for i, M in enumerate(Ms):
+        flat = torch.zeros(blocks.mlp_size(dims), device=dev)
+        v = blocks.mlp_views(flat, 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+        for l in range(L):
+            v[f"l{l}.w"].copy_(rnd(dims[l + 1], dims[l], seed=550 + i + l, scale=1 / math.sqrt(dims[l])))
+            v[f"l{l}.b"].copy_(rnd(dims[l + 1], seed=560 + i + l, scale=0.1))
+        xp = torch.full((M, ld), 7.0, device=dev)
+        xp[:, :dims[0]] = rnd(M, dims[0], seed=570 + i).to(dev)
+        xs.append(xp); flats.append(flat); fb.append(flat.to(torch.bfloat16))
+        n_act = ops.mlp_act_layout(M, dims, acts)[2]
+        a_f.append(torch.zeros(n_act, device=dev)); a_g.append(torch.zeros(n_act, device=dev))
+    ops.mlp_fwd(xs, ld, flats, a_g, Ms, dims, acts, 1)
+    ops.mlp_fwd(xs, ld, flats, a_f, Ms, dims, acts, 1, params_bf16=fb, lean=lean)
+    torch.cuda.synchronize()
+    for i, M in enumerate(Ms):
+        zo, yo, _ = ops.mlp_act_layout(M, dims, acts)
+        out_f, out_g = a_f[i][yo[L - 1]: yo[L - 1] + M * dims[-1]], a_g[i][yo[L - 1]: yo[L - 1] + M * dims[-1]]
+        assert torch.isfinite(out_f).all() and relerr(out_f, out_g) < 2e-3, relerr(out_f, out_g)
+        for l in range(L - 1):  # saved pre-activations (and, unless lean, outputs) of the hidden layers
+            zf, zg = a_f[i][zo[l]: zo[l] + M * dims[l + 1]], a_g[i][zo[l]: zo[l] + M * dims[l + 1]]
+            assert relerr(zf, zg) < 2e-3, (l, relerr(zf, zg))
+            if not lean:
+                yf, yg = a_f[i][yo[l]: yo[l] + M * dims[l + 1]], a_g[i][yo[l]: yo[l] + M * dims[l + 1]]
+                assert relerr(yf, yg) < 2e-3, (l, relerr(yf, yg))
+
+
+@pytest.mark.parametrize("dims,acts", [([71, 256, 256, 256, 1], [2, 2, 2, 0]), ([64, 256, 256, 32], [2, 2, 0]), ([32, 256, 256, 32], [1, 1, 0])])
+def test_mlp_fused_lean_activations(dims, acts):
+    """lean mode: the fused forward does not write the hidden layers' outputs (SiLU: the pre-activation is saved) and the
+    one-launch weight gradients recompute them while staging - outputs, input gradients and weight gradients are bit for
+    bit those of the saving mode, and the skipped regions of the activation buffer are really untouched."""
+    from tacorl_amd import blocks, ops
+
+    dev = _dev()
+    Ms, L = [70, 300], len(dims) - 1
+    ld = (dims[0] + 3) // 4 * 4
+    lean_ok = ops.mlp_lean_ok(len(Ms), dims, ld, dims[-1], ld, 1)
+    assert lean_ok
+    xs, flats, fb, douts = [], [], [], []
+    for i, M in enumerate(Ms):
+        flat = torch.zeros(blocks.mlp_size(dims), device=dev)
+        v = blocks.mlp_views(flat, 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+        for l in range(L):
+            v[f"l{l}.w"].copy_(rnd(dims[l + 1], dims[l], seed=450 + i + l, scale=1 / math.sqrt(dims[l])))
+            v[f"l{l}.b"].copy_(rnd(dims[l + 1], seed=460 + i + l, scale=0.1))
+        xp = torch.zeros(M, ld, device=dev)
+        xp[:, :dims[0]] = rnd(M, dims[0], seed=470 + i).to(dev)
+        xs.append(xp); flats.append(flat); fb.append(flat.to(torch.bfloat16)); douts.append(rnd(M, dims[-1], seed=480 + i).to(dev))
+    res = []
+    for lean in (False, True):
+        actb = [torch.full((ops.mlp_act_layout(M, dims, acts)[2],), float("nan"), device=dev) for M in Ms]
+        ops.mlp_fwd(xs, ld, flats, actb, Ms, dims, acts, 1, params_bf16=fb, lean=lean)
+        g = [torch.zeros_like(f) for f in flats]
+        dx = [torch.zeros(M, ld, device=dev) for M in Ms]
+        ops.mlp_bwd_fused_dgrad(flats, actb, douts, dims[-1], dx, ld, Ms, dims, acts, "t_mlp_lean")
+        ops.mlp_bwd_fused_wgrad(xs, ld, actb, douts, dims[-1], g, Ms, dims, acts, "t_mlp_lean", lean=lean)
+        torch.cuda.synchronize()
+        res.append((actb, g, dx))
+    (a0, g0, d0), (a1, g1, d1) = res
+    for i, M in enumerate(Ms):
+        zo, yo, _ = ops.mlp_act_layout(M, dims, acts)
+        assert torch.equal(a0[i][yo[L - 1]: yo[L - 1] + M * dims[-1]], a1[i][yo[L - 1]: yo[L - 1] + M * dims[-1]])  # the MLP's output
+        assert torch.equal(g0[i], g1[i]) and torch.equal(d0[i], d1[i]) and torch.isfinite(g1[i]).all()
+        for l in range(L - 1):
+            hidden = a1[i][yo[l]: yo[l] + M * dims[l + 1]]
+            if zo[l] >= 0:  # pre-activation saved -> output skipped (still the NaN fill)
+                assert torch.isnan(hidden).all()
+            else:           # ReLU layers save only their output: kept
+                assert torch.isfinite(hidden).all()
+
+
 @pytest.mark.parametrize("dims,acts", [([64, 256, 256, 256, 32], [2, 2, 2, 0]), ([80, 256, 256, 256, 1], [2, 2, 2, 0]),
                                        ([71, 256, 256, 256, 1], [2, 2, 2, 0]), ([32, 256, 256, 32], [1, 1, 0])])
 @pytest.mark.parametrize("want_dx", [True, False])
