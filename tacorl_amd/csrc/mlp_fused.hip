@@ -242,7 +242,10 @@ __global__ __launch_bounds__(256) void mlp_pack_wt_kernel(WtPackArgs a) {
   }
 }
 
-__global__ __launch_bounds__(MF_NT) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
+// (rows per workgroup as in the forward: 32, or 64 for >= 16 k rows - 128 would need 128 accumulator + source registers)
+template <int BMF_>
+__device__ __forceinline__ void mlp_fused_bwd_body(const MlpBwdArgs& a) {
+  constexpr int BMF = BMF_, MTF = BMF_ / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* X = reinterpret_cast<__bf16*>(smem);  // [2][BMF][XP]
   const int p = blockIdx.y, m0 = blockIdx.x * BMF, M = a.M[p];
@@ -354,6 +357,8 @@ __global__ __launch_bounds__(MF_NT) void mlp_fused_bwd_kernel(MlpBwdArgs a) {
     cur ^= 1;
   }
 }
+__global__ __launch_bounds__(MF_NT) void mlp_fused_bwd_kernel(MlpBwdArgs a) { mlp_fused_bwd_body<32>(a); }
+__global__ __launch_bounds__(MF_NT) void mlp_fused_bwd_big_kernel(MlpBwdArgs a) { mlp_fused_bwd_body<64>(a); }
 
 // ---------------------------------------------------------------------------------- weight gradients
 // dW_l = dZ_l^T X_l and db_l = colsum(dZ_l) of EVERY layer and network of an MLP site in one launch (+ one reduce
@@ -644,11 +649,17 @@ int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act
   if (maxM == 0) return TACORL_OK;
   if (mode != 2) hipLaunchKernelGGL(mlp_pack_wt_kernel, dim3(64, L, nprob), dim3(256), 0, st, k);
   if (mode == 1) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
-  constexpr size_t lds = (size_t)2 * BMF * XP * 2;
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_bwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
+  constexpr size_t lds = (size_t)2 * BMF * XP * 2, lds_big = (size_t)2 * 64 * XP * 2;
+  static int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_bwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_bwd_big_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big) == hipSuccess) ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
-  hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3((maxM + BMF - 1) / BMF, nprob), dim3(MF_NT), lds, st, a);
+  static const int big_rows = [] { const char* e = getenv("TACORL_MLP_BIG_ROWS"); return e ? atoi(e) : 16384; }();
+  if (maxM >= big_rows)
+    hipLaunchKernelGGL(mlp_fused_bwd_big_kernel, dim3((maxM + 63) / 64, nprob), dim3(MF_NT), lds_big, st, a);
+  else
+    hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3((maxM + BMF - 1) / BMF, nprob), dim3(MF_NT), lds, st, a);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 

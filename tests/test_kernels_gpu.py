@@ -493,6 +493,41 @@ def test_mlp_fused_forward_ragged_input_width():
         assert relerr(a_f[i], a_g[i]) < 2e-3, relerr(a_f[i], a_g[i])
 
 
+def test_mlp_fused_backward_many_rows():
+    """>= 16384 rows: the 64-rows-per-workgroup input-gradient chain (and the one-launch weight gradients, lean mode) vs
+    the per-layer bf16 backward on the same saved activations."""
+    from tacorl_amd import blocks, ops
+
+    dev = _dev()
+    dims, acts, Ms = [71, 256, 256, 256, 1], [2, 2, 2, 0], [16384 + 77, 130]
+    L, ld = len(dims) - 1, 72
+    xs, flats, fb, act_s, act_l, douts = [], [], [], [], [], []
+    for i, M in enumerate(Ms):
+        flat = torch.zeros(blocks.mlp_size(dims), device=dev)
+        v = blocks.mlp_views(flat, 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+        for l in range(L):
+            v[f"l{l}.w"].copy_(rnd(dims[l + 1], dims[l], seed=650 + i + l, scale=1 / math.sqrt(dims[l])))
+            v[f"l{l}.b"].copy_(rnd(dims[l + 1], seed=660 + i + l, scale=0.1))
+        xp = torch.zeros(M, ld, device=dev)
+        xp[:, :dims[0]] = rnd(M, dims[0], seed=670 + i).to(dev)
+        xs.append(xp); flats.append(flat); fb.append(flat.to(torch.bfloat16))
+        n_act = ops.mlp_act_layout(M, dims, acts)[2]
+        act_s.append(torch.zeros(n_act, device=dev)); act_l.append(torch.zeros(n_act, device=dev))
+        douts.append(rnd(M, dims[-1], seed=680 + i).to(dev))
+    ops.mlp_fwd(xs, ld, flats, act_s, Ms, dims, acts, 1)                                # per-layer forward: everything saved
+    ops.mlp_fwd(xs, ld, flats, act_l, Ms, dims, acts, 1, params_bf16=fb, lean=True)     # fused, lean
+    g_ref, g_fus = [torch.zeros_like(f) for f in flats], [torch.zeros_like(f) for f in flats]
+    dx_ref, dx_fus = [torch.zeros(M, ld, device=dev) for M in Ms], [torch.zeros(M, ld, device=dev) for M in Ms]
+    ops.mlp_bwd(xs, ld, flats, act_s, douts, dims[-1], g_ref, dx_ref, ld, Ms, dims, acts, 1)
+    ops.mlp_bwd_fused_dgrad(flats, act_l, douts, dims[-1], dx_fus, ld, Ms, dims, acts, "t_mlp_big")
+    ops.mlp_bwd_fused_wgrad(xs, ld, act_l, douts, dims[-1], g_fus, Ms, dims, acts, "t_mlp_big", lean=True)
+    torch.cuda.synchronize()
+    for i in range(len(Ms)):
+        assert torch.isfinite(g_fus[i]).all() and torch.isfinite(dx_fus[i]).all()
+        assert relerr(dx_fus[i], dx_ref[i]) < 4e-3, ("dx", i, relerr(dx_fus[i], dx_ref[i]))
+        assert relerr(g_fus[i], g_ref[i]) < 4e-3, ("grads", i, relerr(g_fus[i], g_ref[i]))
+
+
 @pytest.mark.parametrize("lean", [False, True])
 def test_mlp_fused_forward_many_rows(lean):
     """>= 16384 rows take the 128-rows-per-workgroup instantiation (C5's Q networks: 99 k rows): against the per-layer
