@@ -9,15 +9,22 @@ rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 mod = bench.build_module(dev, "bf16", 16, 1)
 batches = [bench.synth_batch(256, 16, 84, 84, dev, 1), bench.synth_batch(256, 16, 84, 84, dev, 2)]
 mod.enable_graph(); mod.log_every_n_steps = 50
+def setv(path, v):
+    o = mod
+    *head, last = path.split(".")
+    for h in head: o = getattr(o, h)
+    setattr(o, last, v)
+    if hasattr(mod.engine, "_lean_cache"): mod.engine._lean_cache = {}
+    mod._graphs = {}  # the captured step depends on the switch
 def run(n):
     for i in range(n): mod.training_step(batches[i % 2])
 for v in (v0, v1):
-    setattr(mod, attr, v); run(10)
+    setv(attr, v); run(10)
 torch.cuda.synchronize()
 res = {repr(v0): [], repr(v1): []}
 for r in range(rounds):
     for v in (v0, v1):
-        setattr(mod, attr, v); run(20); torch.cuda.synchronize()
+        setv(attr, v); run(20); torch.cuda.synchronize()
         t0 = time.perf_counter(); run(400); torch.cuda.synchronize()
         res[repr(v)].append((time.perf_counter() - t0) / 400 * 1e3)
 for k, v in res.items():
