@@ -28,7 +28,7 @@ print(f"imgs {sum(n)} ms {ms:.4f} TF {sum(n)*13.918e6/ms/1e9:.1f}")
 import ctypes as C
 L = _lib.lib()
 if hasattr(L, "tacorl_ef_stamps_read"):
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 64)()
     L.tacorl_ef_stamps_read(buf, 1)
     run(); torch.cuda.synchronize()
     L.tacorl_ef_stamps_read(buf, 0)
@@ -36,3 +36,7 @@ if hasattr(L, "tacorl_ef_stamps_read"):
     tot = sum(buf[:10])
     for k, nm in enumerate(names): print(f"{nm:18s} {buf[k]:9d} clk  {100.0 * buf[k] / tot:5.1f} %")
     print("total clk", tot)
+    if any(buf[16:64]):
+        print("fine stamps (conv1 tiles 16.., conv2 [blocks12, blocks34, epilogue] x tile 24..):")
+        print("  conv1", [buf[k] for k in range(16, 24)])
+        print("  conv2", [buf[k] for k in range(24, 33)])

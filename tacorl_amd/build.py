@@ -14,6 +14,11 @@ OBJ_DIR = os.path.join(HERE, "lib", "obj")
 OUT = os.path.join(HERE, "lib", "libtacorl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17"]
+# per-file extras.  encoder_fused: neither the IR load/store vectorizer nor the SI load/store optimizer - either one
+# fuses the conv1 fragment reads (8-byte halves at a 24-byte pixel stride) into ds_read2_b64, which the LDS serves at
+# 128 B/clk in 16-lane groups; plain ds_read_b64 pairs run at 256 B/clk in the 32-lane groups the tile layout is made for.
+EXTRA = {"encoder_fused": ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllvm",
+                           "-amdgpu-load-store-vectorizer=0"]}
 
 
 def _headers_mtime():
@@ -35,7 +40,7 @@ def build(force=False, verbose=True):
             todo.append((s, o))
 
     def cc(so):
-        cmd = [HIPCC, *FLAGS, "-c", so[0], "-o", so[1]]
+        cmd = [HIPCC, *FLAGS, *EXTRA.get(os.path.basename(so[0])[:-4], []), "-c", so[0], "-o", so[1]]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

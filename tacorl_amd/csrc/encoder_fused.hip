@@ -124,7 +124,7 @@ extern "C" int tacorl_encoder_pack_weights(int nprob, const float* const* params
 // shared destination register).  Inline asm is invisible to hipcc's hazard recogniser, so the chain
 // brackets itself: s_nop before the first MFMA (VALU-written accumulator) and after the last one
 // (MFMA result read by VALU) - cdna_hip_programming.md section 5.7.
-#if EF_VAR == 2
+#if EF_VAR & 2
 #define MFMA_AW(acc, wfrag, bfrag) asm volatile("" : "+v"(acc) : "a"(wfrag), "v"(bfrag))
 #else
 #define MFMA_AW(acc, wfrag, bfrag) \
@@ -134,8 +134,8 @@ extern "C" int tacorl_encoder_pack_weights(int nprob, const float* const* params
 // First MFMA of a chain: the bias registers are its C operand and the accumulator only its destination - no four
 // v_mov per chain to seed the accumulator (22 chains per image), and no VALU-write -> MFMA-read wait either: the
 // bias registers were written once, before the image loop.
-#if EF_VAR == 2
-#define MFMA_FIRST_AW(acc, wfrag, bfrag, bias) asm volatile("v_mov_b32 %0, %0" : "=v"(acc) : "a"(wfrag), "v"(bfrag), "v"(bias))
+#if EF_VAR & 2
+#define MFMA_FIRST_AW(acc, wfrag, bfrag, bias) asm volatile("" : "=v"(acc) : "a"(wfrag), "v"(bfrag), "v"(bias))
 #else
 #define MFMA_FIRST_AW(acc, wfrag, bfrag, bias) \
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc) : "a"(wfrag), "v"(bfrag), "v"(bias))
@@ -143,10 +143,75 @@ extern "C" int tacorl_encoder_pack_weights(int nprob, const float* const* params
 // (12 wait states: what an 8-pass XDL result needs before a non-MFMA reader, cdna_hip_programming.md section 5.7 item 2;
 // v_mfma_f32_16x16x32_bf16 issues every ~17 clk in a dependent chain, i.e. is a 4-pass op - 20 states were used before)
 #define MFMA_CHAIN_END(acc) asm volatile("s_nop 11" : "+v"(acc))
+#if EF_VAR & 2
+#define EF_MFMA_TXT(...) ""
+#else
+#define EF_MFMA_TXT(...) __VA_ARGS__
+#endif
+// ---- MFMA chains as ONE asm statement each (operands: %0 accumulator, then the N weight fragments, the N im2col fragments, the bias).  hipcc pads an
+// `s_nop 0` between two adjacent asm statements and a counted s_waitcnt in front of each one whose fragment is the
+// youngest LDS read: per 16x16x32 MFMA that was 1.3 scalar instructions, each a 4-5 clk issue slot at one wave per SIMD.
+#define MFMA6_FIRST(acc, bias, w, o, f) \
+  asm volatile(EF_MFMA_TXT("v_mfma_f32_16x16x32_bf16 %0, %1, %7, %13\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %2, %8, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %3, %9, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %4, %10, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %5, %11, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %6, %12, %0\n\t") \
+      : "=&v"(acc) : "a"((w)[(o) + 0]), "a"((w)[(o) + 1]), "a"((w)[(o) + 2]), "a"((w)[(o) + 3]), "a"((w)[(o) + 4]), "a"((w)[(o) + 5]), "v"((f)[0]), "v"((f)[1]), "v"((f)[2]), "v"((f)[3]), "v"((f)[4]), "v"((f)[5]), "v"(bias))
+#define MFMA6_MORE(acc, w, o, f) \
+  asm volatile(EF_MFMA_TXT("v_mfma_f32_16x16x32_bf16 %0, %1, %7, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %2, %8, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %3, %9, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %4, %10, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %5, %11, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %6, %12, %0\n\t") \
+      : "+v"(acc) : "a"((w)[(o) + 0]), "a"((w)[(o) + 1]), "a"((w)[(o) + 2]), "a"((w)[(o) + 3]), "a"((w)[(o) + 4]), "a"((w)[(o) + 5]), "v"((f)[0]), "v"((f)[1]), "v"((f)[2]), "v"((f)[3]), "v"((f)[4]), "v"((f)[5]))
+#define MFMA8_FIRST(acc, bias, w, o, f) \
+  asm volatile(EF_MFMA_TXT("v_mfma_f32_16x16x32_bf16 %0, %1, %9, %17\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %2, %10, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %3, %11, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %4, %12, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %5, %13, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %6, %14, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %7, %15, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %8, %16, %0\n\t") \
+      : "=&v"(acc) : "a"((w)[(o) + 0]), "a"((w)[(o) + 1]), "a"((w)[(o) + 2]), "a"((w)[(o) + 3]), "a"((w)[(o) + 4]), "a"((w)[(o) + 5]), "a"((w)[(o) + 6]), "a"((w)[(o) + 7]), "v"((f)[0]), "v"((f)[1]), "v"((f)[2]), "v"((f)[3]), "v"((f)[4]), "v"((f)[5]), "v"((f)[6]), "v"((f)[7]), "v"(bias))
+#define MFMA8_MORE(acc, w, o, f) \
+  asm volatile(EF_MFMA_TXT("v_mfma_f32_16x16x32_bf16 %0, %1, %9, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %2, %10, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %3, %11, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %4, %12, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %5, %13, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %6, %14, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %7, %15, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %8, %16, %0\n\t") \
+      : "+v"(acc) : "a"((w)[(o) + 0]), "a"((w)[(o) + 1]), "a"((w)[(o) + 2]), "a"((w)[(o) + 3]), "a"((w)[(o) + 4]), "a"((w)[(o) + 5]), "a"((w)[(o) + 6]), "a"((w)[(o) + 7]), "v"((f)[0]), "v"((f)[1]), "v"((f)[2]), "v"((f)[3]), "v"((f)[4]), "v"((f)[5]), "v"((f)[6]), "v"((f)[7]))
+#define MFMA9_FIRST(acc, bias, w, o, f) \
+  asm volatile(EF_MFMA_TXT("v_mfma_f32_16x16x32_bf16 %0, %1, %10, %19\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %2, %11, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %3, %12, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %4, %13, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %5, %14, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %6, %15, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %7, %16, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %8, %17, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %9, %18, %0\n\t") \
+      : "=&v"(acc) : "a"((w)[(o) + 0]), "a"((w)[(o) + 1]), "a"((w)[(o) + 2]), "a"((w)[(o) + 3]), "a"((w)[(o) + 4]), "a"((w)[(o) + 5]), "a"((w)[(o) + 6]), "a"((w)[(o) + 7]), "a"((w)[(o) + 8]), "v"((f)[0]), "v"((f)[1]), "v"((f)[2]), "v"((f)[3]), "v"((f)[4]), "v"((f)[5]), "v"((f)[6]), "v"((f)[7]), "v"((f)[8]), "v"(bias))
+#define MFMA9_MORE(acc, w, o, f) \
+  asm volatile(EF_MFMA_TXT("v_mfma_f32_16x16x32_bf16 %0, %1, %10, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %2, %11, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %3, %12, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %4, %13, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %5, %14, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %6, %15, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %7, %16, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %8, %17, %0\n\t" \
+      "v_mfma_f32_16x16x32_bf16 %0, %9, %18, %0\n\t") \
+      : "+v"(acc) : "a"((w)[(o) + 0]), "a"((w)[(o) + 1]), "a"((w)[(o) + 2]), "a"((w)[(o) + 3]), "a"((w)[(o) + 4]), "a"((w)[(o) + 5]), "a"((w)[(o) + 6]), "a"((w)[(o) + 7]), "a"((w)[(o) + 8]), "v"((f)[0]), "v"((f)[1]), "v"((f)[2]), "v"((f)[3]), "v"((f)[4]), "v"((f)[5]), "v"((f)[6]), "v"((f)[7]), "v"((f)[8]))
 
 // ------------------------------------------------------------------------- kernel
 #define ACT1_STRIDE 80   // bytes per conv1-output pixel (32 ch bf16 + 16 pad)
-#define ACT2_STRIDE 160  // bytes per conv2-output pixel (64 ch bf16 + 32 pad)
 #define SA_STRIDE 272    // bytes per image of soft-argmax features (128 bf16 + 16 pad)
 #define H1_STRIDE 528    // bytes per image of fc1 output (256 bf16 + 16 pad)
 
@@ -158,7 +223,23 @@ struct EFGeom {
   static constexpr int OH3 = OH2 - 2, OW3 = OW2 - 2;
   static constexpr int IMG_BYTES = H * W * 6;
   static constexpr int NPX1 = OH1 * OW1, NPX2 = OH2 * OW2, NPX3 = OH3 * OW3;
-  static constexpr int ACT1_BYTES = (NPX1 * 80 + 15) & ~15, ACT2_BYTES = (NPX2 * 160 + 15) & ~15;
+  // Row pitches of the two activation images in LDS.  Pixel strides 80 / 160 B alone are conflict-free only inside one
+  // image row; a 16-pixel tile spans 2-3 rows of a 9- or 7-pixel-wide output, and with dense rows the wrap put two
+  // lanes of a ds_read_b128 lane group on the same banks: 7.3 / 7.0 LDS cycles per read instead of 4 (measured,
+  // scratch/micro/lds_pat; model scratch/micro/bank_sim.py, which also found these pads - the smallest that give 4.0
+  // for every tile and tap of the geometry).
+  static constexpr int PAD1 = (H == 84 && W == 84) ? 16 : (H == 44 && W == 60) ? 0 : 48;
+  static constexpr int PX2 = 160;  // bytes per conv2-output pixel (64 ch bf16 + 32 pad)
+  static constexpr int PAD2 = (H == 44 && W == 60) ? 32 : 192;
+  static constexpr int PITCH1 = OW1 * 80 + PAD1, PITCH2 = OW2 * PX2 + PAD2;
+  static constexpr int ACT1_BYTES = OH1 * PITCH1, ACT2_BYTES = OH2 * PITCH2;
+  // conv1 tiles of 16 output pixels with x stride 2 (all-even-x tiles, all-odd-x tiles, one mixed tail tile): the two
+  // image rows a 32-lane ds_read_b64 group touches are 504 B = 63 (odd) 8-byte units apart, pixels 2 apart are 6
+  // units apart (even), so the group's 32 accesses fall on 32 different 8-byte units mod 256 B - conflict-free, and the
+  // reads are issued as ds_read_b64 pairs at 256 B/clk (hipcc's merged ds_read2_b64 runs at 128 B/clk: 8 LDS cycles
+  // per fragment against 2 x 2.08; this file is compiled with the load-store-opt target feature off, build.py).
+  // Row pitches other than 504 B do not have the property (bank_sim.py).
+  static constexpr bool S2 = (H == 84 && W == 84);
   static constexpr int FIXED_BYTES = ACT1_BYTES + ACT2_BYTES + EF_CHUNK * (272 + 528);
   // The image buffer is double: two whole images when they fit beside the activations (84 x 84: 2 x 42 KB); otherwise
   // conv1 runs over BANDS of BR output rows = 4 BR + 4 image rows (128 x 128: 8 bands of 20 rows, 2 x 15 KB; the 4
@@ -178,8 +259,11 @@ struct EFGeom {
 #ifndef EF_VAR
 #define EF_VAR 0
 #endif
+#ifndef EF_X   // scratch experiments: 1 = no image DMA inside the loop, 2 = conv1 does not store its activations
+#define EF_X 0
+#endif
 #ifdef EF_STAMPS
-__device__ unsigned long long ef_stamps[16];
+__device__ unsigned long long ef_stamps[64];
 #define STAMP(k)                                                    \
   do {                                                              \
     if (blockIdx.x == 0 && threadIdx.x == 0) {                      \
@@ -191,7 +275,7 @@ __device__ unsigned long long ef_stamps[16];
 extern "C" int tacorl_ef_stamps_read(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ef_stamps), sizeof(ef_stamps)) != hipSuccess) return TACORL_ELAUNCH;
   if (reset) {
-    unsigned long long z[16] = {};
+    unsigned long long z[64] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(ef_stamps), z, sizeof(z)) != hipSuccess) return TACORL_ELAUNCH;
   }
   return TACORL_OK;
@@ -221,8 +305,8 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 
   unsigned char* act1 = lds + 2 * a.lds_img;
   const int npx1 = a.OH1 * a.OW1, npx2 = a.OH2 * a.OW2, npx3 = a.OH3 * a.OW3;
-  unsigned char* act2 = act1 + ((npx1 * ACT1_STRIDE + 15) & ~15);
-  unsigned char* sa = act2 + ((npx2 * ACT2_STRIDE + 15) & ~15);
+  unsigned char* act2 = act1 + G::ACT1_BYTES;
+  unsigned char* sa = act2 + G::ACT2_BYTES;
   unsigned char* h1 = sa + EF_CHUNK * SA_STRIDE;
 
   // ---- register-stationary weights and biases
@@ -261,45 +345,62 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
               bias2a = {b2[0][0], b2[0][1], b2[0][2], b2[0][3]}, bias2b = {b2[1][0], b2[1][1], b2[1][2], b2[1][3]},
               bias3 = {b3[0], b3[1], b3[2], b3[3]};
   const float temp = P.params[po[6]];
+  // Every load the COMPILER knows about must have completed before the image loop: hipcc's wait-count pass does not
+  // see the asm-issued LDS-DMA pieces, so a "vmcnt(7)" it places at the first in-loop use of a bias register to
+  // cover these few prologue loads in fact waits for all but the 7 youngest of the NEXT image's pieces - an HBM
+  // round trip exposed at the top of every image (round 2's kernel had four such waits in its loop).
+  asm volatile("" ::"v"(bias1a), "v"(bias1b), "v"(bias2a), "v"(bias2b), "v"(bias3), "v"(temp));
 
+#if EF_VAR & 1
+  u32x4 kconst;  // scratch builds: a benign fragment (bf16 1/128 everywhere) instead of every LDS fragment read
+  asm volatile("v_mov_b32 %0, 0x3c003c00" : "=v"(kconst[0]));
+  kconst[1] = kconst[2] = kconst[3] = kconst[0];
+#endif
   // conv1 k offsets (bytes): lane group g reads image row 4 (s / 3) + g, 8-element group s % 3 of the 24-run
   const int k1g = g * a.W * 6;
 
   // ---- image streaming: LDS-DMA (global_load_lds_dwordx4: no staging registers).  One wave-instruction
   // moves 64 x 16 B = 1 KiB from a contiguous global span to a contiguous LDS span (wave-uniform LDS base).
-  auto dma_load = [&](long img_idx, int band, int buf) {
+  // SGPR-base form: address = uniform 64-bit base (image + 4 KiB step) + one constant per-lane byte offset, LDS
+  // destination in M0 - no per-piece vector address arithmetic (the flat-pointer form cost 4 VALU + 6 SALU per piece).
+  const unsigned dma_voff = (unsigned)tid * 16u;
+  const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)lds;
+  // pieces [i0, i1) of (image, band): piece i = the 256-lane span of 4 KiB at offset 4096 i, this wave's KiB of it
+  auto dma_pieces = [&](long img_idx, int band, int buf, int i0, int i1) {
     const int row0 = G::WHOLE ? 0 : 4 * G::BR * band;                                // first image row of the band
     const int rows = G::WHOLE ? G::H : min(G::BAND_ROWS, G::H - row0);
     const int n16 = G::WHOLE ? (G::IMG_BYTES >> 4) : (rows * G::W * 6) >> 4;          // 16-byte chunks to move
     const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img) + img_idx * G::IMG_BYTES + row0 * (G::W * 6);
-    unsigned char* dstb = lds + buf * a.lds_img;
+    const unsigned dst0 = lds_base + buf * a.lds_img + w * 1024;
 #pragma unroll
-    for (int i = 0; i < EF_MAXCH; i++) {
+    for (int i = i0; i < i1; i++) {
+      if (i >= EF_MAXCH) break;
       const int c0 = i * 256 + w * 64;  // first chunk of this wave-instruction (wave-uniform)
       if (c0 < n16) {
         if (c0 + l < n16) {
           // inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in the loop hipcc degrades every
           // LDS wait of the conv phases to lgkmcnt(0) (it cannot tell the DMA's LDS writes from the fragment
           // reads), which exposes the full LDS latency at each tile; the ordering against the readers of this
-          // buffer is explicit anyway (vmcnt(0) + barrier at the end of the image / band).
-          const unsigned lds_off = __builtin_amdgcn_readfirstlane(
-              (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)(dstb + c0 * 16));  // wave-uniform
-          unsigned keep;
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                       : "=&s"(keep)
-                       : "v"(src + (long)(c0 + l) * 16), "s"(lds_off)
+          // buffer is explicit anyway (vmcnt(0) + barrier at the end of the image / band).  M0 is reserved by
+          // hipcc (never allocated; it sets M0 itself immediately before any instruction of its own that reads it).
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                       :
+                       : "v"(dma_voff), "s"(__builtin_amdgcn_readfirstlane(dst0 + i * 4096)), "s"(src + i * 4096)
                        : "memory");
         }
       }
     }
   };
+  auto dma_load = [&](long img_idx, int band, int buf) { dma_pieces(img_idx, band, buf, 0, EF_MAXCH); };
 
   // images this workgroup processes: worker, worker + nworkers, ... (image granularity: at most one image
   // of imbalance); the FC tail runs after every EF_CHUNK processed images (slots) or at the end.
   long cur = worker;
   int it = 0, buf = 0;
   dma_load(cur, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // vmcnt(0) as the BUILTIN: it empties the compiler's own scoreboard too (an asm wait does not) - see the note at the
+  // bias registers above; the weights load straight into AGPRs and would otherwise be waited for inside the loop
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   STAMP(0);  // prologue: weights to registers, first image
 
@@ -313,24 +414,41 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #pragma unroll 1
     for (int band = 0; band < G::NB; band++) {
       // the other buffer was last read by the previous band's (or image's) conv1, a barrier ago
+      // The next image (band) streams in beside this one's conv1.  Whole-image geometries spread their ~11 pieces per
+      // wave over the conv1 tiles (two per tile, below): issued in one burst the pieces queue behind one another in the
+      // CU's memory pipeline and the issuing wave stands still for ~100 clk per piece (1 000 clk per image).
+#if !(EF_X & 1)
       if (band + 1 < G::NB) dma_load(cur, band + 1, buf ^ 1);
-      else if (has_next) dma_load(nxt, 0, buf ^ 1);
+      else if (has_next && !G::WHOLE) dma_load(nxt, 0, buf ^ 1);
+#endif
       STAMP(1);  // DMA issue
       const unsigned char* ib = lds + buf * a.lds_img;
       constexpr int NT1 = (G::NPXB + 15) >> 4, PER1 = (NT1 + 3) >> 2;
       const int npxb = G::WHOLE ? npx1 : min(G::BR, a.OH1 - band * G::BR) * a.OW1;  // output pixels of this band
       const int nt1 = G::WHOLE ? NT1 : (npxb + 15) >> 4, px0 = band * G::NPXB;
-      auto base1 = [&](int mt) {
-        const int pc = min(mt * 16 + r16, npxb - 1);
-        const int oy = pc / a.OW1, ox = pc - oy * a.OW1;
-        return ib + ((4 * oy * a.W + 4 * ox) * 3) * 2 + k1g;
+      // pixel of lane r16 in tile mt: (oy, ox) inside the band, clamped to a valid pixel; false for padding lanes
+      auto px1 = [&](int mt, int& oy, int& ox) -> bool {
+        if (G::S2) {
+          constexpr int half = G::OW1 / 2, NE = G::OH1 * half, TE = NE / 16, REM = NE % 16;
+          static_assert(!G::S2 || (G::OW1 % 2 == 0 && REM <= 8 && G::WHOLE), "stride-2 conv1 tiles");
+          int par, n; bool ok = true;
+          if (mt < 2 * TE) { par = mt >= TE ? 1 : 0; n = 16 * (mt - par * TE) + r16; }
+          else { par = r16 >> 3; n = 16 * TE + (r16 & 7); ok = (r16 & 7) < REM; n = min(n, NE - 1); }
+          oy = n / half; ox = 2 * (n - oy * half) + par;
+          return ok;
+        } else {
+          const int pb = mt * 16 + r16, pc = min(pb, npxb - 1);
+          oy = pc / a.OW1; ox = pc - oy * a.OW1;
+          return pb < npxb;
+        }
       };
+      auto base1 = [&](int oy, int ox) { return ib + ((4 * oy * a.W + 4 * ox) * 3) * 2 + k1g; };
       auto ld1 = [&](const unsigned char* base, u32x4 (&bf)[6]) {
 #pragma unroll
         for (int s = 0; s < 6; s++) {
           const int off = (s / 3) * 4 * G::W * 6 + (s % 3) * 16;  // compile-time immediate
-#if EF_VAR == 1
-          bf[s] = u32x4{(unsigned)(size_t)base, (unsigned)off, 0u, 0u};
+#if EF_VAR & 1
+          bf[s] = kconst; (void)base;
 #else
           const u32x2 lo = *reinterpret_cast<const u32x2*>(base + off);
           const u32x2 hi = *reinterpret_cast<const u32x2*>(base + off + 8);
@@ -338,38 +456,48 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #endif
         }
       };
-      auto tile1 = [&](int mt, u32x4 (&bf)[6]) {
+      auto tile1 = [&](int oy, int ox, bool ok, u32x4 (&bf)[6]) {
         f32x4 acc0, acc1;
-        MFMA_FIRST_AW(acc0, wc1a[0], bf[0], bias1a);
-#pragma unroll
-        for (int s = 1; s < 6; s++) MFMA_AW(acc0, wc1a[s], bf[s]);
-        MFMA_CHAIN_END(acc0);    // the compiler may schedule acc0's epilogue right here: cover the hazard
-        MFMA_FIRST_AW(acc1, wc1b[0], bf[0], bias1b);  // each accumulator chain stays strictly back-to-back (asm
-#pragma unroll                   // MFMAs get no compiler hazard handling: interleaving two chains returned wrong sums)
-        for (int s = 1; s < 6; s++) MFMA_AW(acc1, wc1b[s], bf[s]);
+        MFMA6_FIRST(acc0, bias1a, wc1a, 0, bf);  // each accumulator chain stays strictly back-to-back (asm MFMAs get no
+        MFMA6_FIRST(acc1, bias1b, wc1b, 0, bf);  // compiler hazard handling: interleaving two chains returned wrong sums)
         MFMA_CHAIN_END(acc1);
-        const int pb = mt * 16 + r16;
-        if (pb < npxb) {
-          const int pm = px0 + pb;
+        asm volatile("" : "+v"(acc0));           // acc0's readers stay behind the second chain (6 MFMAs: hazard covered)
+        if (ok) {
+          const int oyi = band * G::BR + oy;  // row inside the image
           const f32x4 r0 = {relu1(acc0[0]), relu1(acc0[1]), relu1(acc0[2]), relu1(acc0[3])};
           const f32x4 r1 = {relu1(acc1[0]), relu1(acc1[1]), relu1(acc1[2]), relu1(acc1[3])};
           const u32x2 lo = pack4_bf16(r0[0], r0[1], r0[2], r0[3]), hi = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
           const u32x4 pk = {lo[0], lo[1], hi[0], hi[1]};
-          *reinterpret_cast<u32x4*>(act1 + pm * ACT1_STRIDE + (8 * g) * 2) = pk;  // channels 8 g .. 8 g + 7
+#if !(EF_X & 2)
+          *reinterpret_cast<u32x4*>(act1 + oyi * G::PITCH1 + ox * ACT1_STRIDE + (8 * g) * 2) = pk;  // channels 8 g .. 8 g + 7
+#else
+          asm volatile("" :: "v"(pk));
+#endif
           // saved for the backward as bf16 - the very value the next layer consumes (ReLU mask of the dgrad, im2col operand
           // of the wgrad) - at the start of y1's fp32-sized slot: one 16-byte store, half the bytes of the fp32 copy
-          if (P.act) *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(P.act) + ((long)cur * npx1 + pm) * 32 + 8 * g) = pk;
+          if (P.act)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(P.act) + ((long)cur * npx1 + oyi * a.OW1 + ox) * 32 + 8 * g) = pk;
         }
       };
+      constexpr int DPT = G::WHOLE ? ((G::IMG_BYTES + 4095) / 4096 + PER1 - 1) / PER1 : 0;  // DMA pieces per conv1 tile
       u32x4 fa[6], fb[6];
-      ld1(base1(w), fa);
+      int oya, oxa, oyb, oxb;
+      bool oka = px1(w, oya, oxa), okb = false;
+      ld1(base1(oya, oxa), fa);
 #pragma unroll
       for (int i = 0; i < PER1; i += 2) {
-        if (w + 4 * (i + 1) < nt1 && i + 1 < PER1) ld1(base1(w + 4 * (i + 1)), fb);
-        if (w + 4 * i < nt1) tile1(w + 4 * i, fa);
-        if (w + 4 * (i + 2) < nt1 && i + 2 < PER1) ld1(base1(w + 4 * (i + 2)), fa);
-        if (w + 4 * (i + 1) < nt1 && i + 1 < PER1) tile1(w + 4 * (i + 1), fb);
+        if (w + 4 * (i + 1) < nt1 && i + 1 < PER1) { okb = px1(w + 4 * (i + 1), oyb, oxb); ld1(base1(oyb, oxb), fb); }
+#if !(EF_X & 1)
+        if (G::WHOLE && has_next) dma_pieces(nxt, 0, buf ^ 1, i * DPT, (i + 1) * DPT);
+#endif
+        if (w + 4 * i < nt1) tile1(oya, oxa, oka, fa);
+        if (w + 4 * (i + 2) < nt1 && i + 2 < PER1) { oka = px1(w + 4 * (i + 2), oya, oxa); ld1(base1(oya, oxa), fa); }
+#if !(EF_X & 1)
+        if (G::WHOLE && has_next && i + 1 < PER1) dma_pieces(nxt, 0, buf ^ 1, (i + 1) * DPT, (i + 2) * DPT);
+#endif
+        if (w + 4 * (i + 1) < nt1 && i + 1 < PER1) tile1(oyb, oxb, okb, fb);
       }
+      static_assert(!G::WHOLE || PER1 * DPT * 4096 >= G::IMG_BYTES, "every piece of the next image is issued");
       if (band + 1 < G::NB) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next band has landed
         __syncthreads();                                  // ... everyone's, and everyone is done reading this band
@@ -387,16 +515,16 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       auto base2 = [&](int mt) {
         const int pc = min(mt * 16 + r16, npx2 - 1);
         const int oy = pc / a.OW2, ox = pc - oy * a.OW2;
-        return act1 + ((2 * oy) * a.OW1 + 2 * ox) * ACT1_STRIDE + 16 * g;
+        return act1 + (2 * oy) * G::PITCH1 + 2 * ox * ACT1_STRIDE + 16 * g;
       };
       auto ld2 = [&](const unsigned char* base, int h, u32x4 (&bf)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
           const int s = 8 * h + i, ky = s >> 2, kx = s & 3;
-#if EF_VAR == 1
-          bf[i] = u32x4{(unsigned)(size_t)base, (unsigned)s, 0u, 0u};
+#if EF_VAR & 1
+          bf[i] = kconst; (void)base;
 #else
-          bf[i] = *reinterpret_cast<const u32x4*>(base + (ky * a.OW1 + kx) * ACT1_STRIDE);
+          bf[i] = *reinterpret_cast<const u32x4*>(base + ky * G::PITCH1 + kx * ACT1_STRIDE);
 #endif
         }
       };
@@ -414,19 +542,14 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
           if (mt < NT2) {
             f32x4 acc0, acc1;
             ld2(bcur, 1, fb);
-            MFMA_FIRST_AW(acc0, wc2a[0], fa[0], bias2a);
-#pragma unroll
-            for (int i = 1; i < 8; i++) MFMA_AW(acc0, wc2a[i], fa[i]);
-            MFMA_FIRST_AW(acc1, wc2b[0], fa[0], bias2b);
-#pragma unroll
-            for (int i = 1; i < 8; i++) MFMA_AW(acc1, wc2b[i], fa[i]);
-            // next tile's first half (the last tile re-reads its own: a conditional load would push fa[] to scratch)
+            MFMA8_FIRST(acc0, bias2a, wc2a, 0, fa);
+            MFMA8_FIRST(acc1, bias2b, wc2b, 0, fa);
+            // next tile's first half, issued as soon as fa[] is free: 16 MFMAs ahead of its first use (the last tile
+            // re-reads its own: a conditional load would push fa[] to scratch)
             bcur = base2(mt + 2 < NT2 ? mt + 2 : mt);
-#pragma unroll
-            for (int i = 0; i < 8; i++) MFMA_AW(acc0, wc2a[8 + i], fb[i]);
-#pragma unroll
-            for (int i = 0; i < 8; i++) MFMA_AW(acc1, wc2b[8 + i], fb[i]);
             ld2(bcur, 0, fa);
+            MFMA8_MORE(acc0, wc2a, 8, fb);
+            MFMA8_MORE(acc1, wc2b, 8, fb);
             MFMA_CHAIN_END(acc1);             // (acc0's last MFMA is 8 MFMAs older: covered)
             asm volatile("" : "+v"(acc0));
             // (store addresses re-derived behind an opaque zero: hoisted out of the image loop they are spilled, and a
@@ -439,7 +562,8 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
               const f32x4 r1 = {relu1(acc1[0]), relu1(acc1[1]), relu1(acc1[2]), relu1(acc1[3])};
               const u32x2 lo = pack4_bf16(r0[0], r0[1], r0[2], r0[3]), hi = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
               const u32x4 pk = {lo[0], lo[1], hi[0], hi[1]};
-              *reinterpret_cast<u32x4*>(act2 + pm * ACT2_STRIDE + (32 * cg + 8 * g) * 2) = pk;
+              const int oy2 = pm / a.OW2, ox2 = pm - oy2 * a.OW2;
+              *reinterpret_cast<u32x4*>(act2 + oy2 * G::PITCH2 + ox2 * G::PX2 + (32 * cg + 8 * g) * 2) = pk;
               if (P.act) {
                 // bf16 at the start of y2's slot; wave-uniform base + 32-bit lane offset (a 64-bit per-lane address would be
                 // hoisted and spilled)
@@ -465,16 +589,16 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       auto base3 = [&](int mt, int& ox, int& oy) {
         const int pc = min(mt * 16 + r16, npx3 - 1);
         oy = pc / a.OW3; ox = pc - oy * a.OW3;
-        return act2 + (oy * a.OW2 + ox) * ACT2_STRIDE + 16 * g;
+        return act2 + oy * G::PITCH2 + ox * G::PX2 + 16 * g;
       };
       auto ld3 = [&](const unsigned char* base, int h, u32x4 (&bf)[9]) {
 #pragma unroll
         for (int i = 0; i < 9; i++) {
           const int s = 9 * h + i, tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
-#if EF_VAR == 1
-          bf[i] = u32x4{(unsigned)(size_t)base, (unsigned)s, 0u, 0u};
+#if EF_VAR & 1
+          bf[i] = kconst; (void)base;
 #else
-          bf[i] = *reinterpret_cast<const u32x4*>(base + (ky * a.OW2 + kx) * ACT2_STRIDE + 64 * (s & 1));
+          bf[i] = *reinterpret_cast<const u32x4*>(base + ky * G::PITCH2 + kx * G::PX2 + 64 * (s & 1));
 #endif
         }
       };
@@ -487,12 +611,9 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         f32x4 acc;
         fx[mt] = (float)ox; fy[mt] = (float)oy;
         ld3(bcur, 1, fb);
-        MFMA_FIRST_AW(acc, wc3[0], fa[0], bias3);
-#pragma unroll
-        for (int i = 1; i < 9; i++) MFMA_AW(acc, wc3[i], fa[i]);
+        MFMA9_FIRST(acc, bias3, wc3, 0, fa);
         if (mt + 1 < NT3) { bcur = base3(mt + 1, ox, oy); ld3(bcur, 0, fa); }
-#pragma unroll
-        for (int i = 0; i < 9; i++) MFMA_AW(acc, wc3[9 + i], fb[i]);
+        MFMA9_MORE(acc, wc3, 9, fb);
         MFMA_CHAIN_END(acc);
         const bool ok = mt * 16 + r16 < npx3;
         if (P.act && ok)
