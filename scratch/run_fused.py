@@ -16,14 +16,17 @@ ops.call("tacorl_encoder_pack_weights", len(n), ops.ptr_array(flats), ops.ptr_ar
 def run():
     ops.call("tacorl_encoder_fwd_fused", len(n), ops.ptr_array(imgs), ops.ptr_array(packed), ops.ptr_array(flats),
              ops.ptr_array(outs), None, ops.int_array(n), H, W, ops.stream())
-for _ in range(3): run()
+for _ in range(10): run()
 torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(20): run()
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 20
-print(f"imgs {sum(n)} ms {ms:.4f} TF {sum(n)*13.918e6/ms/1e9:.1f}")
+best = []
+for rep in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): run()
+    e1.record(); torch.cuda.synchronize()
+    best.append(e0.elapsed_time(e1) / 50)
+ms = sorted(best)[2]
+print(f"imgs {sum(n)} ms {ms:.4f} (5 x 50 launches: min {min(best):.4f} max {max(best):.4f}) TF {sum(n)*13.918e6/ms/1e9:.1f}")
 # phase stamps (only in a -DEF_STAMPS build of the library)
 import ctypes as C
 L = _lib.lib()

@@ -66,6 +66,24 @@ __device__ __forceinline__ float relu1(float x) {
   asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
   return r;
 }
+// One butterfly step of a 16-lane (DPP row) reduction on FOUR independent values in four instructions: v_op_dpp reads its
+// first source through the lane permutation, so a step is one instruction instead of v_mov_dpp + v_op (hipcc fuses only
+// some of them).  Four values per statement: a VALU result needs two wait states before a DPP read of it, and inline
+// asm gets no hazard padding - the three other instructions of the group provide them.
+#define EF_DPP4(OP, CTRL, x)                                                                  \
+  asm volatile(OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
+               OP " %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
+               OP " %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
+               OP " %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf"                             \
+               : "+v"((x)[0]), "+v"((x)[1]), "+v"((x)[2]), "+v"((x)[3]))
+#define EF_ROW16_4(OP, x)                     \
+  do {                                        \
+    asm volatile("s_nop 1");                  \
+    EF_DPP4(OP, "quad_perm:[1,0,3,2]", x);    \
+    EF_DPP4(OP, "quad_perm:[2,3,0,1]", x);    \
+    EF_DPP4(OP, "row_half_mirror", x);        \
+    EF_DPP4(OP, "row_mirror", x);             \
+  } while (0)
 __device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d) {
   bf16x4 t = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
   return __builtin_bit_cast(u32x2, t);
@@ -456,14 +474,37 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #endif
         }
       };
-      auto tile1 = [&](int oy, int ox, bool ok, u32x4 (&bf)[6]) {
+      auto ld1one = [&](const unsigned char* base, int s) -> u32x4 {
+        const int off = (s / 3) * 4 * G::W * 6 + (s % 3) * 16;  // compile-time immediate
+#if EF_VAR & 1
+        (void)base; return kconst;
+#else
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(base + off);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(base + off + 8);
+        return u32x4{lo[0], lo[1], hi[0], hi[1]};
+#endif
+      };
+      // one tile: two chains over the same six fragments; the second one refills them in place with the fragments of the
+      // tile after next (that tile uses the same register set), two 8-byte reads per MFMA gap - see conv3
+      auto tile1 = [&](int oy, int ox, bool ok, u32x4 (&bf)[6], const unsigned char* refill, bool do_refill) {
         f32x4 acc0, acc1;
+        __builtin_amdgcn_sched_barrier(0);
         MFMA6_FIRST(acc0, bias1a, wc1a, 0, bf);  // each accumulator chain stays strictly back-to-back (asm MFMAs get no
-        MFMA6_FIRST(acc1, bias1b, wc1b, 0, bf);  // compiler hazard handling: interleaving two chains returned wrong sums)
+        MFMA_FIRST_AW(acc1, wc1b[0], bf[0], bias1b);  // compiler hazard handling: interleaving two chains returned wrong sums)
+#pragma unroll
+        for (int s = 1; s < 6; s++) {
+          MFMA_AW(acc1, wc1b[s], bf[s]);
+          if (do_refill) bf[s - 1] = ld1one(refill, s - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         MFMA_CHAIN_END(acc1);
+        if (do_refill) bf[5] = ld1one(refill, 5);
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("" : "+v"(acc0));           // acc0's readers stay behind the second chain (6 MFMAs: hazard covered)
         if (ok) {
           const int oyi = band * G::BR + oy;  // row inside the image
+          // (ReLU as v_pk_max_i16 on the packed bf16 halves the instruction count and measured 4 % SLOWER: a dependent
+          // conversion -> VOP3P pair per register instead of independent v_max_f32 ahead of the conversions)
           const f32x4 r0 = {relu1(acc0[0]), relu1(acc0[1]), relu1(acc0[2]), relu1(acc0[3])};
           const f32x4 r1 = {relu1(acc1[0]), relu1(acc1[1]), relu1(acc1[2]), relu1(acc1[3])};
           const u32x2 lo = pack4_bf16(r0[0], r0[1], r0[2], r0[3]), hi = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
@@ -481,21 +522,27 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       };
       constexpr int DPT = G::WHOLE ? ((G::IMG_BYTES + 4095) / 4096 + PER1 - 1) / PER1 : 0;  // DMA pieces per conv1 tile
       u32x4 fa[6], fb[6];
-      int oya, oxa, oyb, oxb;
-      bool oka = px1(w, oya, oxa), okb = false;
+      int oya, oxa, oyb, oxb, oyn, oxn;
+      bool oka = px1(w, oya, oxa), okb = px1(min(w + 4, nt1 - 1), oyb, oxb), okn;
       ld1(base1(oya, oxa), fa);
+      ld1(base1(oyb, oxb), fb);
 #pragma unroll
       for (int i = 0; i < PER1; i += 2) {
-        if (w + 4 * (i + 1) < nt1 && i + 1 < PER1) { okb = px1(w + 4 * (i + 1), oyb, oxb); ld1(base1(oyb, oxb), fb); }
 #if !(EF_X & 1)
         if (G::WHOLE && has_next) dma_pieces(nxt, 0, buf ^ 1, i * DPT, (i + 1) * DPT);
 #endif
-        if (w + 4 * i < nt1) tile1(oya, oxa, oka, fa);
-        if (w + 4 * (i + 2) < nt1 && i + 2 < PER1) { oka = px1(w + 4 * (i + 2), oya, oxa); ld1(base1(oya, oxa), fa); }
+        // (a tile beyond the wave's last one is refilled from the last one: unconditional loads, never used)
+        okn = px1(min(w + 4 * (i + 2), nt1 - 1), oyn, oxn);
+        if (w + 4 * i < nt1) tile1(oya, oxa, oka, fa, base1(oyn, oxn), i + 2 < PER1);
+        oka = okn; oya = oyn; oxa = oxn;
 #if !(EF_X & 1)
         if (G::WHOLE && has_next && i + 1 < PER1) dma_pieces(nxt, 0, buf ^ 1, (i + 1) * DPT, (i + 2) * DPT);
 #endif
-        if (w + 4 * (i + 1) < nt1 && i + 1 < PER1) tile1(oyb, oxb, okb, fb);
+        if (i + 1 < PER1) {
+          okn = px1(min(w + 4 * (i + 3), nt1 - 1), oyn, oxn);
+          if (w + 4 * (i + 1) < nt1) tile1(oyb, oxb, okb, fb, base1(oyn, oxn), i + 3 < PER1);
+          okb = okn; oyb = oyn; oxb = oxn;
+        }
       }
       static_assert(!G::WHOLE || PER1 * DPT * 4096 >= G::IMG_BYTES, "every piece of the next image is issued");
       if (band + 1 < G::NB) {
@@ -533,24 +580,52 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       // block every MFMA takes the previous one's result as its C (forwarded); a chain is resumed only after the
       // other chain's 8 MFMAs - far beyond the wait states a non-adjacent dependent MFMA needs (hipcc pads
       // nothing for inline asm).
+      auto ld2one = [&](const unsigned char* base, int s) -> u32x4 {
+#if EF_VAR & 1
+        (void)base; return kconst;
+#else
+        return *reinterpret_cast<const u32x4*>(base + (s >> 2) * G::PITCH1 + (s & 3) * ACT1_STRIDE);
+#endif
+      };
       if (ph < NT2) {
         const unsigned char* bcur = base2(ph);
         ld2(bcur, 0, fa);
+        ld2(bcur, 1, fb);
 #pragma unroll
         for (int t2 = 0; t2 < (NT2 + 1) / 2; t2++) {
           const int mt = ph + 2 * t2;
           if (mt < NT2) {
             f32x4 acc0, acc1;
-            ld2(bcur, 1, fb);
-            MFMA8_FIRST(acc0, bias2a, wc2a, 0, fa);
-            MFMA8_FIRST(acc1, bias2b, wc2b, 0, fa);
-            // next tile's first half, issued as soon as fa[] is free: 16 MFMAs ahead of its first use (the last tile
-            // re-reads its own: a conditional load would push fa[] to scratch)
+            // the second chain over a fragment set refills it in place with the next tile's fragments, one read per MFMA
+            // gap (see conv3); the last tile re-reads its own (a conditional load would push the fragments to scratch)
             bcur = base2(mt + 2 < NT2 ? mt + 2 : mt);
-            ld2(bcur, 0, fa);
-            MFMA8_MORE(acc0, wc2a, 8, fb);
-            MFMA8_MORE(acc1, wc2b, 8, fb);
+            // (with an even tile count every wave's last tile is known at compile time: no refill there - its stale
+            // reads would only delay the next phase's first fragment reads into the same registers)
+            const bool refill = NT2 % 2 != 0 || t2 + 1 < NT2 / 2;
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA8_FIRST(acc0, bias2a, wc2a, 0, fa);
+            MFMA_FIRST_AW(acc1, wc2b[0], fa[0], bias2b);
+#pragma unroll
+            for (int i = 1; i < 8; i++) {
+              MFMA_AW(acc1, wc2b[i], fa[i]);
+              if (refill) fa[i - 1] = ld2one(bcur, i - 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            MFMA_AW(acc0, wc2a[8], fb[0]);
+            if (refill) fa[7] = ld2one(bcur, 7);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 1; i < 8; i++) MFMA_AW(acc0, wc2a[8 + i], fb[i]);
+            MFMA_AW(acc1, wc2b[8], fb[0]);
+#pragma unroll
+            for (int i = 1; i < 8; i++) {
+              MFMA_AW(acc1, wc2b[8 + i], fb[i]);
+              if (refill) fb[i - 1] = ld2one(bcur, 8 + i - 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
             MFMA_CHAIN_END(acc1);             // (acc0's last MFMA is 8 MFMAs older: covered)
+            if (refill) fb[7] = ld2one(bcur, 15);
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("" : "+v"(acc0));
             // (store addresses re-derived behind an opaque zero: hoisted out of the image loop they are spilled, and a
             // scratch reload inside the loop waits on vmcnt, i.e. on the next image's DMA)
@@ -583,7 +658,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     // ------------------------------------------------ conv3: 3x3 stride 1, 64 -> 64 + soft-argmax in registers
     {
       constexpr int NT3 = (G::NPX3 + 15) >> 4;
-      const float inv_t = 1.0f / temp;
+      const float inv_t = (1.0f / temp) * 1.44269504088896f;  // log2(e) folded in: the soft-argmax exponentials are exp2
       f32x4 v3[NT3];
       float fx[NT3], fy[NT3];
       auto base3 = [&](int mt, int& ox, int& oy) {
@@ -602,25 +677,48 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #endif
         }
       };
+      // Fragment reads INSIDE the MFMA chain: a ds_read_b128 issued while an MFMA is executing is free, the same read
+      // issued between two chains costs the lone wave of a SIMD ~16 clk of issue (scratch/micro/mfma16_il: 16.6 vs
+      // 24.4 clk per MFMA at conv2's ratio).  So a tile's chain refills its own fragment registers, in place, with the NEXT
+      // tile's data: fragment i is overwritten right after MFMA i + 1 has been issued (the chain is dependent, so MFMA
+      // i has completed by then), one read per MFMA gap, pinned by scheduling barriers; hipcc still counts the waits.
       u32x4 fa[9], fb[9];
       int ox, oy;
       const unsigned char* bcur = base3(0, ox, oy);
       ld3(bcur, 0, fa);
+      ld3(bcur, 1, fb);
+      auto ld3one = [&](const unsigned char* base, int s) -> u32x4 {
+        const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
+#if EF_VAR & 1
+        (void)base; return kconst;
+#else
+        return *reinterpret_cast<const u32x4*>(base + ky * G::PITCH2 + kx * G::PX2 + 64 * (s & 1));
+#endif
+      };
 #pragma unroll
       for (int mt = 0; mt < NT3; mt++) {
         f32x4 acc;
         fx[mt] = (float)ox; fy[mt] = (float)oy;
-        ld3(bcur, 1, fb);
-        MFMA9_FIRST(acc, bias3, wc3, 0, fa);
-        if (mt + 1 < NT3) { bcur = base3(mt + 1, ox, oy); ld3(bcur, 0, fa); }
-        MFMA9_MORE(acc, wc3, 9, fb);
+        const bool more = mt + 1 < NT3;
+        if (more) bcur = base3(mt + 1, ox, oy);
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_FIRST_AW(acc, wc3[0], fa[0], bias3);
+#pragma unroll
+        for (int i = 1; i < 18; i++) {
+          if (i < 9) MFMA_AW(acc, wc3[i], fa[i]); else MFMA_AW(acc, wc3[i], fb[i - 9]);
+          if (more) { if (i - 1 < 9) fa[i - 1] = ld3one(bcur, i - 1); else fb[i - 10] = ld3one(bcur, i - 1); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
         MFMA_CHAIN_END(acc);
+        if (more) fb[8] = ld3one(bcur, 17);
+        __builtin_amdgcn_sched_barrier(0);
         const bool ok = mt * 16 + r16 < npx3;
         if (P.act && ok)
           *reinterpret_cast<f32x4*>(P.act + P.a_y3 + ((long)cur * npx3 + mt * 16 + r16) * 64 + 16 * w + 4 * g) =
               f32x4{relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3])};
 #pragma unroll
-        for (int q = 0; q < 4; q++) v3[mt][q] = ok ? relu1(acc[q]) * inv_t : -INFINITY;
+        for (int q = 0; q < 4; q++)  // (only the last tile has padding lanes)
+          v3[mt][q] = (mt * 16 + 15 < G::NPX3 || ok) ? relu1(acc[q]) * inv_t : -INFINITY;
       }
       STAMP(6);  // conv3 MFMA part
       // pass 1: per-channel max over the image (tiles in registers, then the 16 pixel lanes)
@@ -630,24 +728,26 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         float m = v3[0][q];
 #pragma unroll
         for (int mt = 1; mt < NT3; mt++) m = fmaxf(m, v3[mt][q]);
-        mx[q] = row16_max(m); se[q] = 0.f; sx[q] = 0.f; sy[q] = 0.f;
+        mx[q] = m; se[q] = 0.f; sx[q] = 0.f; sy[q] = 0.f;
       }
-      // pass 2: exp and the three sums (exp(-inf) = 0 masks the padded pixels)
+      EF_ROW16_4("v_max_f32_dpp", mx);
+      // pass 2: exp and the three sums (exp2(-inf) = 0 masks the padded pixels)
 #pragma unroll
       for (int mt = 0; mt < NT3; mt++)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const float e = __expf(v3[mt][q] - mx[q]);
+          const float e = __builtin_amdgcn_exp2f(v3[mt][q] - mx[q]);
           se[q] += e; sx[q] += e * fx[mt]; sy[q] += e * fy[mt];
         }
-#pragma unroll
-      for (int q = 0; q < 4; q++) { se[q] = row16_sum(se[q]); sx[q] = row16_sum(sx[q]); sy[q] = row16_sum(sy[q]); }
+      EF_ROW16_4("v_add_f32_dpp", se);
+      EF_ROW16_4("v_add_f32_dpp", sx);
+      EF_ROW16_4("v_add_f32_dpp", sy);
       if (r16 == 0) {
         // features interleaved [x_c, y_c]; channels 16 w + 4 g + q
         float fx_[4], fy_[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const float r = 1.0f / se[q];
+          const float r = __builtin_amdgcn_rcpf(se[q]);
           fx_[q] = sx[q] * r; fy_[q] = sy[q] * r;
         }
         // the lane's 8 features are adjacent: one 16-byte LDS store (and two 16-byte global ones), not eight 2-byte ones
@@ -672,7 +772,18 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int s = 0; s < 4; s++) wf1[j][s] = P.wpk[WP_F1 + ((4 * w + j) * 4 + s) * 64 + l];
-      __syncthreads();  // soft-argmax features of the whole chunk are in LDS
+      // ... and so do both layers' biases and fc2's fragments: loaded where they were used, each one exposed an L2 round
+      // trip on the chunk's critical path (the tail took ~6 000 clk per chunk for 24 MFMAs)
+      f32x4 bf1[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) bf1[j] = *reinterpret_cast<const f32x4*>(P.params + po[8] + 16 * (4 * w + j) + 4 * g);
+      u32x4 wf2[8];
+#pragma unroll
+      for (int s = 0; s < 8; s++) wf2[s] = P.wpk[WP_F2 + ((w & 1) * 8 + s) * 64 + l];
+      const f32x4 bf2 = *reinterpret_cast<const f32x4*>(P.params + po[10] + 16 * (w & 1) + 4 * g);
+      // (LDS-only barriers: __syncthreads() also drains vmcnt, i.e. waits for every global store still in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // soft-argmax features of the whole chunk are in LDS
       const int n_in_chunk = slot + 1;
       {
         const unsigned char* base = sa + min(r16, EF_CHUNK - 1) * SA_STRIDE + 16 * g;
@@ -680,8 +791,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         for (int j = 0; j < 4; j++) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
           const u32x4 (&wf)[4] = wf1[j];
-          const float* bb = P.params + po[8] + 16 * (4 * w + j) + 4 * g;
-          const float c0 = bb[0], c1 = bb[1], c2 = bb[2], c3 = bb[3];
+          const float c0 = bf1[j][0], c1 = bf1[j][1], c2 = bf1[j][2], c3 = bf1[j][3];
 #pragma unroll
           for (int s = 0; s < 4; s++)
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wf[s]), as_bf16x8(*reinterpret_cast<const u32x4*>(base + 64 * s)), acc, 0, 0, 0);
@@ -693,18 +803,15 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
                                       16 * (4 * w + j) + 4 * g) = r;
         }
       }
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
       if (w < 2) {
         const unsigned char* base = h1 + min(r16, EF_CHUNK - 1) * H1_STRIDE + 16 * g;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        u32x4 wf[8];
-#pragma unroll
-        for (int s = 0; s < 8; s++) wf[s] = P.wpk[WP_F2 + (w * 8 + s) * 64 + l];
-        const float* bb = P.params + po[10] + 16 * w + 4 * g;
-        const float c0 = bb[0], c1 = bb[1], c2 = bb[2], c3 = bb[3];
+        const float c0 = bf2[0], c1 = bf2[1], c2 = bf2[2], c3 = bf2[3];
 #pragma unroll
         for (int s = 0; s < 8; s++)
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wf[s]), as_bf16x8(*reinterpret_cast<const u32x4*>(base + 64 * s)), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wf2[s]), as_bf16x8(*reinterpret_cast<const u32x4*>(base + 64 * s)), acc, 0, 0, 0);
         if (r16 < n_in_chunk) {
           const long img_of_slot = worker + (long)(it - slot + r16) * nworkers;
           float* o = P.out + img_of_slot * 32 + 16 * w + 4 * g;
