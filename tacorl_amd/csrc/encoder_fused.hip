@@ -484,25 +484,24 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         return u32x4{lo[0], lo[1], hi[0], hi[1]};
 #endif
       };
-      // one tile: two chains over the same six fragments; the second one refills them in place with the fragments of the
-      // tile after next (that tile uses the same register set), two 8-byte reads per MFMA gap - see conv3
-      auto tile1 = [&](int oy, int ox, bool ok, u32x4 (&bf)[6], const unsigned char* refill, bool do_refill) {
-        f32x4 acc0, acc1;
-        __builtin_amdgcn_sched_barrier(0);
-        MFMA6_FIRST(acc0, bias1a, wc1a, 0, bf);  // each accumulator chain stays strictly back-to-back (asm MFMAs get no
-        MFMA_FIRST_AW(acc1, wc1b[0], bf[0], bias1b);  // compiler hazard handling: interleaving two chains returned wrong sums)
+      // Per-wave tiles i = 0 .. PER1 - 1 (tile w + 4 i); tile i lives in fragment set i & 1.  A tile is two chains over
+      // the same six fragments; the second chain refills them in place with the fragments of tile i + 2 (two 8-byte
+      // reads per MFMA gap - see conv3), the first chain carries the tile's share of the next image's DMA pieces (after
+      // its 2nd and 4th MFMA: a piece stands ~100 clk at issue, in the shadow of a running MFMA part of that is hidden)
+      // and, for whole-image geometries, the EPILOGUE OF THE PREVIOUS TILE after its 5th MFMA: that accumulator pair is
+      // long past its read-after-MFMA hazard there, and the ~25 VALU/LDS instructions sit in MFMA shadows.
+      constexpr int DPT = G::WHOLE ? ((G::IMG_BYTES + 4095) / 4096 + PER1 - 1) / PER1 : 0;  // DMA pieces per conv1 tile
+      static_assert(DPT <= 2, "a tile's first chain places at most two DMA pieces");
+      constexpr bool OV = G::WHOLE;  // (band geometries: a tile's existence is a run-time fact for every i - plain order)
+      f32x4 A0[PER1], A1[PER1];
+      int OY[PER1], OX[PER1];
+      bool OK[PER1];
 #pragma unroll
-        for (int s = 1; s < 6; s++) {
-          MFMA_AW(acc1, wc1b[s], bf[s]);
-          if (do_refill) bf[s - 1] = ld1one(refill, s - 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        MFMA_CHAIN_END(acc1);
-        if (do_refill) bf[5] = ld1one(refill, 5);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" : "+v"(acc0));           // acc0's readers stay behind the second chain (6 MFMAs: hazard covered)
-        if (ok) {
-          const int oyi = band * G::BR + oy;  // row inside the image
+      for (int i = 0; i < PER1; i++) OK[i] = px1(min(w + 4 * i, nt1 - 1), OY[i], OX[i]);  // (clamped: a tile beyond the last)
+      auto epi1 = [&](int i) {
+        if (OK[i]) {
+          const f32x4 acc0 = A0[i], acc1 = A1[i];
+          const int oyi = band * G::BR + OY[i], ox = OX[i];  // row inside the image
           // (ReLU as v_pk_max_i16 on the packed bf16 halves the instruction count and measured 4 % SLOWER: a dependent
           // conversion -> VOP3P pair per register instead of independent v_max_f32 ahead of the conversions)
           const f32x4 r0 = {relu1(acc0[0]), relu1(acc0[1]), relu1(acc0[2]), relu1(acc0[3])};
@@ -520,28 +519,57 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
             *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(P.act) + ((long)cur * npx1 + oyi * a.OW1 + ox) * 32 + 8 * g) = pk;
         }
       };
-      constexpr int DPT = G::WHOLE ? ((G::IMG_BYTES + 4095) / 4096 + PER1 - 1) / PER1 : 0;  // DMA pieces per conv1 tile
-      u32x4 fa[6], fb[6];
-      int oya, oxa, oyb, oxb, oyn, oxn;
-      bool oka = px1(w, oya, oxa), okb = px1(min(w + 4, nt1 - 1), oyb, oxb), okn;
-      ld1(base1(oya, oxa), fa);
-      ld1(base1(oyb, oxb), fb);
-#pragma unroll
-      for (int i = 0; i < PER1; i += 2) {
+      auto dma_of_tile = [&](int i) {
 #if !(EF_X & 1)
         if (G::WHOLE && has_next) dma_pieces(nxt, 0, buf ^ 1, i * DPT, (i + 1) * DPT);
 #endif
-        // (a tile beyond the wave's last one is refilled from the last one: unconditional loads, never used)
-        okn = px1(min(w + 4 * (i + 2), nt1 - 1), oyn, oxn);
-        if (w + 4 * i < nt1) tile1(oya, oxa, oka, fa, base1(oyn, oxn), i + 2 < PER1);
-        oka = okn; oya = oyn; oxa = oxn;
+      };
+      // the two chains of tile i; prev >= 0: that tile's epilogue rides in the first chain
+      auto chains1 = [&](int i, u32x4 (&bf)[6], int prev) {
+        const bool do_refill = i + 2 < PER1;
+        const unsigned char* refill = base1(OY[do_refill ? i + 2 : i], OX[do_refill ? i + 2 : i]);
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_FIRST_AW(A0[i], wc1a[0], bf[0], bias1a);  // each accumulator chain stays strictly back-to-back (asm MFMAs get
+#pragma unroll                                           // no compiler hazard handling: interleaving two chains returned wrong sums)
+        for (int s = 1; s < 6; s++) {
+          MFMA_AW(A0[i], wc1a[s], bf[s]);
 #if !(EF_X & 1)
-        if (G::WHOLE && has_next && i + 1 < PER1) dma_pieces(nxt, 0, buf ^ 1, (i + 1) * DPT, (i + 2) * DPT);
+          if (G::WHOLE && has_next && (s == 1 || s == 3) && (s >> 1) < DPT) dma_pieces(nxt, 0, buf ^ 1, i * DPT + (s >> 1), i * DPT + (s >> 1) + 1);
 #endif
-        if (i + 1 < PER1) {
-          okn = px1(min(w + 4 * (i + 3), nt1 - 1), oyn, oxn);
-          if (w + 4 * (i + 1) < nt1) tile1(oyb, oxb, okb, fb, base1(oyn, oxn), i + 3 < PER1);
-          okb = okn; oyb = oyn; oxb = oxn;
+          if (s == 4 && prev >= 0) {
+            asm volatile("" : "+v"(A0[prev]), "+v"(A1[prev]));
+            epi1(prev);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        MFMA_FIRST_AW(A1[i], wc1b[0], bf[0], bias1b);
+#pragma unroll
+        for (int s = 1; s < 6; s++) {
+          MFMA_AW(A1[i], wc1b[s], bf[s]);
+          if (do_refill) bf[s - 1] = ld1one(refill, s - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (do_refill) bf[5] = ld1one(refill, 5);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto finish1 = [&](int i) {  // a tile whose epilogue no later chain carries
+        MFMA_CHAIN_END(A1[i]);
+        asm volatile("" : "+v"(A0[i]));  // (its first chain ended six MFMAs earlier)
+        epi1(i);
+      };
+      u32x4 fa[6], fb[6];
+      ld1(base1(OY[0], OX[0]), fa);
+      if (PER1 > 1) ld1(base1(OY[1], OX[1]), fb);
+#pragma unroll
+      for (int i = 0; i < PER1; i++) {
+        // every wave has tiles 0 .. PER1 - 2 of a whole image; the last one (and any tile of a band) is a run-time fact
+        const bool exists = (OV && i + 1 < PER1) || w + 4 * i < nt1;
+        if (exists) {
+          if (i & 1) chains1(i, fb, OV && i > 0 ? i - 1 : -1); else chains1(i, fa, OV && i > 0 ? i - 1 : -1);
+          if (!OV || i + 1 == PER1) finish1(i);
+        } else {
+          dma_of_tile(i);
+          if (OV && i > 0) finish1(i - 1);  // (whole image, no last tile in this wave: its predecessor is still open)
         }
       }
       static_assert(!G::WHOLE || PER1 * DPT * 4096 >= G::IMG_BYTES, "every piece of the next image is issued");
@@ -587,15 +615,44 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         return *reinterpret_cast<const u32x4*>(base + (s >> 2) * G::PITCH1 + (s & 3) * ACT1_STRIDE);
 #endif
       };
+      constexpr int PER2 = (NT2 + 1) / 2;  // tiles per wave: ph, ph + 2, ...; with an odd count the last one only for ph == 0
+      f32x4 C0[PER2], C1[PER2];
+      auto epi2 = [&](int t2) {
+        const f32x4 acc0 = C0[t2], acc1 = C1[t2];
+        // (store addresses re-derived behind an opaque zero: hoisted out of the image loop they are spilled, and a
+        // scratch reload inside the loop waits on vmcnt, i.e. on the next image's DMA)
+        int oz;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+        const int pm = (ph + 2 * t2) * 16 + r16 + oz;
+        if (pm < npx2) {
+          const f32x4 r0 = {relu1(acc0[0]), relu1(acc0[1]), relu1(acc0[2]), relu1(acc0[3])};
+          const f32x4 r1 = {relu1(acc1[0]), relu1(acc1[1]), relu1(acc1[2]), relu1(acc1[3])};
+          const u32x2 lo = pack4_bf16(r0[0], r0[1], r0[2], r0[3]), hi = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
+          const u32x4 pk = {lo[0], lo[1], hi[0], hi[1]};
+          const int oy2 = pm / a.OW2, ox2 = pm - oy2 * a.OW2;
+          *reinterpret_cast<u32x4*>(act2 + oy2 * G::PITCH2 + ox2 * G::PX2 + (32 * cg + 8 * g) * 2) = pk;
+          if (P.act) {
+            // bf16 at the start of y2's slot; wave-uniform base + 32-bit lane offset (a 64-bit per-lane address would be
+            // hoisted and spilled)
+            __bf16* y = reinterpret_cast<__bf16*>(P.act + P.a_y2) + (long)cur * (npx2 * 64) + (unsigned)(pm * 64 + 32 * cg + 8 * g);
+            *reinterpret_cast<u32x4*>(y) = pk;
+          }
+        }
+      };
+      auto finish2 = [&](int t2) {
+        MFMA_CHAIN_END(C1[t2]);  // (acc0's last MFMA is 8 MFMAs older: covered)
+        asm volatile("" : "+v"(C0[t2]));
+        epi2(t2);
+      };
       if (ph < NT2) {
         const unsigned char* bcur = base2(ph);
         ld2(bcur, 0, fa);
         ld2(bcur, 1, fb);
 #pragma unroll
-        for (int t2 = 0; t2 < (NT2 + 1) / 2; t2++) {
+        for (int t2 = 0; t2 < PER2; t2++) {
           const int mt = ph + 2 * t2;
-          if (mt < NT2) {
-            f32x4 acc0, acc1;
+          const bool exists = t2 + 1 < PER2 || NT2 % 2 == 0 || mt < NT2;  // (only an odd count's last tile is a run-time fact)
+          if (exists) {
             // the second chain over a fragment set refills it in place with the next tile's fragments, one read per MFMA
             // gap (see conv3); the last tile re-reads its own (a conditional load would push the fragments to scratch)
             bcur = base2(mt + 2 < NT2 ? mt + 2 : mt);
@@ -603,49 +660,41 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
             // reads would only delay the next phase's first fragment reads into the same registers)
             const bool refill = NT2 % 2 != 0 || t2 + 1 < NT2 / 2;
             __builtin_amdgcn_sched_barrier(0);
-            MFMA8_FIRST(acc0, bias2a, wc2a, 0, fa);
-            MFMA_FIRST_AW(acc1, wc2b[0], fa[0], bias2b);
+            // first block: the previous tile's epilogue rides behind its fifth MFMA (as in conv1)
+            MFMA_FIRST_AW(C0[t2], wc2a[0], fa[0], bias2a);
 #pragma unroll
             for (int i = 1; i < 8; i++) {
-              MFMA_AW(acc1, wc2b[i], fa[i]);
+              MFMA_AW(C0[t2], wc2a[i], fa[i]);
+              if (i == 4 && t2 > 0) {
+                asm volatile("" : "+v"(C0[t2 - 1]), "+v"(C1[t2 - 1]));
+                epi2(t2 - 1);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            MFMA_FIRST_AW(C1[t2], wc2b[0], fa[0], bias2b);
+#pragma unroll
+            for (int i = 1; i < 8; i++) {
+              MFMA_AW(C1[t2], wc2b[i], fa[i]);
               if (refill) fa[i - 1] = ld2one(bcur, i - 1);
               __builtin_amdgcn_sched_barrier(0);
             }
-            MFMA_AW(acc0, wc2a[8], fb[0]);
+            MFMA_AW(C0[t2], wc2a[8], fb[0]);
             if (refill) fa[7] = ld2one(bcur, 7);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 1; i < 8; i++) MFMA_AW(acc0, wc2a[8 + i], fb[i]);
-            MFMA_AW(acc1, wc2b[8], fb[0]);
+            for (int i = 1; i < 8; i++) MFMA_AW(C0[t2], wc2a[8 + i], fb[i]);
+            MFMA_AW(C1[t2], wc2b[8], fb[0]);
 #pragma unroll
             for (int i = 1; i < 8; i++) {
-              MFMA_AW(acc1, wc2b[8 + i], fb[i]);
+              MFMA_AW(C1[t2], wc2b[8 + i], fb[i]);
               if (refill) fb[i - 1] = ld2one(bcur, 8 + i - 1);
               __builtin_amdgcn_sched_barrier(0);
             }
-            MFMA_CHAIN_END(acc1);             // (acc0's last MFMA is 8 MFMAs older: covered)
             if (refill) fb[7] = ld2one(bcur, 15);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" : "+v"(acc0));
-            // (store addresses re-derived behind an opaque zero: hoisted out of the image loop they are spilled, and a
-            // scratch reload inside the loop waits on vmcnt, i.e. on the next image's DMA)
-            int oz;
-            asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
-            const int pm = mt * 16 + r16 + oz;
-            if (pm < npx2) {
-              const f32x4 r0 = {relu1(acc0[0]), relu1(acc0[1]), relu1(acc0[2]), relu1(acc0[3])};
-              const f32x4 r1 = {relu1(acc1[0]), relu1(acc1[1]), relu1(acc1[2]), relu1(acc1[3])};
-              const u32x2 lo = pack4_bf16(r0[0], r0[1], r0[2], r0[3]), hi = pack4_bf16(r1[0], r1[1], r1[2], r1[3]);
-              const u32x4 pk = {lo[0], lo[1], hi[0], hi[1]};
-              const int oy2 = pm / a.OW2, ox2 = pm - oy2 * a.OW2;
-              *reinterpret_cast<u32x4*>(act2 + oy2 * G::PITCH2 + ox2 * G::PX2 + (32 * cg + 8 * g) * 2) = pk;
-              if (P.act) {
-                // bf16 at the start of y2's slot; wave-uniform base + 32-bit lane offset (a 64-bit per-lane address would be
-                // hoisted and spilled)
-                __bf16* y = reinterpret_cast<__bf16*>(P.act + P.a_y2) + (long)cur * (npx2 * 64) + (unsigned)(pm * 64 + 32 * cg + 8 * g);
-                *reinterpret_cast<u32x4*>(y) = pk;
-              }
-            }
+            if (t2 + 1 == PER2) finish2(t2);
+          } else if (t2 > 0) {
+            finish2(t2 - 1);  // (odd tile count, ph == 1: the predecessor is still open)
           }
         }
       }
@@ -695,23 +744,12 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         return *reinterpret_cast<const u32x4*>(base + ky * G::PITCH2 + kx * G::PX2 + 64 * (s & 1));
 #endif
       };
-#pragma unroll
-      for (int mt = 0; mt < NT3; mt++) {
-        f32x4 acc;
-        fx[mt] = (float)ox; fy[mt] = (float)oy;
-        const bool more = mt + 1 < NT3;
-        if (more) bcur = base3(mt + 1, ox, oy);
-        __builtin_amdgcn_sched_barrier(0);
-        MFMA_FIRST_AW(acc, wc3[0], fa[0], bias3);
-#pragma unroll
-        for (int i = 1; i < 18; i++) {
-          if (i < 9) MFMA_AW(acc, wc3[i], fa[i]); else MFMA_AW(acc, wc3[i], fb[i - 9]);
-          if (more) { if (i - 1 < 9) fa[i - 1] = ld3one(bcur, i - 1); else fb[i - 10] = ld3one(bcur, i - 1); }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        MFMA_CHAIN_END(acc);
-        if (more) fb[8] = ld3one(bcur, 17);
-        __builtin_amdgcn_sched_barrier(0);
+      // a tile's epilogue (ReLU, temperature scale, the saved-activation store) runs inside the NEXT tile's chain, after its
+      // fifth MFMA: the finished accumulator is long past its read-after-MFMA hazard there (no s_nop 11), and the VALU
+      // work sits in MFMA shadows instead of between two chains
+      f32x4 accs[NT3];
+      auto epi3 = [&](int mt) {
+        const f32x4 acc = accs[mt];
         const bool ok = mt * 16 + r16 < npx3;
         if (P.act && ok)
           *reinterpret_cast<f32x4*>(P.act + P.a_y3 + ((long)cur * npx3 + mt * 16 + r16) * 64 + 16 * w + 4 * g) =
@@ -719,7 +757,26 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #pragma unroll
         for (int q = 0; q < 4; q++)  // (only the last tile has padding lanes)
           v3[mt][q] = (mt * 16 + 15 < G::NPX3 || ok) ? relu1(acc[q]) * inv_t : -INFINITY;
+      };
+#pragma unroll
+      for (int mt = 0; mt < NT3; mt++) {
+        fx[mt] = (float)ox; fy[mt] = (float)oy;
+        const bool more = mt + 1 < NT3;
+        if (more) bcur = base3(mt + 1, ox, oy);
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_FIRST_AW(accs[mt], wc3[0], fa[0], bias3);
+#pragma unroll
+        for (int i = 1; i < 18; i++) {
+          if (i < 9) MFMA_AW(accs[mt], wc3[i], fa[i]); else MFMA_AW(accs[mt], wc3[i], fb[i - 9]);
+          if (more) { if (i - 1 < 9) fa[i - 1] = ld3one(bcur, i - 1); else fb[i - 10] = ld3one(bcur, i - 1); }
+          if (i == 4 && mt > 0) { asm volatile("" : "+v"(accs[mt - 1])); epi3(mt - 1); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) fb[8] = ld3one(bcur, 17);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      MFMA_CHAIN_END(accs[NT3 - 1]);
+      epi3(NT3 - 1);
       STAMP(6);  // conv3 MFMA part
       // pass 1: per-channel max over the image (tiles in registers, then the 16 pixel lanes)
       float mx[4], se[4], sx[4], sy[4];
