@@ -71,7 +71,7 @@ def build_module(dev, compute, T, world, ad_every=1):
     return mod
 
 
-def time_encoder_fwd(mod, B, H, W, iters=20):
+def time_encoder_fwd(mod, B, H, W, iters=100):
     """HIP-event timing of the step's encoder-forward launch on the stream it runs on (torch's current
     stream): ONE encoder_fused_kernel launch over all 27*B encoder images of the step (frozen LMP B*T
     frames, actor/q1/q2 over [obs;goal], actor(next) and both targets) - the roofline kernel."""
@@ -80,9 +80,8 @@ def time_encoder_fwd(mod, B, H, W, iters=20):
     fn = e.encode_fused_only if fused else e._encode_all
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(3):
+    for _ in range(10):
         n_img = fn()
-    torch.cuda.synchronize()
     ev0.record()
     for _ in range(iters):
         fn()

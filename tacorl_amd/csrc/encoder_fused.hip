@@ -25,7 +25,7 @@
 #include "../../include/tacorl_hip.h"
 #include "common.h"
 
-#define EF_CHUNK 8      // images per FC batch
+#define EF_CHUNK 16     // images per FC batch = the 16 columns of the FC MFMA tiles (8 left half of every tile empty)
 #define EF_MAXCH 12     // 16-byte chunks per thread for one image (<= 49 152 B: up to ~90x90x3 bf16)
 #define EF_MAXP 16
 
