@@ -519,6 +519,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
             *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(P.act) + ((long)cur * npx1 + oyi * a.OW1 + ox) * 32 + 8 * g) = pk;
         }
       };
+      u32x4 fa[6], fb[6];
       auto dma_of_tile = [&](int i) {
 #if !(EF_X & 1)
         if (G::WHOLE && has_next) dma_pieces(nxt, 0, buf ^ 1, i * DPT, (i + 1) * DPT);
@@ -540,6 +541,13 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
             asm volatile("" : "+v"(A0[prev]), "+v"(A1[prev]));
             epi1(prev);
           }
+          if (i == 0 && PER1 > 1) {  // fragment set b = tile 1, six fragments over the five gaps
+            const unsigned char* b1 = base1(OY[1], OX[1]);
+            if (s == 1) fb[0] = ld1one(b1, 0);
+            if (s == 2) { fb[1] = ld1one(b1, 1); fb[2] = ld1one(b1, 2); }
+            if (s == 3) fb[3] = ld1one(b1, 3);
+            if (s == 4) { fb[4] = ld1one(b1, 4); fb[5] = ld1one(b1, 5); }
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         MFMA_FIRST_AW(A1[i], wc1b[0], bf[0], bias1b);
@@ -557,9 +565,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         asm volatile("" : "+v"(A0[i]));  // (its first chain ended six MFMAs earlier)
         epi1(i);
       };
-      u32x4 fa[6], fb[6];
-      ld1(base1(OY[0], OX[0]), fa);
-      if (PER1 > 1) ld1(base1(OY[1], OX[1]), fb);
+      ld1(base1(OY[0], OX[0]), fa);  // (tile 1's fragments arrive in the gaps of tile 0's first chain)
 #pragma unroll
       for (int i = 0; i < PER1; i++) {
         // every wave has tiles 0 .. PER1 - 2 of a whole image; the last one (and any tile of a band) is a run-time fact
@@ -646,8 +652,8 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       };
       if (ph < NT2) {
         const unsigned char* bcur = base2(ph);
-        ld2(bcur, 0, fa);
-        ld2(bcur, 1, fb);
+        const unsigned char* const bfirst = bcur;
+        ld2(bcur, 0, fa);  // (the first tile's second half arrives in the gaps of its first block)
 #pragma unroll
         for (int t2 = 0; t2 < PER2; t2++) {
           const int mt = ph + 2 * t2;
@@ -669,8 +675,10 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
                 asm volatile("" : "+v"(C0[t2 - 1]), "+v"(C1[t2 - 1]));
                 epi2(t2 - 1);
               }
+              if (t2 == 0) fb[i - 1] = ld2one(bfirst, 8 + i - 1);
               __builtin_amdgcn_sched_barrier(0);
             }
+            if (t2 == 0) fb[7] = ld2one(bfirst, 15);
             MFMA_FIRST_AW(C1[t2], wc2b[0], fa[0], bias2b);
 #pragma unroll
             for (int i = 1; i < 8; i++) {
@@ -700,7 +708,13 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       }
     }
     STAMP(4);  // conv2
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // Whole-image geometries without saved activations: the next image's DMA pieces (issued during conv1, thousands of
+    // clocks ago) are waited for HERE, so that this barrier also publishes "the next image has landed" and the
+    // end-of-image barrier can go - the waves then absorb their skew (fc2 runs on two of them) instead of meeting a
+    // fourth time per image.  With saved activations the wait would also cover conv2's global stores: old scheme there.
+    const bool early_land = G::WHOLE && P.act == nullptr;
+    if (early_land) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     STAMP(5);  // barrier after conv2
 
@@ -734,8 +748,8 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       u32x4 fa[9], fb[9];
       int ox, oy;
       const unsigned char* bcur = base3(0, ox, oy);
-      ld3(bcur, 0, fa);
-      ld3(bcur, 1, fb);
+      const unsigned char* const bfirst = bcur;
+      ld3(bcur, 0, fa);  // (only the first half in a burst: the first tile's chain fetches its own second half in its gaps)
       auto ld3one = [&](const unsigned char* base, int s) -> u32x4 {
         const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
 #if EF_VAR & 1
@@ -768,6 +782,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #pragma unroll
         for (int i = 1; i < 18; i++) {
           if (i < 9) MFMA_AW(accs[mt], wc3[i], fa[i]); else MFMA_AW(accs[mt], wc3[i], fb[i - 9]);
+          if (mt == 0 && i <= 9) fb[i - 1] = ld3one(bfirst, 9 + i - 1);
           if (more) { if (i - 1 < 9) fa[i - 1] = ld3one(bcur, i - 1); else fb[i - 10] = ld3one(bcur, i - 1); }
           if (i == 4 && mt > 0) { asm volatile("" : "+v"(accs[mt - 1])); epi3(mt - 1); }
           __builtin_amdgcn_sched_barrier(0);
@@ -879,8 +894,10 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     }
     STAMP(8);  // FC tail (every 8th image)
     if (!has_next) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next image has landed
-    __syncthreads();                                  // ... and everyone's; sa/h1 free for the next chunk
+    if (!early_land) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next image has landed
+      __syncthreads();                                  // ... and everyone's
+    }
     STAMP(9);  // next image landed + end-of-image barrier
     cur = nxt; it++; buf ^= 1;
   }
