@@ -4,9 +4,11 @@ from tacorl_amd import _lib, blocks, ops
 if os.environ.get("TACORL_SCRATCH_LIB"): _lib.LIB_PATH = os.environ["TACORL_SCRATCH_LIB"]
 dev = torch.device('cuda:0')
 H = W = 84
-n = [int(x) for x in (sys.argv[1:] or ["4096", "256", "512", "512"])]
-flats, imgs, outs, packed = [], [], [], []
-for k in n:
+spec = sys.argv[1:] or ["4096", "256", "512", "512"]   # "512a" = that problem also saves its activations (training problems)
+n = [int(x.rstrip("a")) for x in spec]
+flats, imgs, outs, packed, acts = [], [], [], [], []
+for k, sp in zip(n, spec):
+    acts.append(torch.zeros(ops.encoder_act_layout(k, H, W)[1], device=dev) if sp.endswith("a") else None)
     flat = torch.randn(blocks.encoder_size(), device=dev) * 0.05
     flats.append(flat)
     imgs.append((torch.rand(k, H, W, 3, device=dev) * 2 - 1).to(torch.bfloat16))
@@ -15,7 +17,7 @@ for k in n:
 ops.call("tacorl_encoder_pack_weights", len(n), ops.ptr_array(flats), ops.ptr_array(packed), ops.stream())
 def run():
     ops.call("tacorl_encoder_fwd_fused", len(n), ops.ptr_array(imgs), ops.ptr_array(packed), ops.ptr_array(flats),
-             ops.ptr_array(outs), None, ops.int_array(n), H, W, ops.stream())
+             ops.ptr_array(outs), ops.ptr_array(acts) if any(a is not None for a in acts) else None, ops.int_array(n), H, W, ops.stream())
 for _ in range(10): run()
 torch.cuda.synchronize()
 best = []
@@ -43,3 +45,14 @@ if hasattr(L, "tacorl_ef_stamps_read"):
         print("fine stamps (conv1 tiles 16.., conv2 [blocks12, blocks34, epilogue] x tile 24..):")
         print("  conv1", [buf[k] for k in range(16, 24)])
         print("  conv2", [buf[k] for k in range(24, 33)])
+
+if hasattr(L, "tacorl_ef_blk_read"):
+    blk = (C.c_ulonglong * 512)()
+    run(); torch.cuda.synchronize()
+    L.tacorl_ef_blk_read(blk)
+    import collections
+    by = collections.defaultdict(list)
+    for b in range(256):
+        if blk[256 + b]: by[int(blk[256 + b])].append(int(blk[b]))
+    print("workgroup clocks by images served:", {k: (len(v), min(v), sum(v) // len(v), max(v)) for k, v in sorted(by.items())}, "(count, min, mean, max)")
+    print("critical workgroup:", max(int(blk[b]) for b in range(256)), "clk; mean", sum(int(blk[b]) for b in range(256)) // 256)

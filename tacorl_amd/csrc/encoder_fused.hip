@@ -28,6 +28,11 @@
 #define EF_CHUNK 16     // images per FC batch = the 16 columns of the FC MFMA tiles (8 left half of every tile empty)
 #define EF_MAXCH 12     // 16-byte chunks per thread for one image (<= 49 152 B: up to ~90x90x3 bf16)
 #define EF_MAXP 16
+#ifndef EF_ACT_COST
+#define EF_ACT_COST 80  // cost of an image whose activations are also stored, in 1/64 of a plain image: 12.5 k vs 9.8 k clk
+                        // (49 KB of stores through a ~14 B/clk per-CU store path; per-workgroup clocks of a -DEF_BLKCLK build,
+                        // scratch/run_fused.py: critical workgroup 335 k clk at 64, 313 k at 72, 292 k at 80, 295 k at 84; mean 279 k)
+#endif
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -280,6 +285,12 @@ struct EFGeom {
 #ifndef EF_X   // scratch experiments: 1 = no image DMA inside the loop, 2 = conv1 does not store its activations
 #define EF_X 0
 #endif
+#if defined(EF_STAMPS) || defined(EF_BLKCLK)  // scratch builds: per-workgroup shader clocks from entry to exit
+__device__ unsigned long long ef_blk[512];    // [0, 256) clocks, [256, 512) images served
+extern "C" int tacorl_ef_blk_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ef_blk), sizeof(ef_blk)) == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+#endif
 #ifdef EF_STAMPS
 __device__ unsigned long long ef_stamps[64];
 #define STAMP(k)                                                    \
@@ -317,8 +328,11 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
   const EFProblem P = a_.p[pi];
   const int worker = blockIdx.x - P.first_block, nworkers = P.nblocks;
   if (worker >= P.n_img) return;
+#if defined(EF_STAMPS) || defined(EF_BLKCLK)
+  const unsigned long long t_entry = clock64();
+#endif
 #ifdef EF_STAMPS
-  unsigned long long t_prev = clock64();
+  unsigned long long t_prev = t_entry;
 #endif
 
   unsigned char* act1 = lds + 2 * a.lds_img;
@@ -901,6 +915,9 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     STAMP(9);  // next image landed + end-of-image barrier
     cur = nxt; it++; buf ^= 1;
   }
+#if defined(EF_STAMPS) || defined(EF_BLKCLK)
+  if (tid == 0 && blockIdx.x < 256) { ef_blk[blockIdx.x] = clock64() - t_entry; ef_blk[256 + blockIdx.x] = it + 1; }
+#endif
 }
 
 #define EF_GEOMS(X) X(84, 84) X(64, 64) X(44, 60) X(128, 128)
@@ -934,12 +951,49 @@ extern "C" int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const
   long total = 0;
   for (int p = 0; p < nprob; p++) total += n_img[p];
   if (total == 0) return TACORL_OK;
-  // one workgroup per CU; workers are shared out in proportion to each problem's images
+  // One workgroup per CU.  A workgroup serves ONE problem (its weights are register-stationary), so the launch lasts as
+  // long as the slowest workgroup: the largest ceil(images / workgroups) x cost per image over the problems.  Shares
+  // proportional to the image counts left the 4 096-frame problem of the step at 28 images per workgroup and the
+  // problems that also store their activations (1.28 x per image, EF_ACT_COST) at 27 - 35 image-units against an
+  // average of 27.  Instead: the smallest per-workgroup budget M (in units of 1/64 image) for which sum_p ceil(cost_p
+  // n_p / M) fits the CU count, found by bisection; spare workgroups go to the problems closest to the budget.
   const int budget = 256;
+  long cost[EF_MAXP], units = 0;
+  for (int p = 0; p < nprob; p++) {
+    cost[p] = (act && act[p]) ? EF_ACT_COST : 64;
+    units += cost[p] * n_img[p];
+  }
+  auto blocks_for = [&](long M, int* k) {
+    long nbk = 0;
+    for (int p = 0; p < nprob; p++) {
+      const long ipb = M / cost[p] > 0 ? M / cost[p] : 1;  // images per workgroup within the budget
+      k[p] = (int)((n_img[p] + ipb - 1) / ipb);
+      nbk += k[p];
+    }
+    return nbk;
+  };
+  int kk[EF_MAXP];
+  long lo = (units + budget - 1) / budget, hi = units;  // M in [lo, hi]: blocks_for(hi) = nprob <= budget
+  if (lo < 64) lo = 64;
+  if (hi < lo) hi = lo;
+  while (lo < hi) {
+    const long mid = (lo + hi) / 2;
+    if (blocks_for(mid, kk) <= budget) hi = mid; else lo = mid + 1;
+  }
+  long used = blocks_for(lo, kk);
+  for (; used < budget; used++) {  // spare workgroups: to the problem with the highest load per workgroup that can still split
+    int best = -1; double worst = 0.0;
+    for (int p = 0; p < nprob; p++) {
+      if (kk[p] >= n_img[p] || n_img[p] == 0) continue;
+      const double load = (double)cost[p] * ((n_img[p] + kk[p] - 1) / kk[p]);
+      if (load > worst) { worst = load; best = p; }
+    }
+    if (best < 0) break;
+    kk[best]++;
+  }
   int nb = 0;
   for (int p = 0; p < nprob; p++) {
-    int k = (int)(((long)n_img[p] * (budget - nprob)) / total) + (n_img[p] > 0 ? 1 : 0);  // floor share + 1
-    if (k > n_img[p]) k = n_img[p];
+    const int k = n_img[p] > 0 ? kk[p] : 0;
     a.p[p].img = (const __bf16*)img[p]; a.p[p].wpk = (const u32x4*)packed[p]; a.p[p].params = params[p];
     a.p[p].out = out[p]; a.p[p].n_img = n_img[p]; a.p[p].first_block = nb; a.p[p].nblocks = k;
     a.p[p].act = act ? act[p] : nullptr;
