@@ -61,6 +61,16 @@ CASES = {
     "rollout_cql": dict(kind="rollout_cql", B=3, cams={"rgb_static": (84, 84)}, seed=22),
     "playlmp_dropout": dict(kind="playlmp", B=3, T=16, cams={"rgb_static": (84, 84)}, latent=16,
                             steps=2, seed=20, dropout_p=0.1),
+    # validation_step (tacorl.py:275-287, cql_offline_lightning.py:234-236, play_lmp_for_rl.py:319-348): the same
+    # computation with optimize=False, eval mode, no_grad - every `validation/*` scalar (q1_data is what
+    # config/callbacks/checkpoint/rl_real_world.yaml:5 monitors) and the fact that nothing moves
+    "val_tacorl": dict(kind="tacorl", B=3, T=16, cams={"rgb_static": (84, 84)}, latent=16, epoch=5, finetune_ad=False,
+                       steps=1, seed=31, validate=True),
+    "val_tacorl_ad": dict(kind="tacorl", B=2, T=16, cams={"rgb_static": (84, 84)}, latent=16, epoch=5, finetune_ad=True,
+                          steps=1, seed=32, validate=True),
+    "val_cql": dict(kind="cql", B=3, cams={"rgb_static": (84, 84)}, epoch=5, steps=1, seed=33, validate=True),
+    "val_playlmp": dict(kind="playlmp", B=3, T=16, cams={"rgb_static": (84, 84)}, latent=16, steps=1, seed=34,
+                        validate=True),
 }
 
 
@@ -145,6 +155,8 @@ def run_case(name, c):
         mod = lmp
     synth.fill_params_(mod, c["seed"])
     mod.train()
+    if c.get("validate"):
+        mod.eval()  # the Trainer's validation loop: eval mode, no_grad
     mod.current_epoch = c.get("epoch", 0)
     names = [n for n, _ in mod.named_parameters()]
     out["param_names"] = np.array(names)
@@ -160,6 +172,30 @@ def run_case(name, c):
         tape = H.NoiseTape()
         mod.logged = {}
         mod.grad_log = []
+        if c.get("validate"):
+            before = {n: p.detach().clone() for n, p in mod.named_parameters()}
+            with torch.no_grad(), H.record_noise(tape):
+                if c["kind"] == "tacorl":
+                    orig, cap = mod.get_pr_latent_plan, {}
+
+                    def wrapped_v(b, return_emb_states=True, _o=orig, _c=cap):
+                        r = _o(b, return_emb_states=return_emb_states)
+                        _c["plan"] = (r[0] if return_emb_states else r).detach().clone()
+                        return r
+
+                    mod.get_pr_latent_plan = wrapped_v
+                    mod.validation_step(batch)
+                    mod.get_pr_latent_plan = orig
+                    out[f"s{step}/latent_plan"] = cap["plan"].numpy()
+                else:
+                    mod.validation_step(batch, 0)
+            assert all(torch.equal(before[n], p) for n, p in mod.named_parameters()), "validation_step moved a parameter"
+            for i, (kind, t) in enumerate(tape.draws):
+                out[f"s{step}/noise/{i:02d}_{kind}"] = t.numpy()
+            out[f"s{step}/logged"] = np.array(json.dumps(mod.logged))
+            print(f"[{name}] validation: " + ", ".join(f"{k}={v:.5g}" for k, v in sorted(mod.logged.items())))
+            print(f"[{name}] draws: {[k for k, _ in tape.draws]}")
+            continue
         with H.record_noise(tape):
             if c["kind"] == "tacorl":
                 # capture the sampled latent plan (north-star parity item)

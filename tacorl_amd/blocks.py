@@ -91,6 +91,14 @@ class TensorBlock:
             self.step = torch.zeros(1, dtype=torch.int32, device=device)
             self.grad_views = {k: self.grad[o: o + n].view(*shp) for k, (o, shp, n) in self.off.items()}
 
+    def rebind_grad(self, flat):
+        """Move the gradient block into caller-provided storage (a slice of a gradient arena: one all-reduce for
+        several blocks)."""
+        assert self.trainable and flat.numel() == self.size and flat.is_contiguous()
+        flat.copy_(self.grad)
+        self.grad = flat
+        self.grad_views = {k: flat[o: o + n].view(*shp) for k, (o, shp, n) in self.off.items()}
+
     def views_of(self, flat):
         """Reference-named views into another flat buffer of this layout (Adam moments, ...)."""
         return {k: flat[o: o + n].view(*shp) for k, (o, shp, n) in self.off.items()}

@@ -83,7 +83,17 @@ class PlayIndex:
         for i in sim:  # ragged neighbour lists: a short host loop over the similar-robot-obs share of the batch
             opts = self.nn.get(int(start[i] + ws[i] - 1), ())
             goal[i] = opts[min(int(d["u_choice"][i] * len(opts)), len(opts) - 1)] if len(opts) else random_state[i]
+        # frame ids feed an unchecked device gather: keep them inside the dataset (a goal-augmentation noise step of -1 on a
+        # one-frame window at frame 0 is the one way the reference arithmetic leaves it)
+        goal = np.clip(goal, 0, int(self.ep[:, 1].max()))
         return {"frames": frames, "padded": padded, "window_size": ws, "goal": goal, "disp": out_disp, "idx": idx}
+
+
+def check_ids(ids, n_frames):
+    """Host-side range check of the frame ids a gather kernel will dereference (it has none of its own)."""
+    ids = np.asarray(ids)
+    if ids.size and (int(ids.min()) < 0 or int(ids.max()) >= n_frames):
+        raise IndexError(f"replay: frame id outside [0, {n_frames}): min {int(ids.min())}, max {int(ids.max())}")
 
 
 def pad_actions(actions, frames, padded):
@@ -114,7 +124,9 @@ class HbmReplay:
     def batch(self, idx, draws, aug=None):
         s = self.index.sample(idx, draws)
         n, T = s["frames"].shape
-        ids = torch.from_numpy(np.concatenate([s["frames"].reshape(-1), s["goal"]])).to(self.dev, non_blocking=True)
+        all_ids = np.concatenate([s["frames"].reshape(-1), s["goal"]])
+        check_ids(all_ids, min(int(v.shape[0]) for v in self.frames.values()))
+        ids = torch.from_numpy(all_ids).to(self.dev, non_blocking=True)
         states, goal = {}, {}
         for c, fr in self.frames.items():
             H, W = fr.shape[1:3]
@@ -145,6 +157,7 @@ class PinnedReplay:
         self.gather = gather
         self.stream = torch.cuda.Stream(device=self.dev)
         self._slot, self._host, self._dev_buf = 0, [{}, {}], [{}, {}]
+        self._copied = [None, None]  # per slot: the copy stream's event behind the last H2D copy out of its staging buffers
         self._pending = None
 
     def _dev_out(self, slot, key, shape):
@@ -165,8 +178,16 @@ class PinnedReplay:
     def prefetch(self, idx, draws, aug=None):
         s = self.index.sample(idx, draws)
         n, T = s["frames"].shape
+        check_ids(np.concatenate([s["frames"].reshape(-1), s["goal"]]), min(int(v.shape[0]) for v in self.frames.values()))
         slot = self._slot
         self._slot ^= 1
+        # Ring ordering.  The slot's device buffers were handed out two batches ago; the step that reads them has been
+        # enqueued on the compute stream by now (prefetch is called after it), so the copy stream waits for everything
+        # enqueued there so far - not for the step that consumes the OTHER slot next, which it overlaps.
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        # ... and the host may not rewrite a pinned staging buffer while the copy issued from it is still in flight
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()
         jobs = [("states", c, (n, T), ("s", c), fr, s["frames"].reshape(-1)) for c, fr in self.frames.items()]
         jobs += [("goal", c, (n,), ("g", c), fr, s["goal"]) for c, fr in self.frames.items()]
         acts = torch.from_numpy(pad_actions(self.actions, s["frames"], s["padded"])).pin_memory()
@@ -187,6 +208,7 @@ class PinnedReplay:
             b["disp"] = torch.from_numpy(s["disp"]).pin_memory().to(self.dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        self._copied[slot] = ev
         b.update(idx=torch.from_numpy(s["idx"]), window_size=torch.from_numpy(s["window_size"]))
         if aug is not None:
             b["aug"] = aug
@@ -195,6 +217,10 @@ class PinnedReplay:
     def next(self):
         """The prefetched batch; the compute stream waits for its copy."""
         b, ev = self._pending
-        torch.cuda.current_stream().wait_event(ev)
+        cs = torch.cuda.current_stream(self.dev)
+        cs.wait_event(ev)
+        # tensors allocated under the copy stream are read on the compute stream: tell the caching allocator
+        for t in (b["actions"], b["disp"], *b["states"].values(), *b["goal"].values()):
+            t.record_stream(cs)
         self._pending = None
         return b

@@ -141,17 +141,38 @@ class ACEngine:
         self.log_alpha, self.log_alpha_prime = Scalar(device), Scalar(device)
         # one gradient arena [actor | q1 | q2 | log_alpha'] -> ONE all-reduce per step for the update
         # (plus the scalar one for log_alpha, which must be stepped before the actor loss)
-        sizes = [self.actor.size, self.q1.size, self.q2.size, 4]
-        self.grad_arena = torch.zeros(sum(sizes), device=device)
-        o = 0
-        for blk, n_ in zip((self.actor, self.q1, self.q2), sizes):
-            blk.rebind_grad(self.grad_arena[o: o + n_])
-            o += n_
-        self.log_alpha_prime.grad = self.grad_arena[o: o + 1]
+        self.arena_extra = []
+        self._bind_arena()
         self.extra_enc, self._wpk = [], {}
         self.B = None
         if B:
             self.ensure_batch(B)
+
+    def _bind_arena(self):
+        """[actor | q1 | q2 | log_alpha' | extra blocks...]: every gradient the step's second collective reduces, one
+        allocation (the fine-tuned action decoder's block rides in the same all-reduce)."""
+        blks = [self.actor, self.q1, self.q2]
+        sizes = [b.size for b in blks] + [4] + [b.size for b in self.arena_extra]
+        arena = torch.zeros(sum(sizes), device=self.dev)
+        o = 0
+        for blk in blks:
+            blk.rebind_grad(arena[o: o + blk.size])
+            o += blk.size
+        old = self.log_alpha_prime.grad
+        arena[o: o + 1].copy_(old.reshape(-1)[:1])
+        self.log_alpha_prime.grad = arena[o: o + 1]
+        o += 4
+        for blk in self.arena_extra:
+            blk.rebind_grad(arena[o: o + blk.size])
+            o += blk.size
+        self.grad_arena = arena
+
+    def extend_arena(self, blk):
+        """Put another trainable block's gradients (TACORL: the fine-tuned action decoder) into the arena."""
+        if not any(b is blk for b in self.arena_extra):
+            ops.note_alloc()
+            self.arena_extra.append(blk)
+            self._bind_arena()
 
     # ------------------------------------------------------------------ buffers
     def ensure_batch(self, B, hw=None):

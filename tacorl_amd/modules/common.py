@@ -177,12 +177,27 @@ class ModuleMixin:
         kernels address by raw pointer, so the module cannot be moved or cast after construction; a call that
         would not change anything (what Trainer.fit does to a module that is already on its GPU) is accepted."""
         probe = fn(torch.empty(0, device=self.dev))
+        if probe.device.type == "cpu" and probe.dtype == torch.float32:
+            # pytorch_lightning 1.5 / 1.6 end Trainer.fit with `lightning_module.cpu()` (strategy teardown).  The blocks
+            # stay where they are - the module remains usable on its GPU and state_dict() / checkpoints are unaffected.
+            return self
         if probe.device != self.dev or probe.dtype != torch.float32:
             raise RuntimeError(
                 f"{type(self).__name__} lives on {self.dev} as fp32 blocks (views, raw pointers): build it on its GPU "
                 "(device=..., default cuda:$LOCAL_RANK) and select precision with compute_dtype / image_dtype; "
                 f".to({probe.device}, {probe.dtype}) cannot move or cast it")
         return self
+
+    def _tick_optimizers(self):
+        """Under a pytorch_lightning Trainer: one `.step()` per optimizer per training_step, as the reference's manual
+        optimisation does.  BlockAdam.step() itself does nothing (the update is part of the step's kernels), but PL >= 1.6
+        counts `trainer.global_step` - max_steps, every_n_train_steps checkpoints, the logger's x axis - in
+        LightningOptimizer.step() calls."""
+        if self._attached_trainer() is None:
+            return
+        opts = self.optimizers()
+        for o in (opts if isinstance(opts, (list, tuple)) else [opts]):
+            o.step()
 
     def on_fit_start(self):
         """Adopt the trainer's world size (PL DDP: one process per GPU; the gradient blocks are all-reduced

@@ -206,6 +206,7 @@ class CQL_Offline(GraphMixin, ModuleMixin, LightningModuleBase):
 
     def training_step(self, batch, batch_idx=0, noise=None):
         self.compute_update(self.overwrite_batch(batch), optimize=True, log_type="train", noise=noise)
+        self._tick_optimizers()
 
     def validation_step(self, batch, *args, noise=None, **kwargs):
         self.compute_update(self.overwrite_batch(batch), optimize=False, log_type="validation", noise=noise)

@@ -40,13 +40,14 @@ class EncoderRunner:
         call("tacorl_pack_images", ptr(x), 3 * H * W, 1, ptr(img), xd, n, 3, H, W, ops.stream())
         call("tacorl_encoder_fwd", 1, ops.ptr_array([img]), ops.ptr_array([enc_ptr]), ops.ptr_array([out]),
              ops.ptr_array([act]), ops.int_array([n]), H, W, xd, o.compute, ops.stream())
-        return out
+        # a copy, not the cached buffer: two cameras of one geometry (or obs and goal) share (n, hw) and hence `out`
+        return out.clone()
 
 
 def state_from_observation(owner, runner, net, observation, modalities):
     """LateFusion.get_state_from_observation: per-camera embeddings concatenated in `modalities` order."""
     embs = [runner.encode(net.enc(c), observation[c]) for c in modalities]
-    return embs[0].clone() if len(embs) == 1 else torch.cat(embs, dim=-1)
+    return embs[0] if len(embs) == 1 else torch.cat(embs, dim=-1)
 
 
 class ActorSurface:

@@ -246,6 +246,9 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
     self._acts.copy_(batch["actions"])
     acts = self._acts
 
+    if optimize and getattr(self, "world_size", 1) > 1:
+        _grad_arena(self)  # (before anything is captured: the backward kernels write into the arena's slices)
+
     def fwd_bwd():
         _playlmp_fwd_bwd(self, B, T, hw, acts, gs)
 
@@ -258,8 +261,7 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
         if optimize and getattr(self, "world_size", 1) > 1:
             import torch.distributed as dist
 
-            for blk in (net, pr.blk, ad.blk):
-                dist.all_reduce(blk.grad)
+            dist.all_reduce(_grad_arena(self))  # ONE collective: [encoders + proposal | plan recognition | action decoder]
 
     # (a graph replay runs no python: announce the optimiser's writes to torch's version counters - ops.touched)
     self._stepped_blocks = (lambda: [net.param, pr.blk.param, ad.blk.param]) if optimize else None
@@ -377,9 +379,26 @@ def _named_gradients(self):
     return out
 
 
+def _grad_arena(self):
+    """The three blocks' gradients as slices of one allocation (made on first use, i.e. only with several ranks)."""
+    a = self.__dict__.get("_grad_arena_t")
+    if a is None:
+        blks = (self.net, self.pr.blk, self.ad.blk)
+        ops.note_alloc()
+        a = torch.zeros(sum(b.size for b in blks), device=self.dev)
+        o = 0
+        for b in blks:
+            b.rebind_grad(a[o: o + b.size])
+            o += b.size
+        self.__dict__["_grad_arena_t"] = a
+    return a
+
+
 def _training_step(self, batch, batch_idx=0, noise=None):
     """reference :307-317 (returns the total loss; the optimiser step has already run - manual optimisation)."""
-    return _playlmp_step(self, batch, noise, True, "train")
+    out = _playlmp_step(self, batch, noise, True, "train")
+    self._tick_optimizers()
+    return out
 
 
 def _validation_step(self, batch, batch_idx=0, noise=None):

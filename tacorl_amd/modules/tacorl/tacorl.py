@@ -77,6 +77,10 @@ class TACORL(CQL_Offline):
             self._pv["action_decoder"] = register_views(self, "action_decoder.", self.ad.blk.views)
             for k, v in self.ad.buffers.items():
                 self.action_decoder.register_buffer(k, v)
+            if self.finetune_action_decoder:
+                # the decoder's gradients join [actor | q1 | q2 | log_alpha'] in the engine's arena: with several GPUs the
+                # step's second all-reduce covers them - no third collective inside the first segment
+                e.extend_arena(self.ad.blk)
         self._T = None
         # rollout surface (evaluation/rollout_manager.py:330-386): the frozen LMP encoder for the action decoder's state,
         # the decoder's one-step `act` with its carried hidden state
@@ -237,8 +241,11 @@ class TACORL(CQL_Offline):
             ready = torch.cuda.Event()
             ready.record(self._pr_stream)
             if with_ad and not ad_on_side:
-                # fine-tuning: loss + BPTT + Adam (+ all-reduce) stay in line on this branch
-                self.ad.loss_step(self, self.acts, self.plan, B, T, True)
+                # fine-tuning: loss + BPTT (+ Adam on one GPU) stay in line on this branch.  With more than one GPU the
+                # decoder's gradient block is part of the engine's arena: the step's second all-reduce covers it and
+                # the Adam step follows in the last segment (reference tacorl.py:206-233 has no dependency
+                # between this update and the CQL update)
+                self.ad.loss_step(self, self.acts, self.plan, B, T, True, defer_update=self._defer_ad_update())
         if ad_on_side:
             # compute_action_decoder_update (tacorl.py:206-233), frozen decoder: 30 small dependent GEMMs that each
             # fill a fraction of the chip -> their own branch, joined at the end of the step
@@ -264,6 +271,11 @@ class TACORL(CQL_Offline):
             e.action_ready = None
             self._join_ad()
 
+    def _defer_ad_update(self):
+        """More than one rank (or the split-graph test mode): the fine-tuned decoder's Adam step waits for the arena's
+        all-reduce.  On one GPU it stays on the decoder's own branch of the step's graph."""
+        return self.world_size > 1 or getattr(self, "_force_graph_split", False)
+
     def _join_ad(self):
         if getattr(self, "_ad_join", None) is not None:
             torch.cuda.current_stream().wait_stream(self._ad_join)
@@ -287,6 +299,7 @@ class TACORL(CQL_Offline):
 
     def training_step(self, batch, batch_idx=0, noise=None):
         self._step(batch, noise, optimize=True, log_type="train")
+        self._tick_optimizers()
 
     def validation_step(self, batch, *args, noise=None, **kwargs):
         self._step(batch, noise, optimize=False, log_type="validation")
@@ -296,12 +309,13 @@ class TACORL(CQL_Offline):
         with_ad = self._ad_due()
         key = ("tacorl", B, T, tuple(sorted(hw.items())), self.current_epoch < self.bc_epochs, optimize, with_ad)
         e, bc = self.engine, self.current_epoch < self.bc_epochs
-        if with_ad and optimize and self.finetune_action_decoder and self.world_size > 1 and self._use_graph:
-            raise NotImplementedError("hipGraph + multi-GPU + action-decoder fine-tuning: its extra all-reduce sits "
-                                      "inside the first segment; run this combination eagerly")
+        ad_update = with_ad and optimize and self.finetune_action_decoder and self._defer_ad_update()
+
         def tail():
             e.phase_c(optimize)
             self._join_ad()
+            if ad_update:
+                self.ad.update(self)  # its gradients came through the second all-reduce with the arena
             ops.mark("step:end")
 
         # split (multi-GPU) graphs: the frozen, logging-only action-decoder pass leaves the first segment

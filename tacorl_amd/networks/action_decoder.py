@@ -214,7 +214,7 @@ class ActionDecoderLogistic:
              loss_out, B, T, Tm, self.Da, self.K, self.num_classes, float(self.gripper_alpha), float(grad_scale),
              ptr(self.ws), self.ws.numel(), ops.stream())
 
-    def loss_step(self, module, actions, plan, B, T, optimize, frozen=False):
+    def loss_step(self, module, actions, plan, B, T, optimize, frozen=False, defer_update=False):
         """TACORL.compute_action_decoder_update (reference tacorl.py:206-233): loss on emb[:, :-1],
         actions[:, :-1]; logged always, Adam step when fine-tuning."""
         from .._lib import LOG_SLOTS
@@ -241,9 +241,13 @@ class ActionDecoderLogistic:
             # the Adam step moved behind the join - it captured, and the step went 1.82 -> 2.10 ms: three concurrent
             # chains of chip-wide kernels slow each other more than the overlap returns)
             self.backward(B, T - 1, module.compute, need_input_grad=False, wavefront=False)
-            module.engine._allreduce([self.blk.grad])
-            ops.adam_step(self.blk.param, self.blk.grad, self.blk.m, self.blk.v, module.action_decoder_lr, 0.0,
-                          self.blk.step)
+            # defer_update (more than one GPU): the gradient block lives in the engine's arena and is reduced by the
+            # step's second collective; the module steps it afterwards (update())
+            if not defer_update:
+                self.update(module)
+
+    def update(self, module):
+        ops.adam_step(self.blk.param, self.blk.grad, self.blk.m, self.blk.v, module.action_decoder_lr, 0.0, self.blk.step)
 
     # ------------------------------------------------------------------ backward (BPTT)
     def _wgrad(self, x, ldx, dz, ld_dz, M, K, O, dw, db, compute):

@@ -118,6 +118,8 @@ class LightningModule(nn.Module):
 
     def optimizers(self, use_pl_optimizer=True):
         o = self._trainer.optimizers
+        if use_pl_optimizer:
+            o = [LightningOptimizer(x, self._trainer) for x in o]
         return o[0] if len(o) == 1 else o
 
     def manual_backward(self, loss, *args, **kwargs):
@@ -177,6 +179,22 @@ class LightningModule(nn.Module):
 
 def _is_overridden(name, model):
     return getattr(type(model), name) is not getattr(LightningModule, name)
+
+
+class LightningOptimizer:
+    """PL 1.6: what `LightningModule.optimizers()` hands out; its step() is where `trainer.global_step` advances
+    (manual optimisation: loops/optimization/manual_loop.py, optim_step_progress)."""
+
+    def __init__(self, optimizer, trainer):
+        self._optimizer, self._trainer = optimizer, trainer
+
+    def __getattr__(self, name):
+        return getattr(self._optimizer, name)
+
+    def step(self, closure=None, **kw):
+        out = self._optimizer.step(closure) if closure is not None else self._optimizer.step()
+        self._trainer.global_step += 1
+        return out
 
 
 class Trainer:
@@ -255,7 +273,8 @@ class Trainer:
                 self._call(model, "on_train_batch_end", out, batch, batch_idx)
                 for cb in self.callbacks:
                     cb.on_train_batch_end(self, model, out, batch, batch_idx)
-                self.global_step += 1
+                # (global_step advances in LightningOptimizer.step(), as in PL 1.6 - a module that never steps its
+                # optimizers never reaches max_steps and is never checkpointed every_n_train_steps)
                 if self.global_step % self.log_every_n_steps == 0:
                     self.logged_metrics.update(self._results)
                 if 0 < self.max_steps <= self.global_step:
@@ -276,6 +295,7 @@ class Trainer:
             self.current_epoch += 1
         self._call(model, "on_fit_end")
         self.logged_metrics.update(self._results)
+        model.cpu()  # strategy teardown (PL 1.5 / 1.6: lightning_module.cpu() after fit on an accelerator)
 
     # ---- checkpoints: PL's dictionary
     def save_checkpoint(self, path):

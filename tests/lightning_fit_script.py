@@ -61,16 +61,19 @@ def batches(kind, n):
 for kind in ("tacorl", "cql", "playlmp"):
     data = batches(kind, 4)  # host tensors: the trainer moves them (transfer_batch_to_device)
     full = build(kind)
-    tr = Trainer(max_epochs=1, max_steps=4, log_every_n_steps=1, **tkw)
+    # steps per batch as the trainer counts them: PL >= 1.6 counts optimizer steps (one per optimizer per batch, as the
+    # reference's manual optimisation steps them), MiniTrainer counts batches
+    per = 1 if Trainer is L.MiniTrainer else len(L._as_list(full.configure_optimizers()))
+    tr = Trainer(max_epochs=1, max_steps=4 * per, log_every_n_steps=1, **tkw)
     tr.fit(full, train_dataloaders=data)
     torch.cuda.synchronize()
     want = "train/total_loss" if kind == "playlmp" else "train/q1_loss"
     assert want in tr.logged_metrics and tr.logged_metrics[want] == tr.logged_metrics[want], tr.logged_metrics
-    assert tr.global_step == 4
+    assert tr.global_step == 4 * per, (tr.global_step, per)
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "last.ckpt")
         first = build(kind)
-        t1 = Trainer(max_epochs=1, max_steps=2, log_every_n_steps=1, **tkw)
+        t1 = Trainer(max_epochs=1, max_steps=2 * per, log_every_n_steps=1, **tkw)
         t1.fit(first, train_dataloaders=data)
         t1.save_checkpoint(path)
         resumed = build(kind)
@@ -78,10 +81,10 @@ for kind in ("tacorl", "cql", "playlmp"):
             for p in resumed.parameters():
                 p.mul_(0.5)
         # (the checkpoint was written after t1's epoch counter moved on: give the resumed run epochs to spend)
-        t2 = Trainer(max_epochs=10, max_steps=4, log_every_n_steps=1, **tkw)
+        t2 = Trainer(max_epochs=10, max_steps=4 * per, log_every_n_steps=1, **tkw)
         t2.fit(resumed, train_dataloaders=data[2:], ckpt_path=path)
     torch.cuda.synchronize()
-    assert t2.global_step == 4
+    assert t2.global_step == 4 * per
     sa, sb = full.state_dict(), resumed.state_dict()
     for k in sa:
         if sa[k].dtype.is_floating_point:

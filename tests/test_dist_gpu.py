@@ -41,3 +41,13 @@ def test_bench_self_launcher_two_ranks():
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["replicas_in_sync"] is True
     st = res["strong"]
     assert st["per_gpu_batch"] == 32 and st["global_batch"] == 64 and st["value"] > 0 and st["replicas_in_sync"] is True
+
+
+def test_two_rank_shards_equal_the_full_batch_step():
+    """TACORL (frozen / fine-tuned action decoder), CQL_Offline, PlayLMP: two ranks on per-sample shards with sharded
+    noise, hipGraph segments around the all-reduces, against the single-rank full-batch step (tests/dist_shard_script.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(ROOT, "tests", "dist_shard_script.py")]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]

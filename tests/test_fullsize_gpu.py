@@ -401,3 +401,153 @@ def test_bptt_wavefront_equals_per_layer():
     for k in ga:
         d = (ga[k] - gb[k]).norm() / gb[k].norm().clamp_min(1e-30)
         assert d < 2e-5, (k, d.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2] (C3: the default TACORL step, action-decoder fine-tuning on, B=256), configs[3] (C4: one GPU's share
+# of the dual-camera 128x128 real-world batch - 512 / 8 = 64 samples, window 32, latent 32) and configs[0] (C1: PlayLMP,
+# B=32) at FULL size against the oracle: exact-fp32 mode at the north-star 1e-4, bf16 mode against the oracle evaluated
+# with the MFMA's operand rounding.  (tests/test_step_gpu.py holds the same configurations at fixture size against the
+# reference's own outputs; the 128x128 row-band encoder, the two-band conv1 weight gradient and the large-row MLP /
+# RNN instantiations only run at these sizes.)
+def _build_tacorl(compute, cams, T, latent, finetune):
+    from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
+    from tacorl_amd.modules.tacorl.tacorl import TACORL
+
+    names = sorted(cams)
+    actor = {"policy": {"num_layers": 3, "hidden_dim": 256}}
+    critic = {"q_network": {"num_layers": 3, "hidden_dim": 256, "last_layer_activation": "Identity"}}
+    pr = dict(num_heads=8, num_layers=2, encoder_hidden_size=2048, fc_hidden_size=4096, latent_plan_dim=latent,
+              min_std=1e-4, dropout_p=0.0, max_position_embeddings=T)
+    ad = dict(n_mixtures=10, num_layers=2, hidden_size=2048, out_features=7, num_classes=10, latent_plan_dim=latent,
+              rnn_model="rnn_decoder", include_goal=False)
+    torch.manual_seed(3)
+    lmp = PlayLMP(plan_proposal=actor, plan_recognition=pr, action_decoder=ad, plan_proposal_obs_modalities=names,
+                  plan_proposal_goal_modalities=names, plan_recognition_modalities=names, action_decoder_modalities=names,
+                  real_world=True, device="cuda:0", compute_dtype=compute, image_dtype=compute)
+    mod = TACORL(play_lmp=lmp, finetune_action_decoder=finetune, critic=critic, real_world=True, device="cuda:0",
+                 compute_dtype=compute, image_dtype=compute, action_decoder_lr=3e-4, actor_lr=1e-4, critic_lr=3e-4,
+                 discount=0.95, conservative_weight=1.0, reward_scale=10.0, n_action_samples=4, with_lagrange=True,
+                 deterministic_backup=True, bc_epochs=5)
+    mod.current_epoch = 5
+    return mod
+
+
+def _tacorl_oracle(mod, cams, latent, finetune):
+    from oracle import tacorl_oracle as O
+
+    names = sorted(cams)
+    spec = O.ACSpec(cams=names, goal_cams=names, action_dim=latent, n=4, discount=0.95, actor_lr=1e-4, critic_lr=3e-4,
+                    deterministic_backup=True, reward_scale=10.0, bc_epochs=5, with_lagrange=True, discrete_gripper=False,
+                    target_entropy=-7.0, finetune_action_decoder=finetune, ac_cams=names, pr_cams=names,
+                    action_decoder_lr=3e-4)
+    skip = ("one_hot_embedding_eye", "ones", "gripper_bounds", "action_max_bound", "action_min_bound")
+    P = {k: v.detach().cpu().clone().contiguous() for k, v in mod.state_dict().items()
+         if v.dtype == torch.float32 and not any(k.endswith(s) for s in skip)}
+    frozen = ("perceptual_encoder.", "plan_recognition.") + (() if finetune else ("action_decoder.",))
+    O.require_grad_(P, frozen_prefixes=frozen)
+    return O, spec, P
+
+
+def _compare(got, ologs, rtol, grads=None, ograds=None, grad_rtol=None, plan=None, oplan=None, min_common=8):
+    bad = []
+    common = set(ologs) & set(got)
+    assert len(common) >= min_common, (sorted(ologs), sorted(got))
+    for k in sorted(common):
+        v = float(ologs[k])
+        if abs(got[k] - v) > rtol * max(abs(v), 1e-3):
+            bad.append(f"{k}: hip {got[k]:.8g} oracle {v:.8g}")
+    if plan is not None:
+        e = ((plan.cpu() - oplan).norm() / oplan.norm()).item()
+        if e > rtol:
+            bad.append(f"latent plan relerr {e:.3g}")
+    if grads is not None:
+        top = max(g.norm().item() for g in ograds.values() if g is not None)
+        for k, g in ograds.items():
+            if k in grads and g is not None and g.norm() > 1e-6 * top:
+                d = ((grads[k].cpu().reshape(g.shape) - g).norm() / g.norm()).item()
+                if d > grad_rtol:
+                    bad.append(f"grad {k}: relerr {d:.3g}")
+    return bad
+
+
+FULL_TACORL = {
+    # name: (B, T, cameras, latent, fine-tune the action decoder)
+    "c3": (256, 16, {"rgb_static": (84, 84)}, 16, True),
+    "c4_share": (64, 32, {"rgb_static": (128, 128), "rgb_gripper": (128, 128)}, 32, False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL_TACORL))
+def test_fullsize_tacorl_configs_f32_match_oracle(name):
+    from tacorl_amd import synth
+
+    Bn, Tn, cams, latent, finetune = FULL_TACORL[name]
+    mod = _build_tacorl("f32", cams, Tn, latent, finetune)
+    O, spec, P = _tacorl_oracle(mod, cams, latent, finetune)
+    opts = O.make_opts(P, spec)
+    batch = synth.make_play_batch(4200 + len(name), Bn, Tn, cams)
+    mod.logged = {}
+    mod.training_step(_to_dev(batch, mod.device))
+    got, nz = _logs(mod), _cpu(_noise(mod))
+    ologs, oplan, ograds = O.tacorl_step(P, opts, spec, batch, nz, 5)
+    bad = _compare(got, ologs, 1e-4, mod.named_gradients(), ograds, 1e-3, mod.plan, oplan)
+    if finetune:
+        assert "action_loss" in got and any(k.startswith("action_decoder.") for k in ograds)
+    assert not bad, "\n".join(bad[:30])
+
+
+@pytest.mark.parametrize("name", sorted(FULL_TACORL))
+def test_fullsize_tacorl_configs_bf16_vs_rounded_oracle(name):
+    """The benchmarked mode at full size: losses and plans against the oracle evaluated with bf16 operand rounding in
+    every contraction (2e-3 relative: what is left is accumulation order)."""
+    from tacorl_amd import synth
+
+    Bn, Tn, cams, latent, finetune = FULL_TACORL[name]
+    mod = _build_tacorl("bf16", cams, Tn, latent, finetune)
+    O, spec, P = _tacorl_oracle(mod, cams, latent, finetune)
+    opts = O.make_opts(P, spec)
+    batch = synth.make_play_batch(4300 + len(name), Bn, Tn, cams)
+    mod.logged = {}
+    mod.training_step(_to_dev(batch, mod.device))
+    got, nz = _logs(mod), _cpu(_noise(mod))
+    with O.operand_rounding(torch.bfloat16):
+        ologs, oplan, _ = O.tacorl_step(P, opts, spec, batch, nz, 5)
+    bad = _compare(got, ologs, 2e-3, plan=mod.plan, oplan=oplan)
+    assert not bad, "\n".join(bad[:30])
+
+
+@pytest.mark.parametrize("compute,rtol", [("f32", 1e-4), ("bf16", 2e-3)])
+def test_fullsize_playlmp_c1_matches_oracle(compute, rtol):
+    """BASELINE configs[0]: PlayLMP.training_step at batch 32 (84x84, window 16)."""
+    from oracle import tacorl_oracle as O
+    from tacorl_amd import synth
+    from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
+    from tests import cfg_util as C
+
+    cams = {"rgb_static": (84, 84)}
+    strip = lambda c: {k: v for k, v in c.items() if k not in ("_target_", "_recursive_")}  # noqa: E731
+    torch.manual_seed(4)
+    mod = PlayLMP(**strip(C.playlmp_cfg(device="cuda:0", compute_dtype=compute, image_dtype=compute)))
+    P = {k: v.detach().cpu().clone().contiguous() for k, v in mod.state_dict().items() if v.dtype == torch.float32}
+    P = {k: v for k, v in P.items() if k in dict(mod.named_parameters())}
+    O.require_grad_(P)
+    opt = O.Adam([n for n in P], 1e-4)
+    batch = synth.make_play_batch(4400, 32, 16, cams)
+    mod.logged = {}
+    mod.training_step(_to_dev(batch, mod.device), 0)
+    torch.cuda.synchronize()
+    got = {k.split("/", 1)[1]: float(v) for k, v in mod.logged.items()}
+    nz = {k: v.cpu().clone() for k, v in mod.noise.items()}
+    g = torch.Generator().manual_seed(9)
+    nz["rand"] = [torch.rand(32, 15, 6, 10, generator=g), torch.rand(32, 15, 6, generator=g),
+                  torch.rand(32, 15, 6, 10, generator=g), torch.rand(32, 15, 6, generator=g)]
+    nz["u_goal"] = torch.rand(32, 32, generator=g)
+    if compute == "bf16":
+        with O.operand_rounding(torch.bfloat16):
+            ologs, ograds = O.playlmp_step(P, opt, batch, nz, ["rgb_static"], step=False)
+        bad = _compare(got, ologs, rtol, min_common=5)
+    else:
+        ologs, ograds = O.playlmp_step(P, opt, batch, nz, ["rgb_static"], step=False)
+        bad = _compare(got, ologs, rtol, mod.named_gradients(), ograds, 1e-3, min_common=5)
+    assert not bad, "\n".join(bad[:30])

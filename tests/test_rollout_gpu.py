@@ -78,3 +78,28 @@ def test_cql_rollout_discrete_gripper():
     # without injected noise: fresh draws, still a valid action
     a, lp = mod.actor.get_actions(obs)
     assert torch.isfinite(a).all() and torch.isfinite(lp).all() and bool((a[:, :6].abs() <= 1).all())
+
+
+def test_state_from_observation_two_cameras_of_equal_geometry():
+    """Two cameras of the same size share the encoder runner's (n, H, W) buffers: the fused state must still be
+    [enc_static(static) | enc_gripper(gripper)], not the last camera twice (C4: both cameras 128x128)."""
+    from tests.test_step_gpu import build_tacorl, to_dev
+
+    g = Golden("tacorl_c4")
+    mod = build_tacorl(g)
+    mod.load_state_dict(g.params(), strict=False)
+    mod.eval()
+    cams = sorted(g.cams)
+    assert len(cams) == 2
+    states = to_dev(g.batch(0), mod.device)["states"]
+    obs = {c: states[c][:, 0] for c in cams}
+    assert obs[cams[0]].shape == obs[cams[1]].shape
+    both = mod.perceptual_encoder.get_state_from_observation(obs, cams)
+    one = [mod.perceptual_encoder.get_state_from_observation({c: obs[c]}, [c]) for c in cams]
+    assert both.shape == (obs[cams[0]].shape[0], 64)
+    assert torch.equal(both, torch.cat(one, dim=-1))
+    assert not torch.equal(one[0], one[1])
+    # the actor's [obs | goal] representation runs obs and goal through the same runner as well
+    rep = mod.actor.get_emb_representation({"observation": obs, "goal": to_dev(g.batch(0), mod.device)["goal"]})
+    rep_obs_only = mod.actor.get_emb_representation({"observation": obs})
+    assert torch.equal(rep[:, :64], rep_obs_only)

@@ -7,7 +7,8 @@ import copy
 import pytest
 import torch
 
-from tests.golden_util import Golden, check_stats, gradient_floor, resync_oracle, spec_for
+from tests import cfg_util as C
+from tests.golden_util import Golden, check_stats, gradient_floor, record_margin, resync_oracle, spec_for
 
 pytestmark = pytest.mark.gpu
 
@@ -67,10 +68,14 @@ def compare_with_oracle_grads(mod, oracle_grads, rtol, floor=None):
             tol = max(rtol, 3.0 * (floor or {}).get(k, 0.0))
             if k.endswith(".temperature"):
                 d = (got[k].reshape(v.shape).detach().cpu().double() - v.detach().double()).abs().max().item()
+                if floor is not None:
+                    record_margin(k, d / max(v.abs().max().item(), t_scale, 1e-30), tol, floor.get(k))
                 if d > tol * max(v.abs().max().item(), t_scale):
                     bad.append(f"grad {k}: {got[k].item():.6g} vs {v.item():.6g} (tolerance {tol:.3g} of {t_scale:.3g})")
                 continue
             e = relerr(got[k].reshape(v.shape), v)
+            if floor is not None and v.norm() > 1e-12:
+                record_margin(k, e, tol, floor.get(k))
             if e > tol and v.norm() > 1e-12:
                 bad.append(f"grad {k}: relerr {e:.3g} (tolerance {tol:.3g})")
     return bad
@@ -373,10 +378,13 @@ def _bf16_compare(mod, got, ologs, ograds, P_before, P_after, step, plan=None, o
     for k, v in ologs.items():
         # Q heads start at +-1e-3 (reference critic.py:86-87): q*_data/random/policy are ~1e-2 sums with an absolute
         # bf16 noise of ~3e-5, hence the 5e-2 floor of the relative scale
+        if k in got:
+            record_margin(k, abs(got[k] - float(v)) / max(abs(float(v)), 5e-2), BF16_LOG_RTOL, kind="logged scalar")
         if k in got and abs(got[k] - float(v)) > BF16_LOG_RTOL * max(abs(float(v)), 5e-2):
             bad.append(f"{k}: {got[k]:.7g} vs rounded oracle {float(v):.7g}")
     if plan is not None:
         e = relerr(plan, oplan)
+        record_margin("latent plan", e, BF16_PLAN_RTOL, kind="sampled plan")
         if e > BF16_PLAN_RTOL:
             bad.append(f"latent plan relerr {e:.3g}")
     bad += compare_with_oracle_grads(mod, ograds, BF16_GRAD_RTOL, floor)
@@ -499,3 +507,56 @@ def test_playlmp_step_bf16_vs_rounded_oracle():
         floor = _with_bf16_sensitivity(floor, ograds, O.playlmp_step(_snap(before), copy.deepcopy(opt0), batch, nz, cams)[1])
         bad += _bf16_compare(mod, got, ologs, ograds, before, P, step, floor=floor)
     assert not bad, "\n".join(bad[:30])
+
+
+@pytest.mark.parametrize("name", ["val_tacorl", "val_tacorl_ad", "val_cql", "val_playlmp"])
+def test_validation_step(name):
+    """validation_step (reference tacorl.py:275-287, cql_offline_lightning.py:234-236, play_lmp_for_rl.py:319-348): every
+    `validation/*` scalar of the reference - q1_data is what the real-world checkpoint callback monitors
+    (config/callbacks/checkpoint/rl_real_world.yaml:5) - and nothing moves: parameters, targets, Adam state."""
+    g = Golden(name)
+    kind = g.cfg["kind"]
+    if kind == "tacorl":
+        mod = build_tacorl(g)
+    elif kind == "cql":
+        from tacorl_amd.lightning import instantiate
+
+        mod = instantiate(C.cql_cfg(device="cuda:0"))
+    else:
+        from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
+
+        strip = lambda c: {k: v for k, v in c.items() if k not in ("_target_", "_recursive_")}  # noqa: E731
+        mod = PlayLMP(**strip(C.playlmp_cfg(device="cuda:0")))
+    mod.load_state_dict(g.params(), strict=False)
+    if "epoch" in g.cfg:
+        mod.current_epoch = g.cfg["epoch"]
+    mod.eval()
+    before = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    opt_before = [o.state_dict() for o in L_as_list(mod.configure_optimizers())]
+    nz = g.noise(0)
+    if kind == "playlmp":
+        nz = {k: nz[k] for k in ("eps_plan", "u_plan") if k in nz}
+    mod.logged = {}
+    mod.validation_step(to_dev(g.batch(0), mod.device), 0, noise=to_dev(nz, mod.device))
+    torch.cuda.synchronize()
+    assert mod.logged and all(k.startswith("validation/") for k in mod.logged), sorted(mod.logged)
+    got = {k.split("/", 1)[1]: v for k, v in mod.logged.items()}
+    exp = g.logged(0)
+    assert set(exp) <= set(got), sorted(set(exp) - set(got))
+    bad = check_logs(got, exp)
+    if kind == "tacorl":
+        err = relerr(mod.plan, g.latent_plan(0))
+        if err > RTOL:
+            bad.append(f"latent plan relerr {err:.3g}")
+    after = mod.state_dict()
+    bad += [f"{k} moved" for k, v in before.items() if not torch.equal(v, after[k])]
+    for o0, o in zip(opt_before, L_as_list(mod.configure_optimizers())):
+        s1 = o.state_dict()["state"]
+        for i, st in o0["state"].items():
+            if not all(torch.equal(st[f], s1[i][f]) for f in ("step", "exp_avg", "exp_avg_sq")):
+                bad.append(f"optimizer {o.name}: state of parameter {i} moved")
+    assert not bad, "\n".join(bad[:25])
+
+
+def L_as_list(x):
+    return list(x) if isinstance(x, (list, tuple)) else [x]
