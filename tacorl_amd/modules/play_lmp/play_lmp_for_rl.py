@@ -383,6 +383,8 @@ def _grad_arena(self):
     """The three blocks' gradients as slices of one allocation (made on first use, i.e. only with several ranks)."""
     a = self.__dict__.get("_grad_arena_t")
     if a is None:
+        from ... import ops
+
         blks = (self.net, self.pr.blk, self.ad.blk)
         ops.note_alloc()
         a = torch.zeros(sum(b.size for b in blks), device=self.dev)
