@@ -230,13 +230,16 @@ def time_feeder(mod, a, B, T, H, W, dev, barrier, max_over_ranks, n_frames=40000
     def run(steps):
         if pinned:
             rep.prefetch(*draw())
-        for _ in range(steps):
-            if pinned:
+            for _ in range(steps):
                 b = rep.next()
                 rep.prefetch(*draw())  # the gather of the next batch (over PCIe) overlaps this step
-            else:
-                b = rep.batch(*draw())
-            mod.training_step(b)
+                mod.training_step(b)
+        else:
+            from tacorl_amd.data.replay import prefetching
+
+            # frames by index straight into the encoder's buffers; the host side of a batch is prepared two ahead
+            for b in prefetching(lambda: rep.batch(*draw(), fused=True), steps):
+                mod.training_step(b)
 
     run(max(a.warmup, 3))
     barrier()

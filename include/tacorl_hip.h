@@ -250,6 +250,15 @@ int tacorl_pack_images_batch(int njobs, const float* const* src, const long* img
  * bytes read.  Jobs as in tacorl_pack_images_batch; pitches in bytes; H*W*3 % 16 == 0, 16-byte aligned. */
 int tacorl_pack_images_u8_batch(int njobs, const void* const* src, const long* img_pitch_bytes, void* const* dst,
                                 const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream);
+/* The same pack reading its images BY FRAME INDEX out of a uint8 dataset resident in device (or mapped host) memory:
+ * image i of job j is frame index[j][i * index_stride[j]] of the dataset at src[j] (pitch = bytes per frame); index[j]
+ * NULL = image i (the plain pack).  One pass from the replay store into the encoder's image buffers - the window
+ * frames (stride 1) and the obs / goal / next images (strides T, 1, T over the same id table) of a TACORL step -
+ * instead of a gather into a uint8 batch followed by the pack (reference datamodule/dataset/play_dataset.py:115-169,
+ * 357-419 assembles the window on the host).  Ids are NOT range-checked here: tacorl_amd/data/replay.py checks them. */
+int tacorl_pack_images_u8_gather_batch(int njobs, const void* const* src, const long* img_pitch_bytes,
+                                       const long* const* index, const int* index_stride, void* const* dst,
+                                       const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream);
 /* Replay data path on the GPU.
  * tacorl_gather_frames_u8: dst[i] = frames[index[i]] - a step's window / goal frames out of the uint8 HWC dataset
  * resident in HBM (reference datamodule/dataset/play_dataset.py:357-419 loads them from per-frame .npz files);
@@ -266,6 +275,11 @@ int tacorl_pack_images_u8_aug_batch(int njobs, const void* const* src, const lon
                                     void* const* dst, const int* const* shift, const float* const* jitter,
                                     const int* n_img, int dst_dtype, int H, int W, int pad,
                                     tacorl_stream_t stream);
+/* ... and the augmenting pack with the same optional frame-index tables (shift / jitter tables are per IMAGE i). */
+int tacorl_pack_images_u8_aug_gather_batch(int njobs, const void* const* src, const long* img_pitch_bytes,
+                                           const long* const* index, const int* index_stride, void* const* dst,
+                                           const int* const* shift, const float* const* jitter, const int* n_img,
+                                           int dst_dtype, int H, int W, int pad, tacorl_stream_t stream);
 /* reward = done = float(disp == 1) (done may be NULL) and acts_dst[0:n_acts] = acts_src[0:n_acts], one launch:
  * the small tensors of TACORL.get_rl_batch (reference modules/tacorl/tacorl.py:142-179).
  * disp_dtype: 0 float32, 1 int64, 2 int32, 3 uint8 / bool. */

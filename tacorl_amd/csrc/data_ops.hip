@@ -64,6 +64,8 @@ struct AugJob {
   void* dst;                 // NHWC normalised frames
   const int* shift;          // [n][2] (sx, sy) in [0, 2*pad], or NULL: no shift
   const float* jitter;       // [n][8] {brightness, contrast, hue, order0..3, apply}, or NULL: no colour jitter
+  const long* idx;           // optional frame ids: image i is frame idx[i * istride] of the dataset at src
+  int istride;
   int n;
 };
 #define AUG_MAXJ 8
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void pack_u8_aug_kernel(AugTbl t, int H, int W
   const int img = blockIdx.x;
   if (img >= jb.n) return;
   __shared__ float red[4];
-  const unsigned char* __restrict__ src = jb.src + (long)img * jb.pitch;
+  const unsigned char* __restrict__ src = jb.src + (jb.idx ? jb.idx[(long)img * jb.istride] : (long)img) * jb.pitch;
   OutT* __restrict__ dst = reinterpret_cast<OutT*>(jb.dst) + (long)img * H * W * 3;
   const int sx = jb.shift ? jb.shift[2 * img] - pad : 0, sy = jb.shift ? jb.shift[2 * img + 1] - pad : 0;
   float bf = 1.f, cf = 1.f, hf = 0.f;
@@ -155,14 +157,25 @@ extern "C" int tacorl_pack_images_u8_aug_batch(int njobs, const void* const* src
                                                void* const* dst, const int* const* shift, const float* const* jitter,
                                                const int* n_img, int dst_dtype, int H, int W, int pad,
                                                tacorl_stream_t stream) {
+  return tacorl_pack_images_u8_aug_gather_batch(njobs, src, img_pitch_bytes, nullptr, nullptr, dst, shift, jitter, n_img,
+                                                dst_dtype, H, W, pad, stream);
+}
+extern "C" int tacorl_pack_images_u8_aug_gather_batch(int njobs, const void* const* src, const long* img_pitch_bytes,
+                                                      const long* const* index, const int* index_stride,
+                                                      void* const* dst, const int* const* shift, const float* const* jitter,
+                                                      const int* n_img, int dst_dtype, int H, int W, int pad,
+                                                      tacorl_stream_t stream) {
   if (njobs < 1 || njobs > AUG_MAXJ || H < 1 || W < 1 || pad < 0) return TACORL_EINVAL;
   AugTbl t{};
   int m = 0, mx = 0;
   for (int j = 0; j < njobs; j++) {
     if (n_img[j] <= 0) continue;
     if (!src[j] || !dst[j]) return TACORL_EINVAL;
+    const long* ix = index ? index[j] : nullptr;
+    const int is = (ix && index_stride) ? index_stride[j] : 1;
+    if (ix && is < 1) return TACORL_EINVAL;
     t.j[m] = AugJob{(const unsigned char*)src[j], img_pitch_bytes[j], dst[j], shift ? shift[j] : nullptr,
-                    jitter ? jitter[j] : nullptr, n_img[j]};
+                    jitter ? jitter[j] : nullptr, ix, is, n_img[j]};
     mx = n_img[j] > mx ? n_img[j] : mx;
     m++;
   }

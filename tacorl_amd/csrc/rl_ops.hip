@@ -116,6 +116,8 @@ struct PackU8Tbl {
   const unsigned char* src[PACK_MAXJ];
   void* dst[PACK_MAXJ];
   long pitch[PACK_MAXJ];  // bytes between images
+  const long* idx[PACK_MAXJ];  // optional frame ids: image i is frame idx[i * istride] of the dataset at src (replay gather)
+  int istride[PACK_MAXJ];
   int n[PACK_MAXJ];
 };
 typedef unsigned int pk_u32x4 __attribute__((ext_vector_type(4)));
@@ -125,10 +127,13 @@ __global__ void pack_u8_batch_kernel(PackU8Tbl t, int chunks) {  // chunks = H*W
   const long total = (long)t.n[j] * chunks;
   const unsigned char* __restrict__ src = t.src[j];
   OutT* __restrict__ dst = reinterpret_cast<OutT*>(t.dst[j]);
+  const long* __restrict__ idx = t.idx[j];
+  const int istride = t.istride[j];
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
     const long img = q / chunks;
     const int c = (int)(q - img * chunks);
-    const pk_u32x4 v = *reinterpret_cast<const pk_u32x4*>(src + img * t.pitch[j] + (long)c * 16);
+    const long frame = idx ? idx[img * istride] : img;
+    const pk_u32x4 v = *reinterpret_cast<const pk_u32x4*>(src + frame * t.pitch[j] + (long)c * 16);
     float f[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) {
@@ -148,6 +153,11 @@ __global__ void pack_u8_batch_kernel(PackU8Tbl t, int chunks) {  // chunks = H*W
 }
 extern "C" int tacorl_pack_images_u8_batch(int njobs, const void* const* src, const long* img_pitch_bytes, void* const* dst,
                                            const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream) {
+  return tacorl_pack_images_u8_gather_batch(njobs, src, img_pitch_bytes, nullptr, nullptr, dst, n_img, dst_dtype, H, W, stream);
+}
+extern "C" int tacorl_pack_images_u8_gather_batch(int njobs, const void* const* src, const long* img_pitch_bytes,
+                                                  const long* const* index, const int* index_stride, void* const* dst,
+                                                  const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream) {
   const long bytes = (long)H * W * 3;
   if (njobs < 1 || njobs > PACK_MAXJ || bytes % 16) return TACORL_EINVAL;
   PackU8Tbl t{};
@@ -157,6 +167,9 @@ extern "C" int tacorl_pack_images_u8_batch(int njobs, const void* const* src, co
     if (n_img[j] <= 0) continue;
     if (((uintptr_t)src[j] & 15) || ((uintptr_t)dst[j] & 15) || img_pitch_bytes[j] % 16) return TACORL_EINVAL;
     t.src[m] = (const unsigned char*)src[j]; t.dst[m] = dst[j]; t.pitch[m] = img_pitch_bytes[j]; t.n[m] = n_img[j];
+    t.idx[m] = index ? index[j] : nullptr;
+    t.istride[m] = (index && index[j] && index_stride) ? index_stride[j] : 1;
+    if (t.idx[m] && t.istride[m] < 1) return TACORL_EINVAL;
     const long tot = (long)n_img[j] * (bytes / 16);
     mx = tot > mx ? tot : mx;
     m++;

@@ -33,6 +33,14 @@ class PlayIndex:
         self.p_strategy = np.array([gs.get("geometric", 0.0), gs.get("similar_robot_obs", 0.0)])
         self.goal_augmentation = bool(goal_augmentation)
         self.nn = {int(k): np.asarray(v, dtype=np.int64) for k, v in (nn_steps_from_step or {}).items()}
+        # the ragged neighbour lists as one CSR table indexed by frame id (a python loop over half the batch was the
+        # sampler's hot spot: 180 us per 256-sample batch, a fifth of the device step)
+        top = (max(self.nn) + 1) if self.nn else 0
+        cnt = np.zeros(top, dtype=np.int64)
+        for k, v in self.nn.items():
+            cnt[k] = len(v)
+        self._nn_ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        self._nn_val = (np.concatenate([self.nn[k] for k in sorted(self.nn)]) if self.nn else np.zeros(0, np.int64))
         # load_file_indices (:452-473): every start frame that leaves room for a max-size window
         look = []
         for s, e in self.ep:
@@ -79,10 +87,16 @@ class PlayIndex:
         random_state = self.episode_lookup[np.minimum((np.asarray(d["u_random_state"]) * len(self)).astype(np.int64), len(self) - 1)]
         goal = np.where(end >= 0, np.minimum(end, goal_step), random_state)
         out_disp = np.where(strat == GEOMETRIC, disp, -1)
-        sim = np.nonzero(strat == SIMILAR)[0]
-        for i in sim:  # ragged neighbour lists: a short host loop over the similar-robot-obs share of the batch
-            opts = self.nn.get(int(start[i] + ws[i] - 1), ())
-            goal[i] = opts[min(int(d["u_choice"][i] * len(opts)), len(opts) - 1)] if len(opts) else random_state[i]
+        sim = strat == SIMILAR
+        if sim.any():
+            key = start + ws - 1
+            inside = (key >= 0) & (key < len(self._nn_ptr) - 1)
+            kc = np.where(inside, key, 0)
+            lo = self._nn_ptr[kc] if len(self._nn_ptr) > 1 else np.zeros(n, np.int64)
+            cnt = np.where(inside, (self._nn_ptr[kc + 1] - lo) if len(self._nn_ptr) > 1 else 0, 0)
+            pick = np.minimum((np.asarray(d["u_choice"]) * cnt).astype(np.int64), np.maximum(cnt - 1, 0))
+            nbr = self._nn_val[np.minimum(lo + pick, max(len(self._nn_val) - 1, 0))] if len(self._nn_val) else random_state
+            goal = np.where(sim, np.where(cnt > 0, nbr, random_state), goal)
         # frame ids feed an unchecked device gather: keep them inside the dataset (a goal-augmentation noise step of -1 on a
         # one-frame window at frame 0 is the one way the reference arithmetic leaves it)
         goal = np.clip(goal, 0, int(self.ep[:, 1].max()))
@@ -104,6 +118,36 @@ def pad_actions(actions, frames, padded):
     return a
 
 
+class _PinnedRing:
+    """Small host tensors (ids, actions, flags) go to the device through pinned staging slots: a copy from pageable
+    memory blocks the host until the stream has reached it, i.e. for the whole step that is still running - the
+    feeder then cannot prepare batch i + 1 beside step i.  Each slot is reused only after the copies issued from it
+    have completed (an event per slot)."""
+
+    def __init__(self, device, slots=4):
+        self.dev, self.slots, self.k = device, [dict() for _ in range(slots)], 0
+        self.events = [None] * slots
+
+    def begin(self):
+        self.k = (self.k + 1) % len(self.slots)
+        if self.events[self.k] is not None:
+            self.events[self.k].synchronize()
+        return self.k
+
+    def put(self, slot, key, array):
+        a = np.ascontiguousarray(array)
+        h = self.slots[slot].get(key)
+        if h is None or h.shape != a.shape or h.dtype != torch.from_numpy(a).dtype:
+            h = self.slots[slot][key] = torch.empty(a.shape, dtype=torch.from_numpy(a).dtype).pin_memory()
+        h.numpy()[...] = a
+        return h.to(self.dev, non_blocking=True)
+
+    def end(self, slot):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self.events[slot] = ev
+
+
 class HbmReplay:
     """uint8 HWC frames of every camera resident in HBM: frames[cam] = (N,H,W,3) uint8 device tensor."""
 
@@ -113,6 +157,7 @@ class HbmReplay:
         self.actions = np.asarray(actions, dtype=np.float32)
         self.index = index
         self._buf = {}
+        self._ring = _PinnedRing(self.dev)
 
     def _out(self, key, shape):
         t = self._buf.get(key)
@@ -121,24 +166,67 @@ class HbmReplay:
             t = self._buf[key] = torch.empty(shape, dtype=torch.uint8, device=self.dev)
         return t
 
-    def batch(self, idx, draws, aug=None):
+    def batch(self, idx, draws, aug=None, fused=False):
+        """fused=False: the module's uint8 batch (window frames / goal frames gathered into (n, T, H, W, 3) / (n, H, W, 3)).
+        fused=True: no frame is moved here - the batch carries the dataset tensors and the id table
+        (`batch["replay"]`), and the module's image pack reads the frames by index straight out of the dataset on their
+        way into the encoder's buffers (tacorl_pack_images_u8_gather_batch): one pass instead of gather + pack."""
         s = self.index.sample(idx, draws)
         n, T = s["frames"].shape
         all_ids = np.concatenate([s["frames"].reshape(-1), s["goal"]])
         check_ids(all_ids, min(int(v.shape[0]) for v in self.frames.values()))
-        ids = torch.from_numpy(all_ids).to(self.dev, non_blocking=True)
+        slot = self._ring.begin()
+        ids = self._ring.put(slot, "ids", all_ids)
+        acts_d = self._ring.put(slot, "actions", pad_actions(self.actions, s["frames"], s["padded"]))
+        disp_d = self._ring.put(slot, "disp", s["disp"])
+        self._ring.end(slot)
+        if fused:
+            b = {"replay": {"frames": self.frames, "ids": ids, "B": n, "T": T}, "actions": acts_d, "disp": disp_d,
+                 "idx": torch.from_numpy(s["idx"]), "window_size": torch.from_numpy(s["window_size"])}
+            if aug is not None:
+                b["aug"] = aug
+            return b
         states, goal = {}, {}
         for c, fr in self.frames.items():
             H, W = fr.shape[1:3]
             states[c] = ops.gather_frames_u8(fr, ids[: n * T], self._out(("s", c), (n, T, H, W, 3)))
             goal[c] = ops.gather_frames_u8(fr, ids[n * T:], self._out(("g", c), (n, H, W, 3)))
-        b = {"states": states, "goal": goal,
-             "actions": torch.from_numpy(pad_actions(self.actions, s["frames"], s["padded"])).to(self.dev, non_blocking=True),
-             "disp": torch.from_numpy(s["disp"]).to(self.dev, non_blocking=True), "idx": torch.from_numpy(s["idx"]),
+        b = {"states": states, "goal": goal, "actions": acts_d, "disp": disp_d, "idx": torch.from_numpy(s["idx"]),
              "window_size": torch.from_numpy(s["window_size"])}
         if aug is not None:
             b["aug"] = aug
         return b
+
+
+def prefetching(make_batch, n, depth=2):
+    """Generator over `n` batches built by `make_batch()` on a background thread, `depth` ahead: the host work of a batch
+    (index sampling, action padding, the pinned staging copies: ~0.3 ms for 256 windows) runs beside the previous
+    step's launch sequence instead of in front of it - a 0.9 ms device step leaves the main thread no slack for it.
+    The producer enqueues its copies on the device's current stream before it hands the batch over, so the step
+    that consumes the batch is stream-ordered behind them."""
+    import queue
+    import threading
+
+    q = queue.Queue(maxsize=depth)
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+    def produce():
+        try:
+            if dev is not None:
+                torch.cuda.set_device(dev)
+            for _ in range(n):
+                q.put(make_batch())
+        except BaseException as e:  # surface the failure in the consumer
+            q.put(e)
+
+    th = threading.Thread(target=produce, daemon=True)
+    th.start()
+    for _ in range(n):
+        b = q.get()
+        if isinstance(b, BaseException):
+            raise b
+        yield b
+    th.join()
 
 
 class PinnedReplay:

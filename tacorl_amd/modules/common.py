@@ -2,6 +2,8 @@
 import copy
 import re
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -264,6 +266,8 @@ class GraphMixin:
             self._graphs = {}
         from .. import ops
         gs = self._graphs.get(key)
+        if gs is not None:  # least-recently-used order: a hit moves the key to the end
+            self._graphs[key] = self._graphs.pop(key)
         if gs is not None and gs[2] != ops.alloc_epoch():
             # some step buffer or workspace was (re)allocated since the capture (another batch shape came
             # through - the last, partial batch of an epoch - or another module grew a shared workspace): every
@@ -295,6 +299,14 @@ class GraphMixin:
                 if getattr(self, "_side_replay_stream", None) is None:
                     self._side_replay_stream = torch.cuda.Stream(device=self.device)
             self._graphs[key] = (gs, g_side, ops.alloc_epoch())
+            # A long job alternates keys (train / validation, the epoch's last partial batch, the BC -> Q phase switch):
+            # keep the most recently used few and release the rest - dozens of live instantiated graphs in one process
+            # end in a hipGraphLaunch crash on ROCm 7.2, and each one pins its workspaces' addresses.
+            cap = max(1, int(os.environ.get("TACORL_MAX_GRAPHS", "6")))
+            if len(self._graphs) > cap:
+                torch.cuda.synchronize()  # nothing may still be replaying a graph that is about to be destroyed
+                while len(self._graphs) > cap:
+                    del self._graphs[next(iter(self._graphs))]
             return
         gs, g_side, _ = gs
         stepped = getattr(self, "_stepped_blocks", None)

@@ -196,16 +196,21 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
     from ... import ops
     from ..._lib import BF16, F32, call, ptr
 
-    states = batch["states"]
+    rp = batch.get("replay")  # frames by index out of a uint8 dataset (data/replay.py HbmReplay.batch(fused=True))
+    states = rp["frames"] if rp is not None else batch["states"]
     cams, net, pr, ad = self.plan_proposal_obs_modalities, self.net, self.pr, self.ad
     opts = getattr(self, "_optimizers", None)
     if opts and opts[0].lr != self.lr:  # lr edited on the optimiser (scheduler): a launch argument -> new captures
         self.lr, self._graphs = opts[0].lr, {}
-    B, T = next(iter(states.values())).shape[:2]
-    u8 = next(iter(states.values())).dtype == torch.uint8  # the dataset's uint8 HWC frames: normalised by the pack
-    if u8:
-        nchw = False
-    hw = {c: (tuple(v.shape[-2:]) if nchw else tuple(v.shape[-3:-1])) for c, v in states.items()}
+    if rp is not None:
+        B, T, u8, nchw = rp["B"], rp["T"], True, False
+        hw = {c: tuple(v.shape[1:3]) for c, v in states.items()}
+    else:
+        B, T = next(iter(states.values())).shape[:2]
+        u8 = next(iter(states.values())).dtype == torch.uint8  # the dataset's uint8 HWC frames: normalised by the pack
+        if u8:
+            nchw = False
+        hw = {c: (tuple(v.shape[-2:]) if nchw else tuple(v.shape[-3:-1])) for c, v in states.items()}
     _playlmp_ensure(self, B, T, hw)
     R, Ec, A, cd = B * T, 32 * len(cams), pr.A, self.compute
     xd = BF16 if self.img_dtype == torch.bfloat16 else F32
@@ -227,7 +232,17 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
         H, W = hw[c]
         v = states[c].to(self.dev)
         aug = batch.get("aug") if u8 else None
-        if aug is not None:  # train-time augmentations on the way in, draws as device tables
+        if rp is not None:  # window frames by index straight out of the dataset: gather + pack in one pass
+            ids = rp["ids"]
+            job = (v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), R, ids.data_ptr(), 1)
+            if aug is None:
+                ops.pack_images_u8_gather_batch([job], xd, H, W)
+            else:
+                st = aug["states"][c]
+                flat = lambda t: None if t is None else t.reshape(R, t.shape[-1]).contiguous()  # noqa: E731
+                ops.pack_images_u8_gather_batch([job + (flat(st.get("shift")), flat(st.get("jitter")))], xd, H, W,
+                                                pad=aug["pad"][c])
+        elif aug is not None:  # train-time augmentations on the way in, draws as device tables
             st = aug["states"][c]
             flat = lambda t: None if t is None else t.reshape(R, t.shape[-1]).contiguous()  # noqa: E731
             ops.pack_images_u8_aug_batch([(v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), R, flat(st.get("shift")),
@@ -266,6 +281,11 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
     # (a graph replay runs no python: announce the optimiser's writes to torch's version counters - ops.touched)
     self._stepped_blocks = (lambda: [net.param, pr.blk.param, ad.blk.param]) if optimize else None
     self._run_segments(("playlmp", B, T, tuple(sorted(hw.items())), optimize, self._pr_train), [fwd_bwd, opt], [reduce_grads])
+    # metrics cross to the host (a device synchronisation) only on logging steps - Trainer(log_every_n_steps), as the
+    # other two modules do; in between the step returns the last total it read
+    self._step_count += 1
+    if optimize and self.log_every_n_steps > 1 and self._step_count % self.log_every_n_steps:
+        return self.__dict__.get("_last_total")
     lg = self.logs.cpu().tolist()
     names = ["kl_loss", "kl_loss_scaled", "action_loss", "gripper_accuracy", "random_plan_action_loss",
              "random_plan_gripper_accuracy"]
@@ -273,6 +293,7 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
         self.log(f"{log_type}/{k}", v, on_step=True, on_epoch=True, sync_dist=True)
     total = lg[1] + lg[2]
     self.log(f"{log_type}/total_loss", total, on_step=True, on_epoch=True, sync_dist=True)
+    self.__dict__["_last_total"] = total
     return total
 
 

@@ -139,12 +139,18 @@ class TACORL(CQL_Offline):
         fixed buffers, copy the small tensors, draw / copy the noise.
         uint8 frames - the dataset's own format, (B, T, H, W, 3) with goal (B, H, W, 3) - are taken as they are
         and normalised on the way (ToTensor + Normalize(0.5, 0.5), bit-identical to the transformed fp32 frames)."""
-        states = batch["states"]
-        u8 = next(iter(states.values())).dtype == torch.uint8
-        if u8:
-            nchw = False
-        B, T = next(iter(states.values())).shape[:2]
-        hw = {c: (tuple(v.shape[-2:]) if nchw else tuple(v.shape[-3:-1])) for c, v in states.items()}
+        rp = batch.get("replay")  # frames by index out of a uint8 dataset (data/replay.py HbmReplay.batch(fused=True))
+        if rp is not None:
+            u8, nchw, B, T = True, False, rp["B"], rp["T"]
+            states = rp["frames"]
+            hw = {c: tuple(v.shape[1:3]) for c, v in states.items()}
+        else:
+            states = batch["states"]
+            u8 = next(iter(states.values())).dtype == torch.uint8
+            if u8:
+                nchw = False
+            B, T = next(iter(states.values())).shape[:2]
+            hw = {c: (tuple(v.shape[-2:]) if nchw else tuple(v.shape[-3:-1])) for c, v in states.items()}
         self.engine.extra_normal = {"eps_pr": (B, self.action_dim)}  # drawn with the engine's noise (one launch)
         self.engine.ensure_batch(B, {c: hw[c] for c in self.engine.cams})
         self.eps_pr = self.engine.extra_noise["eps_pr"]
@@ -169,6 +175,32 @@ class TACORL(CQL_Offline):
             v = states[c]
             sz = 1 if u8 else 4  # bytes per source element
             assert v.is_cuda and v.is_contiguous() and v.dtype == (torch.uint8 if u8 else torch.float32)
+            if rp is not None:
+                # image i of a job = dataset frame ids[i * stride]: the window (stride 1), obs = ids[b T], goal = the table's
+                # tail, next = ids[b T + T - 1] - gather and pack in one pass over the dataset
+                ids, fb = rp["ids"], 3 * H * W
+                assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == B * T + B
+                ip = ids.data_ptr()
+                jobs = [(v.data_ptr(), fb, self.frames[c].data_ptr(), B * T, ip, 1)] if c in self.all_modalities else []
+                if c in e.cams:
+                    esz, x3 = e.X3[c].element_size(), e.X3[c].data_ptr()
+                    jobs += [(v.data_ptr(), fb, x3, B, ip, T), (v.data_ptr(), fb, x3 + B * fb * esz, B, ip + 8 * B * T, 1),
+                             (v.data_ptr(), fb, x3 + 2 * B * fb * esz, B, ip + 8 * (T - 1), T)]
+                if fb % 16 or v.data_ptr() % 16:
+                    raise ValueError("uint8 dataset: H*W*3 must be a multiple of 16 and the tensor 16-byte aligned")
+                aug = batch.get("aug")
+                if aug is None:
+                    ops.pack_images_u8_gather_batch(jobs, xd, H, W)
+                else:
+                    st, gl = aug["states"][c], aug["goal"][c]
+                    sh, ji = st.get("shift"), st.get("jitter")
+                    row = lambda t, k: None if t is None else t[:, k].contiguous()  # noqa: E731
+                    flat = lambda t: None if t is None else t.reshape(B * T, t.shape[-1]).contiguous()  # noqa: E731
+                    tabs = [(flat(sh), flat(ji))] if c in self.all_modalities else []
+                    if c in e.cams:
+                        tabs += [(row(sh, 0), row(ji, 0)), (gl.get("shift"), gl.get("jitter")), (row(sh, T - 1), row(ji, T - 1))]
+                    ops.pack_images_u8_gather_batch([j + t for j, t in zip(jobs, tabs)], xd, H, W, pad=aug["pad"][c])
+                continue
             jobs = [(v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), B * T)] if c in self.all_modalities else []
             if c in e.cams:
                 g = batch["goal"][c]

@@ -216,6 +216,20 @@ def pack_images_u8_aug_batch(jobs, dst_dtype_flag, H, W, pad):
          int_array([j[3] for j in jobs]), dst_dtype_flag, H, W, int(pad), stream())
 
 
+def pack_images_u8_gather_batch(jobs, dst_dtype_flag, H, W, pad=None):
+    """jobs: [(dataset_ptr, frame_bytes, dst_ptr, n_images, index_ptr (device int64) or None, index_stride[, shift, jitter])]:
+    image i = dataset frame index[i * stride], normalised (pad given: augmented, with the per-image tables) on the way
+    into the NHWC image buffers - the replay gather and the pack in one pass."""
+    k = len(jobs)
+    base = [k, (C.c_void_p * k)(*[j[0] for j in jobs]), (C.c_long * k)(*[j[1] for j in jobs]),
+            (C.c_void_p * k)(*[j[4] for j in jobs]), int_array([j[5] for j in jobs]), (C.c_void_p * k)(*[j[2] for j in jobs])]
+    if pad is None:
+        call("tacorl_pack_images_u8_gather_batch", *base, int_array([j[3] for j in jobs]), dst_dtype_flag, H, W, stream())
+    else:
+        call("tacorl_pack_images_u8_aug_gather_batch", *base, ptr_array([j[6] for j in jobs]), ptr_array([j[7] for j in jobs]),
+             int_array([j[3] for j in jobs]), dst_dtype_flag, H, W, int(pad), stream())
+
+
 def gather_frames_u8(frames, index, out):
     """out[i] = frames[index[i]] (uint8 frames resident in HBM, device int64 index)."""
     fb = frames[0].numel()

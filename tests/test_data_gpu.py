@@ -115,3 +115,46 @@ def test_hbm_and_pinned_replay_feed_the_step():
         torch.cuda.synchronize()
         outs.append(dict(m.logged))
     assert outs[0] == outs[1] and all(v == v for v in outs[0].values()) and outs[0] != ma.logged
+
+
+def test_fused_replay_batch_equals_gathered_batch():
+    """HbmReplay.batch(fused=True): the module's image pack reads the frames by index out of the dataset
+    (tacorl_pack_images_u8_gather_batch) - bit for bit the step of the gathered uint8 batch, for TACORL and PlayLMP,
+    plain and augmented."""
+    from tacorl_amd.data.augment import AugmentSpec, draw_play_batch_augmentation
+    from tacorl_amd.data.replay import HbmReplay, PlayIndex
+    from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
+    from tests import cfg_util as C
+    from tests.test_fullsize_gpu import _mod
+
+    frames, acts = _dataset()
+    ix = PlayIndex([[0, 199], [200, 399]], 16, 16, goal_sampling_prob=0.3)
+    rng = np.random.default_rng(1)
+    B, T = 16, 16
+    idx, draws = rng.integers(len(ix), size=B), ix.draw(B, rng)
+    hbm = HbmReplay({"rgb_static": frames}, acts, ix, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(12)
+    aug = draw_play_batch_augmentation({"rgb_static": AugmentSpec(pad=4)}, B, T, DEV, g)
+    strip = lambda c: {k: v for k, v in c.items() if k not in ("_target_", "_recursive_")}  # noqa: E731
+
+    def tacorl():
+        return _mod("bf16")
+
+    def playlmp():
+        torch.manual_seed(3)
+        return PlayLMP(**strip(C.playlmp_cfg(device="cuda:0", compute_dtype="bf16", image_dtype="bf16")))
+
+    for build, args in ((tacorl, ()), (playlmp, (0,))):
+        for a in (None, aug):
+            outs, imgs = [], []
+            for fused in (False, True):
+                m = build()
+                b = hbm.batch(idx, draws, aug=a, fused=fused)
+                assert ("replay" in b) == fused and ("states" in b) != fused
+                torch.manual_seed(7); torch.cuda.manual_seed(7)
+                m.training_step(b, *args)
+                torch.cuda.synchronize()
+                outs.append(dict(m.logged))
+                imgs.append({c: t.clone() for c, t in m.frames.items()})
+            assert outs[0] == outs[1] and all(v == v for v in outs[0].values()), (build.__name__, a is not None, outs)
+            assert all(torch.equal(imgs[0][c], imgs[1][c]) for c in imgs[0]), "window frames differ"

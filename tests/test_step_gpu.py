@@ -317,6 +317,30 @@ def test_hipgraph_survives_batch_size_changes(kind):
     assert worst < 1e-6, worst
 
 
+def test_captured_graphs_are_capped(monkeypatch):
+    """A job that alternates step shapes (train / validation, phase switch) keeps at most TACORL_MAX_GRAPHS captured
+    steps, least recently used first out, and a re-captured key still computes the same step."""
+    monkeypatch.setenv("TACORL_MAX_GRAPHS", "2")
+    g = Golden("tacorl_q")
+    mod, ref = build_tacorl(g), build_tacorl(g)
+    for m in (mod, ref):
+        m.load_state_dict(g.params(), strict=False)
+        m.current_epoch = g.cfg["epoch"]
+    mod.enable_graph()
+    b, nz = to_dev(g.batch(0), mod.device), to_dev(g.noise(0), mod.device)
+    # four keys: Q-phase train, validation, BC-phase train, BC-phase validation, then the first one again (evicted by then)
+    plan = [(5, True), (5, False), (0, True), (0, False), (5, True), (5, True)]
+    for epoch, train in plan:
+        for m in (mod, ref):
+            m.current_epoch = epoch
+            m.logged = {}
+            (m.training_step if train else m.validation_step)(b, noise=nz)
+        torch.cuda.synchronize()
+        assert len(mod._graphs) <= 2, list(mod._graphs)
+        bad = [k for k in mod.logged if abs(mod.logged[k] - ref.logged[k]) > 1e-6 * max(abs(ref.logged[k]), 1e-3)]
+        assert mod.logged.keys() == ref.logged.keys() and not bad, (epoch, train, bad)
+
+
 @pytest.mark.parametrize("name", ["tacorl_q", "tacorl_bc_ad"])
 def test_tacorl_step_bf16_mode(name):
     """The benchmark's compute mode (bf16 MFMA operands, fp32 accumulate / master weights, every fused
