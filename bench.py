@@ -93,12 +93,58 @@ def time_encoder_fwd(mod, B, H, W, iters=100):
     return ms, n_img, fused
 
 
+def time_encoder_in_step(mod, batch, steps=40):
+    """The same launch timed where it runs: HIP events around the encoder-forward launch INSIDE training steps (eager
+    replays of the step, events on the stream the launch is issued on).  The chip holds a higher clock for a kernel
+    that sits between the step's lighter phases than for 100 copies of it back to back (rocprofv3 kernel trace of this
+    command, profiles/: 126.7 us in the step, 135-145 us in the back-to-back probe) - this is the duration the step pays.
+    An event bracket also contains the launch gaps on either side of the kernel (6.9 us around a 1-thread kernel on a
+    busy stream, scratch/event_overhead.py), so every step brackets a 1-thread time-mark launch right behind the
+    encoder's: kernel duration = encoder bracket - (time-mark bracket - 2.4 us).  The 2.4 us calibrate the bracket against
+    rocprofv3's kernel trace of the same launches (profiles/r03_encoder_launches.json: 128.0 us there, 127.9 us here).
+    Returns (kernel ms, raw bracket ms, bracket overhead ms)."""
+    from tacorl_amd import ops
+    from tacorl_amd._lib import call, ptr
+
+    e = mod.engine
+    if not all(e._fused_ok(c) for c in e.cams):
+        return None
+    pairs, orig, was_graph = [], e._launch_fused, mod._use_graph
+    mark = torch.zeros(8, dtype=torch.int64, device=mod.device)
+
+    def timed(c, pr):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        orig(c, pr)
+        ev[1].record()
+        call("tacorl_time_mark", ptr(mark), 0, ops.stream())
+        ev[2].record()
+        pairs.append(ev)
+
+    mod._use_graph = False
+    try:
+        for _ in range(5):
+            mod.training_step(batch)
+        e._launch_fused = timed
+        for _ in range(steps):
+            mod.training_step(batch)
+        torch.cuda.synchronize()
+    finally:
+        e._launch_fused, mod._use_graph = orig, was_graph
+    raw = sum(a.elapsed_time(b) for a, b, _ in pairs) / len(pairs)
+    null = sum(b.elapsed_time(c) for _, b, c in pairs) / len(pairs)
+    over = max(null - 2.4e-3, 0.0)
+    for _ in range(3):  # back on the captured path
+        mod.training_step(batch)
+    return raw - over, raw, over
+
+
 def measured_traffic(n_img, fused, dtype):
     """HBM bytes per launch of the roofline kernel from the committed PMC passes
-    (profiles/r02_fused_traffic.json: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of this
+    (profiles/r03_fused_traffic.json: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of this
     very command, gfx950 correction applied).  null when this run's launch is not the measured one."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_fused_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_fused_traffic.json")) as f:
             m = json.load(f)["bench_launch"]
     except (OSError, KeyError, ValueError):
         return None
@@ -204,6 +250,122 @@ def step_time_distribution(mod, batch, ms_guess, min_seconds=1.0, max_steps=4000
             "how": "hipEvent after every training_step on torch's current stream"}
 
 
+def time_other_configs(dev, dtype, budget_s=1.0):
+    """The other BASELINE configurations at full size on this GPU, ~1 s of timed steps each, so that their numbers sit in
+    the driver-timed JSON line instead of in prose: C3 (the default TACORL step: action-decoder fine-tuning on, B=256),
+    C4's per-GPU share (dual camera 128x128, window 32, latent 32, B = 512 / 8), C5 (CQL_Offline, discrete gripper, 32
+    action samples, B=1024) and C1's module (PlayLMP.training_step at B=32 and B=256).  hipGraph on, metrics read back
+    every 50 steps; `enc_frac` = the step's encoder-forward launch against the bf16 MFMA peak (13.918 MFLOP per 84x84
+    image; 128x128: 35.35 MFLOP)."""
+    from tacorl_amd import synth
+    from tacorl_amd.modules.cql.cql_offline_lightning import CQL_Offline
+    from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
+    from tacorl_amd.modules.tacorl.tacorl import TACORL
+
+    actor = {"policy": {"num_layers": 3, "hidden_dim": 256}}
+    critic = {"q_network": {"num_layers": 3, "hidden_dim": 256, "last_layer_activation": "Identity"}}
+    yaml = dict(action_decoder_lr=3e-4, actor_lr=1e-4, critic_lr=3e-4, discount=0.95, conservative_weight=1.0,
+                reward_scale=10.0, n_action_samples=4, with_lagrange=True, deterministic_backup=True, bc_epochs=5)
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+
+    def lmp(cams, T, latent):
+        pr = dict(num_heads=8, num_layers=2, encoder_hidden_size=2048, fc_hidden_size=4096, latent_plan_dim=latent,
+                  min_std=1e-4, dropout_p=0.0, max_position_embeddings=T)
+        ad = dict(n_mixtures=10, num_layers=2, hidden_size=2048, out_features=7, num_classes=10, latent_plan_dim=latent,
+                  rnn_model="rnn_decoder", include_goal=False)
+        torch.manual_seed(PARAM_SEED)
+        return PlayLMP(plan_proposal=actor, plan_recognition=pr, action_decoder=ad, plan_proposal_obs_modalities=cams,
+                       plan_proposal_goal_modalities=cams, plan_recognition_modalities=cams, action_decoder_modalities=cams,
+                       real_world=True, device=dev, compute_dtype=dtype, image_dtype=dtype)
+
+    def play_batch(B, T, cams):
+        g = torch.Generator(device=dev).manual_seed(DATA_SEED + 7)
+        u = lambda *s: torch.rand(*s, device=dev, generator=g) * 2 - 1  # noqa: E731
+        acts = u(B, T, 7)
+        acts[..., -1] = torch.where(acts[..., -1] >= 0, 1.0, -1.0)
+        disp = torch.empty(B, device=dev).geometric_(0.3, generator=g).long()
+        return {"states": {c: u(B, T, 3, h, w) for c, (h, w) in cams.items()}, "goal": {c: u(B, 3, h, w) for c, (h, w) in cams.items()},
+                "actions": acts, "disp": disp}
+
+    def run(mod, batch, args, B, flop_per_img=None):
+        mod.enable_graph()
+        mod.log_every_n_steps = 50
+        for _ in range(5):
+            mod.training_step(batch, *args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            mod.training_step(batch, *args)
+        torch.cuda.synchronize()
+        est = (time.perf_counter() - t0) / 10
+        n = int(min(max(budget_s / est, 20), 2000))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            mod.training_step(batch, *args)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        res = {"ms_per_step": round(ms, 4), "samples_per_s": round(B / ms * 1e3, 1), "steps": n, "batch": B}
+        eng = getattr(mod, "engine", None)
+        if eng is not None and flop_per_img and all(eng._fused_ok(c) for c in eng.cams):
+            for _ in range(5):
+                n_img = eng.encode_fused_only()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(50):
+                eng.encode_fused_only()
+            ev1.record()
+            torch.cuda.synchronize()
+            ems = ev0.elapsed_time(ev1) / 50
+            res.update(enc_ms=round(ems, 4), enc_images=n_img, enc_frac=round(n_img * flop_per_img / (ems * 1e-3) / 1e12 / peak, 4))
+        fin = getattr(eng, "logs", getattr(mod, "logs", None))
+        res["losses_finite"] = bool(torch.isfinite(fin).all().item()) if fin is not None else None
+        return res
+
+    def release(mod):
+        # drop the module's captured graphs NOW: a process that accumulates dozens of live instantiated hipGraphs
+        # segfaults in hipGraphLaunch on ROCm 7.2 (the test suite does the same after every test)
+        import gc
+
+        torch.cuda.synchronize()
+        mod._graphs = {}
+        del mod
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    out = {}
+    cams84, cams128 = {"rgb_static": (84, 84)}, {"rgb_gripper": (128, 128), "rgb_static": (128, 128)}
+    m = TACORL(play_lmp=lmp(["rgb_static"], 16, 16), finetune_action_decoder=True, critic=critic, real_world=True, device=dev,
+               compute_dtype=dtype, image_dtype=dtype, **yaml)
+    m.current_epoch = 5
+    out["c3_tacorl_finetune_b256"] = run(m, play_batch(256, 16, cams84), (), 256, ENC_FLOP_PER_IMG_84)
+    release(m)
+    del m
+    m = TACORL(play_lmp=lmp(sorted(cams128), 32, 32), finetune_action_decoder=False, critic=critic, real_world=True, device=dev,
+               compute_dtype=dtype, image_dtype=dtype, **yaml)
+    m.current_epoch = 5
+    out["c4_share_dualcam128_b64"] = run(m, play_batch(64, 32, cams128), (), 64, 35.353e6)  # 2 * 17 676 288 MAC per 128x128 image
+    release(m)
+    del m
+    m = CQL_Offline(actor=dict(actor, discrete_gripper=True), critic=critic, real_world=True, obs_modalities=["rgb_static"],
+                    goal_modalities=["rgb_static"], action_dim=7, device=dev, compute_dtype=dtype, image_dtype=dtype,
+                    discount=0.99, actor_lr=1e-4, critic_lr=3e-4, conservative_weight=1.0, n_action_samples=32,
+                    with_lagrange=True, reward_scale=10.0, deterministic_backup=False, bc_epochs=5)
+    m.current_epoch = 5
+    tb = synth.make_transition_batch(7, 1024, cams84)
+    to_dev = lambda x: {k: to_dev(v) for k, v in x.items()} if isinstance(x, dict) else (x.to(dev) if torch.is_tensor(x) else x)  # noqa: E731
+    out["c5_cql_n32_b1024"] = run(m, to_dev(tb), (0,), 1024, ENC_FLOP_PER_IMG_84)
+    release(m)
+    del m, tb
+    for Bp in (32, 256):
+        m = lmp(["rgb_static"], 16, 16)
+        out[f"c1_playlmp_b{Bp}"] = run(m, play_batch(Bp, 16, cams84), (0,), Bp)
+        release(m)
+        del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def time_feeder(mod, a, B, T, H, W, dev, barrier, max_over_ranks, n_frames=40000):
     """The step fed by the replay data path instead of a resident batch: per step the host samples window / goal
     indices (PlayIndex, the reference's PlayDataset logic), the frames come out of the uint8 dataset (HBM gather, or
@@ -264,6 +426,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-distribution", action="store_true", help="skip the per-step HIP-event statistics")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the ~10 s `configs` block (C3 / C4 share / C5 / PlayLMP / hbm feeder after the headline region)")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous + one host all-reduce only (launcher test)")
     ap.add_argument("--ad-every", type=int, default=1,
                     help="evaluate the (logging-only, frozen) action-decoder loss every k-th step; 1 = every step "
@@ -344,6 +508,10 @@ def main():
     logs = mod.engine.metrics()
     finite = all(v == v and abs(v) < 1e30 for v in logs.values())
     dist_stats = None if a.no_distribution else step_time_distribution(mod, batch, ms_step)
+    # the roofline probe of the dominant kernel, taken here - straight behind the timed steps, the chip in the clock state
+    # the step runs in (behind the other blocks below, after a module teardown, the same launch read up to 8 % slower)
+    enc_probe = time_encoder_fwd(mod, B, H, W) if rank == 0 else None
+    enc_in_step = time_encoder_in_step(mod, batch) if rank == 0 else None
 
     def replicas_in_sync():
         e = mod.engine
@@ -373,10 +541,27 @@ def main():
         feeder = time_feeder(mod, a, B, T, H, W, dev, barrier, max_over_ranks)
         for _ in range(3):
             mod.training_step(batch)
+    configs = None
+    if world == 1 and not a.no_configs and a.frames == "f32" and not a.launch_check:
+        # (after the contract's timed region; `value` is untouched)
+        configs = {}
+        if a.feeder == "none":
+            fa = argparse.Namespace(**{**vars(a), "feeder": "hbm", "steps": min(a.steps, 200), "warmup": 10})
+            f = time_feeder(mod, fa, B, T, H, W, dev, barrier, max_over_ranks)
+            configs["c2_fed_from_hbm_replay"] = {k: f[k] for k in ("ms_per_step", "steps_per_s", "dataset_frames", "bytes_per_step_uint8")}
+            for _ in range(3):
+                mod.training_step(batch)
+        try:
+            configs.update(time_other_configs(dev, a.dtype))
+        except Exception as e:  # the headline line must survive a failure here
+            configs["error"] = f"{type(e).__name__}: {e}"
+        for _ in range(3):
+            mod.training_step(batch)
 
     out = None
     if rank == 0:
-        enc_ms, n_img, fused = time_encoder_fwd(mod, B, H, W)
+        b2b_ms, n_img, fused = enc_probe
+        enc_ms = enc_in_step[0] if (fused and enc_in_step is not None) else b2b_ms
         tflops = n_img * ENC_FLOP_PER_IMG_84 / (enc_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
         out = {
@@ -399,6 +584,7 @@ def main():
             "step_time": dist_stats,
             "strong": strong,
             "feeder": feeder,
+            "configs": configs,
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tflops / peak, 4), "traffic": measured_traffic(n_img, fused, a.dtype),
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
@@ -406,7 +592,13 @@ def main():
                                     "(all 27*B encoder images: frozen LMP B*T frames, actor/q1/q2 over "
                                     "[obs;goal], actor(next), both targets)") if fused else
                                    "LMPVisionEncoder forward, per-layer kernels (tacorl_encoder_fwd)",
-                         "images_per_launch": n_img, "avg_ms": round(enc_ms, 4)},
+                         "images_per_launch": n_img, "avg_ms": round(enc_ms, 4),
+                         "how": ("HIP events around the launch inside 40 training steps (eager replays of the step), "
+                                 "minus the bracket's launch gaps measured on a 1-thread launch right behind it"
+                                 if (fused and enc_in_step is not None) else "HIP events over 100 back-to-back launches"),
+                         "event_bracket_ms": round(enc_in_step[1], 4) if enc_in_step else None,
+                         "event_overhead_ms": round(enc_in_step[2], 4) if enc_in_step else None,
+                         "back_to_back_ms": round(b2b_ms, 4)},
         }
         if world == 1 and not a.no_cpu_baseline and a.frames == "f32":
             bc = {"states": {"rgb_static": batch["states"]["rgb_static"].cpu()},
