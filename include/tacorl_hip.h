@@ -275,6 +275,16 @@ int tacorl_pack_images_u8_aug_batch(int njobs, const void* const* src, const lon
                                     void* const* dst, const int* const* shift, const float* const* jitter,
                                     const int* n_img, int dst_dtype, int H, int W, int pad,
                                     tacorl_stream_t stream);
+/* The whole train pipeline of rl_train.yaml including its first stage, torchvision.transforms.Resize (:3-4,16-17: the
+ * 200x200 camera frames -> 128x128 static / 84x84 gripper): source frames src_H x src_W uint8 HWC (pitch = bytes per
+ * source frame), bilinear with align_corners = False and no antialias on the 0..255 values - what torchvision's
+ * tensor path computes through torch.nn.functional.interpolate - then RandomShiftsAug on the H x W result, x/255,
+ * ColorJitter, Normalize.  src_H == H and src_W == W: no resize (tacorl_pack_images_u8_aug_gather_batch). */
+int tacorl_pack_images_u8_resize_aug_gather_batch(int njobs, const void* const* src, const long* img_pitch_bytes,
+                                                  const long* const* index, const int* index_stride, void* const* dst,
+                                                  const int* const* shift, const float* const* jitter, const int* n_img,
+                                                  int dst_dtype, int src_H, int src_W, int H, int W, int pad,
+                                                  tacorl_stream_t stream);
 /* ... and the augmenting pack with the same optional frame-index tables (shift / jitter tables are per IMAGE i). */
 int tacorl_pack_images_u8_aug_gather_batch(int njobs, const void* const* src, const long* img_pitch_bytes,
                                            const long* const* index, const int* index_stride, void* const* dst,

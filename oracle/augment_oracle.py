@@ -1,8 +1,10 @@
 """CPU restatement of the reference's train-time image pipeline.  TEST INFRASTRUCTURE ONLY.
 
-config/datamodule/transform_manager/transforms/rl_train.yaml per camera (after the resize, which the synthetic
-post-resize inputs do not need): RandomShiftsAug(pad) -> ScaleImageTensor (x / 255) -> ColorTransform = torchvision
-ColorJitter(contrast, brightness, hue) -> Normalize(0.5, 0.5).
+config/datamodule/transform_manager/transforms/rl_train.yaml per camera: torchvision Resize -> RandomShiftsAug(pad) ->
+ScaleImageTensor (x / 255) -> ColorTransform = torchvision ColorJitter(contrast, brightness, hue) -> Normalize(0.5, 0.5).
+
+* resize_bilinear: torchvision's tensor Resize is torch.nn.functional.interpolate; PINNED against F.interpolate's own
+  outputs (tests/golden/resize.npz, oracle/gen_resize_golden.py).
 
 * random_shift: reference utils/transforms.py:265-299.  The reference builds a sampling grid whose points are, for an
   integer draw `shift = randint(0, 2 * pad + 1)`, exactly the pixel centres of the replicate-padded frame translated by
@@ -13,11 +15,41 @@ ColorJitter(contrast, brightness, hue) -> Normalize(0.5, 0.5).
 * color_jitter: torchvision is a third-party dependency that is ABSENT from this image (setup.cfg pins no version; the
   reference imports `torchvision.transforms.ColorJitter`).  The functions below restate the published algorithm of
   torchvision.transforms.v1 ColorJitter.forward and _functional_tensor.py (adjust_brightness / adjust_contrast /
-  adjust_hue with _rgb2hsv / _hsv2rgb, float images in [0, 1]).  PARITY UNPINNED for this part: there is no reference
-  output to compare with here.
+  adjust_hue with _rgb2hsv / _hsv2rgb, float images in [0, 1]).  There is no torchvision output to compare with here
+  (PARITY UNPINNED against torchvision itself); tests/golden/jitter.npz pins it against an INDEPENDENT evaluation of the
+  documented formulas - per-pixel python / colorsys-style arithmetic in fp64, oracle/gen_jitter_golden.py - including the
+  edge cases: grey pixels and frames (hue undefined, saturation 0), pixels on sextant borders, clamping at 0 and 1.
 Every random draw is an explicit argument.
 """
 import torch
+
+
+def resize_bilinear(frames, size):
+    """torchvision.transforms.Resize(size) on float tensors (rl_train.yaml:3-4,16-17; the reference's torchvision
+    generation: bilinear, no antialias) = torch.nn.functional.interpolate(mode="bilinear", align_corners=False), i.e.
+    ATen's upsample_bilinear2d: src = max(scale (dst + 0.5) - 0.5, 0) with scale = in / out in fp32, the two
+    neighbours i0 = floor(src), i1 = i0 + (i0 < in - 1), weights l1 = src - i0, l0 = 1 - l1, and the blend
+    h0 (w0 p00 + w1 p01) + h1 (w0 p10 + w1 p11).  PINNED: tests/golden/resize.npz holds F.interpolate's own outputs
+    (oracle/gen_resize_golden.py).  frames (n,H,W,C) uint8 / float -> (n,size[0],size[1],C) fp32 (0..255 scale kept)."""
+    x = frames.to(torch.float32)
+    n, H, W, C = x.shape
+    oh, ow = size
+
+    def axis(out, inn):
+        scale = torch.tensor(inn / out, dtype=torch.float32)
+        src = torch.clamp(scale * (torch.arange(out, dtype=torch.float32) + 0.5) - 0.5, min=0.0)
+        i0 = src.floor().to(torch.int64).clamp(max=inn - 1)
+        i1 = i0 + (i0 < inn - 1).to(torch.int64)
+        l1 = src - i0.to(torch.float32)
+        return i0, i1, 1.0 - l1, l1
+
+    y0, y1, h0, h1 = axis(oh, H)
+    x0, x1, w0, w1 = axis(ow, W)
+    w0, w1 = w0.view(1, 1, ow, 1), w1.view(1, 1, ow, 1)
+    h0, h1 = h0.view(1, oh, 1, 1), h1.view(1, oh, 1, 1)
+    top = w0 * x[:, y0][:, :, x0] + w1 * x[:, y0][:, :, x1]
+    bot = w0 * x[:, y1][:, :, x0] + w1 * x[:, y1][:, :, x1]
+    return h0 * top + h1 * bot
 
 
 def random_shift(frames, shift, pad):
@@ -103,10 +135,13 @@ def color_jitter(img, brightness_factor, contrast_factor, hue_factor, order):
     return img
 
 
-def train_pipeline(frames_u8, shift=None, jitter=None, pad=0):
+def train_pipeline(frames_u8, shift=None, jitter=None, pad=0, resize=None):
     """uint8 HWC frames (n,H,W,3) -> normalised fp32 NHWC, as the dataloader's transform chain produces them
-    (channels-last here; the reference's tensors are CHW).  jitter (n,8): {b, c, h, order0..3, apply}."""
+    (channels-last here; the reference's tensors are CHW).  jitter (n,8): {b, c, h, order0..3, apply};
+    resize = (H, W): torchvision Resize first, on the 0..255 float frame."""
     x = frames_u8
+    if resize is not None:
+        x = resize_bilinear(x, resize)
     if shift is not None:
         x = random_shift(x, shift, pad)
     x = x.to(torch.float32) / 255.0

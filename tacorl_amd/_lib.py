@@ -101,6 +101,7 @@ _SIGS = {
     "tacorl_pack_images_u8_batch": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_pack_images_u8_gather_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_pack_images_u8_aug_gather_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "tacorl_pack_images_u8_resize_aug_gather_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "tacorl_gather_frames_u8": (_i, [_p, _l, _p, _p, _l, _p]),
     "tacorl_pack_images_u8_aug_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "tacorl_stage_transition": (_i, [_p, _i, _p, _p, _i, _p, _p, _l, _p]),

@@ -74,8 +74,22 @@ struct AugTbl { AugJob j[AUG_MAXJ]; };
 // One workgroup per image.  RandomShiftsAug with integer shifts = a clamped (replicate-padded) translation; the
 // colour operations run in the drawn order; adjust_contrast needs the image's mean grey level AFTER the operations
 // that precede it, hence the first pass (a block reduction) when contrast is drawn.
+// torchvision.transforms.Resize on a float tensor = torch.nn.functional.interpolate(mode="bilinear", align_corners=False),
+// no antialias (the reference's torchvision generation; rl_train.yaml:3-4,16-17: 200x200 -> 128x128 static, -> 84x84
+// gripper, applied to the 0..255 float frame BEFORE RandomShiftsAug): ATen's upsample_bilinear2d,
+//   src = max(scale * (dst + 0.5) - 0.5, 0), scale = in / out (fp32); i0 = floor(src), i1 = i0 + (i0 < in - 1);
+//   l1 = src - i0, l0 = 1 - l1;  out = h0 * (w0 * p00 + w1 * p01) + h1 * (w0 * p10 + w1 * p11)
+__device__ __forceinline__ void bilinear_axis(int dst, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+  const float src = fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
 template <typename OutT>
-__global__ __launch_bounds__(256) void pack_u8_aug_kernel(AugTbl t, int H, int W, int pad) {
+__global__ __launch_bounds__(256) void pack_u8_aug_kernel(AugTbl t, int H, int W, int pad, int Hs, int Ws) {
   const AugJob jb = t.j[blockIdx.y];
   const int img = blockIdx.x;
   if (img >= jb.n) return;
@@ -99,11 +113,27 @@ __global__ __launch_bounds__(256) void pack_u8_aug_kernel(AugTbl t, int H, int W
     jit = p[7] != 0.f;
   }
   const int npx = H * W;
+  const bool resize = Hs != H || Ws != W;
+  const float sch = (float)Hs / (float)H, scw = (float)Ws / (float)W;
   auto load = [&](int px, float& r, float& g, float& b) {
     const int y = px / W, x = px - y * W;
-    const int ys = min(max(y + sy, 0), H - 1), xs = min(max(x + sx, 0), W - 1);
-    const unsigned char* s = src + ((long)ys * W + xs) * 3;
-    r = (float)s[0] / 255.0f; g = (float)s[1] / 255.0f; b = (float)s[2] / 255.0f;  // ScaleImageTensor / ToTensor
+    const int ys = min(max(y + sy, 0), H - 1), xs = min(max(x + sx, 0), W - 1);  // RandomShiftsAug on the (resized) frame
+    if (!resize) {
+      const unsigned char* s = src + ((long)ys * W + xs) * 3;
+      r = (float)s[0] / 255.0f; g = (float)s[1] / 255.0f; b = (float)s[2] / 255.0f;  // ScaleImageTensor / ToTensor
+      return;
+    }
+    int y0, y1, x0, x1;
+    float h0, h1, w0, w1;
+    bilinear_axis(ys, sch, Hs, y0, y1, h0, h1);
+    bilinear_axis(xs, scw, Ws, x0, x1, w0, w1);
+    const unsigned char *p00 = src + ((long)y0 * Ws + x0) * 3, *p01 = src + ((long)y0 * Ws + x1) * 3,
+                        *p10 = src + ((long)y1 * Ws + x0) * 3, *p11 = src + ((long)y1 * Ws + x1) * 3;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+      v[c] = h0 * (w0 * (float)p00[c] + w1 * (float)p01[c]) + h1 * (w0 * (float)p10[c] + w1 * (float)p11[c]);
+    r = v[0] / 255.0f; g = v[1] / 255.0f; b = v[2] / 255.0f;
   };
   float mean = 0.f;
   if (jit) {
@@ -165,7 +195,17 @@ extern "C" int tacorl_pack_images_u8_aug_gather_batch(int njobs, const void* con
                                                       void* const* dst, const int* const* shift, const float* const* jitter,
                                                       const int* n_img, int dst_dtype, int H, int W, int pad,
                                                       tacorl_stream_t stream) {
-  if (njobs < 1 || njobs > AUG_MAXJ || H < 1 || W < 1 || pad < 0) return TACORL_EINVAL;
+  return tacorl_pack_images_u8_resize_aug_gather_batch(njobs, src, img_pitch_bytes, index, index_stride, dst, shift, jitter,
+                                                       n_img, dst_dtype, H, W, H, W, pad, stream);
+}
+extern "C" int tacorl_pack_images_u8_resize_aug_gather_batch(int njobs, const void* const* src, const long* img_pitch_bytes,
+                                                             const long* const* index, const int* index_stride,
+                                                             void* const* dst, const int* const* shift,
+                                                             const float* const* jitter, const int* n_img, int dst_dtype,
+                                                             int src_H, int src_W, int H, int W, int pad,
+                                                             tacorl_stream_t stream) {
+  const int Hs = src_H, Ws = src_W;
+  if (njobs < 1 || njobs > AUG_MAXJ || H < 1 || W < 1 || Hs < 1 || Ws < 1 || pad < 0) return TACORL_EINVAL;
   AugTbl t{};
   int m = 0, mx = 0;
   for (int j = 0; j < njobs; j++) {
@@ -181,8 +221,8 @@ extern "C" int tacorl_pack_images_u8_aug_gather_batch(int njobs, const void* con
   }
   if (m == 0) return TACORL_OK;
   if (dst_dtype == TACORL_BF16)
-    hipLaunchKernelGGL(pack_u8_aug_kernel<__bf16>, dim3(mx, m), dim3(256), 0, (hipStream_t)stream, t, H, W, pad);
+    hipLaunchKernelGGL(pack_u8_aug_kernel<__bf16>, dim3(mx, m), dim3(256), 0, (hipStream_t)stream, t, H, W, pad, Hs, Ws);
   else
-    hipLaunchKernelGGL(pack_u8_aug_kernel<float>, dim3(mx, m), dim3(256), 0, (hipStream_t)stream, t, H, W, pad);
+    hipLaunchKernelGGL(pack_u8_aug_kernel<float>, dim3(mx, m), dim3(256), 0, (hipStream_t)stream, t, H, W, pad, Hs, Ws);
   return LAUNCH_OK();
 }

@@ -8,8 +8,11 @@ class AugmentSpec:
     """One camera's train pipeline: RandomShiftsAug(pad) and ColorTransform(contrast, brightness, hue, prob)
     (rl_train.yaml: pad 6 / 4, contrast 0.1, brightness 0.1, hue 0.02)."""
 
-    def __init__(self, pad=4, brightness=0.1, contrast=0.1, hue=0.02, prob=1.0):
+    def __init__(self, pad=4, brightness=0.1, contrast=0.1, hue=0.02, prob=1.0, resize=None):
         self.pad, self.brightness, self.contrast, self.hue, self.prob = int(pad), brightness, contrast, hue, prob
+        # torchvision.transforms.Resize(size) ahead of the shift (rl_train.yaml:3-4,16-17: [128, 128] static, [84, 84]
+        # gripper): the dataset's frames keep their camera resolution and are resized by the same launch
+        self.resize = None if resize is None else (int(resize[0]), int(resize[1]))
 
     def draw(self, n, device, generator=None):
         """The reference's draws for n frames: shift = randint(0, 2*pad+1, (n,2)) (utils/transforms.py:288-290);
@@ -30,8 +33,10 @@ def draw_play_batch_augmentation(specs, B, T, device, generator=None):
     """batch["aug"] for a play batch: per camera a different draw for every frame of the window and for the goal frame,
     as the reference's dataset applies its transform to (T,3,H,W) windows and to the goal frame separately
     (play_dataset.py:405-412,246-247; RandomShiftsAug draws per leading index)."""
-    aug = {"states": {}, "goal": {}, "pad": {}}
+    aug = {"states": {}, "goal": {}, "pad": {}, "resize": {}}
     for cam, sp in specs.items():
+        if sp.resize is not None:
+            aug["resize"][cam] = sp.resize
         s, j = sp.draw(B * T, device, generator)
         aug["states"][cam] = {"shift": s.view(B, T, 2), "jitter": j.view(B, T, 8)}
         s, j = sp.draw(B, device, generator)

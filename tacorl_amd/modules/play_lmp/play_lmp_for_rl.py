@@ -151,11 +151,19 @@ def load_play_lmp(play_lmp_dir, epoch=-1, overwrite_cfg=None, device=None, compu
     cfg.update(overwrite_cfg or {})
     cfg.setdefault("real_world", True)
     mod = PlayLMP(device=device, compute_dtype=compute_dtype, image_dtype=image_dtype, **cfg)
+    import os
+
+    unsafe_pickle = unsafe_pickle or os.environ.get("TACORL_UNSAFE_PICKLE", "") not in ("", "0")
     try:
         sd = torch.load(ckpt, map_location="cpu", weights_only=True)
-    except Exception:
+    except Exception as e:
+        # real pytorch_lightning checkpoints carry hyper_parameters (an OmegaConf DictConfig) and callback state, which
+        # the weights-only unpickler rejects; loading them executes whatever the file's pickle stream says
         if not unsafe_pickle:
-            raise
+            raise RuntimeError(
+                f"{ckpt}: not loadable with torch.load(weights_only=True) ({type(e).__name__}: {e}).  If you trust the file, "
+                "pass TACORL(..., lmp_unsafe_pickle=True) / load_play_lmp(..., unsafe_pickle=True) or set "
+                "TACORL_UNSAFE_PICKLE=1 to unpickle it in full.") from e
         sd = torch.load(ckpt, map_location="cpu", weights_only=False)
     mod.load_state_dict(sd.get("state_dict", sd))
     return mod
@@ -211,6 +219,12 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
         if u8:
             nchw = False
         hw = {c: (tuple(v.shape[-2:]) if nchw else tuple(v.shape[-3:-1])) for c, v in states.items()}
+    src_hw = dict(hw)  # the frames as stored; an augmentation spec with a Resize stage sets the encoders' geometry
+    rs = (batch.get("aug") or {}).get("resize") or {}
+    if rs:
+        if not u8:
+            raise ValueError("aug['resize'] needs the dataset's uint8 frames (the resize is part of the uint8 pack)")
+        hw = {c: tuple(rs.get(c, hw[c])) for c in hw}
     _playlmp_ensure(self, B, T, hw)
     R, Ec, A, cd = B * T, 32 * len(cams), pr.A, self.compute
     xd = BF16 if self.img_dtype == torch.bfloat16 else F32
@@ -232,21 +246,23 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
         H, W = hw[c]
         v = states[c].to(self.dev)
         aug = batch.get("aug") if u8 else None
+        Hs, Ws = src_hw[c]
         if rp is not None:  # window frames by index straight out of the dataset: gather + pack in one pass
             ids = rp["ids"]
-            job = (v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), R, ids.data_ptr(), 1)
+            job = (v.data_ptr(), 3 * Hs * Ws, self.frames[c].data_ptr(), R, ids.data_ptr(), 1)
             if aug is None:
                 ops.pack_images_u8_gather_batch([job], xd, H, W)
             else:
                 st = aug["states"][c]
                 flat = lambda t: None if t is None else t.reshape(R, t.shape[-1]).contiguous()  # noqa: E731
-                ops.pack_images_u8_gather_batch([job + (flat(st.get("shift")), flat(st.get("jitter")))], xd, H, W,
-                                                pad=aug["pad"][c])
+                ops.pack_images_u8_resize_aug_batch([job + (flat(st.get("shift")), flat(st.get("jitter")))], xd, (Hs, Ws), H, W,
+                                                    aug["pad"][c])
         elif aug is not None:  # train-time augmentations on the way in, draws as device tables
             st = aug["states"][c]
             flat = lambda t: None if t is None else t.reshape(R, t.shape[-1]).contiguous()  # noqa: E731
-            ops.pack_images_u8_aug_batch([(v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), R, flat(st.get("shift")),
-                                           flat(st.get("jitter")))], xd, H, W, aug["pad"][c])
+            ops.pack_images_u8_resize_aug_batch([(v.data_ptr(), 3 * Hs * Ws, self.frames[c].data_ptr(), R, None, 1,
+                                                  flat(st.get("shift")), flat(st.get("jitter")))], xd, (Hs, Ws), H, W,
+                                                aug["pad"][c])
         elif u8:
             if (H * W * 3) % 16 or v.data_ptr() % 16 or not v.is_contiguous():
                 raise ValueError("uint8 frames: contiguous, 16-byte aligned, H*W*3 a multiple of 16")

@@ -30,6 +30,8 @@ class TACORL(CQL_Offline):
         # `action_loss_every_n_steps=k` that logging-only forward runs on every k-th step (match it to
         # Trainer(log_every_n_steps)); fine-tuning (`finetune_action_decoder=True`) always runs it.
         self.action_loss_every_n_steps = kwargs.pop("action_loss_every_n_steps", 1)
+        # opt-in to a full unpickle of the PlayLMP checkpoint (real PL checkpoints carry DictConfig hyper-parameters)
+        self.lmp_unsafe_pickle = bool(kwargs.pop("lmp_unsafe_pickle", False))
         self.__dict__["_play_lmp"] = play_lmp  # nn.Module: must not be registered as a sub-module
         super().__init__(*args, **kwargs)
 
@@ -41,7 +43,7 @@ class TACORL(CQL_Offline):
         lmp = self.__dict__.pop("_play_lmp", None)
         if lmp is None:
             lmp = load_play_lmp(self.play_lmp_dir, self.lmp_epoch_to_load, self.overwrite_lmp_cfg, device=self.dev,
-                                compute_dtype=self.compute, image_dtype=self.img_dtype)
+                                compute_dtype=self.compute, image_dtype=self.img_dtype, unsafe_pickle=self.lmp_unsafe_pickle)
         assert isinstance(lmp, PlayLMP)
         from .. import cfgcheck
 
@@ -151,6 +153,12 @@ class TACORL(CQL_Offline):
                 nchw = False
             B, T = next(iter(states.values())).shape[:2]
             hw = {c: (tuple(v.shape[-2:]) if nchw else tuple(v.shape[-3:-1])) for c, v in states.items()}
+        src_hw = dict(hw)  # the frames as stored; an augmentation spec with a Resize stage sets the encoders' geometry
+        rs = (batch.get("aug") or {}).get("resize") or {}
+        if rs:
+            if not u8:
+                raise ValueError("aug['resize'] needs the dataset's uint8 frames (the resize is part of the uint8 pack)")
+            hw = {c: tuple(rs.get(c, hw[c])) for c in hw}
         self.engine.extra_normal = {"eps_pr": (B, self.action_dim)}  # drawn with the engine's noise (one launch)
         self.engine.ensure_batch(B, {c: hw[c] for c in self.engine.cams})
         self.eps_pr = self.engine.extra_noise["eps_pr"]
@@ -178,14 +186,15 @@ class TACORL(CQL_Offline):
             if rp is not None:
                 # image i of a job = dataset frame ids[i * stride]: the window (stride 1), obs = ids[b T], goal = the table's
                 # tail, next = ids[b T + T - 1] - gather and pack in one pass over the dataset
-                ids, fb = rp["ids"], 3 * H * W
+                Hs, Ws = src_hw[c]
+                ids, fb = rp["ids"], 3 * Hs * Ws
                 assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == B * T + B
                 ip = ids.data_ptr()
                 jobs = [(v.data_ptr(), fb, self.frames[c].data_ptr(), B * T, ip, 1)] if c in self.all_modalities else []
                 if c in e.cams:
-                    esz, x3 = e.X3[c].element_size(), e.X3[c].data_ptr()
-                    jobs += [(v.data_ptr(), fb, x3, B, ip, T), (v.data_ptr(), fb, x3 + B * fb * esz, B, ip + 8 * B * T, 1),
-                             (v.data_ptr(), fb, x3 + 2 * B * fb * esz, B, ip + 8 * (T - 1), T)]
+                    esz, x3, ob = e.X3[c].element_size(), e.X3[c].data_ptr(), 3 * H * W  # (ob: elements per packed image)
+                    jobs += [(v.data_ptr(), fb, x3, B, ip, T), (v.data_ptr(), fb, x3 + B * ob * esz, B, ip + 8 * B * T, 1),
+                             (v.data_ptr(), fb, x3 + 2 * B * ob * esz, B, ip + 8 * (T - 1), T)]
                 if fb % 16 or v.data_ptr() % 16:
                     raise ValueError("uint8 dataset: H*W*3 must be a multiple of 16 and the tensor 16-byte aligned")
                 aug = batch.get("aug")
@@ -199,16 +208,18 @@ class TACORL(CQL_Offline):
                     tabs = [(flat(sh), flat(ji))] if c in self.all_modalities else []
                     if c in e.cams:
                         tabs += [(row(sh, 0), row(ji, 0)), (gl.get("shift"), gl.get("jitter")), (row(sh, T - 1), row(ji, T - 1))]
-                    ops.pack_images_u8_gather_batch([j + t for j, t in zip(jobs, tabs)], xd, H, W, pad=aug["pad"][c])
+                    ops.pack_images_u8_resize_aug_batch([j + t for j, t in zip(jobs, tabs)], xd, (Hs, Ws), H, W, aug["pad"][c])
                 continue
-            jobs = [(v.data_ptr(), 3 * H * W, self.frames[c].data_ptr(), B * T)] if c in self.all_modalities else []
+            Hs, Ws = src_hw[c]
+            simg = 3 * Hs * Ws  # elements of a source frame
+            jobs = [(v.data_ptr(), simg, self.frames[c].data_ptr(), B * T)] if c in self.all_modalities else []
             if c in e.cams:
                 g = batch["goal"][c]
                 assert g.is_cuda and g.is_contiguous() and g.dtype == v.dtype
                 esz, img = e.X3[c].element_size(), H * W * 3
                 x3 = e.X3[c].data_ptr()
-                jobs += [(v.data_ptr(), T * 3 * H * W, x3, B), (g.data_ptr(), 3 * H * W, x3 + B * img * esz, B),
-                         (v.data_ptr() + sz * (T - 1) * 3 * H * W, T * 3 * H * W, x3 + 2 * B * img * esz, B)]
+                jobs += [(v.data_ptr(), T * simg, x3, B), (g.data_ptr(), simg, x3 + B * img * esz, B),
+                         (v.data_ptr() + sz * (T - 1) * simg, T * simg, x3 + 2 * B * img * esz, B)]
             aug = batch.get("aug") if u8 else None
             if aug is not None:
                 # train-time augmentations on the way in: the draws arrive as device tables; the obs / next
@@ -221,7 +232,8 @@ class TACORL(CQL_Offline):
                 tabs = [(flat(sh), flat(ji))] if c in self.all_modalities else []
                 if c in e.cams:
                     tabs += [(row(sh, 0), row(ji, 0)), (gl.get("shift"), gl.get("jitter")), (row(sh, T - 1), row(ji, T - 1))]
-                ops.pack_images_u8_aug_batch([j + t for j, t in zip(jobs, tabs)], xd, H, W, aug["pad"][c])
+                ops.pack_images_u8_resize_aug_batch([j + (None, 1) + t for j, t in zip(jobs, tabs)], xd, (Hs, Ws), H, W,
+                                                    aug["pad"][c])
             elif u8:
                 if (H * W * 3) % 16 or any(j[0] % 16 for j in jobs):
                     raise ValueError("uint8 frames: H*W*3 must be a multiple of 16 and the tensors 16-byte aligned")

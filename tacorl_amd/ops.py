@@ -216,6 +216,17 @@ def pack_images_u8_aug_batch(jobs, dst_dtype_flag, H, W, pad):
          int_array([j[3] for j in jobs]), dst_dtype_flag, H, W, int(pad), stream())
 
 
+def pack_images_u8_resize_aug_batch(jobs, dst_dtype_flag, src_hw, H, W, pad):
+    """jobs: [(src_ptr, source_frame_bytes, dst_ptr, n_images, index_ptr or None, index_stride, shift or None, jitter or
+    None)]: uint8 HWC source frames of size src_hw -> Resize(H, W) -> RandomShiftsAug(pad) -> /255 -> ColorJitter ->
+    Normalize -> NHWC (the whole train pipeline of rl_train.yaml), one launch."""
+    k = len(jobs)
+    call("tacorl_pack_images_u8_resize_aug_gather_batch", k, (C.c_void_p * k)(*[j[0] for j in jobs]),
+         (C.c_long * k)(*[j[1] for j in jobs]), (C.c_void_p * k)(*[j[4] for j in jobs]), int_array([j[5] for j in jobs]),
+         (C.c_void_p * k)(*[j[2] for j in jobs]), ptr_array([j[6] for j in jobs]), ptr_array([j[7] for j in jobs]),
+         int_array([j[3] for j in jobs]), dst_dtype_flag, int(src_hw[0]), int(src_hw[1]), H, W, int(pad), stream())
+
+
 def pack_images_u8_gather_batch(jobs, dst_dtype_flag, H, W, pad=None):
     """jobs: [(dataset_ptr, frame_bytes, dst_ptr, n_images, index_ptr (device int64) or None, index_stride[, shift, jitter])]:
     image i = dataset frame index[i * stride], normalised (pad given: augmented, with the per-image tables) on the way

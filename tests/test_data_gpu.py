@@ -158,3 +158,73 @@ def test_fused_replay_batch_equals_gathered_batch():
                 imgs.append({c: t.clone() for c, t in m.frames.items()})
             assert outs[0] == outs[1] and all(v == v for v in outs[0].values()), (build.__name__, a is not None, outs)
             assert all(torch.equal(imgs[0][c], imgs[1][c]) for c in imgs[0]), "window frames differ"
+
+
+def _resize_pack(frames, size, shift, jitter, pad, dtype=torch.float32):
+    from tacorl_amd import _lib, ops
+
+    n, Hs, Ws, _ = frames.shape
+    H, W = size
+    out = torch.full((n, H, W, 3), float("nan"), device=DEV, dtype=dtype)
+    ops.pack_images_u8_resize_aug_batch([(frames.data_ptr(), Hs * Ws * 3, out.data_ptr(), n, None, 1, shift, jitter)],
+                                        _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, (Hs, Ws), H, W, pad)
+    torch.cuda.synchronize()
+    return out
+
+
+def test_resize_kernel_matches_interpolate_and_oracle():
+    """N3's first stage, torchvision Resize (rl_train.yaml:3-4,16-17): the kernel against F.interpolate's own outputs
+    (tests/golden/resize.npz) and the whole pipeline Resize -> shift -> /255 -> ColorJitter -> Normalize against the oracle."""
+    from oracle import augment_oracle as A
+    from tacorl_amd import _lib
+    from tacorl_amd.data.augment import AugmentSpec
+
+    _lib.call("tacorl_hip_init", 0)
+    R = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resize.npz"))
+    for tag in ("static", "gripper", "rect", "up"):
+        n, hs, ws, ht, wt, seed = (int(v) for v in R[f"{tag}/cfg"])
+        frames = torch.from_numpy(np.random.RandomState(seed).randint(0, 256, size=(n, hs, ws, 3)).astype(np.uint8)).to(DEV)
+        got = _resize_pack(frames, (ht, wt), None, None, 0)
+        ref = (torch.from_numpy(R[f"{tag}/out"]) / 255.0 - 0.5) / 0.5
+        assert (got.cpu() - ref).abs().max().item() < 1e-5, (tag, (got.cpu() - ref).abs().max().item())
+    g = torch.Generator(device=DEV).manual_seed(21)
+    frames = torch.randint(0, 256, (5, 200, 200, 3), device=DEV, dtype=torch.uint8, generator=g)
+    for size, pad in (((128, 128), 6), ((84, 84), 4)):
+        shift, jitter = AugmentSpec(pad=pad, brightness=0.3, contrast=0.3, hue=0.3).draw(5, DEV, g)
+        ref = A.train_pipeline(frames.cpu(), shift.cpu(), jitter.cpu(), pad, resize=size)
+        got = _resize_pack(frames, size, shift, jitter, pad)
+        assert (got.cpu() - ref).abs().max().item() < 5e-5, (size, (got.cpu() - ref).abs().max().item())
+
+
+def test_color_jitter_kernel_matches_independent_fp64_evaluation():
+    J = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jitter.npz"))
+    frames = torch.from_numpy(J["frames"]).to(DEV)
+    params = torch.from_numpy(J["params"]).to(DEV)
+    got = _pack(frames, None, params, 0, torch.float32)
+    ref = (torch.from_numpy(J["out"]) - 0.5) / 0.5
+    d = (got.cpu().double() - ref).abs()
+    assert d.max().item() < 2e-5, d.max().item()
+
+
+def test_step_with_resizing_augmentation():
+    """A TACORL step fed 200x200 uint8 frames with the real-world train pipeline (Resize 84 + shift + jitter): the module
+    adopts the resized geometry and the images it encodes are the oracle's."""
+    from oracle import augment_oracle as A
+    from tacorl_amd.data.augment import AugmentSpec, draw_play_batch_augmentation
+    from tests.test_fullsize_gpu import _mod
+
+    B, T = 4, 16
+    g = torch.Generator(device=DEV).manual_seed(31)
+    st = torch.randint(0, 256, (B, T, 200, 200, 3), device=DEV, dtype=torch.uint8, generator=g)
+    gl = torch.randint(0, 256, (B, 200, 200, 3), device=DEV, dtype=torch.uint8, generator=g)
+    acts = torch.rand(B, T, 7, device=DEV, generator=g) * 2 - 1
+    aug = draw_play_batch_augmentation({"rgb_static": AugmentSpec(pad=4, resize=(84, 84))}, B, T, DEV, g)
+    m = _mod("f32")
+    m.training_step({"states": {"rgb_static": st}, "goal": {"rgb_static": gl}, "actions": acts,
+                     "disp": torch.ones(B, device=DEV).long(), "aug": aug})
+    torch.cuda.synchronize()
+    assert all(v == v for v in m.logged.values()) and m.frames["rgb_static"].shape == (B * T, 84, 84, 3)
+    a = aug["states"]["rgb_static"]
+    ref = A.train_pipeline(st.view(B * T, 200, 200, 3).cpu(), a["shift"].view(B * T, 2).cpu(), a["jitter"].view(B * T, 8).cpu(), 4,
+                           resize=(84, 84))
+    assert (m.frames["rgb_static"].cpu() - ref).abs().max().item() < 5e-5
