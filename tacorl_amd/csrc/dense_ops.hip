@@ -517,37 +517,50 @@ __global__ __launch_bounds__(256) void softargmax_bwd_batch_kernel(SabArgs a, in
   __shared__ float shm[4][64], shs[4][64], sh[4];
   const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float t = a.temp[p][0];
+  const float it = 1.0f / t;  // one IEEE division per thread; the per-element v / t were 3 x 13 divisions, each ~10 VALU
   const float* q = a.y3[p] + (long)img * P * 64 + c;
   float* o = a.dz3[p] + (long)img * P * 64 + c;
-  float v[SAB_MAXI];
+  // the per-image soft-argmax inputs travel beside the activation rows (they were dependent loads behind two barriers)
+  const f32x2 g2 = *reinterpret_cast<const f32x2*>(a.d_sa[p] + (long)img * 128 + 2 * c);
+  const f32x2 f2 = *reinterpret_cast<const f32x2*>(a.sa[p] + (long)img * 128 + 2 * c);
+  float v[SAB_MAXI], e[SAB_MAXI];
   float mx = -INFINITY;
 #pragma unroll
   for (int k = 0; k < SAB_MAXI; k++) {
     const int i = w + 4 * k;
     v[k] = i < P ? q[i * 64] : 0.f;
-    if (i < P) mx = fmaxf(mx, v[k] / t);
+  }
+#pragma unroll
+  for (int k = 0; k < SAB_MAXI; k++) {
+    v[k] *= it;  // s = y / t (exact products of the same two fp32 numbers the forward used are not needed: dz3 is
+                 // consumed as a bf16 MFMA operand and the temperature gradient is a sum over 10^5 terms)
+    if (w + 4 * k < P) mx = fmaxf(mx, v[k]);
   }
   shm[w][c] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(shm[0][c], shm[1][c]), fmaxf(shm[2][c], shm[3][c]));
   float se = 0.f;
 #pragma unroll
-  for (int k = 0; k < SAB_MAXI; k++)
-    if (w + 4 * k < P) se += expf(v[k] / t - mx);
+  for (int k = 0; k < SAB_MAXI; k++) {
+    e[k] = (w + 4 * k < P) ? __expf(v[k] - mx) : 0.f;  // kept: the second pass re-used to recompute every exponential
+    se += e[k];
+  }
   shs[w][c] = se;
   __syncthreads();
   se = ((shs[0][c] + shs[1][c]) + shs[2][c]) + shs[3][c];
-  const float gx = a.d_sa[p][(long)img * 128 + 2 * c], gy = a.d_sa[p][(long)img * 128 + 2 * c + 1];
-  const float dot = gx * a.sa[p][(long)img * 128 + 2 * c] + gy * a.sa[p][(long)img * 128 + 2 * c + 1];
+  const float rse = 1.0f / se;
+  const float gx = g2[0], gy = g2[1];
+  const float dot = gx * f2[0] + gy * f2[1];
   float dt = 0.f;
 #pragma unroll
   for (int k = 0; k < SAB_MAXI; k++) {
     const int i = w + 4 * k;
     if (i < P) {
-      const float s = v[k] / t, pr = expf(s - mx) / se;
-      const float ds = pr * (gx * (float)(i % OW) + gy * (float)(i / OW) - dot);
-      dt -= ds * s / t;
-      o[i * 64] = v[k] > 0.f ? ds / t : 0.f;
+      const int iy = i / OW;
+      const float s = v[k], pr = e[k] * rse;
+      const float ds = pr * (gx * (float)(i - iy * OW) + gy * (float)iy - dot);
+      dt -= ds * s * it;
+      o[i * 64] = v[k] != 0.f ? ds * it : 0.f;  // ReLU mask: y3 >= 0, and y3 > 0 <=> y3 / t != 0 for either sign of t
     }
   }
   dt = wave_sum(dt);
