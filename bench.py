@@ -511,7 +511,8 @@ def main():
     # the roofline probe of the dominant kernel, taken here - straight behind the timed steps, the chip in the clock state
     # the step runs in (behind the other blocks below, after a module teardown, the same launch read up to 8 % slower)
     enc_probe = time_encoder_fwd(mod, B, H, W) if rank == 0 else None
-    enc_in_step = time_encoder_in_step(mod, batch) if rank == 0 else None
+    # (training steps: on N ranks they hold the step's all-reduces, so every rank runs them; rank 0's reading is reported)
+    enc_in_step = time_encoder_in_step(mod, batch)
 
     def replicas_in_sync():
         e = mod.engine
