@@ -4,10 +4,11 @@ refuses two ranks on one device; on a multi-GPU node the backend is RCCL).  Chec
 finishes, losses are finite and both replicas end with identical parameters."""
 import json
 import os
-import subprocess
 import sys
 
 import pytest
+
+from tests.proc_util import free_port, run_group
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,9 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_two_ranks_stay_in_sync():
     env = dict(os.environ, TACORL_DIST_BACKEND="gloo", TACORL_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
            "--batch", "64", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    out = run_group(cmd, env, ROOT, timeout=420)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
@@ -35,7 +36,7 @@ def test_bench_self_launcher_two_ranks():
     env.update(TACORL_DIST_BACKEND="gloo", TACORL_BENCH_SINGLE_DEVICE="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "64",
            "--no-cpu-baseline", "--no-distribution"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    out = run_group(cmd, env, ROOT, timeout=420)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["replicas_in_sync"] is True
@@ -48,6 +49,6 @@ def test_two_rank_shards_equal_the_full_batch_step():
     noise, hipGraph segments around the all-reduces, against the single-rank full-batch step (tests/dist_shard_script.py)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", os.path.join(ROOT, "tests", "dist_shard_script.py")]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_shard_script.py")]
+    out = run_group(cmd, env, ROOT, timeout=600)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
