@@ -10,6 +10,10 @@ mod = bench.build_module(dev, "bf16", 16, 1)
 batches = [bench.synth_batch(256, 16, 84, 84, dev, 1), bench.synth_batch(256, 16, 84, 84, dev, 2)]
 mod.enable_graph(); mod.log_every_n_steps = 50
 def setv(path, v):
+    if path.startswith("env:"):
+        os.environ[path[4:]] = str(v)
+        mod._graphs = {}
+        return
     o = mod
     *head, last = path.split(".")
     for h in head: o = getattr(o, h)

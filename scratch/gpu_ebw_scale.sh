@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for n in 85 170 512 1020; do
   rm -rf /tmp/ebw_$n
-  NIMG=$n rocprofv3 --kernel-trace --stats -d /tmp/ebw_$n -o p -- python3 $R/scratch/run_ebw.py 20 > /dev/null 2>&1
+  NIMG=$n rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ebw_$n -o p -- python3 $R/scratch/run_ebw.py 20 > /dev/null 2>&1
   f=$(find /tmp/ebw_$n -name "*kernel_stats.csv" | head -1)
   echo "== NIMG=$n" >> $R/gpurun_out/ebw_scale.txt
   python3 - "$f" >> $R/gpurun_out/ebw_scale.txt <<'PY'

@@ -926,7 +926,18 @@ extern "C" int tacorl_encoder_bwd_fused_conv_parts(int nprob, const void* const*
     sb.d_sa[p] = sc + pl.so[p][1]; sb.dz3[p] = sc + pl.so[p][2]; sb.dtp[p] = sc + pl.so[p][5];
     sb.gtemp[p] = grads[p] + pl.po[E_T]; sb.n[p] = n_img[p];
   }
-  if (pl.maxn > 0 && (parts & 1)) {
+  // everything requested on one stream: soft-argmax backward, dgrad3 and wgrad3 are one launch (TACORL_EBW_FUSE3=0: the
+  // separate launches, for A/B measurements)
+  const char* fe = getenv("TACORL_EBW_FUSE3");  // (read per call: a captured graph keeps what it was captured with)
+  const int fuse3 = fe ? atoi(fe) : 1;
+  const bool fused3 = fuse3 && (parts & 127) == 127 && ebw_fused3_supported(H, W);
+  if (fused3) {
+    for (int p = 0; p < nprob; p++) {
+      pr[p].y3 = sb.y3[p]; pr[p].temp = sb.temp[p]; pr[p].sa = sb.sa[p]; pr[p].d_sa = sb.d_sa[p];
+      pr[p].dtp = sb.dtp[p]; pr[p].g_temp = sb.gtemp[p];
+    }
+  }
+  if (pl.maxn > 0 && (parts & 1) && !fused3) {
     const int P3 = pl.d.c3.OH * pl.d.c3.OW;
     if (P3 <= 4 * 13) hipLaunchKernelGGL(softargmax_bwd_batch_kernel<13>, dim3((unsigned)pl.maxn, nprob), dim3(256), 0, st, sb, P3, pl.d.c3.OW);
     else hipLaunchKernelGGL(softargmax_bwd_batch_kernel<SAB_MAXI_BIG>, dim3((unsigned)pl.maxn, nprob), dim3(256), 0, st, sb, P3, pl.d.c3.OW);
@@ -935,7 +946,8 @@ extern "C" int tacorl_encoder_bwd_fused_conv_parts(int nprob, const void* const*
   if (!(parts & EBW_ALL)) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
   // (a partial call must not re-pack the W^T fragments behind a dgrad that is reading them: prepacked or EBW_ALL)
   if ((parts & EBW_ALL) != EBW_ALL && !prepacked) FAIL(TACORL_EINVAL, "encoder_bwd_fused_conv_parts: partial calls need prepacked fragments");
-  const int rc = ebw_conv_backward(nprob, pr, H, W, accumulate, (unsigned char*)ws + pl.conv_off, pl.total - pl.conv_off, st, prepacked ? 2 : 0, parts & EBW_ALL);
+  const int rc = ebw_conv_backward(nprob, pr, H, W, accumulate, (unsigned char*)ws + pl.conv_off, pl.total - pl.conv_off, st, prepacked ? 2 : 0,
+                                   (parts & EBW_ALL) | (fused3 ? EBW_FUSED3 : 0));
   if (rc != TACORL_OK) FAIL(rc, "encoder_bwd_fused_conv: conv backward launch failed (%d)", rc);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }

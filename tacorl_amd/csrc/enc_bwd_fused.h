@@ -15,6 +15,10 @@ struct EbwProblem {
   const float* w3;   // [64][3][3][64] fp32
   float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3;
   int n;
+  // EBW_FUSED3 only (soft-argmax backward inside the conv3 launch): conv3 output, temperature, soft-argmax output and
+  // its gradient, per-workgroup scratch for the temperature-gradient partials (>= 256 floats), d(temperature)
+  const float *y3, *temp, *sa, *d_sa;
+  float *dtp, *g_temp;
 };
 
 bool ebw_supported(int H, int W);
@@ -25,6 +29,10 @@ size_t ebw_ws_bytes(int nprob, const int* n_img, int H, int W);
 // parts: which launches of the conv backward to issue on `st` (all of them = EBW_ALL); a caller that spreads them
 // over two streams orders them with events (dgrad2 and wgrad2 read dgrad3's output, wgrad1 reads dgrad2's, the
 // reduce reads every wgrad's slabs).
-enum { EBW_DGRAD3 = 2, EBW_WGRAD3 = 4, EBW_DGRAD2 = 8, EBW_WGRAD2 = 16, EBW_WGRAD1 = 32, EBW_REDUCE = 64, EBW_ALL = 126 };
+enum { EBW_DGRAD3 = 2, EBW_WGRAD3 = 4, EBW_DGRAD2 = 8, EBW_WGRAD2 = 16, EBW_WGRAD1 = 32, EBW_REDUCE = 64, EBW_ALL = 126,
+       // with EBW_ALL: soft-argmax backward + dgrad3 + wgrad3 as ONE launch (pr[].dz3 is then not read; the caller does not
+       // launch the soft-argmax backward or its temperature sum - the reduce adds the temperature gradient)
+       EBW_FUSED3 = 128 };
+bool ebw_fused3_supported(int H, int W);
 int ebw_conv_backward(int nprob, const EbwProblem* pr, int H, int W, int accumulate, void* ws, size_t ws_bytes,
                       hipStream_t st, int mode, int parts = EBW_ALL);

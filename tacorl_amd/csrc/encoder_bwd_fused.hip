@@ -56,7 +56,11 @@ struct ConvL {
   // dgrad
   // PP: dZ pixel pitch in the dgrad's halo image: 160 B for CO = 64 - with ds_read_b128's lane groups ({0-3,12-15,20-27}, ...)
   // the 16 (pixel, k-group) pairs of a group then hit 16 distinct 16-byte slots; CO + 8 (144 B) cost 59 % conflict cycles
-  static constexpr int HA = KA - 1, HB = KB - 1, R = PH + HA, C = PW + HB, PP = CO + 16;
+  // C: pixels per halo row = PW + 8: a 16-pixel tile spans two or three rows, and with PP = 80 (160 B) the 16 lanes of a
+  // ds_read_b128 group hit 16 distinct 16-byte slots only if the row-to-row gap is a multiple of 8 pixels (PW + HB, the
+  // minimum, costs 7.3 - 7.4 LDS cycles per read instead of 4: scratch/micro/bank_sim.py; the dgrads are LDS-bound)
+  static constexpr int HA = KA - 1, HB = KB - 1, R = PH + HA, C = PW + 8, PP = CO + 16;
+  static_assert(HB <= 8, "halo columns");
   static constexpr int KS = KA * KB * CO / 32;
   static constexpr int NCLS = S * S, NTI = CI / 16;
   static constexpr int MTC = (PH * PW + 15) / 16;
@@ -316,7 +320,12 @@ struct RdTrArgs {
   float* gw[3][EBW_MAXP];
   float* gb[3][EBW_MAXP];
   int co[3], taps[3], mpw[3], npw[3], mgrp[3], ngrp[3], kgrp[3], slabf[3];
+  int ileave[3];  // n-tiles interleaved over the wave groups (ebw_l3_kernel) instead of blocked
   int wpp, accumulate;
+  // fused conv3 launch: its per-workgroup temperature-gradient partials are summed here (one otherwise idle block)
+  const float* dtp[EBW_MAXP];
+  float* g_temp[EBW_MAXP];
+  int ndt[EBW_MAXP];  // partials per problem (0 = no temperature sum in this launch)
 };
 __global__ __launch_bounds__(256) void ebw_reduce_tr_kernel(RdTrArgs a) {
   // slab order (coalesced reads): 64 consecutive slab floats per block, the 4 waves take every 4th workgroup slab,
@@ -325,6 +334,18 @@ __global__ __launch_bounds__(256) void ebw_reduce_tr_kernel(RdTrArgs a) {
   const int l = blockIdx.y % 3, p = blockIdx.y / 3;
   const int nW = a.co[l] * a.taps[l], per = nW + a.co[l], KG = a.kgrp[l];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63), kq = threadIdx.x >> 6;
+  if (a.ndt[p] > 0 && l == 0 && blockIdx.x == gridDim.x - 1) {  // (beyond conv1's elements: the host checks)
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.ndt[p]; i += 256) s += a.dtp[p][i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[0][kq] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float v = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3];
+      *a.g_temp[p] = a.accumulate ? *a.g_temp[p] + v : v;
+    }
+    return;
+  }
   if (blockIdx.x * 64 >= per) return;
   float sum = 0.f;
   if (e < per) {
@@ -346,7 +367,8 @@ __global__ __launch_bounds__(256) void ebw_reduce_tr_kernel(RdTrArgs a) {
       const int r = e & 3, lane = (e >> 2) & 63, tt = e >> 8;
       const int nj = tt % a.npw[l], mi = (tt / a.npw[l]) % a.mpw[l], wg = tt / (a.npw[l] * a.mpw[l]);
       const int ng = wg % a.ngrp[l], mg = wg / a.ngrp[l];
-      const int co = 16 * (mg * a.mpw[l] + mi) + 4 * (lane >> 4) + r, tap = 16 * (ng * a.npw[l] + nj) + (lane & 15);
+      const int co = 16 * (mg * a.mpw[l] + mi) + 4 * (lane >> 4) + r;
+      const int tap = 16 * (a.ileave[l] ? nj * a.ngrp[l] + ng : ng * a.npw[l] + nj) + (lane & 15);
       o = a.gw[l][p] + (long)co * a.taps[l] + tap;
     } else {
       o = a.gb[l][p] + (e - nW);
@@ -424,7 +446,7 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
     int m = 16 * (mpart + t * MPARTS) + i;
     m = m < L::PH * L::PW ? m : L::PH * L::PW - 1;
     const int Y = m / L::PW, X = m - Y * L::PW;
-    abase[t] = ((Y + L::HA) * L::C + X + L::HB) * L::PP + 8 * g;
+    abase[t] = (Y * L::C + X) * L::PP + 8 * g;  // halo pixel of tap (KA-1, KB-1): every tap offset below is >= 0 (an immediate)
   }
   // W^T is the MFMA A operand (D rows = input channels): a lane ends with 4 CONSECUTIVE channels of one pixel,
   // i.e. one 8-byte store and one mask nibble per tile instead of four 2-byte stores and four mask bytes.
@@ -496,7 +518,7 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
 #pragma unroll
       for (int ks = 0; ks < L::KS; ks++) {
         const int tp = ks / (L::CO / 32), hf = ks % (L::CO / 32), ta = tp / L::KB, tb = tp % L::KB;
-        const bf16x8 A = *reinterpret_cast<const bf16x8*>(buf + abase[t] - (ta * L::C + tb) * L::PP + 32 * hf);
+        const bf16x8 A = *reinterpret_cast<const bf16x8*>(buf + abase[t] + ((L::HA - ta) * L::C + L::HB - tb) * L::PP + 32 * hf);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[ks], A, acc, 0, 0, 0);
       }
       if (oidx[t] >= 0) {
@@ -511,9 +533,371 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
   }
 }
 
+
+// ===================================================================== conv3, everything in one launch
+// soft-argmax backward -> dZ3 -> { dgrad3 (-> masked dZ2), wgrad3 } per image, dZ3 never leaving LDS: replaces four
+// launches of the dependent chain (soft-argmax backward, its temperature-gradient sum, ebw_dgrad_kernel<L3>,
+// ebw_wgrad_tr_kernel<L3>) - each of which paid its own launch, prologue and first-load latency for ~1 us of work per
+// image - and two of the three passes over y3 / dZ3 / y2 (HBM traffic is what bounds these kernels: 340 MB of
+// activations + 166 MB of slabs at B=256 against ~0.1 ms of MFMA-free time).
+//   dZ3 lives in the dgrad's zero-halo image [R][C][PP]; the transposing reads of the weight gradient address its rows
+//   through a per-lane pixel -> halo-offset table (padded pixels point at a halo corner, which is zero).
+//   The ReLU mask of dgrad3's output is read from the staged y2 itself (8 bytes per lane and tile).
+//   Reference semantics: SpatialSoftmax.backward + nn.Conv2d/ReLU autograd, networks/vision/lmp_vision_network.py:32-72.
+struct L3Args {
+  const float* y3[EBW_MAXP];    // [n][P3][64] conv3 output (post-ReLU, fp32)
+  const float* temp[EBW_MAXP];  // learned temperature (1 float)
+  const float* sa[EBW_MAXP];    // [n][128] soft-argmax output (x, y interleaved per channel)
+  const float* d_sa[EBW_MAXP];  // [n][128] its gradient
+  const __bf16* y2[EBW_MAXP];   // [n][IH*IW][64] conv2 output (post-ReLU)
+  const uint4* wpk[EBW_MAXP];   // packed W3^T fragments (ebw_pack_kernel)
+  __bf16* dz2[EBW_MAXP];        // out: [n][IH*IW][64] masked gradient of conv2's pre-activation
+  float* dtp[EBW_MAXP];         // out: per-workgroup partial of the temperature gradient [wpp]
+  float* slab;                  // out: weight-gradient slabs, ebw_wgrad_tr_kernel<L3>'s layout
+  int n[EBW_MAXP];
+  int wpp;
+};
+// Wave roles: 8 waves per workgroup - waves 0-3 own dgrad3 (one input-channel tile each, W3^T fragments in registers,
+// TG3 pixel tiles in flight), waves 4-7 own wgrad3 (64 output channels x a quarter of the taps each: 144 + 16 accumulator
+// registers; one wave of each role per SIMD, 108 + 80 MFMAs per image).  With
+// every wave doing both (round 3's first version) the 72 fragment + 80 accumulator registers left nothing to read ahead
+// with: dgrad3 ran as 54 x (ds_read, wait, MFMA), 38 us per launch; roles keep the two register sets in different waves
+// and let the two phases of an image overlap on the MFMA pipe.  All waves share the soft-argmax and the staging.
+#ifdef L3_STAMPS  // scratch builds: shader / wall clocks of workgroup 0 per phase, summed over its images
+__device__ unsigned long long l3_st[16];
+extern "C" int tacorl_l3_stamps_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(l3_st), sizeof(l3_st)) == hipSuccess ? 0 : -1;
+}
+#define L3_ST(i) do { if (tid == 64 * w && blockIdx.x == 0 && (w == 0 || w == ND3)) { const unsigned long long t_ = clock64(); st[i] += t_ - tl; tl = t_; } } while (0)
+#else
+#define L3_ST(i) do { } while (0)
+#endif
+constexpr int NT3 = 512, NW3 = NT3 / 64, ND3 = 4;
+struct L3Tile { static constexpr int MGRP = 1, NGRP = 4, KGRP = 1; };  // wgrad3's wave tiling here (TrTile: 2 x 4 over 8 waves)
+template <class L>
+struct L3Geo {
+  using TG = TrGeo<L>;
+  static constexpr int P3 = L::OH * L::OW, K3 = (P3 + NW3 - 1) / NW3;  // soft-argmax: wave w owns pixels w, w + 8, ...
+  static constexpr int HALO = L::R * L::C * L::PP;                     // elements
+  static constexpr int CIP = TG::CIP, Y2E = (L::IH * L::IW * CIP + 7) / 8 * 8;
+  static constexpr int KS = (P3 + 31) / 32;                            // weight-gradient k-steps (32 pixels)
+  static constexpr int Z2E = L::IH * L::IW * L::CI;                     // dZ2 of one image (elements), staged for coalesced stores
+  static constexpr int MPW = L::MT / L3Tile::MGRP, NPW = L::NTL / L3Tile::NGRP;
+  static constexpr size_t lds_bytes = ((size_t)HALO + 2 * Y2E + 2 * Z2E) * 2 + 2 * NW3 * 64 * 4 + 64;
+  static_assert(L::S == 1 && L::CI == 64 && L::CO == 64 && L::NCOMBO == ND3, "conv3 of the LMPVisionEncoder");
+  static constexpr bool ok = K3 <= 8 && lds_bytes <= 160 * 1024;  // (128 x 128: 144 conv3 pixels - the soft-argmax's registers spill)
+};
+
+template <class L>
+__global__ __launch_bounds__(NT3) void ebw_l3_kernel(L3Args a) {
+  using G = L3Geo<L>;
+  using TG = TrGeo<L>;
+  using T = L3Tile;
+  static_assert(T::MGRP * T::NGRP * T::KGRP == NW3 - ND3, "wgrad waves");
+  static_assert(G::ok, "geometry not supported by the fused conv3 backward");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* dzh = reinterpret_cast<__bf16*>(smem);                     // dZ3, zero halo
+  __bf16* y2s = dzh + G::HALO;                                      // 2 x [IH*IW][CIP]
+  __bf16* z2s = y2s + 2 * G::Y2E;                                   // 2 x [IH*IW][64]: dZ2 on its way out
+  float* shm = reinterpret_cast<float*>(z2s + 2 * G::Z2E);          // [NW3][64] per-wave maxima
+  float* shs = shm + NW3 * 64;                                      // [NW3][64] per-wave sums
+  float* shd = shs + NW3 * 64;                                      // [NW3]
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l16 = lane & 15, q = l16 >> 2, pc = l16 & 3;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the role branch below must be a uniform branch
+  const int p = blockIdx.x / a.wpp, j0 = blockIdx.x - p * a.wpp;
+  const int n_img = a.n[p];
+  // only the halo image needs zeros (its border and the pad columns are never written); y2's pad columns are never read
+  for (int e = tid; e < G::HALO / 8; e += NT3) reinterpret_cast<uint4*>(dzh)[e] = make_uint4(0u, 0u, 0u, 0u);
+  const float it = 1.0f / a.temp[p][0];
+  const float* y3 = a.y3[p];
+  const __bf16* y2 = a.y2[p];
+  constexpr int ICH = L::IH * L::IW * (L::CI / 8), ICPT = (ICH + NT3 - 1) / NT3;
+  // One image loop per role (same barrier sequence in both): role 0 = dgrad3, role 1 = wgrad3.
+  auto run = [&](auto role_tag) {
+    constexpr int ROLE = decltype(role_tag)::value;
+    float vn[G::K3];
+    f32x2 gn, fn;
+    bf16x8 ipre[ICPT];
+    // the next image's soft-argmax inputs are fetched once this image's are dead (after the soft-argmax phase: the two
+    // sets never overlap in registers), its y2 at the top of the iteration
+    auto fetch3 = [&](int img) {
+#pragma unroll
+      for (int k = 0; k < G::K3; k++) {
+        const int i = w + NW3 * k;
+        vn[k] = y3[((long)img * G::P3 + (i < G::P3 ? i : G::P3 - 1)) * 64 + lane];
+      }
+      gn = *reinterpret_cast<const f32x2*>(a.d_sa[p] + (long)img * 128 + 2 * lane);
+      fn = *reinterpret_cast<const f32x2*>(a.sa[p] + (long)img * 128 + 2 * lane);
+    };
+    auto fetch = [&](int img) {
+#pragma unroll
+      for (int r = 0; r < ICPT; r++) {
+        const int c = tid + r * NT3;
+        ipre[r] = *reinterpret_cast<const bf16x8*>(y2 + (long)img * L::IH * L::IW * L::CI + 8 * (c < ICH ? c : ICH - 1));
+      }
+    };
+    auto put = [&](__bf16* buf) {
+#pragma unroll
+      for (int r = 0; r < ICPT; r++) {
+        const int c = tid + r * NT3;
+        if (c < ICH) *reinterpret_cast<bf16x8*>(buf + (c / (L::CI / 8)) * G::CIP + 8 * (c % (L::CI / 8))) = ipre[r];
+      }
+    };
+    // dZ2 leaves through LDS: the dgrad waves write their tiles into z2s, and EVERY thread stores 16 contiguous bytes of
+    // the PREVIOUS image behind the next soft-argmax phase - the stores' acknowledgements (in-order vmcnt: any later wait
+    // for a prefetch waits for them too) then have a whole iteration to arrive; issued by the dgrad waves themselves at
+    // the end of their phase they stalled the loop top by a store round trip per image
+    constexpr int ZCH = G::Z2E / 8, ZCPT = (ZCH + NT3 - 1) / NT3;
+    auto flush = [&](int img, const __bf16* zb) {
+#pragma unroll
+      for (int r = 0; r < ZCPT; r++) {
+        const int c = tid + r * NT3;
+        if (c < ZCH) *reinterpret_cast<bf16x8*>(a.dz2[p] + (long)img * G::Z2E + 8 * c) = *reinterpret_cast<const bf16x8*>(zb + 8 * c);
+      }
+    };
+    // ---- role state
+    // dgrad3: wave = input-channel tile nt, all pixel tiles; W3^T fragments stay in registers
+    constexpr int MT = L::MTC, TG3 = 2, NGRP3 = (MT + TG3 - 1) / TG3;  // pixel tiles, processed TG3 at a time
+    bf16x8 Bf[ROLE == 0 ? L::KS : 1];
+    int abase[ROLE == 0 ? MT : 1];
+    int obase = 0;
+    if constexpr (ROLE == 0) {
+      const int nt = w;
+#pragma unroll
+      for (int ks = 0; ks < L::KS; ks++) Bf[ks] = __builtin_bit_cast(bf16x8, a.wpk[p][(nt * L::KS + ks) * 64 + lane]);
+#pragma unroll
+      for (int t = 0; t < MT; t++) {
+        const int m0 = 16 * t + l16;
+        const int m = m0 < L::PH * L::PW ? m0 : L::PH * L::PW - 1;
+        const int Y = m / L::PW, X = m - Y * L::PW;
+        abase[t] = (Y * L::C + X) * L::PP + 8 * g;  // halo pixel (Y, X) = tap (KA-1, KB-1): every tap offset below is >= 0 (an immediate)
+      }
+      // S = 1: output pixel m = 16 t + l16, 4 consecutive input channels: element index obase + t * 16 * CI
+      obase = l16 * L::CI + 16 * nt + 4 * g;
+    }
+    // wgrad3 (TrTile): n-tiles interleaved over the wave groups (tile j of group ng = j NGRP + ng = tap j, channels 16 ng ..):
+    // the tap part of a B-fragment address is a compile-time constant, the lane part one register
+    static_assert(L::CI / 16 == T::NGRP, "one tap per n-tile round");
+    const int wv = w - ND3, ng = wv % T::NGRP, mg = (wv / T::NGRP) % T::MGRP;
+    const int coff = 16 * ng + 4 * pc;
+    int zr0[ROLE == 1 ? G::KS : 1], zr1[ROLE == 1 ? G::KS : 1], ir0[ROLE == 1 ? G::KS : 1], ir1[ROLE == 1 ? G::KS : 1];
+    f32x4 acc[ROLE == 1 ? G::MPW : 1][ROLE == 1 ? G::NPW : 1], bacc[ROLE == 1 ? G::MPW : 1];
+    bf16x8 ones;
+    if constexpr (ROLE == 1) {
+#pragma unroll
+      for (int s = 0; s < G::KS; s++) {  // dZ3 halo rows / input rows of this lane's two pixels per k-step
+        const int P0 = 32 * s + 4 * g + q, P1 = P0 + 16;
+        const int Q0 = P0 < G::P3 ? P0 : G::P3 - 1, Q1 = P1 < G::P3 ? P1 : G::P3 - 1;
+        zr0[s] = P0 < G::P3 ? ((P0 / L::OW + L::HA) * L::C + P0 % L::OW + L::HB) * L::PP : 0;  // halo corner: zero
+        zr1[s] = P1 < G::P3 ? ((P1 / L::OW + L::HA) * L::C + P1 % L::OW + L::HB) * L::PP : 0;
+        ir0[s] = ((Q0 / L::OW) * L::IW + Q0 % L::OW) * G::CIP;
+        ir1[s] = ((Q1 / L::OW) * L::IW + Q1 % L::OW) * G::CIP;
+      }
+#pragma unroll
+      for (int i = 0; i < G::MPW; i++) {
+        bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < G::NPW; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) ones[j] = (__bf16)1.0f;
+    }
+    float dt = 0.f;
+#ifdef L3_STAMPS
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tl = clock64();
+    const unsigned long long w0 = wall_clock64(), c0 = tl;
+#endif
+    __syncthreads();  // zero fill done
+    if (j0 < n_img) { fetch(j0); fetch3(j0); put(y2s); }
+    __syncthreads();
+    int kb = 0;
+    L3_ST(0);  // prologue
+    for (int img = j0; img < n_img; img += a.wpp, kb ^= 1) {
+      const int nxt = img + a.wpp;
+      int wl = w;  // opaque copy: the pixel coordinates derived from it are scalar arithmetic per image; hoisted out of the
+      asm volatile("" : "+s"(wl));  // loop (as floats in VGPRs, one set per role) they were what spilled
+      float v[G::K3];
+#pragma unroll
+      for (int k = 0; k < G::K3; k++) v[k] = vn[k];
+      const float gx = gn[0], gy = gn[1], dot = gn[0] * fn[0] + gn[1] * fn[1];
+      // every use of the previous prefetch sits above this point: a consumer that sinks below the loads issued next waits
+      // for THEM as well (in-order vmcnt) - hipcc had moved `dot` behind the second barrier: a full HBM latency per image
+      asm volatile("" : : "v"(gx), "v"(gy), "v"(dot) : "memory");
+#pragma unroll
+      for (int k = 0; k < G::K3; k++) asm volatile("" : : "v"(v[k]) : "memory");
+      if (nxt < n_img) { fetch(nxt); fetch3(nxt); }  // both prefetches have the whole iteration to land
+      const __bf16* yb = y2s + kb * G::Y2E;
+      // ---- soft-argmax backward (softargmax_bwd_batch_kernel's arithmetic): dZ3 as bf16 into the halo image
+      float mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < G::K3; k++) {
+        v[k] *= it;
+        if (wl + NW3 * k < G::P3) mx = fmaxf(mx, v[k]);
+      }
+      // one barrier for both statistics: every wave publishes its own maximum and its sum of exponentials RELATIVE to
+      // that maximum; the channel's sum is then sum_w s_w exp(m_w - M)
+      float se = 0.f;
+#pragma unroll
+      for (int k = 0; k < G::K3; k++) se += (wl + NW3 * k < G::P3) ? __expf(v[k] - mx) : 0.f;
+      shm[wl * 64 + lane] = mx;
+      shs[wl * 64 + lane] = se;
+      __syncthreads();
+      {
+        float mw[NW3], sw[NW3];  // every read in flight before the first use (hipcc issued them one round trip at a time)
+#pragma unroll
+        for (int ww = 0; ww < NW3; ww++) { mw[ww] = shm[ww * 64 + lane]; sw[ww] = shs[ww * 64 + lane]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ww = 0; ww < NW3; ww++) mx = fmaxf(mx, mw[ww]);
+        se = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW3; ww++) se += sw[ww] * __expf(mw[ww] - mx);  // (a wave without pixels: 0 * exp(-inf) = 0)
+      }
+      const float rse = 1.0f / se;
+#pragma unroll
+      for (int k = 0; k < G::K3; k++) {
+        const int i = wl + NW3 * k;
+        if (i < G::P3) {
+          const int iy = i / L::OW;
+          const float pr = __expf(v[k] - mx) * rse;  // (recomputed: K3 registers matter more here than K3 exponentials)
+          const float ds = pr * (gx * (float)(i - iy * L::OW) + gy * (float)iy - dot);
+          dt -= ds * v[k] * it;
+          dzh[((iy + L::HA) * L::C + (i - iy * L::OW) + L::HB) * L::PP + lane] = (__bf16)(v[k] != 0.f ? ds * it : 0.f);  // ReLU mask: y3 > 0 <=> y3 / t != 0
+        }
+      }
+      L3_ST(1);  // soft-argmax
+      if (img != j0) flush(img - a.wpp, z2s + (kb ^ 1) * G::Z2E);
+      __syncthreads();  // dZ3 of this image complete
+      L3_ST(2);  // flush + barrier
+      if constexpr (ROLE == 0) {
+        // ---- dgrad3: dZ2 = (dZ3 (*) W3^T) masked by y2 > 0; TG3 pixel tiles share every fragment step
+        __bf16* zw = z2s + kb * G::Z2E;
+#pragma unroll
+        for (int tg = 0; tg < NGRP3; tg++) {
+          f32x4 o[TG3];
+#pragma unroll
+          for (int u = 0; u < TG3; u++) o[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          // A fragments: the first HK steps of every tile of the group are read before the first MFMA, each slot is
+          // refilled with step ks + HK as soon as its MFMA has issued (the compiler's own schedule read each fragment
+          // right in front of its MFMA: one LDS round trip per two MFMAs, 72 clk per MFMA)
+          constexpr int HK = L::KS / 2;
+          static_assert(L::KS % 2 == 0, "fragment steps in two halves");
+          auto aoff = [&](int ks) {
+            const int tp = ks / (L::CO / 32), hf = ks % (L::CO / 32), ta = tp / L::KB, tb = tp % L::KB;
+            return ((L::HA - ta) * L::C + L::HB - tb) * L::PP + 32 * hf;
+          };
+          bf16x8 A[TG3][HK];
+#pragma unroll
+          for (int ks = 0; ks < HK; ks++)
+#pragma unroll
+            for (int u = 0; u < TG3; u++)
+              A[u][ks] = *reinterpret_cast<const bf16x8*>(dzh + abase[tg * TG3 + u < MT ? tg * TG3 + u : MT - 1] + aoff(ks));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < L::KS; ks++) {
+#pragma unroll
+            for (int u = 0; u < TG3; u++) {
+              o[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[ks], A[u][ks % HK], o[u], 0, 0, 0);
+              if (ks + HK < L::KS)
+                A[u][ks % HK] = *reinterpret_cast<const bf16x8*>(dzh + abase[tg * TG3 + u < MT ? tg * TG3 + u : MT - 1] + aoff(ks + HK));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int u = 0; u < TG3; u++) {
+            const int t = tg * TG3 + u;
+            if (t >= MT) continue;
+            const int oi = obase + t * 16 * L::CI;
+            if (oi < L::PH * L::PW * L::CI) {
+              const uint2 yv = *reinterpret_cast<const uint2*>(yb + (oi >> 6) * G::CIP + (oi & 63));
+              const bool m0 = (((yv.x & 0xffffu) - 1u) & 0xffffu) < 0x7fffu, m1 = (((yv.x >> 16) - 1u) & 0xffffu) < 0x7fffu;
+              const bool m2 = (((yv.y & 0xffffu) - 1u) & 0xffffu) < 0x7fffu, m3 = (((yv.y >> 16) - 1u) & 0xffffu) < 0x7fffu;
+              *reinterpret_cast<bf16x4*>(zw + oi) =
+                  bf16x4{(__bf16)(m0 ? o[u][0] : 0.f), (__bf16)(m1 ? o[u][1] : 0.f), (__bf16)(m2 ? o[u][2] : 0.f),
+                         (__bf16)(m3 ? o[u][3] : 0.f)};
+            }
+          }
+        }
+      } else {
+        // ---- wgrad3: dW3[co][tap] += sum_pixels dZ3[pixel][co] y2[pixel @ tap]
+#pragma unroll
+        for (int s = 0; s < G::KS; s++) {
+          // the fragments of a k-step are read ahead of their MFMAs in three batches (all 9 tap fragments at once, or 5 + 4, spilled - and a scratch reload waits for the prefetch in flight)
+          constexpr int JB = (G::NPW + 2) / 3;
+          bf16x8 A[G::MPW], B[JB];
+#pragma unroll
+          for (int i = 0; i < G::MPW; i++) {
+            const int col = 16 * (mg * G::MPW + i) + 4 * pc;
+            A[i] = tr_frag(dzh + zr0[s] + col, dzh + zr1[s] + col);
+          }
+#pragma unroll
+          for (int jb = 0; jb < G::NPW; jb += JB) {
+#pragma unroll
+            for (int j = jb; j < jb + JB && j < G::NPW; j++) {
+              const int tofs = ((j / L::KW) * L::IW + j % L::KW) * G::CIP;  // tap j = (ky, kx)
+              B[j - jb] = tr_frag(yb + ir0[s] + coff + tofs, yb + ir1[s] + coff + tofs);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = jb; j < jb + JB && j < G::NPW; j++)
+#pragma unroll
+              for (int i = 0; i < G::MPW; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i], B[j - jb], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (ng == 0) {
+#pragma unroll
+            for (int i = 0; i < G::MPW; i++) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i], ones, bacc[i], 0, 0, 0);
+          }
+        }
+      }
+      L3_ST(3);  // role phase
+      if (nxt < n_img) put(y2s + (kb ^ 1) * G::Y2E);
+      __syncthreads();  // dZ3 / y2 of this image consumed, the next y2 staged
+      L3_ST(4);  // put + barrier
+    }
+    if (j0 < n_img) flush(j0 + ((n_img - 1 - j0) / a.wpp) * a.wpp, z2s + (kb ^ 1) * G::Z2E);  // the last image's dZ2 (its buffer: kb flipped once more)
+    if constexpr (ROLE == 1) {
+      // ---- weight-gradient slab (ebw_wgrad_tr_kernel's order with wave index wv)
+      float* sl = a.slab + (long)blockIdx.x * TG::SLABF;
+#pragma unroll
+      for (int i = 0; i < G::MPW; i++)
+#pragma unroll
+        for (int j = 0; j < G::NPW; j++)
+          *reinterpret_cast<f32x4*>(sl + (((wv * G::MPW + i) * G::NPW + j) * 64 + lane) * 4) = acc[i][j];
+      if (ng == 0 && l16 == 0) {
+#pragma unroll
+        for (int i = 0; i < G::MPW; i++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) sl[L::CO * L::TAPS + 16 * (mg * G::MPW + i) + 4 * g + r] = bacc[i][r];
+      }
+    }
+    // ---- temperature-gradient partial of this workgroup
+    dt = wave_sum(dt);
+    if (lane == 0) shd[w] = dt;
+    __syncthreads();
+    if (tid == 0 && j0 < n_img) {  // (workgroups without an image have nothing to add; dtp holds min(wpp, n) partials)
+      float sum = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NW3; ww++) sum += shd[ww];
+      a.dtp[p][j0] = sum;
+    }
+#ifdef L3_STAMPS
+    L3_ST(5);  // epilogue
+    if (tid == 64 * w && blockIdx.x == 0 && (w == 0 || w == ND3)) {
+      const int o = w == 0 ? 0 : 8;
+      for (int i = 0; i < 6; i++) l3_st[o + i] = st[i];
+      l3_st[o + 6] = clock64() - c0; l3_st[o + 7] = wall_clock64() - w0;
+    }
+#endif
+  };
+  if (w < ND3) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+}
+
 // ====================================================================== host
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int cdivi(long a, long b) { return (int)((a + b - 1) / b); }
+constexpr int cdivi_c(int a, int b) { return (a + b - 1) / b; }
 
 struct WsPlan {
   size_t wpk2[EBW_MAXP], wpk3[EBW_MAXP], dz2[EBW_MAXP], dz1[EBW_MAXP], slab1, slab2, slab3, total;
@@ -566,6 +950,15 @@ int launch_dgrad(const DgArgs& a, int nwg, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, st, a);
   return TACORL_OK;
 }
+template <class L>
+int launch_l3(const L3Args& a, int nwg, hipStream_t st) {
+  auto kern = ebw_l3_kernel<L>;
+  constexpr size_t lds = L3Geo<L>::lds_bytes;
+  static int once = set_lds(kern, lds);
+  if (once) return TACORL_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT3), lds, st, a);
+  return TACORL_OK;
+}
 template <class G>
 int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, int mode, int parts) {
   using L1 = typename G::L1; using L2 = typename G::L2; using L3 = typename G::L3;
@@ -612,9 +1005,26 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
   d2.wpp = (int)((long)k2w * w.wpp < maxn ? (long)k2w * w.wpp : maxn);
   g1.slab = (float*)(base + w.slab1); g2.slab = (float*)(base + w.slab2); g3.slab = (float*)(base + w.slab3);
   int rc;
+  const bool fused3 = (parts & EBW_FUSED3) != 0;
+  if (fused3 && (parts & EBW_ALL) != EBW_ALL) return TACORL_EINVAL;
   {
-    if ((parts & EBW_DGRAD3) && (rc = launch_dgrad<L3, float>(d3, nprob * d3.wpp, st))) return rc;
-    if ((parts & EBW_WGRAD3) && (rc = launch_wgrad_tr<L3, __bf16, float>(g3, nwg, st))) return rc;
+    if (fused3) {
+      L3Args f{};
+      for (int p = 0; p < nprob; p++) {
+        f.y3[p] = pr[p].y3; f.temp[p] = pr[p].temp; f.sa[p] = pr[p].sa; f.d_sa[p] = pr[p].d_sa;
+        f.y2[p] = (const __bf16*)pr[p].y2; f.wpk[p] = k3.out[p]; f.dz2[p] = (__bf16*)(base + w.dz2[p]);
+        f.dtp[p] = pr[p].dtp; f.n[p] = n[p];
+      }
+      f.slab = g3.slab; f.wpp = w.wpp;
+      if constexpr (L3Geo<L3>::ok) {
+        if ((rc = launch_l3<L3>(f, nwg, st))) return rc;
+      } else {
+        return TACORL_EINVAL;  // ebw_fused3_supported() said no
+      }
+    } else {
+      if ((parts & EBW_DGRAD3) && (rc = launch_dgrad<L3, float>(d3, nprob * d3.wpp, st))) return rc;
+      if ((parts & EBW_WGRAD3) && (rc = launch_wgrad_tr<L3, __bf16, float>(g3, nwg, st))) return rc;
+    }
     if ((parts & EBW_DGRAD2) && (rc = launch_dgrad<L2, __bf16>(d2, nprob * d2.wpp, st))) return rc;
     if ((parts & EBW_WGRAD2) && (rc = launch_wgrad_tr<L2, __bf16, __bf16>(g2, nwg, st))) return rc;
     if ((parts & EBW_WGRAD1) && (rc = launch_wgrad_tr<L1, __bf16, __bf16>(g1, nwg, st))) return rc;
@@ -633,6 +1043,11 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
       t.gw[2][p] = gw3[p]; t.gb[2][p] = gb3[p];
     }
     constexpr int maxper_t = cmax(L1::SLABF, cmax(L2::SLABF, L3::SLABF));
+    static_assert(cdivi_c(maxper_t, 64) - 1 > cdivi_c(L1::SLABF, 64), "the temperature block must lie beyond conv1's elements");
+    if (fused3) {
+      for (int p = 0; p < nprob; p++) { t.dtp[p] = pr[p].dtp; t.g_temp[p] = pr[p].g_temp; t.ndt[p] = n[p] < w.wpp ? n[p] : w.wpp; }
+      t.ileave[2] = 1; t.mpw[2] = L3Geo<L3>::MPW; t.npw[2] = L3Geo<L3>::NPW; t.mgrp[2] = L3Tile::MGRP; t.ngrp[2] = L3Tile::NGRP;
+    }
     hipLaunchKernelGGL(ebw_reduce_tr_kernel, dim3(cdivi(maxper_t, 64), 3 * nprob), dim3(256), 0, st, t);
     return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
   }
@@ -643,6 +1058,14 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
 // the geometries encoder_fused.hip is instantiated for (the cameras of the reference's configs)
 #define EBW_GEOMS(X) X(84, 84) X(64, 64) X(44, 60) X(128, 128)
 
+// (conv3 outputs of up to 64 pixels: the soft-argmax keeps a wave's pixels of the image in registers; 128 x 128 - 144
+// pixels - spilled 155 registers and takes the separate launches)
+bool ebw_fused3_supported(int H, int W) {
+#define X(h, w) if (H == h && W == w) return L3Geo<Geo<h, w>::L3>::ok;
+  EBW_GEOMS(X)
+#undef X
+  return false;
+}
 bool ebw_supported(int H, int W) {
 #define X(h, w) if (H == h && W == w) return true;
   EBW_GEOMS(X)
