@@ -26,6 +26,7 @@
 #include "common.h"
 
 #define EF_CHUNK 16     // images per FC batch = the 16 columns of the FC MFMA tiles (8 left half of every tile empty)
+constexpr int cmaxi(int a, int b) { return a > b ? a : b; }
 #define EF_MAXCH 12     // 16-byte chunks per thread for one image (<= 49 152 B: up to ~90x90x3 bf16)
 #define EF_MAXP 16
 #ifndef EF_ACT_COST
@@ -395,21 +396,38 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
   // moves 64 x 16 B = 1 KiB from a contiguous global span to a contiguous LDS span (wave-uniform LDS base).
   // SGPR-base form: address = uniform 64-bit base (image + 4 KiB step) + one constant per-lane byte offset, LDS
   // destination in M0 - no per-piece vector address arithmetic (the flat-pointer form cost 4 VALU + 6 SALU per piece).
-  const unsigned dma_voff = (unsigned)tid * 16u;
+  const unsigned dma_voff = G::WHOLE ? (unsigned)l * 16u : (unsigned)tid * 16u;
   const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)lds;
-  // pieces [i0, i1) of (image, band): piece i = the 256-lane span of 4 KiB at offset 4096 i, this wave's KiB of it
+  // pieces [i0, i1) of (image, band).  Band geometries: piece i = the 256-lane span of 4 KiB at offset 4096 i, this wave's
+  // KiB of it.  Whole-image geometries: the image is NPC KiB-pieces q, wave w issues DQ_LO or DQ_HI consecutive ones from
+  // dq0 - conv1's tiles do not divide by four (84 x 84: 25 tiles = 7 + 6 + 6 + 6) and a piece costs the issuing wave ~100
+  // clk, a quarter of a tile: the waves with the extra tile issue fewer pieces (6 / 12 / 12 / 12 instead of 11 each),
+  // so that all four reach the conv1 -> conv2 barrier together
+  constexpr int NPC = (G::IMG_BYTES + 1023) / 1024;
+  constexpr int NT1W = (G::NPXB + 15) >> 4, PER1W = (NT1W + 3) >> 2, NFULL = NT1W - 4 * (PER1W - 1);  // waves 0 .. NFULL-1 own PER1W tiles
+  constexpr int DQ_BAL = NFULL == 4 ? (NPC + 3) / 4 : (NPC + 4 * NFULL + 3) / 4;  // (a tile ~ four pieces)
+  constexpr int DQ_HI = PER1W > 1 && DQ_BAL > 2 * (PER1W - 1) ? 2 * (PER1W - 1) : DQ_BAL;  // at most two pieces per tile's first chain
+  constexpr int DQ_LO = NFULL == 4 ? DQ_HI : cmaxi((NPC - (4 - NFULL) * DQ_HI + NFULL - 1) / NFULL, 0);
+  static_assert(!G::WHOLE || NFULL * DQ_LO + (4 - NFULL) * DQ_HI >= NPC, "every KiB of the image has an issuer");
+  const int wu = __builtin_amdgcn_readfirstlane(w);  // (scalar: the DMA's base registers derive from it)
+  const int dqn = wu < NFULL ? DQ_LO : DQ_HI, dq0 = wu < NFULL ? wu * DQ_LO : NFULL * DQ_LO + (wu - NFULL) * DQ_HI;
   auto dma_pieces = [&](long img_idx, int band, int buf, int i0, int i1) {
     const int row0 = G::WHOLE ? 0 : 4 * G::BR * band;                                // first image row of the band
     const int rows = G::WHOLE ? G::H : min(G::BAND_ROWS, G::H - row0);
     const int n16 = G::WHOLE ? (G::IMG_BYTES >> 4) : (rows * G::W * 6) >> 4;          // 16-byte chunks to move
     const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img) + img_idx * G::IMG_BYTES + row0 * (G::W * 6);
-    const unsigned dst0 = lds_base + buf * a.lds_img + w * 1024;
+    const unsigned dst0 = lds_base + buf * a.lds_img + (G::WHOLE ? dq0 : w) * 1024;
+    if constexpr (G::WHOLE) src += dq0 * 1024;
 #pragma unroll
     for (int i = i0; i < i1; i++) {
-      if (i >= EF_MAXCH) break;
-      const int c0 = i * 256 + w * 64;  // first chunk of this wave-instruction (wave-uniform)
-      if (c0 < n16) {
-        if (c0 + l < n16) {
+      if (i >= (G::WHOLE ? DQ_HI : EF_MAXCH)) break;
+      constexpr int STEP = G::WHOLE ? 1024 : 4096;
+      const int c0 = G::WHOLE ? (dq0 + i) * 64 : i * 256 + w * 64;  // first chunk of this wave-instruction (wave-uniform)
+      // (whole image: only the last KiB piece is partial - one fixed lane mask instead of a comparison per piece)
+      constexpr int LASTN = (G::IMG_BYTES >> 4) - (NPC - 1) * 64;
+      const bool wave_on = G::WHOLE ? (i < dqn && dq0 + i < NPC) : c0 < n16;
+      if (wave_on) {
+        if (G::WHOLE ? (dq0 + i < NPC - 1 || l < LASTN) : (c0 + l < n16)) {
           // inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in the loop hipcc degrades every
           // LDS wait of the conv phases to lgkmcnt(0) (it cannot tell the DMA's LDS writes from the fragment
           // reads), which exposes the full LDS latency at each tile; the ordering against the readers of this
@@ -417,13 +435,13 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
           // hipcc (never allocated; it sets M0 itself immediately before any instruction of its own that reads it).
           asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
                        :
-                       : "v"(dma_voff), "s"(__builtin_amdgcn_readfirstlane(dst0 + i * 4096)), "s"(src + i * 4096)
+                       : "v"(dma_voff), "s"(__builtin_amdgcn_readfirstlane(dst0 + i * STEP)), "s"(src + i * STEP)
                        : "memory");
         }
       }
     }
   };
-  auto dma_load = [&](long img_idx, int band, int buf) { dma_pieces(img_idx, band, buf, 0, EF_MAXCH); };
+  auto dma_load = [&](long img_idx, int band, int buf) { dma_pieces(img_idx, band, buf, 0, G::WHOLE ? DQ_HI : EF_MAXCH); };
 
   // images this workgroup processes: worker, worker + nworkers, ... (image granularity: at most one image
   // of imbalance); the FC tail runs after every EF_CHUNK processed images (slots) or at the end.
@@ -504,7 +522,8 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       // its 2nd and 4th MFMA: a piece stands ~100 clk at issue, in the shadow of a running MFMA part of that is hidden)
       // and, for whole-image geometries, the EPILOGUE OF THE PREVIOUS TILE after its 5th MFMA: that accumulator pair is
       // long past its read-after-MFMA hazard there, and the ~25 VALU/LDS instructions sit in MFMA shadows.
-      constexpr int DPT = G::WHOLE ? ((G::IMG_BYTES + 4095) / 4096 + PER1 - 1) / PER1 : 0;  // DMA pieces per conv1 tile
+      // DMA pieces per conv1 tile: a wave's DQ_HI (DQ_LO) pieces over the PER1 - 1 (PER1) tiles it certainly has
+      constexpr int DPT = !G::WHOLE ? 0 : PER1 > 1 ? cmaxi((DQ_HI + PER1 - 2) / (PER1 - 1), (DQ_LO + PER1 - 1) / PER1) : DQ_HI;
       static_assert(DPT <= 2, "a tile's first chain places at most two DMA pieces");
       constexpr bool OV = G::WHOLE;  // (band geometries: a tile's existence is a run-time fact for every i - plain order)
       f32x4 A0[PER1], A1[PER1];
@@ -530,7 +549,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
           // saved for the backward as bf16 - the very value the next layer consumes (ReLU mask of the dgrad, im2col operand
           // of the wgrad) - at the start of y1's fp32-sized slot: one 16-byte store, half the bytes of the fp32 copy
           if (P.act)
-            *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(P.act) + ((long)cur * npx1 + oyi * a.OW1 + ox) * 32 + 8 * g) = pk;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(P.act) + (long)cur * npx1 * 32 + (unsigned)((oyi * a.OW1 + ox) * 32 + 8 * g)) = pk;  // uniform base + 32-bit lane offset
         }
       };
       u32x4 fa[6], fb[6];
@@ -592,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
           if (OV && i > 0) finish1(i - 1);  // (whole image, no last tile in this wave: its predecessor is still open)
         }
       }
-      static_assert(!G::WHOLE || PER1 * DPT * 4096 >= G::IMG_BYTES, "every piece of the next image is issued");
+      static_assert(!G::WHOLE || ((PER1 - (NFULL < 4 ? 1 : 0)) * DPT >= DQ_HI && PER1 * DPT >= DQ_LO), "every piece of the next image is issued");
       if (band + 1 < G::NB) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next band has landed
         __syncthreads();                                  // ... everyone's, and everyone is done reading this band
@@ -780,7 +799,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         const f32x4 acc = accs[mt];
         const bool ok = mt * 16 + r16 < npx3;
         if (P.act && ok)
-          *reinterpret_cast<f32x4*>(P.act + P.a_y3 + ((long)cur * npx3 + mt * 16 + r16) * 64 + 16 * w + 4 * g) =
+          *reinterpret_cast<f32x4*>(P.act + P.a_y3 + (long)cur * npx3 * 64 + (unsigned)((mt * 16 + r16) * 64 + 16 * w + 4 * g)) =
               f32x4{relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3])};
 #pragma unroll
         for (int q = 0; q < 4; q++)  // (only the last tile has padding lanes)

@@ -417,6 +417,56 @@ def test_encoder_fused_backward(H, W, accumulate):
                 "vs oracle autograd with bf16 operand rounding", name, e, floors[i].get(name))
 
 
+@pytest.mark.parametrize("H,W,n", [(84, 84, [300, 90, 5]), (64, 64, [200, 171]), (44, 60, [260])])
+def test_encoder_fused_backward_image_loop_and_single_launch_conv3(H, W, n, monkeypatch):
+    """More images than workgroups (every workgroup loops over several images through its double buffers, ragged
+    counts, problems of different sizes): the conv3 stage as ONE launch (soft-argmax backward + dgrad3 + wgrad3 with wave
+    roles, ebw_l3_kernel) against the same stage as four launches (TACORL_EBW_FUSE3=0) and against the generic bf16
+    path - same operand rounding everywhere, fp32 summation order differs; twice, for run-to-run determinism."""
+    from tacorl_amd import blocks, ops
+
+    dev = _dev()
+    flats, imgs, outs, acts, douts = [], [], [], [], []
+    for i, k in enumerate(n):
+        P = _enc_params(220 + i)
+        flat = torch.zeros(blocks.encoder_size(), device=dev)
+        blocks.load_named(blocks.encoder_views(flat), P)
+        flats.append(flat)
+        imgs.append(rnd(k, H, W, 3, seed=230 + i).to(dev).to(torch.bfloat16))
+        outs.append(torch.empty(k, 32, device=dev))
+        acts.append(torch.empty(ops.encoder_act_layout(k, H, W)[1], device=dev))
+        douts.append(rnd(k, 32, seed=240 + i).to(dev))
+    ops.encoder_fwd(imgs, flats, outs, acts, H, W, 1)
+    acts_b = []
+    for i, k in enumerate(n):
+        offs, tot = ops.encoder_act_layout(k, H, W)
+        ab = acts[i].clone()
+        for j in (0, 1):
+            seg = acts[i][offs[j]:offs[j + 1]]
+            ab[offs[j]:offs[j + 1]].view(torch.bfloat16)[: seg.numel()] = seg.to(torch.bfloat16)
+        acts_b.append(ab)
+    g_gen = [torch.full_like(f, float("nan")) for f in flats]
+    ops.encoder_bwd(imgs, flats, acts, douts, g_gen, H, W, 1)
+    res = {}
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("TACORL_EBW_FUSE3", mode)
+        g = [torch.full_like(f, float("nan")) for f in flats]
+        ops.encoder_bwd(imgs, flats, acts_b, douts, g, H, W, 1, fused=True)
+        torch.cuda.synchronize()
+        if mode in res:  # second run of the single-launch path: bit-identical (fixed reduction order, no atomics)
+            for i, (a, b) in enumerate(zip(res[mode], g)):
+                va, vb = blocks.encoder_views(a), blocks.encoder_views(b)
+                bad = {k: int((va[k] != vb[k]).sum()) for k in va if not torch.equal(va[k], vb[k])}
+                assert not bad, f"problem {i}: two runs differ in {bad}"
+        res[mode] = g
+    for i in range(len(n)):
+        v1, v0, vg = (blocks.encoder_views(x[i]) for x in (res["1"], res["0"], g_gen))
+        for name in v1:
+            assert torch.isfinite(v1[name]).all(), name
+            assert relerr(v1[name], v0[name]) < 2e-4, ("one launch vs four", name, relerr(v1[name], v0[name]))
+            assert relerr(v1[name], vg[name]) < 2e-3, ("vs generic bf16", name, relerr(v1[name], vg[name]))
+
+
 @pytest.mark.parametrize("dims,acts", [([64, 256, 256, 256, 32], [2, 2, 2, 0]), ([80, 256, 256, 256, 1], [2, 2, 2, 0]),
                                        ([32, 256, 256, 32], [1, 1, 0]), ([64, 128, 24], [2, 0])])
 def test_mlp_fused_forward(dims, acts):
