@@ -30,7 +30,7 @@ constexpr int cmaxi(int a, int b) { return a > b ? a : b; }
 #define EF_MAXCH 12     // 16-byte chunks per thread for one image (<= 49 152 B: up to ~90x90x3 bf16)
 #define EF_MAXP 16
 #ifndef EF_ACT_COST
-#define EF_ACT_COST 80  // cost of an image whose activations are also stored, in 1/64 of a plain image: 12.5 k vs 9.8 k clk
+#define EF_ACT_COST 72  // cost of an image whose activations are also stored, in 1/64 of a plain image: 10.7 k vs 9.5 k clk (per-workgroup clocks, -DEF_BLKCLK)
                         // (49 KB of stores through a ~14 B/clk per-CU store path; per-workgroup clocks of a -DEF_BLKCLK build,
                         // scratch/run_fused.py: critical workgroup 335 k clk at 64, 313 k at 72, 292 k at 80, 295 k at 84; mean 279 k)
 #endif
@@ -294,9 +294,12 @@ extern "C" int tacorl_ef_blk_read(unsigned long long* out) {
 #endif
 #ifdef EF_STAMPS
 __device__ unsigned long long ef_stamps[64];
+#ifndef EF_STAMP_WAVE
+#define EF_STAMP_WAVE 0
+#endif
 #define STAMP(k)                                                    \
   do {                                                              \
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                      \
+    if (blockIdx.x == 0 && threadIdx.x == 64 * EF_STAMP_WAVE) {     \
       const unsigned long long t_ = clock64();                      \
       atomicAdd(&ef_stamps[k], t_ - t_prev);                        \
       t_prev = t_;                                                  \
