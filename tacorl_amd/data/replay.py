@@ -119,33 +119,69 @@ def pad_actions(actions, frames, padded):
 
 
 class _PinnedRing:
-    """Small host tensors (ids, actions, flags) go to the device through pinned staging slots: a copy from pageable
-    memory blocks the host until the stream has reached it, i.e. for the whole step that is still running - the
-    feeder then cannot prepare batch i + 1 beside step i.  Each slot is reused only after the copies issued from it
-    have completed (an event per slot)."""
+    """Small host tensors (ids, actions, flags) go to the device through pinned staging slots and a private COPY stream.
+    * pageable source: the copy blocks the host until the stream has reached it, i.e. for the whole step still running;
+    * the compute stream itself: with ~10 steps of launches queued ahead of the GPU, hipMemcpyAsync (and the next
+      hipGraphLaunch behind it) block inside the runtime until the stream has drained - 8-14 ms stalls of both threads every
+      20-100 steps (stacks dumped in the stall: the producer in `copy_`, the trainer in `graph.replay`), +7 % on the
+      replay-fed step.  On its own stream the copy only waits, ON THE GPU, for the compute stream's position at the time
+      the slot is taken (every step that read this slot's device buffers has been enqueued by then), and the consumer's
+      stream waits for the slot's `ready` event (`wait_ready`).
+    Each slot is reused only after the copies issued from it have completed (the same event, on the host)."""
 
-    def __init__(self, device, slots=4):
+    def __init__(self, device, slots=6):
         self.dev, self.slots, self.k = device, [dict() for _ in range(slots)], 0
         self.events = [None] * slots
+        self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
 
     def begin(self):
         self.k = (self.k + 1) % len(self.slots)
         if self.events[self.k] is not None:
             self.events[self.k].synchronize()
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         return self.k
 
-    def put(self, slot, key, array):
-        a = np.ascontiguousarray(array)
-        h = self.slots[slot].get(key)
-        if h is None or h.shape != a.shape or h.dtype != torch.from_numpy(a).dtype:
-            h = self.slots[slot][key] = torch.empty(a.shape, dtype=torch.from_numpy(a).dtype).pin_memory()
-        h.numpy()[...] = a
-        return h.to(self.dev, non_blocking=True)
+    def put_all(self, slot, arrays):
+        """{key: host array} -> ONE pinned buffer of this slot -> ONE device buffer, moved by a copy KERNEL that reads the
+        mapped pinned pages (tacorl_copy_cols over the buffer as 4-byte words), not by hipMemcpyAsync: an async copy on a
+        stream that still waits for another stream blocked the producer inside the runtime until that wait had resolved
+        (7-8 ms per occurrence); a kernel launch is only queued.  Returns {key: device view}."""
+        arrs = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+        offs, off = {}, 0
+        for k, a in arrs.items():
+            offs[k] = off
+            off = (off + a.nbytes + 15) // 16 * 16
+        hd = self.slots[slot].get("_packed")
+        if hd is None or hd[0].numel() < off:
+            hd = self.slots[slot]["_packed"] = (torch.empty(off, dtype=torch.uint8).pin_memory(),
+                                               torch.empty(off, dtype=torch.uint8, device=self.dev))
+        hnp = hd[0].numpy()
+        for k, a in arrs.items():
+            hnp[offs[k]:offs[k] + a.nbytes] = a.reshape(-1).view(np.uint8)
+        if self.stream is not None:
+            from .. import ops
+            from .._lib import call
+
+            with torch.cuda.stream(self.stream):
+                call("tacorl_copy_cols", hd[0].data_ptr(), off // 4, hd[1].data_ptr(), off // 4, 1, off // 4, 0, 0, ops.stream())
+        else:
+            hd[1].copy_(hd[0])
+        return {k: hd[1][offs[k]:offs[k] + a.nbytes].view(torch.from_numpy(a).dtype).view(a.shape) for k, a in arrs.items()}
 
     def end(self, slot):
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.dev))
+        ev.record(self.stream)
         self.events[slot] = ev
+        return ev
+
+
+def wait_ready(batch):
+    """Called by the consumer (the modules' frame staging) on the stream that will read the batch: orders that stream
+    behind the copies of the batch's small tables (`batch["ready"]`, set by HbmReplay.batch)."""
+    ev = batch.get("ready") if isinstance(batch, dict) else None
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
 
 
 class HbmReplay:
@@ -176,22 +212,24 @@ class HbmReplay:
         all_ids = np.concatenate([s["frames"].reshape(-1), s["goal"]])
         check_ids(all_ids, min(int(v.shape[0]) for v in self.frames.values()))
         slot = self._ring.begin()
-        ids = self._ring.put(slot, "ids", all_ids)
-        acts_d = self._ring.put(slot, "actions", pad_actions(self.actions, s["frames"], s["padded"]))
-        disp_d = self._ring.put(slot, "disp", s["disp"])
-        self._ring.end(slot)
+        d = self._ring.put_all(slot, {"ids": all_ids.astype(np.int64, copy=False), "actions": pad_actions(self.actions, s["frames"], s["padded"]),
+                                      "disp": s["disp"]})
+        ids, acts_d, disp_d = d["ids"], d["actions"], d["disp"]
+        ready = self._ring.end(slot)
         if fused:
-            b = {"replay": {"frames": self.frames, "ids": ids, "B": n, "T": T}, "actions": acts_d, "disp": disp_d,
+            b = {"replay": {"frames": self.frames, "ids": ids, "B": n, "T": T}, "actions": acts_d, "disp": disp_d, "ready": ready,
                  "idx": torch.from_numpy(s["idx"]), "window_size": torch.from_numpy(s["window_size"])}
             if aug is not None:
                 b["aug"] = aug
             return b
+        if ready is not None and self._ring.stream is not None:
+            torch.cuda.current_stream(self.dev).wait_event(ready)  # the gathers below read the id table on this stream
         states, goal = {}, {}
         for c, fr in self.frames.items():
             H, W = fr.shape[1:3]
             states[c] = ops.gather_frames_u8(fr, ids[: n * T], self._out(("s", c), (n, T, H, W, 3)))
             goal[c] = ops.gather_frames_u8(fr, ids[n * T:], self._out(("g", c), (n, H, W, 3)))
-        b = {"states": states, "goal": goal, "actions": acts_d, "disp": disp_d, "idx": torch.from_numpy(s["idx"]),
+        b = {"states": states, "goal": goal, "actions": acts_d, "disp": disp_d, "ready": ready, "idx": torch.from_numpy(s["idx"]),
              "window_size": torch.from_numpy(s["window_size"])}
         if aug is not None:
             b["aug"] = aug

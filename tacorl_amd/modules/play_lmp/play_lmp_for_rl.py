@@ -203,7 +203,9 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
     """PlayLMP.training_step + the single Adam (reference play_lmp_for_rl.py:200-257,307-317,362-368)."""
     from ... import ops
     from ..._lib import BF16, F32, call, ptr
+    from ...data.replay import wait_ready
 
+    wait_ready(batch)  # a replay batch's small tables travel on the feeder's copy stream
     rp = batch.get("replay")  # frames by index out of a uint8 dataset (data/replay.py HbmReplay.batch(fused=True))
     states = rp["frames"] if rp is not None else batch["states"]
     cams, net, pr, ad = self.plan_proposal_obs_modalities, self.net, self.pr, self.ad

@@ -141,6 +141,9 @@ class TACORL(CQL_Offline):
         fixed buffers, copy the small tensors, draw / copy the noise.
         uint8 frames - the dataset's own format, (B, T, H, W, 3) with goal (B, H, W, 3) - are taken as they are
         and normalised on the way (ToTensor + Normalize(0.5, 0.5), bit-identical to the transformed fp32 frames)."""
+        from ...data.replay import wait_ready
+
+        wait_ready(batch)  # a replay batch's small tables travel on the feeder's copy stream
         rp = batch.get("replay")  # frames by index out of a uint8 dataset (data/replay.py HbmReplay.batch(fused=True))
         if rp is not None:
             u8, nchw, B, T = True, False, rp["B"], rp["T"]
