@@ -839,14 +839,27 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         mx[q] = m; se[q] = 0.f; sx[q] = 0.f; sy[q] = 0.f;
       }
       EF_ROW16_4("v_max_f32_dpp", mx);
-      // pass 2: exp and the three sums (exp2(-inf) = 0 masks the padded pixels)
+      // pass 2: exp and the three sums (exp2(-inf) = 0 masks the padded pixels) on packed fp32 pairs (v_pk_add / v_pk_fma:
+      // 12 instructions per tile instead of 28 - with contraction off every `s += e * f` was a multiply and an add)
+      {
+        const f32x2 m01 = {mx[0], mx[1]}, m23 = {mx[2], mx[3]};
+        f32x2 se01 = {0.f, 0.f}, se23 = {0.f, 0.f}, sxy[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-      for (int mt = 0; mt < NT3; mt++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const float e = __builtin_amdgcn_exp2f(v3[mt][q] - mx[q]);
-          se[q] += e; sx[q] += e * fx[mt]; sy[q] += e * fy[mt];
+        for (int mt = 0; mt < NT3; mt++) {
+          const f32x2 d01 = f32x2{v3[mt][0], v3[mt][1]} - m01, d23 = f32x2{v3[mt][2], v3[mt][3]} - m23;
+          const f32x2 e01 = {__builtin_amdgcn_exp2f(d01[0]), __builtin_amdgcn_exp2f(d01[1])};
+          const f32x2 e23 = {__builtin_amdgcn_exp2f(d23[0]), __builtin_amdgcn_exp2f(d23[1])};
+          se01 += e01; se23 += e23;
+          const f32x2 fxy = {fx[mt], fy[mt]};
+          sxy[0] = __builtin_elementwise_fma(f32x2{e01[0], e01[0]}, fxy, sxy[0]);
+          sxy[1] = __builtin_elementwise_fma(f32x2{e01[1], e01[1]}, fxy, sxy[1]);
+          sxy[2] = __builtin_elementwise_fma(f32x2{e23[0], e23[0]}, fxy, sxy[2]);
+          sxy[3] = __builtin_elementwise_fma(f32x2{e23[1], e23[1]}, fxy, sxy[3]);
         }
+        se[0] = se01[0]; se[1] = se01[1]; se[2] = se23[0]; se[3] = se23[1];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { sx[q] = sxy[q][0]; sy[q] = sxy[q][1]; }
+      }
       EF_ROW16_4("v_add_f32_dpp", se);
       EF_ROW16_4("v_add_f32_dpp", sx);
       EF_ROW16_4("v_add_f32_dpp", sy);
