@@ -895,15 +895,39 @@ __global__ __launch_bounds__(256) void adam_batch_kernel(AdamTbl t) {
   float* __restrict__ v = t.v[b];
   float* __restrict__ target = t.target[b];
   const float tau = t.tau[b];
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < t.n[b]; i += (long)nb * 256) {
-    const float gi = g[i] * coef;
-    const float mi = m[i] * 0.9f + gi * 0.1f;
-    const float vi = v[i] * 0.999f + (gi * gi) * 0.001f;
-    m[i] = mi; v[i] = vi;
+  // the same arithmetic per element as tacorl_adam_step (bit-identical); four elements per thread and access when the
+  // block is 16-byte aligned - the update is the tail of the step's dependent chain, 38 MB of traffic that took 20 us as
+  // seven 4-byte accesses per element
+  auto upd = [&](float pi, float gr, float& mi, float& vi, float& ti, bool has_t) {
+    const float gi = gr * coef;
+    mi = mi * 0.9f + gi * 0.1f;
+    vi = vi * 0.999f + (gi * gi) * 0.001f;
     const float denom = sqrtf(vi) / rsq_bc2 + 1e-8f;
-    const float pn = p[i] - step_size * (mi / denom);
-    p[i] = pn;
-    if (target) target[i] = target[i] * (1.0f - tau) + pn * tau;
+    const float pn = pi - step_size * (mi / denom);
+    if (has_t) ti = ti * (1.0f - tau) + pn * tau;
+    return pn;
+  };
+  const long n = t.n[b];
+  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)target) & 15) == 0);
+  const long n4 = vec ? n / 4 : 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)nb * 256) {
+    f32x4 P = reinterpret_cast<f32x4*>(p)[i], M = reinterpret_cast<f32x4*>(m)[i], V = reinterpret_cast<f32x4*>(v)[i];
+    const f32x4 G = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 T = target ? reinterpret_cast<f32x4*>(target)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float mi = M[e], vi = V[e], ti = T[e];
+      P[e] = upd(P[e], G[e], mi, vi, ti, target != nullptr);
+      M[e] = mi; V[e] = vi; T[e] = ti;
+    }
+    reinterpret_cast<f32x4*>(m)[i] = M; reinterpret_cast<f32x4*>(v)[i] = V; reinterpret_cast<f32x4*>(p)[i] = P;
+    if (target) reinterpret_cast<f32x4*>(target)[i] = T;
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)nb * 256) {
+    float mi = m[i], vi = v[i], ti = target ? target[i] : 0.f;
+    const float pn = upd(p[i], g[i], mi, vi, ti, target != nullptr);
+    m[i] = mi; v[i] = vi; p[i] = pn;
+    if (target) target[i] = ti;
   }
 }
 extern "C" size_t tacorl_adam_batch_ws_bytes(int nb) { return (size_t)nb * 1024 * sizeof(float); }
