@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         const u32x2 lo = pack4_bf16(fx_[0], fy_[0], fx_[1], fy_[1]), hi = pack4_bf16(fx_[2], fy_[2], fx_[3], fy_[3]);
         *reinterpret_cast<u32x4*>(sa + slot * SA_STRIDE + 4 * (16 * w + 4 * g)) = u32x4{lo[0], lo[1], hi[0], hi[1]};
         if (P.act) {
-          float* f = P.act + P.a_sa + (long)cur * 128 + 2 * (16 * w + 4 * g);
+          float* f = P.act + P.a_sa + (long)cur * 128 + (unsigned)(2 * (16 * w + 4 * g));  // uniform base + 32-bit lane offset
           *reinterpret_cast<f32x4*>(f) = f32x4{fx_[0], fy_[0], fx_[1], fy_[1]};
           *reinterpret_cast<f32x4*>(f + 4) = f32x4{fx_[2], fy_[2], fx_[3], fy_[3]};
         }
@@ -920,8 +920,8 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
           if (r16 < EF_CHUNK)
             *reinterpret_cast<u32x2*>(h1 + r16 * H1_STRIDE + (16 * (4 * w + j) + 4 * g) * 2) = pack4_bf16(r[0], r[1], r[2], r[3]);
           if (P.act && r16 < n_in_chunk)
-            *reinterpret_cast<f32x4*>(P.act + P.a_h1 + (worker + (long)(it - slot + r16) * nworkers) * 256 +
-                                      16 * (4 * w + j) + 4 * g) = r;
+            *reinterpret_cast<f32x4*>(P.act + P.a_h1 + (worker + (long)(it - slot) * nworkers) * 256 +
+                                      (unsigned)(r16 * (unsigned)nworkers * 256u + 16 * (4 * w + j) + 4 * g)) = r;  // (32-bit lane offset: < 16 * 256 workers * 1 KB)
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -934,8 +934,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         for (int s = 0; s < 8; s++)
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wf2[s]), as_bf16x8(*reinterpret_cast<const u32x4*>(base + 64 * s)), acc, 0, 0, 0);
         if (r16 < n_in_chunk) {
-          const long img_of_slot = worker + (long)(it - slot + r16) * nworkers;
-          float* o = P.out + img_of_slot * 32 + 16 * w + 4 * g;
+          float* o = P.out + (worker + (long)(it - slot) * nworkers) * 32 + (unsigned)(r16 * (unsigned)nworkers * 32u + 16 * w + 4 * g);
           f32x4 r = {acc[0] + c0, acc[1] + c1, acc[2] + c2, acc[3] + c3};
           *reinterpret_cast<f32x4*>(o) = r;
         }
