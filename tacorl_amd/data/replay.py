@@ -133,13 +133,16 @@ class _PinnedRing:
         self.dev, self.slots, self.k = device, [dict() for _ in range(slots)], 0
         self.events = [None] * slots
         self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        # the stream whose steps read the slots' device buffers: the one current where the ring is BUILT (the trainer's
+        # thread) - `begin` may run on a feeder thread, whose own current stream is the default one
+        self.consumer = torch.cuda.current_stream(device) if self.stream is not None else None
 
     def begin(self):
         self.k = (self.k + 1) % len(self.slots)
         if self.events[self.k] is not None:
             self.events[self.k].synchronize()
         if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+            self.stream.wait_stream(self.consumer)
         return self.k
 
     def put_all(self, slot, arrays):
@@ -187,13 +190,16 @@ def wait_ready(batch):
 class HbmReplay:
     """uint8 HWC frames of every camera resident in HBM: frames[cam] = (N,H,W,3) uint8 device tensor."""
 
-    def __init__(self, frames, actions, index, device=None):
+    def __init__(self, frames, actions, index, device=None, consumer_stream=None):
+        """consumer_stream: the stream the training steps run on (default: the stream current here, at construction)."""
         self.dev = torch.device(device) if device is not None else next(iter(frames.values())).device
         self.frames = {c: v.to(self.dev).contiguous() for c, v in frames.items()}
         self.actions = np.asarray(actions, dtype=np.float32)
         self.index = index
         self._buf = {}
         self._ring = _PinnedRing(self.dev)
+        if consumer_stream is not None:
+            self._ring.consumer = consumer_stream
 
     def _out(self, key, shape):
         t = self._buf.get(key)
