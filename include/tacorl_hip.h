@@ -423,6 +423,10 @@ enum {
 /* alpha_loss and d/dlog_alpha (cql_offline_lightning.py:447-449); grad scaled by grad_scale. */
 int tacorl_alpha_loss(const float* logp, int B, const float* log_alpha, float target_entropy,
                       float grad_scale, float* g_log_alpha, float* logs, tacorl_stream_t stream);
+/* One GPU: the same loss / gradient and Adam's step on log_alpha in ONE launch (adam arithmetic of tacorl_adam_step for
+ * n = 1 without clipping; the logged loss uses the pre-step log_alpha, reference cql_offline_lightning.py:447-455). */
+int tacorl_alpha_loss_step(const float* logp, int B, float* log_alpha, float target_entropy, float* g_log_alpha,
+                           float* logs, float* m, float* v, float lr, int* step_counter, tacorl_stream_t stream);
 /* Q phase actor loss mean(alpha*logpi - min(q1,q2)) and dL/dq_i (:463-466). */
 int tacorl_actor_qmin(const float* q1, const float* q2, const float* logp, int B, const float* log_alpha,
                       float* dq1, float* dq2, float grad_scale, float* logs, tacorl_stream_t stream);

@@ -10,6 +10,7 @@ mod = bench.build_module(dev, "bf16", 16, 1)
 batches = [bench.synth_batch(256, 16, 84, 84, dev, 1), bench.synth_batch(256, 16, 84, 84, dev, 2)]
 mod.enable_graph(); mod.log_every_n_steps = 50
 def setv(path, v):
+    torch.cuda.synchronize()  # (no graph may still be replaying when the captures are dropped)
     if path.startswith("env:"):
         os.environ[path[4:]] = str(v)
         mod._graphs = {}

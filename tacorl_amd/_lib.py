@@ -113,6 +113,7 @@ _SIGS = {
     "tacorl_tanh_normal_sample": (_i, [_p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _p]),
     "tacorl_tanh_normal_sample_batch": (_i, [_i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p]),
     "tacorl_alpha_loss": (_i, [_p, _i, _p, _f, _f, _p, _p, _p]),
+    "tacorl_alpha_loss_step": (_i, [_p, _i, _p, _f, _p, _p, _p, _p, _f, _p, _p]),
     "tacorl_actor_qmin": (_i, [_p, _p, _p, _i, _p, _p, _p, _f, _p, _p]),
     "tacorl_actor_head_bwd": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _f, _p, _i, _i, _i, _p, _p]),
     "tacorl_cql_ws_bytes": (_sz, [_i]),

@@ -544,6 +544,40 @@ __global__ __launch_bounds__(256) void alpha_loss_kernel(const float* __restrict
     logs[LG_ALPHA_LOSS] = -(log_alpha[0] * mean);
   }
 }
+// The same loss and gradient, then Adam's step on log_alpha in the same launch (one GPU: the gradient needs no
+// all-reduce between the two; with several ranks tacorl_alpha_loss + collective #1 + tacorl_adam_step stay separate).
+// alpha_loss is logged with the PRE-step log_alpha as the reference does; the update is adam_kernel's arithmetic for a
+// single element without clipping (bit-identical to tacorl_adam_step(n = 1, max_norm = 0)).
+__global__ __launch_bounds__(256) void alpha_loss_step_kernel(const float* __restrict__ logp, int B, float* log_alpha,
+                                                              float target_entropy, float* g_log_alpha, float* logs,
+                                                              float* m, float* v, float lr, int* step_counter) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) s += logp[i] + target_entropy;
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) {
+    const float mean = s / (float)B, la = log_alpha[0];
+    const float gi = -mean * 1.0f;  // (grad_scale = 1 / world = 1)
+    g_log_alpha[0] = gi;
+    logs[LG_ALPHA_LOSS] = -(la * mean);
+    const int t = step_counter[0] + 1;
+    step_counter[0] = t;
+    const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
+    const float step_size = (float)((double)lr / bc1), rsq_bc2 = (float)sqrt(bc2);
+    const float mi = m[0] * 0.9f + gi * 0.1f;
+    const float vi = v[0] * 0.999f + (gi * gi) * 0.001f;
+    m[0] = mi; v[0] = vi;
+    const float denom = sqrtf(vi) / rsq_bc2 + 1e-8f;
+    log_alpha[0] = la - step_size * (mi / denom);
+  }
+}
+extern "C" int tacorl_alpha_loss_step(const float* logp, int B, float* log_alpha, float target_entropy,
+                                      float* g_log_alpha, float* logs, float* m, float* v, float lr, int* step_counter,
+                                      tacorl_stream_t stream) {
+  hipLaunchKernelGGL(alpha_loss_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, B, log_alpha,
+                     target_entropy, g_log_alpha, logs, m, v, lr, step_counter);
+  return LAUNCH_OK();
+}
 extern "C" int tacorl_alpha_loss(const float* logp, int B, const float* log_alpha, float target_entropy,
                                  float grad_scale, float* g_log_alpha, float* logs, tacorl_stream_t stream) {
   hipLaunchKernelGGL(alpha_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, B, log_alpha,

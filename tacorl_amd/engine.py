@@ -460,7 +460,7 @@ class ACEngine:
         Three collective-free phases (each hipGraph-capturable) separated by the step's two all-reduces:
         a) forward up to the alpha gradient; b) alpha step, critics, losses, every backward;
         c) optimiser steps + soft target update."""
-        self.phase_a(encoded)
+        self.phase_a(encoded, optimize)
         self.allreduce_alpha()
         self.phase_b(bc_phase, optimize)
         self.allreduce_grads()
@@ -472,7 +472,7 @@ class ACEngine:
     def allreduce_grads(self):
         self._allreduce([self.grad_arena])
 
-    def phase_a(self, encoded=False):
+    def phase_a(self, encoded=False, optimize=True):
         B, n, A, Ac, hp, nz = self.B, self.n, self.A, self.Ac, self.hp, self.noise
         gs = 1.0 / self.world
         if not encoded:
@@ -498,8 +498,15 @@ class ACEngine:
              ops.ptr_array([j[6] for j in jobs]), ops.int_array([j[7] for j in jobs]), B, Ac, ptr(nz["u_rand"]),
              at(self.acts_main, B * A), n * B, A, int(self.dg), ops.stream())
         # alpha: loss, gradient, Adam step (alpha is read post-step below; SURVEY 8a note 2)
-        call("tacorl_alpha_loss", ptr(self.logp_pi), B, ptr(self.log_alpha.param), float(hp["target_entropy"]), gs,
-             ptr(self.log_alpha.grad), ptr(self.logs), ops.stream())
+        # (one GPU and an optimising step: loss + gradient + Adam in one launch; otherwise the step follows collective #1)
+        self._alpha_stepped = bool(optimize and self.world == 1 and not getattr(self, "split_alpha_step", False))
+        if self._alpha_stepped:
+            la = self.log_alpha
+            call("tacorl_alpha_loss_step", ptr(self.logp_pi), B, ptr(la.param), float(hp["target_entropy"]), ptr(la.grad),
+                 ptr(self.logs), ptr(la.m), ptr(la.v), float(hp["actor_lr"]), ptr(la.step), ops.stream())
+        else:
+            call("tacorl_alpha_loss", ptr(self.logp_pi), B, ptr(self.log_alpha.param), float(hp["target_entropy"]), gs,
+                 ptr(self.log_alpha.grad), ptr(self.logs), ops.stream())
         ops.mark("a:alpha")
         if getattr(self, "_prepacked", False):  # the side branch ends inside this phase
             torch.cuda.current_stream().wait_stream(self._pack_stream)
@@ -509,7 +516,7 @@ class ACEngine:
         B, n, A, Ac, hp, nz = self.B, self.n, self.A, self.Ac, self.hp, self.noise
         gs = 1.0 / self.world
         head_cur = self._head("a")
-        if optimize:
+        if optimize and not getattr(self, "_alpha_stepped", False):
             ops.adam_step(self.log_alpha.param, self.log_alpha.grad, self.log_alpha.m, self.log_alpha.v,
                           hp["actor_lr"], 0.0, self.log_alpha.step)
         # Q inputs: [S | action]; the data action is read here first (phase_a does not need it, so a caller

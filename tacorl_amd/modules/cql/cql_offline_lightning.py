@@ -190,7 +190,7 @@ class CQL_Offline(GraphMixin, ModuleMixin, LightningModuleBase):
         bc = self.current_epoch < self.bc_epochs
         e = self.engine
         self._run_segments(("cql", e.B, bc, optimize),
-                           [lambda: e.phase_a(), lambda: e.phase_b(bc, optimize), lambda: e.phase_c(optimize)],
+                           [lambda: e.phase_a(optimize=optimize), lambda: e.phase_b(bc, optimize), lambda: e.phase_c(optimize)],
                            [e.allreduce_alpha, e.allreduce_grads])
         self._publish_logs(log_type)
 

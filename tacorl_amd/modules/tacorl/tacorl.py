@@ -303,7 +303,7 @@ class TACORL(CQL_Offline):
                 ops.mark("ad:end")
             self._ad_join = self._side_stream
         e.action_ready = ready
-        e.phase_a(encoded=True)
+        e.phase_a(encoded=True, optimize=optimize)
         segmented = self.world_size > 1 or getattr(self, "_force_graph_split", False) or not self._use_graph
         if with_ad and not ad_on_side:
             if segmented:
