@@ -13,6 +13,8 @@ gradients, optimiser steps and soft target update, but scheduled MI355X-first:
 
 Random draws are explicit inputs (`noise` dict, reference draw order - SURVEY 8a note 1).
 """
+import os
+
 import torch
 
 from . import blocks, ops
@@ -311,7 +313,11 @@ class ACEngine:
     use_fused = True  # tests flip this to compare the fused launch against the per-layer path
     # MLP weight gradients on side streams (parallel graph branches): they are needed only by Adam, so
     # they leave the dependent chain of the update (1.70 -> 1.60 ms/step at the bench shapes)
-    wgrad_side_streams = True
+    # MLP weight gradients on side streams (graph branches joined before the optimiser) or in line behind their input-gradient
+    # launch: True / False / a collection of site tags ("q", "pi", "genc").  In line since round 3: beside the action-decoder
+    # branch's chip-wide GEMMs a third set of concurrent launches costs the chain more than its own kernels' time
+    # (same-process A/B on the headline step: 0.8801 -> 0.8682 ms; TACORL_WGRAD_SIDE=1 restores the branches)
+    wgrad_side_streams = os.environ.get("TACORL_WGRAD_SIDE", "0") == "1"
     conv_wgrad_side_stream = False  # measured: 0.97 -> 1.12 ms/step when on (co-resident workgroups slow the chain); conv3 / conv2 weight gradients beside the dgrad chain (see _encoders_backward)
 
     def _fused_ok(self, c):
@@ -611,7 +617,8 @@ class ACEngine:
                                 prepacked=getattr(self, "_prepacked", False))
         if all(g is None for g in grads):
             return
-        if not self.wgrad_side_streams:
+        side = self.wgrad_side_streams
+        if not (side is True or (side and tag in side)):  # True / False / a collection of site tags
             ops.mlp_bwd_fused_wgrad(xs, ldx, acts_buf, d_outs, ldo, grads, M, dims, acts, "mlp_bwdf_" + tag, lean=self._lean(tag))
             return
         if not hasattr(self, "_wg_streams"):
