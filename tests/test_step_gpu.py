@@ -397,9 +397,16 @@ def _with_bf16_sensitivity(floor, g_rounded, g_fp32):
     return out
 
 
-def _bf16_compare(mod, got, ologs, ograds, P_before, P_after, step, plan=None, oplan=None, floor=None):
+def _bf16_compare(mod, got, ologs, ograds, P_before, P_after, step, plan=None, oplan=None, floor=None, acc_rows=None):
     bad = []
     for k, v in ologs.items():
+        if acc_rows and "accuracy" in k and k in got:
+            # a count over acc_rows rows: with bf16 operand rounding ONE row whose two gripper logits are within rounding of
+            # each other may fall on either side (the f32 test holds the same metric to 1e-4); more than one row is an error
+            record_margin(k, abs(got[k] - float(v)) * acc_rows, 1.0 + 1e-3, kind="logged count (rows)")
+            if abs(got[k] - float(v)) * acc_rows > 1.0 + 1e-3:
+                bad.append(f"{k}: {got[k]:.7g} vs rounded oracle {float(v):.7g} (more than one of {acc_rows} rows)")
+            continue
         # Q heads start at +-1e-3 (reference critic.py:86-87): q*_data/random/policy are ~1e-2 sums with an absolute
         # bf16 noise of ~3e-5, hence the 5e-2 floor of the relative scale
         if k in got:
@@ -529,7 +536,7 @@ def test_playlmp_step_bf16_vs_rounded_oracle():
             ologs, ograds = O.playlmp_step(P, opt, batch, nz, cams)
             floor = gradient_floor(lambda Pp: O.playlmp_step(Pp, copy.deepcopy(opt0), batch, nz, cams)[1], before, ograds)
         floor = _with_bf16_sensitivity(floor, ograds, O.playlmp_step(_snap(before), copy.deepcopy(opt0), batch, nz, cams)[1])
-        bad += _bf16_compare(mod, got, ologs, ograds, before, P, step, floor=floor)
+        bad += _bf16_compare(mod, got, ologs, ograds, before, P, step, floor=floor, acc_rows=batch["actions"].shape[0] * (c["T"] - 1))
     assert not bad, "\n".join(bad[:30])
 
 
