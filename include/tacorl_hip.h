@@ -378,6 +378,11 @@ int tacorl_pr_sample(const float* head, const float* eps, float* plan, float* mu
 /* Time-major RNN input x[(t*B+b)] = [plan[b] | emb[b*T+t]], t < Tm (:279-281). */
 int tacorl_build_ad_input(const float* plan, const float* emb, int ld_emb, float* out, int B, int T,
                           int Tm, int P, int E, tacorl_stream_t stream);
+/* bf16 compute: the RNN's layer-0 input projection straight from (plan, frame embeddings), without x_seq:
+ * out[t*B + b][n] = b_ih[n] + sum_k bf16(x[k]) bf16(w_ih[n][k]), x = [plan[b] (P) | emb[b*T + t] (E)], P + E <= 64, H % 16 == 0
+ * (reference action_decoder_logistic.py:279-281 + nn.RNN's weight_ih_l0). */
+int tacorl_ad_input_proj(const float* plan, const float* emb, int ld_emb, const float* w_ih, const float* b_ih,
+                         float* out, int B, int T, int Tm, int P, int E, int H, tacorl_stream_t stream);
 size_t tacorl_logistic_mixture_ws_bytes(int B, int Tm, int Da);
 /* Discretised-logistic-mixture NLL + gripper CE (:110-235), forward + backward fused.
  * heads[(t*B+b)] = [means Da*K | log_scales Da*K | logit_probs Da*K | gripper 2]; actions batch-major

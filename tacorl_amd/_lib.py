@@ -58,6 +58,7 @@ _SIGS = {
     "tacorl_mean_over_t": (_i, [_p, _p, _i, _i, _i, _p]),
     "tacorl_pr_sample": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "tacorl_build_ad_input": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "tacorl_ad_input_proj": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "tacorl_logistic_mixture_ws_bytes": (_sz, [_i, _i, _i]),
     "tacorl_logistic_mixture_loss": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p]),
     "tacorl_logistic_mixture_sample": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _p]),

@@ -197,6 +197,69 @@ extern "C" int tacorl_build_ad_input(const float* plan, const float* emb, int ld
   return LAUNCH_OK();
 }
 
+// The RNN's layer-0 input projection straight from (plan, frame embeddings): xin[t*B + b][n] = b_ih[n] +
+// sum_k bf16(x[t*B + b][k]) bf16(W_ih[n][k]),  x = [plan[b] | emb[b*T + t]]  (K = P + E <= 64) - build_ad_input + the generic
+// GEMM were two launches (4 + 21 us: a K = 48 contraction is all epilogue) at the head of the action-decoder branch.
+// W is the MFMA A operand (a lane ends with 4 consecutive n of one row: 16-byte stores), a wave owns 16 rows x 512
+// columns, a workgroup 64 rows; bf16 operand rounding and fp32 accumulation as the generic bf16 path.
+__global__ __launch_bounds__(256) void ad_input_proj_kernel(const float* __restrict__ plan, const float* __restrict__ emb,
+                                                            int ld_emb, const float* __restrict__ W, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int B, int T, int Tm, int P, int E, int H) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
+  const int R = Tm * B, K = P + E;
+  const int r = blockIdx.x * 64 + 16 * w + m, rc = r < R ? r : R - 1;
+  const int b = rc % B, t = rc / B;
+  bf16x8 X[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = 32 * ks + 8 * g + j;
+      const float v = k < P ? plan[(long)b * P + k] : (k < K ? emb[((long)b * T + t) * ld_emb + (k - P)] : 0.f);
+      X[ks][j] = (__bf16)v;
+    }
+  const int n_begin = blockIdx.y * 512, n_end = min(H, n_begin + 512);
+  // four column tiles per iteration, every W load of the group in flight before the first conversion (one tile at a time
+  // the loop was a chain of L2 round trips: 32 x ~1.5 us per wave)
+  constexpr int NU = 4;
+  const bool k2 = 32 + 8 * g < K;  // this lane's second k-step holds real columns (K = 48: g < 2)
+  for (int n0 = n_begin; n0 < n_end; n0 += 16 * NU) {
+    f32x4 raw[NU][4];
+    f32x4 acc[NU];
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const int nn = min(n0 + 16 * u, n_end - 16);
+      const float* wr = W + (long)(nn + m) * K + 8 * g;  // A operand: row nn + m of W, 8 consecutive k per k-step
+      raw[u][0] = *reinterpret_cast<const f32x4*>(wr);
+      raw[u][1] = *reinterpret_cast<const f32x4*>(wr + 4);
+      raw[u][2] = k2 ? *reinterpret_cast<const f32x4*>(wr + 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+      raw[u][3] = k2 ? *reinterpret_cast<const f32x4*>(wr + 36) : f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[u] = *reinterpret_cast<const f32x4*>(bias + nn + 4 * g);  // D rows = n: this lane's 4 consecutive columns
+    }
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        bf16x8 A;
+#pragma unroll
+        for (int j = 0; j < 8; j++) A[j] = (__bf16)raw[u][2 * ks + (j >> 2)][j & 3];
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, X[ks], acc[u], 0, 0, 0);
+      }
+      if (r < R && n0 + 16 * u < n_end) *reinterpret_cast<f32x4*>(out + (long)r * H + n0 + 16 * u + 4 * g) = acc[u];
+    }
+  }
+}
+extern "C" int tacorl_ad_input_proj(const float* plan, const float* emb, int ld_emb, const float* w_ih, const float* b_ih,
+                                    float* out, int B, int T, int Tm, int P, int E, int H, tacorl_stream_t stream) {
+  // (K % 8 == 0 and 16-byte aligned W rows: the fragment loads are 16-byte vectors; columns 32.. need whole 8-groups)
+  if (P + E > 64 || (P + E) % 8 || H % 16 || H < 16 || B < 1 || Tm < 1) return TACORL_EINVAL;
+  if (((uintptr_t)out | (uintptr_t)b_ih | (uintptr_t)w_ih) & 15) return TACORL_EINVAL;
+  const int R = B * Tm;
+  hipLaunchKernelGGL(ad_input_proj_kernel, dim3((R + 63) / 64, (H + 511) / 512), dim3(256), 0, (hipStream_t)stream, plan, emb,
+                     ld_emb, w_ih, b_ih, out, B, T, Tm, P, E, H);
+  return LAUNCH_OK();
+}
+
 // Discretised logistic mixture NLL + gripper cross-entropy, forward and backward fused
 // (reference action_decoder_logistic.py:110-235; bounds +-1, num_classes bins, n_mix mixtures).
 // heads[(t*B+b)] = [means (Da*K) | log_scales (Da*K) | logit_probs (Da*K) | gripper (2)], ld = ldh.

@@ -146,9 +146,13 @@ class ActionDecoderLogistic:
         (load_state_dict / copy_)."""
         self._ensure(B, Tm)
         blk, H, R = self.blk, self.hidden, B * Tm
-        call("tacorl_build_ad_input", ptr(plan), ptr(emb), ld_emb, ptr(self.x_seq), B, T, Tm, self.P, self.E,
-             ops.stream())
         x, K = self.x_seq, self.P + self.E
+        # bf16 mode: the layer-0 projection reads (plan, embeddings) itself (tacorl_ad_input_proj); x_seq is then only the
+        # weight-gradient operand of a backward that follows (not built for the frozen, logging-only pass)
+        proj_fused = compute == ops.BF16 and K <= 64 and K % 8 == 0 and H % 16 == 0 and getattr(self, "fused_input_proj", True)
+        if not (proj_fused and frozen):
+            call("tacorl_build_ad_input", ptr(plan), ptr(emb), ld_emb, ptr(self.x_seq), B, T, Tm, self.P, self.E,
+                 ops.stream())
         # bf16 mode: the recurrent step runs as ONE launch (LDS-DMA ring GEMM, rnn_ops.hip) on bf16 copies of
         # W_hh (refreshed here: the weights may have been stepped) and of the previous hidden state
         fast = compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H))
@@ -167,7 +171,11 @@ class ActionDecoderLogistic:
             # input projection of step s-2l+1 of layers l >= 1 (operand h_{l-1}[s-2l+1] left launch s-1) as
             # independent problems of ONE batched ring-GEMM launch whose workgroups are co-resident:
             # T + 2(L-1) dependent launches instead of L*T + (L-1).
-            self._lin(x, K, blk.p("rnn.weight_ih_l0"), blk.p("rnn.bias_ih_l0"), self.xin[0], R, K, H, ACT_NONE, compute)
+            if proj_fused:
+                call("tacorl_ad_input_proj", ptr(plan), ptr(emb), ld_emb, blk.p("rnn.weight_ih_l0"), blk.p("rnn.bias_ih_l0"),
+                     ptr(self.xin[0]), B, T, Tm, self.P, self.E, H, ops.stream())
+            else:
+                self._lin(x, K, blk.p("rnn.weight_ih_l0"), blk.p("rnn.bias_ih_l0"), self.xin[0], R, K, H, ACT_NONE, compute)
             L = self.L
             hbp = lambda l, t: C.c_void_p(self.hb[l].data_ptr() + 2 * t * B * H)  # noqa: E731
             for s_ in range(Tm + 2 * (L - 1)):
