@@ -203,6 +203,10 @@ extern "C" int tacorl_rnn_linear_bwd_batch(int nprob, const void* const* x_bf16,
     if ((uintptr_t)yb & 7) return TACORL_EINVAL;
     ab.p[p] = RnnArgs{(const __bf16*)x_bf16[p], (const __bf16*)wt_bf16[p], nullptr, ad, ms, y[p], (__bf16*)yb, M, K, N, ld_add, ACT_NONE};
   }
+  {
+    const char* se = getenv("TACORL_RNN_SMALL_UPTO");  // (see tacorl_rnn_linear_fwd_batch)
+    if (nprob <= (se ? atoi(se) : 2) && M % 64 == 0 && N % 32 == 0) return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
+  }
   if (M % 128 == 0 && N % 64 == 0) return launch_ring<128, 64, 2, 8>(ab, nprob, (hipStream_t)stream);
   return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
 }
@@ -392,6 +396,13 @@ extern "C" int tacorl_rnn_linear_fwd_batch(int nprob, const void* const* x_bf16,
   static const int tile = [] { const char* e = getenv("TACORL_RNN_TILE"); return e ? atoi(e) : 0; }();  // A/B switch
   if (tile == 1 && M % 128 == 0 && N % 128 == 0) return launch_ring<128, 128, 2, 8>(ab, nprob, (hipStream_t)stream);
   if (tile == 3 && M % 64 == 0 && N % 128 == 0) return launch_ring<64, 128, 2, 4>(ab, nprob, (hipStream_t)stream);
+  // the first two and the last two launches of a wavefront hold one or two problems: 64 / 128 workgroups of 128 x 64
+  // tiles - a quarter / half of the chip, each streaming 768 KB; as 64 x 32 tiles they are 256 / 512 workgroups streaming
+  // 384 KB each.  Same-process A/B on the headline step: small tiles for nprob <= 1 / <= 2 / <= 3: -8.5 / -16 / +14 us
+  // (three problems as 768 small workgroups crowd the step's other branches).  TACORL_RNN_SMALL_UPTO overrides.
+  const char* se = getenv("TACORL_RNN_SMALL_UPTO");
+  const int small_upto = se ? atoi(se) : 2;  // problems per launch up to which the small tile is used
+  if (nprob <= small_upto && M % 64 == 0 && N % 32 == 0) return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
   if (M % 128 == 0 && N % 64 == 0) return launch_ring<128, 64, 2, 8>(ab, nprob, (hipStream_t)stream);
   return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
 }
