@@ -9,8 +9,9 @@
 // no split, no second launch; bias, the input-projection addend and the activation are applied in the
 // epilogue, which also writes the bf16 copy that is the next step's operand.  Tile shapes in use:
 // 64 x 32 / 4 stages / 4 waves (single recurrent step, BPTT step), 128 x 64 / 3 stages / 4 waves
-// (sequence-wide projections), 128 x 64 / 2 stages / 8 waves (the wavefront batches of up to 4 problems:
-// a quarter of the workgroups of the 64 x 32 variant at the same launch time).
+// (sequence-wide projections), 128 x 64 / 2 stages / 8 waves (the wavefront batches of 3 - 4 problems:
+// a quarter of the workgroups of the 64 x 32 variant at the same launch time; the head and tail launches of a
+// wavefront, one or two problems, take 64 x 32 / 2 stages: they would fill a quarter / half of the chip otherwise).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
