@@ -47,7 +47,7 @@ def synth_batch(B, T, H, W, dev, seed):
             "disp": disp}
 
 
-def build_module(dev, compute, T, world, ad_every=1):
+def build_module(dev, compute, T, world, ad_every=1, finetune=False):
     from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
     from tacorl_amd.modules.tacorl.tacorl import TACORL
 
@@ -62,7 +62,7 @@ def build_module(dev, compute, T, world, ad_every=1):
     lmp = PlayLMP(plan_proposal=actor, plan_recognition=pr, action_decoder=ad, plan_proposal_obs_modalities=cams,
                   plan_proposal_goal_modalities=cams, plan_recognition_modalities=cams, action_decoder_modalities=cams,
                   real_world=True, device=dev, compute_dtype=compute, image_dtype=compute)
-    mod = TACORL(play_lmp=lmp, finetune_action_decoder=False, critic=critic, real_world=True, device=dev,
+    mod = TACORL(play_lmp=lmp, finetune_action_decoder=finetune, critic=critic, real_world=True, device=dev,
                  compute_dtype=compute, image_dtype=compute, world_size=world, action_loss_every_n_steps=ad_every,
                  # config/module/tacorl.yaml:8-30
                  action_decoder_lr=3e-4, actor_lr=1e-4, critic_lr=3e-4, discount=0.95, conservative_weight=1.0,
@@ -96,12 +96,12 @@ def time_encoder_fwd(mod, B, H, W, iters=100):
 def time_encoder_in_step(mod, batch, steps=40):
     """The same launch timed where it runs: HIP events around the encoder-forward launch INSIDE training steps (eager
     replays of the step, events on the stream the launch is issued on).  The chip holds a higher clock for a kernel
-    that sits between the step's lighter phases than for 100 copies of it back to back (rocprofv3 kernel trace of this
-    command, profiles/: 126.7 us in the step, 135-145 us in the back-to-back probe) - this is the duration the step pays.
-    An event bracket also contains the launch gaps on either side of the kernel (6.9 us around a 1-thread kernel on a
-    busy stream, scratch/event_overhead.py), so every step brackets a 1-thread time-mark launch right behind the
-    encoder's: kernel duration = encoder bracket - (time-mark bracket - 2.4 us).  The 2.4 us calibrate the bracket against
-    rocprofv3's kernel trace of the same launches (profiles/r03_encoder_launches.json: 128.0 us there, 127.9 us here).
+    that sits between the step's lighter phases than for 100 copies of it back to back - this is the duration the step
+    pays.  An event bracket also contains the launch gaps on either side of the kernel; they are measured, not assumed:
+    right behind the encoder's bracket every step brackets ONE 1-thread time-mark launch (n1) and then TWO of them (n2).
+    n2 - n1 = one more tiny launch (its duration + its gap), so the bracket's own overhead is n1 - (n2 - n1) = 2 n1 - n2 and
+    kernel duration = encoder bracket - (2 n1 - n2).  No fitted constant (round 3 subtracted a calibrated 2.4 us); the
+    evidence for the figure is rocprofv3's kernel trace of the same command (profiles/).
     Returns (kernel ms, raw bracket ms, bracket overhead ms)."""
     from tacorl_amd import ops
     from tacorl_amd._lib import call, ptr
@@ -113,12 +113,15 @@ def time_encoder_in_step(mod, batch, steps=40):
     mark = torch.zeros(8, dtype=torch.int64, device=mod.device)
 
     def timed(c, pr):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
         orig(c, pr)
         ev[1].record()
         call("tacorl_time_mark", ptr(mark), 0, ops.stream())
         ev[2].record()
+        call("tacorl_time_mark", ptr(mark), 1, ops.stream())
+        call("tacorl_time_mark", ptr(mark), 2, ops.stream())
+        ev[3].record()
         pairs.append(ev)
 
     mod._use_graph = False
@@ -131,21 +134,33 @@ def time_encoder_in_step(mod, batch, steps=40):
         torch.cuda.synchronize()
     finally:
         e._launch_fused, mod._use_graph = orig, was_graph
-    raw = sum(a.elapsed_time(b) for a, b, _ in pairs) / len(pairs)
-    null = sum(b.elapsed_time(c) for _, b, c in pairs) / len(pairs)
-    over = max(null - 2.4e-3, 0.0)
+    raw = sum(ev[0].elapsed_time(ev[1]) for ev in pairs) / len(pairs)
+    n1 = sum(ev[1].elapsed_time(ev[2]) for ev in pairs) / len(pairs)
+    n2 = sum(ev[2].elapsed_time(ev[3]) for ev in pairs) / len(pairs)
+    over = min(max(2 * n1 - n2, 0.0), n1)
     for _ in range(3):  # back on the captured path
         mod.training_step(batch)
     return raw - over, raw, over
 
 
+def kernel_source_hash():
+    import hashlib
+
+    with open(os.path.join(ROOT, "tacorl_amd", "csrc", "encoder_fused.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def measured_traffic(n_img, fused, dtype):
-    """HBM bytes per launch of the roofline kernel from the committed PMC passes
-    (profiles/r03_fused_traffic.json: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of this
-    very command, gfx950 correction applied).  null when this run's launch is not the measured one."""
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/r04_fused_traffic.json:
+    FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of this very command, gfx950 correction applied;
+    scratch/gpu_traffic.sh).  The file records the sha256 of the kernel source it was measured on: null when the source
+    has changed since (a stale figure must not ride on a new kernel), or when this run's launch is not the measured one."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_fused_traffic.json")) as f:
-            m = json.load(f)["bench_launch"]
+        with open(os.path.join(ROOT, "profiles", "r04_fused_traffic.json")) as f:
+            doc = json.load(f)
+        m = doc["bench_launch"]
+        if doc.get("encoder_fused_hip_sha256") != kernel_source_hash():
+            return None
     except (OSError, KeyError, ValueError):
         return None
     if fused and dtype == "bf16" and m["images_per_launch"] == n_img:
@@ -180,6 +195,98 @@ def cpu_baseline(mod, batch_cpu, noise_cpu, B, budget_s=25.0):
             "sample": f"{reps} full training steps at batch {B} (T=16, 84x84, n=4, Q phase), reference schedule "
                       f"(88*B encoder images/step), after 1 warm-up step; torch-CPU fp32, {cores} threads",
             "s_per_step": round(dt, 3)}
+
+
+def segment_probe(dtype):
+    """`--probe segments` (a child process of the default run; also runnable by hand): the per-GPU step SHAPE of an N-GPU
+    run, timed on this one GPU with RCCL really in the loop.  torch.distributed is initialised with backend nccl (= RCCL)
+    and world_size 1 and TACORL_FORCE_COLLECTIVES=1 makes every collective of a data-parallel step execute (an all-reduce
+    over one rank is the identity): all-reduce #1 (d log alpha) and #2 (the gradient arena) eager between the step's three
+    hipGraph segments - the default N-GPU form - and, second, captured as nodes of the step's one graph
+    (TACORL_GRAPH_COLLECTIVES=1).  Same process, same module, alternating with the collective-free single graph, so the three
+    numbers are a same-box A/B.  Shapes: C2 at B=256 (the weak-scaling share) and C3 (decoder fine-tuning on) at B=32
+    (its strong-scaling share of a global batch of 256 on 8 GPUs).  Prints one JSON object."""
+    import torch.distributed as dist
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from tacorl_amd import _lib
+
+    _lib.call("tacorl_hip_init", 0)
+    warm = torch.ones(1024, device=dev)
+    dist.all_reduce(warm)
+    torch.cuda.synchronize()
+    with open("/proc/self/maps") as f:
+        rccl = sorted({ln.split()[-1] for ln in f if "librccl" in ln})
+
+    def timeit(mod, batch, n):
+        for _ in range(12):
+            mod.training_step(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            mod.training_step(batch)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def forms(mod, batch, n):
+        out = {}
+        best = {}
+        for rep in range(2):  # alternate the forms twice; report the better pass of each (the box drifts by 1-2 %)
+            for name, force, ing in (("single_graph_no_collectives", "0", "0"), ("three_segments_eager_rccl", "1", "0"),
+                                     ("one_graph_rccl_nodes", "1", "1")):
+                if out.get(name) == "failed":
+                    continue
+                os.environ["TACORL_FORCE_COLLECTIVES"], os.environ["TACORL_GRAPH_COLLECTIVES"] = force, ing
+                mod._graphs = {}
+                try:
+                    ms = timeit(mod, batch, n)
+                    best[name] = min(best.get(name, 1e9), ms)
+                    out[name] = round(best[name], 4)
+                    out.setdefault("graphs_per_step", {})[name] = [len(v[0]) + (v[1] is not None) for v in mod._graphs.values()]
+                except Exception as e:  # noqa: BLE001 - a capture that RCCL refuses must not take the other forms down
+                    out[name] = "failed"
+                    out[name + "_error"] = f"{type(e).__name__}: {str(e)[:300]}"
+                    torch.cuda.synchronize()
+        os.environ["TACORL_FORCE_COLLECTIVES"], os.environ["TACORL_GRAPH_COLLECTIVES"] = "0", "0"
+        mod._graphs = {}
+        return out
+
+    res = {"rccl_libraries_mapped": rccl, "backend": dist.get_backend(), "world_size": 1}
+    mod = build_module(dev, dtype, 16, 1)
+    mod.enable_graph()
+    mod.log_every_n_steps = 50
+    res["c2_b256"] = forms(mod, synth_batch(256, 16, 84, 84, dev, DATA_SEED), 300)
+    mod._graphs = {}
+    del mod
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    mod = build_module(dev, dtype, 16, 1, finetune=True)
+    mod.enable_graph()
+    mod.log_every_n_steps = 50
+    res["c3_b32"] = forms(mod, synth_batch(32, 16, 84, 84, dev, DATA_SEED), 300)
+    print("PROBE " + json.dumps(res), flush=True)
+    dist.destroy_process_group()
+
+
+def run_segment_probe(dtype, timeout=420):
+    """The probe runs in a child process: it initialises RCCL, which the headline measurement never does on one GPU, and
+    a hang or crash in there must not cost the JSON line."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--probe", "segments", "--dtype", dtype]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timeout after {timeout}s"}
+    for ln in out.stdout.splitlines():
+        if ln.startswith("PROBE "):
+            return json.loads(ln[6:])
+    return {"error": f"rc {out.returncode}: {out.stderr[-400:]}"}
 
 
 def launch_ranks(n, argv):
@@ -441,8 +548,11 @@ def main():
     ap.add_argument("--frames", default="f32", choices=["f32", "u8"],
                     help="f32: the reference's batch schema (transformed fp32 CHW frames; the contract of `value`); "
                          "u8: the dataset's uint8 HWC frames, normalised on the GPU (SURVEY 8f N2; reported in DESIGN.md)")
+    ap.add_argument("--probe", default=None, choices=["segments"], help="internal: run one of the child-process probes")
     a = ap.parse_args()
 
+    if a.probe == "segments":
+        return segment_probe(a.dtype)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))  # no GPU call has happened in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -556,6 +666,16 @@ def main():
             configs.update(time_other_configs(dev, a.dtype))
         except Exception as e:  # the headline line must survive a failure here
             configs["error"] = f"{type(e).__name__}: {e}"
+        torch.cuda.synchronize()
+        # the per-GPU step shape of an N-GPU run with RCCL executing (1-rank communicator), in a child process
+        pr = run_segment_probe(a.dtype)
+        c2, c3 = pr.get("c2_b256", {}), pr.get("c3_b32", {})
+        configs["c2_three_segment"] = dict(c2, rccl=pr.get("rccl_libraries_mapped"), error=pr.get("error"),
+                                           note="ms/step at B=256: the collective-free single graph (= the headline form), the "
+                                                "N-GPU default (3 graph segments, 2 eager RCCL all-reduces between them) and the "
+                                                "one-graph form with the all-reduces as graph nodes; world_size 1, same process")
+        configs["c3_strong_share_b32"] = dict(c3, note="C3 (decoder fine-tuning) at B=32 = its per-GPU share of a global batch of "
+                                                       "256 on 8 GPUs, same three forms")
         for _ in range(3):
             mod.training_step(batch)
 

@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void ad_input_proj_kernel(const float* __restr
 extern "C" int tacorl_ad_input_proj(const float* plan, const float* emb, int ld_emb, const float* w_ih, const float* b_ih,
                                     float* out, int B, int T, int Tm, int P, int E, int H, tacorl_stream_t stream) {
   // (K % 8 == 0 and 16-byte aligned W rows: the fragment loads are 16-byte vectors; columns 32.. need whole 8-groups)
-  if (P + E > 64 || (P + E) % 8 || H % 16 || H < 16 || B < 1 || Tm < 1) return TACORL_EINVAL;
+  // (P + E >= 32: the first k-step reads W columns 0..31 of every row unmasked)
+  if (P + E < 32 || P + E > 64 || (P + E) % 8 || H % 16 || H < 16 || B < 1 || Tm < 1) return TACORL_EINVAL;
   if (((uintptr_t)out | (uintptr_t)b_ih | (uintptr_t)w_ih) & 15) return TACORL_EINVAL;
   const int R = B * Tm;
   hipLaunchKernelGGL(ad_input_proj_kernel, dim3((R + 63) / 64, (H + 511) / 512), dim3(256), 0, (hipStream_t)stream, plan, emb,

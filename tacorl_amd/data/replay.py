@@ -129,10 +129,17 @@ class _PinnedRing:
       stream waits for the slot's `ready` event (`wait_ready`).
     Each slot is reused only after the copies issued from it have completed (the same event, on the host)."""
 
-    def __init__(self, device, slots=6):
+    def __init__(self, device, slots=6, slot_bytes=1 << 20):
         self.dev, self.slots, self.k = device, [dict() for _ in range(slots)], 0
         self.events = [None] * slots
         self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        # every slot's pinned + device staging buffer exists before the first batch (1 MiB holds the tables of ~4 000
+        # windows of 16 frames): a feeder thread that calls hipHostMalloc / hipMalloc while the trainer thread is inside a
+        # hipGraph capture can invalidate that capture (they grow - under ops.capture_lock - only for larger batches)
+        if self.stream is not None:
+            for sl in self.slots:
+                sl["_packed"] = (torch.empty(slot_bytes, dtype=torch.uint8).pin_memory(),
+                                 torch.empty(slot_bytes, dtype=torch.uint8, device=self.dev))
         # the stream whose steps read the slots' device buffers: the one current where the ring is BUILT (the trainer's
         # thread) - `begin` may run on a feeder thread, whose own current stream is the default one
         self.consumer = torch.cuda.current_stream(device) if self.stream is not None else None
@@ -251,26 +258,47 @@ def prefetching(make_batch, n, depth=2):
     import queue
     import threading
 
+    from .. import ops
+
     q = queue.Queue(maxsize=depth)
     dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    stop = threading.Event()
+
+    def put(x):
+        while not stop.is_set():
+            try:
+                q.put(x, timeout=0.05)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def produce():
         try:
             if dev is not None:
                 torch.cuda.set_device(dev)
             for _ in range(n):
-                q.put(make_batch())
+                # the batch's device work (staging-slot copies, events, stream waits) never runs beside a hipGraph capture
+                # on the trainer's thread: captures hold the same lock (modules/common.py _run_segments)
+                with ops.capture_lock:
+                    b = make_batch()
+                if not put(b):
+                    return
         except BaseException as e:  # surface the failure in the consumer
-            q.put(e)
+            put(e)
 
     th = threading.Thread(target=produce, daemon=True)
     th.start()
-    for _ in range(n):
-        b = q.get()
-        if isinstance(b, BaseException):
-            raise b
-        yield b
-    th.join()
+    try:
+        for _ in range(n):
+            b = q.get()
+            if isinstance(b, BaseException):
+                raise b
+            yield b
+    finally:
+        # the consumer is done (or raised, or dropped the generator early): release a producer blocked on a full queue
+        stop.set()
+        th.join(timeout=10.0)
 
 
 class PinnedReplay:

@@ -3,6 +3,8 @@ blocks.  Every loss on the hot path is a mean over per-sample terms (the CQL log
 reference cql_offline_lightning.py:374-387), so with equal shards the average of per-rank gradients
 equals the full-batch gradient; kernels pre-scale by 1/world and the collective is a plain sum
 (RCCL over xGMI on the GPUs, gloo in the CPU tests)."""
+import os
+
 import torch
 
 
@@ -36,11 +38,54 @@ def shard_noise(noise, rank, world, n_samples):
     return out
 
 
-def allreduce_sum_(tensors):
+def group_ready():
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized()
+
+
+def collectives_on(world):
+    """Does a step with this world size issue its collectives?  With several ranks: always.  With one rank only when
+    TACORL_FORCE_COLLECTIVES=1 and a process group exists: the 1-GPU boxes of the test pool then run the very RCCL calls
+    (communicator init, stream ordering between hipGraph segments, capture inside a graph) an N-GPU step makes -
+    an all-reduce over one rank is the identity, so results must equal the collective-free step bit for bit."""
+    if world > 1:
+        return True
+    return os.environ.get("TACORL_FORCE_COLLECTIVES", "0") == "1" and group_ready()
+
+
+def graph_collectives():
+    """TACORL_GRAPH_COLLECTIVES=1: the step stays ONE captured hipGraph on N GPUs and the all-reduces are nodes of it
+    (RCCL kernels captured on the step's stream) instead of eager calls between three graph segments."""
+    return os.environ.get("TACORL_GRAPH_COLLECTIVES", "0") == "1"
+
+
+def all_reduce_sum_(t):
+    """In-place sum over ranks on the current stream (backend nccl = RCCL over xGMI; gloo in the CPU / 1-GPU tests)."""
+    import torch.distributed as dist
+
+    dist.all_reduce(t)
+
+
+def allreduce_sum_(tensors, world=None):
     """In-place sum over ranks of a list of flat blocks (no-op without a process group)."""
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not group_ready() or not collectives_on(dist.get_world_size() if world is None else world):
         return
     for t in tensors:
         dist.all_reduce(t)
+
+
+def reduce_logs_(logs, world):
+    """The step's logged scalars are per-rank batch means (or rank-independent values): their mean over ranks is the
+    full-batch value the reference publishes with sync_dist=True (modules/tacorl/tacorl.py:196-202,
+    play_lmp_for_rl.py:162,183,292-339).  One small collective, issued only on steps whose metrics are read back.
+    Returns (summed copy, divisor to apply on the host)."""
+    if not collectives_on(world) or not group_ready():
+        return logs, 1.0
+    import torch.distributed as dist
+
+    out = logs.clone()  # (a slot that a later step does not rewrite must not be summed twice)
+    dist.all_reduce(out)
+    return out, float(dist.get_world_size())

@@ -18,6 +18,7 @@ import os
 import torch
 
 from . import blocks, ops
+from . import dist as D
 from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, BF16, F32, LOG_SLOTS, call, ptr
 
 
@@ -505,7 +506,7 @@ class ACEngine:
              at(self.acts_main, B * A), n * B, A, int(self.dg), ops.stream())
         # alpha: loss, gradient, Adam step (alpha is read post-step below; SURVEY 8a note 2)
         # (one GPU and an optimising step: loss + gradient + Adam in one launch; otherwise the step follows collective #1)
-        self._alpha_stepped = bool(optimize and self.world == 1 and not getattr(self, "split_alpha_step", False))
+        self._alpha_stepped = bool(optimize and not D.collectives_on(self.world) and not getattr(self, "split_alpha_step", False))
         if self._alpha_stepped:
             la = self.log_alpha
             call("tacorl_alpha_loss_step", ptr(self.logp_pi), B, ptr(la.param), float(hp["target_entropy"]), ptr(la.grad),
@@ -737,12 +738,14 @@ class ACEngine:
         ops.mark("c:adam")
 
     def _allreduce(self, tensors):
-        if self.world > 1:
-            import torch.distributed as dist
-
+        if D.collectives_on(self.world):
             for t in tensors:
-                dist.all_reduce(t)
+                D.all_reduce_sum_(t)
 
     def metrics(self):
-        v = self.logs.cpu().tolist()
-        return dict(zip(LOG_SLOTS, v))
+        """The logged scalars, read back (one D2H sync).  With several ranks they are first averaged over the ranks (one
+        small collective on the steps that log): every slot is a per-rank batch mean or rank-independent, so the result is
+        the full-batch value - what the reference's sync_dist=True logs give."""
+        logs, div = D.reduce_logs_(self.logs, self.world)
+        v = logs.cpu().tolist()
+        return dict(zip(LOG_SLOTS, [x / div for x in v]))

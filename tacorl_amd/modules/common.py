@@ -117,7 +117,9 @@ def broadcast_blocks(blocks, src=0):
     process group."""
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    from .. import dist as D
+
+    if not D.group_ready() or not D.collectives_on(dist.get_world_size()):
         return
     for blk in blocks:
         for name in ("param", "m", "v", "step"):
@@ -229,6 +231,21 @@ class GraphMixin:
 
     _use_graph = False
 
+    def _collectives_in_graph(self):
+        from .. import dist as D
+
+        return D.graph_collectives() and D.collectives_on(getattr(self, "world_size", 1))
+
+    def _segmented(self):
+        """Is the device side of a step run as collective-free segments with eager all-reduces between them?  Yes with
+        several ranks (or TACORL_FORCE_COLLECTIVES=1 on one) unless the collectives are captured into the step's graph;
+        `_force_graph_split` is the test switch that splits without any collective."""
+        from .. import dist as D
+
+        if getattr(self, "_force_graph_split", False):
+            return True
+        return D.collectives_on(getattr(self, "world_size", 1)) and not D.graph_collectives()
+
     def enable_graph(self, on=True):
         """Replay the device side of the step from a captured hipGraph (one graph on a single GPU; with
         several ranks one graph per collective-free segment, the RCCL all-reduces stay eager between them)."""
@@ -275,38 +292,8 @@ class GraphMixin:
             self._graphs = {}
             gs = None
         if gs is None:
-            eager()  # warm-up: sizes every workspace, so the capture allocates nothing
-            torch.cuda.synchronize()
-            split = getattr(self, "world_size", 1) > 1 or getattr(self, "_force_graph_split", False)
-            if split:
-                parts = [[f] for f in segs]
-            else:
-                parts = [list(segs)]
-                if side is not None:
-                    parts[0].insert(side[0] + 1, side[1])
-            gs = []
-            for part in parts:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    for f in part:
-                        f()
-                gs.append(g)
-            g_side = None
-            if split and side is not None:
-                g_side = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_side):
-                    side[1]()
-                if getattr(self, "_side_replay_stream", None) is None:
-                    self._side_replay_stream = torch.cuda.Stream(device=self.device)
-            self._graphs[key] = (gs, g_side, ops.alloc_epoch())
-            # A long job alternates keys (train / validation, the epoch's last partial batch, the BC -> Q phase switch):
-            # keep the most recently used few and release the rest - dozens of live instantiated graphs in one process
-            # end in a hipGraphLaunch crash on ROCm 7.2, and each one pins its workspaces' addresses.
-            cap = max(1, int(os.environ.get("TACORL_MAX_GRAPHS", "6")))
-            if len(self._graphs) > cap:
-                torch.cuda.synchronize()  # nothing may still be replaying a graph that is about to be destroyed
-                while len(self._graphs) > cap:
-                    del self._graphs[next(iter(self._graphs))]
+            with ops.capture_lock:  # no feeder thread prepares a batch (allocations, event waits) beside the capture
+                self._capture(key, segs, collectives, side, eager)
             return
         gs, g_side, _ = gs
         stepped = getattr(self, "_stepped_blocks", None)
@@ -323,3 +310,47 @@ class GraphMixin:
                 collectives[i]()
         if g_side is not None:
             cur.wait_stream(self._side_replay_stream)
+
+    def _capture(self, key, segs, collectives, side, eager):
+        """One eager pass (sizes every workspace, so the capture allocates nothing; it IS this call's step), then the
+        capture(s) of the step for later calls."""
+        from .. import ops
+
+        eager()  # warm-up: sizes every workspace, so the capture allocates nothing
+        torch.cuda.synchronize()
+        split = self._segmented()
+        if split:
+            parts = [[f] for f in segs]
+        else:
+            # one graph for the whole step; with TACORL_GRAPH_COLLECTIVES=1 on several ranks the all-reduces are
+            # captured between the segments as nodes of that graph (RCCL kernels on the capturing stream)
+            parts = [[]]
+            for i, f in enumerate(segs):
+                parts[0].append(f)
+                if side is not None and side[0] == i:
+                    parts[0].append(side[1])
+                if i < len(collectives) and self._collectives_in_graph():
+                    parts[0].append(collectives[i])
+        gs = []
+        for part in parts:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for f in part:
+                    f()
+            gs.append(g)
+        g_side = None
+        if split and side is not None:
+            g_side = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_side, capture_error_mode="thread_local"):
+                side[1]()
+            if getattr(self, "_side_replay_stream", None) is None:
+                self._side_replay_stream = torch.cuda.Stream(device=self.device)
+        self._graphs[key] = (gs, g_side, ops.alloc_epoch())
+        # A long job alternates keys (train / validation, the epoch's last partial batch, the BC -> Q phase switch):
+        # keep the most recently used few and release the rest - dozens of live instantiated graphs in one process
+        # end in a hipGraphLaunch crash on ROCm 7.2 (DESIGN.md), and each one pins its workspaces' addresses.
+        cap = max(1, int(os.environ.get("TACORL_MAX_GRAPHS", "6")))
+        if len(self._graphs) > cap:
+            torch.cuda.synchronize()  # nothing may still be replaying a graph that is about to be destroyed
+            while len(self._graphs) > cap:
+                del self._graphs[next(iter(self._graphs))]

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib
+from ... import dist as _D
 from ...engine import ACEngine
 from ...lightning import LightningModuleBase
 from ..common import GraphMixin, ModuleMixin, broadcast_blocks, register_views, to_plain
@@ -60,7 +61,7 @@ class CQL_Offline(GraphMixin, ModuleMixin, LightningModuleBase):
         # target entropy: -action_dim (real world, :93-94) or -prod(env.action_space.shape) = -7 (:96-98)
         self.target_entropy = -float(action_dim) if real_world else -7.0
         self.build_networks()
-        if world_size > 1:
+        if _D.collectives_on(world_size):
             self.sync_from_rank0()
 
     # ------------------------------------------------------------------ construction

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib
+from ... import dist as _D
 from ..._lib import ACT_NONE, ACT_SILU
 from ...engine import NetBlock
 from ...init import init_views_
@@ -49,7 +50,7 @@ class PlayLMP(GraphMixin, ModuleMixin, LightningModuleBase):
         self.pp_cfg, self.pr_cfg, self.ad_cfg = to_plain(plan_proposal), to_plain(plan_recognition), to_plain(action_decoder)
         self.pe_cfg, self.ge_cfg = to_plain(perceptual_encoder), to_plain(goal_encoder)
         self.build_networks()
-        if self.world_size > 1:
+        if _D.collectives_on(self.world_size):
             self.sync_from_rank0()
 
     def build_networks(self):
@@ -279,7 +280,10 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
     self._acts.copy_(batch["actions"])
     acts = self._acts
 
-    if optimize and getattr(self, "world_size", 1) > 1:
+    from ... import dist as D
+
+    reduce_on = optimize and D.collectives_on(getattr(self, "world_size", 1))
+    if reduce_on:
         _grad_arena(self)  # (before anything is captured: the backward kernels write into the arena's slices)
 
     def fwd_bwd():
@@ -291,10 +295,8 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
                                  for blk in (net, pr.blk, ad.blk)])
 
     def reduce_grads():
-        if optimize and getattr(self, "world_size", 1) > 1:
-            import torch.distributed as dist
-
-            dist.all_reduce(_grad_arena(self))  # ONE collective: [encoders + proposal | plan recognition | action decoder]
+        if reduce_on:
+            D.all_reduce_sum_(_grad_arena(self))  # ONE collective: [encoders + proposal | plan recognition | action decoder]
 
     # (a graph replay runs no python: announce the optimiser's writes to torch's version counters - ops.touched)
     self._stepped_blocks = (lambda: [net.param, pr.blk.param, ad.blk.param]) if optimize else None
@@ -302,9 +304,15 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
     # metrics cross to the host (a device synchronisation) only on logging steps - Trainer(log_every_n_steps), as the
     # other two modules do; in between the step returns the last total it read
     self._step_count += 1
-    if optimize and self.log_every_n_steps > 1 and self._step_count % self.log_every_n_steps:
-        return self.__dict__.get("_last_total")
-    lg = self.logs.cpu().tolist()
+    # Deviation from the reference (which logs and returns the total on every step, :307-317): with log_every_n_steps = k > 1
+    # the train/* values - and their on_epoch means - come from every k-th step, and the steps in between return the last
+    # total that was read (never None: the first step always reads).
+    if (optimize and self.log_every_n_steps > 1 and self._step_count % self.log_every_n_steps
+            and self.__dict__.get("_last_total") is not None):
+        return self.__dict__["_last_total"]
+    # (sync_dist=True in the reference, :162,183,292-339: the per-rank batch means are averaged over the ranks first)
+    logs, div = D.reduce_logs_(self.logs, getattr(self, "world_size", 1))
+    lg = [x / div for x in logs.cpu().tolist()]
     names = ["kl_loss", "kl_loss_scaled", "action_loss", "gripper_accuracy", "random_plan_action_loss",
              "random_plan_gripper_accuracy"]
     for k, v in zip(names, lg):

@@ -10,6 +10,7 @@ from pathlib import Path
 import torch
 import torch.nn as nn
 
+from ... import dist as D
 from ... import ops
 from ..._lib import BF16, F32, call, ptr
 from ..common import register_views
@@ -304,9 +305,11 @@ class TACORL(CQL_Offline):
             self._ad_join = self._side_stream
         e.action_ready = ready
         e.phase_a(encoded=True, optimize=optimize)
-        segmented = self.world_size > 1 or getattr(self, "_force_graph_split", False) or not self._use_graph
+        segmented = self._segmented() or not self._use_graph
         if with_ad and not ad_on_side:
-            if segmented:
+            if segmented or D.collectives_on(self.world_size):
+                # (collectives captured inside the one graph: the decoder's gradients are part of the arena the second
+                # all-reduce sums, so its branch joins here as well)
                 main.wait_stream(self._pr_stream)
             else:
                 # one graph for the whole step: the fine-tuning chain (loss, BPTT, weight gradients, Adam - 1.4 ms, touching
@@ -321,7 +324,7 @@ class TACORL(CQL_Offline):
     def _defer_ad_update(self):
         """More than one rank (or the split-graph test mode): the fine-tuned decoder's Adam step waits for the arena's
         all-reduce.  On one GPU it stays on the decoder's own branch of the step's graph."""
-        return self.world_size > 1 or getattr(self, "_force_graph_split", False)
+        return D.collectives_on(self.world_size) or getattr(self, "_force_graph_split", False)
 
     def _join_ad(self):
         if getattr(self, "_ad_join", None) is not None:
@@ -367,7 +370,7 @@ class TACORL(CQL_Offline):
 
         # split (multi-GPU) graphs: the frozen, logging-only action-decoder pass leaves the first segment
         # and runs as a side graph beside the all-reduces and the other segments
-        segmented = self.world_size > 1 or getattr(self, "_force_graph_split", False)
+        segmented = self._segmented()
         ad_side = with_ad and segmented and self._use_graph and not (optimize and self.finetune_action_decoder)
         side = (0, lambda: self.ad.loss_step(self, self.acts, self.plan, B, T, False, frozen=not self.finetune_action_decoder)) if ad_side else None
         self._run_segments(key, [lambda: self._device_front(B, T, hw, optimize, with_ad and not ad_side),

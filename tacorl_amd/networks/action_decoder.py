@@ -149,13 +149,15 @@ class ActionDecoderLogistic:
         x, K = self.x_seq, self.P + self.E
         # bf16 mode: the layer-0 projection reads (plan, embeddings) itself (tacorl_ad_input_proj); x_seq is then only the
         # weight-gradient operand of a backward that follows (not built for the frozen, logging-only pass)
-        proj_fused = compute == ops.BF16 and K <= 64 and K % 8 == 0 and H % 16 == 0 and getattr(self, "fused_input_proj", True)
-        if not (proj_fused and frozen):
-            call("tacorl_build_ad_input", ptr(plan), ptr(emb), ld_emb, ptr(self.x_seq), B, T, Tm, self.P, self.E,
-                 ops.stream())
         # bf16 mode: the recurrent step runs as ONE launch (LDS-DMA ring GEMM, rnn_ops.hip) on bf16 copies of
         # W_hh (refreshed here: the weights may have been stepped) and of the previous hidden state
         fast = compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H))
+        # (the fused projection exists only on the ring-GEMM path: with a hidden size that path does not take - H % 128 != 0 -
+        # the generic per-step path below reads x_seq, so it must be built; 32 <= K: the kernel's first k-step is unmasked)
+        proj_fused = (fast and 32 <= K <= 64 and K % 8 == 0 and H % 16 == 0 and getattr(self, "fused_input_proj", True))
+        if not (proj_fused and frozen):
+            call("tacorl_build_ad_input", ptr(plan), ptr(emb), ld_emb, ptr(self.x_seq), B, T, Tm, self.P, self.E,
+                 ops.stream())
         ver = blk.param._version
         fresh = frozen and getattr(self, "_bf16_version", None) == ver  # bf16 weight copies still valid
         if fast:

@@ -7,8 +7,15 @@ import torch
 from . import _lib as L
 from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, BF16, F32, call, int_array, ptr, ptr_array, stream  # noqa: F401
 
+import threading
+
 _ws_cache = {}
 _alloc_epoch = 0
+# Held by a hipGraph capture (modules/common.py GraphMixin._run_segments: warm-up + capture) and by a feeder thread while it
+# prepares a batch's device-side tables (data/replay.py prefetching): pinned / device allocations, event synchronisation or
+# stream waits issued from another thread during a capture can fail it (hipErrorStreamCaptureUnsupported).  Re-entrant:
+# a capture may nest helpers that take it again.
+capture_lock = threading.RLock()
 
 
 def note_alloc():

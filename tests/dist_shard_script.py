@@ -76,7 +76,7 @@ def one_step(kind, mod, g, batch, noise):
     torch.cuda.synchronize()
     grads = {k: v.detach().clone() for k, v in mod.named_gradients().items()}
     params = {k: v.detach().clone() for k, v in mod.state_dict().items() if v.dtype.is_floating_point}
-    return grads, params
+    return grads, params, dict(mod.logged)
 
 
 def rel(a, b):
@@ -98,13 +98,13 @@ def main():
         # the single-rank step on the full batch (world_size 1: no collectives)
         full = build(kind, g, 1)
         full.load_state_dict(params0, strict=False)
-        g_full, p_full = one_step(kind, full, g, batch, noise)
+        g_full, p_full, l_full = one_step(kind, full, g, batch, noise)
         del full
         # the same step on this rank's shard; gradients meet in the module's collectives
         mod = build(kind, g, 2)
         mod.load_state_dict(params0, strict=False)
         sb, sn = D.shard_batch(batch, rank, world), D.shard_noise(noise, rank, world, n_s)
-        g_sh, p_sh = one_step(kind, mod, g, sb, sn)
+        g_sh, p_sh, l_sh = one_step(kind, mod, g, sb, sn)
         bad = []
         for k, v in g_full.items():
             if v.norm() > 0 and rel(g_sh[k], v) > 1e-5:
@@ -117,6 +117,15 @@ def main():
                 bad.append(f"param {k}: rel {rel(p_sh[k], v):.3g} max|d| {float(d.max()):.3g}")
             elif rel(p_sh[k], v) > 1e-3:
                 bad.append(f"param {k}: rel {rel(p_sh[k], v):.3g}")
+        # logged scalars: every rank publishes the mean over ranks of the per-shard batch means = the full-batch value
+        # (the reference's sync_dist=True logs, modules/tacorl/tacorl.py:196-202, play_lmp_for_rl.py:162,183,292-339)
+        assert l_full and set(l_full) <= set(l_sh), f"{name}: logged keys differ: {sorted(set(l_full) - set(l_sh))}"
+        for k, v in l_full.items():
+            tol = 2e-5 * max(abs(v), 1e-2)
+            if "accuracy" in k:
+                tol = 1e-6
+            if abs(l_sh[k] - v) > tol:
+                bad.append(f"log {k}: shards {l_sh[k]!r} full {v!r}")
         moved = sum(float((p_full[k] - params0[k].to(p_full[k].device)).abs().max()) > 0 for k in p_full if k in params0)
         assert moved > 0, f"{name}: the step did not move any parameter"
         assert not bad, f"{name} rank {rank}: shard != full\n" + "\n".join(bad[:20])

@@ -52,3 +52,24 @@ def test_two_rank_shards_equal_the_full_batch_step():
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_shard_script.py")]
     out = run_group(cmd, env, ROOT, timeout=600)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def _one_rank(args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    return run_group([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank_script.py"), *args], env, ROOT, timeout=timeout)
+
+
+def test_rccl_one_rank_collectives_between_graph_segments():
+    """backend nccl (RCCL), world_size 1, TACORL_FORCE_COLLECTIVES=1: the broadcast, both all-reduces of a step between its
+    three hipGraph segments, PlayLMP's arena all-reduce and the log reduction really execute in librccl; TACORL (frozen and
+    fine-tuned decoder), CQL_Offline and PlayLMP end three graph-mode steps where the collective-free single graph ends."""
+    out = _one_rank([])
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "librccl" in out.stdout
+
+
+def test_rccl_one_rank_collectives_inside_the_graph():
+    """TACORL_GRAPH_COLLECTIVES=1: the all-reduces captured as nodes of the step's ONE graph."""
+    out = _one_rank(["--in-graph"])
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
