@@ -611,8 +611,28 @@ def main():
             return t.item()
         return x
 
-    for _ in range(a.warmup):
-        mod.training_step(batch)
+    from tacorl_amd import dist as D
+
+    coll_form = None
+    if world > 1:
+        coll_form = "rccl nodes inside the step's one hipGraph" if (use_graph and D.graph_collectives()) else \
+            "eager all-reduces between three hipGraph segments"
+    try:
+        for _ in range(max(a.warmup, 2)):
+            mod.training_step(batch)
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        if not (world > 1 and use_graph and D.graph_collectives()):
+            raise
+        # the capture of a collective was refused (every rank runs the same code, so every rank lands here): fall back to the
+        # segmented form - collective-free graphs with the all-reduces issued eagerly between them
+        print(f"[rank {rank}] in-graph collectives failed ({type(e).__name__}: {str(e)[:200]}); using graph segments", file=sys.stderr, flush=True)
+        os.environ["TACORL_GRAPH_COLLECTIVES"] = "0"
+        coll_form = "eager all-reduces between three hipGraph segments (in-graph capture failed)"
+        mod._graphs = {}
+        torch.cuda.synchronize()
+        for _ in range(max(a.warmup, 2)):
+            mod.training_step(batch)
     dt = max_over_ranks(timed_steps(mod, batch, a.steps, barrier))
     ms_step = dt / a.steps * 1e3
     logs = mod.engine.metrics()
@@ -699,6 +719,7 @@ def main():
                        "action_decoder_loss": ("every step (reference behaviour)" if a.ad_every <= 1 else
                                                f"every {a.ad_every} steps (logging cadence)"), "parallelism": f"dp{world}",
                        "collective_backend": None if world == 1 else ("rccl" if backend == "nccl" else backend),
+                       "collectives": coll_form,
                        "hip_graph": bool(use_graph),
                        "samples_per_s": round(world * B / (ms_step * 1e-3), 1), "losses_finite": finite,
                        "replicas_in_sync": in_sync},

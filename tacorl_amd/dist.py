@@ -55,9 +55,19 @@ def collectives_on(world):
 
 
 def graph_collectives():
-    """TACORL_GRAPH_COLLECTIVES=1: the step stays ONE captured hipGraph on N GPUs and the all-reduces are nodes of it
-    (RCCL kernels captured on the step's stream) instead of eager calls between three graph segments."""
-    return os.environ.get("TACORL_GRAPH_COLLECTIVES", "0") == "1"
+    """Are the step's all-reduces nodes of its ONE captured hipGraph (RCCL kernels captured on the step's stream) instead of
+    eager calls between three graph segments?  Default: yes when the process group's backend is nccl (= RCCL) - measured
+    on one MI355X with a 1-rank communicator (bench.py --probe segments, profiles/r04_segment_probe.json): 0.883 ms/step
+    against 0.963 for the three-segment form and 0.874 for the collective-free graph.  gloo cannot be captured: the
+    CPU-backend tests always run segments.  TACORL_GRAPH_COLLECTIVES=0 / 1 overrides."""
+    env = os.environ.get("TACORL_GRAPH_COLLECTIVES")
+    if env is not None:
+        return env == "1"
+    if not group_ready():
+        return False
+    import torch.distributed as dist
+
+    return dist.get_backend() == "nccl"
 
 
 def all_reduce_sum_(t):

@@ -473,6 +473,7 @@ def _compare(got, ologs, rtol, grads=None, ograds=None, grad_rtol=None, plan=Non
 
 FULL_TACORL = {
     # name: (B, T, cameras, latent, fine-tune the action decoder)
+    "c2": (256, 16, {"rgb_static": (84, 84)}, 16, False),  # the headline configuration (BASELINE configs[1])
     "c3": (256, 16, {"rgb_static": (84, 84)}, 16, True),
     "c4_share": (64, 32, {"rgb_static": (128, 128), "rgb_gripper": (128, 128)}, 32, False),
 }
@@ -497,11 +498,31 @@ def test_fullsize_tacorl_configs_f32_match_oracle(name):
     assert not bad, "\n".join(bad[:30])
 
 
+def _bf16_grad_check(mod, eval_rounded, eval_f32, P_before, ograds):
+    """Full-size bf16 gradients against the rounded oracle, norm-wise per tensor: tolerance max(1e-2, 3 x the tensor's
+    reproducibility floor) - the floor is how far the rounded oracle's own gradient moves under a 1-ulp perturbation of
+    the parameters (golden_util.gradient_floor, 2 runs) or a sixth of what bf16 rounding changes at all
+    (test_step_gpu._with_bf16_sensitivity) - every comparison recorded through record_margin.
+    eval_*(P) -> {name: gradient} must not modify P's originals."""
+    from oracle import tacorl_oracle as O
+    from tests.golden_util import gradient_floor
+    from tests.test_step_gpu import _snap, _with_bf16_sensitivity, compare_with_oracle_grads
+
+    with O.operand_rounding(torch.bfloat16):
+        floor = gradient_floor(eval_rounded, P_before, ograds, runs=2)
+    floor = _with_bf16_sensitivity(floor, ograds, eval_f32(_snap(P_before)))
+    return compare_with_oracle_grads(mod, ograds, 1e-2, floor)
+
+
 @pytest.mark.parametrize("name", sorted(FULL_TACORL))
 def test_fullsize_tacorl_configs_bf16_vs_rounded_oracle(name):
-    """The benchmarked mode at full size: losses and plans against the oracle evaluated with bf16 operand rounding in
-    every contraction (2e-3 relative: what is left is accumulation order)."""
+    """The benchmarked mode at full size (C2 = the headline step, C3, C4's share): losses and plans against the oracle
+    evaluated with bf16 operand rounding in every contraction (2e-3 relative: what is left is accumulation order), and
+    every gradient norm-wise against the same oracle (1e-2 or 3 x its reproducibility floor)."""
+    import copy
+
     from tacorl_amd import synth
+    from tests.test_step_gpu import _snap
 
     Bn, Tn, cams, latent, finetune = FULL_TACORL[name]
     mod = _build_tacorl("bf16", cams, Tn, latent, finetune)
@@ -511,9 +532,63 @@ def test_fullsize_tacorl_configs_bf16_vs_rounded_oracle(name):
     mod.logged = {}
     mod.training_step(_to_dev(batch, mod.device))
     got, nz = _logs(mod), _cpu(_noise(mod))
+    before, opts0 = _snap(P), copy.deepcopy(opts)
     with O.operand_rounding(torch.bfloat16):
-        ologs, oplan, _ = O.tacorl_step(P, opts, spec, batch, nz, 5)
+        ologs, oplan, ograds = O.tacorl_step(P, opts, spec, batch, nz, 5)
     bad = _compare(got, ologs, 2e-3, plan=mod.plan, oplan=oplan)
+    ev = lambda Pp: O.tacorl_step(Pp, copy.deepcopy(opts0), spec, batch, nz, 5)[2]  # noqa: E731
+    bad += _bf16_grad_check(mod, ev, ev, before, ograds)
+    assert not bad, "\n".join(bad[:30])
+
+
+def test_fullsize_cql_baseline_c5_bf16_vs_rounded_oracle():
+    """BASELINE configs C5 at its stated size (B=1024, n=32: the Q networks run over 99 328 rows - the many-row MLP
+    kernels) in the benchmarked bf16 mode against the oracle with bf16 operand rounding: every logged loss 2e-3, every
+    gradient norm-wise 1e-2 (or 3 x floor)."""
+    import copy
+
+    from oracle import tacorl_oracle as O
+    from tacorl_amd import synth
+    from tacorl_amd.init import init_views_
+    from tacorl_amd.modules.cql.cql_offline_lightning import CQL_Offline
+    from tests.test_step_gpu import _snap
+
+    dev = torch.device("cuda:0")
+    Bc, n = 1024, 32
+    torch.manual_seed(3)
+    mod = CQL_Offline(actor={"policy": {"num_layers": 3, "hidden_dim": 256}, "discrete_gripper": True},
+                      critic={"q_network": {"num_layers": 3, "hidden_dim": 256, "last_layer_activation": "Identity"}},
+                      real_world=True, obs_modalities=["rgb_static"], goal_modalities=["rgb_static"], action_dim=7, device="cuda:0",
+                      compute_dtype="bf16", image_dtype="bf16", discount=0.99, actor_lr=1e-4, critic_lr=3e-4,
+                      conservative_weight=1.0, n_action_samples=n, with_lagrange=True, reward_scale=10.0,
+                      deterministic_backup=False, bc_epochs=5)
+    mod.current_epoch = 5
+    for blk in (mod.engine.actor, mod.engine.q1, mod.engine.q2):
+        init_views_(blk.views)
+    mod.sync_targets()
+    cams = ["rgb_static"]
+    spec = O.ACSpec(cams=cams, goal_cams=cams, action_dim=7, n=n, discount=0.99, actor_lr=1e-4, critic_lr=3e-4,
+                    deterministic_backup=False, reward_scale=10.0, bc_epochs=5, with_lagrange=True,
+                    discrete_gripper=True, target_entropy=-7.0)
+    P = {k: v.detach().cpu().clone().contiguous() for k, v in mod.state_dict().items()}
+    O.require_grad_(P)
+    opts = O.make_opts(P, spec)
+    batch = synth.make_transition_batch(7, Bc, {"rgb_static": (84, 84)})
+    mod.logged = {}
+    mod.training_step(_to_dev(batch, dev), 0)
+    torch.cuda.synchronize()
+    got = {k.split("/", 1)[1]: float(v) for k, v in mod.logged.items()}
+    nz = {k: v.detach().cpu().clone() for k, v in mod.engine.noise.items()}
+    before, opts0 = _snap(P), copy.deepcopy(opts)
+    with O.operand_rounding(torch.bfloat16):
+        ologs, ograds = O.cql_step(P, opts, spec, batch, nz, 5)
+    # (Q heads start at +-1e-3: q*_data / random / policy are ~1e-2 sums, hence the 5e-2 floor of the relative scale -
+    # as in tests/test_step_gpu.py::_bf16_compare)
+    bad = [f"{k}: hip {got[k]:.8g} rounded oracle {float(v):.8g}" for k, v in ologs.items()
+           if k in got and abs(got[k] - float(v)) > 2e-3 * max(abs(float(v)), 5e-2)]
+    assert len(set(ologs) & set(got)) >= 8, (sorted(ologs), sorted(got))
+    ev = lambda Pp: O.cql_step(Pp, copy.deepcopy(opts0), spec, batch, nz, 5)[1]  # noqa: E731
+    bad += _bf16_grad_check(mod, ev, ev, before, ograds)
     assert not bad, "\n".join(bad[:30])
 
 
@@ -547,6 +622,8 @@ def test_fullsize_playlmp_c1_matches_oracle(compute, rtol):
         with O.operand_rounding(torch.bfloat16):
             ologs, ograds = O.playlmp_step(P, opt, batch, nz, ["rgb_static"], step=False)
         bad = _compare(got, ologs, rtol, min_common=5)
+        ev = lambda Pp: O.playlmp_step(Pp, opt, batch, nz, ["rgb_static"], step=False)[1]  # noqa: E731
+        bad += _bf16_grad_check(mod, ev, ev, P, ograds)
     else:
         ologs, ograds = O.playlmp_step(P, opt, batch, nz, ["rgb_static"], step=False)
         bad = _compare(got, ologs, rtol, mod.named_gradients(), ograds, 1e-3, min_common=5)

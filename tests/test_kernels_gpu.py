@@ -572,10 +572,37 @@ def test_mlp_fused_backward_many_rows():
     ops.mlp_bwd_fused_dgrad(flats, act_l, douts, dims[-1], dx_fus, ld, Ms, dims, acts, "t_mlp_big")
     ops.mlp_bwd_fused_wgrad(xs, ld, act_l, douts, dims[-1], g_fus, Ms, dims, acts, "t_mlp_big", lean=True)
     torch.cuda.synchronize()
+    from oracle import tacorl_oracle as O
+    from tests.golden_util import record_margin
+
     for i in range(len(Ms)):
         assert torch.isfinite(g_fus[i]).all() and torch.isfinite(dx_fus[i]).all()
         assert relerr(dx_fus[i], dx_ref[i]) < 4e-3, ("dx", i, relerr(dx_fus[i], dx_ref[i]))
         assert relerr(g_fus[i], g_ref[i]) < 4e-3, ("grads", i, relerr(g_fus[i], g_ref[i]))
+        # ... and against the CPU oracle's linear layers under the MFMA's operand rounding (torch autograd): forward output,
+        # input gradients and every weight / bias gradient of the many-row kernels (mlp_fused_{fwd,bwd}_big, mlp_wgrad_fused)
+        v = blocks.mlp_views(flats[i], 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+        Pw = {k: t.detach().cpu().clone().requires_grad_(True) for k, t in v.items()}
+        x0 = xs[i][:, :dims[0]].cpu().clone().requires_grad_(True)
+        h = x0
+        with O.operand_rounding(torch.bfloat16):
+            for l in range(L):
+                h = O._linear(h, Pw[f"l{l}.w"], Pw[f"l{l}.b"])
+                h = [h, F.relu(h), F.silu(h)][acts[l]]
+            (h * douts[i].cpu()).sum().backward()
+        yo = ops.mlp_act_layout(Ms[i], dims, acts)[1]
+        out = act_l[i][yo[L - 1]: yo[L - 1] + Ms[i] * dims[-1]].reshape(Ms[i], dims[-1])
+        e = relerr(out, h)
+        record_margin(f"mlp many rows M={Ms[i]}: forward output", e, FWD_BF16_ROUNDED, kind="kernel vs rounded oracle")
+        assert e < FWD_BF16_ROUNDED, ("forward vs rounded oracle", i, e)
+        e = relerr(dx_fus[i][:, :dims[0]], x0.grad)
+        record_margin(f"mlp many rows M={Ms[i]}: dx", e, GRAD_BF16_ROUNDED, kind="kernel vs rounded oracle")
+        assert e < GRAD_BF16_ROUNDED, ("dx vs rounded oracle", i, e)
+        gv = blocks.mlp_views(g_fus[i], 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+        for k, t in Pw.items():
+            e = relerr(gv[k], t.grad)
+            record_margin(f"mlp many rows M={Ms[i]}: d{k}", e, GRAD_BF16_ROUNDED, kind="kernel vs rounded oracle")
+            assert e < GRAD_BF16_ROUNDED, (k, i, e)
 
 
 @pytest.mark.parametrize("lean", [False, True])
@@ -1029,3 +1056,33 @@ def test_pack_images_u8(flag, dt):
     torch.cuda.synchronize()
     assert torch.equal(all_.cpu().view(n, T, H, W, 3), ref)
     assert torch.equal(first.cpu(), ref[:, 0])
+
+
+@pytest.mark.parametrize("H", [64, 192, 256])
+def test_action_decoder_frozen_bf16_hidden_sizes(H):
+    """bf16, frozen decoder (TACORL's logging-only pass, validation): hidden sizes the ring-GEMM path does not take (64,
+    192: H % 128 != 0) go through the generic per-step path, which reads x_seq - it must have been built for THIS batch
+    (round-3 advisor finding: it was skipped whenever the fused input projection's own gate held).  The heads of the
+    frozen pass must equal the non-frozen pass on the same inputs and sit at bf16 distance from the f32 path."""
+    from tacorl_amd import ops
+    from tacorl_amd.init import init_views_
+    from tacorl_amd.networks.action_decoder import ActionDecoderLogistic
+
+    dev = _dev()
+    B, T, P, E = 8, 6, 16, 32
+    torch.manual_seed(11)
+    ad = ActionDecoderLogistic(dev, state_dim=E, latent_plan_dim=P, hidden_size=H, out_features=7, num_layers=2)
+    init_views_(ad.blk.views, rnn_hidden=H)
+    plan = rnd(B, P, seed=1).to(dev)
+    emb = rnd(B * T, E, seed=2).to(dev)
+    res = {}
+    for tag, compute, frozen in (("f32", ops.F32, False), ("bf16", ops.BF16, False), ("bf16_frozen", ops.BF16, True)):
+        ad._ensure(B, T - 1)
+        ad.x_seq.fill_(float("nan"))  # a stale / unbuilt input must show
+        ad._bf16_version = None
+        ad.forward(plan, emb, E, B, T, T - 1, compute, frozen=frozen)
+        torch.cuda.synchronize()
+        res[tag] = ad.heads[:, :ad.NH].clone()
+        assert torch.isfinite(res[tag]).all(), tag
+    assert relerr(res["bf16_frozen"], res["bf16"]) < 1e-6
+    assert relerr(res["bf16"], res["f32"]) < TOL_BF16
