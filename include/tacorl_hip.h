@@ -221,6 +221,10 @@ int tacorl_mlp_bwd(int nprob, const float* const* x, int ldx, const float* const
  * networks/actor_critic/{actor,critic}.py and visual_encoders/goal_encoder.py). */
 int tacorl_mlp_bwd_fused_supported(int nprob, int n_layers, const int* dims, int ldo, int ldd);
 size_t tacorl_mlp_bwd_fused_ws_bytes(int nprob, const int* M, int n_layers, const int* dims);
+/* prepacked: bit 0 = weight transposes already in ws (tacorl_mlp_bwd_fused_pack); bit 1 = this MLP site runs lean
+ * (tacorl_mlp_fwd_fused and _wgrad with lean != 0): at >= 16 384 rows (C5's Q networks: 99 328) the forward then also
+ * leaves bf16 copies of the hidden outputs, _dgrad leaves its dZ_l as bf16, and _wgrad streams both by LDS-DMA
+ * (mlp_wgrad_big_kernel) - the three calls must agree on the flag. */
 int tacorl_mlp_bwd_fused_dgrad(int nprob, const float* const* params, const float* const* act,
                                const float* const* d_out, int ldo, float* const* d_x, int ldd,
                                const int* M, int n_layers, const int* dims, const int* acts,

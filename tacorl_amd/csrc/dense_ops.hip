@@ -1025,17 +1025,36 @@ extern "C" int tacorl_mlp_fwd_fused(int nprob, const float* const* x, int ldx, c
   if (!mlp_fused_fwd_ok(nprob, L, dims, ldx)) FAIL(TACORL_EINVAL, "mlp_fwd_fused: shapes not supported");
   long wo[MLP_MAXL], bo[MLP_MAXL];
   tacorl_mlp_param_layout(L, dims, wo, bo);
-  long zo[MF_MAXP * MF_MAXL], yo[MF_MAXP * MF_MAXL];
+  // Many-row problems of a lean site (>= 16 384 rows: C5's Q networks) take kernels of their own and save, per hidden
+  // layer, a bf16 copy of the output and an fp16 copy of act'(z) in the regions the fp32 z / y would occupy (mlp_fused.h);
+  // the site's _dgrad (prepacked bit 1) and _wgrad (lean) calls read exactly that.
+  const float *xs[2][MF_MAXP], *ps[2][MF_MAXP];
+  const void* pb[2][MF_MAXP];
+  float* as[2][MF_MAXP];
+  int Ms[2][MF_MAXP], n[2] = {0, 0};
+  long zo[MF_MAXP * MF_MAXL], yo[MF_MAXP * MF_MAXL], ybf[MF_MAXP * MF_MAXL], sbf[MF_MAXP * MF_MAXL], yout[MF_MAXP];
   for (int p = 0; p < nprob; p++) {
     long z1[MLP_MAXL], y1[MLP_MAXL];
     tacorl_mlp_act_layout(M[p], L, dims, acts, z1, y1);
+    const int b = (lean && mlp_big_prob_ok(M[p], L, dims, acts)) ? 1 : 0, q = n[b]++;
+    xs[b][q] = x[p]; ps[b][q] = params[p]; pb[b][q] = params_bf16[p]; as[b][q] = act[p]; Ms[b][q] = M[p];
     for (int l = 0; l < L; l++) {
-      zo[p * MF_MAXL + l] = z1[l];
-      yo[p * MF_MAXL + l] = (lean && l + 1 < L && z1[l] >= 0) ? -1 : y1[l];
+      if (b) { ybf[q * MF_MAXL + l] = y1[l]; sbf[q * MF_MAXL + l] = z1[l]; }
+      else {
+        zo[q * MF_MAXL + l] = z1[l];
+        yo[q * MF_MAXL + l] = (lean && l + 1 < L && z1[l] >= 0) ? -1 : y1[l];
+      }
     }
+    if (b) yout[q] = y1[L - 1];
   }
-  const int rc = mlp_fused_fwd(nprob, x, ldx, params, params_bf16, act, M, L, dims, acts, zo, yo, wo, bo, (hipStream_t)stream);
-  if (rc != TACORL_OK) FAIL(rc, "mlp_fwd_fused: launch failed (%d)", rc);
+  if (n[1]) {
+    const int rc = mlp_big_fwd(n[1], xs[1], ldx, ps[1], pb[1], as[1], Ms[1], L, dims, acts, ybf, sbf, yout, wo, bo, (hipStream_t)stream);
+    if (rc != TACORL_OK) FAIL(rc, "mlp_fwd_fused: many-row launch failed (%d)", rc);
+  }
+  if (n[0]) {
+    const int rc = mlp_fused_fwd(n[0], xs[0], ldx, ps[0], pb[0], as[0], Ms[0], L, dims, acts, zo, yo, wo, bo, (hipStream_t)stream);
+    if (rc != TACORL_OK) FAIL(rc, "mlp_fwd_fused: launch failed (%d)", rc);
+  }
   return TACORL_OK;
 }
 struct ToBf16Tbl { const float* src[16]; __bf16* dst[16]; long n4[16]; };
@@ -1065,7 +1084,7 @@ extern "C" int tacorl_to_bf16_batch(int n, const float* const* src, void* const*
 // ---- MLP backward, bf16 mode: the input-gradient chain as one launch (mlp_fused.hip) and the weight
 // gradients as a separate call, so that a caller can take them off the dependent chain (another stream).
 // Workspace: [dZ_l of every problem, l = 0..L-2][transposed bf16 weights][wgrad slabs].
-struct MlpBwdWs { long dzoff[MF_MAXP * MF_MAXL]; size_t dz_floats, wt_off[MF_MAXP], wt_bytes_each, slab_off, slab_bytes, total; };
+struct MlpBwdWs { long dzoff[MF_MAXP * MF_MAXL]; size_t dz_floats, wt_off[MF_MAXP], wt_bytes_each, xb_off[MF_MAXP], slab_off, slab_bytes, total; };
 static MlpBwdWs mlp_bwd_fused_plan(int nprob, const int* M, int L, const int* dims) {
   MlpBwdWs w{};
   long off = 0, maxM = 0;
@@ -1077,10 +1096,19 @@ static MlpBwdWs mlp_bwd_fused_plan(int nprob, const int* M, int L, const int* di
   size_t b = ((size_t)off * sizeof(float) + 255) & ~(size_t)255;
   w.wt_bytes_each = (mlp_fused_wt_elems(L, dims, nullptr) * 2 + 255) & ~(size_t)255;
   for (int p = 0; p < nprob; p++) { w.wt_off[p] = b; b += w.wt_bytes_each; }
+  int Mb[MF_MAXP], nb = 0;  // many-row problems: layer 0's input as a bf16 copy for the LDS-DMA weight gradients
+  for (int p = 0; p < nprob; p++) {
+    w.xb_off[p] = b;
+    if (mlp_big_prob_ok(M[p], L, dims, nullptr)) { b += (mlp_big_xb_bytes(M[p]) + 255) & ~(size_t)255; Mb[nb++] = M[p]; }
+  }
   w.slab_off = b;
   for (int l = 0; l < L; l++) { size_t s = wgrad_ws_bytes(nprob, dims[l], dims[l + 1], maxM); w.slab_bytes = s > w.slab_bytes ? s : w.slab_bytes; }
   if (mlp_fused_wgrad_ok(nprob, L, dims)) {  // one-launch weight gradients: a record of every layer per 256-row slice
     const size_t s = mlp_fused_wgrad_slab_floats(nprob, M, L, dims) * sizeof(float);
+    w.slab_bytes = s > w.slab_bytes ? s : w.slab_bytes;
+  }
+  if (nb) {
+    const size_t s = mlp_big_wgrad_slab_floats(nb, Mb, L, dims) * sizeof(float);
     w.slab_bytes = s > w.slab_bytes ? s : w.slab_bytes;
   }
   w.total = b + w.slab_bytes;
@@ -1103,18 +1131,39 @@ extern "C" int tacorl_mlp_bwd_fused_dgrad(int nprob, const float* const* params,
   if (ws_bytes < w.total) FAIL(TACORL_ENOMEM, "mlp_bwd_fused: workspace too small");
   long wo[MLP_MAXL], bo[MLP_MAXL], src[MF_MAXP * MF_MAXL];
   tacorl_mlp_param_layout(L, dims, wo, bo);
-  float* dz[MF_MAXP];
-  void* wt[MF_MAXP];
+  // prepacked: bit 0 = the weight transposes are in ws already; bit 1 = the caller's forward and weight gradients run lean:
+  // many-row problems then read the fp16 act' copies of the forward and hand dZ_l over as bf16 (mlp_fused.h)
+  const float *ps[2][MF_MAXP], *as[2][MF_MAXP], *ds[2][MF_MAXP];
+  float *dzs[2][MF_MAXP], *dxs[2][MF_MAXP];
+  void* wts[2][MF_MAXP];
+  int Ms[2][MF_MAXP], n[2] = {0, 0};
+  long dzo[2][MF_MAXP * MF_MAXL], sbf[MF_MAXP * MF_MAXL];
   for (int p = 0; p < nprob; p++) {
     long zo[MLP_MAXL], yo[MLP_MAXL];
     tacorl_mlp_act_layout(M[p], L, dims, acts, zo, yo);
-    for (int l = 0; l < L; l++) src[p * MF_MAXL + l] = acts[l] == ACT_SILU ? zo[l] : (acts[l] == ACT_RELU ? yo[l] : -1);
-    dz[p] = (float*)ws;
-    wt[p] = (unsigned char*)ws + w.wt_off[p];
+    const int b = ((prepacked & 2) && mlp_big_prob_ok(M[p], L, dims, acts)) ? 1 : 0, q = n[b]++;
+    ps[b][q] = params[p]; as[b][q] = act[p]; ds[b][q] = d_out[p]; dzs[b][q] = (float*)ws; dxs[b][q] = d_x ? d_x[p] : nullptr;
+    wts[b][q] = (unsigned char*)ws + w.wt_off[p]; Ms[b][q] = M[p];
+    for (int l = 0; l < L; l++) {
+      dzo[b][q * MF_MAXL + l] = w.dzoff[p * MF_MAXL + l];
+      if (b) sbf[q * MF_MAXL + l] = zo[l];
+      else src[q * MF_MAXL + l] = acts[l] == ACT_SILU ? zo[l] : (acts[l] == ACT_RELU ? yo[l] : -1);
+    }
   }
-  const int rc = mlp_fused_bwd(nprob, params, act, d_out, ldo, dz, d_x, ldd, wt, M, L, dims, acts, src, w.dzoff, wo,
-                               (hipStream_t)stream, prepacked ? 2 : 0);
-  if (rc != TACORL_OK) FAIL(rc, "mlp_bwd_fused: launch failed (%d)", rc);
+  hipStream_t st = (hipStream_t)stream;
+  if (n[1]) {
+    if (!(prepacked & 1)) {
+      const int rc = mlp_fused_bwd(n[1], ps[1], nullptr, nullptr, 0, dzs[1], nullptr, 0, wts[1], Ms[1], L, dims, acts, sbf, dzo[1], wo, st, 1);
+      if (rc != TACORL_OK) FAIL(rc, "mlp_bwd_fused: weight transposes failed (%d)", rc);
+    }
+    const int rc = mlp_big_bwd(n[1], as[1], ds[1], ldo, dzs[1], dxs[1], ldd, wts[1], Ms[1], L, dims, sbf, dzo[1], st);
+    if (rc != TACORL_OK) FAIL(rc, "mlp_bwd_fused: many-row launch failed (%d)", rc);
+  }
+  if (n[0]) {
+    const int rc = mlp_fused_bwd(n[0], ps[0], as[0], ds[0], ldo, dzs[0], dxs[0], ldd, wts[0], Ms[0], L, dims, acts, src, dzo[0], wo,
+                                 st, (prepacked & 1) ? 2 : 0);
+    if (rc != TACORL_OK) FAIL(rc, "mlp_bwd_fused: launch failed (%d)", rc);
+  }
   return TACORL_OK;
 }
 /* The weight transposes _dgrad needs, alone: they depend only on the parameters, so a caller can run them
@@ -1146,16 +1195,30 @@ extern "C" int tacorl_mlp_bwd_fused_wgrad(int nprob, const float* const* x, int 
   long wo[MLP_MAXL], bo[MLP_MAXL];
   tacorl_mlp_param_layout(L, dims, wo, bo);
   void* slab = (unsigned char*)ws + w.slab_off;
-  if (mlp_fused_wgrad_ok(nprob, L, dims)) {  // every layer and network in one launch (+ one reduce)
-    long yoffs[MF_MAXP * MF_MAXL];
-    const float* dzp[MF_MAXP];
-    for (int p = 0; p < nprob; p++) {
-      long zo[MLP_MAXL], yo[MLP_MAXL];
-      tacorl_mlp_act_layout(M[p], L, dims, acts, zo, yo);
-      for (int l = 0; l < L; l++) yoffs[p * MF_MAXL + l] = (lean && l + 1 < L && zo[l] >= 0) ? -(zo[l] + 1) : yo[l];
-      dzp[p] = (const float*)ws;
+  // many-row problems of a lean site: LDS-DMA over the bf16 copies left by the forward and the (lean-flagged) dgrad launch;
+  // the others: the one-launch form / per-layer GEMMs below (both groups use the slab region, one after the other)
+  const float *xs[2][MF_MAXP], *as[2][MF_MAXP], *ds[2][MF_MAXP], *dzp[2][MF_MAXP];
+  float* gs[2][MF_MAXP];
+  void* xb[MF_MAXP];
+  int Ms[2][MF_MAXP], n[2] = {0, 0};
+  long yoffs[2][MF_MAXP * MF_MAXL], dzo[2][MF_MAXP * MF_MAXL];
+  for (int p = 0; p < nprob; p++) {
+    long zo[MLP_MAXL], yo[MLP_MAXL];
+    tacorl_mlp_act_layout(M[p], L, dims, acts, zo, yo);
+    const int b = (lean && mlp_big_prob_ok(M[p], L, dims, acts)) ? 1 : 0, q = n[b]++;
+    xs[b][q] = x[p]; as[b][q] = act[p]; ds[b][q] = d_out[p]; dzp[b][q] = (const float*)ws; gs[b][q] = grads[p]; Ms[b][q] = M[p];
+    if (b) xb[q] = (unsigned char*)ws + w.xb_off[p];
+    for (int l = 0; l < L; l++) {
+      dzo[b][q * MF_MAXL + l] = w.dzoff[p * MF_MAXL + l];
+      yoffs[b][q * MF_MAXL + l] = b ? yo[l] : ((lean && l + 1 < L && zo[l] >= 0) ? -(zo[l] + 1) : yo[l]);
     }
-    if (mlp_fused_wgrad(nprob, x, ldx, act, d_out, ldo, dzp, grads, (float*)slab, M, L, dims, yoffs, w.dzoff, wo, bo,
+  }
+  if (n[1] && mlp_fused_wgrad_big(n[1], xs[1], ldx, as[1], ds[1], ldo, dzp[1], gs[1], (float*)slab, xb, Ms[1], L, dims, yoffs[1],
+                                  dzo[1], wo, bo, accumulate, st))
+    FAIL(TACORL_ELAUNCH, "mlp_bwd_fused_wgrad: many-row launch failed");
+  if (!n[0]) return TACORL_OK;
+  if (mlp_fused_wgrad_ok(n[0], L, dims)) {  // every layer and network in one launch (+ one reduce)
+    if (mlp_fused_wgrad(n[0], xs[0], ldx, as[0], ds[0], ldo, dzp[0], gs[0], (float*)slab, Ms[0], L, dims, yoffs[0], dzo[0], wo, bo,
                         accumulate, st, acts))
       FAIL(TACORL_ELAUNCH, "mlp_bwd_fused_wgrad: launch failed");
     return TACORL_OK;
@@ -1165,13 +1228,13 @@ extern "C" int tacorl_mlp_bwd_fused_wgrad(int nprob, const float* const* x, int 
     const float *xg[GEMM_MAXP], *dzg[GEMM_MAXP];
     float *dwg[GEMM_MAXP], *dbg[GEMM_MAXP];
     int Mc[GEMM_MAXP], n2 = 0;
-    for (int p = 0; p < nprob; p++) {
-      if (!grads[p] || M[p] <= 0) continue;
+    for (int q = 0; q < n[0]; q++) {
+      if (!gs[0][q] || Ms[0][q] <= 0) continue;
       long zo[MLP_MAXL], yo[MLP_MAXL];
-      tacorl_mlp_act_layout(M[p], L, dims, acts, zo, yo);
-      xg[n2] = l == 0 ? x[p] : act[p] + yo[l - 1];
-      dzg[n2] = l == L - 1 ? d_out[p] : (const float*)ws + w.dzoff[p * MF_MAXL + l];
-      dwg[n2] = grads[p] + wo[l]; dbg[n2] = grads[p] + bo[l]; Mc[n2] = M[p]; n2++;
+      tacorl_mlp_act_layout(Ms[0][q], L, dims, acts, zo, yo);
+      xg[n2] = l == 0 ? xs[0][q] : as[0][q] + yo[l - 1];
+      dzg[n2] = l == L - 1 ? ds[0][q] : (const float*)ws + dzo[0][q * MF_MAXL + l];
+      dwg[n2] = gs[0][q] + wo[l]; dbg[n2] = gs[0][q] + bo[l]; Mc[n2] = Ms[0][q]; n2++;
     }
     if (n2) CHECK(k_linear_wgrad(n2, xg, l == 0 ? ldx : dims[l], dzg, l == L - 1 ? ldo : dims[l + 1], Mc, dims[l], dims[l + 1],
                                  dwg, dbg, accumulate, slab, w.slab_bytes, TACORL_BF16, st));

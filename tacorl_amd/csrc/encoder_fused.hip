@@ -434,12 +434,12 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
           // inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in the loop hipcc degrades every
           // LDS wait of the conv phases to lgkmcnt(0) (it cannot tell the DMA's LDS writes from the fragment
           // reads), which exposes the full LDS latency at each tile; the ordering against the readers of this
-          // buffer is explicit anyway (vmcnt(0) + barrier at the end of the image / band).  M0 is written here and
-          // listed as clobbered (hipcc never allocates it and sets it right before its own uses).
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
-                       :
+          // buffer is explicit anyway (vmcnt(0) + barrier at the end of the image / band).
+          unsigned keep_m0;  // M0 is saved and restored around the piece: hipcc rejects "m0" as a clobber (reserved register)
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep_m0)
                        : "v"(dma_voff), "s"(__builtin_amdgcn_readfirstlane(dst0 + i * STEP)), "s"(src + i * STEP)
-                       : "memory", "m0");  // (declared: an M0 value hipcc keeps live across this asm would be re-made)
+                       : "memory");
         }
       }
     }

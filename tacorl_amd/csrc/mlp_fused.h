@@ -38,3 +38,23 @@ int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* cons
                     const long* yoff, const long* dzoff, const long* woff, const long* boff, int accumulate, hipStream_t st,
                     const int* acts = nullptr);
 // yoff[...] < 0 (forward: do not save that layer's output; wgrad: -(zoff + 1), recompute it from the pre-activation with acts[l])
+
+// ---- many-row problems (>= TACORL_MLP_BIG_ROWS = 16384 rows: C5's Q networks, 99 328): kernels of their own.  Eligible:
+// L >= 2, hidden widths 256 with SiLU, dims[0] <= 128, dims[L] <= 4.  A hidden layer l saves, instead of fp32 z / y:
+//   ybf[p*MF_MAXL + l]: bf16 [Mp][256] copy of its output (the next layer's MFMA operand and the weight gradients' x operand),
+//   sbf[p*MF_MAXL + l]: fp16 [Mp][256] copy of act'(z)   (Mp = M rounded up to 64; float offsets into act[p]);
+// the input-gradient chain leaves dZ_l as bf16 [Mp][256] at dz[p] + dzoff (floats), and the weight gradients stream both by
+// LDS-DMA (mlp_wgrad_big_kernel).  yout[p]: float offset of the last layer's fp32 output.
+bool mlp_big_prob_ok(int M, int L, const int* dims, const int* acts);
+int mlp_big_fwd(int nprob, const float* const* x, int ldx, const float* const* params, const void* const* params_bf16,
+                float* const* act, const int* M, int L, const int* dims, const int* acts, const long* ybf, const long* sbf,
+                const long* yout, const long* woff, const long* boff, hipStream_t st);
+int mlp_big_bwd(int nprob, const float* const* act, const float* const* d_out, int ldo, float* const* dz, float* const* d_x,
+                int ldd, void* const* wt, const int* M, int L, const int* dims, const long* sbf, const long* dzoff,
+                hipStream_t st);
+size_t mlp_big_wgrad_slab_floats(int nprob, const int* M, int L, const int* dims);
+size_t mlp_big_xb_bytes(int M);
+int mlp_fused_wgrad_big(int nprob, const float* const* x, int ldx, const float* const* act, const float* const* d_out, int ldo,
+                        const float* const* dz, float* const* grads, float* slab, void* const* xb, const int* M, int L,
+                        const int* dims, const long* ybf, const long* dzoff, const long* woff, const long* boff, int accumulate,
+                        hipStream_t st);

@@ -42,15 +42,20 @@ struct MlpFwdArgs {
 
 // bf16-mode activation math: hardware exp / reciprocal (relative error ~1e-6, far below the bf16 operand
 // rounding of these kernels); the exact expf / IEEE-division forms cost ~3 us per layer and workgroup here
+// (v_exp_f32 / v_rcp_f32 directly: `__frcp_rn` is the correctly rounded reciprocal, i.e. hipcc's 11-instruction IEEE
+// division sequence - per element, in every epilogue of these kernels)
+__device__ __forceinline__ float sigmoid_fast(float z) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * z));
+}
 __device__ __forceinline__ float act_fast(int act, float z) {
   if (act == ACT_RELU) return z > 0.f ? z : 0.f;
-  if (act == ACT_SILU) return z * __frcp_rn(1.f + __expf(-z));
+  if (act == ACT_SILU) return z * sigmoid_fast(z);
   return z;
 }
 __device__ __forceinline__ float act_grad_fast(int act, float zy) {
   if (act == ACT_RELU) return zy > 0.f ? 1.f : 0.f;
   if (act == ACT_SILU) {
-    const float sg = __frcp_rn(1.f + __expf(-zy));
+    const float sg = sigmoid_fast(zy);
     return sg * (1.f + zy * (1.f - sg));
   }
   return 1.f;
@@ -543,6 +548,569 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(MlpWgReduceArgs a
   }
 }
 
+
+// ------------------------------------------------------------------ forward / input gradients, tens of thousands of rows
+// C5's Q networks: 99 328 rows each.  With the kernels above (128 / 64 rows per workgroup) the forward wrote every hidden
+// pre-activation as fp32 straight from the accumulators - one 64-byte segment per (row, wave): 610 MB in 319 us - and the
+// input-gradient chain read them back the same way and wrote every dZ_l as fp32 (428 us).  What the backward needs of a
+// hidden SiLU layer is not z but act'(z) (the chain) and y = act(z) rounded to bf16 (the weight gradients' MFMA operand).
+// The many-row kernels save exactly those: y as bf16 (the very values the next layer consumed) and s = act'(z) as fp16
+// (|s| <= 1.1, 11 significant bits; it multiplies a gradient that is rounded to bf16 right after), both row-major
+// [Mp][256] (Mp = M rounded up to 64, zero rows beyond M) - 4 bytes per element instead of 4 (+ 4 for dZ) - and both
+// leave through LDS as 16-byte-per-lane coalesced stores.  Same structure as mlp_fused_{fwd,bwd}_body otherwise.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#ifdef MLP_STAMPS  // scratch builds (scratch/mklib2.sh): phase clocks of one workgroup's wave 0, read by tacorl_dbg_mlp_stamps
+__device__ unsigned long long g_mlp_stamps[2][64];
+#define MLP_STAMP(k, j) do { if (stamp_on) g_mlp_stamps[k][j] = clock64(); } while (0)
+#else
+#define MLP_STAMP(k, j) do { } while (0)
+#endif
+
+struct MlpBigFwdArgs {
+  const float* x[MF_MAXP];
+  const float* params[MF_MAXP];
+  const __bf16* pbf[MF_MAXP];
+  float* act[MF_MAXP];
+  int M[MF_MAXP];
+  long ybf[MF_MAXP][MF_MAXL], sbf[MF_MAXP][MF_MAXL];  // float offsets in act[p]: bf16 output copy / fp16 act' copy of hidden layer l
+  long yout[MF_MAXP];                                  // float offset of the last layer's fp32 output [M][dims[L]]
+  long woff[MF_MAXL], boff[MF_MAXL];
+  int dims[MF_MAXL + 1], acts[MF_MAXL];
+  int L, ldx;
+};
+
+__global__ __launch_bounds__(MF_NT) void mlp_big_fwd_kernel(MlpBigFwdArgs a) {
+  constexpr int BMF = 128, MTF = BMF / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* X = reinterpret_cast<__bf16*>(smem);  // [2][BMF][XP]
+  const int p = blockIdx.y, m0 = blockIdx.x * BMF, M = a.M[p];
+  if (m0 >= M) return;
+  const int Mp = (M + 63) & ~63;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int n0 = MF_CW * w;
+#ifdef MLP_STAMPS
+  const bool stamp_on = blockIdx.x == 300 && p == 0 && tid == 0;
+#endif
+  MLP_STAMP(0, 0);
+  // ONE global round trip in front of the first layer: the input rows (8-column chunks, up to two per thread) and the
+  // first layer's weights are requested together, LDS is zeroed meanwhile; no barrier of the prologue drains vmcnt
+  // (a workgroup starts behind the 393 KB its predecessor on this CU has just stored: every dependent round trip
+  // up here costs ~5 us - the two-step prologue of mlp_fused_fwd_body read 11 us of a 52 us workgroup)
+  const int K0 = a.dims[0], c8 = (K0 + 7) / 8;  // c8 <= 16 (dims[0] <= 128): BMF * c8 <= 2 * MF_NT
+  f32x4 xr[2][2];
+  const float* x = a.x[p];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int c = tid + u * MF_NT, row = c / c8, k = (c - row * c8) * 8;
+    const bool ok = c < BMF * c8 && m0 + row < M;
+    const float* q = x + (ok ? (long)(m0 + row) * a.ldx + k : 0);
+    if (ok && k + 8 <= a.ldx) { xr[u][0] = *reinterpret_cast<const f32x4*>(q); xr[u][1] = *reinterpret_cast<const f32x4*>(q + 4); }
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) { xr[u][0][j] = ok && k + j < K0 ? q[j] : 0.f; xr[u][1][j] = ok && k + 4 + j < K0 ? q[4 + j] : 0.f; }
+    }
+  }
+  bf16x8 B[8][MF_NTW];
+  auto load_layer = [&](int l) {
+    const int K = a.dims[l], N = a.dims[l + 1];
+    const __bf16* Wb = a.pbf[p] + a.woff[l];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+      for (int nt = 0; nt < MF_NTW; nt++) B[ks][nt] = load_w(Wb, K, N, n0 + 16 * nt + i, 32 * ks + 8 * g);
+  };
+  if (n0 < a.dims[1]) load_layer(0);
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  for (int e = tid; e < 2 * BMF * XP / 8; e += MF_NT) reinterpret_cast<f32x4*>(X)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  lds_barrier();
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int c = tid + u * MF_NT, row = c / c8, k = (c - row * c8) * 8;
+    if (c < BMF * c8 && m0 + row < M) {
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { v[j] = (__bf16)(k + j < K0 ? xr[u][0][j] : 0.f); v[4 + j] = (__bf16)(k + 4 + j < K0 ? xr[u][1][j] : 0.f); }
+      *reinterpret_cast<bf16x8*>(X + row * XP + k) = v;
+    }
+  }
+  lds_barrier();
+  int cur = 0;
+  for (int l = 0; l < a.L; l++) {
+    MLP_STAMP(0, 8 * l + 1);
+    const int K = a.dims[l], N = a.dims[l + 1], KS = (K + 31) / 32, act = a.acts[l];
+    const bool hidden = l + 1 < a.L;
+    const float* bias = a.params[p] + a.boff[l];
+    const __bf16* xin = X + cur * BMF * XP;
+    __bf16* xout = X + (cur ^ 1) * BMF * XP;
+    f32x4 acc[MTF][MF_NTW], bvv[MF_NTW];
+    f16x4 sreg[MTF][MF_NTW];
+    const bool vec = (N & 3) == 0;
+    if (n0 < N) {
+#pragma unroll
+      for (int nt = 0; nt < MF_NTW; nt++) {
+        const int col = n0 + 16 * nt + 4 * g;
+        bvv[nt] = *reinterpret_cast<const f32x4*>(bias + (vec && col < N ? col : 0));
+      }
+#pragma unroll
+      for (int mt = 0; mt < MTF; mt++)
+#pragma unroll
+        for (int nt = 0; nt < MF_NTW; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        if (ks >= KS) break;
+        bf16x8 A[MTF];
+#pragma unroll
+        for (int mt = 0; mt < MTF; mt++) A[mt] = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
+#pragma unroll
+        for (int nt = 0; nt < MF_NTW; nt++)
+          if (n0 + 16 * nt < N) {
+#pragma unroll
+            for (int mt = 0; mt < MTF; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nt], A[mt], acc[mt][nt], 0, 0, 0);
+          }
+      }
+    }
+    MLP_STAMP(0, 8 * l + 2);
+    if (hidden && n0 < a.dims[l + 2]) load_layer(l + 1);
+    // (the copy-out of the previous layer read both buffers: nobody may write xout before every wave is past it)
+    lds_barrier();
+    MLP_STAMP(0, 8 * l + 3);
+    if (hidden) {  // SiLU over all 256 columns (mlp_big_prob_ok): y = z sg, act' = sg + y (1 - sg), one exp / rcp for both
+#pragma unroll
+      for (int nt = 0; nt < MF_NTW; nt++) {
+        const int col = n0 + 16 * nt + 4 * g;
+        const f32x4 bv = bvv[nt];
+#pragma unroll
+        for (int mt = 0; mt < MTF; mt++) {
+          const int row = 16 * mt + i;
+          const f32x4 z = acc[mt][nt] + bv;
+          f32x4 y, sd;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float sg = sigmoid_fast(z[r]);
+            y[r] = z[r] * sg;
+            sd[r] = sg + y[r] * (1.f - sg);
+          }
+          *reinterpret_cast<bf16x4*>(xout + row * XP + col) = bf16x4{(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
+          sreg[mt][nt] = f16x4{(_Float16)sd[0], (_Float16)sd[1], (_Float16)sd[2], (_Float16)sd[3]};
+        }
+      }
+    } else if (n0 < N) {  // the output layer (1..4 columns, no activation): fp32 rows
+      float* yb = a.act[p] + a.yout[p];
+#pragma unroll
+      for (int nt = 0; nt < MF_NTW; nt++) {
+        const int col = n0 + 16 * nt + 4 * g;
+        if (n0 + 16 * nt >= N) continue;
+#pragma unroll
+        for (int mt = 0; mt < MTF; mt++) {
+          const int row = 16 * mt + i;
+          if (m0 + row < M) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              if (col + r < N) yb[(long)(m0 + row) * N + col + r] = acc[mt][nt][r] + bias[col + r];
+          }
+        }
+      }
+    }
+    MLP_STAMP(0, 8 * l + 4);
+    lds_barrier();  // xout complete, xin dead
+    MLP_STAMP(0, 8 * l + 5);
+    if (hidden) {
+      // act' through the dead input buffer, then both copies leave as 16-byte coalesced stores
+      _Float16* sb = reinterpret_cast<_Float16*>(X + cur * BMF * XP);
+      if (n0 < N) {
+#pragma unroll
+        for (int nt = 0; nt < MF_NTW; nt++) {
+          const int col = n0 + 16 * nt + 4 * g;
+          if (n0 + 16 * nt >= N) continue;
+#pragma unroll
+          for (int mt = 0; mt < MTF; mt++) *reinterpret_cast<f16x4*>(sb + (16 * mt + i) * XP + col) = sreg[mt][nt];
+        }
+      }
+      lds_barrier();
+      MLP_STAMP(0, 8 * l + 6);
+      __bf16* y16 = reinterpret_cast<__bf16*>(a.act[p] + a.ybf[p][l]);
+      __bf16* s16 = reinterpret_cast<__bf16*>(a.act[p] + a.sbf[p][l]);  // (fp16 payload moved as 16-byte vectors)
+      const int c8n = N >> 3;
+      for (int c = tid; c < BMF * c8n; c += MF_NT) {
+        const int row = c / c8n, k = (c - row * c8n) * 8;
+        if (m0 + row < Mp) {
+          const __bf16 z0 = (__bf16)0.f;
+          bf16x8 yv = {z0, z0, z0, z0, z0, z0, z0, z0}, sv = yv;
+          if (m0 + row < M) {
+            yv = *reinterpret_cast<const bf16x8*>(xout + row * XP + k);
+            sv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(sb) + row * XP + k);
+          }
+          *reinterpret_cast<bf16x8*>(y16 + (long)(m0 + row) * N + k) = yv;
+          *reinterpret_cast<bf16x8*>(s16 + (long)(m0 + row) * N + k) = sv;
+        }
+      }
+    }
+    MLP_STAMP(0, 8 * l + 7);
+    cur ^= 1;
+  }
+}
+
+struct MlpBigBwdArgs {
+  const float* d_out[MF_MAXP];
+  const float* act[MF_MAXP];
+  const __bf16* wt[MF_MAXP];
+  float* dz[MF_MAXP];      // dZ_l (bf16 [Mp][dims[l+1]]) at dzoff[p][l] floats, l = 0 .. L-2
+  float* d_x[MF_MAXP];     // optional fp32 [M][ldd]
+  int M[MF_MAXP];
+  long sbf[MF_MAXP][MF_MAXL];  // float offset in act[p] of hidden layer l's fp16 act' copy
+  long dzoff[MF_MAXP][MF_MAXL];
+  long wtoff[MF_MAXL];
+  int dims[MF_MAXL + 1];
+  int L, ldo, ldd;
+};
+
+__global__ __launch_bounds__(MF_NT) void mlp_big_bwd_kernel(MlpBigBwdArgs a) {
+  constexpr int BMF = 64, MTF = BMF / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* X = reinterpret_cast<__bf16*>(smem);                      // [2][BMF][XP]
+  _Float16* S = reinterpret_cast<_Float16*>(X + 2 * BMF * XP);      // [BMF][XP] act' of the layer below
+  const int p = blockIdx.y, m0 = blockIdx.x * BMF, M = a.M[p];
+  if (m0 >= M) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int n0 = MF_CW * w;
+  bf16x8 B[8][MF_NTW];
+  auto load_layer = [&](int l) {
+    const int KO = a.dims[l], NP = (a.dims[l + 1] + 7) / 8 * 8;
+    const __bf16* T = a.wt[p] + a.wtoff[l];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+      for (int nt = 0; nt < MF_NTW; nt++) B[ks][nt] = load_w(T, NP, KO, n0 + 16 * nt + i, 32 * ks + 8 * g);
+  };
+  const int l_last = a.d_x[p] ? 0 : 1;
+  // one global round trip in front of the chain (see mlp_big_fwd_kernel): d_out rows and the last layer's W^T together
+  const int NL = a.dims[a.L];  // <= 4: BMF * NL <= MF_NT
+  float dreg = 0.f;
+  {
+    const int row = tid / NL, n = tid - row * NL;
+    if (tid < BMF * NL && m0 + row < M) dreg = a.d_out[p][(long)(m0 + row) * a.ldo + n];
+  }
+  if (a.L - 1 >= l_last && n0 < a.dims[a.L - 1]) load_layer(a.L - 1);
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  for (int e = tid; e < 2 * BMF * XP / 8; e += MF_NT) reinterpret_cast<f32x4*>(X)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  lds_barrier();
+  if (tid < BMF * NL) { const int row = tid / NL, n = tid - row * NL; X[row * XP + n] = (__bf16)dreg; }
+  lds_barrier();
+  int cur = 0;
+  for (int l = a.L - 1; l >= l_last; l--) {
+    const int KO = a.dims[l], NR = a.dims[l + 1], KS = (NR + 31) / 32;
+    const __bf16* xin = X + cur * BMF * XP;
+    __bf16* xout = X + (cur ^ 1) * BMF * XP;
+    f32x4 acc[MTF][MF_NTW];
+    const bool masked = l > 0;  // hidden layer l-1's act' multiplies this layer's input gradient
+    const int ldout = l > 0 ? KO : a.ldd;
+    const bool vec = (KO & 3) == 0 && (ldout & 3) == 0;
+    // this workgroup's 64 x KO tile of act' (fp16, row-major: 16 bytes per lane, coalesced) travels under the MFMA loop
+    bf16x8 spre[2];
+    const int c8n = KO >> 3;  // (KO % 8 == 0 for hidden widths)
+    if (masked) {
+      const __bf16* s16 = reinterpret_cast<const __bf16*>(a.act[p] + a.sbf[p][l - 1]);
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int c = tid + u * MF_NT, row = c / c8n, k = (c - row * c8n) * 8;
+        const bool ok = c < BMF * c8n && m0 + row < M;
+        spre[u] = *reinterpret_cast<const bf16x8*>(s16 + (ok ? (long)(m0 + row) * KO + k : 0));
+      }
+    }
+    if (n0 < KO) {
+#pragma unroll
+      for (int mt = 0; mt < MTF; mt++)
+#pragma unroll
+        for (int nt = 0; nt < MF_NTW; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        if (ks >= KS) break;
+        bf16x8 A[MTF];
+#pragma unroll
+        for (int mt = 0; mt < MTF; mt++) A[mt] = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
+#pragma unroll
+        for (int nt = 0; nt < MF_NTW; nt++)
+          if (n0 + 16 * nt < KO) {
+#pragma unroll
+            for (int mt = 0; mt < MTF; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ks][nt], A[mt], acc[mt][nt], 0, 0, 0);
+          }
+      }
+    }
+    if (l - 1 >= l_last && n0 < a.dims[l - 1]) load_layer(l - 1);
+    if (masked) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int c = tid + u * MF_NT, row = c / c8n, k = (c - row * c8n) * 8;
+        if (c < BMF * c8n) *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(S) + row * XP + k) = spre[u];
+      }
+      lds_barrier();
+    }
+    if (n0 < KO) {
+#pragma unroll
+      for (int nt = 0; nt < MF_NTW; nt++) {
+        const int col = n0 + 16 * nt + 4 * g;
+        if (n0 + 16 * nt >= KO) continue;
+#pragma unroll
+        for (int mt = 0; mt < MTF; mt++) {
+          const int row = 16 * mt + i;
+          const bool rok = m0 + row < M;
+          f32x4 v = acc[mt][nt];
+          if (masked) {
+            const f16x4 sv = *reinterpret_cast<const f16x4*>(S + row * XP + col);
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] *= (float)sv[r];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (!rok || col + r >= KO) v[r] = 0.f;
+          if (l == 0 && rok) {
+            float* o = a.d_x[p] + (long)(m0 + row) * ldout + col;
+            if (vec && col < KO) *reinterpret_cast<f32x4*>(o) = v;
+            else {
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                if (col + r < KO) o[r] = v[r];
+            }
+          }
+          *reinterpret_cast<bf16x4*>(xout + row * XP + col) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
+      }
+    }
+    lds_barrier();
+    if (l > 0) {  // dZ_{l-1} as the chain consumes it leaves from LDS, 16 bytes per lane (zero rows beyond M)
+      __bf16* d16 = reinterpret_cast<__bf16*>(a.dz[p] + a.dzoff[p][l - 1]);
+      for (int c = tid; c < BMF * c8n; c += MF_NT) {
+        const int row = c / c8n, k = (c - row * c8n) * 8;
+        *reinterpret_cast<bf16x8*>(d16 + (long)(m0 + row) * KO + k) = *reinterpret_cast<const bf16x8*>(xout + row * XP + k);
+      }
+    }
+    cur ^= 1;
+  }
+}
+
+// ------------------------------------------------------------------ weight gradients, tens of thousands of rows
+// C5's Q networks see (3 n + 1) B = 99 328 rows each.  mlp_wgrad_fused_kernel above reads both operands as fp32, recomputes
+// the SiLU of the lean forward per element and re-lays everything through registers: 915 us per step for the two
+// networks (61 TFLOP/s, 1.3 TB/s) - bound by the VALU work in front of every MFMA, not by bytes.  Here both operands arrive
+// as the bf16 row-major copies their producers leave behind (the forward: y_l = the very bf16 values the next layer
+// consumed; the input-gradient chain: dZ_l as the next layer of the chain consumed it) and go HBM -> LDS by LDS-DMA in
+// their natural order, 64 rows per stage on a 2-stage ring, 16-byte chunks XOR-swizzled through the choice of global
+// chunk per lane; MFMA fragments by ds_read_b64_tr_b16 (the reduction index - the batch row - is the slow index of both:
+// rnn_ops.hip's rnn_wgrad_kernel has the derivation).  A workgroup owns ALL 256 dZ columns x 128 x columns of one
+// (network, layer) over a slice of rows (dZ is then read twice per layer, x once): 8 waves as 4 (64 dZ columns) x 2
+// (64 x columns), 64 accumulator registers; the bias gradient is one more MFMA against ones.  Slices go to the slab
+// records mlp_wgrad_reduce_kernel sums in slice order (deterministic).  Layer 0's x (71 columns of fp32) is first
+// converted to a zero-padded bf16 [Mp][128] copy (mlp_x_to_bf16_kernel); the last layer (256 -> 1..4 outputs) is a
+// weighted column sum of y_{L-2} (mlp_wgrad_out_kernel).
+constexpr int BG_R = 64, BG_S = 2;                 // rows per stage, stages
+constexpr int BG_OPB = BG_R * 256;                  // bytes of one 128-column operand block of a stage
+constexpr int BG_STAGE = 3 * BG_OPB;                // [dZ columns 0..127][dZ columns 128..255][x columns of this tile]
+constexpr int BG_NW = 8;
+
+typedef __bf16 bf16x4tr __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 bg_tr_frag8(const unsigned char* lo, const unsigned char* hi) {
+  const bf16x4tr a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4tr*)(lo));
+  const bf16x4tr b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4tr*)(hi));
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+struct MlpWgBigArgs {
+  const __bf16* dz[MF_MAXP][MF_MAXL];  // [Mp][256]
+  const __bf16* xb[MF_MAXP][MF_MAXL];  // [Mp][ldxb[l]]
+  float* slab[MF_MAXP];
+  int Mp[MF_MAXP];
+  long sloff[MF_MAXL], rec;
+  int K[MF_MAXL], ldxb[MF_MAXL];       // true input width of the layer (columns of dW), row pitch of its bf16 operand
+  int tile0[MF_MAXL + 1];              // first x tile (128 columns) of layer l in blockIdx.y
+  int nl;                              // layers handled here (0 .. L-2)
+  int rps;                             // rows per slice (a multiple of BG_R)
+};
+
+__global__ __launch_bounds__(64 * BG_NW) void mlp_wgrad_big_kernel(MlpWgBigArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int p = blockIdx.z, Mp = a.Mp[p];
+  const int r_begin = blockIdx.x * a.rps;
+  if (r_begin >= Mp) return;
+  const int r_end = min(Mp, r_begin + a.rps), nk = (r_end - r_begin) / BG_R;
+  int l = 0;
+  while (l + 1 < a.nl && (int)blockIdx.y >= a.tile0[l + 1]) l++;
+  const int nt = blockIdx.y - a.tile0[l], n0 = nt * 128;  // x columns [n0, n0 + 128)
+  const __bf16* __restrict__ dz = a.dz[p][l] + (long)r_begin * 256;
+  const int ldx = a.ldxb[l], K = a.K[l];
+  const __bf16* __restrict__ xb = a.xb[p][l] + (long)r_begin * ldx + n0;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l16 = lane & 15, q = l16 >> 2, pc = l16 & 3;
+  const int wm = w >> 1, wn = w & 1;  // wave grid: 4 (64 dZ columns each) x 2 (64 x columns each)
+  constexpr int DPW = 3 * (BG_R / 4) / BG_NW;  // DMA wave-instructions per stage and wave (4 rows x 256 B of one block each)
+
+  auto issue = [&](int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < DPW; i++) {
+      const int id = w + BG_NW * i;
+      const int op = id / (BG_R / 4), row4 = (id % (BG_R / 4)) * 4;
+      const int r = row4 + (lane >> 4), cpos = lane & 15, c = cpos ^ (2 * (r & 7));
+      const __bf16* src = (op == 2 ? xb + (long)(kt * BG_R + r) * ldx : dz + (long)(kt * BG_R + r) * 256 + 128 * op) + c * 8;
+      const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)(
+          lds + slot * BG_STAGE + op * BG_OPB + row4 * 256));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(src), "s"(lds_off)
+                   : "memory");
+    }
+  };
+
+  f32x4 acc[4][4], bacc[4];  // [x tile ni][dZ tile mi]
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++) {
+    bacc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; j++) ones[j] = (__bf16)1.0f;
+  if (nk > 0) issue(0, 0);
+  // fragment addresses inside a stage: row 4 g + q (+16), 16-byte chunk (2 tile + pc / 2) ^ swizzle, half pc % 2
+  const int row = 4 * g + q, sw = 2 * (row & 7), half = 8 * (pc & 1);
+  int offA[4], offB[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++)
+    offA[mi] = (wm >> 1) * BG_OPB + row * 256 + (((2 * (4 * (wm & 1) + mi) + (pc >> 1)) ^ sw) << 4) + half;
+#pragma unroll
+  for (int ni = 0; ni < 4; ni++) offB[ni] = 2 * BG_OPB + row * 256 + (((2 * (4 * wn + ni) + (pc >> 1)) ^ sw) << 4) + half;
+  const bool bias_wave = wn == 0 && nt == 0;
+
+  for (int kt = 0; kt < nk; kt++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of stage kt have landed
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone's have; stage kt - 1 is no longer read
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const unsigned char* st = lds + (kt & 1) * BG_STAGE;
+#pragma unroll
+    for (int sub = 0; sub < BG_R / 32; sub++) {
+      const unsigned char* sb = st + sub * 32 * 256;
+      bf16x8 A[4], B[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++) A[mi] = bg_tr_frag8(sb + offA[mi], sb + offA[mi] + 16 * 256);
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++) B[ni] = bg_tr_frag8(sb + offB[ni], sb + offB[ni] + 16 * 256);
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ni], A[mi], acc[ni][mi], 0, 0, 0);
+        if (bias_wave) bacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, A[mi], bacc[mi], 0, 0, 0);
+      }
+    }
+  }
+  // D[i][j]: i = x column inside its 16-tile (this lane: 4 g .. 4 g + 3), j = dZ column (lane l16) -> dW[n][k .. k + 3]
+  float* rec = a.slab[p] + (long)blockIdx.x * a.rec + a.sloff[l];
+  const bool vecK = (K & 3) == 0;
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++) {
+    const int n = 64 * wm + 16 * mi + l16;
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      const int k = n0 + 64 * wn + 16 * ni + 4 * g;
+      float* o = rec + (long)n * K + k;
+      if (vecK) {
+        if (k < K) *reinterpret_cast<f32x4*>(o) = acc[ni][mi];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (k + r < K) o[r] = acc[ni][mi][r];
+      }
+    }
+    if (bias_wave && g == 0) rec[(long)256 * K + n] = bacc[mi][0];
+  }
+}
+
+// x fp32 [M][ldx] (K0 columns) -> bf16 [Mp][128], zero beyond K0 columns / M rows
+struct MlpXbArgs { const float* x[MF_MAXP]; __bf16* xb[MF_MAXP]; int M[MF_MAXP], Mp[MF_MAXP]; int ldx, K0; };
+__global__ __launch_bounds__(256) void mlp_x_to_bf16_kernel(MlpXbArgs a) {
+  const int p = blockIdx.y, M = a.M[p], Mp = a.Mp[p], K0 = a.K0;
+  const float* __restrict__ x = a.x[p];
+  __bf16* __restrict__ o = a.xb[p];
+  for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < (long)Mp * 16; c += (long)gridDim.x * 256) {
+    const int row = (int)(c >> 4), k = ((int)c & 15) * 8;
+    const __bf16 z0 = (__bf16)0.f;
+    bf16x8 v = {z0, z0, z0, z0, z0, z0, z0, z0};
+    if (row < M && k < K0) {
+      const float* q = x + (long)row * a.ldx + k;
+      if (k + 8 <= a.ldx && (a.ldx & 3) == 0) {  // inside the row's allocation: two 16-byte loads, masked at the ragged end
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(q), hi = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { v[j] = (__bf16)(k + j < K0 ? lo[j] : 0.f); v[4 + j] = (__bf16)(k + 4 + j < K0 ? hi[j] : 0.f); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          if (k + j < K0) v[j] = (__bf16)q[j];
+      }
+    }
+    *reinterpret_cast<bf16x8*>(o + (long)row * 128 + k) = v;
+  }
+}
+
+// last layer with NL <= 4 outputs: dW[n][k] = sum_r bf16(d_out[r][n]) * y[r][k], db[n] = sum_r bf16(d_out[r][n]) (the operand
+// rounding of the MFMA path); y bf16 [Mp][256].  A bandwidth kernel (51 MB of y per network): OUT_RPW rows per workgroup,
+// thread = (row group of 8, 8 columns), four 16-byte loads in flight per thread; partials [slice][NL][257] to a slab of
+// their own, summed in slice order by mlp_wgrad_reduce_kernel (as a one-layer record).
+constexpr int OUT_RPW = 512;
+struct MlpWgOutArgs {
+  const __bf16* y[MF_MAXP]; const float* dlast[MF_MAXP]; float* slab[MF_MAXP];
+  int M[MF_MAXP];
+  long rec;
+  int NL, ldo;
+};
+__global__ __launch_bounds__(256) void mlp_wgrad_out_kernel(MlpWgOutArgs a) {
+  __shared__ float red[8][4][256 + 1];
+  const int p = blockIdx.y, M = a.M[p], r0 = blockIdx.x * OUT_RPW;
+  if (r0 >= M) return;
+  const int r1 = min(M, r0 + OUT_RPW), tid = threadIdx.x, cg = tid & 31, rg = tid >> 5, NL = a.NL;
+  float acc[4][8], bsum[4];
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    bsum[n] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[n][j] = 0.f;
+  }
+  const __bf16* __restrict__ y = a.y[p];
+  const float* __restrict__ d = a.dlast[p];
+  for (int rb = r0 + rg; rb < r1; rb += 32) {
+    bf16x8 v[4];
+    float dv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {  // (rows beyond the slice: clamped address, zero weight)
+      const int r = rb + 8 * u, rc = r < r1 ? r : r0;
+      v[u] = *reinterpret_cast<const bf16x8*>(y + (long)rc * 256 + 8 * cg);
+#pragma unroll
+      for (int n = 0; n < 4; n++) dv[u][n] = (n < NL && r < r1) ? (float)(__bf16)d[(long)rc * a.ldo + n] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int n = 0; n < 4; n++)
+        if (n < NL) {
+          bsum[n] += dv[u][n];
+#pragma unroll
+          for (int j = 0; j < 8; j++) acc[n][j] += dv[u][n] * (float)v[u][j];
+        }
+  }
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) red[rg][n][8 * cg + j] = acc[n][j];
+    if (cg == 0) red[rg][n][256] = bsum[n];
+  }
+  __syncthreads();
+  float* rec = a.slab[p] + (long)blockIdx.x * a.rec;  // one-layer record: [NL][256] then [NL]
+  for (int e = tid; e < NL * 257; e += 256) {
+    const int n = e / 257, k = e - n * 257;
+    float t = 0.f;
+#pragma unroll
+    for (int g8 = 0; g8 < 8; g8++) t += red[g8][n][k];  // fixed order
+    if (k < 256) rec[(long)n * 256 + k] = t; else rec[(long)NL * 256 + n] = t;
+  }
+}
+
 }  // namespace
 
 bool mlp_fused_wgrad_ok(int nprob, int L, const int* dims) {
@@ -612,6 +1180,165 @@ int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* cons
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ---- many-row weight gradients (mlp_wgrad_big_kernel): eligibility, sizes, launch
+static int mlp_big_rows() {
+  static const int v = [] { const char* e = getenv("TACORL_MLP_BIG_ROWS"); return e ? atoi(e) : 16384; }();
+  return v;
+}
+bool mlp_big_prob_ok(int M, int L, const int* dims, const int* acts) {
+  static const int on = [] { const char* e = getenv("TACORL_MLP_BIG"); return e ? atoi(e) : 1; }();  // A/B switch
+  if (!on || L < 2 || L > MF_MAXL || M < mlp_big_rows()) return false;
+  if (dims[0] < 8 || dims[0] > 128 || dims[L] < 1 || dims[L] > 4) return false;
+  for (int l = 1; l < L; l++)
+    if (dims[l] != 256) return false;
+  if (acts) {
+    for (int l = 0; l + 1 < L; l++)
+      if (acts[l] != ACT_SILU) return false;
+    if (acts[L - 1] != ACT_NONE) return false;
+  }
+  return true;
+}
+#ifdef MLP_STAMPS
+extern "C" int tacorl_dbg_mlp_stamps(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_mlp_stamps), sizeof(g_mlp_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
+int mlp_big_fwd(int nprob, const float* const* x, int ldx, const float* const* params, const void* const* params_bf16,
+                float* const* act, const int* M, int L, const int* dims, const int* acts, const long* ybf, const long* sbf,
+                const long* yout, const long* woff, const long* boff, hipStream_t st) {
+  MlpBigFwdArgs a{};
+  int maxM = 0;
+  for (int p = 0; p < nprob; p++) {
+    if (((uintptr_t)x[p] & 15) || ((uintptr_t)params[p] & 15) || ((uintptr_t)params_bf16[p] & 7) || ((uintptr_t)act[p] & 15)) return TACORL_EINVAL;
+    a.x[p] = x[p]; a.params[p] = params[p]; a.pbf[p] = (const __bf16*)params_bf16[p]; a.act[p] = act[p]; a.M[p] = M[p];
+    for (int l = 0; l < L; l++) { a.ybf[p][l] = ybf[p * MF_MAXL + l]; a.sbf[p][l] = sbf[p * MF_MAXL + l]; }
+    a.yout[p] = yout[p];
+    maxM = M[p] > maxM ? M[p] : maxM;
+  }
+  for (int l = 0; l < L; l++) {
+    if (woff[l] % 4) return TACORL_EINVAL;
+    a.woff[l] = woff[l]; a.boff[l] = boff[l]; a.dims[l] = dims[l]; a.acts[l] = acts[l];
+  }
+  a.dims[L] = dims[L]; a.L = L; a.ldx = ldx;
+  if (maxM == 0) return TACORL_OK;
+  constexpr size_t lds = (size_t)2 * 128 * XP * 2;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_big_fwd_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
+  if (once) return TACORL_ELAUNCH;
+  hipLaunchKernelGGL(mlp_big_fwd_kernel, dim3((maxM + 127) / 128, nprob), dim3(MF_NT), lds, st, a);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+// the input-gradient chain of many-row problems (the transposed weights wt[p] are already packed: mlp_fused_bwd mode 1)
+int mlp_big_bwd(int nprob, const float* const* act, const float* const* d_out, int ldo, float* const* dz, float* const* d_x,
+                int ldd, void* const* wt, const int* M, int L, const int* dims, const long* sbf, const long* dzoff,
+                hipStream_t st) {
+  MlpBigBwdArgs a{};
+  long wtoff[MF_MAXL];
+  mlp_fused_wt_elems(L, dims, wtoff);
+  int maxM = 0;
+  for (int p = 0; p < nprob; p++) {
+    if (((uintptr_t)wt[p] | (uintptr_t)dz[p] | (uintptr_t)act[p]) & 15) return TACORL_EINVAL;
+    a.d_out[p] = d_out[p]; a.act[p] = act[p]; a.wt[p] = (const __bf16*)wt[p]; a.dz[p] = dz[p];
+    a.d_x[p] = d_x ? d_x[p] : nullptr; a.M[p] = M[p];
+    for (int l = 0; l < L; l++) { a.sbf[p][l] = sbf[p * MF_MAXL + l]; a.dzoff[p][l] = dzoff[p * MF_MAXL + l]; }
+    maxM = M[p] > maxM ? M[p] : maxM;
+  }
+  for (int l = 0; l < L; l++) a.wtoff[l] = wtoff[l];
+  for (int l = 0; l <= L; l++) a.dims[l] = dims[l];
+  a.L = L; a.ldo = ldo; a.ldd = ldd;
+  if (maxM == 0) return TACORL_OK;
+  constexpr size_t lds = (size_t)3 * 64 * XP * 2;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_big_bwd_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
+  if (once) return TACORL_ELAUNCH;
+  hipLaunchKernelGGL(mlp_big_bwd_kernel, dim3((maxM + 63) / 64, nprob), dim3(MF_NT), lds, st, a);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+static int mlp_big_tiles(int L) { return 1 + 2 * (L - 2); }  // layer 0: one 128-column x tile; hidden layers: two
+static int mlp_big_rps(int nprob, const int* M, int L) {
+  int maxMp = 0, n = 0;
+  for (int p = 0; p < nprob; p++)
+    if (M[p] > 0) { const int mp = (M[p] + 63) & ~63; maxMp = mp > maxMp ? mp : maxMp; n++; }
+  if (!n) return BG_R;
+  int nslice = 512 / (mlp_big_tiles(L) * n);
+  nslice = nslice < 1 ? 1 : nslice;
+  const int stages = maxMp / BG_R;
+  const int sps = (stages + nslice - 1) / nslice;
+  return (sps < 4 ? 4 : sps) * BG_R;
+}
+static long mlp_big_out_rec(int L, const int* dims) { return ((long)dims[L] * 257 + 3) & ~3L; }
+size_t mlp_big_wgrad_slab_floats(int nprob, const int* M, int L, const int* dims) {
+  const long rec = mlp_wgrad_record(L, dims, nullptr), orec = mlp_big_out_rec(L, dims);
+  const int rps = mlp_big_rps(nprob, M, L);
+  size_t tot = 0;
+  for (int p = 0; p < nprob; p++)
+    if (M[p] > 0) tot += (size_t)((((M[p] + 63) & ~63) + rps - 1) / rps) * rec + (size_t)((M[p] + OUT_RPW - 1) / OUT_RPW) * orec;
+  return tot;
+}
+size_t mlp_big_xb_bytes(int M) { return (size_t)((M + 63) & ~63) * 128 * 2; }
+// ybf[p*MF_MAXL + l]: float offset in act[p] of layer l's bf16 output copy (l < L-1); dz[p] + dzoff[p*MF_MAXL + l]: bf16 dZ_l;
+// xb[p]: scratch of mlp_big_xb_bytes(M[p]) bytes for layer 0's input
+int mlp_fused_wgrad_big(int nprob, const float* const* x, int ldx, const float* const* act, const float* const* d_out, int ldo,
+                        const float* const* dz, float* const* grads, float* slab, void* const* xb, const int* M, int L,
+                        const int* dims, const long* ybf, const long* dzoff, const long* woff, const long* boff, int accumulate,
+                        hipStream_t st) {
+  MlpWgBigArgs a{};
+  MlpXbArgs xa{};
+  MlpWgOutArgs oa{};
+  MlpWgReduceArgs r{}, ro{};
+  a.rec = r.rec = mlp_wgrad_record(L, dims, a.sloff);
+  oa.rec = ro.rec = mlp_big_out_rec(L, dims);
+  r.accumulate = ro.accumulate = accumulate;
+  int Mg[MF_MAXP], ng = 0;
+  for (int p = 0; p < nprob; p++)
+    if (grads[p] && M[p] > 0) Mg[ng++] = M[p];
+  if (!ng) return 0;
+  a.rps = mlp_big_rps(ng, Mg, L);
+  a.nl = L - 1;
+  for (int l = 0; l <= L; l++) r.dims[l] = dims[l];
+  for (int l = 0; l < L; l++) { r.sloff[l] = a.sloff[l]; r.woff[l] = woff[l]; r.boff[l] = boff[l]; }
+  // the last layer's partials: a one-layer record of their own (more, finer slices than the MFMA kernel's)
+  ro.dims[0] = dims[L - 1]; ro.dims[1] = dims[L]; ro.sloff[0] = 0; ro.woff[0] = woff[L - 1]; ro.boff[0] = boff[L - 1];
+  a.tile0[0] = 0;
+  for (int l = 0; l + 1 < L; l++) {
+    a.K[l] = dims[l]; a.ldxb[l] = l == 0 ? 128 : 256;
+    a.tile0[l + 1] = a.tile0[l] + (l == 0 ? 1 : 2);
+  }
+  xa.ldx = ldx; xa.K0 = dims[0];
+  oa.NL = dims[L]; oa.ldo = ldo;
+  int n2 = 0, maxs = 0, maxso = 0, maxMp = 0;
+  float* sp = slab;
+  for (int p = 0; p < nprob; p++) {
+    if (!grads[p] || M[p] <= 0) continue;
+    const int Mp = (M[p] + 63) & ~63, ns = (Mp + a.rps - 1) / a.rps, nso = (M[p] + OUT_RPW - 1) / OUT_RPW;
+    if (((uintptr_t)xb[p] | (uintptr_t)dz[p] | (uintptr_t)act[p]) & 15) return -1;
+    a.Mp[n2] = Mp; a.slab[n2] = sp;
+    for (int l = 0; l + 1 < L; l++) {
+      a.dz[n2][l] = reinterpret_cast<const __bf16*>(dz[p] + dzoff[p * MF_MAXL + l]);
+      a.xb[n2][l] = l == 0 ? reinterpret_cast<const __bf16*>(xb[p]) : reinterpret_cast<const __bf16*>(act[p] + ybf[p * MF_MAXL + l - 1]);
+    }
+    xa.x[n2] = x[p]; xa.xb[n2] = reinterpret_cast<__bf16*>(xb[p]); xa.M[n2] = M[p]; xa.Mp[n2] = Mp;
+    r.slab[n2] = sp; r.grad[n2] = grads[p]; r.nslice[n2] = ns;
+    sp += (size_t)ns * a.rec;
+    oa.y[n2] = reinterpret_cast<const __bf16*>(act[p] + ybf[p * MF_MAXL + L - 2]); oa.dlast[n2] = d_out[p]; oa.slab[n2] = sp; oa.M[n2] = M[p];
+    ro.slab[n2] = sp; ro.grad[n2] = grads[p]; ro.nslice[n2] = nso;
+    sp += (size_t)nso * oa.rec;
+    maxs = ns > maxs ? ns : maxs; maxso = nso > maxso ? nso : maxso; maxMp = Mp > maxMp ? Mp : maxMp;
+    n2++;
+  }
+  constexpr int lds = BG_S * BG_STAGE;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_big_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess ? 0 : -1;
+  if (once) return -1;
+  const int xblocks = (int)(((long)maxMp * 16 + 255) / 256);
+  hipLaunchKernelGGL(mlp_x_to_bf16_kernel, dim3(xblocks > 4096 ? 4096 : xblocks, n2), dim3(256), 0, st, xa);
+  hipLaunchKernelGGL(mlp_wgrad_big_kernel, dim3(maxs, a.tile0[L - 1], n2), dim3(64 * BG_NW), lds, st, a);
+  hipLaunchKernelGGL(mlp_wgrad_out_kernel, dim3(maxso, n2), dim3(256), 0, st, oa);
+  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(256, L - 1, n2), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(8, 1, n2), dim3(256), 0, st, ro);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 bool mlp_fused_bwd_ok(int nprob, int L, const int* dims, int ldo, int ldd) {
   if (nprob < 1 || nprob > MF_MAXP || L < 1 || L > MF_MAXL) return false;
   for (int l = 0; l <= L; l++)
@@ -655,8 +1382,7 @@ int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act
                      hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_bwd_big_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big) == hipSuccess) ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
-  static const int big_rows = [] { const char* e = getenv("TACORL_MLP_BIG_ROWS"); return e ? atoi(e) : 16384; }();
-  if (maxM >= big_rows)
+  if (maxM >= mlp_big_rows())
     hipLaunchKernelGGL(mlp_fused_bwd_big_kernel, dim3((maxM + 63) / 64, nprob), dim3(MF_NT), lds_big, st, a);
   else
     hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3((maxM + BMF - 1) / BMF, nprob), dim3(MF_NT), lds, st, a);
@@ -695,8 +1421,7 @@ int mlp_fused_fwd(int nprob, const float* const* x, int ldx, const float* const*
                      hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_fwd_big_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big) == hipSuccess) ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
-  static const int big_rows = [] { const char* e = getenv("TACORL_MLP_BIG_ROWS"); return e ? atoi(e) : 16384; }();
-  if (maxM >= big_rows)
+  if (maxM >= mlp_big_rows())
     hipLaunchKernelGGL(mlp_fused_fwd_big_kernel, dim3((maxM + 127) / 128, nprob), dim3(MF_NT), lds_big, st, a);
   else
     hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3((maxM + BMF - 1) / BMF, nprob), dim3(MF_NT), lds, st, a);

@@ -615,7 +615,7 @@ class ACEngine:
                         ws_tag="mlp_bwd_" + tag)
             return
         ops.mlp_bwd_fused_dgrad(params, acts_buf, d_outs, ldo, d_xs, ldd, M, dims, acts, "mlp_bwdf_" + tag,
-                                prepacked=getattr(self, "_prepacked", False))
+                                prepacked=getattr(self, "_prepacked", False), lean=self._lean(tag))
         if all(g is None for g in grads):
             return
         side = self.wgrad_side_streams

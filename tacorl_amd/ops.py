@@ -171,14 +171,15 @@ def mlp_bwd_fused_pack(params, M, dims, ws_tag, device):
          ws.numel(), stream())
 
 
-def mlp_bwd_fused_dgrad(params, acts_buf, d_outs, ldo, d_xs, ldd, M, dims, acts, ws_tag, prepacked=False):
+def mlp_bwd_fused_dgrad(params, acts_buf, d_outs, ldo, d_xs, ldd, M, dims, acts, ws_tag, prepacked=False, lean=False):
     """Input-gradient chain of the whole MLP in one launch; leaves every layer's dZ in workspace(ws_tag)
-    for mlp_bwd_fused_wgrad (same ws_tag, same shapes)."""
+    for mlp_bwd_fused_wgrad (same ws_tag, same shapes, same `lean` as the forward and the weight gradients: at
+    >= 16 384 rows a lean site hands dZ over as bf16 for the LDS-DMA weight-gradient kernel)."""
     nb = L.lib().tacorl_mlp_bwd_fused_ws_bytes(len(params), int_array(M), len(dims) - 1, int_array(dims))
     ws = workspace(nb, acts_buf[0].device, ws_tag)
     call("tacorl_mlp_bwd_fused_dgrad", len(params), ptr_array(params), ptr_array(acts_buf), ptr_array(d_outs), ldo,
          ptr_array(d_xs) if d_xs is not None else ptr_array([None] * len(params)), ldd, int_array(M), len(dims) - 1,
-         int_array(dims), int_array(acts), int(prepacked), ptr(ws), ws.numel(), stream())
+         int_array(dims), int_array(acts), int(bool(prepacked)) | (2 if lean else 0), ptr(ws), ws.numel(), stream())
 
 
 def mlp_bwd_fused_wgrad(xs, ldx, acts_buf, d_outs, ldo, grads, M, dims, acts, ws_tag, accumulate=False, lean=False):

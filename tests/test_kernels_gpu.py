@@ -544,8 +544,9 @@ def test_mlp_fused_forward_ragged_input_width():
 
 
 def test_mlp_fused_backward_many_rows():
-    """>= 16384 rows: the 64-rows-per-workgroup input-gradient chain (and the one-launch weight gradients, lean mode) vs
-    the per-layer bf16 backward on the same saved activations."""
+    """>= 16384 rows: the 64-rows-per-workgroup input-gradient chain and the many-row weight gradients (lean mode: LDS-DMA
+    over the bf16 copies the forward and the chain leave behind, mlp_wgrad_big_kernel) vs the per-layer bf16 backward on the
+    same saved activations, and vs the oracle's linear layers under bf16 operand rounding."""
     from tacorl_amd import blocks, ops
 
     dev = _dev()
@@ -569,7 +570,7 @@ def test_mlp_fused_backward_many_rows():
     g_ref, g_fus = [torch.zeros_like(f) for f in flats], [torch.zeros_like(f) for f in flats]
     dx_ref, dx_fus = [torch.zeros(M, ld, device=dev) for M in Ms], [torch.zeros(M, ld, device=dev) for M in Ms]
     ops.mlp_bwd(xs, ld, flats, act_s, douts, dims[-1], g_ref, dx_ref, ld, Ms, dims, acts, 1)
-    ops.mlp_bwd_fused_dgrad(flats, act_l, douts, dims[-1], dx_fus, ld, Ms, dims, acts, "t_mlp_big")
+    ops.mlp_bwd_fused_dgrad(flats, act_l, douts, dims[-1], dx_fus, ld, Ms, dims, acts, "t_mlp_big", lean=True)
     ops.mlp_bwd_fused_wgrad(xs, ld, act_l, douts, dims[-1], g_fus, Ms, dims, acts, "t_mlp_big", lean=True)
     torch.cuda.synchronize()
     from oracle import tacorl_oracle as O
@@ -635,6 +636,18 @@ def test_mlp_fused_forward_many_rows(lean):
         assert torch.isfinite(out_f).all() and relerr(out_f, out_g) < 2e-3, relerr(out_f, out_g)
         for l in range(L - 1):  # saved pre-activations (and, unless lean, outputs) of the hidden layers
             zf, zg = a_f[i][zo[l]: zo[l] + M * dims[l + 1]], a_g[i][zo[l]: zo[l] + M * dims[l + 1]]
+            if lean and M >= 16384:
+                # many-row problems of a lean site save what the backward reads instead of fp32 z / y (mlp_big_fwd_kernel):
+                # the output as bf16 [Mp][N] in the y region, act'(z) as fp16 [Mp][N] in the z region, zero rows beyond M
+                N, Mp = dims[l + 1], (M + 63) // 64 * 64
+                yb = a_f[i][yo[l]: yo[l] + Mp * N // 2].view(torch.bfloat16).reshape(Mp, N)
+                sb = a_f[i][zo[l]: zo[l] + Mp * N // 2].view(torch.float16).reshape(Mp, N)
+                zr = zg.reshape(M, N)
+                sg = torch.sigmoid(zr)
+                assert relerr(yb[:M].float(), (zr * sg).to(torch.bfloat16).float()) < 2e-3
+                assert relerr(sb[:M].float(), sg * (1 + zr * (1 - sg))) < 2e-3
+                assert not yb[M:].any()
+                continue
             assert relerr(zf, zg) < 2e-3, (l, relerr(zf, zg))
             if not lean:
                 yf, yg = a_f[i][yo[l]: yo[l] + M * dims[l + 1]], a_g[i][yo[l]: yo[l] + M * dims[l + 1]]
