@@ -496,27 +496,40 @@ def time_feeder(mod, a, B, T, H, W, dev, barrier, max_over_ranks, n_frames=40000
     def draw():
         return rng.integers(len(ix), size=B), ix.draw(B, rng), (draw_play_batch_augmentation(spec, B, T, dev) if spec else None)
 
-    def run(steps):
+    def run(steps, evs=None):
+        def mark():
+            if evs is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append(e)
+
+        mark()
         if pinned:
             rep.prefetch(*draw())
             for _ in range(steps):
                 b = rep.next()
                 rep.prefetch(*draw())  # the gather of the next batch (over PCIe) overlaps this step
                 mod.training_step(b)
+                mark()
         else:
             from tacorl_amd.data.replay import prefetching
 
             # frames by index straight into the encoder's buffers; the host side of a batch is prepared two ahead
             for b in prefetching(lambda: rep.batch(*draw(), fused=True), steps):
                 mod.training_step(b)
+                mark()
 
     run(max(a.warmup, 50))  # (the first ~40 fed steps hold one-time host stalls of ~13 ms each: capture of the new batch key,
     barrier()               # pinned / device staging buffers, the prefetch thread's first allocations)
+    evs = []
     t0 = time.perf_counter()
-    run(a.steps)
+    run(a.steps, evs)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1))
+    q = lambda f: round(ts[min(len(ts) - 1, int(f * len(ts)))], 4)  # noqa: E731
     return {"kind": a.feeder, "augment": bool(a.augment), "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "p50_ms": q(0.5), "p90_ms": q(0.9), "p99_ms": q(0.99), "max_ms": round(ts[-1], 4),
             "steps_per_s": round(a.steps / dt, 2), "dataset_frames": n_frames,
             "bytes_per_step_uint8": int(B * (T + 1) * H * W * 3),
             "note": "hbm: nothing but indices/actions crosses PCIe; pinned: PCIe-inclusive, the GPU gathers the frames out of pinned "
@@ -679,7 +692,8 @@ def main():
         if a.feeder == "none":
             fa = argparse.Namespace(**{**vars(a), "feeder": "hbm", "steps": 400 if a.steps >= 200 else a.steps, "warmup": 10})
             f = time_feeder(mod, fa, B, T, H, W, dev, barrier, max_over_ranks)
-            configs["c2_fed_from_hbm_replay"] = {k: f[k] for k in ("ms_per_step", "steps_per_s", "dataset_frames", "bytes_per_step_uint8")}
+            configs["c2_fed_from_hbm_replay"] = {k: f[k] for k in ("ms_per_step", "p50_ms", "p90_ms", "p99_ms", "max_ms", "steps_per_s",
+                                                                   "dataset_frames", "bytes_per_step_uint8")}
             for _ in range(3):
                 mod.training_step(batch)
         try:
