@@ -371,6 +371,13 @@ int tacorl_pr_encoder_fused_sample(const float* emb, int ld_emb, const float* pa
                                    const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
                                    const float* Wc, const float* bc, const float* eps, float* head, float* plan,
                                    int A, float min_std, tacorl_stream_t stream);
+/* Train mode of the same launch (PlayLMP.training_step with plan-recognition dropout 0): additionally writes, per layer, the
+ * tensors the per-op backward reads, in the per-op forward's layouts (fp32, batch-major rows).  save[9 l + k], k = 0..8: layer
+ * input [B T][32], q|k|v [B T][96], attention output [B T][32], out-projection [B T][32], LayerNorm-1 output [B T][32],
+ * post-ReLU FFN hidden [B T][FF], FFN output [B T][32], LayerNorm-1 {mean, rstd} [B T][2], LayerNorm-2 {mean, rstd} [B T][2]. */
+int tacorl_pr_encoder_fused_train(const float* emb, int ld_emb, const float* params, const void* params_bf16,
+                                  const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
+                                  float* const* save, tacorl_stream_t stream);
 int tacorl_pr_head_compose(const float* w_fc, const float* b_fc, const float* w_head, const float* b_head,
                            float* Wc, float* bc, int D, int FC, int A2, tacorl_stream_t stream);
 int tacorl_mean_over_t(const float* x, float* out, int B, int T, int D, tacorl_stream_t stream);

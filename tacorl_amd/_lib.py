@@ -38,6 +38,7 @@ _SIGS = {
     "tacorl_transpose_to_bf16": (_i, [_p, _p, _i, _i, _p]),
     "tacorl_pr_encoder_fused_supported": (_i, [_i, _i, _i, _i, _i]),
     "tacorl_pr_encoder_fused": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "tacorl_pr_encoder_fused_train": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "tacorl_pr_encoder_fused_sample": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _f, _p]),
     "tacorl_pr_head_compose": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_to_bf16_batch": (_i, [_i, _p, _p, _p, _p]),

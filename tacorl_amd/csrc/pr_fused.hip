@@ -27,6 +27,11 @@ constexpr int HB_P = 264;   // bf16 row pitch of one FFN hidden chunk
 constexpr int QKV_P = 100;  // fp32 row pitch of q|k|v
 
 struct PrLayerOff { long in_w, in_b, out_w, out_b, w1, b1, w2, b2, n1w, n1b, n2w, n2b; };
+// train mode (PlayLMP, no dropout): what the per-op backward (networks/plan_recognition.py) reads of a layer, written by this
+// launch in that path's layouts - batch-major rows r = b T + t, fp32: the layer input, q|k|v, the attention output, the
+// out-projection (pre-residual), LayerNorm-1 output and {mean, rstd}, the post-ReLU FFN hidden state, the FFN output
+// (pre-residual), LayerNorm-2 {mean, rstd}
+struct PrSaveL { float *xin, *qkv, *att, *proj, *x1, *ff1, *ff2, *st1, *st2; };
 struct PrArgs {
   const float* emb;     // [B*T][ld_emb], first 32 columns used
   const float* P;       // fp32 parameter block
@@ -43,6 +48,8 @@ struct PrArgs {
   float* plan;       // [B][A]   tanh(mean + eps * std)
   int A;
   float min_std;
+  PrSaveL sv[PR_MAXL];
+  int save;
 };
 
 __device__ __forceinline__ bf16x8 cvt8(const float* p) {
@@ -52,7 +59,7 @@ __device__ __forceinline__ bf16x8 cvt8(const float* p) {
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // LayerNorm over the 32 features of each row; v[nt][r] = feature 16 nt + 4 g + r of row i (lanes i, i+16, i+32, i+48)
-__device__ __forceinline__ void layer_norm32(f32x4 (&v)[2], const float* w, const float* b, int g) {
+__device__ __forceinline__ void layer_norm32(f32x4 (&v)[2], const float* w, const float* b, int g, float* st = nullptr) {
   float s = 0.f;
 #pragma unroll
   for (int nt = 0; nt < 2; nt++)
@@ -69,6 +76,7 @@ __device__ __forceinline__ void layer_norm32(f32x4 (&v)[2], const float* w, cons
   q += __shfl_xor(q, 16, 64);
   q += __shfl_xor(q, 32, 64);
   const float rstd = 1.0f / sqrtf(q / 32.f + 1e-5f);
+  if (st && g == 0) { st[0] = mean; st[1] = rstd; }
 #pragma unroll
   for (int nt = 0; nt < 2; nt++) {
     const f32x4 ww = *reinterpret_cast<const f32x4*>(w + 16 * nt + 4 * g), bb = *reinterpret_cast<const f32x4*>(b + 16 * nt + 4 * g);
@@ -118,8 +126,15 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
           bf16x4{(__bf16)v[nt][0], (__bf16)v[nt][1], (__bf16)v[nt][2], (__bf16)v[nt][3]};
   };
   const int nchunk = a.FF / PR_CH;
+  const bool sv0 = a.save && w == 0;  // (the attention half runs redundantly on all four waves: wave 0 writes the saves)
+  const long rrow = (long)b * PR_T + i;  // this lane's batch-major row
   for (int l = 0; l < a.L; l++) {
     const PrLayerOff& o = a.l[l];
+    const PrSaveL& S = a.sv[l];
+    if (sv0) {
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(S.xin + rrow * PR_D + 16 * nt + 4 * g) = x[nt];
+    }
     // ---- q|k|v = x Win^T + b  (6 N tiles, K = 32)
     put_xb(x);
     lds_sync();
@@ -131,6 +146,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
         f32x4 acc = *reinterpret_cast<const f32x4*>(a.P + o.in_b + 16 * nt + 4 * g);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc, 0, 0, 0);
         *reinterpret_cast<f32x4*>(qkv + i * QKV_P + 16 * nt + 4 * g) = acc;
+        if (sv0) *reinterpret_cast<f32x4*>(S.qkv + rrow * 3 * PR_D + 16 * nt + 4 * g) = acc;
       }
     }
     lds_sync();
@@ -160,6 +176,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
         for (int e = 0; e < 4; e++) ov[e] += pr * vv[e];
       }
       *reinterpret_cast<bf16x4*>(xb + qi * XB_P + PR_HD * h) = bf16x4{(__bf16)ov[0], (__bf16)ov[1], (__bf16)ov[2], (__bf16)ov[3]};
+      if (sv0) *reinterpret_cast<f32x4*>(S.att + ((long)b * PR_T + qi) * PR_D + PR_HD * h) = ov;
     }
     lds_sync();
     // ---- out-projection + residual + LayerNorm 1
@@ -170,9 +187,14 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
         const bf16x8 wf = cvt8(a.P + o.out_w + (long)(16 * nt + i) * PR_D + 8 * g);
         f32x4 acc = *reinterpret_cast<const f32x4*>(a.P + o.out_b + 16 * nt + 4 * g);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc, 0, 0, 0);
+        if (sv0) *reinterpret_cast<f32x4*>(S.proj + rrow * PR_D + 16 * nt + 4 * g) = acc;
         x[nt] += acc;
       }
-      layer_norm32(x, a.P + o.n1w, a.P + o.n1b, g);
+      layer_norm32(x, a.P + o.n1w, a.P + o.n1b, g, sv0 ? S.st1 + 2 * rrow : nullptr);
+      if (sv0) {
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(S.x1 + rrow * PR_D + 16 * nt + 4 * g) = x[nt];
+      }
     }
     lds_sync();  // every lane has read its out-projection operand before xb is overwritten
     put_xb(x);
@@ -200,8 +222,9 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
       for (int nt = 0; nt < 16; nt++) {
         f32x4 hacc = *reinterpret_cast<const f32x4*>(a.P + o.b1 + PR_CH * c + 16 * nt + 4 * g);
         hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[nt], xf, hacc, 0, 0, 0);
-        *reinterpret_cast<bf16x4*>(hb + i * HB_P + 16 * nt + 4 * g) =
-            bf16x4{(__bf16)fmaxf(hacc[0], 0.f), (__bf16)fmaxf(hacc[1], 0.f), (__bf16)fmaxf(hacc[2], 0.f), (__bf16)fmaxf(hacc[3], 0.f)};
+        const f32x4 hr = {fmaxf(hacc[0], 0.f), fmaxf(hacc[1], 0.f), fmaxf(hacc[2], 0.f), fmaxf(hacc[3], 0.f)};
+        *reinterpret_cast<bf16x4*>(hb + i * HB_P + 16 * nt + 4 * g) = bf16x4{(__bf16)hr[0], (__bf16)hr[1], (__bf16)hr[2], (__bf16)hr[3]};
+        if (a.save) *reinterpret_cast<f32x4*>(S.ff1 + rrow * a.FF + PR_CH * c + 16 * nt + 4 * g) = hr;  // (each wave its own chunks)
       }
       lds_sync();
       // the next chunk's W1 fragments travel while FFN2 runs
@@ -231,10 +254,11 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
         f32x4 t = *reinterpret_cast<const f32x4*>(ypart[l & 1][0] + i * PR_D + 16 * nt + 4 * g);
 #pragma unroll
         for (int ww = 1; ww < 4; ww++) t += *reinterpret_cast<const f32x4*>(ypart[l & 1][ww] + i * PR_D + 16 * nt + 4 * g);
+        if (sv0) *reinterpret_cast<f32x4*>(S.ff2 + rrow * PR_D + 16 * nt + 4 * g) = t;
         x[nt] += t;
       }
     }
-    layer_norm32(x, a.P + o.n2w, a.P + o.n2b, g);
+    layer_norm32(x, a.P + o.n2w, a.P + o.n2b, g, sv0 ? S.st2 + 2 * rrow : nullptr);
   }
   if (w != 0) return;  // every wave holds the same result: wave 0 writes it
   // ---- mean over the 16 time steps (lanes i = 0..15 of each g)
@@ -308,7 +332,7 @@ extern "C" int tacorl_pr_encoder_fused_supported(int D, int T, int H, int FF, in
 static int pr_encoder_fused_launch(const float* emb, int ld_emb, const float* params, const void* params_bf16,
                                    const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
                                    const float* Wc, const float* bc, const float* eps, float* head, float* plan, int A,
-                                   float min_std, tacorl_stream_t stream) {
+                                   float min_std, tacorl_stream_t stream, float* const* save = nullptr) {
   if (!tacorl_pr_encoder_fused_supported(D, T, H, FF, L) || ld_emb % 4 || B < 1) return TACORL_EINVAL;
   if (((uintptr_t)emb | (uintptr_t)params | (uintptr_t)params_bf16 | (uintptr_t)pooled) & 15) return TACORL_EINVAL;
   PrArgs a{};
@@ -324,8 +348,28 @@ static int pr_encoder_fused_launch(const float* emb, int ld_emb, const float* pa
     if (!bc || !eps || !head || !plan || A < 1 || 2 * A > 64 || ((uintptr_t)Wc & 15)) return TACORL_EINVAL;
     a.Wc = Wc; a.bc = bc; a.eps = eps; a.head = head; a.plan = plan; a.A = A; a.min_std = min_std;
   }
+  if (save) {
+    for (int l = 0; l < L; l++) {
+      float* const* q = save + 9 * l;
+      for (int k = 0; k < 9; k++)
+        if (!q[k] || ((uintptr_t)q[k] & 15)) return TACORL_EINVAL;
+      a.sv[l] = PrSaveL{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]};
+    }
+    a.save = 1;
+  }
   hipLaunchKernelGGL(pr_encoder_fused_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+/* The same launch in train mode (no dropout): also writes, per layer, what the per-op backward reads.  save[9 l + k], k = 0..8:
+ * layer input [B T][32], q|k|v [B T][96], attention output [B T][32], out-projection [B T][32], LayerNorm-1 output [B T][32],
+ * post-ReLU FFN hidden [B T][FF], FFN output [B T][32], LayerNorm-1 {mean, rstd} [B T][2], LayerNorm-2 {mean, rstd} [B T][2]
+ * (fp32, 16-byte aligned) - the tensors tacorl_linear_add_fwd / attention_fwd / add_layernorm_fwd leave behind. */
+extern "C" int tacorl_pr_encoder_fused_train(const float* emb, int ld_emb, const float* params, const void* params_bf16,
+                                             const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
+                                             float* const* save, tacorl_stream_t stream) {
+  if (!save) return TACORL_EINVAL;
+  return pr_encoder_fused_launch(emb, ld_emb, params, params_bf16, offsets, pooled, B, D, T, H, FF, L, nullptr, nullptr,
+                                 nullptr, nullptr, nullptr, 0, 0.f, stream, save);
 }
 extern "C" int tacorl_pr_encoder_fused(const float* emb, int ld_emb, const float* params, const void* params_bf16,
                                        const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,

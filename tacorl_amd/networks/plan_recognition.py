@@ -160,6 +160,34 @@ class PlanRecognition:
             self._lin(self.fc_out, self.FC, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.head, B, self.FC,
                       2 * self.A, ACT_NONE, compute)
             return self.head
+        if not inference and not drop and getattr(self, "fused_train", True) and self.fused_inference_ok(T, ld_emb, compute):
+            # train mode without dropout (bf16): the encoder layers + time pooling as ONE launch that also writes what the
+            # per-op backward below reads (layer inputs, q|k|v, attention / projection / FFN outputs, LayerNorm statistics)
+            # in the per-op forward's layouts - ~17 dependent launches of PlayLMP.training_step's chain become one
+            import ctypes as C
+            if getattr(self, "_pb", None) is None:
+                ops.note_alloc()
+                self._pb = torch.zeros(blk.param.numel(), device=self.dev, dtype=torch.bfloat16)
+                self._foff = (C.c_long * (1 + 12 * self.L))(*self._fused_offsets())
+                self._Wc = torch.zeros(2 * self.A, self.D, device=self.dev)
+                self._bc = torch.zeros(2 * self.A, device=self.dev)
+            call("tacorl_to_bf16_batch", 1, ops.ptr_array([blk.param]), ops.ptr_array([self._pb]),
+                 (C.c_long * 1)(blk.param.numel() // 4 * 4), ops.stream())
+            self._prep_version = None  # (the mirror is current, the composed inference head is not)
+            save = []
+            for l in range(self.L):
+                save += [self.x[2 * l], self.qkv[l], self.att[l], self.proj[l], self.x[2 * l + 1], self.ff1[l], self.ff2[l],
+                         self.stats[2 * l], self.stats[2 * l + 1]]
+            call("tacorl_pr_encoder_fused_train", ptr(emb), ld_emb, ptr(blk.param), ptr(self._pb), self._foff, ptr(self.pooled),
+                 B, D, T, self.H, self.FF, self.L, ops.ptr_array(save), ops.stream())
+            self._lin(self.pooled, D, blk.p("fc.weight"), blk.p("fc.bias"), self.fc_out, B, D, self.FC, ACT_NONE, compute)
+            self._lin(self.fc_out, self.FC, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.head, B, self.FC,
+                      2 * self.A, ACT_NONE, compute)
+            if sample is not None:
+                eps, plan = sample
+                call("tacorl_pr_sample", ptr(self.head), ptr(eps), ptr(plan), None, None, B, self.A, float(self.min_std),
+                     ops.stream())
+            return self.head
         call("tacorl_add_rows_bcast", ptr(emb), ld_emb, blk.p("position_embeddings.weight"), ptr(self.x[0]), R, T,
              self.D_in, D, ops.stream())
         if drop:

@@ -1000,6 +1000,60 @@ def test_plan_recognition_fused_encoder():
     assert e_mu < 5e-3 and e_sd < 5e-3, ("posterior vs oracle with bf16 operand rounding", e_mu, e_sd)
 
 
+def test_plan_recognition_fused_train_forward():
+    """Train-mode forward of the plan recognition as ONE launch (bf16, no dropout): every tensor it saves for the per-op
+    backward against what the per-op forward saves (same operand roundings; the FFN's fp32 summation order differs), the
+    posterior against the oracle with bf16 operand rounding, and the backward run on either set of saves gives the same
+    gradients."""
+    from oracle import tacorl_oracle as O
+    from tacorl_amd import ops
+    from tacorl_amd.networks.plan_recognition import PlanRecognition
+
+    dev = _dev()
+    B, T, D, A = 37, 16, 32, 16
+    pr = PlanRecognition(state_dim=D, latent_plan_dim=A, device=dev, num_heads=8, num_layers=2, encoder_hidden_size=2048,
+                         fc_hidden_size=4096, max_position_embeddings=T)
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for k, v in pr.blk.views.items():
+            if k.endswith("weight") and v.dim() == 2:
+                v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) / math.sqrt(v.shape[1]))
+            elif "norm" in k and k.endswith("weight"):
+                v.copy_(1 + 0.1 * torch.randn(v.shape, generator=g))
+            else:
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+    emb = rnd(B * T, D, seed=19).to(dev)
+    d_head = rnd(B, 2 * A, seed=20).to(dev)
+    saves = lambda: {"x": [t.clone() for t in pr.x[: 2 * pr.L]], "qkv": [t.clone() for t in pr.qkv],  # noqa: E731
+                     "att": [t.clone() for t in pr.att], "proj": [t.clone() for t in pr.proj],
+                     "ff1": [t.clone() for t in pr.ff1], "ff2": [t.clone() for t in pr.ff2],
+                     "stats": [t.clone() for t in pr.stats]}
+    res = {}
+    for fused in (False, True):
+        pr.fused_train = fused
+        for t in pr.x + pr.qkv + pr.att + pr.proj + pr.ff1 + pr.ff2 + pr.stats if pr._shape else []:
+            t.fill_(float("nan"))
+        head = pr.forward(emb, D, B, T, 1, train=True).clone()
+        sv = saves()
+        pr.blk.grad.zero_()
+        dx = pr.backward(d_head, B, T, 1).clone()
+        torch.cuda.synchronize()
+        res[fused] = (head, sv, dx, pr.blk.grad.clone())
+    (h0, s0, dx0, g0), (h1, s1, dx1, g1) = res[False], res[True]
+    for k in s0:
+        for l, (a, b) in enumerate(zip(s0[k], s1[k])):
+            assert torch.isfinite(b).all(), (k, l)
+            assert relerr(b, a) < 5e-3, (k, l, relerr(b, a))
+    assert relerr(h1, h0) < 5e-3, relerr(h1, h0)
+    assert relerr(dx1, dx0) < 1e-2 and relerr(g1, g0) < 1e-2, (relerr(dx1, dx0), relerr(g1, g0))
+    P = {k: v.detach().cpu() for k, v in pr.blk.views.items()}
+    with O.operand_rounding(torch.bfloat16):
+        mu, std = O.plan_recognition(P, "", emb.cpu().view(B, T, D), min_std=pr.min_std)
+    e_mu = relerr(h1[:, :A], mu)
+    e_sd = relerr(F.softplus(h1[:, A:]) + pr.min_std, std)
+    assert e_mu < 5e-3 and e_sd < 5e-3, ("posterior vs oracle with bf16 operand rounding", e_mu, e_sd)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.int64, torch.int32, torch.uint8, torch.bool])
 def test_stage_transition_dtypes(dt):
     """reward = done = float(disp == 1) for every disp dtype a dataloader may deliver, plus the action-window copy
