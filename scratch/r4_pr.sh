@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/r4pr; mkdir -p $O
 timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "plan_recognition" > $O/k.txt 2>&1; echo "rc=$?" >> $O/k.txt
-timeout 1200 python -m pytest tests/test_step_gpu.py tests/test_fullsize_gpu.py -x -q -m gpu -k "playlmp" > $O/t.txt 2>&1; echo "rc=$?" >> $O/t.txt
+timeout 1500 python -m pytest tests/test_step_gpu.py tests/test_fullsize_gpu.py -x -q -m gpu -k "playlmp or attention or layernorm or plan_rec or transformer" > $O/t.txt 2>&1; echo "rc=$?" >> $O/t.txt
 python - > $O/time.txt 2>&1 <<'PY'
 import sys, time, torch
 sys.path.insert(0, ".")

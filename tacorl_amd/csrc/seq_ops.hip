@@ -671,10 +671,77 @@ __global__ void attention_bwd_kernel(const float* __restrict__ qkv, const float*
   }
 }
 #undef ATT_W
+// The same backward for the configured plan recognition (T = 16 key / query positions, head_dim 4; plan_recognition_transformer.py:
+// d_model 32, 8 heads): 16 lanes per (sequence, head) pair - lane = query row in the first half, key / value row in the second -
+// four pairs per wave, operands staged once in LDS as 16-byte rows (the general kernel above runs 16 of 64 threads per block
+// through run-time loops over scalar global loads: 43 / 59 us at B = 32 / 256 on PlayLMP's dependent chain).
+__global__ __launch_bounds__(256) void attention_bwd_t16_kernel(const float* __restrict__ qkv, const float* __restrict__ d_out,
+                                                                float* __restrict__ d_qkv, int npairs, int D, int H,
+                                                                const unsigned char* __restrict__ keep, float ks) {
+  __shared__ __attribute__((aligned(16))) float rows[16][16 * 16];   // per pair: [row][q(4) | k(4) | v(4) | dO(4)]
+  __shared__ __attribute__((aligned(16))) float pm[16][2][16 * 17];  // per pair: p[r][j], ds[r][j] (pitch 17)
+  const int lp = threadIdx.x >> 4, i = threadIdx.x & 15, pair = blockIdx.x * 16 + lp;
+  const bool on = pair < npairs;
+  const int b = on ? pair / H : 0, h = on ? pair % H : 0;
+  const float* base = qkv + ((long)b * 16 + i) * 3 * D + 4 * h;
+  const f32x4 q = *reinterpret_cast<const f32x4*>(base), k = *reinterpret_cast<const f32x4*>(base + D),
+              v = *reinterpret_cast<const f32x4*>(base + 2 * D), dO = *reinterpret_cast<const f32x4*>(d_out + ((long)b * 16 + i) * D + 4 * h);
+  float* R = rows[lp];
+  *reinterpret_cast<f32x4*>(R + i * 16) = q * 0.5f;  // 1 / sqrt(head_dim)
+  *reinterpret_cast<f32x4*>(R + i * 16 + 4) = k;
+  *reinterpret_cast<f32x4*>(R + i * 16 + 8) = v;
+  *reinterpret_cast<f32x4*>(R + i * 16 + 12) = dO;
+  __syncthreads();
+  const unsigned char* kb = keep && on ? keep + (long)pair * 256 : nullptr;
+  const f32x4 qs = q * 0.5f;
+  float w[16], dp[16], mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const f32x4 kj = *reinterpret_cast<const f32x4*>(R + j * 16 + 4), vj = *reinterpret_cast<const f32x4*>(R + j * 16 + 8);
+    w[j] = ((qs[0] * kj[0] + qs[1] * kj[1]) + qs[2] * kj[2]) + qs[3] * kj[3];
+    dp[j] = ((dO[0] * vj[0] + dO[1] * vj[1]) + dO[2] * vj[2]) + dO[3] * vj[3];
+    if (kb) dp[j] *= kb[i * 16 + j] ? ks : 0.f;
+    mx = fmaxf(mx, w[j]);
+  }
+  float l = 0.f, dd = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; j++) { w[j] = expf(w[j] - mx); l += w[j]; dd += w[j] * dp[j]; }
+  dd /= l;
+  f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const float pj = w[j] / l, ds = pj * (dp[j] - dd);
+    const f32x4 kj = *reinterpret_cast<const f32x4*>(R + j * 16 + 4);
+    dq += ds * kj;
+    pm[lp][0][i * 17 + j] = kb ? pj * (kb[i * 16 + j] ? ks : 0.f) : pj;  // the (dropped) probability that multiplied v_j
+    pm[lp][1][i * 17 + j] = ds;
+  }
+  __syncthreads();
+  // this lane as key / value row i: dk_i = scale sum_r ds[r][i] q_r, dv_i = sum_r p[r][i] dO_r
+  f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const f32x4 qr = *reinterpret_cast<const f32x4*>(R + r * 16), dor = *reinterpret_cast<const f32x4*>(R + r * 16 + 12);
+    dk += pm[lp][1][r * 17 + i] * qr;   // (qr already carries the scale)
+    dv += pm[lp][0][r * 17 + i] * dor;
+  }
+  if (on) {
+    float* o = d_qkv + ((long)b * 16 + i) * 3 * D + 4 * h;
+    *reinterpret_cast<f32x4*>(o) = dq * 0.5f;
+    *reinterpret_cast<f32x4*>(o + D) = dk;
+    *reinterpret_cast<f32x4*>(o + 2 * D) = dv;
+  }
+}
 static int attention_bwd_launch(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int D, int H,
                                 const unsigned char* keep, float ks, tacorl_stream_t stream) {
   if (T > ATT_MAX_T || D % H || D / H > ATT_MAX_HD) return TACORL_EINVAL;
   if (B <= 0) return TACORL_OK;
+  if (T == 16 && D / H == 4 && D % 4 == 0 && !(((uintptr_t)qkv | (uintptr_t)d_out | (uintptr_t)d_qkv) & 15)) {
+    const int npairs = B * H;
+    hipLaunchKernelGGL(attention_bwd_t16_kernel, dim3((npairs + 15) / 16), dim3(256), 0, (hipStream_t)stream, qkv, d_out, d_qkv,
+                       npairs, D, H, keep, ks);
+    return LAUNCH_OK();
+  }
   hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, qkv, d_out, d_qkv, B, T, D, H, keep,
                      ks);
   return LAUNCH_OK();
@@ -732,14 +799,31 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
   }
 }
 // column sums of the [rows][2D] partial matrix: first D columns -> dw, last D -> db
-__global__ void colsum2_kernel(const float* __restrict__ in, int rows, int D, float* __restrict__ dw,
-                               float* __restrict__ db, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * D) return;
+// (256 threads per 64 columns: four row phases with eight independent loads in flight each, summed in fixed order - one
+// thread per column over 128 dependent-latency rows took 30 us, four times per PlayLMP step at B = 32)
+__global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ in, int rows, int D, float* __restrict__ dw,
+                                                      float* __restrict__ db, int accumulate) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int r = 0; r < rows; r++) s += in[(long)r * 2 * D + c];
-  float* o = c < D ? dw + c : db + (c - D);
-  *o = accumulate ? *o + s : s;
+  if (c < 2 * D) {
+    int r = ph;
+    for (; r + 28 < rows; r += 32) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = in[(long)(r + 4 * u) * 2 * D + c];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += t[u];
+    }
+    for (; r < rows; r += 4) s += in[(long)r * 2 * D + c];
+  }
+  part[ph][cl] = s;
+  __syncthreads();
+  if (ph == 0 && c < 2 * D) {
+    const float t = ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl];
+    float* o = c < D ? dw + c : db + (c - D);
+    *o = accumulate ? *o + t : t;
+  }
 }
 // first stage for tall partial matrices: block b sums rows [64 b, 64 b + 64) -> out[b][2D]
 __global__ void colsum2_stage_kernel(const float* __restrict__ in, int rows, int D, float* __restrict__ out) {
@@ -770,7 +854,7 @@ extern "C" int tacorl_add_layernorm_bwd(const float* dy, const float* x, const f
     hipLaunchKernelGGL(colsum2_stage_kernel, dim3(rows), dim3(2 * D), 0, (hipStream_t)stream, part, nb, D, p2);
     part = p2;
   }
-  hipLaunchKernelGGL(colsum2_kernel, dim3((2 * D + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, rows, D, dw, db,
+  hipLaunchKernelGGL(colsum2_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, rows, D, dw, db,
                      accumulate);
   return LAUNCH_OK();
 }

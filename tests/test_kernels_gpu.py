@@ -1153,3 +1153,40 @@ def test_action_decoder_frozen_bf16_hidden_sizes(H):
         assert torch.isfinite(res[tag]).all(), tag
     assert relerr(res["bf16_frozen"], res["bf16"]) < 1e-6
     assert relerr(res["bf16"], res["f32"]) < TOL_BF16
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+@pytest.mark.parametrize("B", [5, 40])
+def test_attention_fwd_bwd_t16(B, dropout):
+    """Multi-head self-attention core of the plan recognition (T = 16, 8 heads of 4: the 16-lanes-per-(sequence, head) backward
+    kernel) against torch autograd on the same q|k|v, with and without the keep mask on the attention probabilities."""
+    from tacorl_amd import _lib
+    from tacorl_amd._lib import call, ptr
+    from tacorl_amd import ops
+
+    dev = _dev()
+    T, D, H = 16, 32, 8
+    qkv = rnd(B * T, 3 * D, seed=31, scale=1.5)
+    d_out = rnd(B * T, D, seed=32)
+    keep = (torch.rand(B, H, T, T, generator=torch.Generator().manual_seed(33)) > 0.2) if dropout else None
+    ks = 1.0 / 0.8
+    q = qkv.clone().requires_grad_(True)
+    qq, kk, vv = (t.reshape(B, T, H, 4).transpose(1, 2) for t in q.split(D, dim=-1))
+    p = torch.softmax(qq @ kk.transpose(-1, -2) / 2.0, dim=-1)
+    if dropout:
+        p = p * keep.float() * ks
+    out = (p @ vv).transpose(1, 2).reshape(B * T, D)
+    (out * d_out).sum().backward()
+    qd, dd = qkv.to(dev), d_out.to(dev)
+    o = torch.full((B * T, D), float("nan"), device=dev)
+    dq = torch.full((B * T, 3 * D), float("nan"), device=dev)
+    if dropout:
+        kd = keep.to(torch.uint8).to(dev).contiguous()
+        call("tacorl_attention_dropout_fwd", ptr(qd), ptr(o), ptr(kd), ks, B, T, D, H, ops.stream())
+        call("tacorl_attention_dropout_bwd", ptr(qd), ptr(dd), ptr(dq), ptr(kd), ks, B, T, D, H, ops.stream())
+    else:
+        call("tacorl_attention_fwd", ptr(qd), ptr(o), B, T, D, H, ops.stream())
+        call("tacorl_attention_bwd", ptr(qd), ptr(dd), ptr(dq), B, T, D, H, ops.stream())
+    torch.cuda.synchronize()
+    assert relerr(o, out) < TOL_F32, relerr(o, out)
+    assert torch.isfinite(dq).all() and relerr(dq, q.grad) < TOL_F32, relerr(dq, q.grad)
