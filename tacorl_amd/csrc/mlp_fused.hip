@@ -22,7 +22,9 @@ constexpr int BMF = 32;   // rows per workgroup (these kernels are latency-bound
                           // workgroups with 32 rows, 104 with 64; measured with 16 waves: 16 rows 1.09-1.10,
                           // 32 rows 1.07, 64 rows 1.08-1.12 ms/step)
 constexpr int MTF = BMF / 16;
-constexpr int XP = 264;   // LDS row pitch (bf16): 528 B -> 16 consecutive rows hit distinct bank groups
+constexpr int XP = 272;   // LDS row pitch (bf16): 544 B = 34 x 16 B, 34 = 2 (mod 4) and even: the ds_read_b128 lane groups {0-3,12-15,20-27}, .. of a
+                          // 16-row fragment read land on 16 distinct 16-byte slots (264 - 33 slots per row - was read as conflict-free for two rounds;
+                          // PMC on the many-row forward: 45 % of the LDS-active cycles were bank conflicts)
 constexpr int MAXD = 256; // widest layer
 // 16 waves per workgroup, 16 output columns each (measured at the bench shapes, ms/step: 4 waves 1.183,
 // 8 waves 1.122, 16 waves 1.106)
