@@ -98,10 +98,11 @@ def time_encoder_in_step(mod, batch, steps=40):
     replays of the step, events on the stream the launch is issued on).  The chip holds a higher clock for a kernel
     that sits between the step's lighter phases than for 100 copies of it back to back - this is the duration the step
     pays.  An event bracket also contains the launch gaps on either side of the kernel; they are measured, not assumed:
-    right behind the encoder's bracket every step brackets ONE 1-thread time-mark launch (n1) and then TWO of them (n2).
-    n2 - n1 = one more tiny launch (its duration + its gap), so the bracket's own overhead is n1 - (n2 - n1) = 2 n1 - n2 and
-    kernel duration = encoder bracket - (2 n1 - n2).  No fitted constant (round 3 subtracted a calibrated 2.4 us); the
-    evidence for the figure is rocprofv3's kernel trace of the same command (profiles/).
+    right behind the encoder's bracket every step brackets a CALIBRATION kernel of about the same length - one thread that
+    spins on the device's constant 100 MHz clock for 120 us and records its own begin and end (tacorl_time_spin) - so
+    overhead = (event bracket around the spin) - (the spin's own duration), and kernel duration = encoder bracket - overhead.
+    No fitted constant (round 3 subtracted a calibrated 2.4 us from a 1-thread launch's bracket); the evidence for the
+    figure is rocprofv3's kernel trace of the same command (profiles/).
     Returns (kernel ms, raw bracket ms, bracket overhead ms)."""
     from tacorl_amd import ops
     from tacorl_amd._lib import call, ptr
@@ -110,18 +111,16 @@ def time_encoder_in_step(mod, batch, steps=40):
     if not all(e._fused_ok(c) for c in e.cams):
         return None
     pairs, orig, was_graph = [], e._launch_fused, mod._use_graph
-    mark = torch.zeros(8, dtype=torch.int64, device=mod.device)
+    marks = torch.zeros(2 * (steps + 8), dtype=torch.int64, device=mod.device)
+    spin_ticks = 12000  # 120 us at 100 MHz
 
     def timed(c, pr):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()
         orig(c, pr)
         ev[1].record()
-        call("tacorl_time_mark", ptr(mark), 0, ops.stream())
+        call("tacorl_time_spin", ptr(marks), 2 * len(pairs), spin_ticks, ops.stream())
         ev[2].record()
-        call("tacorl_time_mark", ptr(mark), 1, ops.stream())
-        call("tacorl_time_mark", ptr(mark), 2, ops.stream())
-        ev[3].record()
         pairs.append(ev)
 
     mod._use_graph = False
@@ -134,10 +133,12 @@ def time_encoder_in_step(mod, batch, steps=40):
         torch.cuda.synchronize()
     finally:
         e._launch_fused, mod._use_graph = orig, was_graph
-    raw = sum(ev[0].elapsed_time(ev[1]) for ev in pairs) / len(pairs)
-    n1 = sum(ev[1].elapsed_time(ev[2]) for ev in pairs) / len(pairs)
-    n2 = sum(ev[2].elapsed_time(ev[3]) for ev in pairs) / len(pairs)
-    over = min(max(2 * n1 - n2, 0.0), n1)
+    n = len(pairs)
+    raw = sum(ev[0].elapsed_time(ev[1]) for ev in pairs) / n
+    spin_bracket = sum(ev[1].elapsed_time(ev[2]) for ev in pairs) / n
+    m = marks[: 2 * n].cpu().view(n, 2)
+    spin_actual = float((m[:, 1] - m[:, 0]).double().mean()) * 1e-5  # 100 MHz ticks -> ms
+    over = min(max(spin_bracket - spin_actual, 0.0), raw)
     for _ in range(3):  # back on the captured path
         mod.training_step(batch)
     return raw - over, raw, over
@@ -749,8 +750,9 @@ def main():
                                     "[obs;goal], actor(next), both targets)") if fused else
                                    "LMPVisionEncoder forward, per-layer kernels (tacorl_encoder_fwd)",
                          "images_per_launch": n_img, "avg_ms": round(enc_ms, 4),
-                         "how": ("HIP events around the launch inside 40 training steps (eager replays of the step), "
-                                 "minus the bracket's launch gaps measured on a 1-thread launch right behind it"
+                         "how": ("HIP events around the launch inside 40 training steps (eager replays of the step), minus the "
+                                 "bracket's launch gaps, measured on a 120 us one-thread spin kernel that records its own "
+                                 "duration, bracketed right behind it"
                                  if (fused and enc_in_step is not None) else "HIP events over 100 back-to-back launches"),
                          "event_bracket_ms": round(enc_in_step[1], 4) if enc_in_step else None,
                          "event_overhead_ms": round(enc_in_step[2], 4) if enc_in_step else None,

@@ -32,6 +32,9 @@ int tacorl_hip_init(int device);             /* idempotent; checks the device is
 const char* tacorl_hip_last_error(void);
 /* tracing aid: marks[slot] = device wall clock (100 MHz ticks) when the stream reaches this point */
 int tacorl_time_mark(unsigned long long* marks, int slot, tacorl_stream_t stream);
+/* calibration aid: a 1-thread kernel that runs for `ticks` of that clock and stores its own begin / end in marks[slot],
+ * marks[slot + 1] - an event bracket around it minus that difference is the bracket's overhead for a kernel of that length */
+int tacorl_time_spin(unsigned long long* marks, int slot, long ticks, tacorl_stream_t stream);
 
 /* ---- primitives ------------------------------------------------------------------ */
 /* y = act(x W^T + b), optional pre-activation z.  Replaces nn.Linear (+F.silu / nn.ReLU):

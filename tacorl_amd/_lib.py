@@ -25,6 +25,7 @@ _SIGS = {
     "tacorl_hip_init": (_i, [_i]),
     "tacorl_hip_last_error": (C.c_char_p, []),
     "tacorl_time_mark": (_i, [_p, _i, _p]),
+    "tacorl_time_spin": (_i, [_p, _i, _l, _p]),
     "tacorl_linear_fwd": (_i, [_i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "tacorl_linear_add_fwd_ws_bytes": (_sz, [_i, _p, _i, _i]),
     "tacorl_linear_add_fwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _sz, _p]),

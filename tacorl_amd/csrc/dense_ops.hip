@@ -43,6 +43,21 @@ extern "C" int tacorl_time_mark(unsigned long long* marks, int slot, tacorl_stre
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
+// Calibration aid for event brackets: a 1-thread kernel that runs for `ticks` of that clock and records its own begin and
+// end (marks[slot], marks[slot + 1]).  A HIP-event bracket around it reads its duration PLUS the bracket's launch gaps, so
+// bracket - (marks[slot + 1] - marks[slot]) is the overhead of a bracket around a kernel of that length (bench.py).
+__global__ void time_spin_kernel(unsigned long long* marks, int slot, unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  marks[slot] = t0;
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  marks[slot + 1] = wall_clock64();
+}
+extern "C" int tacorl_time_spin(unsigned long long* marks, int slot, long ticks, tacorl_stream_t stream) {
+  if (!marks || slot < 0 || ticks < 0 || ticks > 100000000L) FAIL(TACORL_EINVAL, "time_spin: bad arguments");
+  hipLaunchKernelGGL(time_spin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, marks, slot, (unsigned long long)ticks);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
 static inline long al4(long x) { return (x + 3) & ~3L; }
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
