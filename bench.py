@@ -706,9 +706,10 @@ def main():
         pr = run_segment_probe(a.dtype)
         c2, c3 = pr.get("c2_b256", {}), pr.get("c3_b32", {})
         configs["c2_three_segment"] = dict(c2, rccl=pr.get("rccl_libraries_mapped"), error=pr.get("error"),
-                                           note="ms/step at B=256: the collective-free single graph (= the headline form), the "
-                                                "N-GPU default (3 graph segments, 2 eager RCCL all-reduces between them) and the "
-                                                "one-graph form with the all-reduces as graph nodes; world_size 1, same process")
+                                           note="ms/step at B=256: the collective-free single graph (= the headline form), 3 graph "
+                                                "segments with 2 eager RCCL all-reduces between them (the only form gloo can run) and the "
+                                                "one-graph form with the all-reduces as graph nodes (the N-GPU default with backend nccl); "
+                                                "world_size 1, same process")
         configs["c3_strong_share_b32"] = dict(c3, note="C3 (decoder fine-tuning) at B=32 = its per-GPU share of a global batch of "
                                                        "256 on 8 GPUs, same three forms")
         for _ in range(3):
