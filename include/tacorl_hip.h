@@ -66,6 +66,15 @@ int tacorl_rnn_linear_fwd_batch(int nprob, const void* const* x_bf16, const void
                                 const float* const* bias, const float* const* addend, int ld_add,
                                 float* const* y, void* const* y_bf16, int M, int K, int N, const int* acts,
                                 tacorl_stream_t stream);
+/* tacorl_rnn_linear_fwd_batch with twin rows: problem p additionally computes y2[p] = act(x2[p] W[p]^T + b[p] + addend2[p])
+ * for M2 more rows held in other buffers - the same weights, read once (every problem of the launch carries twin rows).
+ * PlayLMP.training_step: the logging-only random-plan pass of the action decoder (reference play_lmp_for_rl.py:243-252)
+ * rides in the launches of the real pass. */
+int tacorl_rnn_linear_fwd_batch_twin(int nprob, const void* const* x_bf16, const void* const* x2_bf16,
+                                     const void* const* w_bf16, const float* const* bias, const float* const* addend,
+                                     const float* const* addend2, int ld_add, float* const* y, float* const* y2,
+                                     void* const* y_bf16, void* const* y2_bf16, int M, int M2, int K, int N,
+                                     const int* acts, tacorl_stream_t stream);
 /* BPTT step of the same RNN: y = (x Wt^T + addend) * [mask_src > 0], x = dZ_t (bf16), Wt = W_hh^T (bf16,
  * tacorl_transpose_to_bf16), addend = dH_{t-1}, mask_src = h_{t-1}; y fp32 + bf16 copy (next step's x). */
 int tacorl_rnn_linear_bwd_step(const void* x_bf16, const void* wt_bf16, const float* addend, int ld_add,
@@ -381,6 +390,17 @@ int tacorl_pr_encoder_fused_sample(const float* emb, int ld_emb, const float* pa
 int tacorl_pr_encoder_fused_train(const float* emb, int ld_emb, const float* params, const void* params_bf16,
                                   const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
                                   float* const* save, tacorl_stream_t stream);
+/* Train-mode backward of the same encoder: the input-gradient chain of all layers in ONE launch (+ one small reduce), from
+ * d_pool [B][32] (gradient of the time-pooled output) to dx [B T][32] (gradient of the position-embedded input).
+ * saved[9 l + k]: what tacorl_pr_encoder_fused_train wrote.  dz[4 l + k], k = 0..3, outputs - the dZ operands of the per-op
+ * weight-gradient GEMMs: LayerNorm-2 input gradient [B T][32] (linear2), masked hidden gradient [B T][FF] (linear1),
+ * LayerNorm-1 input gradient [B T][32] (out_proj), d(q|k|v) [B T][96] (in_proj).  wt[2 l + {0, 1}]: linear1.weight^T
+ * [32][FF], linear2.weight^T [FF][32] as bf16 (tacorl_transpose_to_bf16).  ln_part: scratch of L * 2 * B * 64 floats;
+ * ln_grads[4 l + k]: norm1.weight, norm1.bias, norm2.weight, norm2.bias gradients (written, not accumulated).
+ * Reference: autograd through plan_recognition_transformer.py:70-88 (nn.TransformerEncoderLayer, post-norm, ReLU). */
+int tacorl_pr_encoder_bwd_fused(const float* params, const long* offsets, const float* d_pool, float* dx,
+                                const float* const* saved, float* const* dz, const void* const* wt, float* ln_part,
+                                float* const* ln_grads, int B, int D, int T, int H, int FF, int L, tacorl_stream_t stream);
 int tacorl_pr_head_compose(const float* w_fc, const float* b_fc, const float* w_head, const float* b_head,
                            float* Wc, float* bc, int D, int FC, int A2, tacorl_stream_t stream);
 int tacorl_mean_over_t(const float* x, float* out, int B, int T, int D, tacorl_stream_t stream);

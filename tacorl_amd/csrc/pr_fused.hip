@@ -295,6 +295,285 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward (train mode)
+// The input-gradient chain of the same encoder in ONE launch (round 4): from the gradient of the time-pooled output back to
+// the gradient of the position-embedded input, through both layers - LayerNorm 2, FFN (the 2048-wide hidden gradient in
+// 256-column chunks split over the four waves, masked by the saved post-ReLU hidden state), LayerNorm 1, out-projection,
+// the 8-head attention, in-projection - reading what tacorl_pr_encoder_fused_train saved.  As per-op launches this chain
+// was ~9 dependent launches per layer (LayerNorm backward + column sums, two FFN input-gradient GEMMs - one split-K with
+// its reduce -, out-projection, attention, in-projection) on PlayLMP.training_step's critical path.  The weight gradients
+// stay per-op GEMMs on the caller's side stream: this launch writes their dZ operands (LayerNorm-2 / LayerNorm-1 input
+// gradients, the masked hidden gradient, d(q|k|v)) and per-sequence partial sums of the LayerNorm weight / bias gradients
+// (pr_ln_reduce_kernel adds them up in batch order).  Same structure as the forward: one workgroup per sequence,
+// activations in registers in the MFMA D layout, the cheap parts redundantly on all four waves, one barrier per layer.
+// The FFN needs W1^T [32][FF] and W2^T [FF][32] as bf16 (tacorl_transpose_to_bf16, weights only); the 32 x 32 / 96 x 32
+// projection matrices are gathered transposed from the fp32 block.
+constexpr int DQ_P = 104;  // bf16 row pitch of d(q|k|v) as the in-projection's MFMA B operand (208 B)
+struct PrBwdL {
+  const float *xin, *qkv, *att, *proj, *x1, *ff1, *ff2, *st1, *st2;  // saved by the train-mode forward
+  float *dvb, *d_ff1, *dv1b, *d_qkv;                                  // dZ operands of the weight-gradient GEMMs
+  const __bf16 *w1t, *w2t;                                            // W1^T [32][FF], W2^T [FF][32]
+};
+struct PrBwdArgs {
+  const float* P;
+  const float* d_pool;  // [B][32]
+  float* dx;            // [B*T][32]
+  float* lnpart;        // [L][2][B][64]: per-sequence (dw | db) partials of LayerNorm 1 / 2
+  PrLayerOff l[PR_MAXL];
+  PrBwdL s[PR_MAXL];
+  int B, FF, L;
+};
+
+// LayerNorm(xa + xr) backward for this lane's 8 features of row i; dy in / dv out in the D layout; part: [64] (dw | db)
+// partial of this sequence (written by the lanes i == 0), or null
+__device__ __forceinline__ void ln_bwd32(const f32x4 (&dy)[2], const float* xa, const float* xr, const float* st, const float* w,
+                                         long rrow, int i, int g, f32x4 (&dv)[2], float* part) {
+  const float mean = st[2 * rrow], rstd = st[2 * rrow + 1];
+  f32x4 xh[2], gv[2];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) {
+    const long o = rrow * PR_D + 16 * nt + 4 * g;
+    const f32x4 u = *reinterpret_cast<const f32x4*>(xa + o) + *reinterpret_cast<const f32x4*>(xr + o);
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(w + 16 * nt + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      xh[nt][r] = (u[r] - mean) * rstd;
+      gv[nt][r] = dy[nt][r] * ww[r];
+      s1 += gv[nt][r];
+      s2 += gv[nt][r] * xh[nt][r];
+    }
+  }
+  s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+  s1 *= (1.f / 32.f); s2 *= (1.f / 32.f);
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) dv[nt][r] = rstd * (gv[nt][r] - s1 - xh[nt][r] * s2);
+  if (part) {  // sums over the 16 rows (lanes i) of dy * xhat and dy, per feature
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float gw = dy[nt][r] * xh[nt][r], gb = dy[nt][r];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { gw += __shfl_xor(gw, off, 64); gb += __shfl_xor(gb, off, 64); }
+        if (i == 0) { part[16 * nt + 4 * g + r] = gw; part[32 + 16 * nt + 4 * g + r] = gb; }
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void pr_encoder_bwd_fused_kernel(PrBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 xb_s[4][PR_T * XB_P];
+  __shared__ __attribute__((aligned(16))) unsigned char big_s[4][PR_T * HB_P * 2];  // q|k|v (fp32) or hidden-gradient chunk (bf16)
+  __shared__ __attribute__((aligned(16))) float datt_s[4][PR_T * 36];
+  __shared__ __attribute__((aligned(16))) float pm_s[4][4][2][PR_T * 17];            // per wave: 4 heads x (p, ds)
+  __shared__ __attribute__((aligned(16))) __bf16 dqb_s[4][PR_T * DQ_P];
+  __shared__ __attribute__((aligned(16))) float ypart[2][4][PR_T * PR_D];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+  if (b >= a.B) return;
+  __bf16* xb = xb_s[w];
+  float* qkv = reinterpret_cast<float*>(big_s[w]);
+  __bf16* hb = reinterpret_cast<__bf16*>(big_s[w]);
+  float* datt = datt_s[w];
+  __bf16* dqb = dqb_s[w];
+  const bool sv0 = w == 0;
+  const long rrow = (long)b * PR_T + i;
+  const int nchunk = a.FF / PR_CH;
+  auto put_xb = [&](const f32x4 (&v)[2]) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+      *reinterpret_cast<bf16x4*>(xb + i * XB_P + 16 * nt + 4 * g) =
+          bf16x4{(__bf16)v[nt][0], (__bf16)v[nt][1], (__bf16)v[nt][2], (__bf16)v[nt][3]};
+  };
+  // gradient of the mean over time: every row takes d_pool / T
+  f32x4 dx[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) dx[nt] = *reinterpret_cast<const f32x4*>(a.d_pool + (long)b * PR_D + 16 * nt + 4 * g) * (1.0f / PR_T);
+  for (int l = a.L - 1; l >= 0; l--) {
+    const PrLayerOff& o = a.l[l];
+    const PrBwdL& S = a.s[l];
+    float* lp = a.lnpart + ((long)(2 * l) * a.B + b) * 64;  // LayerNorm 1 partial of this sequence; LayerNorm 2: + B * 64
+    // ---- LayerNorm 2: y = LN(x1 + ff2)
+    f32x4 dv[2];
+    ln_bwd32(dx, S.x1, S.ff2, S.st2, a.P + o.n2w, rrow, i, g, dv, sv0 ? lp + (long)a.B * 64 : nullptr);
+    if (sv0) {
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(S.dvb + rrow * PR_D + 16 * nt + 4 * g) = dv[nt];
+    }
+    // ---- FFN: d_hidden = (dv W2) * [hidden > 0] in 256-column chunks (written out for linear1's weight gradient),
+    //      d_x1 += d_hidden W1
+    put_xb(dv);
+    lds_sync();
+    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + i * XB_P + 8 * g);
+    f32x4 y[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int c = w; c < nchunk; c += 4) {
+      bf16x8 w1tf[8][2];
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+          w1tf[ks][nt] = *reinterpret_cast<const bf16x8*>(S.w1t + (long)(16 * nt + i) * a.FF + PR_CH * c + 32 * ks + 8 * g);
+#pragma unroll
+      for (int nt = 0; nt < 16; nt++) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(S.w2t + (long)(PR_CH * c + 16 * nt + i) * PR_D + 8 * g);
+        const long ho = rrow * a.FF + PR_CH * c + 16 * nt + 4 * g;
+        const f32x4 hm = *reinterpret_cast<const f32x4*>(S.ff1 + ho);  // post-ReLU hidden state: the mask
+        f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
+        hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, hacc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) hacc[r] = hm[r] > 0.f ? hacc[r] : 0.f;
+        *reinterpret_cast<f32x4*>(S.d_ff1 + ho) = hacc;
+        *reinterpret_cast<bf16x4*>(hb + i * HB_P + 16 * nt + 4 * g) = bf16x4{(__bf16)hacc[0], (__bf16)hacc[1], (__bf16)hacc[2], (__bf16)hacc[3]};
+      }
+      lds_sync();
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hb + i * HB_P + 32 * ks + 8 * g);
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) y[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1tf[ks][nt], hf, y[nt], 0, 0, 0);
+      }
+      lds_sync();
+    }
+    f32x4 dx1[2];
+    {
+      float* yp = ypart[l & 1][w];
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(yp + i * PR_D + 16 * nt + 4 * g) = y[nt];
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(ypart[l & 1][0] + i * PR_D + 16 * nt + 4 * g);
+#pragma unroll
+        for (int ww = 1; ww < 4; ww++) t += *reinterpret_cast<const f32x4*>(ypart[l & 1][ww] + i * PR_D + 16 * nt + 4 * g);
+        dx1[nt] = dv[nt] + t;  // (the residual: LayerNorm 2's input is x1 + ff2)
+      }
+    }
+    // ---- LayerNorm 1: x1 = LN(xin + proj)
+    f32x4 dv1[2];
+    ln_bwd32(dx1, S.xin, S.proj, S.st1, a.P + o.n1w, rrow, i, g, dv1, sv0 ? lp : nullptr);
+    if (sv0) {
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(S.dv1b + rrow * PR_D + 16 * nt + 4 * g) = dv1[nt];
+    }
+    // ---- out-projection: d_att = dv1 Wo  (Wo^T gathered from the fp32 block: 32 x 32)
+    put_xb(dv1);
+    lds_sync();
+    {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(xb + i * XB_P + 8 * g);
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        bf16x8 wf;
+#pragma unroll
+        for (int q = 0; q < 8; q++) wf[q] = (__bf16)a.P[o.out_w + (long)(8 * g + q) * PR_D + 16 * nt + i];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc, 0, 0, 0);
+        *reinterpret_cast<f32x4*>(datt + i * 36 + 16 * nt + 4 * g) = acc;
+      }
+    }
+    // the saved q|k|v of this sequence -> LDS (16 rows x 96 floats: six 16-byte pieces per lane)
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int e = lane + 64 * k, row = e / 24, c4 = e - row * 24;
+      *reinterpret_cast<f32x4*>(qkv + row * QKV_P + 4 * c4) = *reinterpret_cast<const f32x4*>(S.qkv + ((long)b * PR_T + row) * 3 * PR_D + 4 * c4);
+    }
+    lds_sync();
+    // ---- attention backward: four heads per pass, lane = (head, row)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int hl = lane >> 4, h = 4 * j + hl, qi = lane & 15;
+      float* pp = pm_s[w][hl][0];
+      float* pd = pm_s[w][hl][1];
+      f32x4 qs = *reinterpret_cast<const f32x4*>(qkv + qi * QKV_P + PR_HD * h);
+      qs *= 0.5f;  // 1 / sqrt(head_dim)
+      const f32x4 dO = *reinterpret_cast<const f32x4*>(datt + qi * 36 + PR_HD * h);
+      float ws_[PR_T], dp[PR_T], mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < PR_T; t++) {
+        const f32x4 kt = *reinterpret_cast<const f32x4*>(qkv + t * QKV_P + PR_D + PR_HD * h);
+        const f32x4 vt = *reinterpret_cast<const f32x4*>(qkv + t * QKV_P + 2 * PR_D + PR_HD * h);
+        ws_[t] = ((qs[0] * kt[0] + qs[1] * kt[1]) + qs[2] * kt[2]) + qs[3] * kt[3];
+        dp[t] = ((dO[0] * vt[0] + dO[1] * vt[1]) + dO[2] * vt[2]) + dO[3] * vt[3];
+        mx = fmaxf(mx, ws_[t]);
+      }
+      float se = 0.f, dd = 0.f;
+#pragma unroll
+      for (int t = 0; t < PR_T; t++) { ws_[t] = expf(ws_[t] - mx); se += ws_[t]; dd += ws_[t] * dp[t]; }
+      dd /= se;
+      f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < PR_T; t++) {
+        const float pj = ws_[t] / se, ds = pj * (dp[t] - dd);
+        const f32x4 kt = *reinterpret_cast<const f32x4*>(qkv + t * QKV_P + PR_D + PR_HD * h);
+        dq += ds * kt;
+        pp[qi * 17 + t] = pj;
+        pd[qi * 17 + t] = ds;
+      }
+      lds_sync();
+      // this lane as key / value row qi: dk = scale sum_r ds[r][qi] q_r, dv = sum_r p[r][qi] dO_r
+      f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dvv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < PR_T; r++) {
+        f32x4 qr = *reinterpret_cast<const f32x4*>(qkv + r * QKV_P + PR_HD * h);
+        const f32x4 dor = *reinterpret_cast<const f32x4*>(datt + r * 36 + PR_HD * h);
+        qr *= 0.5f;
+        dk += pd[r * 17 + qi] * qr;
+        dvv += pp[r * 17 + qi] * dor;
+      }
+      dq *= 0.5f;
+      if (sv0) {
+        float* dst = S.d_qkv + ((long)b * PR_T + qi) * 3 * PR_D + PR_HD * h;
+        *reinterpret_cast<f32x4*>(dst) = dq;
+        *reinterpret_cast<f32x4*>(dst + PR_D) = dk;
+        *reinterpret_cast<f32x4*>(dst + 2 * PR_D) = dvv;
+      }
+      __bf16* db_ = dqb + qi * DQ_P + PR_HD * h;
+      *reinterpret_cast<bf16x4*>(db_) = bf16x4{(__bf16)dq[0], (__bf16)dq[1], (__bf16)dq[2], (__bf16)dq[3]};
+      *reinterpret_cast<bf16x4*>(db_ + PR_D) = bf16x4{(__bf16)dk[0], (__bf16)dk[1], (__bf16)dk[2], (__bf16)dk[3]};
+      *reinterpret_cast<bf16x4*>(db_ + 2 * PR_D) = bf16x4{(__bf16)dvv[0], (__bf16)dvv[1], (__bf16)dvv[2], (__bf16)dvv[3]};
+      lds_sync();  // (p / ds of this pass consumed before the next pass overwrites them; d(q|k|v) visible)
+    }
+    // ---- in-projection: dx = d(q|k|v) Win + dv1  (K = 96; Win^T gathered from the fp32 block)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+      f32x4 acc = dv1[nt];
+#pragma unroll
+      for (int ks = 0; ks < 3; ks++) {
+        const bf16x8 df = *reinterpret_cast<const bf16x8*>(dqb + i * DQ_P + 32 * ks + 8 * g);
+        bf16x8 wf;
+#pragma unroll
+        for (int q = 0; q < 8; q++) wf[q] = (__bf16)a.P[o.in_w + (long)(32 * ks + 8 * g + q) * PR_D + 16 * nt + i];
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, df, acc, 0, 0, 0);
+      }
+      dx[nt] = acc;
+    }
+    lds_sync();  // every lane has read its operands before the next layer overwrites xb / the scratch buffers
+  }
+  if (sv0) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(a.dx + rrow * PR_D + 16 * nt + 4 * g) = dx[nt];
+  }
+}
+
+// LayerNorm weight / bias gradients: sum the per-sequence partials in batch order.  grid = 2 L blocks of 256 threads:
+// thread = (column 0..63, row phase 0..3); out[blockIdx.x] -> (dw, db) pointers of that LayerNorm.
+struct PrLnReduceArgs { const float* part; float* dw[2 * PR_MAXL]; float* db[2 * PR_MAXL]; int B; };
+__global__ __launch_bounds__(256) void pr_ln_reduce_kernel(PrLnReduceArgs a) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const float* in = a.part + (long)blockIdx.x * a.B * 64;
+  float s = 0.f;
+  for (int r = ph; r < a.B; r += 4) s += in[(long)r * 64 + c];
+  red[ph][c] = s;
+  __syncthreads();
+  if (ph == 0) {
+    const float t = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+    if (c < 32) a.dw[blockIdx.x][c] = t; else a.db[blockIdx.x][c - 32] = t;
+  }
+}
+
 // Wc = W_head W_fc ([2A][D]), bc = W_head b_fc + b_head: the two bias-only Linear layers after the time pooling
 // (fc: D -> FC, mean_fc: FC -> 2A, no activation between them) are one affine map.  Weights only, so it runs off
 // the dependent chain; fixed reduction order (deterministic).  grid = 2A blocks of 256 threads, D = 32.
@@ -390,5 +669,45 @@ extern "C" int tacorl_pr_head_compose(const float* w_fc, const float* b_fc, cons
   if (D != PR_D || FC < 1 || A2 < 1 || !w_fc || !b_fc || !w_head || !b_head || !Wc || !bc) return TACORL_EINVAL;
   hipLaunchKernelGGL(pr_head_compose_kernel, dim3(A2), dim3(256), 0, (hipStream_t)stream, w_fc, b_fc, w_head, b_head, Wc, bc,
                      FC);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
+/* Train-mode backward of the same encoder: the whole input-gradient chain in ONE launch (+ one small reduce), from the
+ * gradient of the time-pooled output d_pool [B][32] to dx [B T][32].  saved[9 l + k]: what tacorl_pr_encoder_fused_train
+ * wrote; dz[4 l + k], k = 0..3: outputs for the per-op weight-gradient GEMMs - LayerNorm-2 input gradient [B T][32]
+ * (linear2's dZ), the masked hidden gradient [B T][FF] (linear1's dZ), LayerNorm-1 input gradient [B T][32] (out-proj's
+ * dZ), d(q|k|v) [B T][96] (in-proj's dZ); wt[2 l + {0,1}]: W1^T [32][FF], W2^T [FF][32] as bf16 (tacorl_transpose_to_bf16);
+ * ln_part: scratch of L * 2 * B * 64 floats; ln_grads[4 l + k]: norm1.weight, norm1.bias, norm2.weight, norm2.bias gradients.
+ * Reference: autograd through plan_recognition_transformer.py:70-88 (nn.TransformerEncoderLayer, post-norm, ReLU). */
+extern "C" int tacorl_pr_encoder_bwd_fused(const float* params, const long* offsets, const float* d_pool, float* dx,
+                                           const float* const* saved, float* const* dz, const void* const* wt,
+                                           float* ln_part, float* const* ln_grads, int B, int D, int T, int H, int FF, int L,
+                                           tacorl_stream_t stream) {
+  if (!tacorl_pr_encoder_fused_supported(D, T, H, FF, L) || B < 1) return TACORL_EINVAL;
+  if (!params || !d_pool || !dx || !saved || !dz || !wt || !ln_part || !ln_grads) return TACORL_EINVAL;
+  if (((uintptr_t)params | (uintptr_t)d_pool | (uintptr_t)dx | (uintptr_t)ln_part) & 15) return TACORL_EINVAL;
+  PrBwdArgs a{};
+  PrLnReduceArgs r{};
+  a.P = params; a.d_pool = d_pool; a.dx = dx; a.lnpart = ln_part; a.B = B; a.FF = FF; a.L = L;
+  r.part = ln_part; r.B = B;
+  for (int l = 0; l < L; l++) {
+    const long* q = offsets + 1 + 12 * l;
+    for (int k = 0; k < 12; k++)
+      if (q[k] % 4) return TACORL_EINVAL;
+    a.l[l] = PrLayerOff{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]};
+    const float* const* sv = saved + 9 * l;
+    float* const* z = dz + 4 * l;
+    for (int k = 0; k < 9; k++)
+      if (!sv[k] || ((uintptr_t)sv[k] & 15)) return TACORL_EINVAL;
+    for (int k = 0; k < 4; k++)
+      if (!z[k] || ((uintptr_t)z[k] & 15) || !ln_grads[4 * l + k]) return TACORL_EINVAL;
+    if (!wt[2 * l] || !wt[2 * l + 1] || (((uintptr_t)wt[2 * l] | (uintptr_t)wt[2 * l + 1]) & 15)) return TACORL_EINVAL;
+    a.s[l] = PrBwdL{sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7], sv[8], z[0], z[1], z[2], z[3],
+                    (const __bf16*)wt[2 * l], (const __bf16*)wt[2 * l + 1]};
+    r.dw[2 * l] = ln_grads[4 * l]; r.db[2 * l] = ln_grads[4 * l + 1];
+    r.dw[2 * l + 1] = ln_grads[4 * l + 2]; r.db[2 * l + 1] = ln_grads[4 * l + 3];
+  }
+  hipLaunchKernelGGL(pr_encoder_bwd_fused_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(pr_ln_reduce_kernel, dim3(2 * L), dim3(256), 0, (hipStream_t)stream, r);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }

@@ -34,6 +34,14 @@ struct RnnArgs {
   float* y;
   __bf16* yb;
   int M, K, N, ld_add, act;
+  // optional twin rows: M2 more rows of the same problem (same W, bias, act) whose activations live in other buffers -
+  // rows M .. M + M2 - 1 of the tile grid read x2 / addend2 and write y2 / yb2 (PlayLMP: the logging-only random-plan
+  // pass of the action decoder rides in the real pass's launches; at B = 32 the two fill one 64-row tile)
+  const __bf16* x2;
+  const float* addend2;
+  float* y2;
+  __bf16* yb2;
+  int M2;
 };
 
 // One RB_M x RB_N output tile per workgroup (4 waves stacked along M), RB_S-stage ring.
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(64 * NW) void rnn_gemm_kernel(RnnBatch ab, int MT, 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
   const int m0 = mt * RB_M, n0 = ntile * RB_N;
-  const int nk = a.K / RB_K;
+  const int nk = a.K / RB_K, mtot = a.M + a.M2;
 
   auto issue = [&](int kt, int slot) {
     unsigned char* base = lds + slot * STAGE_BYTES;
@@ -70,8 +78,9 @@ __global__ __launch_bounds__(64 * NW) void rnn_gemm_kernel(RnnBatch ab, int MT, 
     for (int q = 0; q < DMA_PER_WAVE; q++) {
       const int row4 = (w + NW * q) * 4;  // first of the 4 rows this wave-instruction fills
       const int r = row4 + (lane >> 4), cpos = lane & 15, c = cpos ^ (r & 15);
-      const int xm = m0 + r < a.M ? m0 + r : a.M - 1;  // rows past M are loaded (clamped) but never stored
-      const __bf16* src = (r < RB_M ? a.x + (long)xm * a.K : a.w + (long)(n0 + r - RB_M) * a.K) + kt * RB_K + c * 8;
+      const int xm = m0 + r < mtot ? m0 + r : mtot - 1;  // rows past the last one are loaded (clamped) but never stored
+      const __bf16* xrow = xm < a.M ? a.x + (long)xm * a.K : a.x2 + (long)(xm - a.M) * a.K;
+      const __bf16* src = (r < RB_M ? xrow : a.w + (long)(n0 + r - RB_M) * a.K) + kt * RB_K + c * 8;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + row4 * ROW_BYTES), 16, 0, 0);
     }
@@ -116,23 +125,28 @@ __global__ __launch_bounds__(64 * NW) void rnn_gemm_kernel(RnnBatch ab, int MT, 
   }
 #pragma unroll
   for (int mi = 0; mi < MI; mi++) {
-    const int m = m0 + arow + 16 * mi;
-    if (m >= a.M) continue;
+    int m = m0 + arow + 16 * mi;
+    if (m >= mtot) continue;
+    const bool twin = m >= a.M;
+    if (twin) m -= a.M;
+    const float* addend = twin ? a.addend2 : a.addend;
+    float* y = twin ? a.y2 : a.y;
+    __bf16* yb = twin ? a.yb2 : a.yb;
 #pragma unroll
     for (int nt = 0; nt < NI; nt++) {
       const int n = n0 + 16 * nt + 4 * g;
       f32x4 z = acc[mi][nt];
       if (a.bias) z += *reinterpret_cast<const f32x4*>(a.bias + n);
-      if (a.addend) z += *reinterpret_cast<const f32x4*>(a.addend + (long)m * a.ld_add + n);
+      if (addend) z += *reinterpret_cast<const f32x4*>(addend + (long)m * a.ld_add + n);
 #pragma unroll
       for (int r = 0; r < 4; r++) z[r] = act_apply(a.act, z[r]);
-      if (a.mask_src) {
+      if (a.mask_src && !twin) {
         const f32x4 ms = *reinterpret_cast<const f32x4*>(a.mask_src + (long)m * a.N + n);
 #pragma unroll
         for (int r = 0; r < 4; r++) z[r] = ms[r] > 0.f ? z[r] : 0.f;
       }
-      *reinterpret_cast<f32x4*>(a.y + (long)m * a.N + n) = z;
-      if (a.yb) *reinterpret_cast<bf16x4*>(a.yb + (long)m * a.N + n) = bf16x4{(__bf16)z[0], (__bf16)z[1], (__bf16)z[2], (__bf16)z[3]};
+      *reinterpret_cast<f32x4*>(y + (long)m * a.N + n) = z;
+      if (yb) *reinterpret_cast<bf16x4*>(yb + (long)m * a.N + n) = bf16x4{(__bf16)z[0], (__bf16)z[1], (__bf16)z[2], (__bf16)z[3]};
     }
   }
 }
@@ -146,7 +160,7 @@ int launch_ring(const RnnBatch& ab, int nprob, hipStream_t st) {
                             hipSuccess ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
   const RnnArgs& a = ab.p[0];
-  const int MT = (a.M + RB_M - 1) / RB_M, NT = a.N / RB_N, NTX = (NT + 7) / 8;
+  const int MT = (a.M + a.M2 + RB_M - 1) / RB_M, NT = a.N / RB_N, NTX = (NT + 7) / 8;
   hipLaunchKernelGGL(kern, dim3(8 * MT * NTX * nprob), dim3(64 * NW), lds, st, ab, MT, NT, NTX);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
@@ -377,11 +391,12 @@ extern "C" int tacorl_transpose_to_bf16(const float* src, void* dst, int R, int 
  * 2-stage ring (48 KB of LDS per workgroup, so the workgroups of three problems are co-resident on a CU):
  * the wavefront schedule of a stacked RNN - recurrent steps of both layers and the upper layer's input
  * projection of the next step - as T + 2(L-1) launches instead of L*T + L. */
-extern "C" int tacorl_rnn_linear_fwd_batch(int nprob, const void* const* x_bf16, const void* const* w_bf16,
-                                           const float* const* bias, const float* const* addend, int ld_add,
-                                           float* const* y, void* const* y_bf16, int M, int K, int N, const int* acts,
-                                           tacorl_stream_t stream) {
-  if (nprob < 1 || nprob > RNN_MAXP || !tacorl_rnn_linear_supported(M, K, N) || ld_add % 4) return TACORL_EINVAL;
+static int rnn_fwd_batch(int nprob, const void* const* x_bf16, const void* const* w_bf16, const float* const* bias,
+                         const float* const* addend, int ld_add, float* const* y, void* const* y_bf16, int M, int K, int N,
+                         const int* acts, const void* const* x2_bf16, const float* const* addend2, float* const* y2,
+                         void* const* y2_bf16, int M2, tacorl_stream_t stream) {
+  if (nprob < 1 || nprob > RNN_MAXP || !tacorl_rnn_linear_supported(M, K, N) || ld_add % 4 || M2 < 0) return TACORL_EINVAL;
+  if (M2 > 0 && (!x2_bf16 || !y2)) return TACORL_EINVAL;
   RnnBatch ab{};
   for (int p = 0; p < nprob; p++) {
     const float* ad = addend ? addend[p] : nullptr;
@@ -390,6 +405,18 @@ extern "C" int tacorl_rnn_linear_fwd_batch(int nprob, const void* const* x_bf16,
     if (((uintptr_t)x_bf16[p] | (uintptr_t)w_bf16[p] | (uintptr_t)y[p] | (uintptr_t)bi | (uintptr_t)ad) & 15) return TACORL_EINVAL;
     if ((uintptr_t)yb & 7) return TACORL_EINVAL;
     ab.p[p] = RnnArgs{(const __bf16*)x_bf16[p], (const __bf16*)w_bf16[p], bi, ad, nullptr, y[p], (__bf16*)yb, M, K, N, ld_add, acts[p]};
+    if (M2 > 0 && x2_bf16[p]) {  // (a problem without twin rows: x2[p] == NULL)
+      const float* ad2 = addend2 ? addend2[p] : nullptr;
+      void* yb2 = y2_bf16 ? y2_bf16[p] : nullptr;
+      if (!y2[p] || (((uintptr_t)x2_bf16[p] | (uintptr_t)y2[p] | (uintptr_t)ad2) & 15) || ((uintptr_t)yb2 & 7)) return TACORL_EINVAL;
+      ab.p[p].x2 = (const __bf16*)x2_bf16[p]; ab.p[p].addend2 = ad2; ab.p[p].y2 = y2[p]; ab.p[p].yb2 = (__bf16*)yb2;
+      ab.p[p].M2 = M2;
+    }
+  }
+  if (M2 > 0) {  // the tile grid is sized by the first problem: give every problem of the launch the same row count
+    for (int p = 0; p < nprob; p++)
+      if (ab.p[p].M2 != M2) return TACORL_EINVAL;
+    M += M2;     // (tile choice below: by the rows of the launch)
   }
   // 128 x 64 tiles, 8 waves (two per SIMD): the launch itself takes as long as with 64 x 32 tiles and 4 waves
   // (20 us for three problems; a third stage changes nothing), but it is 192 workgroups instead of 768 and the
@@ -404,6 +431,31 @@ extern "C" int tacorl_rnn_linear_fwd_batch(int nprob, const void* const* x_bf16,
   const char* se = getenv("TACORL_RNN_SMALL_UPTO");
   const int small_upto = se ? atoi(se) : 2;  // problems per launch up to which the small tile is used
   if (nprob <= small_upto && M % 64 == 0 && N % 32 == 0) return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
+  {
+    // twin launches of >= 512 rows: three problems as 128 x 64 tiles are 384 workgroups of 96 KB LDS - one and a half
+    // rounds over the chip; as 128 x 128 tiles they are 192, each streaming 1 MB instead of 768 KB for twice the outputs
+    const char* tw = getenv("TACORL_RNN_TWIN_WIDE");
+    if (M2 > 0 && (tw ? atoi(tw) : 1) && nprob > 2 && M >= 512 && M % 128 == 0 && N % 128 == 0)
+      return launch_ring<128, 128, 2, 8>(ab, nprob, (hipStream_t)stream);
+  }
   if (M % 128 == 0 && N % 64 == 0) return launch_ring<128, 64, 2, 8>(ab, nprob, (hipStream_t)stream);
   return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
+}
+extern "C" int tacorl_rnn_linear_fwd_batch(int nprob, const void* const* x_bf16, const void* const* w_bf16,
+                                           const float* const* bias, const float* const* addend, int ld_add,
+                                           float* const* y, void* const* y_bf16, int M, int K, int N, const int* acts,
+                                           tacorl_stream_t stream) {
+  return rnn_fwd_batch(nprob, x_bf16, w_bf16, bias, addend, ld_add, y, y_bf16, M, K, N, acts, nullptr, nullptr, nullptr, nullptr, 0,
+                       stream);
+}
+/* The same launch with twin rows: every problem p additionally computes y2[p] = act(x2[p] W[p]^T + b[p] + addend2[p]) for M2
+ * more rows whose activations live in other buffers - same weights, one pass over them (PlayLMP.training_step: the
+ * logging-only random-plan pass of the action decoder, play_lmp_for_rl.py:243-252, rides in the real pass's launches). */
+extern "C" int tacorl_rnn_linear_fwd_batch_twin(int nprob, const void* const* x_bf16, const void* const* x2_bf16,
+                                                const void* const* w_bf16, const float* const* bias,
+                                                const float* const* addend, const float* const* addend2, int ld_add,
+                                                float* const* y, float* const* y2, void* const* y_bf16, void* const* y2_bf16,
+                                                int M, int M2, int K, int N, const int* acts, tacorl_stream_t stream) {
+  return rnn_fwd_batch(nprob, x_bf16, w_bf16, bias, addend, ld_add, y, y_bf16, M, K, N, acts, x2_bf16, addend2, y2, y2_bf16, M2,
+                       stream);
 }

@@ -361,16 +361,33 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     s_rand, s_pp, s_wg = self._branch if getattr(self, "branches", True) else [main] * 3  # tests switch the branches off
     # logging-only pass with a uniform random plan (reference :243-252) - before the real pass, whose activations
     # are the ones the backward sees (the decoder's buffers are shared: the real pass waits for this branch)
+    # Where the ring-GEMM path runs (bf16), the random-plan pass is not a pass of its own: its rows ride in the launches of
+    # the real pass (same weights, read once - ActionDecoderLogistic.twin_*); only its input projection and its loss
+    # stay on the branch.
+    twin = None
     s_rand.wait_stream(main)
     with torch.cuda.stream(s_rand):
         call("tacorl_uniform_actions", ptr(self.noise["u_plan"]), ptr(self.rplan), A, B, A, 0, ops.stream())
-        ad.forward(self.rplan, self.emb, Ec, B, T, T - 1, cd)
-        ad.loss(acts, ops._at(self.logs, 4), B, T, T - 1, want_grad=False)
+        if ad.twin_ok(B, cd):
+            twin = ad.twin_input_proj(self.rplan, self.emb, Ec, B, T, T - 1)
+        else:
+            ad.forward(self.rplan, self.emb, Ec, B, T, T - 1, cd)
+            ad.loss(acts, ops._at(self.logs, 4), B, T, T - 1, want_grad=False)
     ops.copy_cols(self.emb, (T - 1) * Ec, T * Ec, self.gin, 0, Ec, B, Ec)  # pp_goal input = emb[:, -1]
-    ops.mlp_fwd([self.gin], Ec, [net.genc()], [self.gact], [B], net.genc_dims, net.genc_acts, cd)
+    # bf16 mode: the goal encoder and the plan proposal's policy head run as the single-launch MLP kernels (forward, input
+    # gradients, weight gradients) on a bf16 mirror of their weights, as in the actor-critic engine.  (Per layer they are 7
+    # generic GEMM launches on this chain: hidden behind the random-plan decoder pass while that was a pass of its own -
+    # no gain then -, on the critical path since it rides in the real pass.)
+    pb_g = pb_h = None
+    if cd == BF16 and getattr(self, "fused_mlps", True):
+        import ctypes as C
+        call("tacorl_to_bf16_batch", 1, ops.ptr_array([net.genc()]), ops.ptr_array([net.genc_bf16()]),
+             (C.c_long * 1)(net.size - net.genc_off), ops.stream())
+        pb_g, pb_h = [net.genc_bf16()], [net.head_bf16()]
+    ops.mlp_fwd([self.gin], Ec, [net.genc()], [self.gact], [B], net.genc_dims, net.genc_acts, cd, params_bf16=pb_g)
     ops.copy_cols(self.emb, 0, T * Ec, self.S, 0, 2 * Ec, B, Ec)  # pp_state = emb[:, 0]
     ops.copy_cols(self.gact, self.g_yoff, Ec, self.S, Ec, 2 * Ec, B, Ec)
-    ops.mlp_fwd([self.S], 2 * Ec, [net.head()], [self.pact], [B], net.head_dims, net.head_acts, cd)
+    ops.mlp_fwd([self.S], 2 * Ec, [net.head()], [self.pact], [B], net.head_dims, net.head_acts, cd, params_bf16=pb_h)
     head_pp = self.pact[self.p_yoff: self.p_yoff + B * 2 * A]
     head_pr = pr.forward(self.emb, Ec, B, T, cd, train=getattr(self, "_pr_train", False))
     call("tacorl_gauss_kl_balanced", ptr(head_pr), ptr(head_pp), ptr(self.d_head_pr), ptr(self.d_head_pp), B, A,
@@ -379,14 +396,26 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     # plan proposal backward (needs only the KL's gradient): its own branch; d_emb gets its share after the join
     s_pp.wait_stream(main)
     with torch.cuda.stream(s_pp):
-        ops.mlp_bwd([self.S], 2 * Ec, [net.head()], [self.pact], [self.d_head_pp], 2 * A, [net.head(net.grad)], [self.dS],
-                    2 * Ec, [B], net.head_dims, net.head_acts, cd)
-        ops.mlp_bwd([self.gin], Ec, [net.genc()], [self.gact], [ops._at(self.dS, Ec)], 2 * Ec, [net.genc(net.grad)],
-                    [self.dgin], Ec, [B], net.genc_dims, net.genc_acts, cd)
+        def mlp_backward(tag, x, ldx, par, act, d_out, ldo, grad, d_x, ldd, dims, acts):
+            if pb_g is not None and ops.mlp_bwd_fused_ok(1, dims, ldo, ldd, cd):
+                ops.mlp_bwd_fused_dgrad([par], [act], [d_out], ldo, [d_x], ldd, [B], dims, acts, "plmp_" + tag)
+                ops.mlp_bwd_fused_wgrad([x], ldx, [act], [d_out], ldo, [grad], [B], dims, acts, "plmp_" + tag)
+            else:
+                ops.mlp_bwd([x], ldx, [par], [act], [d_out], ldo, [grad], [d_x], ldd, [B], dims, acts, cd, ws_tag="plmp_" + tag)
+
+        mlp_backward("pp", self.S, 2 * Ec, net.head(), self.pact, self.d_head_pp, 2 * A, net.head(net.grad), self.dS, 2 * Ec,
+                     net.head_dims, net.head_acts)
+        mlp_backward("genc", self.gin, Ec, net.genc(), self.gact, ops._at(self.dS, Ec), 2 * Ec, net.genc(net.grad), self.dgin, Ec,
+                     net.genc_dims, net.genc_acts)
     call("tacorl_pr_sample", ptr(head_pr), ptr(self.noise["eps_plan"]), ptr(self.plan), None, None, B, A,
          float(pr.min_std), ops.stream())
     main.wait_stream(s_rand)
-    ad.forward(self.plan, self.emb, Ec, B, T, T - 1, cd, mirrors_current=True)  # (the random-plan pass refreshed the bf16 mirrors)
+    # (mirrors_current: a random-plan pass of its own has refreshed the bf16 mirrors of the weights)
+    ad.forward(self.plan, self.emb, Ec, B, T, T - 1, cd, mirrors_current=twin is None, twin=twin)
+    if twin is not None:
+        s_rand.wait_stream(main)
+        with torch.cuda.stream(s_rand):
+            ad.loss(acts, ops._at(self.logs, 4), B, T, T - 1, want_grad=False, twin=twin)
     ad.loss(acts, ops._at(self.logs, 2), B, T, T - 1, want_grad=True, grad_scale=gs)
     if self.add_random_plan_loss:
         raise NotImplementedError("add_random_plan_loss=True is not used by any in-scope config")
@@ -410,6 +439,7 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
         ops.encoder_bwd([self.frames[c]], [net.enc(c)], [self.f_act[c]], [self.f_dout[c]], [net.enc(c, net.grad)], H, W, cd,
                         fused=fused)
     main.wait_stream(s_wg)
+    main.wait_stream(s_rand)
 
 
 def _named_gradients(self):

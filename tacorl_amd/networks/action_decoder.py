@@ -131,6 +131,37 @@ class ActionDecoderLogistic:
         self.headw_b, self.headb = bf(self.NHP, H), f(self.NHP)    # output heads, rows padded with zeros
         self._shape = (B, Tm)
 
+    # ------------------------------------------------------------------ twin pass (logging-only second plan)
+    def twin_ok(self, B, compute):
+        """A second, logging-only pass (other plan, same frames, same weights) can ride in the launches of forward():
+        the ring-GEMM path with the fused input projection (bf16)."""
+        H, K = self.hidden, self.P + self.E
+        return (compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H)) and 32 <= K <= 64
+                and K % 8 == 0 and H % 16 == 0 and getattr(self, "fused_input_proj", True) and getattr(self, "twin_pass", True))
+
+    def twin_state(self, B, Tm):
+        """Activation buffers of the twin pass (the weights and their bf16 mirrors are this decoder's)."""
+        tw = getattr(self, "_twin", None)
+        if tw is None or tw.shape != (B, Tm):
+            ops.note_alloc()
+            self._ensure(B, Tm)
+            R, H = B * Tm, self.hidden
+            f = lambda *s: torch.zeros(*s, device=self.dev)  # noqa: E731
+            bf = lambda *s: torch.zeros(*s, device=self.dev, dtype=torch.bfloat16)  # noqa: E731
+            tw = self._twin = type("TwinPass", (), {})()
+            tw.shape = (B, Tm)
+            tw.xin, tw.h, tw.hb = [f(R, H) for _ in range(self.L)], [f(R, H) for _ in range(self.L)], [bf(R, H) for _ in range(self.L)]
+            tw.heads = f(R, self.NHP)
+            tw.ws = torch.empty(self.ws.numel(), dtype=torch.uint8, device=self.dev)
+        return tw
+
+    def twin_input_proj(self, plan, emb, ld_emb, B, T, Tm):
+        """Layer-0 input projection of the twin pass (reads the fp32 weights: may run before forward(), on another stream)."""
+        tw, blk = self.twin_state(B, Tm), self.blk
+        call("tacorl_ad_input_proj", ptr(plan), ptr(emb), ld_emb, blk.p("rnn.weight_ih_l0"), blk.p("rnn.bias_ih_l0"),
+             ptr(tw.xin[0]), B, T, Tm, self.P, self.E, self.hidden, ops.stream())
+        return tw
+
     def _lin(self, x, ldx, w, b, y, M, K, N, act, compute, ldy=None):
         # split-K capable entry (skinny outputs with a long K: linear2 2048->32, the 2048->182 heads)
         nb = ops.L.lib().tacorl_linear_add_fwd_ws_bytes(1, ops.int_array([M]), K, N)
@@ -139,11 +170,13 @@ class ActionDecoderLogistic:
              ops.ptr_array([y]), N if ldy is None else ldy, ops.int_array([M]), K, N, act, compute, ptr(ws), ws.numel(),
              ops.stream())
 
-    def forward(self, plan, emb, ld_emb, B, T, Tm, compute, frozen=False, mirrors_current=False):
+    def forward(self, plan, emb, ld_emb, B, T, Tm, compute, frozen=False, mirrors_current=False, twin=None):
         """plan (B,P); emb [B*T][ld_emb] batch-major frame embeddings; uses steps t < Tm.  Fills self.heads.
         frozen=True: the caller never steps these weights with the library's optimiser kernels, so the bf16
         copies of the weight matrices are refreshed only when the block's torch version counter moved
-        (load_state_dict / copy_)."""
+        (load_state_dict / copy_).
+        twin: a twin_state() whose layer-0 projection has been issued (twin_input_proj) - its recurrent steps and heads
+        are computed as extra rows of this pass's launches (twin_ok() must hold); fills twin.heads."""
         self._ensure(B, Tm)
         blk, H, R = self.blk, self.hidden, B * Tm
         x, K = self.x_seq, self.P + self.E
@@ -181,19 +214,31 @@ class ActionDecoderLogistic:
             else:
                 self._lin(x, K, blk.p("rnn.weight_ih_l0"), blk.p("rnn.bias_ih_l0"), self.xin[0], R, K, H, ACT_NONE, compute)
             L = self.L
-            hbp = lambda l, t: C.c_void_p(self.hb[l].data_ptr() + 2 * t * B * H)  # noqa: E731
+            assert twin is None or (proj_fused and twin.shape == (B, Tm)), "twin pass: twin_ok() / twin_state(B, Tm)"
+            hbp = lambda l, t, o=self: C.c_void_p(o.hb[l].data_ptr() + 2 * t * B * H)  # noqa: E731
             for s_ in range(Tm + 2 * (L - 1)):
                 xs, wt, bs, ad, ys, yb, ac = [], [], [], [], [], [], []
+                x2, ad2, y2, yb2 = [], [], [], []
                 for l in range(L):
                     t = s_ - 2 * l
                     if 0 <= t < Tm:  # h_l[t] = relu(W_hh h_l[t-1] + b_hh + xin_l[t])
                         xs.append(ptr(self.h0b) if t == 0 else hbp(l, t - 1)); wt.append(ptr(self.whb[l]))
                         bs.append(blk.p(f"rnn.bias_hh_l{l}")); ad.append(at(self.xin[l], t * B * H))
                         ys.append(at(self.h[l], t * B * H)); yb.append(hbp(l, t)); ac.append(ACT_RELU)
+                        if twin is not None:
+                            x2.append(ptr(self.h0b) if t == 0 else hbp(l, t - 1, twin)); ad2.append(at(twin.xin[l], t * B * H))
+                            y2.append(at(twin.h[l], t * B * H)); yb2.append(hbp(l, t, twin))
                     t = s_ - 2 * l + 1
                     if l >= 1 and 0 <= t < Tm:  # xin_l[t] = W_ih h_{l-1}[t] + b_ih
                         xs.append(hbp(l - 1, t)); wt.append(ptr(self.wib[l])); bs.append(blk.p(f"rnn.bias_ih_l{l}"))
                         ad.append(None); ys.append(at(self.xin[l], t * B * H)); yb.append(None); ac.append(ACT_NONE)
+                        if twin is not None:
+                            x2.append(hbp(l - 1, t, twin)); ad2.append(None); y2.append(at(twin.xin[l], t * B * H)); yb2.append(None)
+                if twin is not None:
+                    call("tacorl_rnn_linear_fwd_batch_twin", len(xs), ops.ptr_array(xs), ops.ptr_array(x2), ops.ptr_array(wt),
+                         ops.ptr_array(bs), ops.ptr_array(ad), ops.ptr_array(ad2), H, ops.ptr_array(ys), ops.ptr_array(y2),
+                         ops.ptr_array(yb), ops.ptr_array(yb2), B, B, H, H, ops.int_array(ac), ops.stream())
+                    continue
                 call("tacorl_rnn_linear_fwd_batch", len(xs), ops.ptr_array(xs), ops.ptr_array(wt), ops.ptr_array(bs),
                      ops.ptr_array(ad), H, ops.ptr_array(ys), ops.ptr_array(yb), B, H, H, ops.int_array(ac), ops.stream())
             x, K = self.h[L - 1], H
@@ -213,18 +258,24 @@ class ActionDecoderLogistic:
                      (C.c_long * 1)(self.NH * H), ops.stream())
                 ob = blk.off["mean_fc.bias"][0]  # the four heads' biases sit back to back
                 self.headb[: self.NH].copy_(blk.param[ob: ob + self.NH])
+            if twin is not None:
+                call("tacorl_rnn_linear_fwd_batch_twin", 1, ops.ptr_array([self.hb[self.L - 1]]), ops.ptr_array([twin.hb[self.L - 1]]),
+                     ops.ptr_array([self.headw_b]), ops.ptr_array([self.headb]), None, None, 0, ops.ptr_array([self.heads]),
+                     ops.ptr_array([twin.heads]), None, None, R, R, H, self.NHP, ops.int_array([ACT_NONE]), ops.stream())
+                return
             call("tacorl_rnn_linear_fwd", ptr(self.hb[self.L - 1]), ptr(self.headw_b), ptr(self.headb), None, 0,
                  ptr(self.heads), None, R, H, self.NHP, ACT_NONE, ops.stream())
         else:
             self._lin(x, H, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.heads, R, H, self.NH, ACT_NONE, compute,
                       ldy=self.NHP)
 
-    def loss(self, actions, loss_out, B, T, Tm, want_grad, grad_scale=1.0):
+    def loss(self, actions, loss_out, B, T, Tm, want_grad, grad_scale=1.0, twin=None):
         """actions: device [B][T][Da+1]; writes the scalar loss to loss_out (device float) and, if
-        want_grad, dL/dheads into self.d_heads."""
-        call("tacorl_logistic_mixture_loss", ptr(self.heads), self.NHP, ptr(actions), ptr(self.d_heads) if want_grad else None,
+        want_grad, dL/dheads into self.d_heads.  twin: the loss of that twin pass's heads instead (no gradient)."""
+        heads, ws = (self.heads, self.ws) if twin is None else (twin.heads, twin.ws)
+        call("tacorl_logistic_mixture_loss", ptr(heads), self.NHP, ptr(actions), ptr(self.d_heads) if want_grad and twin is None else None,
              loss_out, B, T, Tm, self.Da, self.K, self.num_classes, float(self.gripper_alpha), float(grad_scale),
-             ptr(self.ws), self.ws.numel(), ops.stream())
+             ptr(ws), ws.numel(), ops.stream())
 
     def loss_step(self, module, actions, plan, B, T, optimize, frozen=False, defer_update=False):
         """TACORL.compute_action_decoder_update (reference tacorl.py:206-233): loss on emb[:, :-1],

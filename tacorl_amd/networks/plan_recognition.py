@@ -180,6 +180,7 @@ class PlanRecognition:
                          self.stats[2 * l], self.stats[2 * l + 1]]
             call("tacorl_pr_encoder_fused_train", ptr(emb), ld_emb, ptr(blk.param), ptr(self._pb), self._foff, ptr(self.pooled),
                  B, D, T, self.H, self.FF, self.L, ops.ptr_array(save), ops.stream())
+            self._fused_saved = (B, T)  # (backward may take the fused chain: every saved tensor is in the fused layout)
             self._lin(self.pooled, D, blk.p("fc.weight"), blk.p("fc.bias"), self.fc_out, B, D, self.FC, ACT_NONE, compute)
             self._lin(self.fc_out, self.FC, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.head, B, self.FC,
                       2 * self.A, ACT_NONE, compute)
@@ -188,6 +189,7 @@ class PlanRecognition:
                 call("tacorl_pr_sample", ptr(self.head), ptr(eps), ptr(plan), None, None, B, self.A, float(self.min_std),
                      ops.stream())
             return self.head
+        self._fused_saved = None
         call("tacorl_add_rows_bcast", ptr(emb), ld_emb, blk.p("position_embeddings.weight"), ptr(self.x[0]), R, T,
              self.D_in, D, ops.stream())
         if drop:
@@ -274,10 +276,59 @@ class PlanRecognition:
             with torch.cuda.stream(wgrad_stream):
                 fn()
 
+        fused = (getattr(self, "_fused_saved", None) == (B, T) and getattr(self, "fused_backward", True)
+                 and not getattr(self, "_dropping", False))
+        wt_ready = None
+        if fused:
+            # W1^T / W2^T as bf16 for the fused chain: weights only, so beside the head's input gradients
+            if getattr(self, "_wt", None) is None or self._lnpart.numel() != self.L * 2 * B * 64:
+                ops.note_alloc()
+                self._wt = [torch.zeros(FF * D, device=self.dev, dtype=torch.bfloat16) for _ in range(2 * self.L)]
+                self._lnpart = torch.zeros(self.L * 2 * B * 64, device=self.dev)
+            main = torch.cuda.current_stream()
+
+            def transposes():
+                for l in range(self.L):
+                    p = f"transformer_encoder.layers.{l}."
+                    call("tacorl_transpose_to_bf16", blk.p(p + "linear1.weight"), ptr(self._wt[2 * l]), FF, D, ops.stream())
+                    call("tacorl_transpose_to_bf16", blk.p(p + "linear2.weight"), ptr(self._wt[2 * l + 1]), D, FF, ops.stream())
+            side(transposes)
+            if wgrad_stream is not None:
+                wt_ready = torch.cuda.Event()
+                wt_ready.record(wgrad_stream)
         side(lambda: self._wgrad(self.fc_out, FC, d_head, A2, B, FC, A2, blk.g("mean_fc.weight"), blk.g("mean_fc.bias"), compute))
         self._dgrad(d_head, A2, blk.p("mean_fc.weight"), self.d_fc, FC, B, A2, FC, compute)
         side(lambda: self._wgrad(self.pooled, D, self.d_fc, FC, B, D, FC, blk.g("fc.weight"), blk.g("fc.bias"), compute))
         self._dgrad(self.d_fc, FC, blk.p("fc.weight"), self.d_pool, D, B, FC, D, compute)
+        if fused:
+            # the whole input-gradient chain of the encoder layers in one launch (csrc/pr_fused.hip); the weight gradients
+            # stay per-op GEMMs on the side stream and read the dZ operands that launch wrote
+            main.wait_event(wt_ready) if wt_ready is not None else None
+            saved, dz, lng = [], [], []
+            for l in range(self.L):
+                p = f"transformer_encoder.layers.{l}."
+                saved += [self.x[2 * l], self.qkv[l], self.att[l], self.proj[l], self.x[2 * l + 1], self.ff1[l], self.ff2[l],
+                          self.stats[2 * l], self.stats[2 * l + 1]]
+                dz += [self.dv[l], self.d_ff1[l], self.dv1[l], self.d_qkv[l]]
+                lng += [blk.g(p + "norm1.weight"), blk.g(p + "norm1.bias"), blk.g(p + "norm2.weight"), blk.g(p + "norm2.bias")]
+            call("tacorl_pr_encoder_bwd_fused", ptr(blk.param), self._foff, ptr(self.d_pool), ptr(self.dx),
+                 ops.ptr_array(saved), ops.ptr_array(dz), ops.ptr_array(self._wt), ptr(self._lnpart), ops.ptr_array(lng),
+                 B, D, T, self.H, FF, self.L, ops.stream())
+
+            def wgrads():
+                for l in reversed(range(self.L)):
+                    p = f"transformer_encoder.layers.{l}."
+                    self._wgrad(self.ff1[l], FF, self.dv[l], D, R, FF, D, blk.g(p + "linear2.weight"), blk.g(p + "linear2.bias"), compute)
+                    self._wgrad(self.x[2 * l + 1], D, self.d_ff1[l], FF, R, D, FF, blk.g(p + "linear1.weight"), blk.g(p + "linear1.bias"), compute)
+                    self._wgrad(self.att[l], D, self.dv1[l], D, R, D, D, blk.g(p + "self_attn.out_proj.weight"),
+                                blk.g(p + "self_attn.out_proj.bias"), compute)
+                    self._wgrad(self.x[2 * l], D, self.d_qkv[l], 3 * D, R, D, 3 * D, blk.g(p + "self_attn.in_proj_weight"),
+                                blk.g(p + "self_attn.in_proj_bias"), compute)
+            side(wgrads)
+            call("tacorl_reduce_rows_mod", ptr(self.dx), D, blk.g("position_embeddings.weight"), D, T, D, B, ops.stream())
+            if self.T_max > T:
+                blk.grad_views["position_embeddings.weight"][T:].zero_()
+            return self.dx
         call("tacorl_bcast_over_t", ptr(self.d_pool), ptr(self.dx), B, T, D, 1.0 / T, 0, ops.stream())
         # train mode: the forward dropped ff2 / ff1 / proj / attention probabilities / embeddings in place (the saved
         # buffers ARE the dropped values, so the weight gradients and the fused ReLU mask see what the next layer saw);

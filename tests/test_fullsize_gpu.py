@@ -368,6 +368,46 @@ def test_playlmp_branches_equal_serial(graph):
         assert torch.equal(pa[k], pb[k]), k
 
 
+@pytest.mark.parametrize("B", [32, 64])
+def test_playlmp_twin_pass_equals_own_pass(B):
+    """PlayLMP.training_step (bf16, graph): the logging-only random-plan decoder pass as twin rows of the real pass's
+    launches against a pass of its own - same weights, same inputs, the same per-element accumulation order in the ring
+    GEMM: every log (random_plan_* included), every gradient and the stepped weights agree bit for bit."""
+    import bench
+    from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
+
+    dev = torch.device("cuda:0")
+    T, cams = 16, ["rgb_static"]
+    actor = {"policy": {"num_layers": 3, "hidden_dim": 256}}
+    pr = dict(num_heads=8, num_layers=2, encoder_hidden_size=2048, fc_hidden_size=4096, latent_plan_dim=16, min_std=1e-4,
+              dropout_p=0.0, max_position_embeddings=T)
+    ad = dict(n_mixtures=10, num_layers=2, hidden_size=2048, out_features=7, num_classes=10, latent_plan_dim=16,
+              rnn_model="rnn_decoder", include_goal=False)
+    batch = bench.synth_batch(B, T, 84, 84, dev, 1)
+    res = []
+    for twin in (True, False):
+        torch.manual_seed(0)
+        m = PlayLMP(plan_proposal=actor, plan_recognition=pr, action_decoder=ad, plan_proposal_obs_modalities=cams,
+                    plan_proposal_goal_modalities=cams, plan_recognition_modalities=cams, action_decoder_modalities=cams,
+                    real_world=True, device=dev, compute_dtype="bf16", image_dtype="bf16")
+        m.ad.twin_pass = twin
+        assert bool(m.ad.twin_ok(B, m.compute)) == twin
+        m.enable_graph()
+        torch.manual_seed(5); torch.cuda.manual_seed(5)
+        for _ in range(3):
+            m.training_step(batch, 0)
+        torch.cuda.synchronize()
+        res.append((dict(m.logged), {k: v.clone() for k, v in m.named_gradients().items()},
+                    {k: v.clone() for k, v in m.state_dict().items()}))
+    (la, ga, pa), (lb, gb, pb) = res
+    assert la == lb and all(v == v for v in la.values()), (la, lb)
+    assert any("random_plan_action_loss" in k for k in la)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+
+
 def test_bptt_wavefront_equals_per_layer():
     """Action-decoder backward at bench shapes: the wavefront of batched ring-GEMM launches (both layers' recurrent
     gradient steps + the projection onto the lower layer per launch) against one launch per (layer, step) + a projection

@@ -785,6 +785,52 @@ def test_rnn_linear_bf16(M, K, N, act):
     assert torch.equal(yb, y.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("M,M2,nprob", [(32, 32, 3), (256, 256, 3), (64, 64, 2), (40, 24, 1), (3840, 3840, 1)])
+def test_rnn_linear_fwd_batch_twin(M, M2, nprob):
+    """Twin rows of the batched ring GEMM (PlayLMP's logging-only random-plan decoder pass riding in the real pass's
+    launches): rows M.. of every problem read x2 / addend2 and write y2 / yb2 - bit-identical to running the twin rows as a
+    launch of their own (same weights, same per-element accumulation order), and the first M rows unchanged."""
+    from tacorl_amd import ops
+
+    dev = _dev()
+    K = N = 256 if M > 1000 else 2048
+    if M > 1000:
+        N = 192
+    mk = lambda *s, seed, dt=torch.float32: rnd(*s, seed=seed).to(dt).to(dev)  # noqa: E731
+    xs = [mk(M, K, seed=10 + p, dt=torch.bfloat16) for p in range(nprob)]
+    x2 = [mk(M2, K, seed=20 + p, dt=torch.bfloat16) for p in range(nprob)]
+    ws = [(rnd(N, K, seed=30 + p) / math.sqrt(K)).to(torch.bfloat16).to(dev) for p in range(nprob)]
+    bs = [mk(N, seed=40 + p) for p in range(nprob)]
+    ad = [mk(M, N, seed=50 + p) if p != 1 else None for p in range(nprob)]
+    ad2 = [mk(M2, N, seed=60 + p) if p != 1 else None for p in range(nprob)]
+    acts = [1 if p != 1 else 0 for p in range(nprob)]
+    nan = lambda r, dt=torch.float32: torch.full((r, N), float("nan"), device=dev, dtype=dt)  # noqa: E731
+    y, y2, yb, yb2 = ([nan(M) for _ in range(nprob)], [nan(M2) for _ in range(nprob)],
+                      [nan(M, torch.bfloat16) if p != 1 else None for p in range(nprob)],
+                      [nan(M2, torch.bfloat16) if p != 1 else None for p in range(nprob)])
+    ops.call("tacorl_rnn_linear_fwd_batch_twin", nprob, ops.ptr_array(xs), ops.ptr_array(x2), ops.ptr_array(ws), ops.ptr_array(bs),
+             ops.ptr_array(ad), ops.ptr_array(ad2), N, ops.ptr_array(y), ops.ptr_array(y2), ops.ptr_array(yb), ops.ptr_array(yb2),
+             M, M2, K, N, ops.int_array(acts), ops.stream())
+    for rows, xx, aa, yy, yyb in ((M, xs, ad, y, yb), (M2, x2, ad2, y2, yb2)):
+        r, rb = [nan(rows) for _ in range(nprob)], [nan(rows, torch.bfloat16) if p != 1 else None for p in range(nprob)]
+        ops.call("tacorl_rnn_linear_fwd_batch", nprob, ops.ptr_array(xx), ops.ptr_array(ws), ops.ptr_array(bs), ops.ptr_array(aa), N,
+                 ops.ptr_array(r), ops.ptr_array(rb), rows, K, N, ops.int_array(acts), ops.stream())
+        torch.cuda.synchronize()
+        for p in range(nprob):
+            assert torch.isfinite(yy[p]).all() and torch.equal(yy[p], r[p]), (rows, p)
+            assert yyb[p] is None or torch.equal(yyb[p], rb[p]), (rows, p)
+            z = xx[p].float() @ ws[p].float().t() + bs[p] + (aa[p] if aa[p] is not None else 0)
+            assert relerr(yy[p], F.relu(z) if acts[p] else z) < 1e-5
+    # a twin launch needs twin rows in every problem
+    if nprob > 1:
+        x2[0] = None
+        from tacorl_amd import _lib
+        rc = _lib.lib().tacorl_rnn_linear_fwd_batch_twin(
+            nprob, ops.ptr_array(xs), ops.ptr_array(x2), ops.ptr_array(ws), ops.ptr_array(bs), ops.ptr_array(ad), ops.ptr_array(ad2),
+            N, ops.ptr_array(y), ops.ptr_array(y2), ops.ptr_array(yb), ops.ptr_array(yb2), M, M2, K, N, ops.int_array(acts), ops.stream())
+        assert rc != 0
+
+
 def test_rnn_bptt_step_and_transpose():
     """BPTT step through the ring GEMM: (x Wt^T + addend) * [mask > 0] with Wt from the transpose kernel."""
     from tacorl_amd import ops
@@ -1029,17 +1075,41 @@ def test_plan_recognition_fused_train_forward():
                      "ff1": [t.clone() for t in pr.ff1], "ff2": [t.clone() for t in pr.ff2],
                      "stats": [t.clone() for t in pr.stats]}
     res = {}
-    for fused in (False, True):
-        pr.fused_train = fused
+    for fused, fused_bwd in ((False, False), (True, False), (True, True)):
+        pr.fused_train, pr.fused_backward = fused, fused_bwd
         for t in pr.x + pr.qkv + pr.att + pr.proj + pr.ff1 + pr.ff2 + pr.stats if pr._shape else []:
             t.fill_(float("nan"))
         head = pr.forward(emb, D, B, T, 1, train=True).clone()
         sv = saves()
         pr.blk.grad.zero_()
+        if fused_bwd:  # (every parameter's gradient must be WRITTEN by this path; the block's padding stays 0)
+            for v in pr.blk.grad_views.values():
+                v.fill_(float("nan"))
+        if getattr(pr, "_bshape", None):
+            for t in [pr.dx] + pr.dv + pr.dv1 + pr.d_ff1 + pr.d_qkv:
+                t.fill_(float("nan"))
         dx = pr.backward(d_head, B, T, 1).clone()
         torch.cuda.synchronize()
-        res[fused] = (head, sv, dx, pr.blk.grad.clone())
-    (h0, s0, dx0, g0), (h1, s1, dx1, g1) = res[False], res[True]
+        dz = {"dv": [t.clone() for t in pr.dv], "dv1": [t.clone() for t in pr.dv1], "d_ff1": [t.clone() for t in pr.d_ff1],
+              "d_qkv": [t.clone() for t in pr.d_qkv]}
+        res[(fused, fused_bwd)] = (head, sv, dx, pr.blk.grad.clone(), dz)
+    # the input-gradient chain as ONE launch (round 4) against the per-op chain on the same saved tensors: every dZ operand
+    # it hands to the weight-gradient GEMMs, the input gradient and all parameter gradients (LayerNorm's included)
+    (_, _, dxp, gp, zp), (_, _, dxf, gf, zf) = res[(True, False)], res[(True, True)]
+    bad = [k for k, (o, _, n) in pr.blk.off.items()  # ("layernorm.*": declared by the reference, never used in forward)
+           if not k.startswith("layernorm.") and not torch.isfinite(gf[o: o + n]).all()]
+    assert not bad and torch.isfinite(dxf).all(), ("not written / not finite", bad)
+    for k in zp:
+        for l, (a, b) in enumerate(zip(zp[k], zf[k])):
+            assert torch.isfinite(b).all(), (k, l)
+            assert relerr(b, a) < 6e-3, ("fused backward", k, l, relerr(b, a))
+    assert relerr(dxf, dxp) < 6e-3, relerr(dxf, dxp)
+    for name, (o, _, n) in pr.blk.off.items():
+        if name.startswith("layernorm."):
+            gf[o: o + n] = 0
+            continue
+        assert relerr(gf[o: o + n], gp[o: o + n]) < 1e-2, ("fused backward", name, relerr(gf[o: o + n], gp[o: o + n]))
+    (h0, s0, dx0, g0, _), (h1, s1, dx1, g1, _) = res[(False, False)], res[(True, True)]
     for k in s0:
         for l, (a, b) in enumerate(zip(s0[k], s1[k])):
             assert torch.isfinite(b).all(), (k, l)
