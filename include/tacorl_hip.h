@@ -95,6 +95,12 @@ int tacorl_rnn_linear_bwd_batch(int nprob, const void* const* x_bf16, const void
                                 float* const* y, void* const* y_bf16, int M, int K, int N, tacorl_stream_t stream);
 /* dst[c][r] = bf16(src[r][c]); R, C multiples of 32. */
 int tacorl_transpose_to_bf16(const float* src, void* dst, int R, int C, tacorl_stream_t stream);
+/* dst[c][r] = r < R ? bf16(src[r][c]) : 0 for r < ld_dst (C, ld_dst multiples of 32): a weight whose row count is no multiple
+ * of the ring GEMM's k-step as its K-padded transposed operand (the action decoder's 182 x H output heads, reference
+ * action_decoder_logistic.py:44-52, in dH = d_heads W). */
+int tacorl_transpose_pad_to_bf16(const float* src, void* dst, int R, int C, int ld_dst, tacorl_stream_t stream);
+/* dst[r][c] = c < cols ? bf16(src[r][c]) : 0 for c < ld_dst (ld_dst % 8 == 0): a fp32 matrix as a K-padded bf16 operand. */
+int tacorl_pad_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, tacorl_stream_t stream);
 
 /* Backward primitives of y = act(x W^T + b):
  *   dgrad: out[m][i] = (sum_o dz[m][o] W[o][i] + addend[m][i]) * act'(src[m][i])

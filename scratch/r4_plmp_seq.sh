@@ -21,7 +21,7 @@ p.enable_graph(); p.log_every_n_steps = 50
 for _ in range(170): p.training_step(batch, 0)
 torch.cuda.synchronize()
 PY
-B=32 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 /tmp/run_pl.py > $O/run.log 2> $O/trace.err
+B=${B:-32} timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 /tmp/run_pl.py > $O/run.log 2> $O/trace.err
 python scratch/step_sequence.py $O/trace > $O/seq.txt
 rm -rf $O/trace
 tail -3 $O/seq.txt

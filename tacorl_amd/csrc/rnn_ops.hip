@@ -387,6 +387,46 @@ extern "C" int tacorl_transpose_to_bf16(const float* src, void* dst, int R, int 
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
+// The same with a row count that is no multiple of 32 and a padded destination: dst[c][r] = r < R ? bf16(src[r][c]) : 0 for
+// r < ld_dst (the output heads' 182 x H weight as the K-padded W^T operand of the ring GEMM: dH = d_heads W).
+__global__ __launch_bounds__(256) void transpose_pad_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int R,
+                                                                    int C, int ld_dst) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; k++) tile[ty + 8 * k][tx] = r0 + ty + 8 * k < R ? src[(long)(r0 + ty + 8 * k) * C + c0 + tx] : 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) dst[(long)(c0 + ty + 8 * k) * ld_dst + r0 + tx] = (__bf16)tile[tx][ty + 8 * k];
+}
+extern "C" int tacorl_transpose_pad_to_bf16(const float* src, void* dst, int R, int C, int ld_dst, tacorl_stream_t stream) {
+  if (R < 1 || C % 32 || C < 32 || ld_dst % 32 || ld_dst < R) return TACORL_EINVAL;
+  hipLaunchKernelGGL(transpose_pad_to_bf16_kernel, dim3(C / 32, ld_dst / 32), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst,
+                     R, C, ld_dst);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+// dst[r][c] = c < cols ? bf16(src[r][c]) : 0 for c < ld_dst: a fp32 matrix as a K-padded bf16 operand; 8 columns per thread
+__global__ __launch_bounds__(256) void pad_to_bf16_kernel(const float* __restrict__ src, int ld_src, __bf16* __restrict__ dst,
+                                                          int ld_dst, long rows, int cols) {
+  const int per = ld_dst / 8;
+  const long total = rows * per;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+    const long r = q / per;
+    const int c = (int)(q - r * per) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = (__bf16)(c + j < cols ? src[r * ld_src + c + j] : 0.f);
+    *reinterpret_cast<bf16x8*>(dst + r * ld_dst + c) = o;
+  }
+}
+extern "C" int tacorl_pad_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, long rows, int cols, tacorl_stream_t stream) {
+  if (rows < 1 || cols < 1 || ld_src < cols || ld_dst < cols || ld_dst % 8 || ((uintptr_t)dst & 15)) return TACORL_EINVAL;
+  const long total = rows * (ld_dst / 8);
+  hipLaunchKernelGGL(pad_to_bf16_kernel, dim3((int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, ld_src, (__bf16*)dst, ld_dst, rows, cols);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
 /* nprob <= 4 independent y = act(x W^T + b + addend) of one shape in ONE launch (blockIdx.z = problem), on a
  * 2-stage ring (48 KB of LDS per workgroup, so the workgroups of three problems are co-resident on a CU):
  * the wavefront schedule of a stacked RNN - recurrent steps of both layers and the upper layer's input

@@ -425,8 +425,22 @@ class ActionDecoderLogistic:
 
         side(lambda: self._wgrad(self.h[L - 1], H, self.d_heads, self.NHP, R, H, self.NH, blk.g("mean_fc.weight"),
                                  blk.g("mean_fc.bias"), compute))
-        self._dgrad(self.d_heads, self.NHP, blk.p("mean_fc.weight"), self.dH, H, R, self.NH, H, compute)
         fast = compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H)) and H % 32 == 0
+        KP = (self.NH + 127) // 128 * 128  # the heads' width as a contraction length of the ring GEMM
+        if fast and H % 32 == 0 and getattr(self, "heads_dgrad_ring", True) and bool(ops.L.lib().tacorl_rnn_linear_supported(R, KP, H)):
+            # dH = d_heads W through the ring GEMM (K = 182 padded to 256, two k-steps): the generic GEMM spends 64 us at
+            # 3 840 rows on this K-short, epilogue-bound product.  Operands: d_heads as K-padded bf16, W^T K-padded.
+            if getattr(self, "_hd_shape", None) != (R, KP):
+                ops.note_alloc()
+                self.d_heads_b = torch.zeros(R, KP, device=self.dev, dtype=torch.bfloat16)
+                self.headwt_b = torch.zeros(H, KP, device=self.dev, dtype=torch.bfloat16)
+                self._hd_shape = (R, KP)
+            call("tacorl_transpose_pad_to_bf16", blk.p("mean_fc.weight"), ptr(self.headwt_b), self.NH, H, KP, ops.stream())
+            call("tacorl_pad_to_bf16", ptr(self.d_heads), self.NHP, ptr(self.d_heads_b), KP, R, self.NH, ops.stream())
+            call("tacorl_rnn_linear_bwd_batch", 1, ops.ptr_array([self.d_heads_b]), ops.ptr_array([self.headwt_b]), None, H, None,
+                 ops.ptr_array([self.dH]), None, R, KP, H, ops.stream())
+        else:
+            self._dgrad(self.d_heads, self.NHP, blk.p("mean_fc.weight"), self.dH, H, R, self.NH, H, compute)
         if fast and getattr(self, "_bptt_shape", None) != (B, Tm):
             ops.note_alloc()
             bf = lambda *s: torch.zeros(*s, device=self.dev, dtype=torch.bfloat16)  # noqa: E731

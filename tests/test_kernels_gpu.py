@@ -1225,6 +1225,46 @@ def test_action_decoder_frozen_bf16_hidden_sizes(H):
     assert relerr(res["bf16"], res["f32"]) < TOL_BF16
 
 
+@pytest.mark.parametrize("B,T", [(16, 6), (256, 16)])
+def test_action_decoder_heads_dgrad_ring(B, T):
+    """bf16 backward of the action decoder: dH = d_heads W through the ring GEMM (d_heads and W^T as K-padded bf16 operands:
+    tacorl_pad_to_bf16 / tacorl_transpose_pad_to_bf16, K = 182 -> 256) against the generic bf16 GEMM on the same
+    operands - same bf16 products, fp32 accumulation in another order - and the two helper kernels against torch."""
+    from tacorl_amd import ops
+    from tacorl_amd.init import init_views_
+    from tacorl_amd.networks.action_decoder import ActionDecoderLogistic
+
+    dev = _dev()
+    P, E, H = 16, 32, 256 if B < 100 else 2048
+    torch.manual_seed(12)
+    ad = ActionDecoderLogistic(dev, state_dim=E, latent_plan_dim=P, hidden_size=H, out_features=7, num_layers=2)
+    init_views_(ad.blk.views, rnn_hidden=H)
+    plan, emb = rnd(B, P, seed=1).to(dev), rnd(B * T, E, seed=2).to(dev)
+    acts = rnd(B, T, 7, seed=3).clamp(-1, 1).to(dev)
+    acts[..., 6] = torch.sign(acts[..., 6])
+    loss = torch.zeros(1, device=dev)
+    res = {}
+    for ring in (True, False):
+        ad.heads_dgrad_ring = ring
+        ad.forward(plan, emb, E, B, T, T - 1, ops.BF16)
+        ad.loss(acts, ops.ptr(loss), B, T, T - 1, want_grad=True)
+        ad.blk.grad.zero_()
+        ad.backward(B, T - 1, ops.BF16, need_input_grad=True)
+        torch.cuda.synchronize()
+        res[ring] = (ad.dH.clone(), ad.blk.grad.clone(), ad.dx_seq.clone())
+    assert getattr(ad, "d_heads_b", None) is not None, "the ring path did not run"
+    for a, b, name in zip(res[True], res[False], ("dH", "grad", "dx_seq")):
+        assert torch.isfinite(a).all() and relerr(a, b) < 2e-5, (name, relerr(a, b))
+    R, KP = B * (T - 1), ad.d_heads_b.shape[1]
+    ref = torch.zeros(R, KP, device=dev)
+    ref[:, : ad.NH] = ad.d_heads[:, : ad.NH]
+    assert torch.equal(ad.d_heads_b, ref.to(torch.bfloat16))
+    wt = torch.zeros(H, KP, device=dev)
+    o = ad.blk.off["mean_fc.weight"][0]  # (the four heads' weights sit back to back: one NH x H matrix)
+    wt[:, : ad.NH] = ad.blk.param[o: o + ad.NH * H].view(ad.NH, H).t()
+    assert torch.equal(ad.headwt_b, wt.to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("dropout", [False, True])
 @pytest.mark.parametrize("B", [5, 40])
 def test_attention_fwd_bwd_t16(B, dropout):
