@@ -403,10 +403,18 @@ int tacorl_pr_encoder_fused_train(const float* emb, int ld_emb, const float* par
  * LayerNorm-1 input gradient [B T][32] (out_proj), d(q|k|v) [B T][96] (in_proj).  wt[2 l + {0, 1}]: linear1.weight^T
  * [32][FF], linear2.weight^T [FF][32] as bf16 (tacorl_transpose_to_bf16).  ln_part: scratch of L * 2 * B * 64 floats;
  * ln_grads[4 l + k]: norm1.weight, norm1.bias, norm2.weight, norm2.bias gradients (written, not accumulated).
+ * d_pool == NULL: d_pool = d_head Wc computed in the launch (d_head [B][A2], Wc [A2][32] from tacorl_pr_head_compose).
  * Reference: autograd through plan_recognition_transformer.py:70-88 (nn.TransformerEncoderLayer, post-norm, ReLU). */
-int tacorl_pr_encoder_bwd_fused(const float* params, const long* offsets, const float* d_pool, float* dx,
-                                const float* const* saved, float* const* dz, const void* const* wt, float* ln_part,
-                                float* const* ln_grads, int B, int D, int T, int H, int FF, int L, tacorl_stream_t stream);
+int tacorl_pr_encoder_bwd_fused(const float* params, const long* offsets, const float* d_pool, const float* d_head,
+                                const float* Wc, int A2, float* dx, const float* const* saved, float* const* dz,
+                                const void* const* wt, float* ln_part, float* const* ln_grads, int B, int D, int T, int H,
+                                int FF, int L, tacorl_stream_t stream);
+/* tacorl_pr_encoder_fused_train with the posterior head and the plan sample in the launch (head = Wc pooled + bc, composed
+ * by tacorl_pr_head_compose; plan = tanh(mean + eps * std)); its backward: tacorl_pr_encoder_bwd_fused with d_pool == NULL. */
+int tacorl_pr_encoder_fused_train_sample(const float* emb, int ld_emb, const float* params, const void* params_bf16,
+                                         const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
+                                         float* const* save, const float* Wc, const float* bc, const float* eps,
+                                         float* head, float* plan, int A, float min_std, tacorl_stream_t stream);
 int tacorl_pr_head_compose(const float* w_fc, const float* b_fc, const float* w_head, const float* b_head,
                            float* Wc, float* bc, int D, int FC, int A2, tacorl_stream_t stream);
 int tacorl_mean_over_t(const float* x, float* out, int B, int T, int D, tacorl_stream_t stream);

@@ -43,7 +43,8 @@ _SIGS = {
     "tacorl_pr_encoder_fused_supported": (_i, [_i, _i, _i, _i, _i]),
     "tacorl_pr_encoder_fused": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "tacorl_pr_encoder_fused_train": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
-    "tacorl_pr_encoder_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "tacorl_pr_encoder_bwd_fused": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "tacorl_pr_encoder_fused_train_sample": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _f, _p]),
     "tacorl_pr_encoder_fused_sample": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _f, _p]),
     "tacorl_pr_head_compose": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_to_bf16_batch": (_i, [_i, _p, _p, _p, _p]),

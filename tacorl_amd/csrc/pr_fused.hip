@@ -316,7 +316,10 @@ struct PrBwdL {
 };
 struct PrBwdArgs {
   const float* P;
-  const float* d_pool;  // [B][32]
+  const float* d_pool;  // [B][32]; or null: d_pool = d_head Wc computed here
+  const float* d_head;  // [B][A2]
+  const float* Wc;      // [A2][32] composed head weight (tacorl_pr_head_compose)
+  int A2;
   float* dx;            // [B*T][32]
   float* lnpart;        // [L][2][B][64]: per-sequence (dw | db) partials of LayerNorm 1 / 2
   PrLayerOff l[PR_MAXL];
@@ -390,8 +393,19 @@ __global__ __launch_bounds__(256) void pr_encoder_bwd_fused_kernel(PrBwdArgs a) 
   };
   // gradient of the mean over time: every row takes d_pool / T
   f32x4 dx[2];
+  if (a.d_pool) {
 #pragma unroll
-  for (int nt = 0; nt < 2; nt++) dx[nt] = *reinterpret_cast<const f32x4*>(a.d_pool + (long)b * PR_D + 16 * nt + 4 * g) * (1.0f / PR_T);
+    for (int nt = 0; nt < 2; nt++) dx[nt] = *reinterpret_cast<const f32x4*>(a.d_pool + (long)b * PR_D + 16 * nt + 4 * g) * (1.0f / PR_T);
+  } else {  // d_pool = d_head Wc (fp32; the composed head of the forward)
+    dx[0] = dx[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < a.A2; j++) {
+      const float dh = a.d_head[(long)b * a.A2 + j];
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) dx[nt] += dh * *reinterpret_cast<const f32x4*>(a.Wc + (long)j * PR_D + 16 * nt + 4 * g);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) dx[nt] *= (1.0f / PR_T);
+  }
   for (int l = a.L - 1; l >= 0; l--) {
     const PrLayerOff& o = a.l[l];
     const PrBwdL& S = a.s[l];
@@ -650,6 +664,19 @@ extern "C" int tacorl_pr_encoder_fused_train(const float* emb, int ld_emb, const
   return pr_encoder_fused_launch(emb, ld_emb, params, params_bf16, offsets, pooled, B, D, T, H, FF, L, nullptr, nullptr,
                                  nullptr, nullptr, nullptr, 0, 0.f, stream, save);
 }
+/* Train mode with the posterior head and the plan sample in the launch (as tacorl_pr_encoder_fused_sample: head = Wc pooled +
+ * bc with the composed (Wc, bc) of tacorl_pr_head_compose).  The backward takes d_pool = d_head Wc the same way
+ * (tacorl_pr_encoder_bwd_fused, d_head / Wc arguments); fc's and mean_fc's weight gradients need fc_out = pooled W_fc^T + b_fc
+ * and d_fc = d_head W_head as per-op GEMMs - off the dependent chain. */
+extern "C" int tacorl_pr_encoder_fused_train_sample(const float* emb, int ld_emb, const float* params, const void* params_bf16,
+                                                    const long* offsets, float* pooled, int B, int D, int T, int H, int FF,
+                                                    int L, float* const* save, const float* Wc, const float* bc,
+                                                    const float* eps, float* head, float* plan, int A, float min_std,
+                                                    tacorl_stream_t stream) {
+  if (!save || !Wc) return TACORL_EINVAL;
+  return pr_encoder_fused_launch(emb, ld_emb, params, params_bf16, offsets, pooled, B, D, T, H, FF, L, Wc, bc, eps, head, plan,
+                                 A, min_std, stream, save);
+}
 extern "C" int tacorl_pr_encoder_fused(const float* emb, int ld_emb, const float* params, const void* params_bf16,
                                        const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
                                        tacorl_stream_t stream) {
@@ -678,17 +705,19 @@ extern "C" int tacorl_pr_head_compose(const float* w_fc, const float* b_fc, cons
  * (linear2's dZ), the masked hidden gradient [B T][FF] (linear1's dZ), LayerNorm-1 input gradient [B T][32] (out-proj's
  * dZ), d(q|k|v) [B T][96] (in-proj's dZ); wt[2 l + {0,1}]: W1^T [32][FF], W2^T [FF][32] as bf16 (tacorl_transpose_to_bf16);
  * ln_part: scratch of L * 2 * B * 64 floats; ln_grads[4 l + k]: norm1.weight, norm1.bias, norm2.weight, norm2.bias gradients.
+ * d_pool == NULL: d_pool = d_head Wc is computed in the launch (d_head [B][A2], Wc [A2][32] from tacorl_pr_head_compose).
  * Reference: autograd through plan_recognition_transformer.py:70-88 (nn.TransformerEncoderLayer, post-norm, ReLU). */
-extern "C" int tacorl_pr_encoder_bwd_fused(const float* params, const long* offsets, const float* d_pool, float* dx,
-                                           const float* const* saved, float* const* dz, const void* const* wt,
-                                           float* ln_part, float* const* ln_grads, int B, int D, int T, int H, int FF, int L,
-                                           tacorl_stream_t stream) {
+extern "C" int tacorl_pr_encoder_bwd_fused(const float* params, const long* offsets, const float* d_pool, const float* d_head,
+                                           const float* Wc, int A2, float* dx, const float* const* saved, float* const* dz,
+                                           const void* const* wt, float* ln_part, float* const* ln_grads, int B, int D, int T,
+                                           int H, int FF, int L, tacorl_stream_t stream) {
   if (!tacorl_pr_encoder_fused_supported(D, T, H, FF, L) || B < 1) return TACORL_EINVAL;
-  if (!params || !d_pool || !dx || !saved || !dz || !wt || !ln_part || !ln_grads) return TACORL_EINVAL;
-  if (((uintptr_t)params | (uintptr_t)d_pool | (uintptr_t)dx | (uintptr_t)ln_part) & 15) return TACORL_EINVAL;
+  if (!params || !dx || !saved || !dz || !wt || !ln_part || !ln_grads) return TACORL_EINVAL;
+  if (!d_pool && (!d_head || !Wc || A2 < 1)) return TACORL_EINVAL;
+  if (((uintptr_t)params | (uintptr_t)d_pool | (uintptr_t)dx | (uintptr_t)ln_part | (uintptr_t)Wc) & 15) return TACORL_EINVAL;
   PrBwdArgs a{};
   PrLnReduceArgs r{};
-  a.P = params; a.d_pool = d_pool; a.dx = dx; a.lnpart = ln_part; a.B = B; a.FF = FF; a.L = L;
+  a.P = params; a.d_pool = d_pool; a.d_head = d_head; a.Wc = Wc; a.A2 = A2; a.dx = dx; a.lnpart = ln_part; a.B = B; a.FF = FF; a.L = L;
   r.part = ln_part; r.B = B;
   for (int l = 0; l < L; l++) {
     const long* q = offsets + 1 + 12 * l;

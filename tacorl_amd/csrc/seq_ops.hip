@@ -863,15 +863,16 @@ extern "C" int tacorl_add_layernorm_bwd(const float* dy, const float* x, const f
 // underlying Normals (reference play_lmp_for_rl.py:259-301), forward + backward fused:
 //   kl = alpha*KL(sg(q)||p) + (1-alpha)*KL(q||sg(p)),  mean over batch;  loss = beta*kl.
 // head_q = [mean | var_raw] (std = softplus+min_std), head_p = [mean_raw | log_std_raw] (policy clamps).
-// d_head_* receive d(beta*kl)/d(raw head).  One block.
-__global__ __launch_bounds__(256) void gauss_kl_kernel(const float* __restrict__ hq, const float* __restrict__ hp,
+// d_head_* receive d(beta*kl)/d(raw head).  One block of 16 waves (B A = 4 096 elements at B = 256: four per thread; as 256
+// threads the launch took 22 us there).
+__global__ __launch_bounds__(1024) void gauss_kl_kernel(const float* __restrict__ hq, const float* __restrict__ hp,
                                                        float* __restrict__ dq, float* __restrict__ dp, int B, int A,
                                                        float alpha, float beta, float min_std, int balanced,
                                                        float grad_scale, float* out /*[2]: kl, beta*kl*/) {
-  __shared__ float sh[4];
+  __shared__ float sh[16];
   float s = 0.f;
   const float c = beta * grad_scale / (float)B;
-  for (int i = threadIdx.x; i < B * A; i += 256) {
+  for (int i = threadIdx.x; i < B * A; i += 1024) {
     const int b = i / A, j = i - b * A;
     const float mq = hq[(long)b * 2 * A + j], vr = hq[(long)b * 2 * A + A + j];
     const float sq = (vr > 20.f ? vr : log1pf(expf(vr))) + min_std;
@@ -894,14 +895,16 @@ __global__ __launch_bounds__(256) void gauss_kl_kernel(const float* __restrict__
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float kl = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)B;
+    float t = 0.f;
+    for (int w = 0; w < 16; w++) t += sh[w];
+    const float kl = t / (float)B;
     out[0] = kl; out[1] = kl * beta;
   }
 }
 extern "C" int tacorl_gauss_kl_balanced(const float* head_q, const float* head_p, float* d_head_q, float* d_head_p,
                                         int B, int A, float kl_alpha, float kl_beta, float min_std, int balanced,
                                         float grad_scale, float* out2, tacorl_stream_t stream) {
-  hipLaunchKernelGGL(gauss_kl_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, head_q, head_p, d_head_q, d_head_p, B,
+  hipLaunchKernelGGL(gauss_kl_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, head_q, head_p, d_head_q, d_head_p, B,
                      A, kl_alpha, kl_beta, min_std, balanced, grad_scale, out2);
   return LAUNCH_OK();
 }

@@ -364,12 +364,20 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     # Where the ring-GEMM path runs (bf16), the random-plan pass is not a pass of its own: its rows ride in the launches of
     # the real pass (same weights, read once - ActionDecoderLogistic.twin_*); only its input projection and its loss
     # stay on the branch.
-    twin = None
+    twin, ad_prepared, pr_ready = None, False, None
     s_rand.wait_stream(main)
     with torch.cuda.stream(s_rand):
+        if cd == BF16 and not getattr(self, "_pr_train", False) and getattr(self, "early_prepare", True):
+            # weights only: the plan recognition's bf16 mirror and its composed posterior head, beside the encoder's tail
+            pr.prepare_inference()
+            pr_ready = torch.cuda.Event()
+            pr_ready.record(s_rand)
         call("tacorl_uniform_actions", ptr(self.noise["u_plan"]), ptr(self.rplan), A, B, A, 0, ops.stream())
         if ad.twin_ok(B, cd):
             twin = ad.twin_input_proj(self.rplan, self.emb, Ec, B, T, T - 1)
+            # weights-only preparation of the real pass and of the backward rides on this branch (joined before the pass)
+            ad.refresh_mirrors(B, T - 1)
+            ad_prepared = ad.prepare_backward(B, T - 1, cd) if getattr(self, "early_prepare", True) else False
         else:
             ad.forward(self.rplan, self.emb, Ec, B, T, T - 1, cd)
             ad.loss(acts, ops._at(self.logs, 4), B, T, T - 1, want_grad=False)
@@ -389,7 +397,10 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     ops.copy_cols(self.gact, self.g_yoff, Ec, self.S, Ec, 2 * Ec, B, Ec)
     ops.mlp_fwd([self.S], 2 * Ec, [net.head()], [self.pact], [B], net.head_dims, net.head_acts, cd, params_bf16=pb_h)
     head_pp = self.pact[self.p_yoff: self.p_yoff + B * 2 * A]
-    head_pr = pr.forward(self.emb, Ec, B, T, cd, train=getattr(self, "_pr_train", False))
+    if pr_ready is not None:
+        main.wait_event(pr_ready)
+    head_pr = pr.forward(self.emb, Ec, B, T, cd, train=getattr(self, "_pr_train", False), prepared=pr_ready is not None,
+                         sample=(self.noise["eps_plan"], self.plan) if pr_ready is not None else None)
     call("tacorl_gauss_kl_balanced", ptr(head_pr), ptr(head_pp), ptr(self.d_head_pr), ptr(self.d_head_pp), B, A,
          float(self.kl_alpha), float(self.kl_beta), float(pr.min_std), int(self.kl_balancing), gs, ptr(self.logs),
          ops.stream())
@@ -407,11 +418,12 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
                      net.head_dims, net.head_acts)
         mlp_backward("genc", self.gin, Ec, net.genc(), self.gact, ops._at(self.dS, Ec), 2 * Ec, net.genc(net.grad), self.dgin, Ec,
                      net.genc_dims, net.genc_acts)
-    call("tacorl_pr_sample", ptr(head_pr), ptr(self.noise["eps_plan"]), ptr(self.plan), None, None, B, A,
-         float(pr.min_std), ops.stream())
+    if pr_ready is None:  # (otherwise pr.forward sampled the plan - inside its one launch where that path runs)
+        call("tacorl_pr_sample", ptr(head_pr), ptr(self.noise["eps_plan"]), ptr(self.plan), None, None, B, A,
+             float(pr.min_std), ops.stream())
     main.wait_stream(s_rand)
-    # (mirrors_current: a random-plan pass of its own has refreshed the bf16 mirrors of the weights)
-    ad.forward(self.plan, self.emb, Ec, B, T, T - 1, cd, mirrors_current=twin is None, twin=twin)
+    # (mirrors_current: the branch above has refreshed the bf16 mirrors of the weights - in the random-plan pass of its own, or explicitly)
+    ad.forward(self.plan, self.emb, Ec, B, T, T - 1, cd, mirrors_current=True, twin=twin)
     if twin is not None:
         s_rand.wait_stream(main)
         with torch.cuda.stream(s_rand):
@@ -420,7 +432,7 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     if self.add_random_plan_loss:
         raise NotImplementedError("add_random_plan_loss=True is not used by any in-scope config")
     # ---- backward
-    ad.backward(B, T - 1, cd, need_input_grad=True, wgrad_stream=s_wg, join=False)
+    ad.backward(B, T - 1, cd, need_input_grad=True, wgrad_stream=s_wg, join=False, prepared=ad_prepared)
     self.d_emb.zero_()
     call("tacorl_ad_input_bwd", ptr(ad.dx_seq), ptr(self.d_plan), ptr(self.d_emb), Ec, B, T, T - 1, ad.P, ad.E, 1,
          ops.stream())

@@ -162,6 +162,56 @@ class ActionDecoderLogistic:
              ptr(tw.xin[0]), B, T, Tm, self.P, self.E, self.hidden, ops.stream())
         return tw
 
+    def refresh_mirrors(self, B, Tm):
+        """bf16 copies of the recurrent / projection / head weights for the ring GEMMs (weights only: forward() issues this
+        itself unless told the mirrors are current; a caller may issue it early on another stream)."""
+        self._ensure(B, Tm)
+        blk, H = self.blk, self.hidden
+        srcs = ([blk.p(f"rnn.weight_hh_l{l}") for l in range(self.L)] + [blk.p(f"rnn.weight_ih_l{l}") for l in range(1, self.L)]
+                + [blk.p("mean_fc.weight")])
+        dsts = self.whb + self.wib[1:] + [self.headw_b]
+        call("tacorl_to_bf16_batch", len(srcs), ops.ptr_array(srcs), ops.ptr_array(dsts),
+             (C.c_long * len(srcs))(*([H * H] * (len(srcs) - 1) + [self.NH * H])), ops.stream())
+        ob = blk.off["mean_fc.bias"][0]  # the four heads' biases sit back to back
+        self.headb[: self.NH].copy_(blk.param[ob: ob + self.NH])
+
+    def prepare_backward(self, B, Tm, compute):
+        """Weights-only preparation of backward() (transposed bf16 copies for the BPTT ring GEMMs and the heads' input
+        gradient); backward(prepared=True) then skips it.  May run early, on another stream."""
+        if not self._bwd_fast(B, compute):
+            return False
+        self._ensure(B, Tm)
+        self._ensure_bptt(B, Tm)
+        self._transpose_weights()
+        if self._heads_ring(B * Tm):
+            call("tacorl_transpose_pad_to_bf16", self.blk.p("mean_fc.weight"), ptr(self.headwt_b), self.NH, self.hidden,
+                 self.headwt_b.shape[1], ops.stream())
+        return True
+
+    def _bwd_fast(self, B, compute):
+        H = self.hidden
+        return compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H)) and H % 32 == 0
+
+    def _heads_ring(self, R):
+        KP = (self.NH + 127) // 128 * 128  # the heads' width as a contraction length of the ring GEMM
+        ok = getattr(self, "heads_dgrad_ring", True) and bool(ops.L.lib().tacorl_rnn_linear_supported(R, KP, self.hidden))
+        if ok and getattr(self, "_hd_shape", None) != (R, KP):
+            ops.note_alloc()
+            self.d_heads_b = torch.zeros(R, KP, device=self.dev, dtype=torch.bfloat16)
+            self.headwt_b = torch.zeros(self.hidden, KP, device=self.dev, dtype=torch.bfloat16)
+            self._hd_shape = (R, KP)
+        return ok
+
+    def _ensure_bptt(self, B, Tm):
+        if getattr(self, "_bptt_shape", None) != (B, Tm):
+            ops.note_alloc()
+            H, L, R = self.hidden, self.L, B * Tm
+            bf = lambda *s: torch.zeros(*s, device=self.dev, dtype=torch.bfloat16)  # noqa: E731
+            self.DZb = [bf(R, H) for _ in range(L)]   # bf16 copies of dZ_t: the ring GEMM's operand
+            self.whtb = [bf(H, H) for _ in range(L)]  # W_hh^T
+            self.wihtb = [None] + [bf(H, H) for _ in range(1, L)]  # W_ih^T of layers >= 1 (wavefront projections)
+            self._bptt_shape = (B, Tm)
+
     def _lin(self, x, ldx, w, b, y, M, K, N, act, compute, ldy=None):
         # split-K capable entry (skinny outputs with a long K: linear2 2048->32, the 2048->182 heads)
         nb = ops.L.lib().tacorl_linear_add_fwd_ws_bytes(1, ops.int_array([M]), K, N)
@@ -198,10 +248,7 @@ class ActionDecoderLogistic:
         if fast:
             self._bf16_version = ver if frozen else None
         if fast and not fresh:
-            srcs = [blk.p(f"rnn.weight_hh_l{l}") for l in range(self.L)] + [blk.p(f"rnn.weight_ih_l{l}") for l in range(1, self.L)]
-            dsts = self.whb + self.wib[1:]
-            call("tacorl_to_bf16_batch", len(srcs), ops.ptr_array(srcs), ops.ptr_array(dsts),
-                 (C.c_long * len(srcs))(*([H * H] * len(srcs))), ops.stream())
+            self.refresh_mirrors(B, Tm)
         at = ops._at
         if fast:
             # Wavefront over (layer, step): launch s holds the recurrent step s-2l of every layer l and the
@@ -253,11 +300,6 @@ class ActionDecoderLogistic:
                      ptr(self.rnn_ws), self.rnn_ws.numel(), ops.stream())
             x, K = self.h[l], H
         if fast:  # output heads through the ring GEMM (bf16 weights, rows padded to a multiple of 32)
-            if not fresh:
-                call("tacorl_to_bf16_batch", 1, ops.ptr_array([blk.p("mean_fc.weight")]), ops.ptr_array([self.headw_b]),
-                     (C.c_long * 1)(self.NH * H), ops.stream())
-                ob = blk.off["mean_fc.bias"][0]  # the four heads' biases sit back to back
-                self.headb[: self.NH].copy_(blk.param[ob: ob + self.NH])
             if twin is not None:
                 call("tacorl_rnn_linear_fwd_batch_twin", 1, ops.ptr_array([self.hb[self.L - 1]]), ops.ptr_array([twin.hb[self.L - 1]]),
                      ops.ptr_array([self.headw_b]), ops.ptr_array([self.headb]), None, None, 0, ops.ptr_array([self.heads]),
@@ -353,7 +395,7 @@ class ActionDecoderLogistic:
         call("tacorl_copy_cols", blk.g(f"rnn.bias_ih_l{l}"), H, blk.g(f"rnn.bias_hh_l{l}"), H, 1, H, 0, 0,
              ops.stream())
 
-    def _bptt_wavefront(self, B, Tm):
+    def _bptt_wavefront(self, B, Tm, prepared=False):
         """BPTT of all layers as a wavefront of batched ring-GEMM launches (rnn_ops.hip tacorl_rnn_linear_bwd_batch).
         With k = L-1-l the depth of layer l below the top, launch s holds
           step(l, u), u = Tm-2-(s-2k):  dZ_l[u] = (dZ_l[u+1] W_hh_l + dH_l[u]) * [h_l[u] > 0]
@@ -363,7 +405,8 @@ class ActionDecoderLogistic:
         at = ops._at
         bfp = lambda t, off: C.c_void_p(t.data_ptr() + 2 * off)  # noqa: E731
         row = lambda t: t * B * H  # noqa: E731
-        self._transpose_weights()
+        if not prepared:
+            self._transpose_weights()
         top, last = L - 1, row(Tm - 1)
         call("tacorl_relu_mask_mul", at(self.dHs[top], last), None, at(self.h[top], last), at(self.DZ[top], last), B * H, ops.stream())
         call("tacorl_to_bf16_batch", 1, ops.ptr_array([at(self.DZ[top], last)]), ops.ptr_array([bfp(self.DZb[top], last)]),
@@ -396,7 +439,7 @@ class ActionDecoderLogistic:
             if l >= 1:
                 call("tacorl_transpose_to_bf16", blk.p(f"rnn.weight_ih_l{l}"), ptr(self.wihtb[l]), H, H, ops.stream())
 
-    def backward(self, B, Tm, compute, need_input_grad=False, wgrad_stream=None, join=True, wavefront=True):
+    def backward(self, B, Tm, compute, need_input_grad=False, wgrad_stream=None, join=True, wavefront=True, prepared=False):
         """Gradients of the loss (dL/dheads in self.d_heads) into self.blk.grad; optionally
         d(x_seq) into self.dx_seq.  ReLU-RNN BPTT: dz_{t-1} = (dz_t W_hh + dH_{t-1}) * [h_{t-1} > 0].
         wgrad_stream: the weight gradients - which only the optimiser reads - go to that stream (a branch of a
@@ -425,31 +468,22 @@ class ActionDecoderLogistic:
 
         side(lambda: self._wgrad(self.h[L - 1], H, self.d_heads, self.NHP, R, H, self.NH, blk.g("mean_fc.weight"),
                                  blk.g("mean_fc.bias"), compute))
-        fast = compute == ops.BF16 and bool(ops.L.lib().tacorl_rnn_linear_supported(B, H, H)) and H % 32 == 0
-        KP = (self.NH + 127) // 128 * 128  # the heads' width as a contraction length of the ring GEMM
-        if fast and H % 32 == 0 and getattr(self, "heads_dgrad_ring", True) and bool(ops.L.lib().tacorl_rnn_linear_supported(R, KP, H)):
+        fast = self._bwd_fast(B, compute)
+        if fast and self._heads_ring(R):
             # dH = d_heads W through the ring GEMM (K = 182 padded to 256, two k-steps): the generic GEMM spends 64 us at
             # 3 840 rows on this K-short, epilogue-bound product.  Operands: d_heads as K-padded bf16, W^T K-padded.
-            if getattr(self, "_hd_shape", None) != (R, KP):
-                ops.note_alloc()
-                self.d_heads_b = torch.zeros(R, KP, device=self.dev, dtype=torch.bfloat16)
-                self.headwt_b = torch.zeros(H, KP, device=self.dev, dtype=torch.bfloat16)
-                self._hd_shape = (R, KP)
-            call("tacorl_transpose_pad_to_bf16", blk.p("mean_fc.weight"), ptr(self.headwt_b), self.NH, H, KP, ops.stream())
+            KP = self.headwt_b.shape[1]
+            if not prepared:
+                call("tacorl_transpose_pad_to_bf16", blk.p("mean_fc.weight"), ptr(self.headwt_b), self.NH, H, KP, ops.stream())
             call("tacorl_pad_to_bf16", ptr(self.d_heads), self.NHP, ptr(self.d_heads_b), KP, R, self.NH, ops.stream())
             call("tacorl_rnn_linear_bwd_batch", 1, ops.ptr_array([self.d_heads_b]), ops.ptr_array([self.headwt_b]), None, H, None,
                  ops.ptr_array([self.dH]), None, R, KP, H, ops.stream())
         else:
             self._dgrad(self.d_heads, self.NHP, blk.p("mean_fc.weight"), self.dH, H, R, self.NH, H, compute)
-        if fast and getattr(self, "_bptt_shape", None) != (B, Tm):
-            ops.note_alloc()
-            bf = lambda *s: torch.zeros(*s, device=self.dev, dtype=torch.bfloat16)  # noqa: E731
-            self.DZb = [bf(R, H) for _ in range(L)]   # bf16 copies of dZ_t: the ring GEMM's operand
-            self.whtb = [bf(H, H) for _ in range(L)]  # W_hh^T
-            self.wihtb = [None] + [bf(H, H) for _ in range(1, L)]  # W_ih^T of layers >= 1 (wavefront projections)
-            self._bptt_shape = (B, Tm)
+        if fast:
+            self._ensure_bptt(B, Tm)
         if fast and Tm > 1 and 2 * L - 1 <= 4 and wavefront and getattr(self, "bptt_wavefront", True):
-            self._bptt_wavefront(B, Tm)
+            self._bptt_wavefront(B, Tm, prepared)
             for l in reversed(range(L)):
                 side(lambda l=l: self._layer_wgrads(l, B, Tm, compute, fast))
             if need_input_grad:

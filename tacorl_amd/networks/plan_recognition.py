@@ -165,22 +165,34 @@ class PlanRecognition:
             # per-op backward below reads (layer inputs, q|k|v, attention / projection / FFN outputs, LayerNorm statistics)
             # in the per-op forward's layouts - ~17 dependent launches of PlayLMP.training_step's chain become one
             import ctypes as C
-            if getattr(self, "_pb", None) is None:
-                ops.note_alloc()
-                self._pb = torch.zeros(blk.param.numel(), device=self.dev, dtype=torch.bfloat16)
-                self._foff = (C.c_long * (1 + 12 * self.L))(*self._fused_offsets())
-                self._Wc = torch.zeros(2 * self.A, self.D, device=self.dev)
-                self._bc = torch.zeros(2 * self.A, device=self.dev)
-            call("tacorl_to_bf16_batch", 1, ops.ptr_array([blk.param]), ops.ptr_array([self._pb]),
-                 (C.c_long * 1)(blk.param.numel() // 4 * 4), ops.stream())
-            self._prep_version = None  # (the mirror is current, the composed inference head is not)
+            if not prepared:
+                if getattr(self, "_pb", None) is None:
+                    ops.note_alloc()
+                    self._pb = torch.zeros(blk.param.numel(), device=self.dev, dtype=torch.bfloat16)
+                    self._foff = (C.c_long * (1 + 12 * self.L))(*self._fused_offsets())
+                    self._Wc = torch.zeros(2 * self.A, self.D, device=self.dev)
+                    self._bc = torch.zeros(2 * self.A, device=self.dev)
+                call("tacorl_to_bf16_batch", 1, ops.ptr_array([blk.param]), ops.ptr_array([self._pb]),
+                     (C.c_long * 1)(blk.param.numel() // 4 * 4), ops.stream())
+            self._prep_version = None  # (whatever is current now will not be after the optimiser step that follows)
             save = []
             for l in range(self.L):
                 save += [self.x[2 * l], self.qkv[l], self.att[l], self.proj[l], self.x[2 * l + 1], self.ff1[l], self.ff2[l],
                          self.stats[2 * l], self.stats[2 * l + 1]]
+            self._fused_saved = (B, T)  # (backward may take the fused chain: every saved tensor is in the fused layout)
+            # prepared (prepare_inference() issued for the current weights, e.g. early on a side stream): the posterior head
+            # as ONE affine map and the plan sample ride in the launch, as in the inference path - fc (32 -> 4096), mean_fc
+            # (4096 -> 2A, split-K + reduce) and the sample kernel leave the dependent chain; backward() takes d_pool =
+            # d_head Wc inside its launch and computes fc_out / d_fc for the two weight gradients beside the chain
+            self._composed = bool(prepared and sample is not None and 2 * self.A <= 64 and getattr(self, "composed_head", True))
+            if self._composed:
+                eps, plan = sample
+                call("tacorl_pr_encoder_fused_train_sample", ptr(emb), ld_emb, ptr(blk.param), ptr(self._pb), self._foff,
+                     ptr(self.pooled), B, D, T, self.H, self.FF, self.L, ops.ptr_array(save), ptr(self._Wc), ptr(self._bc),
+                     ptr(eps), ptr(self.head), ptr(plan), self.A, float(self.min_std), ops.stream())
+                return self.head
             call("tacorl_pr_encoder_fused_train", ptr(emb), ld_emb, ptr(blk.param), ptr(self._pb), self._foff, ptr(self.pooled),
                  B, D, T, self.H, self.FF, self.L, ops.ptr_array(save), ops.stream())
-            self._fused_saved = (B, T)  # (backward may take the fused chain: every saved tensor is in the fused layout)
             self._lin(self.pooled, D, blk.p("fc.weight"), blk.p("fc.bias"), self.fc_out, B, D, self.FC, ACT_NONE, compute)
             self._lin(self.fc_out, self.FC, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.head, B, self.FC,
                       2 * self.A, ACT_NONE, compute)
@@ -189,7 +201,7 @@ class PlanRecognition:
                 call("tacorl_pr_sample", ptr(self.head), ptr(eps), ptr(plan), None, None, B, self.A, float(self.min_std),
                      ops.stream())
             return self.head
-        self._fused_saved = None
+        self._fused_saved, self._composed = None, False
         call("tacorl_add_rows_bcast", ptr(emb), ld_emb, blk.p("position_embeddings.weight"), ptr(self.x[0]), R, T,
              self.D_in, D, ops.stream())
         if drop:
@@ -296,10 +308,19 @@ class PlanRecognition:
             if wgrad_stream is not None:
                 wt_ready = torch.cuda.Event()
                 wt_ready.record(wgrad_stream)
-        side(lambda: self._wgrad(self.fc_out, FC, d_head, A2, B, FC, A2, blk.g("mean_fc.weight"), blk.g("mean_fc.bias"), compute))
-        self._dgrad(d_head, A2, blk.p("mean_fc.weight"), self.d_fc, FC, B, A2, FC, compute)
-        side(lambda: self._wgrad(self.pooled, D, self.d_fc, FC, B, D, FC, blk.g("fc.weight"), blk.g("fc.bias"), compute))
-        self._dgrad(self.d_fc, FC, blk.p("fc.weight"), self.d_pool, D, B, FC, D, compute)
+        composed = fused and getattr(self, "_composed", False)
+        if composed:
+            def head_grads():  # fc_out and d_fc exist only for the two weight gradients: all of it beside the chain
+                self._lin(self.pooled, D, blk.p("fc.weight"), blk.p("fc.bias"), self.fc_out, B, D, FC, ACT_NONE, compute)
+                self._wgrad(self.fc_out, FC, d_head, A2, B, FC, A2, blk.g("mean_fc.weight"), blk.g("mean_fc.bias"), compute)
+                self._dgrad(d_head, A2, blk.p("mean_fc.weight"), self.d_fc, FC, B, A2, FC, compute)
+                self._wgrad(self.pooled, D, self.d_fc, FC, B, D, FC, blk.g("fc.weight"), blk.g("fc.bias"), compute)
+            side(head_grads)
+        else:
+            side(lambda: self._wgrad(self.fc_out, FC, d_head, A2, B, FC, A2, blk.g("mean_fc.weight"), blk.g("mean_fc.bias"), compute))
+            self._dgrad(d_head, A2, blk.p("mean_fc.weight"), self.d_fc, FC, B, A2, FC, compute)
+            side(lambda: self._wgrad(self.pooled, D, self.d_fc, FC, B, D, FC, blk.g("fc.weight"), blk.g("fc.bias"), compute))
+            self._dgrad(self.d_fc, FC, blk.p("fc.weight"), self.d_pool, D, B, FC, D, compute)
         if fused:
             # the whole input-gradient chain of the encoder layers in one launch (csrc/pr_fused.hip); the weight gradients
             # stay per-op GEMMs on the side stream and read the dZ operands that launch wrote
@@ -311,8 +332,8 @@ class PlanRecognition:
                           self.stats[2 * l], self.stats[2 * l + 1]]
                 dz += [self.dv[l], self.d_ff1[l], self.dv1[l], self.d_qkv[l]]
                 lng += [blk.g(p + "norm1.weight"), blk.g(p + "norm1.bias"), blk.g(p + "norm2.weight"), blk.g(p + "norm2.bias")]
-            call("tacorl_pr_encoder_bwd_fused", ptr(blk.param), self._foff, ptr(self.d_pool), ptr(self.dx),
-                 ops.ptr_array(saved), ops.ptr_array(dz), ops.ptr_array(self._wt), ptr(self._lnpart), ops.ptr_array(lng),
+            call("tacorl_pr_encoder_bwd_fused", ptr(blk.param), self._foff, None if composed else ptr(self.d_pool), ptr(d_head),
+                 ptr(self._Wc), A2, ptr(self.dx), ops.ptr_array(saved), ops.ptr_array(dz), ops.ptr_array(self._wt), ptr(self._lnpart), ops.ptr_array(lng),
                  B, D, T, self.H, FF, self.L, ops.stream())
 
             def wgrads():

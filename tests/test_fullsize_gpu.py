@@ -489,12 +489,18 @@ def _tacorl_oracle(mod, cams, latent, finetune):
     return O, spec, P
 
 
-def _compare(got, ologs, rtol, grads=None, ograds=None, grad_rtol=None, plan=None, oplan=None, min_common=8):
+def _compare(got, ologs, rtol, grads=None, ograds=None, grad_rtol=None, plan=None, oplan=None, min_common=8, acc_atol=None):
+    """acc_atol: absolute tolerance for the *_accuracy logs - means of 0/1 argmax decisions, which move in steps of 1 / rows when
+    a near-tie flips under another operand rounding (bf16 comparisons only: a few decisions)."""
     bad = []
     common = set(ologs) & set(got)
     assert len(common) >= min_common, (sorted(ologs), sorted(got))
     for k in sorted(common):
         v = float(ologs[k])
+        if acc_atol is not None and k.endswith("accuracy"):
+            if abs(got[k] - v) > acc_atol:
+                bad.append(f"{k}: hip {got[k]:.8g} oracle {v:.8g} (more than {acc_atol:.4g} apart)")
+            continue
         if abs(got[k] - v) > rtol * max(abs(v), 1e-3):
             bad.append(f"{k}: hip {got[k]:.8g} oracle {v:.8g}")
     if plan is not None:
@@ -661,7 +667,7 @@ def test_fullsize_playlmp_c1_matches_oracle(compute, rtol):
     if compute == "bf16":
         with O.operand_rounding(torch.bfloat16):
             ologs, ograds = O.playlmp_step(P, opt, batch, nz, ["rgb_static"], step=False)
-        bad = _compare(got, ologs, rtol, min_common=5)
+        bad = _compare(got, ologs, rtol, min_common=5, acc_atol=3.0 / (32 * 15))  # (3 of the 480 gripper decisions)
         ev = lambda Pp: O.playlmp_step(Pp, opt, batch, nz, ["rgb_static"], step=False)[1]  # noqa: E731
         bad += _bf16_grad_check(mod, ev, ev, P, ograds)
     else:

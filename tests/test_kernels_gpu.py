@@ -1109,6 +1109,26 @@ def test_plan_recognition_fused_train_forward():
             gf[o: o + n] = 0
             continue
         assert relerr(gf[o: o + n], gp[o: o + n]) < 1e-2, ("fused backward", name, relerr(gf[o: o + n], gp[o: o + n]))
+    # composed posterior head (prepare_inference() issued: head = Wc pooled + bc and the plan sample inside the forward launch,
+    # d_pool = d_head Wc inside the backward launch, fc_out / d_fc only for the two weight gradients)
+    eps, plan = rnd(B, A, seed=21).to(dev), torch.full((B, A), float("nan"), device=dev)
+    pr.fused_train = pr.fused_backward = True
+    pr.prepare_inference()
+    headc = pr.forward(emb, D, B, T, 1, train=True, prepared=True, sample=(eps, plan)).clone()
+    assert pr._composed
+    pr.blk.grad.zero_()
+    for v in pr.blk.grad_views.values():
+        v.fill_(float("nan"))
+    dxc = pr.backward(d_head, B, T, 1).clone()
+    torch.cuda.synchronize()
+    gc = pr.blk.grad.clone()
+    assert relerr(headc, res[(True, True)][0]) < 5e-3, relerr(headc, res[(True, True)][0])
+    sd = F.softplus(headc[:, A:]) + pr.min_std
+    assert relerr(plan, torch.tanh(headc[:, :A] + eps * sd)) < 1e-5
+    assert relerr(dxc, dxf) < 6e-3, relerr(dxc, dxf)
+    for name, (o, _, n) in pr.blk.off.items():
+        if not name.startswith("layernorm."):
+            assert torch.isfinite(gc[o: o + n]).all() and relerr(gc[o: o + n], gp[o: o + n]) < 1e-2, ("composed head", name)
     (h0, s0, dx0, g0, _), (h1, s1, dx1, g1, _) = res[(False, False)], res[(True, True)]
     for k in s0:
         for l, (a, b) in enumerate(zip(s0[k], s1[k])):
