@@ -87,6 +87,13 @@ int tacorl_rnn_linear_bwd_step(const void* x_bf16, const void* wt_bf16, const fl
 int tacorl_rnn_wgrad_supported(int R, int M, int N);
 int tacorl_rnn_wgrad(const void* dz_bf16, int ld_dz, const void* x_bf16, int ld_x, int R, int M, int N, float* dw,
                      float* db, int accumulate, tacorl_stream_t stream);
+/* The same products for a FEW output rows and many reduction rows (the action decoder's 182 x H output heads): dz bf16
+ * [R][ld_dz] with Mp >= rows columns in use (Mp % 128 == 0, columns >= rows zero), x bf16 [R][ld_x]; R is cut into `slabs` row
+ * ranges (R % (64 slabs) == 0) that run side by side, a second launch sums the partial results in slab order into
+ * dw[rows][N] / db[rows].  ws: tacorl_rnn_wgrad_slabs_ws_bytes(slabs, Mp, N). */
+size_t tacorl_rnn_wgrad_slabs_ws_bytes(int slabs, int Mp, int N);
+int tacorl_rnn_wgrad_slabs(const void* dz_bf16, int ld_dz, const void* x_bf16, int ld_x, int R, int Mp, int N, int rows,
+                           int slabs, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes, tacorl_stream_t stream);
 /* The BPTT wavefront launch: nprob <= 4 problems y[p] = (x[p] Wt[p]^T + addend[p]) * [mask_src[p] > 0] (addend / mask
  * entries may be NULL) of one shape, fp32 y + optional bf16 copy: recurrent gradient steps of all layers and the
  * projection dH_{l-1}[t] = dZ_l[t] W_ih_l (Wt = W_ih_l^T) side by side (reference: autograd of nn.RNN, rnn_models.py:5-16). */

@@ -262,6 +262,11 @@ __global__ __launch_bounds__(64 * WG_NW) void rnn_wgrad_kernel(const __bf16* __r
       const int b = blockIdx.x; mt = b / NT; nt = b % NT;
     }
   }
+  // blockIdx.y: row slab (R rows each) with its own output (tacorl_rnn_wgrad_slabs: few output tiles, many rows)
+  dz += (long)blockIdx.y * R * ld_dz;
+  x += (long)blockIdx.y * R * ld_x;
+  dw += (long)blockIdx.y * MT * WG_T * ld_w;
+  if (db) db += (long)blockIdx.y * MT * WG_T;
   constexpr int WG_OP_BYTES = WG_R * WG_T * 2, WG_STAGE_BYTES = 2 * WG_OP_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l16 = lane & 15, q = l16 >> 2, pc = l16 & 3;
@@ -351,14 +356,14 @@ extern "C" int tacorl_rnn_wgrad_supported(int R, int M, int N) {
 }
 template <int WG_R, int WG_S>
 static int launch_wgrad(const void* dz_bf16, int ld_dz, const void* x_bf16, int ld_x, int R, int M, int N, float* dw, float* db,
-                        int accumulate, hipStream_t st) {
+                        int accumulate, hipStream_t st, int slabs = 1) {
   constexpr int lds = WG_S * 2 * WG_R * WG_T * 2;
   auto kern = rnn_wgrad_kernel<WG_R, WG_S>;
   static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
   const int MT = M / WG_T, NT = N / WG_T;
-  hipLaunchKernelGGL(kern, dim3(MT * NT), dim3(64 * WG_NW), lds, st, (const __bf16*)dz_bf16, ld_dz, (const __bf16*)x_bf16, ld_x, R, MT,
-                     NT, dw, N, db, accumulate);
+  hipLaunchKernelGGL(kern, dim3(MT * NT, slabs), dim3(64 * WG_NW), lds, st, (const __bf16*)dz_bf16, ld_dz, (const __bf16*)x_bf16, ld_x,
+                     R, MT, NT, dw, N, db, accumulate);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 /* dw[M][N] (+)= dz^T x, db[M] (+)= column sums of dz;  dz bf16 [R][ld_dz] (M columns used), x bf16 [R][ld_x] (N columns) */
@@ -369,6 +374,48 @@ extern "C" int tacorl_rnn_wgrad(const void* dz_bf16, int ld_dz, const void* x_bf
   // measured (R = 3840, 2048 x 2048, us): 64 rows x 2 stages 59.6, x 3 72.2, x 4 58.1, 128 x 2 83.8, 32 x 4 77.2 - the launch
   // moves 491 MB through LDS-DMA at 8.5 TB/s, the same chip-wide ingest rate the ring GEMM's DMA-only run reaches
   return launch_wgrad<64, 2>(dz_bf16, ld_dz, x_bf16, ld_x, R, M, N, dw, db, accumulate, (hipStream_t)stream);
+}
+
+// out[r][c] (+)= sum over slabs of part[s][r][c] for r < rows (slab pitch Mp rows), in slab order; the bias column likewise
+__global__ __launch_bounds__(256) void wgrad_slab_sum_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int slabs,
+                                                             int Mp, int N, int rows, float* __restrict__ dw, float* __restrict__ db,
+                                                             int accumulate) {
+  const long total = (long)rows * N / 4;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total + rows; q += (long)gridDim.x * 256) {
+    if (q < total) {
+      f32x4 v = accumulate ? *reinterpret_cast<const f32x4*>(dw + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s_ = 0; s_ < slabs; s_++) v += *reinterpret_cast<const f32x4*>(part + (long)s_ * Mp * N + 4 * q);
+      *reinterpret_cast<f32x4*>(dw + 4 * q) = v;
+    } else if (db) {
+      const int r = (int)(q - total);
+      float v = accumulate ? db[r] : 0.f;
+      for (int s_ = 0; s_ < slabs; s_++) v += bpart[(long)s_ * Mp + r];
+      db[r] = v;
+    }
+  }
+}
+extern "C" size_t tacorl_rnn_wgrad_slabs_ws_bytes(int slabs, int Mp, int N) { return (size_t)slabs * Mp * ((size_t)N + 1) * 4; }
+/* dw[rows][N] (+)= dz^T x and db[rows] (+)= column sums of dz for a FEW output rows and many reduction rows: dz bf16 [R][ld_dz]
+ * with Mp >= rows columns used (a multiple of 128; columns >= rows hold zeros), x bf16 [R][ld_x].  R is cut into `slabs` row
+ * ranges (R % (64 slabs) == 0) that run side by side - Mp / 128 x N / 128 output tiles alone would leave most of the chip
+ * idle - and a second launch sums their partial results in slab order.  The action decoder's 182 x 2048 output heads
+ * (reference action_decoder_logistic.py:44-52): 97 us as the generic split GEMM + slab reduce at 3 840 rows. */
+extern "C" int tacorl_rnn_wgrad_slabs(const void* dz_bf16, int ld_dz, const void* x_bf16, int ld_x, int R, int Mp, int N, int rows,
+                                      int slabs, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes,
+                                      tacorl_stream_t stream) {
+  if (slabs < 1 || R % slabs || !tacorl_rnn_wgrad_supported(R / slabs, Mp, N) || rows < 1 || rows > Mp || ld_dz % 8 || ld_x % 8 ||
+      ld_dz < Mp || ld_x < N)
+    return TACORL_EINVAL;
+  if (((uintptr_t)dz_bf16 | (uintptr_t)x_bf16 | (uintptr_t)dw | (uintptr_t)ws) & 15) return TACORL_EINVAL;
+  if (ws_bytes < tacorl_rnn_wgrad_slabs_ws_bytes(slabs, Mp, N)) return TACORL_ENOMEM;
+  float* part = (float*)ws;
+  float* bpart = part + (size_t)slabs * Mp * N;
+  const int rc = launch_wgrad<64, 2>(dz_bf16, ld_dz, x_bf16, ld_x, R / slabs, Mp, N, part, bpart, 0, (hipStream_t)stream, slabs);
+  if (rc != TACORL_OK) return rc;
+  const long total = (long)rows * N / 4 + rows;
+  hipLaunchKernelGGL(wgrad_slab_sum_kernel, dim3((int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, part, bpart, slabs, Mp, N, rows, dw, db, accumulate);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
 // dst[c][r] = bf16(src[r][c]): 32 x 32 tiles through LDS (R, C multiples of 32)

@@ -293,6 +293,7 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
         if optimize:
             ops.adam_step_batch([(blk.param, blk.grad, blk.m, blk.v, self.lr, 0.0, blk.step, None, 0.0)
                                  for blk in (net, pr.blk, ad.blk)])
+        ops.mark("end")
 
     def reduce_grads():
         if reduce_on:
@@ -332,6 +333,7 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     cams, net, pr, ad = self.plan_proposal_obs_modalities, self.net, self.pr, self.ad
     R, Ec, A, cd = B * T, 32 * len(cams), pr.A, self.compute
     xd = BF16 if self.img_dtype == torch.bfloat16 else F32
+    ops.mark("start")
     for j, c in enumerate(cams):
         H, W = hw[c]
         fused = (cd == BF16 and xd == BF16 and bool(ops.L.lib().tacorl_encoder_fused_supported(H, W))
@@ -351,6 +353,7 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
                  ops.ptr_array([self.f_out[c]]), ops.ptr_array([self.f_act[c]]), ops.int_array([R]), H, W, xd, cd,
                  ops.stream())
         ops.copy_cols(self.f_out[c], 0, 32, self.emb, 32 * j, Ec, R, 32)
+    ops.mark("encoded")
     # Branches (torch streams: branches of the captured graph).  The step is a long chain of small kernels; what does not
     # depend on each other runs side by side: the logging-only random-plan decoder pass beside the plan proposal /
     # recognition forward, the plan proposal's backward beside the decoder's, the decoder's and the plan recognition's
@@ -372,12 +375,15 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
             pr.prepare_inference()
             pr_ready = torch.cuda.Event()
             pr_ready.record(s_rand)
+            # (NOT pr.prepare_backward(): its transposes ride on the weight-gradient stream, behind the decoder's weight
+            # gradients - the plan recognition's backward then waits for those, and that serialisation is faster: see there)
         call("tacorl_uniform_actions", ptr(self.noise["u_plan"]), ptr(self.rplan), A, B, A, 0, ops.stream())
         if ad.twin_ok(B, cd):
             twin = ad.twin_input_proj(self.rplan, self.emb, Ec, B, T, T - 1)
             # weights-only preparation of the real pass and of the backward rides on this branch (joined before the pass)
             ad.refresh_mirrors(B, T - 1)
             ad_prepared = ad.prepare_backward(B, T - 1, cd) if getattr(self, "early_prepare", True) else False
+            ops.mark("rand:prepared")
         else:
             ad.forward(self.rplan, self.emb, Ec, B, T, T - 1, cd)
             ad.loss(acts, ops._at(self.logs, 4), B, T, T - 1, want_grad=False)
@@ -397,6 +403,7 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     ops.copy_cols(self.gact, self.g_yoff, Ec, self.S, Ec, 2 * Ec, B, Ec)
     ops.mlp_fwd([self.S], 2 * Ec, [net.head()], [self.pact], [B], net.head_dims, net.head_acts, cd, params_bf16=pb_h)
     head_pp = self.pact[self.p_yoff: self.p_yoff + B * 2 * A]
+    ops.mark("pp_fwd")
     if pr_ready is not None:
         main.wait_event(pr_ready)
     head_pr = pr.forward(self.emb, Ec, B, T, cd, train=getattr(self, "_pr_train", False), prepared=pr_ready is not None,
@@ -404,6 +411,7 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     call("tacorl_gauss_kl_balanced", ptr(head_pr), ptr(head_pp), ptr(self.d_head_pr), ptr(self.d_head_pp), B, A,
          float(self.kl_alpha), float(self.kl_beta), float(pr.min_std), int(self.kl_balancing), gs, ptr(self.logs),
          ops.stream())
+    ops.mark("kl")
     # plan proposal backward (needs only the KL's gradient): its own branch; d_emb gets its share after the join
     s_pp.wait_stream(main)
     with torch.cuda.stream(s_pp):
@@ -422,6 +430,7 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
         call("tacorl_pr_sample", ptr(head_pr), ptr(self.noise["eps_plan"]), ptr(self.plan), None, None, B, A,
              float(pr.min_std), ops.stream())
     main.wait_stream(s_rand)
+    ops.mark("ad:start")
     # (mirrors_current: the branch above has refreshed the bf16 mirrors of the weights - in the random-plan pass of its own, or explicitly)
     ad.forward(self.plan, self.emb, Ec, B, T, T - 1, cd, mirrors_current=True, twin=twin)
     if twin is not None:
@@ -431,14 +440,17 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     ad.loss(acts, ops._at(self.logs, 2), B, T, T - 1, want_grad=True, grad_scale=gs)
     if self.add_random_plan_loss:
         raise NotImplementedError("add_random_plan_loss=True is not used by any in-scope config")
+    ops.mark("ad:loss")
     # ---- backward
     ad.backward(B, T - 1, cd, need_input_grad=True, wgrad_stream=s_wg, join=False, prepared=ad_prepared)
     self.d_emb.zero_()
     call("tacorl_ad_input_bwd", ptr(ad.dx_seq), ptr(self.d_plan), ptr(self.d_emb), Ec, B, T, T - 1, ad.P, ad.E, 1,
          ops.stream())
+    ops.mark("ad:bwd")
     call("tacorl_pr_sample_bwd", ptr(head_pr), ptr(self.noise["eps_plan"]), ptr(self.d_plan), ptr(self.d_head_pr), B, A,
          float(pr.min_std), ops.stream())
     dx = pr.backward(self.d_head_pr, B, T, cd, wgrad_stream=s_wg)
+    ops.mark("pr:bwd")
     ops.copy_cols(dx, 0, pr.D, self.d_emb, 0, Ec, R, pr.D_in, accumulate=True)
     main.wait_stream(s_pp)
     ops.copy_cols(self.dS, 0, 2 * Ec, self.d_emb, 0, T * Ec, B, Ec, accumulate=True)
@@ -450,8 +462,10 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
                  and ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(1, ops.int_array([R]), H, W) > 0)  # forward and backward
         ops.encoder_bwd([self.frames[c]], [net.enc(c)], [self.f_act[c]], [self.f_dout[c]], [net.enc(c, net.grad)], H, W, cd,
                         fused=fused)
+    ops.mark("enc:bwd")
     main.wait_stream(s_wg)
     main.wait_stream(s_rand)
+    ops.mark("joined")
 
 
 def _named_gradients(self):

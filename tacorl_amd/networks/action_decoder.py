@@ -124,7 +124,8 @@ class ActionDecoderLogistic:
         self.rnn_ws = torch.empty(max(256, nb), dtype=torch.uint8, device=self.dev)
         # bf16 mode: hidden states and the H x H recurrent weights also live as bf16 (the ring GEMM's operands)
         bf = lambda *s: torch.zeros(*s, device=self.dev, dtype=torch.bfloat16)  # noqa: E731
-        self.hb = [bf(R, H) for _ in range(self.L)]
+        # (rows padded to a multiple of 64 with zeros: the top layer's copy is also the row-slabbed heads weight gradient's operand)
+        self.hb = [bf((R + 63) // 64 * 64, H) for _ in range(self.L)]
         self.h0b = bf(B, H)
         self.whb = [bf(H, H) for _ in range(self.L)]
         self.wib = [None] + [bf(H, H) for _ in range(1, self.L)]  # W_ih of layers >= 1 (H x H)
@@ -197,7 +198,7 @@ class ActionDecoderLogistic:
         ok = getattr(self, "heads_dgrad_ring", True) and bool(ops.L.lib().tacorl_rnn_linear_supported(R, KP, self.hidden))
         if ok and getattr(self, "_hd_shape", None) != (R, KP):
             ops.note_alloc()
-            self.d_heads_b = torch.zeros(R, KP, device=self.dev, dtype=torch.bfloat16)
+            self.d_heads_b = torch.zeros((R + 63) // 64 * 64, KP, device=self.dev, dtype=torch.bfloat16)  # (pad rows stay zero)
             self.headwt_b = torch.zeros(self.hidden, KP, device=self.dev, dtype=torch.bfloat16)
             self._hd_shape = (R, KP)
         return ok
@@ -466,16 +467,33 @@ class ActionDecoderLogistic:
             with torch.cuda.stream(wgrad_stream):
                 fn()
 
-        side(lambda: self._wgrad(self.h[L - 1], H, self.d_heads, self.NHP, R, H, self.NH, blk.g("mean_fc.weight"),
-                                 blk.g("mean_fc.bias"), compute))
         fast = self._bwd_fast(B, compute)
-        if fast and self._heads_ring(R):
+        ring = fast and self._heads_ring(R)
+        if ring:
             # dH = d_heads W through the ring GEMM (K = 182 padded to 256, two k-steps): the generic GEMM spends 64 us at
             # 3 840 rows on this K-short, epilogue-bound product.  Operands: d_heads as K-padded bf16, W^T K-padded.
             KP = self.headwt_b.shape[1]
             if not prepared:
                 call("tacorl_transpose_pad_to_bf16", blk.p("mean_fc.weight"), ptr(self.headwt_b), self.NH, H, KP, ops.stream())
             call("tacorl_pad_to_bf16", ptr(self.d_heads), self.NHP, ptr(self.d_heads_b), KP, R, self.NH, ops.stream())
+        # the heads' weight gradient [182][H] = d_heads^T h: from the same bf16 operands through the transposing-read kernel
+        # of the recurrent matrices, the rows cut into slabs that run side by side (2 x 16 output tiles alone would leave the
+        # chip idle); generic split GEMM + slab reduce otherwise (97 us at 3 840 rows)
+        Rp = (R + 63) // 64 * 64
+        slabs = max(d for d in range(1, 9) if (Rp // 64) % d == 0)
+        if (ring and getattr(self, "heads_wgrad_slabs", True) and H % 128 == 0
+                and bool(ops.L.lib().tacorl_rnn_wgrad_supported(Rp // slabs, self.headwt_b.shape[1], H))):
+            def heads_wgrad():
+                KP = self.headwt_b.shape[1]
+                nb = ops.L.lib().tacorl_rnn_wgrad_slabs_ws_bytes(slabs, KP, H)
+                ws = ops.workspace(nb, self.dev, "ad_heads_wgrad")
+                call("tacorl_rnn_wgrad_slabs", ptr(self.d_heads_b), KP, ptr(self.hb[L - 1]), H, Rp, KP, H, self.NH, slabs,
+                     blk.g("mean_fc.weight"), blk.g("mean_fc.bias"), 0, ptr(ws), ws.numel(), ops.stream())
+            side(heads_wgrad)
+        else:
+            side(lambda: self._wgrad(self.h[L - 1], H, self.d_heads, self.NHP, R, H, self.NH, blk.g("mean_fc.weight"),
+                                     blk.g("mean_fc.bias"), compute))
+        if ring:
             call("tacorl_rnn_linear_bwd_batch", 1, ops.ptr_array([self.d_heads_b]), ops.ptr_array([self.headwt_b]), None, H, None,
                  ops.ptr_array([self.dH]), None, R, KP, H, ops.stream())
         else:

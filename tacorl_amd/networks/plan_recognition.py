@@ -264,7 +264,19 @@ class PlanRecognition:
         call("tacorl_add_layernorm_bwd", ptr(dy), ptr(x), ptr(res), w, ptr(stats), ptr(dv), dw, db, R, D, 0, ptr(ws),
              ws.numel(), ops.stream())
 
-    def backward(self, d_head, B, T, compute, wgrad_stream=None):
+    def prepare_backward(self, B):
+        """Weights-only preparation of the fused backward: linear1.weight^T / linear2.weight^T of every layer as bf16."""
+        blk, D, FF = self.blk, self.D, self.FF
+        if getattr(self, "_wt", None) is None or self._lnpart.numel() != self.L * 2 * B * 64:
+            ops.note_alloc()
+            self._wt = [torch.zeros(FF * D, device=self.dev, dtype=torch.bfloat16) for _ in range(2 * self.L)]
+            self._lnpart = torch.zeros(self.L * 2 * B * 64, device=self.dev)
+        for l in range(self.L):
+            p = f"transformer_encoder.layers.{l}."
+            call("tacorl_transpose_to_bf16", blk.p(p + "linear1.weight"), ptr(self._wt[2 * l]), FF, D, ops.stream())
+            call("tacorl_transpose_to_bf16", blk.p(p + "linear2.weight"), ptr(self._wt[2 * l + 1]), D, FF, ops.stream())
+
+    def backward(self, d_head, B, T, compute, wgrad_stream=None, prepared=False):
         """d_head: (B, 2A) gradient w.r.t. [mean | var_raw].  Fills self.blk.grad and returns the
         (B*T, D) gradient w.r.t. the (padded) input embeddings.
         wgrad_stream: the Linear weight gradients - read only by the optimiser - are issued on that stream (a branch
@@ -291,20 +303,13 @@ class PlanRecognition:
         fused = (getattr(self, "_fused_saved", None) == (B, T) and getattr(self, "fused_backward", True)
                  and not getattr(self, "_dropping", False))
         wt_ready = None
-        if fused:
-            # W1^T / W2^T as bf16 for the fused chain: weights only, so beside the head's input gradients
-            if getattr(self, "_wt", None) is None or self._lnpart.numel() != self.L * 2 * B * 64:
-                ops.note_alloc()
-                self._wt = [torch.zeros(FF * D, device=self.dev, dtype=torch.bfloat16) for _ in range(2 * self.L)]
-                self._lnpart = torch.zeros(self.L * 2 * B * 64, device=self.dev)
-            main = torch.cuda.current_stream()
-
-            def transposes():
-                for l in range(self.L):
-                    p = f"transformer_encoder.layers.{l}."
-                    call("tacorl_transpose_to_bf16", blk.p(p + "linear1.weight"), ptr(self._wt[2 * l]), FF, D, ops.stream())
-                    call("tacorl_transpose_to_bf16", blk.p(p + "linear2.weight"), ptr(self._wt[2 * l + 1]), D, FF, ops.stream())
-            side(transposes)
+        if fused and not prepared:
+            # W1^T / W2^T as bf16 for the fused chain: weights only, so on the weight-gradient stream.  NB that stream's queue
+            # may hold another network's weight gradients (PlayLMP: the action decoder's), which the chain below then waits
+            # for.  Measured, that wait PAYS: with the transposes issued early elsewhere (prepare_backward(), prepared=True)
+            # the decoder's weight gradients run beside this chain and the encoder backward and the step is 20-40 us
+            # slower (chip-wide kernels beside a latency-bound chain).
+            side(lambda: self.prepare_backward(B))
             if wgrad_stream is not None:
                 wt_ready = torch.cuda.Event()
                 wt_ready.record(wgrad_stream)
@@ -324,7 +329,8 @@ class PlanRecognition:
         if fused:
             # the whole input-gradient chain of the encoder layers in one launch (csrc/pr_fused.hip); the weight gradients
             # stay per-op GEMMs on the side stream and read the dZ operands that launch wrote
-            main.wait_event(wt_ready) if wt_ready is not None else None
+            if wt_ready is not None:
+                torch.cuda.current_stream().wait_event(wt_ready)
             saved, dz, lng = [], [], []
             for l in range(self.L):
                 p = f"transformer_encoder.layers.{l}."

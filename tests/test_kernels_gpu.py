@@ -1264,7 +1264,7 @@ def test_action_decoder_heads_dgrad_ring(B, T):
     acts[..., 6] = torch.sign(acts[..., 6])
     loss = torch.zeros(1, device=dev)
     res = {}
-    for ring in (True, False):
+    for ring in (True, False):  # (True: also the heads' weight gradient through the row-slabbed transposing-read kernel)
         ad.heads_dgrad_ring = ring
         ad.forward(plan, emb, E, B, T, T - 1, ops.BF16)
         ad.loss(acts, ops.ptr(loss), B, T, T - 1, want_grad=True)
@@ -1278,7 +1278,8 @@ def test_action_decoder_heads_dgrad_ring(B, T):
     R, KP = B * (T - 1), ad.d_heads_b.shape[1]
     ref = torch.zeros(R, KP, device=dev)
     ref[:, : ad.NH] = ad.d_heads[:, : ad.NH]
-    assert torch.equal(ad.d_heads_b, ref.to(torch.bfloat16))
+    assert torch.equal(ad.d_heads_b[:R], ref.to(torch.bfloat16))
+    assert ad.d_heads_b.shape[0] % 64 == 0 and not ad.d_heads_b[R:].any() and not ad.hb[-1][R:].any()  # (zero pad rows: slab operands)
     wt = torch.zeros(H, KP, device=dev)
     o = ad.blk.off["mean_fc.weight"][0]  # (the four heads' weights sit back to back: one NH x H matrix)
     wt[:, : ad.NH] = ad.blk.param[o: o + ad.NH * H].view(ad.NH, H).t()
