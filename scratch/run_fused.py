@@ -3,7 +3,7 @@ import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__
 from tacorl_amd import _lib, blocks, ops
 if os.environ.get("TACORL_SCRATCH_LIB"): _lib.LIB_PATH = os.environ["TACORL_SCRATCH_LIB"]
 dev = torch.device('cuda:0')
-H = W = 84
+H = W = int(os.environ.get("HW", 84))
 spec = sys.argv[1:] or ["4096", "256", "512", "512"]   # "512a" = that problem also saves its activations (training problems)
 n = [int(x.rstrip("a")) for x in spec]
 flats, imgs, outs, packed, acts = [], [], [], [], []
@@ -38,7 +38,8 @@ if hasattr(L, "tacorl_ef_stamps_read"):
     run(); torch.cuda.synchronize()
     L.tacorl_ef_stamps_read(buf, 0)
     names = ["prologue", "dma issue", "conv1", "barrier1", "conv2", "barrier2", "conv3 mfma", "soft-argmax", "fc tail", "img wait+barrier"]
-    tot = sum(buf[:10])
+    if any(buf[10:13]): print("band phases: compute", buf[10], "own DMA wait", buf[11], "barrier", buf[12])
+    tot = sum(buf[:13])
     for k, nm in enumerate(names): print(f"{nm:18s} {buf[k]:9d} clk  {100.0 * buf[k] / tot:5.1f} %")
     print("total clk", tot)
     if any(buf[16:64]):
