@@ -173,6 +173,21 @@ int launch_ring(const RnnArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// Batched launches as 64 x 32 tiles: a 4-stage ring (96 KB of LDS, one workgroup per CU) when the whole launch is at most
+// 192 workgroups (a 256-workgroup single problem of the headline step runs beside other branches, whose kernels the 96 KB
+// keep off its CUs: +2.5 us there) - with few rows (PlayLMP at B = 32: M = 64 with the twin rows, 192 workgroups) the launch is a chain of
+// 16 L2 round trips per workgroup and three stages in flight instead of one take 12.5 -> ~9 us off each of the step's 33
+// launches (1.340 -> 1.279 ms/step, same box) - and the 2-stage ring (48 KB, three workgroups per CU) otherwise.
+// TACORL_RNN_SMALL_STAGES = 2 / 3 / 4 overrides (A/B).
+static int launch_small(const RnnBatch& ab, int nprob, hipStream_t st) {
+  const RnnArgs& a = ab.p[0];
+  const int MT = (a.M + a.M2 + 63) / 64, NT = a.N / 32, NTX = (NT + 7) / 8;
+  const char* e = getenv("TACORL_RNN_SMALL_STAGES");
+  const int stages = e && atoi(e) ? atoi(e) : (8 * MT * NTX * nprob <= 192 ? 4 : 2);  // (0 / unset: by the launch's size)
+  if (stages == 4) return launch_ring<64, 32, 4>(ab, nprob, st);
+  if (stages == 3) return launch_ring<64, 32, 3>(ab, nprob, st);
+  return launch_ring<64, 32, 2>(ab, nprob, st);
+}
 extern "C" int tacorl_rnn_linear_supported(int M, int K, int N) {
   return M >= 1 && K >= RB_K && K % RB_K == 0 && N >= 32 && N % 32 == 0 ? 1 : 0;
 }
@@ -220,10 +235,10 @@ extern "C" int tacorl_rnn_linear_bwd_batch(int nprob, const void* const* x_bf16,
   }
   {
     const char* se = getenv("TACORL_RNN_SMALL_UPTO");  // (see tacorl_rnn_linear_fwd_batch)
-    if (nprob <= (se ? atoi(se) : 2) && M % 64 == 0 && N % 32 == 0) return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
+    if (nprob <= (se ? atoi(se) : 2) && M % 64 == 0 && N % 32 == 0) return launch_small(ab, nprob, (hipStream_t)stream);
   }
   if (M % 128 == 0 && N % 64 == 0) return launch_ring<128, 64, 2, 8>(ab, nprob, (hipStream_t)stream);
-  return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
+  return launch_small(ab, nprob, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -517,7 +532,7 @@ static int rnn_fwd_batch(int nprob, const void* const* x_bf16, const void* const
   // (three problems as 768 small workgroups crowd the step's other branches).  TACORL_RNN_SMALL_UPTO overrides.
   const char* se = getenv("TACORL_RNN_SMALL_UPTO");
   const int small_upto = se ? atoi(se) : 2;  // problems per launch up to which the small tile is used
-  if (nprob <= small_upto && M % 64 == 0 && N % 32 == 0) return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
+  if (nprob <= small_upto && M % 64 == 0 && N % 32 == 0) return launch_small(ab, nprob, (hipStream_t)stream);
   {
     // twin launches of >= 512 rows: three problems as 128 x 64 tiles are 384 workgroups of 96 KB LDS - one and a half
     // rounds over the chip; as 128 x 128 tiles they are 192, each streaming 1 MB instead of 768 KB for twice the outputs
@@ -526,7 +541,7 @@ static int rnn_fwd_batch(int nprob, const void* const* x_bf16, const void* const
       return launch_ring<128, 128, 2, 8>(ab, nprob, (hipStream_t)stream);
   }
   if (M % 128 == 0 && N % 64 == 0) return launch_ring<128, 64, 2, 8>(ab, nprob, (hipStream_t)stream);
-  return launch_ring<64, 32, 2>(ab, nprob, (hipStream_t)stream);
+  return launch_small(ab, nprob, (hipStream_t)stream);
 }
 extern "C" int tacorl_rnn_linear_fwd_batch(int nprob, const void* const* x_bf16, const void* const* w_bf16,
                                            const float* const* bias, const float* const* addend, int ld_add,
