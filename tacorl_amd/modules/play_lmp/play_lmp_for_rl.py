@@ -325,6 +325,31 @@ def _playlmp_step(self, batch, noise=None, optimize=True, log_type="train", nchw
 
 
 
+def _playlmp_pp_forward(self, B, T, Ec, A, cd):
+    """Plan proposal: goal encoder on emb[:, -1], policy head on [emb[:, 0] | goal]; returns the (B, 2A) head view."""
+    from ... import ops
+    from ..._lib import BF16, call
+
+    net = self.net
+    ops.copy_cols(self.emb, (T - 1) * Ec, T * Ec, self.gin, 0, Ec, B, Ec)  # pp_goal input = emb[:, -1]
+    # bf16 mode: the goal encoder and the plan proposal's policy head run as the single-launch MLP kernels (forward, input
+    # gradients, weight gradients) on a bf16 mirror of their weights, as in the actor-critic engine.  (Per layer they are 7
+    # generic GEMM launches on this chain: hidden behind the random-plan decoder pass while that was a pass of its own -
+    # no gain then -, on the critical path since it rides in the real pass.)
+    pb_g = pb_h = None
+    if cd == BF16 and getattr(self, "fused_mlps", True):
+        import ctypes as C
+        call("tacorl_to_bf16_batch", 1, ops.ptr_array([net.genc()]), ops.ptr_array([net.genc_bf16()]),
+             (C.c_long * 1)(net.size - net.genc_off), ops.stream())
+        pb_g, pb_h = [net.genc_bf16()], [net.head_bf16()]
+    self._pp_bf16 = pb_g
+    ops.mlp_fwd([self.gin], Ec, [net.genc()], [self.gact], [B], net.genc_dims, net.genc_acts, cd, params_bf16=pb_g)
+    ops.copy_cols(self.emb, 0, T * Ec, self.S, 0, 2 * Ec, B, Ec)  # pp_state = emb[:, 0]
+    ops.copy_cols(self.gact, self.g_yoff, Ec, self.S, Ec, 2 * Ec, B, Ec)
+    ops.mlp_fwd([self.S], 2 * Ec, [net.head()], [self.pact], [B], net.head_dims, net.head_acts, cd, params_bf16=pb_h)
+    return self.pact[self.p_yoff: self.p_yoff + B * 2 * A]
+
+
 def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     """Device side of the PlayLMP step up to the gradients (fixed buffers only: hipGraph-capturable)."""
     from ... import ops
@@ -387,27 +412,21 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
         else:
             ad.forward(self.rplan, self.emb, Ec, B, T, T - 1, cd)
             ad.loss(acts, ops._at(self.logs, 4), B, T, T - 1, want_grad=False)
-    ops.copy_cols(self.emb, (T - 1) * Ec, T * Ec, self.gin, 0, Ec, B, Ec)  # pp_goal input = emb[:, -1]
-    # bf16 mode: the goal encoder and the plan proposal's policy head run as the single-launch MLP kernels (forward, input
-    # gradients, weight gradients) on a bf16 mirror of their weights, as in the actor-critic engine.  (Per layer they are 7
-    # generic GEMM launches on this chain: hidden behind the random-plan decoder pass while that was a pass of its own -
-    # no gain then -, on the critical path since it rides in the real pass.)
-    pb_g = pb_h = None
-    if cd == BF16 and getattr(self, "fused_mlps", True):
-        import ctypes as C
-        call("tacorl_to_bf16_batch", 1, ops.ptr_array([net.genc()]), ops.ptr_array([net.genc_bf16()]),
-             (C.c_long * 1)(net.size - net.genc_off), ops.stream())
-        pb_g, pb_h = [net.genc_bf16()], [net.head_bf16()]
-    ops.mlp_fwd([self.gin], Ec, [net.genc()], [self.gact], [B], net.genc_dims, net.genc_acts, cd, params_bf16=pb_g)
-    ops.copy_cols(self.emb, 0, T * Ec, self.S, 0, 2 * Ec, B, Ec)  # pp_state = emb[:, 0]
-    ops.copy_cols(self.gact, self.g_yoff, Ec, self.S, Ec, 2 * Ec, B, Ec)
-    ops.mlp_fwd([self.S], 2 * Ec, [net.head()], [self.pact], [B], net.head_dims, net.head_acts, cd, params_bf16=pb_h)
-    head_pp = self.pact[self.p_yoff: self.p_yoff + B * 2 * A]
+    # The plan proposal's forward (goal encoder -> policy head: a dependent chain of its own, ~55 us at B = 32) needs only the
+    # embeddings, like the plan recognition - but on its own branch beside the plan recognition's launch, joined at the KL,
+    # the step is SLOWER (1.252 -> 1.302 ms at B = 32, 2.365 -> 2.410 at B = 256, same-process A/B): a third concurrent
+    # branch at that point (the early preparation branch is still running) costs more than the 55 us it hides.  In line.
+    pp_side = s_pp if getattr(self, "pp_forward_side", False) else main
+    pp_side.wait_stream(main)
+    with torch.cuda.stream(pp_side):
+        head_pp = _playlmp_pp_forward(self, B, T, Ec, A, cd)
     ops.mark("pp_fwd")
     if pr_ready is not None:
         main.wait_event(pr_ready)
     head_pr = pr.forward(self.emb, Ec, B, T, cd, train=getattr(self, "_pr_train", False), prepared=pr_ready is not None,
                          sample=(self.noise["eps_plan"], self.plan) if pr_ready is not None else None)
+    main.wait_stream(pp_side)
+    pb_g = self._pp_bf16
     call("tacorl_gauss_kl_balanced", ptr(head_pr), ptr(head_pp), ptr(self.d_head_pr), ptr(self.d_head_pp), B, A,
          float(self.kl_alpha), float(self.kl_beta), float(pr.min_std), int(self.kl_balancing), gs, ptr(self.logs),
          ops.stream())
