@@ -6,8 +6,9 @@ from tacorl_amd import _lib
 dev = torch.device("cuda:0"); _lib.call("tacorl_hip_init", 0)
 attr, v0, v1 = sys.argv[1], eval(sys.argv[2]), eval(sys.argv[3])
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-mod = bench.build_module(dev, "bf16", 16, 1)
-batches = [bench.synth_batch(256, 16, 84, 84, dev, 1), bench.synth_batch(256, 16, 84, 84, dev, 2)]
+BSZ = int(os.environ.get("BSZ", 256))  # FINETUNE=1: C3 (action-decoder fine-tuning); BSZ: batch size
+mod = bench.build_module(dev, "bf16", 16, 1, finetune=bool(int(os.environ.get("FINETUNE", 0))))
+batches = [bench.synth_batch(BSZ, 16, 84, 84, dev, 1), bench.synth_batch(BSZ, 16, 84, 84, dev, 2)]
 mod.enable_graph(); mod.log_every_n_steps = 50
 def setv(path, v):
     torch.cuda.synchronize()  # (no graph may still be replaying when the captures are dropped)

@@ -346,7 +346,10 @@ class ActionDecoderLogistic:
             # that branch crashed hipStreamEndCapture on ROCm 7.2; forked from and joined into the main stream instead - with
             # the Adam step moved behind the join - it captured, and the step went 1.82 -> 2.10 ms: three concurrent
             # chains of chip-wide kernels slow each other more than the overlap returns)
-            self.backward(B, T - 1, module.compute, need_input_grad=False, wavefront=False)
+            # (round 4: BPTT as the wavefront of batched launches here too.  Round 2 measured it 35 % slower beside the CQL
+            # update; with the step as it is now - small-tile head / tail launches, one-launch RNN weight gradients - it is
+            # faster: C3 1.683 -> 1.571 ms/step, its B = 32 share 1.078 -> 0.903, same-process A/B)
+            self.backward(B, T - 1, module.compute, need_input_grad=False, wavefront=getattr(self, "finetune_wavefront", True))
             # defer_update (more than one GPU): the gradient block lives in the engine's arena and is reduced by the
             # step's second collective; the module steps it afterwards (update())
             if not defer_update:
@@ -446,9 +449,9 @@ class ActionDecoderLogistic:
         wgrad_stream: the weight gradients - which only the optimiser reads - go to that stream (a branch of a
         captured graph) beside the dependent chain heads -> BPTT -> input gradient; join=False leaves the join
         (`current.wait_stream(wgrad_stream)`) to the caller, who may put more work in front of it.
-        wavefront: BPTT as Tm+1 batched launches (_bptt_wavefront) - right when this backward has the chip to itself
-        (PlayLMP: 3.06 -> 2.98 ms/step); beside another chain (TACORL fine-tuning: a branch beside the CQL update) the
-        chip-wide batched launches cost more than they save (1.80 -> 2.43 ms/step), there one launch per step stays."""
+        wavefront: BPTT as Tm+1 batched launches (_bptt_wavefront) instead of one launch per (layer, step) and a projection
+        GEMM per layer (PlayLMP: 3.06 -> 2.98 ms/step in round 2; TACORL fine-tuning, a branch beside the CQL update: slower in
+        round 2 - 1.80 -> 2.43 - and faster in round 4 - 1.68 -> 1.57 -, see loss_step)."""
         blk, H, R, L = self.blk, self.hidden, B * Tm, self.L
         if getattr(self, "_bshape", None) != (B, Tm):
             ops.note_alloc()
