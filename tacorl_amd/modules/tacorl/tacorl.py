@@ -268,6 +268,17 @@ class TACORL(CQL_Offline):
         mods = self.plan_recognition_modalities
         # one camera: the frame embeddings are the transformer's input as they stand
         emb, ld = (self.f_out[mods[0]], 32) if len(mods) == 1 else (self.pr_in, self.pr_in.shape[1])
+        # fine-tuning: the decoder's weights-only preparation (bf16 mirrors, transposed copies for BPTT and the heads' input
+        # gradient: ~45 us at the head of the decoder's chain, which is the step's critical path in C3) beside the encoders
+        ad_prep, ad_prepared = None, False
+        if (with_ad and optimize and self.finetune_action_decoder and getattr(self, "ad_early_prepare", True)
+                and self.ad._bwd_fast(B, self.compute)):
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                self.ad.refresh_mirrors(B, T - 1)
+                ad_prepared = self.ad.prepare_backward(B, T - 1, self.compute)
+                ad_prep = torch.cuda.Event()
+                ad_prep.record(self._side_stream)
         e._encode_all()
         ops.mark("front:encoded")
         # Plan recognition -> plan -> (action-decoder loss) only need the frame embeddings; the first phase of
@@ -293,7 +304,10 @@ class TACORL(CQL_Offline):
                 # decoder's gradient block is part of the engine's arena: the step's second all-reduce covers it and
                 # the Adam step follows in the last segment (reference tacorl.py:206-233 has no dependency
                 # between this update and the CQL update)
-                self.ad.loss_step(self, self.acts, self.plan, B, T, True, defer_update=self._defer_ad_update())
+                if ad_prep is not None:
+                    self._pr_stream.wait_event(ad_prep)
+                self.ad.loss_step(self, self.acts, self.plan, B, T, True, defer_update=self._defer_ad_update(),
+                                  mirrors_current=ad_prep is not None, prepared=ad_prepared)
         if ad_on_side:
             # compute_action_decoder_update (tacorl.py:206-233), frozen decoder: 30 small dependent GEMMs that each
             # fill a fraction of the chip -> their own branch, joined at the end of the step
@@ -305,6 +319,8 @@ class TACORL(CQL_Offline):
             self._ad_join = self._side_stream
         e.action_ready = ready
         e.phase_a(encoded=True, optimize=optimize)
+        if ad_prep is not None:
+            main.wait_stream(self._side_stream)  # (every forked stream joins the capture's origin)
         segmented = self._segmented() or not self._use_graph
         if with_ad and not ad_on_side:
             if segmented or D.collectives_on(self.world_size):

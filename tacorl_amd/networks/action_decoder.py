@@ -320,7 +320,8 @@ class ActionDecoderLogistic:
              loss_out, B, T, Tm, self.Da, self.K, self.num_classes, float(self.gripper_alpha), float(grad_scale),
              ptr(ws), ws.numel(), ops.stream())
 
-    def loss_step(self, module, actions, plan, B, T, optimize, frozen=False, defer_update=False):
+    def loss_step(self, module, actions, plan, B, T, optimize, frozen=False, defer_update=False, mirrors_current=False,
+                  prepared=False):
         """TACORL.compute_action_decoder_update (reference tacorl.py:206-233): loss on emb[:, :-1],
         actions[:, :-1]; logged always, Adam step when fine-tuning."""
         from .._lib import LOG_SLOTS
@@ -338,7 +339,8 @@ class ActionDecoderLogistic:
             for j, c in enumerate(cams):
                 ops.copy_cols(module.f_out[c], 0, 32, module._ad_in, 32 * j, module._ad_in.shape[1], B * T, 32)
             emb, ld = module._ad_in, module._ad_in.shape[1]
-        self.forward(plan, emb, ld, B, T, T - 1, module.compute, frozen=frozen and not optimize)
+        # (mirrors_current / prepared: the caller has issued refresh_mirrors() / prepare_backward() for the current weights)
+        self.forward(plan, emb, ld, B, T, T - 1, module.compute, frozen=frozen and not optimize, mirrors_current=mirrors_current)
         slot = ops._at(module.engine.logs, LOG_SLOTS.index("action_loss"))
         self.loss(acts, slot, B, T, T - 1, want_grad=optimize, grad_scale=1.0 / module.world_size)
         if optimize:
@@ -349,7 +351,8 @@ class ActionDecoderLogistic:
             # (round 4: BPTT as the wavefront of batched launches here too.  Round 2 measured it 35 % slower beside the CQL
             # update; with the step as it is now - small-tile head / tail launches, one-launch RNN weight gradients - it is
             # faster: C3 1.683 -> 1.571 ms/step, its B = 32 share 1.078 -> 0.903, same-process A/B)
-            self.backward(B, T - 1, module.compute, need_input_grad=False, wavefront=getattr(self, "finetune_wavefront", True))
+            self.backward(B, T - 1, module.compute, need_input_grad=False, wavefront=getattr(self, "finetune_wavefront", True),
+                          prepared=prepared)
             # defer_update (more than one GPU): the gradient block lives in the engine's arena and is reduced by the
             # step's second collective; the module steps it afterwards (update())
             if not defer_update:
