@@ -9,7 +9,7 @@ for kv in sys.argv[1:]:
 dev = torch.device("cuda:0"); _lib.call("tacorl_hip_init", 0)
 for traced in (False, True):
     reader = ops.trace_marks(dev) if traced else None
-    mod = bench.build_module(dev, "bf16", 16, 1)
+    mod = bench.build_module(dev, "bf16", 16, 1, finetune=bool(int(os.environ.get("FINETUNE", 0))))
     batches = [bench.synth_batch(256, 16, 84, 84, dev, 1), bench.synth_batch(256, 16, 84, 84, dev, 2)]
     mod.enable_graph(); mod.log_every_n_steps = 50
     def run(n):
