@@ -407,8 +407,9 @@ int tacorl_pr_encoder_fused_train(const float* emb, int ld_emb, const float* par
  * d_pool [B][32] (gradient of the time-pooled output) to dx [B T][32] (gradient of the position-embedded input).
  * saved[9 l + k]: what tacorl_pr_encoder_fused_train wrote.  dz[4 l + k], k = 0..3, outputs - the dZ operands of the per-op
  * weight-gradient GEMMs: LayerNorm-2 input gradient [B T][32] (linear2), masked hidden gradient [B T][FF] (linear1),
- * LayerNorm-1 input gradient [B T][32] (out_proj), d(q|k|v) [B T][96] (in_proj).  wt[2 l + {0, 1}]: linear1.weight^T
- * [32][FF], linear2.weight^T [FF][32] as bf16 (tacorl_transpose_to_bf16).  ln_part: scratch of L * 2 * B * 64 floats;
+ * LayerNorm-1 input gradient [B T][32] (out_proj), d(q|k|v) [B T][96] (in_proj).  wt[4 l + {0, 1, 2, 3}]: linear1.weight^T
+ * [32][FF], linear2.weight^T [FF][32], out_proj.weight^T [32][32], in_proj_weight^T [32][96] as bf16
+ * (tacorl_transpose_to_bf16; the last two may be NULL: gathered from the fp32 block inside the launch).  ln_part: scratch of L * 2 * B * 64 floats;
  * ln_grads[4 l + k]: norm1.weight, norm1.bias, norm2.weight, norm2.bias gradients (written, not accumulated).
  * d_pool == NULL: d_pool = d_head Wc computed in the launch (d_head [B][A2], Wc [A2][32] from tacorl_pr_head_compose).
  * Reference: autograd through plan_recognition_transformer.py:70-88 (nn.TransformerEncoderLayer, post-norm, ReLU). */

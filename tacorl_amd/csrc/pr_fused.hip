@@ -313,6 +313,7 @@ struct PrBwdL {
   const float *xin, *qkv, *att, *proj, *x1, *ff1, *ff2, *st1, *st2;  // saved by the train-mode forward
   float *dvb, *d_ff1, *dv1b, *d_qkv;                                  // dZ operands of the weight-gradient GEMMs
   const __bf16 *w1t, *w2t;                                            // W1^T [32][FF], W2^T [FF][32]
+  const __bf16 *wot, *wint;                                           // Wo^T [32][32], Win^T [32][96] (or null: gathered from the fp32 block)
 };
 struct PrBwdArgs {
   const float* P;
@@ -480,8 +481,12 @@ __global__ __launch_bounds__(256) void pr_encoder_bwd_fused_kernel(PrBwdArgs a) 
 #pragma unroll
       for (int nt = 0; nt < 2; nt++) {
         bf16x8 wf;
+        if (S.wot) {
+          wf = *reinterpret_cast<const bf16x8*>(S.wot + (16 * nt + i) * PR_D + 8 * g);
+        } else {
 #pragma unroll
-        for (int q = 0; q < 8; q++) wf[q] = (__bf16)a.P[o.out_w + (long)(8 * g + q) * PR_D + 16 * nt + i];
+          for (int q = 0; q < 8; q++) wf[q] = (__bf16)a.P[o.out_w + (long)(8 * g + q) * PR_D + 16 * nt + i];
+        }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc, 0, 0, 0);
         *reinterpret_cast<f32x4*>(datt + i * 36 + 16 * nt + 4 * g) = acc;
@@ -557,8 +562,12 @@ __global__ __launch_bounds__(256) void pr_encoder_bwd_fused_kernel(PrBwdArgs a) 
       for (int ks = 0; ks < 3; ks++) {
         const bf16x8 df = *reinterpret_cast<const bf16x8*>(dqb + i * DQ_P + 32 * ks + 8 * g);
         bf16x8 wf;
+        if (S.wint) {
+          wf = *reinterpret_cast<const bf16x8*>(S.wint + (16 * nt + i) * (3 * PR_D) + 32 * ks + 8 * g);
+        } else {
 #pragma unroll
-        for (int q = 0; q < 8; q++) wf[q] = (__bf16)a.P[o.in_w + (long)(32 * ks + 8 * g + q) * PR_D + 16 * nt + i];
+          for (int q = 0; q < 8; q++) wf[q] = (__bf16)a.P[o.in_w + (long)(32 * ks + 8 * g + q) * PR_D + 16 * nt + i];
+        }
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, df, acc, 0, 0, 0);
       }
       dx[nt] = acc;
@@ -703,7 +712,8 @@ extern "C" int tacorl_pr_head_compose(const float* w_fc, const float* b_fc, cons
  * gradient of the time-pooled output d_pool [B][32] to dx [B T][32].  saved[9 l + k]: what tacorl_pr_encoder_fused_train
  * wrote; dz[4 l + k], k = 0..3: outputs for the per-op weight-gradient GEMMs - LayerNorm-2 input gradient [B T][32]
  * (linear2's dZ), the masked hidden gradient [B T][FF] (linear1's dZ), LayerNorm-1 input gradient [B T][32] (out-proj's
- * dZ), d(q|k|v) [B T][96] (in-proj's dZ); wt[2 l + {0,1}]: W1^T [32][FF], W2^T [FF][32] as bf16 (tacorl_transpose_to_bf16);
+ * dZ), d(q|k|v) [B T][96] (in-proj's dZ); wt[4 l + {0,1,2,3}]: W1^T [32][FF], W2^T [FF][32], Wo^T [32][32], Win^T [32][96] as bf16
+ * (tacorl_transpose_to_bf16; the last two may be NULL);
  * ln_part: scratch of L * 2 * B * 64 floats; ln_grads[4 l + k]: norm1.weight, norm1.bias, norm2.weight, norm2.bias gradients.
  * d_pool == NULL: d_pool = d_head Wc is computed in the launch (d_head [B][A2], Wc [A2][32] from tacorl_pr_head_compose).
  * Reference: autograd through plan_recognition_transformer.py:70-88 (nn.TransformerEncoderLayer, post-norm, ReLU). */
@@ -711,6 +721,8 @@ extern "C" int tacorl_pr_encoder_bwd_fused(const float* params, const long* offs
                                            const float* Wc, int A2, float* dx, const float* const* saved, float* const* dz,
                                            const void* const* wt, float* ln_part, float* const* ln_grads, int B, int D, int T,
                                            int H, int FF, int L, tacorl_stream_t stream) {
+  // wt[4 l + {0, 1, 2, 3}]: linear1.weight^T, linear2.weight^T, out_proj.weight^T [32][32], in_proj_weight^T [32][96] as bf16
+  // (the last two may be NULL: gathered transposed from the fp32 block inside the launch)
   if (!tacorl_pr_encoder_fused_supported(D, T, H, FF, L) || B < 1) return TACORL_EINVAL;
   if (!params || !dx || !saved || !dz || !wt || !ln_part || !ln_grads) return TACORL_EINVAL;
   if (!d_pool && (!d_head || !Wc || A2 < 1)) return TACORL_EINVAL;
@@ -730,9 +742,11 @@ extern "C" int tacorl_pr_encoder_bwd_fused(const float* params, const long* offs
       if (!sv[k] || ((uintptr_t)sv[k] & 15)) return TACORL_EINVAL;
     for (int k = 0; k < 4; k++)
       if (!z[k] || ((uintptr_t)z[k] & 15) || !ln_grads[4 * l + k]) return TACORL_EINVAL;
-    if (!wt[2 * l] || !wt[2 * l + 1] || (((uintptr_t)wt[2 * l] | (uintptr_t)wt[2 * l + 1]) & 15)) return TACORL_EINVAL;
+    if (!wt[4 * l] || !wt[4 * l + 1] ||
+        (((uintptr_t)wt[4 * l] | (uintptr_t)wt[4 * l + 1] | (uintptr_t)wt[4 * l + 2] | (uintptr_t)wt[4 * l + 3]) & 15))
+      return TACORL_EINVAL;
     a.s[l] = PrBwdL{sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7], sv[8], z[0], z[1], z[2], z[3],
-                    (const __bf16*)wt[2 * l], (const __bf16*)wt[2 * l + 1]};
+                    (const __bf16*)wt[4 * l], (const __bf16*)wt[4 * l + 1], (const __bf16*)wt[4 * l + 2], (const __bf16*)wt[4 * l + 3]};
     r.dw[2 * l] = ln_grads[4 * l]; r.db[2 * l] = ln_grads[4 * l + 1];
     r.dw[2 * l + 1] = ln_grads[4 * l + 2]; r.db[2 * l + 1] = ln_grads[4 * l + 3];
   }

@@ -269,12 +269,15 @@ class PlanRecognition:
         blk, D, FF = self.blk, self.D, self.FF
         if getattr(self, "_wt", None) is None or self._lnpart.numel() != self.L * 2 * B * 64:
             ops.note_alloc()
-            self._wt = [torch.zeros(FF * D, device=self.dev, dtype=torch.bfloat16) for _ in range(2 * self.L)]
+            bf = lambda n: torch.zeros(n, device=self.dev, dtype=torch.bfloat16)  # noqa: E731
+            self._wt = [t for _ in range(self.L) for t in (bf(FF * D), bf(FF * D), bf(D * D), bf(3 * D * D))]
             self._lnpart = torch.zeros(self.L * 2 * B * 64, device=self.dev)
         for l in range(self.L):
             p = f"transformer_encoder.layers.{l}."
-            call("tacorl_transpose_to_bf16", blk.p(p + "linear1.weight"), ptr(self._wt[2 * l]), FF, D, ops.stream())
-            call("tacorl_transpose_to_bf16", blk.p(p + "linear2.weight"), ptr(self._wt[2 * l + 1]), D, FF, ops.stream())
+            call("tacorl_transpose_to_bf16", blk.p(p + "linear1.weight"), ptr(self._wt[4 * l]), FF, D, ops.stream())
+            call("tacorl_transpose_to_bf16", blk.p(p + "linear2.weight"), ptr(self._wt[4 * l + 1]), D, FF, ops.stream())
+            call("tacorl_transpose_to_bf16", blk.p(p + "self_attn.out_proj.weight"), ptr(self._wt[4 * l + 2]), D, D, ops.stream())
+            call("tacorl_transpose_to_bf16", blk.p(p + "self_attn.in_proj_weight"), ptr(self._wt[4 * l + 3]), 3 * D, D, ops.stream())
 
     def backward(self, d_head, B, T, compute, wgrad_stream=None, prepared=False):
         """d_head: (B, 2A) gradient w.r.t. [mean | var_raw].  Fills self.blk.grad and returns the
@@ -339,7 +342,9 @@ class PlanRecognition:
                 dz += [self.dv[l], self.d_ff1[l], self.dv1[l], self.d_qkv[l]]
                 lng += [blk.g(p + "norm1.weight"), blk.g(p + "norm1.bias"), blk.g(p + "norm2.weight"), blk.g(p + "norm2.bias")]
             call("tacorl_pr_encoder_bwd_fused", ptr(blk.param), self._foff, None if composed else ptr(self.d_pool), ptr(d_head),
-                 ptr(self._Wc), A2, ptr(self.dx), ops.ptr_array(saved), ops.ptr_array(dz), ops.ptr_array(self._wt), ptr(self._lnpart), ops.ptr_array(lng),
+                 ptr(self._Wc), A2, ptr(self.dx), ops.ptr_array(saved), ops.ptr_array(dz), ops.ptr_array(self._wt if getattr(self, "bwd_transposed_proj", True) else
+                                                                              [t if k % 4 < 2 else None for k, t in enumerate(self._wt)]),
+                 ptr(self._lnpart), ops.ptr_array(lng),
                  B, D, T, self.H, FF, self.L, ops.stream())
 
             def wgrads():
