@@ -379,12 +379,15 @@ int tacorl_dropout_mul(float* x, const unsigned char* keep, float keep_scale, lo
 int tacorl_add_layernorm_fwd(const float* x, const float* res, const float* w, const float* b, float* y,
                              float* stats, int R, int D, float eps, tacorl_stream_t stream);
 /* Frozen / eval plan-recognition encoder in ONE launch: position embedding + L post-norm transformer
- * encoder layers (ReLU FFN) + mean over time -> pooled [B][32]; d_model 32, T 16, 8 heads, FF % 256 == 0,
- * L <= 4 (reference plan_recognition_transformer.py:36-88).  One wave per sequence, bf16 MFMA, nothing saved
- * for a backward.  offsets: [position_embeddings, then per layer in_proj_weight, in_proj_bias,
+ * encoder layers (ReLU FFN) + mean over time -> pooled [B][D]; d_model 32 or 64 (one or two cameras), T 16 or 32, 8 heads,
+ * FF % 256 == 0, L <= 4 (reference plan_recognition_transformer.py:36-88).  One workgroup per sequence, bf16 MFMA, nothing
+ * saved for a backward.  offsets: [position_embeddings, then per layer in_proj_weight, in_proj_bias,
  * out_proj.weight, out_proj.bias, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.weight,
  * norm1.bias, norm2.weight, norm2.bias] - element offsets into params and its bf16 copy params_bf16. */
 int tacorl_pr_encoder_fused_supported(int D, int T, int H, int FF, int L);
+/* the train-mode launches (tacorl_pr_encoder_fused_train / _train_sample) exist for d_model 32 (T 16 or 32); the one-launch
+ * backward for T 16 */
+int tacorl_pr_encoder_fused_train_supported(int D, int T, int H, int FF, int L);
 int tacorl_pr_encoder_fused(const float* emb, int ld_emb, const float* params, const void* params_bf16,
                             const long* offsets, float* pooled, int B, int D, int T, int H, int FF, int L,
                             tacorl_stream_t stream);

@@ -50,6 +50,12 @@ else:
     disp = torch.ones(B, device=dev).long()
     batch = {"states": {c: u(B, T, 3, 128, 128) for c in cams}, "goal": {c: u(B, 3, 128, 128) for c in cams}, "actions": acts, "disp": disp}
     (None if os.environ.get('NOGRAPH') else mod.enable_graph()); mod.log_every_n_steps = 50
+    if os.environ.get("MARKS"):  # device-mark timeline of the step's branches (MARKS=1; the module must be built after this)
+        from tacorl_amd import ops
+        reader = ops.trace_marks(dev)
+        mod._graphs = {}
+        timeit(mod, batch, steps=10, warm=3)
+        print("  ".join(f"{n}={t:.0f}" for n, t in reader()))
     ms = timeit(mod, batch, steps=10, warm=3)
     logs = mod.engine.metrics()
     print(f"C4-like TACORL dual-cam 128x128 A=32 T=32 B={B} bf16: {ms:.3f} ms/step = {B / ms * 1e3:.0f} samples/s; finite={all(v == v for v in logs.values())}")

@@ -43,6 +43,7 @@ _SIGS = {
     "tacorl_transpose_pad_to_bf16": (_i, [_p, _p, _i, _i, _i, _p]),
     "tacorl_pad_to_bf16": (_i, [_p, _i, _p, _i, _l, _i, _p]),
     "tacorl_pr_encoder_fused_supported": (_i, [_i, _i, _i, _i, _i]),
+    "tacorl_pr_encoder_fused_train_supported": (_i, [_i, _i, _i, _i, _i]),
     "tacorl_pr_encoder_fused": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "tacorl_pr_encoder_fused_train": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "tacorl_pr_encoder_bwd_fused": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -85,21 +85,26 @@ __device__ __forceinline__ void layer_norm32(f32x4 (&v)[2], const float* w, cons
   }
 }
 
+// RT: 16-row tiles per sequence (T = 16 RT: window 16 - one MFMA tile, as the reference's default - or 32, the real-world
+// configuration's window: BASELINE configs[3]; round 4 - at T = 32 the per-op path put 349 us of launches in front of BOTH
+// chains of the C4 step).  Everything row-shaped simply exists RT times per lane; the attention has 8 T (head, query) pairs.
+template <int RT>
 __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
-  __shared__ __attribute__((aligned(16))) __bf16 xb_s[4][PR_T * XB_P];
-  __shared__ __attribute__((aligned(16))) unsigned char big_s[4][PR_T * HB_P * 2];  // q|k|v (fp32) or FFN hidden chunk (bf16)
+  constexpr int T = 16 * RT;
+  __shared__ __attribute__((aligned(16))) __bf16 xb_s[4][T * XB_P];
+  __shared__ __attribute__((aligned(16))) unsigned char big_s[4][T * HB_P * 2];  // q|k|v (fp32) or FFN hidden chunk (bf16)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   // One workgroup per sequence.  Its four waves each run the (cheap) attention half of a layer redundantly on
   // private scratch and split the FFN - two thirds of the work, 256 KB of weights per layer - by hidden chunks
   // (wave w: chunks w, w + 4, ...); the partial FFN outputs meet in LDS once per layer.  B workgroups instead
   // of B / 4: at B = 256 the launch covers every CU instead of a quarter of them.
-  __shared__ __attribute__((aligned(16))) float ypart[2][4][PR_T * PR_D];  // [layer parity][wave]
+  __shared__ __attribute__((aligned(16))) float ypart[2][4][T * PR_D];  // [layer parity][wave]
   const int b = blockIdx.x;
   if (b >= a.B) return;  // block-uniform
   __bf16* xb = xb_s[w];
   float* qkv = reinterpret_cast<float*>(big_s[w]);
   __bf16* hb = reinterpret_cast<__bf16*>(big_s[w]);
-  static_assert(PR_T * QKV_P * 4 <= PR_T * HB_P * 2, "q|k|v fits in the hidden-chunk buffer");
+  static_assert(T * QKV_P * 4 <= T * HB_P * 2, "q|k|v fits in the hidden-chunk buffer");
 
   // posterior-head operands of this lane (output j = lane): fetched now, used after the last layer
   const int A_ = a.A, jh = lane < 2 * A_ ? lane : 0;
@@ -111,100 +116,127 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
     hbias = a.bc[jh];
     heps = a.eps[(long)b * A_ + (lane < A_ ? lane : 0)];
   }
-  // x = emb + position embedding, in D layout: v[nt][r] = feature 16 nt + 4 g + r of row (time step) i
-  f32x4 x[2];
+  // x = emb + position embedding, in D layout: x[rt][nt][r] = feature 16 nt + 4 g + r of row (time step) 16 rt + i
+  f32x4 x[RT][2];
 #pragma unroll
-  for (int nt = 0; nt < 2; nt++) {
-    const int n = 16 * nt + 4 * g;
-    x[nt] = *reinterpret_cast<const f32x4*>(a.emb + ((long)b * PR_T + i) * a.ld_emb + n) +
-            *reinterpret_cast<const f32x4*>(a.P + a.pos + i * PR_D + n);
-  }
-  auto put_xb = [&](const f32x4 (&v)[2]) {
+  for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++)
-      *reinterpret_cast<bf16x4*>(xb + i * XB_P + 16 * nt + 4 * g) =
-          bf16x4{(__bf16)v[nt][0], (__bf16)v[nt][1], (__bf16)v[nt][2], (__bf16)v[nt][3]};
+    for (int nt = 0; nt < 2; nt++) {
+      const int n = 16 * nt + 4 * g, t = 16 * rt + i;
+      x[rt][nt] = *reinterpret_cast<const f32x4*>(a.emb + ((long)b * T + t) * a.ld_emb + n) +
+                  *reinterpret_cast<const f32x4*>(a.P + a.pos + t * PR_D + n);
+    }
+  auto put_xb = [&](const f32x4 (&v)[RT][2]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++)
+        *reinterpret_cast<bf16x4*>(xb + (16 * rt + i) * XB_P + 16 * nt + 4 * g) =
+            bf16x4{(__bf16)v[rt][nt][0], (__bf16)v[rt][nt][1], (__bf16)v[rt][nt][2], (__bf16)v[rt][nt][3]};
   };
   const int nchunk = a.FF / PR_CH;
   const bool sv0 = a.save && w == 0;  // (the attention half runs redundantly on all four waves: wave 0 writes the saves)
-  const long rrow = (long)b * PR_T + i;  // this lane's batch-major row
+  long rrow[RT];                      // this lane's batch-major rows
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) rrow[rt] = (long)b * T + 16 * rt + i;
   for (int l = 0; l < a.L; l++) {
     const PrLayerOff& o = a.l[l];
     const PrSaveL& S = a.sv[l];
     if (sv0) {
 #pragma unroll
-      for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(S.xin + rrow * PR_D + 16 * nt + 4 * g) = x[nt];
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(S.xin + rrow[rt] * PR_D + 16 * nt + 4 * g) = x[rt][nt];
     }
     // ---- q|k|v = x Win^T + b  (6 N tiles, K = 32)
     put_xb(x);
     lds_sync();
     {
-      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + i * XB_P + 8 * g);
+      bf16x8 xf[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) xf[rt] = *reinterpret_cast<const bf16x8*>(xb + (16 * rt + i) * XB_P + 8 * g);
 #pragma unroll
       for (int nt = 0; nt < 6; nt++) {
         const bf16x8 wf = cvt8(a.P + o.in_w + (long)(16 * nt + i) * PR_D + 8 * g);
-        f32x4 acc = *reinterpret_cast<const f32x4*>(a.P + o.in_b + 16 * nt + 4 * g);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc, 0, 0, 0);
-        *reinterpret_cast<f32x4*>(qkv + i * QKV_P + 16 * nt + 4 * g) = acc;
-        if (sv0) *reinterpret_cast<f32x4*>(S.qkv + rrow * 3 * PR_D + 16 * nt + 4 * g) = acc;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.in_b + 16 * nt + 4 * g);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+          f32x4 acc = bias;
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[rt], acc, 0, 0, 0);
+          *reinterpret_cast<f32x4*>(qkv + (16 * rt + i) * QKV_P + 16 * nt + 4 * g) = acc;
+          if (sv0) *reinterpret_cast<f32x4*>(S.qkv + rrow[rt] * 3 * PR_D + 16 * nt + 4 * g) = acc;
+        }
       }
     }
     lds_sync();
-    // ---- attention: 8 heads x 16 queries = 128 (head, query) pairs, two per lane; result -> xb (bf16)
+    // ---- attention: 8 heads x T queries = 8 T (head, query) pairs, 2 RT per lane; result -> xb (bf16)
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int p = lane + 64 * j, h = p >> 4, qi = p & 15;
+    for (int j = 0; j < 2 * RT; j++) {
+      const int p = lane + 64 * j, h = p / T, qi = p % T;
       f32x4 q = *reinterpret_cast<const f32x4*>(qkv + qi * QKV_P + PR_HD * h);
 #pragma unroll
       for (int e = 0; e < 4; e++) q[e] *= 0.5f;  // 1 / sqrt(head_dim)
-      float s[PR_T], mx = -INFINITY;
+      float s[T], mx = -INFINITY;
 #pragma unroll
-      for (int t = 0; t < PR_T; t++) {
+      for (int t = 0; t < T; t++) {
         const f32x4 k = *reinterpret_cast<const f32x4*>(qkv + t * QKV_P + PR_D + PR_HD * h);
         s[t] = ((q[0] * k[0] + q[1] * k[1]) + q[2] * k[2]) + q[3] * k[3];
         mx = fmaxf(mx, s[t]);
       }
       float se = 0.f;
 #pragma unroll
-      for (int t = 0; t < PR_T; t++) { s[t] = expf(s[t] - mx); se += s[t]; }
+      for (int t = 0; t < T; t++) { s[t] = expf(s[t] - mx); se += s[t]; }
       f32x4 ov = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < PR_T; t++) {
+      for (int t = 0; t < T; t++) {
         const f32x4 vv = *reinterpret_cast<const f32x4*>(qkv + t * QKV_P + 2 * PR_D + PR_HD * h);
         const float pr = s[t] / se;
 #pragma unroll
         for (int e = 0; e < 4; e++) ov[e] += pr * vv[e];
       }
       *reinterpret_cast<bf16x4*>(xb + qi * XB_P + PR_HD * h) = bf16x4{(__bf16)ov[0], (__bf16)ov[1], (__bf16)ov[2], (__bf16)ov[3]};
-      if (sv0) *reinterpret_cast<f32x4*>(S.att + ((long)b * PR_T + qi) * PR_D + PR_HD * h) = ov;
+      if (sv0) *reinterpret_cast<f32x4*>(S.att + ((long)b * T + qi) * PR_D + PR_HD * h) = ov;
     }
     lds_sync();
     // ---- out-projection + residual + LayerNorm 1
     {
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(xb + i * XB_P + 8 * g);
+      bf16x8 af[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) af[rt] = *reinterpret_cast<const bf16x8*>(xb + (16 * rt + i) * XB_P + 8 * g);
 #pragma unroll
       for (int nt = 0; nt < 2; nt++) {
         const bf16x8 wf = cvt8(a.P + o.out_w + (long)(16 * nt + i) * PR_D + 8 * g);
-        f32x4 acc = *reinterpret_cast<const f32x4*>(a.P + o.out_b + 16 * nt + 4 * g);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc, 0, 0, 0);
-        if (sv0) *reinterpret_cast<f32x4*>(S.proj + rrow * PR_D + 16 * nt + 4 * g) = acc;
-        x[nt] += acc;
-      }
-      layer_norm32(x, a.P + o.n1w, a.P + o.n1b, g, sv0 ? S.st1 + 2 * rrow : nullptr);
-      if (sv0) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.out_b + 16 * nt + 4 * g);
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(S.x1 + rrow * PR_D + 16 * nt + 4 * g) = x[nt];
+        for (int rt = 0; rt < RT; rt++) {
+          f32x4 acc = bias;
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[rt], acc, 0, 0, 0);
+          if (sv0) *reinterpret_cast<f32x4*>(S.proj + rrow[rt] * PR_D + 16 * nt + 4 * g) = acc;
+          x[rt][nt] += acc;
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) {
+        layer_norm32(x[rt], a.P + o.n1w, a.P + o.n1b, g, sv0 ? S.st1 + 2 * rrow[rt] : nullptr);
+        if (sv0) {
+#pragma unroll
+          for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(S.x1 + rrow[rt] * PR_D + 16 * nt + 4 * g) = x[rt][nt];
+        }
       }
     }
     lds_sync();  // every lane has read its out-projection operand before xb is overwritten
     put_xb(x);
     lds_sync();
     // ---- FFN: relu(x W1^T + b1) W2^T + b2, hidden processed in chunks of 256 kept in LDS as bf16
-    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + i * XB_P + 8 * g);
-    f32x4 y[2];
+    bf16x8 xf[RT];
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++)
-      y[nt] = w == 0 ? *reinterpret_cast<const f32x4*>(a.P + o.b2 + 16 * nt + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < RT; rt++) xf[rt] = *reinterpret_cast<const bf16x8*>(xb + (16 * rt + i) * XB_P + 8 * g);
+    f32x4 y[RT][2];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++)
+        y[rt][nt] = w == 0 ? *reinterpret_cast<const f32x4*>(a.P + o.b2 + 16 * nt + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
     const __bf16* W1 = a.Pb + o.w1;
     const __bf16* W2 = a.Pb + o.w2;
     bf16x8 w1f[16], w2f[8][2];
@@ -220,11 +252,15 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
           w2f[ks][nt] = *reinterpret_cast<const bf16x8*>(W2 + (long)(16 * nt + i) * a.FF + PR_CH * c + 32 * ks + 8 * g);
 #pragma unroll
       for (int nt = 0; nt < 16; nt++) {
-        f32x4 hacc = *reinterpret_cast<const f32x4*>(a.P + o.b1 + PR_CH * c + 16 * nt + 4 * g);
-        hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[nt], xf, hacc, 0, 0, 0);
-        const f32x4 hr = {fmaxf(hacc[0], 0.f), fmaxf(hacc[1], 0.f), fmaxf(hacc[2], 0.f), fmaxf(hacc[3], 0.f)};
-        *reinterpret_cast<bf16x4*>(hb + i * HB_P + 16 * nt + 4 * g) = bf16x4{(__bf16)hr[0], (__bf16)hr[1], (__bf16)hr[2], (__bf16)hr[3]};
-        if (a.save) *reinterpret_cast<f32x4*>(S.ff1 + rrow * a.FF + PR_CH * c + 16 * nt + 4 * g) = hr;  // (each wave its own chunks)
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.b1 + PR_CH * c + 16 * nt + 4 * g);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+          f32x4 hacc = bias;
+          hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[nt], xf[rt], hacc, 0, 0, 0);
+          const f32x4 hr = {fmaxf(hacc[0], 0.f), fmaxf(hacc[1], 0.f), fmaxf(hacc[2], 0.f), fmaxf(hacc[3], 0.f)};
+          *reinterpret_cast<bf16x4*>(hb + (16 * rt + i) * HB_P + 16 * nt + 4 * g) = bf16x4{(__bf16)hr[0], (__bf16)hr[1], (__bf16)hr[2], (__bf16)hr[3]};
+          if (a.save) *reinterpret_cast<f32x4*>(S.ff1 + rrow[rt] * a.FF + PR_CH * c + 16 * nt + 4 * g) = hr;  // (each wave its own chunks)
+        }
       }
       lds_sync();
       // the next chunk's W1 fragments travel while FFN2 runs
@@ -235,9 +271,12 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
       }
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
-        const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hb + i * HB_P + 32 * ks + 8 * g);
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) y[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks][nt], hf, y[nt], 0, 0, 0);
+        for (int rt = 0; rt < RT; rt++) {
+          const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hb + (16 * rt + i) * HB_P + 32 * ks + 8 * g);
+#pragma unroll
+          for (int nt = 0; nt < 2; nt++) y[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks][nt], hf, y[rt][nt], 0, 0, 0);
+        }
       }
       lds_sync();  // hidden chunk consumed before the next one overwrites it
     }
@@ -247,31 +286,38 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
     {
       float* yp = ypart[l & 1][w];
 #pragma unroll
-      for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(yp + i * PR_D + 16 * nt + 4 * g) = y[nt];
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(yp + (16 * rt + i) * PR_D + 16 * nt + 4 * g) = y[rt][nt];
       __syncthreads();
 #pragma unroll
-      for (int nt = 0; nt < 2; nt++) {
-        f32x4 t = *reinterpret_cast<const f32x4*>(ypart[l & 1][0] + i * PR_D + 16 * nt + 4 * g);
+      for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-        for (int ww = 1; ww < 4; ww++) t += *reinterpret_cast<const f32x4*>(ypart[l & 1][ww] + i * PR_D + 16 * nt + 4 * g);
-        if (sv0) *reinterpret_cast<f32x4*>(S.ff2 + rrow * PR_D + 16 * nt + 4 * g) = t;
-        x[nt] += t;
-      }
+        for (int nt = 0; nt < 2; nt++) {
+          f32x4 t = *reinterpret_cast<const f32x4*>(ypart[l & 1][0] + (16 * rt + i) * PR_D + 16 * nt + 4 * g);
+#pragma unroll
+          for (int ww = 1; ww < 4; ww++) t += *reinterpret_cast<const f32x4*>(ypart[l & 1][ww] + (16 * rt + i) * PR_D + 16 * nt + 4 * g);
+          if (sv0) *reinterpret_cast<f32x4*>(S.ff2 + rrow[rt] * PR_D + 16 * nt + 4 * g) = t;
+          x[rt][nt] += t;
+        }
     }
-    layer_norm32(x, a.P + o.n2w, a.P + o.n2b, g, sv0 ? S.st2 + 2 * rrow : nullptr);
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) layer_norm32(x[rt], a.P + o.n2w, a.P + o.n2b, g, sv0 ? S.st2 + 2 * rrow[rt] : nullptr);
   }
   if (w != 0) return;  // every wave holds the same result: wave 0 writes it
-  // ---- mean over the 16 time steps (lanes i = 0..15 of each g)
+  // ---- mean over the T time steps (row tiles in order, then lanes i = 0..15 of each g)
 #pragma unroll
   for (int nt = 0; nt < 2; nt++) {
-    f32x4 s = x[nt];
+    f32x4 s = x[0][nt];
+#pragma unroll
+    for (int rt = 1; rt < RT; rt++) s += x[rt][nt];
 #pragma unroll
     for (int off = 1; off < 16; off <<= 1)
 #pragma unroll
       for (int r = 0; r < 4; r++) s[r] += __shfl_xor(s[r], off, 64);
     if (i == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) s[r] *= (1.0f / PR_T);
+      for (int r = 0; r < 4; r++) s[r] *= (1.0f / T);
       *reinterpret_cast<f32x4*>(a.pooled + (long)b * PR_D + 16 * nt + 4 * g) = s;
       if (a.Wc) *reinterpret_cast<f32x4*>(qkv + 16 * nt + 4 * g) = s;
     }
@@ -292,6 +338,258 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
   if (lane < A) {
     const float sd = (vr > 20.f ? vr : log1pf(expf(vr))) + a.min_std;
     a.plan[(long)b * A + lane] = tanhf(h + heps * sd);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ d_model 64 (two cameras)
+// The same launch for d_model = 64 (the real-world configuration: two cameras x 32 features, 8 heads of 8, window 32 -
+// BASELINE configs[3]), inference only (frozen LMP inside TACORL; round 4: the per-op path put 349 us of launches in front of
+// BOTH chains of the C4 step).  Same structure - one workgroup per sequence, activations in registers in the MFMA D layout
+// (four 16-feature tiles per row), the attention half redundantly on the four waves, the FFN split by hidden chunks - with
+// K = 64 contractions as two k-steps, 128-wide hidden chunks (16 + 16 weight fragments in registers) and ONE partial-sum
+// buffer (two barriers per layer: 32 KB; two buffers would not fit beside 4 x 30 KB of wave scratch).
+constexpr int D6 = 64, HD6 = 8, CH6 = 128;
+constexpr int XB6_P = 72;    // bf16 row pitch of the 64-wide B operand (144 B)
+constexpr int HB6_P = 136;   // bf16 row pitch of a 128-wide hidden chunk (272 B)
+constexpr int QKV6_P = 196;  // fp32 row pitch of q|k|v (192 + 4)
+
+__device__ __forceinline__ void layer_norm64(f32x4 (&v)[4], const float* w, const float* b, int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) s += v[nt][r];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s / 64.f;
+  float q = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const float c = v[nt][r] - mean; q += c * c; }
+  q += __shfl_xor(q, 16, 64);
+  q += __shfl_xor(q, 32, 64);
+  const float rstd = 1.0f / sqrtf(q / 64.f + 1e-5f);
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++) {
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(w + 16 * nt + 4 * g), bb = *reinterpret_cast<const f32x4*>(b + 16 * nt + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[nt][r] = (v[nt][r] - mean) * rstd * ww[r] + bb[r];
+  }
+}
+
+template <int RT>
+__global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
+  constexpr int T = 16 * RT;
+  constexpr int BIG = (T * QKV6_P * 4 > T * HB6_P * 2) ? T * QKV6_P * 4 : T * HB6_P * 2;
+  __shared__ __attribute__((aligned(16))) __bf16 xb_s[4][T * XB6_P];
+  __shared__ __attribute__((aligned(16))) unsigned char big_s[4][BIG];  // q|k|v (fp32) or FFN hidden chunk (bf16)
+  __shared__ __attribute__((aligned(16))) float ypart[4][T * D6];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+  if (b >= a.B) return;  // block-uniform
+  __bf16* xb = xb_s[w];
+  float* qkv = reinterpret_cast<float*>(big_s[w]);
+  __bf16* hb = reinterpret_cast<__bf16*>(big_s[w]);
+  // x[rt][nt][r] = feature 16 nt + 4 g + r of row (time step) 16 rt + i
+  f32x4 x[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+      const int n = 16 * nt + 4 * g, t = 16 * rt + i;
+      x[rt][nt] = *reinterpret_cast<const f32x4*>(a.emb + ((long)b * T + t) * a.ld_emb + n) +
+                  *reinterpret_cast<const f32x4*>(a.P + a.pos + t * D6 + n);
+    }
+  auto put_xb = [&](const f32x4 (&v)[RT][4]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++)
+        *reinterpret_cast<bf16x4*>(xb + (16 * rt + i) * XB6_P + 16 * nt + 4 * g) =
+            bf16x4{(__bf16)v[rt][nt][0], (__bf16)v[rt][nt][1], (__bf16)v[rt][nt][2], (__bf16)v[rt][nt][3]};
+  };
+  auto get_xf = [&](bf16x8 (&xf)[RT][2]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) xf[rt][ks] = *reinterpret_cast<const bf16x8*>(xb + (16 * rt + i) * XB6_P + 32 * ks + 8 * g);
+  };
+  const int nchunk = a.FF / CH6;
+  for (int l = 0; l < a.L; l++) {
+    const PrLayerOff& o = a.l[l];
+    // ---- q|k|v = x Win^T + b  (12 N tiles, K = 64)
+    put_xb(x);
+    lds_sync();
+    {
+      bf16x8 xf[RT][2];
+      get_xf(xf);
+#pragma unroll
+      for (int nt = 0; nt < 12; nt++) {
+        const bf16x8 wf0 = cvt8(a.P + o.in_w + (long)(16 * nt + i) * D6 + 8 * g), wf1 = cvt8(a.P + o.in_w + (long)(16 * nt + i) * D6 + 32 + 8 * g);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.in_b + 16 * nt + 4 * g);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+          f32x4 acc = bias;
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, xf[rt][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, xf[rt][1], acc, 0, 0, 0);
+          *reinterpret_cast<f32x4*>(qkv + (16 * rt + i) * QKV6_P + 16 * nt + 4 * g) = acc;
+        }
+      }
+    }
+    lds_sync();
+    // ---- attention: 8 heads x T queries, 2 RT (head, query) pairs per lane, head_dim 8; result -> xb (bf16)
+#pragma unroll 1
+    for (int j = 0; j < 2 * RT; j++) {
+      const int p = lane + 64 * j, h = p / T, qi = p % T;
+      f32x4 q0 = *reinterpret_cast<const f32x4*>(qkv + qi * QKV6_P + HD6 * h), q1 = *reinterpret_cast<const f32x4*>(qkv + qi * QKV6_P + HD6 * h + 4);
+      const float sc = 0.35355339059327379f;  // 1 / sqrt(8)
+      q0 *= sc; q1 *= sc;
+      float s[T], mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(qkv + t * QKV6_P + D6 + HD6 * h), k1 = *reinterpret_cast<const f32x4*>(qkv + t * QKV6_P + D6 + HD6 * h + 4);
+        s[t] = (((q0[0] * k0[0] + q0[1] * k0[1]) + q0[2] * k0[2]) + q0[3] * k0[3]) + (((q1[0] * k1[0] + q1[1] * k1[1]) + q1[2] * k1[2]) + q1[3] * k1[3]);
+        mx = fmaxf(mx, s[t]);
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; t++) { s[t] = expf(s[t] - mx); se += s[t]; }
+      f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(qkv + t * QKV6_P + 2 * D6 + HD6 * h), v1 = *reinterpret_cast<const f32x4*>(qkv + t * QKV6_P + 2 * D6 + HD6 * h + 4);
+        const float pr = s[t] / se;
+        o0 += pr * v0; o1 += pr * v1;
+      }
+      *reinterpret_cast<bf16x8*>(xb + qi * XB6_P + HD6 * h) =
+          bf16x8{(__bf16)o0[0], (__bf16)o0[1], (__bf16)o0[2], (__bf16)o0[3], (__bf16)o1[0], (__bf16)o1[1], (__bf16)o1[2], (__bf16)o1[3]};
+    }
+    lds_sync();
+    // ---- out-projection + residual + LayerNorm 1
+    {
+      bf16x8 af[RT][2];
+      get_xf(af);
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) {
+        const bf16x8 wf0 = cvt8(a.P + o.out_w + (long)(16 * nt + i) * D6 + 8 * g), wf1 = cvt8(a.P + o.out_w + (long)(16 * nt + i) * D6 + 32 + 8 * g);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.out_b + 16 * nt + 4 * g);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+          f32x4 acc = bias;
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, af[rt][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, af[rt][1], acc, 0, 0, 0);
+          x[rt][nt] += acc;
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) layer_norm64(x[rt], a.P + o.n1w, a.P + o.n1b, g);
+    }
+    lds_sync();  // every lane has read its out-projection operand before xb is overwritten
+    put_xb(x);
+    lds_sync();
+    // ---- FFN: relu(x W1^T + b1) W2^T + b2, hidden in chunks of 128 kept in LDS as bf16
+    bf16x8 xf[RT][2];
+    get_xf(xf);
+    f32x4 y[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++)
+        y[rt][nt] = w == 0 ? *reinterpret_cast<const f32x4*>(a.P + o.b2 + 16 * nt + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const __bf16* W1 = a.Pb + o.w1;
+    const __bf16* W2 = a.Pb + o.w2;
+    for (int c = w; c < nchunk; c += 4) {
+      bf16x8 w1f[8][2], w2f[4][4];
+#pragma unroll
+      for (int nt = 0; nt < 8; nt++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) w1f[nt][ks] = *reinterpret_cast<const bf16x8*>(W1 + (long)(CH6 * c + 16 * nt + i) * D6 + 32 * ks + 8 * g);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+          w2f[ks][nt] = *reinterpret_cast<const bf16x8*>(W2 + (long)(16 * nt + i) * a.FF + CH6 * c + 32 * ks + 8 * g);
+#pragma unroll
+      for (int nt = 0; nt < 8; nt++) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.b1 + CH6 * c + 16 * nt + 4 * g);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+          f32x4 hacc = bias;
+          hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[nt][0], xf[rt][0], hacc, 0, 0, 0);
+          hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[nt][1], xf[rt][1], hacc, 0, 0, 0);
+          *reinterpret_cast<bf16x4*>(hb + (16 * rt + i) * HB6_P + 16 * nt + 4 * g) =
+              bf16x4{(__bf16)fmaxf(hacc[0], 0.f), (__bf16)fmaxf(hacc[1], 0.f), (__bf16)fmaxf(hacc[2], 0.f), (__bf16)fmaxf(hacc[3], 0.f)};
+        }
+      }
+      lds_sync();
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+          const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hb + (16 * rt + i) * HB6_P + 32 * ks + 8 * g);
+#pragma unroll
+          for (int nt = 0; nt < 4; nt++) y[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks][nt], hf, y[rt][nt], 0, 0, 0);
+        }
+      }
+      lds_sync();  // hidden chunk consumed before the next one overwrites it
+    }
+    // the four partial FFN outputs meet in LDS (fixed summation order: every wave ends with the same bits)
+    {
+      float* yp = ypart[w];
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) *reinterpret_cast<f32x4*>(yp + (16 * rt + i) * D6 + 16 * nt + 4 * g) = y[rt][nt];
+      __syncthreads();
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+          f32x4 t = *reinterpret_cast<const f32x4*>(ypart[0] + (16 * rt + i) * D6 + 16 * nt + 4 * g);
+#pragma unroll
+          for (int ww = 1; ww < 4; ww++) t += *reinterpret_cast<const f32x4*>(ypart[ww] + (16 * rt + i) * D6 + 16 * nt + 4 * g);
+          x[rt][nt] += t;
+        }
+      __syncthreads();  // (one buffer: everyone has read the partials before the next layer's are written)
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) layer_norm64(x[rt], a.P + o.n2w, a.P + o.n2b, g);
+  }
+  if (w != 0) return;  // every wave holds the same result: wave 0 writes it
+  // ---- mean over the T time steps
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++) {
+    f32x4 s = x[0][nt];
+#pragma unroll
+    for (int rt = 1; rt < RT; rt++) s += x[rt][nt];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+      for (int r = 0; r < 4; r++) s[r] += __shfl_xor(s[r], off, 64);
+    if (i == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) s[r] *= (1.0f / T);
+      *reinterpret_cast<f32x4*>(a.pooled + (long)b * D6 + 16 * nt + 4 * g) = s;
+      if (a.Wc) *reinterpret_cast<f32x4*>(qkv + 16 * nt + 4 * g) = s;
+    }
+  }
+  if (!a.Wc) return;
+  // ---- posterior head on the pooled vector: head = Wc pooled + bc (lane j = output j), std = softplus(var_raw) + min_std,
+  // plan = tanh(mean + eps * std)  (plan_recognition_transformer.py:89-104)
+  lds_sync();
+  const int A = a.A, jh = lane < 2 * A ? lane : 0;
+  float h = a.bc[jh];
+#pragma unroll
+  for (int d = 0; d < D6; d += 4) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.Wc + jh * D6 + d), pv = *reinterpret_cast<const f32x4*>(qkv + d);
+    h += wv[0] * pv[0] + wv[1] * pv[1] + wv[2] * pv[2] + wv[3] * pv[3];
+  }
+  if (lane < 2 * A) a.head[(long)b * 2 * A + lane] = h;
+  const float vr = __shfl(h, (lane + A) & 63, 64);
+  if (lane < A) {
+    const float sd = (vr > 20.f ? vr : log1pf(expf(vr))) + a.min_std;
+    a.plan[(long)b * A + lane] = tanhf(h + a.eps[(long)b * A + lane] * sd);
   }
 }
 
@@ -602,23 +900,24 @@ __global__ __launch_bounds__(256) void pr_ln_reduce_kernel(PrLnReduceArgs a) {
 // the dependent chain; fixed reduction order (deterministic).  grid = 2A blocks of 256 threads, D = 32.
 __global__ __launch_bounds__(256) void pr_head_compose_kernel(const float* __restrict__ w_fc, const float* __restrict__ b_fc,
                                                               const float* __restrict__ w_head, const float* __restrict__ b_head,
-                                                              float* __restrict__ Wc, float* __restrict__ bc, int FC) {
-  __shared__ float part[8][PR_D + 1];
-  const int j = blockIdx.x, d = threadIdx.x & 31, fg = threadIdx.x >> 5;
+                                                              float* __restrict__ Wc, float* __restrict__ bc, int FC, int D) {
+  __shared__ float part[8][64 + 1];
+  const int NG = 256 / D;  // feature groups of threads: 8 (D = 32) or 4 (D = 64)
+  const int j = blockIdx.x, d = threadIdx.x % D, fg = threadIdx.x / D;
   float acc = 0.f, accb = 0.f;
 #pragma unroll 16
-  for (int f = fg; f < FC; f += 8) {  // independent iterations: 16 x 3 loads in flight per thread
+  for (int f = fg; f < FC; f += NG) {  // independent iterations: 16 x 3 loads in flight per thread
     const float wh = w_head[(long)j * FC + f];
-    acc += wh * w_fc[(long)f * PR_D + d];
+    acc += wh * w_fc[(long)f * D + d];
     accb += wh * b_fc[f];
   }
   part[fg][d] = acc;
-  if (d == 0) part[fg][PR_D] = accb;
+  if (d == 0) part[fg][D] = accb;
   __syncthreads();
-  if (threadIdx.x <= PR_D) {
+  if (threadIdx.x <= D) {
     float t = 0.f;
-    for (int q = 0; q < 8; q++) t += part[q][threadIdx.x];
-    if (threadIdx.x < PR_D) Wc[j * PR_D + threadIdx.x] = t;
+    for (int q = 0; q < NG; q++) t += part[q][threadIdx.x];
+    if (threadIdx.x < D) Wc[j * D + threadIdx.x] = t;
     else bc[j] = t + b_head[j];
   }
 }
@@ -626,7 +925,13 @@ __global__ __launch_bounds__(256) void pr_head_compose_kernel(const float* __res
 }  // namespace
 
 extern "C" int tacorl_pr_encoder_fused_supported(int D, int T, int H, int FF, int L) {
-  return D == PR_D && T == PR_T && H == PR_H && FF >= PR_CH && FF % PR_CH == 0 && L >= 1 && L <= PR_MAXL ? 1 : 0;
+  return (D == PR_D || D == D6) && (T == PR_T || T == 2 * PR_T) && H == PR_H && FF >= PR_CH && FF % PR_CH == 0 && L >= 1 &&
+                 L <= PR_MAXL
+             ? 1 : 0;
+}
+/* the train-mode launch (activations saved for the backward) exists for d_model 32 */
+extern "C" int tacorl_pr_encoder_fused_train_supported(int D, int T, int H, int FF, int L) {
+  return D == PR_D && tacorl_pr_encoder_fused_supported(D, T, H, FF, L) ? 1 : 0;
 }
 // offsets: [position_embeddings, then per layer: in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias,
 // linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias]
@@ -659,7 +964,12 @@ static int pr_encoder_fused_launch(const float* emb, int ld_emb, const float* pa
     }
     a.save = 1;
   }
-  hipLaunchKernelGGL(pr_encoder_fused_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  if (D == D6) {
+    if (save) return TACORL_EINVAL;  // (inference only)
+    if (T == PR_T) hipLaunchKernelGGL(pr_encoder_fused64_kernel<1>, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(pr_encoder_fused64_kernel<2>, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (T == PR_T) hipLaunchKernelGGL(pr_encoder_fused_kernel<1>, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(pr_encoder_fused_kernel<2>, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 /* The same launch in train mode (no dropout): also writes, per layer, what the per-op backward reads.  save[9 l + k], k = 0..8:
@@ -702,9 +1012,9 @@ extern "C" int tacorl_pr_encoder_fused_sample(const float* emb, int ld_emb, cons
 }
 extern "C" int tacorl_pr_head_compose(const float* w_fc, const float* b_fc, const float* w_head, const float* b_head,
                                       float* Wc, float* bc, int D, int FC, int A2, tacorl_stream_t stream) {
-  if (D != PR_D || FC < 1 || A2 < 1 || !w_fc || !b_fc || !w_head || !b_head || !Wc || !bc) return TACORL_EINVAL;
+  if ((D != PR_D && D != D6) || FC < 1 || A2 < 1 || !w_fc || !b_fc || !w_head || !b_head || !Wc || !bc) return TACORL_EINVAL;
   hipLaunchKernelGGL(pr_head_compose_kernel, dim3(A2), dim3(256), 0, (hipStream_t)stream, w_fc, b_fc, w_head, b_head, Wc, bc,
-                     FC);
+                     FC, D);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
@@ -723,7 +1033,7 @@ extern "C" int tacorl_pr_encoder_bwd_fused(const float* params, const long* offs
                                            int H, int FF, int L, tacorl_stream_t stream) {
   // wt[4 l + {0, 1, 2, 3}]: linear1.weight^T, linear2.weight^T, out_proj.weight^T [32][32], in_proj_weight^T [32][96] as bf16
   // (the last two may be NULL: gathered transposed from the fp32 block inside the launch)
-  if (!tacorl_pr_encoder_fused_supported(D, T, H, FF, L) || B < 1) return TACORL_EINVAL;
+  if (!tacorl_pr_encoder_fused_supported(D, T, H, FF, L) || T != PR_T || B < 1) return TACORL_EINVAL;  // (backward: window 16 only)
   if (!params || !dx || !saved || !dz || !wt || !ln_part || !ln_grads) return TACORL_EINVAL;
   if (!d_pool && (!d_head || !Wc || A2 < 1)) return TACORL_EINVAL;
   if (((uintptr_t)params | (uintptr_t)d_pool | (uintptr_t)dx | (uintptr_t)ln_part | (uintptr_t)Wc) & 15) return TACORL_EINVAL;

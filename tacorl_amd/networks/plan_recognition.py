@@ -160,7 +160,8 @@ class PlanRecognition:
             self._lin(self.fc_out, self.FC, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.head, B, self.FC,
                       2 * self.A, ACT_NONE, compute)
             return self.head
-        if not inference and not drop and getattr(self, "fused_train", True) and self.fused_inference_ok(T, ld_emb, compute):
+        if (not inference and not drop and getattr(self, "fused_train", True) and self.fused_inference_ok(T, ld_emb, compute)
+                and ops.L.lib().tacorl_pr_encoder_fused_train_supported(self.D, T, self.H, self.FF, self.L)):
             # train mode without dropout (bf16): the encoder layers + time pooling as ONE launch that also writes what the
             # per-op backward below reads (layer inputs, q|k|v, attention / projection / FFN outputs, LayerNorm statistics)
             # in the per-op forward's layouts - ~17 dependent launches of PlayLMP.training_step's chain become one
@@ -304,7 +305,7 @@ class PlanRecognition:
                 fn()
 
         fused = (getattr(self, "_fused_saved", None) == (B, T) and getattr(self, "fused_backward", True)
-                 and not getattr(self, "_dropping", False))
+                 and not getattr(self, "_dropping", False) and T == 16)  # (the one-launch backward exists for window 16)
         wt_ready = None
         if fused and not prepared:
             # W1^T / W2^T as bf16 for the fused chain: weights only, so on the weight-gradient stream.  NB that stream's queue
