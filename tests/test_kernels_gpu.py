@@ -911,6 +911,39 @@ def test_rnn_wgrad(R, M, N, ld, accumulate):
     assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("R,slabs,rows,N,accumulate", [(3840, 6, 182, 2048, False), (512, 8, 182, 2048, True), (128, 2, 100, 256, False),
+                                                        (64, 1, 128, 128, False)])
+def test_rnn_wgrad_slabs(R, slabs, rows, N, accumulate):
+    """dW[rows][N] = dz^T x and db = column sums for a FEW output rows (the action decoder's 182 x 2048 heads): dz K-padded to
+    Mp = 128-multiple columns (zeros beyond `rows`), the reduction rows cut into `slabs` ranges that run side by side and
+    are summed in slab order - vs fp32 torch on the same bf16 values; rows beyond `rows` of the destination stay untouched."""
+    from tacorl_amd import _lib, ops
+
+    dev = _dev()
+    Mp = (rows + 127) // 128 * 128
+    dz = torch.zeros(R, Mp)
+    dz[:, :rows] = rnd(R, rows, seed=1)
+    dz, x = dz.to(torch.bfloat16), rnd(R, N, seed=2).to(torch.bfloat16)
+    ref_w, ref_b = dz[:, :rows].float().t() @ x.float(), dz[:, :rows].float().sum(0)
+    base = 0.25 if accumulate else float("nan")
+    dw, db = torch.full((rows + 3, N), base, device=dev), torch.full((rows + 3,), base, device=dev)
+    dzd, xd = dz.to(dev), x.to(dev)
+    nb = _lib.lib().tacorl_rnn_wgrad_slabs_ws_bytes(slabs, Mp, N)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    ops.call("tacorl_rnn_wgrad_slabs", ops.ptr(dzd), Mp, ops.ptr(xd), N, R, Mp, N, rows, slabs, ops.ptr(dw), ops.ptr(db), int(accumulate),
+             ops.ptr(ws), ws.numel(), ops.stream())
+    torch.cuda.synchronize()
+    off = 0.25 if accumulate else 0.0
+    assert relerr(dw[:rows] - off, ref_w) < 1e-5, relerr(dw[:rows] - off, ref_w)
+    assert relerr(db[:rows] - off, ref_b) < 1e-5, relerr(db[:rows] - off, ref_b)
+    tail_w, tail_b = dw[rows:], db[rows:]
+    assert (torch.isnan(tail_w).all() and torch.isnan(tail_b).all()) if not accumulate else (bool((tail_w == base).all()) and bool((tail_b == base).all()))
+    # row ranges that do not divide into 64-row stages are refused
+    rc = _lib.lib().tacorl_rnn_wgrad_slabs(ops.ptr(dzd), Mp, ops.ptr(xd), N, R, Mp, N, rows, slabs + (7 if R % (64 * (slabs + 7)) else 1), ops.ptr(dw),
+                                           ops.ptr(db), 0, ops.ptr(ws), ws.numel(), ops.stream())
+    assert rc != 0
+
+
 @pytest.mark.parametrize("R", [100, 4096])
 def test_add_layernorm_fwd_bwd(R):
     """y = LayerNorm(x + res) forward and backward (dv, dw, db) vs torch autograd; R = 4096 exercises the
