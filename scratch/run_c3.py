@@ -16,7 +16,7 @@ def lmp():
                    plan_recognition_modalities=cams, action_decoder_modalities=cams, real_world=True, device=dev, compute_dtype="bf16", image_dtype="bf16")
 B = int(os.environ.get("B", 256))
 batch = bench.synth_batch(B, T, 84, 84, dev, 1)
-def timeit(f, steps=20, warm=5):
+def timeit(f, steps=int(os.environ.get("STEPS", 20)), warm=int(os.environ.get("WARM", 5))):
     for _ in range(warm): f()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): f()
