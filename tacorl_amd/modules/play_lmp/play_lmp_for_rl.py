@@ -455,6 +455,7 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     if twin is not None:
         s_rand.wait_stream(main)
         with torch.cuda.stream(s_rand):
+            ad.twin_heads(twin, B, T - 1)  # (the random pass's heads and loss: off the real pass's chain)
             ad.loss(acts, ops._at(self.logs, 4), B, T, T - 1, want_grad=False, twin=twin)
     ad.loss(acts, ops._at(self.logs, 2), B, T, T - 1, want_grad=True, grad_scale=gs)
     if self.add_random_plan_loss:

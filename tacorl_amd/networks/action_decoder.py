@@ -213,6 +213,14 @@ class ActionDecoderLogistic:
             self.wihtb = [None] + [bf(H, H) for _ in range(1, L)]  # W_ih^T of layers >= 1 (wavefront projections)
             self._bptt_shape = (B, Tm)
 
+    def twin_heads(self, twin, B, Tm):
+        """Output heads of the twin pass (after forward(twin=...)): a launch of its own, for the caller's side stream."""
+        if getattr(twin, "heads_done", False):
+            return
+        call("tacorl_rnn_linear_fwd", ptr(twin.hb[self.L - 1]), ptr(self.headw_b), ptr(self.headb), None, 0, ptr(twin.heads), None,
+             B * Tm, self.hidden, self.NHP, ACT_NONE, ops.stream())
+        twin.heads_done = True
+
     def _lin(self, x, ldx, w, b, y, M, K, N, act, compute, ldy=None):
         # split-K capable entry (skinny outputs with a long K: linear2 2048->32, the 2048->182 heads)
         nb = ops.L.lib().tacorl_linear_add_fwd_ws_bytes(1, ops.int_array([M]), K, N)
@@ -301,11 +309,14 @@ class ActionDecoderLogistic:
                      ptr(self.rnn_ws), self.rnn_ws.numel(), ops.stream())
             x, K = self.h[l], H
         if fast:  # output heads through the ring GEMM (bf16 weights, rows padded to a multiple of 32)
-            if twin is not None:
+            if twin is not None and not getattr(self, "twin_heads_apart", True):
                 call("tacorl_rnn_linear_fwd_batch_twin", 1, ops.ptr_array([self.hb[self.L - 1]]), ops.ptr_array([twin.hb[self.L - 1]]),
                      ops.ptr_array([self.headw_b]), ops.ptr_array([self.headb]), None, None, 0, ops.ptr_array([self.heads]),
                      ops.ptr_array([twin.heads]), None, None, R, R, H, self.NHP, ops.int_array([ACT_NONE]), ops.stream())
+                twin.heads_done = True
                 return
+            if twin is not None:
+                twin.heads_done = False  # (the caller issues twin_heads() where it wants them: off the real pass's chain)
             call("tacorl_rnn_linear_fwd", ptr(self.hb[self.L - 1]), ptr(self.headw_b), ptr(self.headb), None, 0,
                  ptr(self.heads), None, R, H, self.NHP, ACT_NONE, ops.stream())
         else:
