@@ -326,6 +326,10 @@ class PlanRecognition:
                 self._wgrad(self.pooled, D, self.d_fc, FC, B, D, FC, blk.g("fc.weight"), blk.g("fc.bias"), compute)
             side(head_grads)
         else:
+            if getattr(self, "_composed", False):
+                # (the forward took the head as one composed affine map - fc_out was never formed - but this backward is the
+                # per-op chain, e.g. window 32: form it now, mean_fc's weight gradient reads it)
+                self._lin(self.pooled, D, blk.p("fc.weight"), blk.p("fc.bias"), self.fc_out, B, D, FC, ACT_NONE, compute)
             side(lambda: self._wgrad(self.fc_out, FC, d_head, A2, B, FC, A2, blk.g("mean_fc.weight"), blk.g("mean_fc.bias"), compute))
             self._dgrad(d_head, A2, blk.p("mean_fc.weight"), self.d_fc, FC, B, A2, FC, compute)
             side(lambda: self._wgrad(self.pooled, D, self.d_fc, FC, B, D, FC, blk.g("fc.weight"), blk.g("fc.bias"), compute))

@@ -1118,6 +1118,17 @@ def test_plan_recognition_fused_train_forward_window32():
     for k, (a, b) in enumerate(zip(s0, s1)):
         assert torch.isfinite(b).all() and relerr(b, a) < 5e-3, (k, relerr(b, a))
     assert relerr(h1, h0) < 5e-3 and relerr(dx1, dx0) < 1e-2 and relerr(g1, g0) < 1e-2, (relerr(h1, h0), relerr(dx1, dx0), relerr(g1, g0))
+    # composed head + plan sample inside the launch (prepare_inference() issued), per-op backward: fc_out is formed there
+    eps, plan = rnd(B, A, seed=21).to(dev), torch.full((B, A), float("nan"), device=dev)
+    pr.prepare_inference()
+    pr.fc_out.fill_(float("nan"))
+    hc = pr.forward(emb, D, B, T, 1, train=True, prepared=True, sample=(eps, plan)).clone()
+    assert pr._composed and torch.isfinite(plan).all()
+    pr.blk.grad.zero_()
+    dxc = pr.backward(d_head, B, T, 1).clone()
+    torch.cuda.synchronize()
+    gc = pr.blk.grad.clone()
+    assert relerr(hc, h0) < 5e-3 and relerr(dxc, dx0) < 1e-2 and torch.isfinite(gc).all() and relerr(gc, g0) < 1e-2, (relerr(hc, h0), relerr(dxc, dx0), relerr(gc, g0))
 
 
 def test_plan_recognition_fused_train_forward():
