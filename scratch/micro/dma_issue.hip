@@ -20,7 +20,44 @@ __global__ __launch_bounds__(256) void k(const unsigned char* __restrict__ img, 
   for (int i = blockIdx.x; i < n_img; i += gridDim.x) {
     const unsigned char* src = img + (long)i * IMG;
     const unsigned long long t0 = clock64();
-    if (MODE == 0) {
+    if (MODE == 2 || MODE == 3) {
+      // C: the classic path - global_load_dwordx4 into VGPRs (4 per piece), ds_write_b128 once the data is there.
+      //    MODE 2: five pieces in flight, written, five more (20 VGPRs); MODE 3: all ten in flight (40 VGPRs)
+      constexpr int G = MODE == 2 ? 5 : 10;
+      u32x4 v[G];
+      for (int q0 = 0; q0 < 10; q0 += G) {
+#pragma unroll
+        for (int q = 0; q < G; q++)
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v[q]) : "v"(voff), "s"(src + (q0 + q) * 4096) : "memory");
+        if (MODE == 2) spent += 0;  // (the wait below is part of what the issuing wave pays in this form)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < G; q++)
+          *reinterpret_cast<u32x4*>(lds + buf * 43008 + (q0 + q) * 4096 + tid * 16) = v[q];
+      }
+    } else if (MODE == 4) {
+      // D: as C with ten pieces in flight, but the wait + LDS writes AFTER the image's other work (what a software-pipelined
+      //    kernel would do: loads issued early, written late) - only the issue and the writes are charged
+      u32x4 v[10];
+#pragma unroll
+      for (int q = 0; q < 10; q++)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v[q]) : "v"(voff), "s"(src + q * 4096) : "memory");
+      spent += clock64() - t0;
+      for (int r = 0; r < 60; r++) asm volatile("s_sleep 16");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long t1 = clock64();
+#pragma unroll
+      for (int q = 0; q < 10; q++) {
+        asm volatile("" : "+v"(v[q]));
+        *reinterpret_cast<u32x4*>(lds + buf * 43008 + q * 4096 + tid * 16) = v[q];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      spent += clock64() - t1;
+      __syncthreads();
+      acc += reinterpret_cast<const unsigned*>(lds + buf * 43008)[tid] + reinterpret_cast<const unsigned*>(lds + buf * 43008 + 40000)[tid & 63];
+      buf ^= 1;
+      continue;
+    } else if (MODE == 0) {
 #pragma unroll
       for (int q = 0; q < 10; q++) {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
@@ -80,5 +117,8 @@ int main() {
   };
   run("global_load_lds, SGPR base + lane VGPR", k<0>);
   run("buffer_load lds, ADD_TID resource, no VGPR", k<1>);
+  run("global_load -> VGPR, wait, ds_write (5 in flight)", k<2>);
+  run("global_load -> VGPR, wait, ds_write (10 in flight)", k<3>);
+  run("global_load -> VGPR early, ds_write late", k<4>);
   return 0;
 }
