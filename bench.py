@@ -290,31 +290,188 @@ def run_segment_probe(dtype, timeout=420):
     return {"error": f"rc {out.returncode}: {out.stderr[-400:]}"}
 
 
-def launch_ranks(n, argv):
-    """Self-launcher: one child process per GPU, rendezvous on 127.0.0.1.  Nothing in this (parent) process has
-    touched the GPU - it only waits for the children and passes rank 0's JSON line through its own stdout."""
+# ---------------------------------------------------------------------------------------------------------------------
+# N-rank supervisor: the first multi-GPU run must not be lost to a hang.
+#
+# With --gpus N > 1 the processes that the driver (or the user) started never touch a GPU.  They are SUPERVISORS: each
+# starts its rank's WORKER as a fresh child process and watches it.  The workers try the step's collective forms in turn,
+#   1. "graph-nodes": RCCL all-reduces captured as nodes of the step's ONE hipGraph (fastest; verified with a 1-rank
+#      communicator only - the pool hands out 1-GPU boxes),
+#   2. "segments":    three collective-free hipGraph segments with eager all-reduces between them (what every 2-rank test runs),
+#   3. "eager":       no hipGraph at all,
+# and an attempt ends - everywhere - as soon as any rank's worker fails, reports replicas out of sync, or prints nothing
+# for TACORL_BENCH_STAGE_TIMEOUT seconds (workers print a heartbeat line per stage).  Then every worker of the attempt is
+# killed and the next form starts in NEW processes on a new rendezvous port: a process that has touched the GPU is never
+# re-exec'ed or reused.  Two launch modes: `python bench.py --gpus N` (one supervisor, N workers) and
+# `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (N supervisors - torchrun's ranks - that agree
+# through a gloo group on host tensors, one worker each).  Rank 0's JSON line is printed once, by its supervisor, with a
+# `launcher` block (the attempts and their outcomes) and `config.collectives` naming the form that produced it.
+FORMS = (("graph-nodes", {"TACORL_GRAPH_COLLECTIVES": "1"}, ()),
+         ("segments", {"TACORL_GRAPH_COLLECTIVES": "0"}, ()),
+         ("eager", {"TACORL_GRAPH_COLLECTIVES": "0"}, ("--no-graph",)))
+FORM_TEXT = {"graph-nodes": "rccl nodes inside the step's one hipGraph",
+             "segments": "eager all-reduces between three hipGraph segments",
+             "eager": "eager all-reduces, no hipGraph"}
+
+
+def _forms():
+    names = os.environ.get("TACORL_BENCH_FORMS")
+    if names:
+        return [f for f in FORMS if f[0] in names.split(",")]
+    if os.environ.get("TACORL_DIST_BACKEND", "nccl") != "nccl":
+        return list(FORMS[1:])  # gloo cannot be captured into a graph
+    return list(FORMS)
+
+
+def _free_port():
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        return so.getsockname()[1]
+
+
+def heartbeat(stage):
+    """Worker side: one line per stage on stdout (a pipe to the supervisor, which times the silence between lines)."""
+    if os.environ.get("TACORL_BENCH_WORKER"):
+        print(f"HB {stage}", flush=True)
+
+
+def inject_hang(rank):
+    """Test hook: TACORL_BENCH_INJECT_HANG="<form>:<rank>" makes that rank's worker of that attempt stall for ever at the
+    point where a stuck collective would (tests/test_dist_cpu.py; never set by the driver)."""
+    spec = os.environ.get("TACORL_BENCH_INJECT_HANG")
+    if spec and os.environ.get("TACORL_BENCH_WORKER"):
+        form, r = spec.rsplit(":", 1)
+        if form == os.environ.get("TACORL_BENCH_FORM") and int(r) == rank:
+            print(f"[rank {rank}] injected hang in form {form}", file=sys.stderr, flush=True)
+            while True:
+                time.sleep(3600)
+
+
+class _Worker:
+    """One rank's worker process: stdout through a pipe (heartbeats + the JSON line), stderr passed through."""
+
+    def __init__(self, rank, world, port, form, argv):
+        import threading
+
+        name, env_extra, extra_args = form
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}  # (the agent's store is not ours)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TACORL_BENCH_WORKER="1", TACORL_BENCH_FORM=name,
+                   PYTHONUNBUFFERED="1", **env_extra)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
-    rc = 0
-    live = list(procs)
-    while live:
-        time.sleep(0.2)
-        for p in list(live):
-            code = p.poll()
-            if code is None:
-                continue
-            live.remove(p)
-            if code != 0 and rc == 0:  # a rank died: the others would wait in a collective for ever
-                rc = code
-                for q in live:
-                    q.terminate()
+        self.rank, self.lines, self.stage, self.last = rank, [], "start", time.monotonic()
+        self.p = subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv, *extra_args], env=env,
+                                  stdout=subprocess.PIPE, text=True, bufsize=1)
+        self.t = threading.Thread(target=self._read, daemon=True)
+        self.t.start()
+
+    def _read(self):
+        for ln in self.p.stdout:
+            self.last = time.monotonic()
+            ln = ln.rstrip("\n")
+            if ln.startswith("HB "):
+                self.stage = ln[3:]
+            else:
+                self.lines.append(ln)
+
+    def state(self, start_timeout, stage_timeout):
+        """'run' | 'ok' | 'rc <n>' | 'stalled ...'"""
+        code = self.p.poll()
+        if code is not None:
+            self.t.join(timeout=5)
+            return "ok" if code == 0 else f"rc {code} at stage {self.stage}"
+        idle = time.monotonic() - self.last
+        if idle > (start_timeout if self.stage == "start" else stage_timeout):
+            return f"stalled {idle:.0f}s at stage {self.stage}"
+        return "run"
+
+    def kill(self):
+        if self.p.poll() is None:
+            self.p.terminate()
+            try:
+                self.p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                self.p.kill()
+                self.p.wait()
+
+
+def _timeouts():
+    # the first `import torch` on a fresh box pages the image in (1-2 min); after that every stage is seconds
+    return (float(os.environ.get("TACORL_BENCH_START_TIMEOUT", "420")), float(os.environ.get("TACORL_BENCH_STAGE_TIMEOUT", "150")))
+
+
+def _publish(lines, attempts, form):
+    for ln in lines:
+        if ln.startswith("{"):
+            try:
+                d = json.loads(ln)
+                d["launcher"] = {"attempts": attempts, "form": form,
+                                 "note": "supervised launch: workers are fresh child processes per attempt; an attempt ends "
+                                         "everywhere when any rank fails or is silent past its stage timeout"}
+                ln = json.dumps(d)
+            except ValueError:
+                pass
+        print(ln, flush=True)
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N`: ONE supervisor (this process, which has touched no GPU) and N workers per attempt."""
+    t_start, t_stage = _timeouts()
+    attempts = []
+    for form in _forms():
+        ws = [_Worker(r, n, port, form, argv) for port in [_free_port()] for r in range(n)]
+        outcome = None
+        while outcome is None:
+            time.sleep(0.2)
+            st = [w.state(t_start, t_stage) for w in ws]
+            bad = [f"rank {w.rank}: {s}" for w, s in zip(ws, st) if s not in ("run", "ok")]
+            if bad:
+                outcome = "; ".join(bad)
+            elif all(s == "ok" for s in st):
+                outcome = "ok"
+        for w in ws:
+            w.kill()
+        attempts.append({"form": form[0], "outcome": outcome})
+        if outcome == "ok":
+            _publish(ws[0].lines, attempts, form[0])
+            return 0
+        print(f"[bench supervisor] form {form[0]} abandoned: {outcome}", file=sys.stderr, flush=True)
+    return 1
+
+
+def supervise_rank(argv):
+    """Under torch.distributed.run: this process is rank RANK's supervisor.  The supervisors form a gloo group on host
+    tensors (the rendezvous torchrun set up; no GPU call) and agree once a second on the attempt's fate."""
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    t_start, t_stage = _timeouts()
+    attempts, rc = [], 1
+    for form in _forms():
+        port = torch.tensor([_free_port() if rank == 0 else 0])
+        dist.broadcast(port, 0)
+        w = _Worker(rank, world, int(port.item()), form, argv)
+        outcome = None
+        while outcome is None:
+            time.sleep(1.0)
+            s = w.state(t_start, t_stage)
+            v = torch.tensor([float(s == "ok"), float(s not in ("run", "ok"))])
+            dist.all_reduce(v)  # every supervisor sees the same sums, so every supervisor takes the same decision
+            if v[1] > 0:
+                outcome = s if s not in ("run", "ok") else "abandoned: another rank failed or stalled"
+            elif v[0] == world:
+                outcome = "ok"
+        w.kill()
+        attempts.append({"form": form[0], "outcome": outcome})
+        if outcome == "ok":
+            if rank == 0:
+                _publish(w.lines, attempts, form[0])
+            rc = 0
+            break
+        print(f"[bench supervisor {rank}] form {form[0]} abandoned: {outcome}", file=sys.stderr, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
     return rc
 
 
@@ -322,7 +479,10 @@ def launch_check(world, rank):
     """`--launch-check`: rendezvous + one all-reduce on host tensors, no GPU work (the CPU test of the launcher)."""
     import torch.distributed as dist
 
+    heartbeat("imported")
     dist.init_process_group(os.environ.get("TACORL_DIST_BACKEND", "gloo"))
+    heartbeat("group")
+    inject_hang(rank)
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t)
     if rank == 0:
@@ -567,8 +727,13 @@ def main():
 
     if a.probe == "segments":
         return segment_probe(a.dtype)
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))  # no GPU call has happened in this process
+    if a.gpus > 1 and not os.environ.get("TACORL_BENCH_WORKER"):
+        # no GPU call has happened (or will happen) in this process: it supervises fresh worker processes
+        if "WORLD_SIZE" not in os.environ:
+            sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+        if int(os.environ["WORLD_SIZE"]) != a.gpus:
+            sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: start with --nproc-per-node {a.gpus}")
+        sys.exit(supervise_rank(sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -582,6 +747,7 @@ def main():
     if os.environ.get("TACORL_BENCH_SINGLE_DEVICE"):
         local = 0
     backend = os.environ.get("TACORL_DIST_BACKEND", "nccl")
+    heartbeat("imported")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     if world > 1:
@@ -592,6 +758,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        heartbeat("group")
 
     from tacorl_amd import _lib
 
@@ -627,28 +794,35 @@ def main():
 
     from tacorl_amd import dist as D
 
-    coll_form = None
+    heartbeat("module built")
+    ranks_seen = None
     if world > 1:
-        coll_form = "rccl nodes inside the step's one hipGraph" if (use_graph and D.graph_collectives()) else \
-            "eager all-reduces between three hipGraph segments"
-    try:
-        for _ in range(max(a.warmup, 2)):
-            mod.training_step(batch)
-        torch.cuda.synchronize()
-    except Exception as e:  # noqa: BLE001
-        if not (world > 1 and use_graph and D.graph_collectives()):
-            raise
-        # the capture of a collective was refused (every rank runs the same code, so every rank lands here): fall back to the
-        # segmented form - collective-free graphs with the all-reduces issued eagerly between them
-        print(f"[rank {rank}] in-graph collectives failed ({type(e).__name__}: {str(e)[:200]}); using graph segments", file=sys.stderr, flush=True)
-        os.environ["TACORL_GRAPH_COLLECTIVES"] = "0"
-        coll_form = "eager all-reduces between three hipGraph segments (in-graph capture failed)"
-        mod._graphs = {}
-        torch.cuda.synchronize()
-        for _ in range(max(a.warmup, 2)):
-            mod.training_step(batch)
-    dt = max_over_ranks(timed_steps(mod, batch, a.steps, barrier))
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)  # (also the communicator's first collective, outside any capture)
+        ranks_seen = int(ones.item())
+        heartbeat("first all-reduce")
+    for i in range(max(a.warmup, 2)):
+        mod.training_step(batch)
+        if i == 1:  # eager pass + capture done, first replay issued
+            torch.cuda.synchronize()
+            heartbeat("captured")
+            inject_hang(rank)
+    torch.cuda.synchronize()
+    heartbeat("warm")
+    coll_form = None
+    if world > 1:  # read AFTER the captures: a refused in-graph capture falls back to segments inside the library
+        coll_form = FORM_TEXT["eager"] if not use_graph else FORM_TEXT["graph-nodes" if D.graph_collectives() else "segments"]
+        if os.environ.get("TACORL_BENCH_FORM") == "graph-nodes" and not D.graph_collectives():
+            coll_form += " (in-graph capture was refused)"
+    my_dt = timed_steps(mod, batch, a.steps, barrier)
+    dt = max_over_ranks(my_dt)
     ms_step = dt / a.steps * 1e3
+    rank_ms = None
+    if world > 1:  # arrival skew: every rank's own wall time over the same region
+        lo = torch.tensor([my_dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        rank_ms = {"min": round(lo.item() / a.steps * 1e3, 4), "max": round(ms_step, 4)}
+    heartbeat("timed")
     logs = mod.engine.metrics()
     finite = all(v == v and abs(v) < 1e30 for v in logs.values())
     dist_stats = None if a.no_distribution else step_time_distribution(mod, batch, ms_step)
@@ -657,6 +831,7 @@ def main():
     enc_probe = time_encoder_fwd(mod, B, H, W) if rank == 0 else None
     # (training steps: on N ranks they hold the step's all-reduces, so every rank runs them; rank 0's reading is reported)
     enc_in_step = time_encoder_in_step(mod, batch)
+    heartbeat("probes")
 
     def replicas_in_sync():
         e = mod.engine
@@ -669,6 +844,9 @@ def main():
     in_sync, strong = None, None
     if world > 1:  # replicas must hold identical parameters after the timed steps (same all-reduced grads)
         in_sync = replicas_in_sync()
+        if not in_sync and os.environ.get("TACORL_BENCH_WORKER"):
+            # a form whose all-reduces did not reduce is a failed attempt: the supervisor moves on to the next one
+            sys.exit(f"[rank {rank}] replicas out of sync after the timed steps with {coll_form}")
         # strong scaling: the SAME global batch of 256, 256/N samples per GPU -> true optimiser steps per second
         if B % world == 0:
             sb = synth_batch(B // world, T, H, W, dev, DATA_SEED + 100 + rank)
@@ -680,6 +858,7 @@ def main():
                       "replicas_in_sync": replicas_in_sync()}
             for _ in range(3):  # back to the bench shape for the roofline probe below
                 mod.training_step(batch)
+        heartbeat("strong")
 
     feeder = None
     if a.feeder != "none":
@@ -735,7 +914,7 @@ def main():
                        "action_decoder_loss": ("every step (reference behaviour)" if a.ad_every <= 1 else
                                                f"every {a.ad_every} steps (logging cadence)"), "parallelism": f"dp{world}",
                        "collective_backend": None if world == 1 else ("rccl" if backend == "nccl" else backend),
-                       "collectives": coll_form,
+                       "collectives": coll_form, "rccl_ranks_seen": ranks_seen, "rank_ms_per_step": rank_ms,
                        "hip_graph": bool(use_graph),
                        "samples_per_s": round(world * B / (ms_step * 1e-3), 1), "losses_finite": finite,
                        "replicas_in_sync": in_sync},

@@ -56,18 +56,40 @@ def collectives_on(world):
 
 def graph_collectives():
     """Are the step's all-reduces nodes of its ONE captured hipGraph (RCCL kernels captured on the step's stream) instead of
-    eager calls between three graph segments?  Default: yes when the process group's backend is nccl (= RCCL) - measured
-    on one MI355X with a 1-rank communicator (bench.py --probe segments, profiles/r04_segment_probe.json): 0.883 ms/step
-    against 0.963 for the three-segment form and 0.874 for the collective-free graph.  gloo cannot be captured: the
-    CPU-backend tests always run segments.  TACORL_GRAPH_COLLECTIVES=0 / 1 overrides."""
-    env = os.environ.get("TACORL_GRAPH_COLLECTIVES")
-    if env is not None:
-        return env == "1"
-    if not group_ready():
+    eager calls between three graph segments?
+
+    Default: **no** - segments, the form every N-rank test has run (gloo, 2 ranks) and the ordinary way RCCL is driven.
+    The one-graph form is opt-in with TACORL_GRAPH_COLLECTIVES=1 (backend nccl only; gloo cannot be captured): it measures
+    0.878 ms/step against 0.964 for segments on one MI355X with a 1-rank communicator (bench.py --probe segments), but an
+    N > 1 RCCL capture has never run on this pool (1-GPU boxes), so the library does not bet a training run on it
+    (ADVICE r4).  `bench.py --gpus N` opts in for its first attempt under a supervisor that falls back to segments
+    (fresh processes) when the attempt fails or stalls; a refused capture inside a Trainer run falls back in
+    GraphMixin._capture."""
+    if os.environ.get("TACORL_GRAPH_COLLECTIVES", "0") != "1" or not group_ready():
         return False
     import torch.distributed as dist
 
     return dist.get_backend() == "nccl"
+
+
+def refuse_graph_collectives(reason=""):
+    """Called when a capture that contains collectives failed: from here on this process uses segments."""
+    os.environ["TACORL_GRAPH_COLLECTIVES"] = "0"
+    if reason:
+        import sys
+
+        print(f"[tacorl_amd.dist] all-reduces stay outside the hipGraph from now on: {reason}", file=sys.stderr, flush=True)
+
+
+def any_rank(flag, device):
+    """max over ranks of a host boolean (one tiny eager all-reduce; no-op without a group)."""
+    if not group_ready():
+        return bool(flag)
+    import torch.distributed as dist
+
+    t = torch.tensor([1.0 if flag else 0.0], device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item() > 0)
 
 
 def all_reduce_sum_(t):

@@ -282,6 +282,10 @@ class GraphMixin:
         if not hasattr(self, "_graphs"):
             self._graphs = {}
         from .. import ops
+        base_key = key
+        # the collective form is part of what a capture froze: a graph captured without collectives, or as
+        # one graph, must not be replayed after TACORL_FORCE_COLLECTIVES / TACORL_GRAPH_COLLECTIVES / _force_graph_split moved
+        key = (base_key, self._segmented(), self._collectives_in_graph())
         gs = self._graphs.get(key)
         if gs is not None:  # least-recently-used order: a hit moves the key to the end
             self._graphs[key] = self._graphs.pop(key)
@@ -293,7 +297,7 @@ class GraphMixin:
             gs = None
         if gs is None:
             with ops.capture_lock:  # no feeder thread prepares a batch (allocations, event waits) beside the capture
-                self._capture(key, segs, collectives, side, eager)
+                self._capture(base_key, segs, collectives, side, eager)
             return
         gs, g_side, _ = gs
         stepped = getattr(self, "_stepped_blocks", None)
@@ -314,11 +318,16 @@ class GraphMixin:
     def _capture(self, key, segs, collectives, side, eager):
         """One eager pass (sizes every workspace, so the capture allocates nothing; it IS this call's step), then the
         capture(s) of the step for later calls."""
-        from .. import ops
-
         eager()  # warm-up: sizes every workspace, so the capture allocates nothing
         torch.cuda.synchronize()
+        self._capture_only(key, segs, collectives, side)
+
+    def _capture_only(self, key, segs, collectives, side):
+        from .. import dist as D
+        from .. import ops
+
         split = self._segmented()
+        in_graph = (not split) and self._collectives_in_graph()
         if split:
             parts = [[f] for f in segs]
         else:
@@ -329,15 +338,30 @@ class GraphMixin:
                 parts[0].append(f)
                 if side is not None and side[0] == i:
                     parts[0].append(side[1])
-                if i < len(collectives) and self._collectives_in_graph():
+                if i < len(collectives) and in_graph:
                     parts[0].append(collectives[i])
-        gs = []
-        for part in parts:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                for f in part:
-                    f()
-            gs.append(g)
+        gs, failed = [], None
+        try:
+            for part in parts:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    for f in part:
+                        f()
+                gs.append(g)
+        except Exception as e:  # noqa: BLE001
+            if not in_graph:
+                raise
+            failed = e
+        if in_graph and D.any_rank(failed is not None, self.device):
+            # The capture of a collective was refused on some rank (every rank asks, so every rank lands here together):
+            # drop it everywhere and capture the step again as collective-free segments with eager all-reduces between
+            # them - the form the N-rank tests run.  (A capture that *hangs* cannot be caught in-process: that is what
+            # bench.py's supervisor and a Trainer's own timeout are for.)
+            del gs
+            D.refuse_graph_collectives(f"capture failed ({type(failed).__name__}: {str(failed)[:160]})" if failed
+                                       else "capture failed on another rank")
+            torch.cuda.synchronize()
+            return self._capture_only(key, segs, collectives, side)
         g_side = None
         if split and side is not None:
             g_side = torch.cuda.CUDAGraph()
@@ -345,6 +369,7 @@ class GraphMixin:
                 side[1]()
             if getattr(self, "_side_replay_stream", None) is None:
                 self._side_replay_stream = torch.cuda.Stream(device=self.device)
+        key = (key, split, in_graph)
         self._graphs[key] = (gs, g_side, ops.alloc_epoch())
         # A long job alternates keys (train / validation, the epoch's last partial batch, the BC -> Q phase switch):
         # keep the most recently used few and release the rest - dozens of live instantiated graphs in one process

@@ -81,9 +81,66 @@ def test_bench_self_launcher_rendezvous():
                          cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    launcher = res.pop("launcher")
     assert res == {"launch_check": True, "world": 2, "sum": 3.0}
+    assert launcher["form"] == "segments" and launcher["attempts"] == [{"form": "segments", "outcome": "ok"}]
     # a rank that fails takes the launch down with a non-zero exit code instead of hanging the others
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
                          env=dict(env, TACORL_DIST_BACKEND="no-such-backend"), cwd=root, capture_output=True, text=True,
                          timeout=300)
     assert bad.returncode != 0
+
+
+def _launch_check(cmd_prefix, extra_env, timeout=300):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TACORL_DIST_BACKEND="gloo", TACORL_BENCH_STAGE_TIMEOUT="6", **extra_env)
+    out = subprocess.run([sys.executable, *cmd_prefix, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         cwd=root, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out, [json.loads(ln) for ln in lines]
+
+
+def _torchrun():
+    from tests.proc_util import free_port
+
+    return ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+            str(free_port())]
+
+
+def test_bench_supervisor_survives_a_hung_rank_self_launched():
+    """a rank that stalls inside a collective form (injected: rank 1 sleeps for ever in the 'segments'
+    attempt) must cost the stage timeout, not the line - the supervisor kills the attempt's workers and starts FRESH
+    processes with the next form, and the line says which form produced it."""
+    out, res = _launch_check([], {"TACORL_BENCH_INJECT_HANG": "segments:1"})
+    assert out.returncode == 0 and len(res) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    at = res[0]["launcher"]["attempts"]
+    assert res[0]["launcher"]["form"] == "eager" and [x["form"] for x in at] == ["segments", "eager"]
+    assert "stalled" in at[0]["outcome"] and "rank 1" in at[0]["outcome"] and at[1]["outcome"] == "ok"
+    assert res[0]["sum"] == 3.0
+
+
+def test_bench_supervisor_survives_a_hung_rank_under_torchrun():
+    """The driver's launch form: torch.distributed.run starts the two ranks, each of which is a supervisor (gloo group on
+    host tensors, no GPU call) with one worker; a hang on rank 0's worker is seen by both, both move on together."""
+    out, res = _launch_check(_torchrun(), {"TACORL_BENCH_INJECT_HANG": "segments:0"})
+    assert out.returncode == 0 and len(res) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    at = res[0]["launcher"]["attempts"]
+    assert res[0]["launcher"]["form"] == "eager" and [x["form"] for x in at] == ["segments", "eager"]
+    assert "stalled" in at[0]["outcome"] and at[1]["outcome"] == "ok"
+    assert res[0]["world"] == 2 and res[0]["sum"] == 3.0
+
+
+def test_bench_supervisor_under_torchrun_without_faults():
+    out, res = _launch_check(_torchrun(), {})
+    assert out.returncode == 0 and len(res) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    assert res[0]["launcher"]["attempts"] == [{"form": "segments", "outcome": "ok"}]
+
+
+def test_bench_supervisor_gives_up_with_nonzero_exit_when_every_form_hangs():
+    out, res = _launch_check([], {"TACORL_BENCH_INJECT_HANG": "segments:1", "TACORL_BENCH_FORMS": "segments"})
+    assert out.returncode != 0 and not res

@@ -44,6 +44,27 @@ def test_bench_self_launcher_two_ranks():
     assert st["per_gpu_batch"] == 32 and st["global_batch"] == 64 and st["value"] > 0 and st["replicas_in_sync"] is True
 
 
+def test_bench_supervisor_falls_back_when_a_rank_hangs_in_the_step():
+    """VERDICT r4 #2 on the real step: under torch.distributed.run (the driver's form) rank 1's worker stalls right after
+    its first graph replay of the 'segments' attempt (injected).  Both supervisors see the silence, kill their workers and
+    start fresh processes with the next form; the line comes from that form and carries the N-rank evidence fields."""
+    env = dict(os.environ, TACORL_DIST_BACKEND="gloo", TACORL_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1",
+               TACORL_BENCH_INJECT_HANG="segments:1", TACORL_BENCH_STAGE_TIMEOUT="45")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--batch", "64", "--no-cpu-baseline", "--no-distribution"]
+    out = run_group(cmd, env, ROOT, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    at = res["launcher"]["attempts"]
+    assert [x["form"] for x in at] == ["segments", "eager"] and "stalled" in at[0]["outcome"] and at[1]["outcome"] == "ok"
+    assert res["config"]["hip_graph"] is False and "no hipGraph" in res["config"]["collectives"]
+    assert res["config"]["rccl_ranks_seen"] == 2 and res["config"]["replicas_in_sync"] is True
+    assert res["config"]["rank_ms_per_step"]["min"] <= res["config"]["rank_ms_per_step"]["max"] == res["ms_per_step"]
+
+
 def test_two_rank_shards_equal_the_full_batch_step():
     """TACORL (frozen / fine-tuned action decoder), CQL_Offline, PlayLMP: two ranks on per-sample shards with sharded
     noise, hipGraph segments around the all-reduces, against the single-rank full-batch step (tests/dist_shard_script.py)."""
