@@ -1229,8 +1229,8 @@ extern "C" int tacorl_mlp_bwd_fused_wgrad(int nprob, const float* const* x, int 
     }
   }
   if (n[1] && mlp_fused_wgrad_big(n[1], xs[1], ldx, as[1], ds[1], ldo, dzp[1], gs[1], (float*)slab, xb, Ms[1], L, dims, yoffs[1],
-                                  dzo[1], wo, bo, accumulate, st))
-    FAIL(TACORL_ELAUNCH, "mlp_bwd_fused_wgrad: many-row launch failed");
+                                  dzo[1], wo, bo, accumulate, st, w.slab_bytes / sizeof(float)))
+    FAIL(TACORL_ELAUNCH, "mlp_bwd_fused_wgrad: many-row launch failed (or its records exceed the planned slab)");
   if (!n[0]) return TACORL_OK;
   if (mlp_fused_wgrad_ok(n[0], L, dims)) {  // every layer and network in one launch (+ one reduce)
     if (mlp_fused_wgrad(n[0], xs[0], ldx, as[0], ds[0], ldo, dzp[0], gs[0], (float*)slab, Ms[0], L, dims, yoffs[0], dzo[0], wo, bo,

@@ -57,4 +57,4 @@ size_t mlp_big_xb_bytes(int M);
 int mlp_fused_wgrad_big(int nprob, const float* const* x, int ldx, const float* const* act, const float* const* d_out, int ldo,
                         const float* const* dz, float* const* grads, float* slab, void* const* xb, const int* M, int L,
                         const int* dims, const long* ybf, const long* dzoff, const long* woff, const long* boff, int accumulate,
-                        hipStream_t st);
+                        hipStream_t st, size_t slab_floats);

@@ -1283,7 +1283,7 @@ size_t mlp_big_xb_bytes(int M) { return (size_t)((M + 63) & ~63) * 128 * 2; }
 int mlp_fused_wgrad_big(int nprob, const float* const* x, int ldx, const float* const* act, const float* const* d_out, int ldo,
                         const float* const* dz, float* const* grads, float* slab, void* const* xb, const int* M, int L,
                         const int* dims, const long* ybf, const long* dzoff, const long* woff, const long* boff, int accumulate,
-                        hipStream_t st) {
+                        hipStream_t st, size_t slab_floats) {
   MlpWgBigArgs a{};
   MlpXbArgs xa{};
   MlpWgOutArgs oa{};
@@ -1291,11 +1291,12 @@ int mlp_fused_wgrad_big(int nprob, const float* const* x, int ldx, const float* 
   a.rec = r.rec = mlp_wgrad_record(L, dims, a.sloff);
   oa.rec = ro.rec = mlp_big_out_rec(L, dims);
   r.accumulate = ro.accumulate = accumulate;
-  int Mg[MF_MAXP], ng = 0;
-  for (int p = 0; p < nprob; p++)
-    if (grads[p] && M[p] > 0) Mg[ng++] = M[p];
+  int ng = 0;
+  for (int p = 0; p < nprob; p++) ng += (grads[p] && M[p] > 0) ? 1 : 0;
   if (!ng) return 0;
-  a.rps = mlp_big_rps(ng, Mg, L);
+  // rows per slice from EVERY problem of the call, graded or not - the set mlp_big_wgrad_slab_floats sized the slab for
+  // (fewer problems would mean more, shorter slices: more records than planned); the capacity is checked below
+  a.rps = mlp_big_rps(nprob, M, L);
   a.nl = L - 1;
   for (int l = 0; l <= L; l++) r.dims[l] = dims[l];
   for (int l = 0; l < L; l++) { r.sloff[l] = a.sloff[l]; r.woff[l] = woff[l]; r.boff[l] = boff[l]; }
@@ -1325,6 +1326,7 @@ int mlp_fused_wgrad_big(int nprob, const float* const* x, int ldx, const float* 
     oa.y[n2] = reinterpret_cast<const __bf16*>(act[p] + ybf[p * MF_MAXL + L - 2]); oa.dlast[n2] = d_out[p]; oa.slab[n2] = sp; oa.M[n2] = M[p];
     ro.slab[n2] = sp; ro.grad[n2] = grads[p]; ro.nslice[n2] = nso;
     sp += (size_t)nso * oa.rec;
+    if ((size_t)(sp - slab) > slab_floats) return -2;  // the records would run past the caller's slab
     maxs = ns > maxs ? ns : maxs; maxso = nso > maxso ? nso : maxso; maxMp = Mp > maxMp ? Mp : maxMp;
     n2++;
   }

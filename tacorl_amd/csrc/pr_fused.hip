@@ -1033,7 +1033,9 @@ extern "C" int tacorl_pr_encoder_bwd_fused(const float* params, const long* offs
                                            int H, int FF, int L, tacorl_stream_t stream) {
   // wt[4 l + {0, 1, 2, 3}]: linear1.weight^T, linear2.weight^T, out_proj.weight^T [32][32], in_proj_weight^T [32][96] as bf16
   // (the last two may be NULL: gathered transposed from the fp32 block inside the launch)
-  if (!tacorl_pr_encoder_fused_supported(D, T, H, FF, L) || T != PR_T || B < 1) return TACORL_EINVAL;  // (backward: window 16 only)
+  // backward: d_model 32 (PR_D: 64-column LayerNorm partials, [32][*] transposes and saves) and window 16 only - the
+  // forward also takes d_model 64 / window 32, which must be refused here instead of running out of bounds
+  if (!tacorl_pr_encoder_fused_train_supported(D, T, H, FF, L) || D != PR_D || T != PR_T || B < 1) return TACORL_EINVAL;
   if (!params || !dx || !saved || !dz || !wt || !ln_part || !ln_grads) return TACORL_EINVAL;
   if (!d_pool && (!d_head || !Wc || A2 < 1)) return TACORL_EINVAL;
   if (((uintptr_t)params | (uintptr_t)d_pool | (uintptr_t)dx | (uintptr_t)ln_part | (uintptr_t)Wc) & 15) return TACORL_EINVAL;

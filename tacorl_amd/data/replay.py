@@ -164,8 +164,16 @@ class _PinnedRing:
             off = (off + a.nbytes + 15) // 16 * 16
         hd = self.slots[slot].get("_packed")
         if hd is None or hd[0].numel() < off:
-            hd = self.slots[slot]["_packed"] = (torch.empty(off, dtype=torch.uint8).pin_memory(),
-                                               torch.empty(off, dtype=torch.uint8, device=self.dev))
+            from .. import ops
+
+            # growth (a batch larger than the pre-allocated staging): hipHostMalloc / hipMalloc must not run beside a
+            # capture, whoever called us - prefetching() holds the lock already (an RLock), a user's own feeder thread
+            # calling HbmReplay.batch() directly does not - and captured graphs that could hold the old
+            # buffer's address are invalidated
+            with ops.capture_lock:
+                hd = self.slots[slot]["_packed"] = (torch.empty(off, dtype=torch.uint8).pin_memory(),
+                                                   torch.empty(off, dtype=torch.uint8, device=self.dev))
+                ops.note_alloc()
         hnp = hd[0].numpy()
         for k, a in arrs.items():
             hnp[offs[k]:offs[k] + a.nbytes] = a.reshape(-1).view(np.uint8)

@@ -1406,3 +1406,26 @@ def test_attention_fwd_bwd_t16(B, dropout):
     torch.cuda.synchronize()
     assert relerr(o, out) < TOL_F32, relerr(o, out)
     assert torch.isfinite(dq).all() and relerr(dq, q.grad) < TOL_F32, relerr(dq, q.grad)
+
+
+def test_plan_recognition_fused_backward_refuses_shapes_it_is_not_built_for():
+    """the forward launch also takes d_model 64 / window 32, the backward launch is d_model 32, window 16 only
+    (64-column LayerNorm partials, [32][*] transposes): a direct C-ABI call with another shape must return EINVAL before
+    anything is launched, not run out of bounds.  All pointers valid-looking and 16-byte aligned so that only the shape
+    check can refuse."""
+    import ctypes as C
+
+    from tacorl_amd import _lib, ops
+
+    dev = _dev()
+    buf = torch.zeros(1 << 16, device=dev)
+    p = ops.ptr(buf)
+    offs = (C.c_long * 40)(*([0] * 40))
+    pa = _lib.ptr_array([buf] * 18)
+    L = _lib.lib()
+    assert L.tacorl_pr_encoder_fused_supported(64, 32, 8, 2048, 2) == 1
+    for D, T in ((64, 32), (64, 16), (32, 32)):
+        assert L.tacorl_pr_encoder_fused_train_supported(D, T, 8, 2048, 2) in (0, 1)
+        rc = L.tacorl_pr_encoder_bwd_fused(p, offs, p, p, p, 32, p, pa, pa, pa, p, pa, 4, D, T, 8, 2048, 2, ops.stream())
+        assert rc != 0, (D, T)
+    torch.cuda.synchronize()
