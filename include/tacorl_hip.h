@@ -225,6 +225,23 @@ int tacorl_mlp_lean_supported(int nprob, int n_layers, const int* dims, int ldx,
 int tacorl_mlp_fwd_fused(int nprob, const float* const* x, int ldx, const float* const* params,
                          const void* const* params_bf16, float* const* act, const int* M,
                          int n_layers, const int* dims, const int* acts, int lean, tacorl_stream_t stream);
+/* tacorl_mlp_fwd_fused with a GATHERED layer-0 input: row r of problem p is the concatenation of nseg[p] <= 4 column
+ * segments; segment t supplies columns [seg_c0[4p+t], seg_c0[4p+t+1]) (the last one up to dims[0]) from
+ * seg_ptr[4p+t][(seg_mod[4p+t] ? r % seg_mod[4p+t] : r) * seg_ld[4p+t] + col - seg_c0[4p+t]].  This is the reference's
+ * torch.cat([enc(obs), goal_enc(enc(goal))]) (networks/actor_critic/visual_actor_wrapper.py:41-62,
+ * visual_critic_wrapper.py:50-71), torch.cat([emb, action]) (critic.py:92-97) and expand_obs (utils/misc.py:132-153:
+ * state rows repeated for every sampled action = seg_mod B) read where the producers left them, with no copy launch in
+ * front of the MLP.  x_out != NULL and x_out[p] != NULL: the assembled fp32 rows are also written to x_out[p] ([M][ldx]),
+ * layer 0's operand of the weight-gradient launch.  seg_c0 % 8 == 0, seg_ld % 4 == 0, pointers 16-byte aligned.
+ * _supported == 0 (a many-row problem of a lean site, or shapes the fused forward does not take): assemble with
+ * tacorl_copy_cols_batch and call tacorl_mlp_fwd_fused / tacorl_mlp_fwd. */
+int tacorl_mlp_fwd_fused_gather_supported(int nprob, const int* M, int n_layers, const int* dims, const int* acts,
+                                          int ldx, int lean);
+int tacorl_mlp_fwd_fused_gather(int nprob, const int* nseg, const float* const* seg_ptr, const int* seg_ld,
+                                const int* seg_c0, const int* seg_mod, float* const* x_out, int ldx,
+                                const float* const* params, const void* const* params_bf16, float* const* act,
+                                const int* M, int n_layers, const int* dims, const int* acts, int lean,
+                                tacorl_stream_t stream);
 /* dst[i][:] = bf16(src[i][:]) for n <= 16 buffers in one launch (count[i] % 4 == 0). */
 int tacorl_to_bf16_batch(int n, const float* const* src, void* const* dst, const long* count,
                          tacorl_stream_t stream);
@@ -524,6 +541,15 @@ int tacorl_adam_step_batch(int nb, float* const* param, const float* const* grad
                            float* const* v, const long* n, const float* lr, const float* max_norm,
                            int* const* step_counter, float* const* target, const float* tau, void* ws,
                            size_t ws_bytes, tacorl_stream_t stream);
+/* The same update; mirror[b] / target_mirror[b] (either array or any entry may be NULL): bf16 copies of the UPDATED
+ * parameter block / Polyak target at the same element offsets, written by the update launch itself - the fused MLP
+ * kernels' MFMA operand (params_bf16 of tacorl_mlp_fwd_fused) is then current when the step ends and the next step needs
+ * no tacorl_to_bf16_batch launch at the head of its dependent chain. */
+int tacorl_adam_step_batch_mirror(int nb, float* const* param, const float* const* grad, float* const* m,
+                                  float* const* v, const long* n, const float* lr, const float* max_norm,
+                                  int* const* step_counter, float* const* target, const float* tau,
+                                  void* const* mirror, void* const* target_mirror, void* ws, size_t ws_bytes,
+                                  tacorl_stream_t stream);
 
 #ifdef __cplusplus
 }

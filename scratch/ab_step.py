@@ -21,6 +21,7 @@ def setv(path, v):
     for h in head: o = getattr(o, h)
     setattr(o, last, v)
     if hasattr(mod.engine, "_lean_cache"): mod.engine._lean_cache = {}
+    if hasattr(mod.engine, "_gather_cache"): mod.engine._gather_cache = {}
     mod._graphs = {}  # the captured step depends on the switch
 def run(n):
     for i in range(n): mod.training_step(batches[i % 2])

@@ -59,6 +59,8 @@ _SIGS = {
     "tacorl_mlp_fwd_fused_supported": (_i, [_i, _i, _p, _i]),
     "tacorl_mlp_lean_supported": (_i, [_i, _i, _p, _i, _i, _i]),
     "tacorl_mlp_fwd_fused": (_i, [_i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _i, _p]),
+    "tacorl_mlp_fwd_fused_gather_supported": (_i, [_i, _p, _i, _p, _p, _i, _i]),
+    "tacorl_mlp_fwd_fused_gather": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _i, _p]),
     "tacorl_add_rows_bcast": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "tacorl_attention_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "tacorl_attention_dropout_fwd": (_i, [_p, _p, _p, _f, _i, _i, _i, _i, _p]),
@@ -133,6 +135,7 @@ _SIGS = {
     "tacorl_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _p, _p, _f, _p, _sz, _p]),
     "tacorl_adam_batch_ws_bytes": (_sz, [_i]),
     "tacorl_adam_step_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "tacorl_adam_step_batch_mirror": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
 }
 
 _lib = None

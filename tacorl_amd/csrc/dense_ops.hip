@@ -1034,9 +1034,9 @@ extern "C" int tacorl_mlp_fwd_fused_supported(int nprob, int L, const int* dims,
 extern "C" int tacorl_mlp_lean_supported(int nprob, int L, const int* dims, int ldx, int ldo, int ldd) {
   return mlp_fused_fwd_ok(nprob, L, dims, ldx) && mlp_fused_bwd_ok(nprob, L, dims, ldo, ldd) && mlp_fused_wgrad_ok(nprob, L, dims) ? 1 : 0;
 }
-extern "C" int tacorl_mlp_fwd_fused(int nprob, const float* const* x, int ldx, const float* const* params,
-                                    const void* const* params_bf16, float* const* act, const int* M, int L,
-                                    const int* dims, const int* acts, int lean, tacorl_stream_t stream) {
+static int mlp_fwd_fused_impl(int nprob, const float* const* x, int ldx, const float* const* params,
+                              const void* const* params_bf16, float* const* act, const int* M, int L,
+                              const int* dims, const int* acts, int lean, tacorl_stream_t stream, const MlpXGather* gather) {
   if (!mlp_fused_fwd_ok(nprob, L, dims, ldx)) FAIL(TACORL_EINVAL, "mlp_fwd_fused: shapes not supported");
   long wo[MLP_MAXL], bo[MLP_MAXL];
   tacorl_mlp_param_layout(L, dims, wo, bo);
@@ -1046,13 +1046,14 @@ extern "C" int tacorl_mlp_fwd_fused(int nprob, const float* const* x, int ldx, c
   const float *xs[2][MF_MAXP], *ps[2][MF_MAXP];
   const void* pb[2][MF_MAXP];
   float* as[2][MF_MAXP];
-  int Ms[2][MF_MAXP], n[2] = {0, 0};
+  int Ms[2][MF_MAXP], gm[2][MF_MAXP], n[2] = {0, 0};
   long zo[MF_MAXP * MF_MAXL], yo[MF_MAXP * MF_MAXL], ybf[MF_MAXP * MF_MAXL], sbf[MF_MAXP * MF_MAXL], yout[MF_MAXP];
   for (int p = 0; p < nprob; p++) {
     long z1[MLP_MAXL], y1[MLP_MAXL];
     tacorl_mlp_act_layout(M[p], L, dims, acts, z1, y1);
     const int b = (lean && mlp_big_prob_ok(M[p], L, dims, acts)) ? 1 : 0, q = n[b]++;
-    xs[b][q] = x[p]; ps[b][q] = params[p]; pb[b][q] = params_bf16[p]; as[b][q] = act[p]; Ms[b][q] = M[p];
+    gm[b][q] = p;
+    xs[b][q] = x ? x[p] : nullptr; ps[b][q] = params[p]; pb[b][q] = params_bf16[p]; as[b][q] = act[p]; Ms[b][q] = M[p];
     for (int l = 0; l < L; l++) {
       if (b) { ybf[q * MF_MAXL + l] = y1[l]; sbf[q * MF_MAXL + l] = z1[l]; }
       else {
@@ -1063,14 +1064,50 @@ extern "C" int tacorl_mlp_fwd_fused(int nprob, const float* const* x, int ldx, c
     if (b) yout[q] = y1[L - 1];
   }
   if (n[1]) {
-    const int rc = mlp_big_fwd(n[1], xs[1], ldx, ps[1], pb[1], as[1], Ms[1], L, dims, acts, ybf, sbf, yout, wo, bo, (hipStream_t)stream);
+    const int rc = mlp_big_fwd(n[1], xs[1], ldx, ps[1], pb[1], as[1], Ms[1], L, dims, acts, ybf, sbf, yout, wo, bo, (hipStream_t)stream, gather, gm[1]);
     if (rc != TACORL_OK) FAIL(rc, "mlp_fwd_fused: many-row launch failed (%d)", rc);
   }
   if (n[0]) {
-    const int rc = mlp_fused_fwd(n[0], xs[0], ldx, ps[0], pb[0], as[0], Ms[0], L, dims, acts, zo, yo, wo, bo, (hipStream_t)stream);
+    const int rc = mlp_fused_fwd(n[0], xs[0], ldx, ps[0], pb[0], as[0], Ms[0], L, dims, acts, zo, yo, wo, bo, (hipStream_t)stream, gather, gm[0]);
     if (rc != TACORL_OK) FAIL(rc, "mlp_fwd_fused: launch failed (%d)", rc);
   }
   return TACORL_OK;
+}
+extern "C" int tacorl_mlp_fwd_fused(int nprob, const float* const* x, int ldx, const float* const* params,
+                                    const void* const* params_bf16, float* const* act, const int* M, int L,
+                                    const int* dims, const int* acts, int lean, tacorl_stream_t stream) {
+  return mlp_fwd_fused_impl(nprob, x, ldx, params, params_bf16, act, M, L, dims, acts, lean, stream, nullptr);
+}
+/* tacorl_mlp_fwd_fused with a GATHERED layer-0 input: row r of problem p is the concatenation of nseg[p] <= 4 column
+ * segments, segment t = columns [seg_c0[4p+t], seg_c0[4p+t+1]) (the last: up to dims[0]) read from
+ * seg_ptr[4p+t][(seg_mod ? r % seg_mod : r) * seg_ld + col - seg_c0] - the reference's torch.cat([enc(obs),
+ * goal_enc(enc(goal))]) (visual_actor_wrapper.py:41-62), cat(emb, action) (critic.py:92-97) and expand_obs
+ * (utils/misc.py:132-153: state rows repeated per sampled action = seg_mod B) without a copy launch in front of the MLP.
+ * x_out[p] != NULL: the assembled fp32 rows are also written to x_out[p] ([M][ldx]) - layer 0's operand of the
+ * weight-gradient launch.  seg_c0 % 8 == 0, seg_ld % 4 == 0, pointers 16-byte aligned.  Not for many-row problems
+ * (tacorl_mlp_fwd_fused_gather_supported == 0: assemble with tacorl_copy_cols_batch and call tacorl_mlp_fwd_fused). */
+extern "C" int tacorl_mlp_fwd_fused_gather_supported(int nprob, const int* M, int L, const int* dims, const int* acts, int ldx,
+                                                     int lean) {
+  (void)M; (void)acts; (void)lean;  // (the many-row kernels gather too since round 5)
+  return mlp_fused_fwd_ok(nprob, L, dims, ldx) ? 1 : 0;
+}
+extern "C" int tacorl_mlp_fwd_fused_gather(int nprob, const int* nseg, const float* const* seg_ptr, const int* seg_ld,
+                                           const int* seg_c0, const int* seg_mod, float* const* x_out, int ldx,
+                                           const float* const* params, const void* const* params_bf16, float* const* act,
+                                           const int* M, int L, const int* dims, const int* acts, int lean,
+                                           tacorl_stream_t stream) {
+  if (nprob < 1 || nprob > MF_MAXP || !nseg || !seg_ptr || !seg_ld || !seg_c0 || !seg_mod) FAIL(TACORL_EINVAL, "mlp_fwd_fused_gather: arguments");
+  MlpXGather g{};
+  for (int p = 0; p < nprob; p++) {
+    if (nseg[p] < 1 || nseg[p] > MF_MAXSEG) FAIL(TACORL_EINVAL, "mlp_fwd_fused_gather: nseg[%d] = %d", p, nseg[p]);
+    g.nseg[p] = nseg[p];
+    g.xw[p] = x_out ? x_out[p] : nullptr;
+    for (int t = 0; t < nseg[p]; t++) {
+      g.ptr[p][t] = seg_ptr[MF_MAXSEG * p + t]; g.ld[p][t] = seg_ld[MF_MAXSEG * p + t];
+      g.c0[p][t] = seg_c0[MF_MAXSEG * p + t]; g.mod[p][t] = seg_mod[MF_MAXSEG * p + t];
+    }
+  }
+  return mlp_fwd_fused_impl(nprob, nullptr, ldx, params, params_bf16, act, M, L, dims, acts, lean, stream, &g);
 }
 struct ToBf16Tbl { const float* src[16]; __bf16* dst[16]; long n4[16]; };
 __global__ void to_bf16_batch_kernel(ToBf16Tbl t) {

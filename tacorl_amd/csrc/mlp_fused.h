@@ -4,6 +4,18 @@
 
 #define MF_MAXP 8  // problems per launch
 #define MF_MAXL 4  // layers
+#define MF_MAXSEG 4  // column segments of a gathered layer-0 input
+
+// Gathered layer-0 input of the fused forward (nseg[p] == 0: plain x[p]).  Segment t of problem p supplies columns
+// [c0[p][t], c0[p][t+1]) (the last one up to dims[0]) of row r from ptr[p][t][(mod ? r % mod : r) * ld + col - c0];
+// c0 % 8 == 0, ld % 4 == 0, pointers 16-byte aligned.  xw[p] != NULL: the assembled fp32 rows are also written there
+// ([M][ldx]) for the weight-gradient launch.
+struct MlpXGather {
+  const float* ptr[MF_MAXP][MF_MAXSEG];
+  int ld[MF_MAXP][MF_MAXSEG], c0[MF_MAXP][MF_MAXSEG], mod[MF_MAXP][MF_MAXSEG];
+  int nseg[MF_MAXP];
+  float* xw[MF_MAXP];
+};
 
 // bf16 compute only: hidden widths multiples of 8, every width <= 256 (the input width may be ragged, e.g. 64 + 7).
 bool mlp_fused_fwd_ok(int nprob, int L, const int* dims, int ldx);
@@ -13,7 +25,8 @@ bool mlp_fused_fwd_ok(int nprob, int L, const int* dims, int ldx);
 int mlp_fused_fwd(int nprob, const float* const* x, int ldx, const float* const* params, const void* const* params_bf16,
                   float* const* act,
                   const int* M, int L, const int* dims, const int* acts, const long* zoff, const long* yoff,
-                  const long* woff, const long* boff, hipStream_t st);
+                  const long* woff, const long* boff, hipStream_t st, const MlpXGather* gather = nullptr,
+                  const int* gmap = nullptr);  // gmap[p]: the gather's problem index of this launch's problem p
 
 // Backward input-gradient chain in one launch (+ one weight-transpose pack launch): writes dZ_l (fp32,
 // [M][dims[l+1]]) for l = 0..L-2 at dz[p] + dzoff[p*MF_MAXL + l] and, if d_x[p] != NULL, the input gradient.
@@ -48,7 +61,8 @@ int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* cons
 bool mlp_big_prob_ok(int M, int L, const int* dims, const int* acts);
 int mlp_big_fwd(int nprob, const float* const* x, int ldx, const float* const* params, const void* const* params_bf16,
                 float* const* act, const int* M, int L, const int* dims, const int* acts, const long* ybf, const long* sbf,
-                const long* yout, const long* woff, const long* boff, hipStream_t st);
+                const long* yout, const long* woff, const long* boff, hipStream_t st, const MlpXGather* gather = nullptr,
+                const int* gmap = nullptr);
 int mlp_big_bwd(int nprob, const float* const* act, const float* const* d_out, int ldo, float* const* dz, float* const* d_x,
                 int ldd, void* const* wt, const int* M, int L, const int* dims, const long* sbf, const long* dzoff,
                 hipStream_t st);

@@ -30,7 +30,16 @@ constexpr int MAXD = 256; // widest layer
 // 8 waves 1.122, 16 waves 1.106)
 constexpr int MF_NT = 1024, MF_CW = MAXD / (MF_NT / 64), MF_NTW = MF_CW / 16;
 
+// Gathered layer-0 input: columns [c0, next segment's c0) of row r come from p[(mod ? r % mod : r) * ld + (col - c0)].
+// The concatenations the reference builds in front of its MLPs ([enc(obs) | goal_enc(..)], [state | action] with the state
+// rows repeated for the n sampled actions - expand_obs, utils/misc.py:132-153) then cost no launch of their own: the
+// forward reads its input where the producers left it and, if asked (xw), also writes the assembled fp32 row - the
+// weight-gradient launch's layer-0 operand - from the registers it already holds.
+struct MlpXSeg { const float* p; int ld, c0, mod, pad; };
 struct MlpFwdArgs {
+  MlpXSeg seg[MF_MAXP][MF_MAXSEG];
+  int nseg[MF_MAXP];            // 0: plain x[p] / ldx
+  float* xw[MF_MAXP];           // optional assembled copy [M][ldx]
   const float* x[MF_MAXP];
   const float* params[MF_MAXP];
   const __bf16* pbf[MF_MAXP];  // bf16 copy of the parameter block (same element offsets)
@@ -108,7 +117,40 @@ __device__ __forceinline__ void mlp_fused_fwd_body(const MlpFwdArgs& a) {
   // zero both buffers once: padded K columns are multiplied by zero weights and must stay finite
   for (int e = tid; e < 2 * BMF * XP / 8; e += MF_NT) reinterpret_cast<f32x4*>(X)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  {  // stage the input rows as bf16 (chunks of 8 columns; a ragged last chunk - K0 % 8 != 0 - element by element)
+  if (a.nseg[p] > 0) {  // gathered input (segment starts are multiples of 8, lds multiples of 4, bases 16-byte aligned)
+    const int K0 = a.dims[0], c8 = (K0 + 7) / 8, ns = a.nseg[p];
+    float* xw = a.xw[p];
+    for (int c = tid; c < BMF * c8; c += MF_NT) {
+      const int row = c / c8, k = (c - row * c8) * 8;
+      if (m0 + row < M) {
+        int sg = 0;
+#pragma unroll
+        for (int t = 1; t < MF_MAXSEG; t++) sg = (t < ns && k >= a.seg[p][t].c0) ? t : sg;
+        const MlpXSeg s = a.seg[p][sg];
+        const int cend = sg + 1 < ns ? a.seg[p][sg + 1].c0 : K0;  // the segment's columns end here
+        const int r = s.mod ? (m0 + row) % s.mod : m0 + row;
+        const float* q = s.p + (long)r * s.ld + (k - s.c0);
+        f32x4 lo, hi;
+        if (k + 8 <= cend) { lo = *reinterpret_cast<const f32x4*>(q); hi = *reinterpret_cast<const f32x4*>(q + 4); }
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { lo[j] = k + j < cend ? q[j] : 0.f; hi[j] = k + 4 + j < cend ? q[4 + j] : 0.f; }
+        }
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { v[j] = (__bf16)lo[j]; v[4 + j] = (__bf16)hi[j]; }
+        *reinterpret_cast<bf16x8*>(X + row * XP + k) = v;
+        if (xw) {
+          float* o = xw + (long)(m0 + row) * a.ldx + k;
+          if (k + 8 <= a.ldx) { *reinterpret_cast<f32x4*>(o) = lo; *reinterpret_cast<f32x4*>(o + 4) = hi; }
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { if (k + j < a.ldx) o[j] = lo[j]; if (k + 4 + j < a.ldx) o[4 + j] = hi[j]; }
+          }
+        }
+      }
+    }
+  } else {  // stage the input rows as bf16 (chunks of 8 columns; a ragged last chunk - K0 % 8 != 0 - element by element)
     const int K0 = a.dims[0], c8 = (K0 + 7) / 8;
     const float* x = a.x[p];
     for (int c = tid; c < BMF * c8; c += MF_NT) {
@@ -569,6 +611,9 @@ __device__ unsigned long long g_mlp_stamps[2][64];
 #endif
 
 struct MlpBigFwdArgs {
+  MlpXSeg seg[MF_MAXP][MF_MAXSEG];  // gathered layer-0 input (see MlpFwdArgs)
+  int nseg[MF_MAXP];
+  float* xw[MF_MAXP];
   const float* x[MF_MAXP];
   const float* params[MF_MAXP];
   const __bf16* pbf[MF_MAXP];
@@ -581,13 +626,17 @@ struct MlpBigFwdArgs {
   int L, ldx;
 };
 
-__global__ __launch_bounds__(MF_NT) void mlp_big_fwd_kernel(MlpBigFwdArgs a) {
-  constexpr int BMF = 128, MTF = BMF / 16;
+// BMF_ rows per workgroup: 128 for >= 16 384 rows (C5), 32 for the thousands of rows of the other configurations' Q
+// networks (round 5: (3 n + 1) B = 3 328 at B = 256 - more workgroups, same saves, so that their weight gradients can
+// take mlp_wgrad_big_kernel too)
+template <int BMF_>
+__device__ __forceinline__ void mlp_big_fwd_body(const MlpBigFwdArgs& a) {
+  constexpr int BMF = BMF_, MTF = BMF / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* X = reinterpret_cast<__bf16*>(smem);  // [2][BMF][XP]
   const int p = blockIdx.y, m0 = blockIdx.x * BMF, M = a.M[p];
-  if (m0 >= M) return;
   const int Mp = (M + 63) & ~63;
+  if (m0 >= Mp) return;  // (a block of padding rows only still writes their zeros)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
   const int n0 = MF_CW * w;
 #ifdef MLP_STAMPS
@@ -601,10 +650,26 @@ __global__ __launch_bounds__(MF_NT) void mlp_big_fwd_kernel(MlpBigFwdArgs a) {
   const int K0 = a.dims[0], c8 = (K0 + 7) / 8;  // c8 <= 16 (dims[0] <= 128): BMF * c8 <= 2 * MF_NT
   f32x4 xr[2][2];
   const float* x = a.x[p];
+  const int ns = a.nseg[p];
 #pragma unroll
   for (int u = 0; u < 2; u++) {
     const int c = tid + u * MF_NT, row = c / c8, k = (c - row * c8) * 8;
     const bool ok = c < BMF * c8 && m0 + row < M;
+    if (ns > 0) {  // gathered input: the chunk's segment, its row (modulo) and the segment's end
+      int sg = 0;
+#pragma unroll
+      for (int t = 1; t < MF_MAXSEG; t++) sg = (t < ns && k >= a.seg[p][t].c0) ? t : sg;
+      const MlpXSeg s = a.seg[p][sg];
+      const int cend = sg + 1 < ns ? a.seg[p][sg + 1].c0 : K0;
+      const int r = s.mod ? (m0 + row) % s.mod : m0 + row;
+      const float* q = s.p + (ok ? (long)r * s.ld + (k - s.c0) : 0);
+      if (ok && k + 8 <= cend) { xr[u][0] = *reinterpret_cast<const f32x4*>(q); xr[u][1] = *reinterpret_cast<const f32x4*>(q + 4); }
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { xr[u][0][j] = ok && k + j < cend ? q[j] : 0.f; xr[u][1][j] = ok && k + 4 + j < cend ? q[4 + j] : 0.f; }
+      }
+      continue;
+    }
     const float* q = x + (ok ? (long)(m0 + row) * a.ldx + k : 0);
     if (ok && k + 8 <= a.ldx) { xr[u][0] = *reinterpret_cast<const f32x4*>(q); xr[u][1] = *reinterpret_cast<const f32x4*>(q + 4); }
     else {
@@ -633,6 +698,14 @@ __global__ __launch_bounds__(MF_NT) void mlp_big_fwd_kernel(MlpBigFwdArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; j++) { v[j] = (__bf16)(k + j < K0 ? xr[u][0][j] : 0.f); v[4 + j] = (__bf16)(k + 4 + j < K0 ? xr[u][1][j] : 0.f); }
       *reinterpret_cast<bf16x8*>(X + row * XP + k) = v;
+      if (ns > 0 && a.xw[p]) {  // the assembled fp32 rows (the gather masked them at the segment ends: pad columns are zeros)
+        float* o = a.xw[p] + (long)(m0 + row) * a.ldx + k;
+        if (k + 8 <= a.ldx) { *reinterpret_cast<f32x4*>(o) = xr[u][0]; *reinterpret_cast<f32x4*>(o + 4) = xr[u][1]; }
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { if (k + j < a.ldx) o[j] = xr[u][0][j]; if (k + 4 + j < a.ldx) o[4 + j] = xr[u][1][j]; }
+        }
+      }
     }
   }
   lds_barrier();
@@ -751,6 +824,8 @@ __global__ __launch_bounds__(MF_NT) void mlp_big_fwd_kernel(MlpBigFwdArgs a) {
     cur ^= 1;
   }
 }
+__global__ __launch_bounds__(MF_NT) void mlp_big_fwd_kernel(MlpBigFwdArgs a) { mlp_big_fwd_body<128>(a); }
+__global__ __launch_bounds__(MF_NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void mlp_mid_fwd_kernel(MlpBigFwdArgs a) { mlp_big_fwd_body<32>(a); }
 
 struct MlpBigBwdArgs {
   const float* d_out[MF_MAXP];
@@ -766,13 +841,14 @@ struct MlpBigBwdArgs {
   int L, ldo, ldd;
 };
 
-__global__ __launch_bounds__(MF_NT) void mlp_big_bwd_kernel(MlpBigBwdArgs a) {
-  constexpr int BMF = 64, MTF = BMF / 16;
+template <int BMF_>
+__device__ __forceinline__ void mlp_big_bwd_body(const MlpBigBwdArgs& a) {
+  constexpr int BMF = BMF_, MTF = BMF / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* X = reinterpret_cast<__bf16*>(smem);                      // [2][BMF][XP]
   _Float16* S = reinterpret_cast<_Float16*>(X + 2 * BMF * XP);      // [BMF][XP] act' of the layer below
   const int p = blockIdx.y, m0 = blockIdx.x * BMF, M = a.M[p];
-  if (m0 >= M) return;
+  if (m0 >= ((M + 63) & ~63)) return;  // (a block of padding rows only still writes their zero dZ rows)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
   const int n0 = MF_CW * w;
   bf16x8 B[8][MF_NTW];
@@ -889,6 +965,8 @@ __global__ __launch_bounds__(MF_NT) void mlp_big_bwd_kernel(MlpBigBwdArgs a) {
     cur ^= 1;
   }
 }
+__global__ __launch_bounds__(MF_NT) void mlp_big_bwd_kernel(MlpBigBwdArgs a) { mlp_big_bwd_body<64>(a); }
+__global__ __launch_bounds__(MF_NT) void mlp_mid_bwd_kernel(MlpBigBwdArgs a) { mlp_big_bwd_body<32>(a); }
 
 // ------------------------------------------------------------------ weight gradients, tens of thousands of rows
 // C5's Q networks see (3 n + 1) B = 99 328 rows each.  mlp_wgrad_fused_kernel above reads both operands as fp32, recomputes
@@ -1060,13 +1138,13 @@ struct MlpWgOutArgs {
   const __bf16* y[MF_MAXP]; const float* dlast[MF_MAXP]; float* slab[MF_MAXP];
   int M[MF_MAXP];
   long rec;
-  int NL, ldo;
+  int NL, ldo, rpw;  // rpw: rows per workgroup (OUT_RPW at tens of thousands of rows, 64 at a few thousand: latency, not bytes)
 };
 __global__ __launch_bounds__(256) void mlp_wgrad_out_kernel(MlpWgOutArgs a) {
   __shared__ float red[8][4][256 + 1];
-  const int p = blockIdx.y, M = a.M[p], r0 = blockIdx.x * OUT_RPW;
+  const int p = blockIdx.y, M = a.M[p], r0 = blockIdx.x * a.rpw;
   if (r0 >= M) return;
-  const int r1 = min(M, r0 + OUT_RPW), tid = threadIdx.x, cg = tid & 31, rg = tid >> 5, NL = a.NL;
+  const int r1 = min(M, r0 + a.rpw), tid = threadIdx.x, cg = tid & 31, rg = tid >> 5, NL = a.NL;
   float acc[4][8], bsum[4];
 #pragma unroll
   for (int n = 0; n < 4; n++) {
@@ -1184,7 +1262,8 @@ int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* cons
 
 // ---- many-row weight gradients (mlp_wgrad_big_kernel): eligibility, sizes, launch
 static int mlp_big_rows() {
-  static const int v = [] { const char* e = getenv("TACORL_MLP_BIG_ROWS"); return e ? atoi(e) : 16384; }();
+  // 2048 since round 5 (16384 before): below 16 384 rows the same saves come from 32-row workgroups (mlp_mid_*_kernel)
+  static const int v = [] { const char* e = getenv("TACORL_MLP_BIG_ROWS"); return e ? atoi(e) : 2048; }();
   return v;
 }
 bool mlp_big_prob_ok(int M, int L, const int* dims, const int* acts) {
@@ -1205,13 +1284,32 @@ extern "C" int tacorl_dbg_mlp_stamps(unsigned long long* dst) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_mlp_stamps), sizeof(g_mlp_stamps)) == hipSuccess ? 0 : -1;
 }
 #endif
+// rows per workgroup of the many-row forward / input-gradient kernels: 128 / 64 at >= 16 384 rows, 32 / 32 below
+static bool mlp_rows_huge(int maxM) { return maxM >= 16384; }
+template <class Args>
+static int mlp_set_gather(Args& a, int p, int q, const MlpXGather* gather, int K0) {  // gather's problem q -> args' problem p
+  const int ns = gather ? gather->nseg[q] : 0;
+  if (ns < 0 || ns > MF_MAXSEG) return TACORL_EINVAL;
+  a.nseg[p] = ns;
+  a.xw[p] = ns ? gather->xw[q] : nullptr;
+  if ((uintptr_t)a.xw[p] & 15) return TACORL_EINVAL;
+  for (int t = 0; t < ns; t++) {
+    const int c0 = gather->c0[q][t], ld = gather->ld[q][t];
+    if (((uintptr_t)gather->ptr[q][t] & 15) || !gather->ptr[q][t] || ld % 4 || c0 % 8 || (t == 0 ? c0 != 0 : c0 <= gather->c0[q][t - 1]) ||
+        c0 >= K0 || gather->mod[q][t] < 0)
+      return TACORL_EINVAL;
+    a.seg[p][t] = MlpXSeg{gather->ptr[q][t], ld, c0, gather->mod[q][t], 0};
+  }
+  return TACORL_OK;
+}
 int mlp_big_fwd(int nprob, const float* const* x, int ldx, const float* const* params, const void* const* params_bf16,
                 float* const* act, const int* M, int L, const int* dims, const int* acts, const long* ybf, const long* sbf,
-                const long* yout, const long* woff, const long* boff, hipStream_t st) {
+                const long* yout, const long* woff, const long* boff, hipStream_t st, const MlpXGather* gather, const int* gmap) {
   MlpBigFwdArgs a{};
   int maxM = 0;
   for (int p = 0; p < nprob; p++) {
-    if (((uintptr_t)x[p] & 15) || ((uintptr_t)params[p] & 15) || ((uintptr_t)params_bf16[p] & 7) || ((uintptr_t)act[p] & 15)) return TACORL_EINVAL;
+    if (mlp_set_gather(a, p, gmap ? gmap[p] : p, gather, dims[0]) != TACORL_OK) return TACORL_EINVAL;
+    if ((!a.nseg[p] && ((uintptr_t)x[p] & 15)) || ((uintptr_t)params[p] & 15) || ((uintptr_t)params_bf16[p] & 7) || ((uintptr_t)act[p] & 15)) return TACORL_EINVAL;
     a.x[p] = x[p]; a.params[p] = params[p]; a.pbf[p] = (const __bf16*)params_bf16[p]; a.act[p] = act[p]; a.M[p] = M[p];
     for (int l = 0; l < L; l++) { a.ybf[p][l] = ybf[p * MF_MAXL + l]; a.sbf[p][l] = sbf[p * MF_MAXL + l]; }
     a.yout[p] = yout[p];
@@ -1223,11 +1321,15 @@ int mlp_big_fwd(int nprob, const float* const* x, int ldx, const float* const* p
   }
   a.dims[L] = dims[L]; a.L = L; a.ldx = ldx;
   if (maxM == 0) return TACORL_OK;
-  constexpr size_t lds = (size_t)2 * 128 * XP * 2;
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_big_fwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
+  constexpr size_t lds = (size_t)2 * 128 * XP * 2, lds_mid = (size_t)2 * 32 * XP * 2;
+  static int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_big_fwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_mid_fwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid) == hipSuccess) ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
-  hipLaunchKernelGGL(mlp_big_fwd_kernel, dim3((maxM + 127) / 128, nprob), dim3(MF_NT), lds, st, a);
+  const int maxMp = (maxM + 63) & ~63;  // (the blocks cover the zero rows up to a multiple of 64 too)
+  if (mlp_rows_huge(maxM)) hipLaunchKernelGGL(mlp_big_fwd_kernel, dim3((maxMp + 127) / 128, nprob), dim3(MF_NT), lds, st, a);
+  else hipLaunchKernelGGL(mlp_mid_fwd_kernel, dim3(maxMp / 32, nprob), dim3(MF_NT), lds_mid, st, a);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 // the input-gradient chain of many-row problems (the transposed weights wt[p] are already packed: mlp_fused_bwd mode 1)
@@ -1249,11 +1351,14 @@ int mlp_big_bwd(int nprob, const float* const* act, const float* const* d_out, i
   for (int l = 0; l <= L; l++) a.dims[l] = dims[l];
   a.L = L; a.ldo = ldo; a.ldd = ldd;
   if (maxM == 0) return TACORL_OK;
-  constexpr size_t lds = (size_t)3 * 64 * XP * 2;
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_big_bwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
+  constexpr size_t lds = (size_t)3 * 64 * XP * 2, lds_mid = (size_t)3 * 32 * XP * 2;
+  static int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_big_bwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_mid_bwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid) == hipSuccess) ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
-  hipLaunchKernelGGL(mlp_big_bwd_kernel, dim3((maxM + 63) / 64, nprob), dim3(MF_NT), lds, st, a);
+  if (mlp_rows_huge(maxM)) hipLaunchKernelGGL(mlp_big_bwd_kernel, dim3((maxM + 63) / 64, nprob), dim3(MF_NT), lds, st, a);
+  else hipLaunchKernelGGL(mlp_mid_bwd_kernel, dim3(((maxM + 63) & ~63) / 32, nprob), dim3(MF_NT), lds_mid, st, a);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 static int mlp_big_tiles(int L) { return 1 + 2 * (L - 2); }  // layer 0: one 128-column x tile; hidden layers: two
@@ -1268,13 +1373,18 @@ static int mlp_big_rps(int nprob, const int* M, int L) {
   const int sps = (stages + nslice - 1) / nslice;
   return (sps < 4 ? 4 : sps) * BG_R;
 }
+static int mlp_out_rpw(int nprob, const int* M) {
+  int maxM = 0;
+  for (int p = 0; p < nprob; p++) maxM = M[p] > maxM ? M[p] : maxM;
+  return mlp_rows_huge(maxM) ? OUT_RPW : 64;
+}
 static long mlp_big_out_rec(int L, const int* dims) { return ((long)dims[L] * 257 + 3) & ~3L; }
 size_t mlp_big_wgrad_slab_floats(int nprob, const int* M, int L, const int* dims) {
   const long rec = mlp_wgrad_record(L, dims, nullptr), orec = mlp_big_out_rec(L, dims);
-  const int rps = mlp_big_rps(nprob, M, L);
+  const int rps = mlp_big_rps(nprob, M, L), rpw = mlp_out_rpw(nprob, M);
   size_t tot = 0;
   for (int p = 0; p < nprob; p++)
-    if (M[p] > 0) tot += (size_t)((((M[p] + 63) & ~63) + rps - 1) / rps) * rec + (size_t)((M[p] + OUT_RPW - 1) / OUT_RPW) * orec;
+    if (M[p] > 0) tot += (size_t)((((M[p] + 63) & ~63) + rps - 1) / rps) * rec + (size_t)((M[p] + rpw - 1) / rpw) * orec;
   return tot;
 }
 size_t mlp_big_xb_bytes(int M) { return (size_t)((M + 63) & ~63) * 128 * 2; }
@@ -1308,12 +1418,12 @@ int mlp_fused_wgrad_big(int nprob, const float* const* x, int ldx, const float* 
     a.tile0[l + 1] = a.tile0[l] + (l == 0 ? 1 : 2);
   }
   xa.ldx = ldx; xa.K0 = dims[0];
-  oa.NL = dims[L]; oa.ldo = ldo;
+  oa.NL = dims[L]; oa.ldo = ldo; oa.rpw = mlp_out_rpw(nprob, M);
   int n2 = 0, maxs = 0, maxso = 0, maxMp = 0;
   float* sp = slab;
   for (int p = 0; p < nprob; p++) {
     if (!grads[p] || M[p] <= 0) continue;
-    const int Mp = (M[p] + 63) & ~63, ns = (Mp + a.rps - 1) / a.rps, nso = (M[p] + OUT_RPW - 1) / OUT_RPW;
+    const int Mp = (M[p] + 63) & ~63, ns = (Mp + a.rps - 1) / a.rps, nso = (M[p] + oa.rpw - 1) / oa.rpw;
     if (((uintptr_t)xb[p] | (uintptr_t)dz[p] | (uintptr_t)act[p]) & 15) return -1;
     a.Mp[n2] = Mp; a.slab[n2] = sp;
     for (int l = 0; l + 1 < L; l++) {
@@ -1403,11 +1513,15 @@ bool mlp_fused_fwd_ok(int nprob, int L, const int* dims, int ldx) {
 int mlp_fused_fwd(int nprob, const float* const* x, int ldx, const float* const* params, const void* const* params_bf16,
                   float* const* act,
                   const int* M, int L, const int* dims, const int* acts, const long* zoff, const long* yoff,
-                  const long* woff, const long* boff, hipStream_t st) {
+                  const long* woff, const long* boff, hipStream_t st, const MlpXGather* gather, const int* gmap) {
   MlpFwdArgs a{};
   int maxM = 0;
   for (int p = 0; p < nprob; p++) {
-    if (((uintptr_t)x[p] & 15) || ((uintptr_t)params[p] & 15)) return TACORL_EINVAL;
+    if (mlp_set_gather(a, p, gmap ? gmap[p] : p, gather, dims[0]) != TACORL_OK) return TACORL_EINVAL;
+    const int ns = a.nseg[p];
+    if (ns) {  // (x[p] is not read)
+      if ((uintptr_t)params[p] & 15) return TACORL_EINVAL;
+    } else if (((uintptr_t)x[p] & 15) || ((uintptr_t)params[p] & 15)) return TACORL_EINVAL;
     if ((uintptr_t)params_bf16[p] & 7) return TACORL_EINVAL;
     a.x[p] = x[p]; a.params[p] = params[p]; a.pbf[p] = (const __bf16*)params_bf16[p]; a.act[p] = act[p]; a.M[p] = M[p];
     for (int l = 0; l < L; l++) { a.zoff[p][l] = zoff[p * MF_MAXL + l]; a.yoff[p][l] = yoff[p * MF_MAXL + l]; }

@@ -896,6 +896,8 @@ struct AdamTbl {
   long n[ADAM_MAXB];
   float lr[ADAM_MAXB], max_norm[ADAM_MAXB], tau[ADAM_MAXB];
   int blocks[ADAM_MAXB];
+  __bf16* mirror[ADAM_MAXB];   // optional bf16 copies of the updated parameters / of the updated Polyak target, same
+  __bf16* tmirror[ADAM_MAXB];  // element offsets (the fused MLP kernels' MFMA operand: no conversion launch next step)
 };
 __global__ __launch_bounds__(256) void sqnorm_partial_batch_kernel(AdamTbl t) {
   __shared__ float sh[4];
@@ -942,7 +944,10 @@ __global__ __launch_bounds__(256) void adam_batch_kernel(AdamTbl t) {
     return pn;
   };
   const long n = t.n[b];
-  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)target) & 15) == 0);
+  __bf16* __restrict__ mir = t.mirror[b];
+  __bf16* __restrict__ tmir = target ? t.tmirror[b] : nullptr;
+  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)target) & 15) == 0) &&
+                   ((((uintptr_t)mir | (uintptr_t)tmir) & 7) == 0);
   const long n4 = vec ? n / 4 : 0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)nb * 256) {
     f32x4 P = reinterpret_cast<f32x4*>(p)[i], M = reinterpret_cast<f32x4*>(m)[i], V = reinterpret_cast<f32x4*>(v)[i];
@@ -956,12 +961,16 @@ __global__ __launch_bounds__(256) void adam_batch_kernel(AdamTbl t) {
     }
     reinterpret_cast<f32x4*>(m)[i] = M; reinterpret_cast<f32x4*>(v)[i] = V; reinterpret_cast<f32x4*>(p)[i] = P;
     if (target) reinterpret_cast<f32x4*>(target)[i] = T;
+    if (mir) reinterpret_cast<bf16x4*>(mir)[i] = bf16x4{(__bf16)P[0], (__bf16)P[1], (__bf16)P[2], (__bf16)P[3]};
+    if (tmir) reinterpret_cast<bf16x4*>(tmir)[i] = bf16x4{(__bf16)T[0], (__bf16)T[1], (__bf16)T[2], (__bf16)T[3]};
   }
   for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)nb * 256) {
     float mi = m[i], vi = v[i], ti = target ? target[i] : 0.f;
     const float pn = upd(p[i], g[i], mi, vi, ti, target != nullptr);
     m[i] = mi; v[i] = vi; p[i] = pn;
     if (target) target[i] = ti;
+    if (mir) mir[i] = (__bf16)pn;
+    if (tmir) tmir[i] = (__bf16)ti;
   }
 }
 extern "C" size_t tacorl_adam_batch_ws_bytes(int nb) { return (size_t)nb * 1024 * sizeof(float); }
@@ -969,6 +978,14 @@ extern "C" int tacorl_adam_step_batch(int nb, float* const* param, const float* 
                                       float* const* v, const long* n, const float* lr, const float* max_norm,
                                       int* const* step_counter, float* const* target, const float* tau, void* ws,
                                       size_t ws_bytes, tacorl_stream_t stream) {
+  return tacorl_adam_step_batch_mirror(nb, param, grad, m, v, n, lr, max_norm, step_counter, target, tau, nullptr, nullptr, ws,
+                                       ws_bytes, stream);
+}
+extern "C" int tacorl_adam_step_batch_mirror(int nb, float* const* param, const float* const* grad, float* const* m,
+                                             float* const* v, const long* n, const float* lr, const float* max_norm,
+                                             int* const* step_counter, float* const* target, const float* tau,
+                                             void* const* mirror, void* const* target_mirror, void* ws, size_t ws_bytes,
+                                             tacorl_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (nb < 1 || nb > ADAM_MAXB) return TACORL_EINVAL;
   if (ws_bytes < tacorl_adam_batch_ws_bytes(nb)) return TACORL_ENOMEM;
@@ -981,6 +998,8 @@ extern "C" int tacorl_adam_step_batch(int nb, float* const* param, const float* 
     t.p[b] = param[b]; t.g[b] = grad[b]; t.m[b] = m[b]; t.v[b] = v[b]; t.target[b] = target ? target[b] : nullptr;
     t.step[b] = step_counter[b]; t.partial[b] = (float*)ws + (long)b * 1024; t.n[b] = n[b]; t.lr[b] = lr[b];
     t.max_norm[b] = max_norm[b]; t.tau[b] = tau ? tau[b] : 0.f; t.blocks[b] = (int)blocks;
+    t.mirror[b] = mirror ? (__bf16*)mirror[b] : nullptr; t.tmirror[b] = target_mirror ? (__bf16*)target_mirror[b] : nullptr;
+    if (((uintptr_t)t.mirror[b] | (uintptr_t)t.tmirror[b]) & 1) return TACORL_EINVAL;
     maxb = (int)blocks > maxb ? (int)blocks : maxb;
     any_clip |= max_norm[b] > 0.f;
   }

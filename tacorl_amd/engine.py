@@ -228,7 +228,10 @@ class ACEngine:
         self.d_head = f(B, self.HD)
         self.dS = {k: f(B, self.lds) for k in ("a", "q1", "q2")}
         self.dgin = {k: f(B, self.G) for k in ("a", "q1", "q2")}
-        self.reward, self.done, self.action = f(B), f(B), f(B, self.A)
+        self.reward, self.done = f(B), f(B)
+        # the data action IS rows [0, B) of the Q networks' action column block (no copy in front of the Q forward):
+        # load_transition / TACORL's plan-recognition sample write it in place
+        self.action = self.acts_main[:B]
         # all noise of a step in two flat buffers (normal | uniform): two generator launches per step
         shapes = dict(eps_pi=(B, self.Ac), eps_next=(B, self.Ac), eps_cur=(n, B, self.Ac), eps_nxt=(n, B, self.Ac))
         shapes.update(getattr(self, "extra_normal", {}))  # e.g. TACORL's plan-recognition eps
@@ -385,14 +388,44 @@ class ACEngine:
                      ops.ptr_array([x[3] for x in pr]), ops.int_array([x[4] for x in pr]), H, W, xd, self.compute,
                      ops.stream())
 
+    # bf16 mirrors of the MLP weights (the fused MLP kernels' MFMA operand).  Round 5: the Adam / Polyak launch writes them
+    # itself (ops.adam_step_batch(mirrors=...)), so the conversion launch at the head of the next step's chain is gone; a
+    # mirror counts as current while its block's torch version counter is the one recorded when it was written (every
+    # other writer - load_state_dict, broadcast, sync_targets, a user's in-place edit - moves the counter), and the
+    # conversion launch below runs only for blocks that are not (first step, after a load).
+    # MEASURED SLOWER, default off (round 5, separate processes on one box, ms/step: 0.8370 with the conversion launch
+    # against 0.8431 - 0.8485 without it): the plan recognition's 256 one-per-CU workgroups (351 registers: no fused-MLP
+    # workgroup fits beside one) start their launch beside the first kernels of phase_a; whatever delays phase_a's first
+    # MLP launch by a few microseconds lets all of them start at once, and the action-decoder branch behind them - the
+    # step's co-critical chain - starts that much earlier.  The conversion launch is such a delay and costs nothing else.
+    adam_writes_mirrors = os.environ.get("TACORL_ADAM_MIRRORS", "0") == "1"
+
+    def _mirror_nets(self):
+        return [self.actor, self.q1, self.q2, self.tq1, self.tq2]
+
+    def mirrors_stale(self):
+        return self.compute == BF16 and any(getattr(n_, "_mirror_ver", None) != n_.param._version for n_ in self._mirror_nets())
+
+    def mirrors_written(self):
+        """The optimiser launch (eager, or the replayed graph's) has just written every mirror: record the versions."""
+        if self.compute == BF16 and self.adam_writes_mirrors:
+            for n_ in self._mirror_nets():
+                n_._mirror_ver = n_.param._version
+
     def _refresh_bf16(self):
-        """bf16 copies of the five networks' MLP weights (one launch); the fp32 blocks stay the masters."""
+        """bf16 copies of the five networks' MLP weights (one launch) where they are not current; the fp32 blocks stay the masters."""
         if self.compute != BF16:
             return
-        nets = [self.actor, self.q1, self.q2, self.tq1, self.tq2]
+        nets = [n_ for n_ in self._mirror_nets()
+                if not self.adam_writes_mirrors or getattr(n_, "_mirror_ver", None) != n_.param._version
+                or os.environ.get("TACORL_ALWAYS_REFRESH") == "1"]
+        if not nets:
+            return
         call("tacorl_to_bf16_batch", len(nets), ops.ptr_array([n_.genc() for n_ in nets]),
              ops.ptr_array([n_.genc_bf16() for n_ in nets]), (ops.C.c_long * len(nets))(*[n_.size - n_.genc_off for n_ in nets]),
              ops.stream())
+        for n_ in nets:
+            n_._mirror_ver = n_.param._version
 
     def _mlp_bwd_sites(self):
         """(tag, params, M, dims) of every fused-MLP backward of the update, as _mlp_backward receives them."""
@@ -410,10 +443,15 @@ class ACEngine:
         self._prepacked = False
         if self.compute != BF16:
             return
+        # in line since round 5 (TACORL_PACK_INLINE=0: a side branch of the graph, as before): these launches are small
+        # enough in registers to run beside the plan recognition's workgroups, which the fused MLP forwards that follow
+        # are not, and without the fork / join the step is 8 us shorter (0.8467 / 0.8432 -> 0.8370 ms, same box)
+        inline = os.environ.get("TACORL_PACK_INLINE", "1") == "1"
         if getattr(self, "_pack_stream", None) is None:
             self._pack_stream = torch.cuda.Stream(device=self.dev)
-        ps = self._pack_stream
-        ps.wait_stream(torch.cuda.current_stream())
+        ps = torch.cuda.current_stream() if inline else self._pack_stream
+        if not inline:
+            ps.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(ps):
             for tag, params, M, dims in self._mlp_bwd_sites():
                 ops.mlp_bwd_fused_pack(params, M, dims, "mlp_bwdf_" + tag, self.dev)
@@ -428,30 +466,75 @@ class ACEngine:
                          ws.numel(), ops.stream())
         self._prepacked = True
 
+    # Gathered MLP inputs (round 5): the concatenations in front of the goal encoders, the policy head and the Q heads are
+    # read by the fused forward's input stage where their producers left them (ops.mlp_fwd_gather) instead of being
+    # assembled by a copy launch first - three launches fewer on the step's dependent chain.  TACORL_MLP_GATHER=0 (or a
+    # shape the gathered forward does not take: f32 mode, C5's many-row Q problems) restores copy + forward.
+    gather_inputs = os.environ.get("TACORL_MLP_GATHER", "1") == "1"
+
+    def _gather_ok(self, tag):
+        if not (self.gather_inputs if self.gather_inputs is not None else os.environ.get("TACORL_MLP_GATHER", "1") == "1") \
+                or self.compute != BF16:
+            return False
+        cache = self.__dict__.setdefault("_gather_cache", {})
+        key = (tag, self.B)
+        if key not in cache:
+            B = self.B
+            M, net, ldx = {"genc": ([B] * 5, (self.actor.genc_dims, self.actor.genc_acts), self.G),
+                           "pi": ([B] * 2, (self.actor.head_dims, self.actor.head_acts), self.lds),
+                           "q": ([self.R, self.R, B, B, B, B], (self.q1.head_dims, self.q1.head_acts), self.ldq)}[tag]
+            # (segment pitches must be multiples of 4 floats: the action block's is A - 7 for the CQL baseline)
+            cache[key] = (tag != "q" or self.A % 4 == 0) and ops.mlp_fwd_gather_ok(M, net[0], net[1], ldx, self.compute, self._lean(tag))
+        return cache[key]
+
+    def _emb_segs(self, ek, row0, gk, mod=0):
+        """[enc(obs or next) per camera | goal_enc(enc(goal))] as input segments."""
+        segs = [(self.enc_out[(ek, c)], row0 * 32, 32, 32 * j, mod) for j, c in enumerate(self.cams)]
+        segs.append((self.gact[gk], self.g_yoff, self.G, self.Eo, mod))
+        return segs
+
+    _OBS_SRC = {"a": ("a_og", 0, "a"), "a_nx": ("a_nx", 0, "a"), "q1": ("q1", 0, "q1"), "q2": ("q2", 0, "q2"),
+                "tq1": ("tq1", 1, "tq1"), "tq2": ("tq2", 1, "tq2")}  # (encoder problem, first row / B, goal-encoder net)
+
     def _assemble_states(self):
         B = self.B
         # goal-encoder inputs: concat over cams of enc(goal)
         src = {"a": ("a_og", B), "q1": ("q1", B), "q2": ("q2", B), "tq1": ("tq1", 0), "tq2": ("tq2", 0)}
-        with ops.copy_batch():
-            for k, (ek, row0) in src.items():
-                for j, c in enumerate(self.cams):
-                    ops.copy_cols(self.enc_out[(ek, c)], row0 * 32, 32, self.gin[k], 32 * j, self.G, B, 32)
         nets = dict(self.nets)
         ks = ["a", "q1", "q2", "tq1", "tq2"]
-        ops.mlp_fwd([self.gin[k] for k in ks], self.G, [nets[k].genc() for k in ks], [self.gact[k] for k in ks],
-                    [B] * 5, self.actor.genc_dims, self.actor.genc_acts, self.compute,
-                    params_bf16=[nets[k].genc_bf16() for k in ks], lean=self._lean("genc"))
-        # S = [enc(obs or next) | goal_enc(enc(goal))]
-        obs_src = {"a": ("a_og", 0, "a"), "a_nx": ("a_nx", 0, "a"), "q1": ("q1", 0, "q1"), "q2": ("q2", 0, "q2"),
-                   "tq1": ("tq1", B, "tq1"), "tq2": ("tq2", B, "tq2")}
-        with ops.copy_batch():
-            for k, (ek, row0, gk) in obs_src.items():
-                for j, c in enumerate(self.cams):
-                    ops.copy_cols(self.enc_out[(ek, c)], row0 * 32, 32, self.S[k], 32 * j, self.lds, B, 32)
-                ops.copy_cols(self.gact[gk], self.g_yoff, self.G, self.S[k], self.Eo, self.lds, B, self.G)
+        if self._gather_ok("genc"):
+            segs = [[(self.enc_out[(src[k][0], c)], src[k][1] * 32, 32, 32 * j, 0) for j, c in enumerate(self.cams)] for k in ks]
+            ops.mlp_fwd_gather(segs, [self.gin[k] for k in ks], self.G, [nets[k].genc() for k in ks],
+                               [nets[k].genc_bf16() for k in ks], [self.gact[k] for k in ks], [B] * 5, self.actor.genc_dims,
+                               self.actor.genc_acts, lean=self._lean("genc"))
+        else:
+            with ops.copy_batch():
+                for k, (ek, row0) in src.items():
+                    for j, c in enumerate(self.cams):
+                        ops.copy_cols(self.enc_out[(ek, c)], row0 * 32, 32, self.gin[k], 32 * j, self.G, B, 32)
+            ops.mlp_fwd([self.gin[k] for k in ks], self.G, [nets[k].genc() for k in ks], [self.gact[k] for k in ks],
+                        [B] * 5, self.actor.genc_dims, self.actor.genc_acts, self.compute,
+                        params_bf16=[nets[k].genc_bf16() for k in ks], lean=self._lean("genc"))
+        # S = [enc(obs or next) | goal_enc(enc(goal))]: assembled by a copy only for the forwards that do not gather
+        need = [k for k in self._OBS_SRC if not self._gather_ok("pi" if k in ("a", "a_nx") else "q")]
+        if need:
+            with ops.copy_batch():
+                for k in need:
+                    ek, r0, gk = self._OBS_SRC[k]
+                    for j, c in enumerate(self.cams):
+                        ops.copy_cols(self.enc_out[(ek, c)], r0 * B * 32, 32, self.S[k], 32 * j, self.lds, B, 32)
+                    ops.copy_cols(self.gact[gk], self.g_yoff, self.G, self.S[k], self.Eo, self.lds, B, self.G)
 
     def _policy_fwd(self):
         ks = ["a", "a_nx"]
+        if self._gather_ok("pi"):
+            B = self.B
+            segs = [self._emb_segs(self._OBS_SRC[k][0], self._OBS_SRC[k][1] * B, self._OBS_SRC[k][2]) for k in ks]
+            # (S["a"] is the policy head's layer-0 operand in the backward: written from the forward's registers)
+            ops.mlp_fwd_gather(segs, [self.S["a"], None], self.lds, [self.actor.head()] * 2, [self.actor.head_bf16()] * 2,
+                               [self.pact[k] for k in ks], [B] * 2, self.actor.head_dims, self.actor.head_acts,
+                               lean=self._lean("pi"))
+            return
         ops.mlp_fwd([self.S[k] for k in ks], self.lds, [self.actor.head()] * 2, [self.pact[k] for k in ks],
                     [self.B] * 2, self.actor.head_dims, self.actor.head_acts, self.compute,
                     params_bf16=[self.actor.head_bf16()] * 2, lean=self._lean("pi"))
@@ -515,7 +598,7 @@ class ACEngine:
             call("tacorl_alpha_loss", ptr(self.logp_pi), B, ptr(self.log_alpha.param), float(hp["target_entropy"]), gs,
                  ptr(self.log_alpha.grad), ptr(self.logs), ops.stream())
         ops.mark("a:alpha")
-        if getattr(self, "_prepacked", False):  # the side branch ends inside this phase
+        if getattr(self, "_prepacked", False) and os.environ.get("TACORL_PACK_INLINE", "1") != "1":  # the side branch ends inside this phase
             torch.cuda.current_stream().wait_stream(self._pack_stream)
         ops.mark("a:end")
 
@@ -532,25 +615,34 @@ class ACEngine:
             torch.cuda.current_stream().wait_event(self.action_ready)
             self.action_ready = None
         ops.mark("b:start")
-        with ops.copy_batch():  # one launch; rows [0,B) of the Q input take the data action straight from its source
-            ops.copy_cols(self.action, 0, A, self.acts_main, 0, A, B, A)
-            for k in ("q1", "q2"):
-                ops.copy_cols(self.S[k], 0, self.lds, self.XQ[k], 0, self.ldq, self.R, self.E, src_row_mod=B)
-                ops.copy_cols(self.action, 0, A, self.XQ[k], self.E, self.ldq, B, A)
-                ops.copy_cols(self.acts_main, B * A, A, self.XQ[k], B * self.ldq + self.E, self.ldq, self.R - B, A)
-                ops.copy_cols(self.S[k], 0, self.lds, self.XQpi[k], 0, self.ldq, B, self.E)
-                ops.copy_cols(self.act_pi, 0, A, self.XQpi[k], self.E, self.ldq, B, A)
-            for k in ("tq1", "tq2"):
-                ops.copy_cols(self.S[k], 0, self.lds, self.XT[k], 0, self.ldq, B, self.E)
-                ops.copy_cols(self.act_next, 0, A, self.XT[k], self.E, self.ldq, B, A)
         qd, qa = self.q1.head_dims, self.q1.head_acts
-        xs = [self.XQ["q1"], self.XQ["q2"], self.XQpi["q1"], self.XQpi["q2"], self.XT["tq1"], self.XT["tq2"]]
         ps = [self.q1.head(), self.q2.head(), self.q1.head(), self.q2.head(), self.tq1.head(), self.tq2.head()]
         ac = [self.qact["q1"], self.qact["q2"], self.qact_pi["q1"], self.qact_pi["q2"], self.qact_t["tq1"],
               self.qact_t["tq2"]]
         pb = [self.q1.head_bf16(), self.q2.head_bf16(), self.q1.head_bf16(), self.q2.head_bf16(), self.tq1.head_bf16(),
               self.tq2.head_bf16()]
-        ops.mlp_fwd(xs, self.ldq, ps, ac, [self.R, self.R, B, B, B, B], qd, qa, self.compute, params_bf16=pb, lean=self._lean("q"))
+        if self._gather_ok("q"):
+            # Q inputs [enc(obs) | goal_enc | action] read in place: the state rows repeat every B rows (expand_obs on
+            # embeddings), the actions are acts_main = [data | uniform | n x pi(obs) | n x pi(next)]; only the two
+            # problems with weight gradients (q1 / q2 over all R rows) also write their assembled rows
+            E = self.E
+            seg = lambda k, mod, a_t: self._emb_segs(self._OBS_SRC[k][0], self._OBS_SRC[k][1] * B, self._OBS_SRC[k][2], mod) + [(a_t, 0, A, E, 0)]  # noqa: E731
+            segs = [seg("q1", B, self.acts_main), seg("q2", B, self.acts_main), seg("q1", 0, self.act_pi), seg("q2", 0, self.act_pi),
+                    seg("tq1", 0, self.act_next), seg("tq2", 0, self.act_next)]
+            ops.mlp_fwd_gather(segs, [self.XQ["q1"], self.XQ["q2"], None, None, None, None], self.ldq, ps, pb, ac,
+                               [self.R, self.R, B, B, B, B], qd, qa, lean=self._lean("q"))
+        else:
+            with ops.copy_batch():  # one launch
+                for k in ("q1", "q2"):
+                    ops.copy_cols(self.S[k], 0, self.lds, self.XQ[k], 0, self.ldq, self.R, self.E, src_row_mod=B)
+                    ops.copy_cols(self.acts_main, 0, A, self.XQ[k], self.E, self.ldq, self.R, A)
+                    ops.copy_cols(self.S[k], 0, self.lds, self.XQpi[k], 0, self.ldq, B, self.E)
+                    ops.copy_cols(self.act_pi, 0, A, self.XQpi[k], self.E, self.ldq, B, A)
+                for k in ("tq1", "tq2"):
+                    ops.copy_cols(self.S[k], 0, self.lds, self.XT[k], 0, self.ldq, B, self.E)
+                    ops.copy_cols(self.act_next, 0, A, self.XT[k], self.E, self.ldq, B, A)
+            xs = [self.XQ["q1"], self.XQ["q2"], self.XQpi["q1"], self.XQpi["q2"], self.XT["tq1"], self.XT["tq2"]]
+            ops.mlp_fwd(xs, self.ldq, ps, ac, [self.R, self.R, B, B, B, B], qd, qa, self.compute, params_bf16=pb, lean=self._lean("q"))
         qout = lambda buf, off, rows: buf[off: off + rows]  # noqa: E731
         q1m, q2m = qout(self.qact["q1"], self.q_yoff_R, self.R), qout(self.qact["q2"], self.q_yoff_R, self.R)
         q1p, q2p = qout(self.qact_pi["q1"], self.q_yoff_B, B), qout(self.qact_pi["q2"], self.q_yoff_B, B)
@@ -731,10 +823,16 @@ class ACEngine:
         if optimize:
             a = self.actor
             items = [(lap.param, lap.grad, lap.m, lap.v, hp["critic_lr"], 0.0, lap.step, None, 0.0)] if self.with_lagrange else []
+            mir = [(None, None)] * len(items)
             items.append((a.param, a.grad, a.m, a.v, hp["actor_lr"], hp["clip"], a.step, None, 0.0))
+            mir.append((a.param_bf16, None))
             for q, t in ((self.q1, self.tq1), (self.q2, self.tq2)):
                 items.append((q.param, q.grad, q.m, q.v, hp["critic_lr"], hp["clip"], q.step, t.param, hp["tau"]))
-            ops.adam_step_batch(items)  # two launches for all blocks
+                mir.append((q.param_bf16, t.param_bf16))
+            write = self.compute == BF16 and self.adam_writes_mirrors
+            ops.adam_step_batch(items, mirrors=mir if write else None)  # two launches for all blocks
+            if write:  # (this launch rewrote every mirror from the updated parameters, whatever state they were in)
+                self.mirrors_written()
         ops.mark("c:adam")
 
     def _allreduce(self, tensors):

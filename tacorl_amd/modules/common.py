@@ -289,6 +289,13 @@ class GraphMixin:
         gs = self._graphs.get(key)
         if gs is not None:  # least-recently-used order: a hit moves the key to the end
             self._graphs[key] = self._graphs.pop(key)
+        stale = getattr(self, "_derived_stale", None)
+        if gs is not None and stale is not None and stale():
+            # the captured step relies on weight-derived buffers that the previous step's optimiser launch left current
+            # (bf16 mirrors written by the Adam kernel); something else has written the parameters since - a user's
+            # in-place edit, a broadcast - so run the step in python once more (it refreshes what is stale) and re-capture
+            self._graphs = {}
+            gs = None
         if gs is not None and gs[2] != ops.alloc_epoch():
             # some step buffer or workspace was (re)allocated since the capture (another batch shape came
             # through - the last, partial batch of an epoch - or another module grew a shared workspace): every
@@ -303,6 +310,9 @@ class GraphMixin:
         stepped = getattr(self, "_stepped_blocks", None)
         if stepped is not None:  # a replay runs no python: the optimiser kernels' writes are announced here
             ops.touched(*stepped())
+            after = getattr(self, "_after_replay_touch", None)
+            if after is not None:
+                after()
         cur = torch.cuda.current_stream()
         for i, g in enumerate(gs):
             g.replay()

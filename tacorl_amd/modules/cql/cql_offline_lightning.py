@@ -154,6 +154,15 @@ class CQL_Offline(GraphMixin, ModuleMixin, LightningModuleBase):
             out.append(ad.blk.param)
         return out
 
+    def _derived_stale(self):
+        """GraphMixin asks before every replay: are the engine's Adam-written bf16 mirrors still those of the parameters?"""
+        e = self.engine
+        return e.adam_writes_mirrors and e.mirrors_stale()
+
+    def _after_replay_touch(self):
+        """A replay has just run (its optimiser launch rewrote the mirrors) and the version counters were bumped for it."""
+        self.engine.mirrors_written()
+
     def named_gradients(self):
         e = self.engine
         out = {}

@@ -7,6 +7,8 @@ Select with `module._target_=tacorl_amd.modules.tacorl.tacorl.TACORL`.
 """
 from pathlib import Path
 
+import os
+
 import torch
 import torch.nn as nn
 

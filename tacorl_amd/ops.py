@@ -149,6 +149,25 @@ def mlp_fwd(xs, ldx, params, acts_buf, M, dims, acts, compute=F32, params_bf16=N
          len(dims) - 1, int_array(dims), int_array(acts), compute, stream())
 
 
+def mlp_fwd_gather_ok(M, dims, acts, ldx, compute, lean):
+    return compute == BF16 and bool(L.lib().tacorl_mlp_fwd_fused_gather_supported(
+        len(M), int_array(M), len(dims) - 1, int_array(dims), int_array(acts), ldx, int(lean)))
+
+
+def mlp_fwd_gather(segs, x_out, ldx, params, params_bf16, acts_buf, M, dims, acts, lean=False):
+    """The fused forward with gathered layer-0 inputs.  segs[p] = [(tensor, float offset, ld, first column, row modulo)],
+    <= 4 per problem, in column order; x_out[p]: tensor that also receives the assembled fp32 rows, or None."""
+    n = len(segs)
+    sp, sl, sc, sm = [0] * (4 * n), [0] * (4 * n), [0] * (4 * n), [0] * (4 * n)
+    for p, ss in enumerate(segs):
+        assert 1 <= len(ss) <= 4
+        for t, (ten, off, ld, c0, mod) in enumerate(ss):
+            sp[4 * p + t], sl[4 * p + t], sc[4 * p + t], sm[4 * p + t] = ten.data_ptr() + 4 * off, ld, c0, mod
+    call("tacorl_mlp_fwd_fused_gather", n, int_array([len(ss) for ss in segs]), (C.c_void_p * (4 * n))(*[v or None for v in sp]),
+         int_array(sl), int_array(sc), int_array(sm), ptr_array(x_out), ldx, ptr_array(params), ptr_array(params_bf16),
+         ptr_array(acts_buf), int_array(M), len(dims) - 1, int_array(dims), int_array(acts), int(lean), stream())
+
+
 def mlp_bwd(xs, ldx, params, acts_buf, d_outs, ldo, grads, d_xs, ldd, M, dims, acts, compute=F32, accumulate=False,
             ws_tag="mlp_bwd"):
     """ws_tag: scratch buffer name - calls that may overlap on different streams need different tags."""
@@ -342,17 +361,20 @@ def tanh_normal_sample(head, ld_head, eps, gumbel_u, hard, act_out, act_off, ld_
          ld_act, ptr(logp), ptr(grip_idx), n, M, Ac, stream())
 
 
-def adam_step_batch(items):
+def adam_step_batch(items, mirrors=None):
     """items: list of (param, grad, m, v, lr, max_norm, step_counter, target_or_None, tau) - one
-    norm (+ step counter) launch and one update launch for all of them."""
+    norm (+ step counter) launch and one update launch for all of them.
+    mirrors: optional list of (bf16 mirror of param or None, bf16 mirror of target or None), written by the update launch."""
     k = len(items)
     nb = L.lib().tacorl_adam_batch_ws_bytes(k)
     ws = workspace(nb, items[0][0].device, "adam_batch")
-    call("tacorl_adam_step_batch", k, ptr_array([i[0] for i in items]), ptr_array([i[1] for i in items]),
+    mir = ptr_array([m_[0] for m_ in mirrors]) if mirrors else None
+    tmir = ptr_array([m_[1] for m_ in mirrors]) if mirrors else None
+    call("tacorl_adam_step_batch_mirror", k, ptr_array([i[0] for i in items]), ptr_array([i[1] for i in items]),
          ptr_array([i[2] for i in items]), ptr_array([i[3] for i in items]), (C.c_long * k)(*[i[0].numel() for i in items]),
          (C.c_float * k)(*[float(i[4]) for i in items]), (C.c_float * k)(*[float(i[5]) for i in items]),
          ptr_array([i[6] for i in items]), ptr_array([i[7] for i in items]), (C.c_float * k)(*[float(i[8]) for i in items]),
-         ptr(ws), ws.numel(), stream())
+         mir, tmir, ptr(ws), ws.numel(), stream())
     touched(*[i[0] for i in items], *[i[7] for i in items if i[7] is not None])
 
 

@@ -543,14 +543,83 @@ def test_mlp_fused_forward_ragged_input_width():
         assert relerr(a_f[i], a_g[i]) < 2e-3, relerr(a_f[i], a_g[i])
 
 
-def test_mlp_fused_backward_many_rows():
-    """>= 16384 rows: the 64-rows-per-workgroup input-gradient chain and the many-row weight gradients (lean mode: LDS-DMA
-    over the bf16 copies the forward and the chain leave behind, mlp_wgrad_big_kernel) vs the per-layer bf16 backward on the
-    same saved activations, and vs the oracle's linear layers under bf16 operand rounding."""
+@pytest.mark.parametrize("A,cams,B,lean", [(16, 1, 37, False), (32, 2, 37, False), (7, 1, 37, False), (16, 1, 210, True)])
+def test_mlp_fused_forward_gathered_input(A, cams, B, lean):
+    """tacorl_mlp_fwd_fused_gather: the Q head's input [enc(obs) per camera | goal_enc | action] read in place - state rows
+    repeating every B rows (expand_obs on embeddings, reference utils/misc.py:132-153), actions one row each - must give
+    bit for bit the activations of `copy_cols` + tacorl_mlp_fwd_fused, write the assembled rows where asked and leave the
+    other problems' x_out alone.  A = 7: a ragged last segment (64 + 7 columns, row pitch 72) taken from an 8-float pitch."""
     from tacorl_amd import blocks, ops
 
     dev = _dev()
-    dims, acts, Ms = [71, 256, 256, 256, 1], [2, 2, 2, 0], [16384 + 77, 130]
+    n = 3  # (B = 210, lean: 2 100 rows - the many-row kernels with 32-row workgroups, bf16 y / fp16 act' saves)
+    R, E = (3 * n + 1) * B, 64 * cams
+    lda = (A + 3) // 4 * 4
+    dims, acts = [E + A, 256, 256, 256, 1], [2, 2, 2, 0]
+    ldq, L = (E + A + 3) // 4 * 4, 4
+    Ms = [R, B]
+    enc = [rnd(B + 5, 32, seed=900 + j).to(dev) for j in range(cams)]      # rows [5, 5 + B) are the problem's
+    gact = rnd(1000 + B * 32 * cams, seed=910).to(dev)                     # goal-encoder output at a float offset
+    actions = [torch.full((R, lda), 3.0, device=dev), torch.full((B, lda), 3.0, device=dev)]
+    for i, a in enumerate(actions):
+        a[:, :A] = rnd(a.shape[0], A, seed=920 + i).to(dev)
+    flats, fb = [], []
+    for i in range(2):
+        flat = torch.zeros(blocks.mlp_size(dims), device=dev)
+        v = blocks.mlp_views(flat, 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+        for l in range(L):
+            v[f"l{l}.w"].copy_(rnd(dims[l + 1], dims[l], seed=930 + i + l, scale=1 / math.sqrt(dims[l])))
+            v[f"l{l}.b"].copy_(rnd(dims[l + 1], seed=940 + i + l, scale=0.1))
+        flats.append(flat); fb.append(flat.to(torch.bfloat16))
+    # reference: assemble, then the plain fused forward
+    xs = [torch.zeros(M, ldq, device=dev) for M in Ms]
+    for x, M, a in zip(xs, Ms, actions):
+        rows = torch.arange(M, device=dev) % B
+        for j in range(cams):
+            x[:, 32 * j: 32 * j + 32] = enc[j][5 + rows]
+        x[:, 32 * cams: 64 * cams] = gact[1000:].view(B, 32 * cams)[rows]
+        x[:, E: E + A] = a[:, :A]
+    a_ref = [torch.zeros(ops.mlp_act_layout(M, dims, acts)[2], device=dev) for M in Ms]
+    a_got = [torch.full_like(t, float("nan")) for t in a_ref]
+    ops.mlp_fwd(xs, ldq, flats, a_ref, Ms, dims, acts, 1, params_bf16=fb, lean=lean)
+    assert ops.mlp_fwd_gather_ok(Ms, dims, acts, ldq, 1, lean)
+    segs = [[(enc[j], 5 * 32, 32, 32 * j, mod) for j in range(cams)] + [(gact, 1000, 32 * cams, 32 * cams, mod), (a, 0, lda, E, 0)]
+            for mod, a in ((B, actions[0]), (0, actions[1]))]
+    x_out = torch.full((R, ldq), float("nan"), device=dev)
+    if lean:
+        a_got = [torch.zeros_like(t) for t in a_ref]
+    ops.mlp_fwd_gather(segs, [x_out, None], ldq, flats, fb, a_got, Ms, dims, acts, lean=lean)
+    torch.cuda.synchronize()
+    for i, M in enumerate(Ms):
+        if lean:  # (hidden outputs are not saved / saved as bf16 + fp16 copies: compare the buffers as they are)
+            assert torch.equal(a_got[i].view(torch.int32), a_ref[i].view(torch.int32)), i
+            continue
+        zo, yo, _ = ops.mlp_act_layout(M, dims, acts)
+        for l in range(L):  # (alignment gaps between layers stay unwritten)
+            for off in (zo[l], yo[l]):
+                if off >= 0:
+                    sl = slice(off, off + M * dims[l + 1])
+                    assert torch.equal(a_got[i][sl], a_ref[i][sl]), (i, l)
+    assert torch.equal(x_out[:, :E + A], xs[0][:, :E + A])
+    assert bool((x_out[:, E + A:] == 0).all())  # pad columns of the assembled copy: zeros, never the source's garbage
+    # shapes the gather refuses: a segment start that is not a multiple of 8, a pitch that is not a multiple of 4
+    from tacorl_amd import _lib
+    with pytest.raises(_lib.TacorlHipError):
+        ops.mlp_fwd_gather([[(enc[0], 0, 32, 0, 0), (gact, 1000, 32, 20, 0)]], [None], ldq, flats[:1], fb[:1], a_got[1:], [B], dims, acts)
+    with pytest.raises(_lib.TacorlHipError):
+        ops.mlp_fwd_gather([[(enc[0], 0, 30, 0, 0)]], [None], ldq, flats[:1], fb[:1], a_got[1:], [B], dims, acts)
+
+
+@pytest.mark.parametrize("rows", [16384 + 77, 2048 + 13])  # (2 061: d_out's seeded mean is not ~0 there - at 2 125 rows the bias
+def test_mlp_fused_backward_many_rows(rows):               # sums cancel to 3 % of their l2 scale and bf16 dZ alone moves them 6 %)
+    """>= 16384 rows: the 64-rows-per-workgroup input-gradient chain and the many-row weight gradients (lean mode: LDS-DMA
+    over the bf16 copies the forward and the chain leave behind, mlp_wgrad_big_kernel) vs the per-layer bf16 backward on the
+    same saved activations, and vs the oracle's linear layers under bf16 operand rounding.  2 048 .. 16 383 rows (round 5:
+    the headline step's Q networks, 3 328 rows): the same saves and weight-gradient kernel behind 32-row workgroups."""
+    from tacorl_amd import blocks, ops
+
+    dev = _dev()
+    dims, acts, Ms = [71, 256, 256, 256, 1], [2, 2, 2, 0], [rows, 130]
     L, ld = len(dims) - 1, 72
     xs, flats, fb, act_s, act_l, douts = [], [], [], [], [], []
     for i, M in enumerate(Ms):
@@ -606,14 +675,15 @@ def test_mlp_fused_backward_many_rows():
             assert e < GRAD_BF16_ROUNDED, (k, i, e)
 
 
+@pytest.mark.parametrize("rows", [16384 + 77, 2048 + 77])
 @pytest.mark.parametrize("lean", [False, True])
-def test_mlp_fused_forward_many_rows(lean):
+def test_mlp_fused_forward_many_rows(lean, rows):
     """>= 16384 rows take the 128-rows-per-workgroup instantiation (C5's Q networks: 99 k rows): against the per-layer
     bf16 path on the same inputs, ragged last block included; in lean mode the final output must agree as well."""
     from tacorl_amd import blocks, ops
 
     dev = _dev()
-    dims, acts, Ms, ld = [71, 256, 256, 256, 1], [2, 2, 2, 0], [16384 + 77, 300], 72
+    dims, acts, Ms, ld = [71, 256, 256, 256, 1], [2, 2, 2, 0], [rows, 300], 72  # (2 048 .. 16 383 rows: 32-row workgroups)
     L = len(dims) - 1
     xs, flats, fb, a_f, a_g = [], [], [], [], []
     for i, M in enumerate(Ms):
@@ -636,7 +706,7 @@ def test_mlp_fused_forward_many_rows(lean):
         assert torch.isfinite(out_f).all() and relerr(out_f, out_g) < 2e-3, relerr(out_f, out_g)
         for l in range(L - 1):  # saved pre-activations (and, unless lean, outputs) of the hidden layers
             zf, zg = a_f[i][zo[l]: zo[l] + M * dims[l + 1]], a_g[i][zo[l]: zo[l] + M * dims[l + 1]]
-            if lean and M >= 16384:
+            if lean and M >= 2048:
                 # many-row problems of a lean site save what the backward reads instead of fp32 z / y (mlp_big_fwd_kernel):
                 # the output as bf16 [Mp][N] in the y region, act'(z) as fp16 [Mp][N] in the z region, zero rows beyond M
                 N, Mp = dims[l + 1], (M + 63) // 64 * 64
