@@ -826,6 +826,7 @@ __device__ __forceinline__ void mlp_big_fwd_body(const MlpBigFwdArgs& a) {
 }
 __global__ __launch_bounds__(MF_NT) void mlp_big_fwd_kernel(MlpBigFwdArgs a) { mlp_big_fwd_body<128>(a); }
 __global__ __launch_bounds__(MF_NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void mlp_mid_fwd_kernel(MlpBigFwdArgs a) { mlp_big_fwd_body<32>(a); }
+__global__ __launch_bounds__(MF_NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void mlp_m64_fwd_kernel(MlpBigFwdArgs a) { mlp_big_fwd_body<64>(a); }
 
 struct MlpBigBwdArgs {
   const float* d_out[MF_MAXP];
@@ -1286,6 +1287,10 @@ extern "C" int tacorl_dbg_mlp_stamps(unsigned long long* dst) {
 #endif
 // rows per workgroup of the many-row forward / input-gradient kernels: 128 / 64 at >= 16 384 rows, 32 / 32 below
 static bool mlp_rows_huge(int maxM) { return maxM >= 16384; }
+// experiment switches (rows per workgroup of the many-row forward / chain at >= 16 384 rows: 128 / 64 by default)
+static int mlp_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int mlp_huge_fwd_rows() { static const int v = mlp_env_int("TACORL_MLP_HUGE_FWD_ROWS", 128); return v; }
+static int mlp_huge_bwd_rows() { static const int v = mlp_env_int("TACORL_MLP_HUGE_BWD_ROWS", 64); return v; }
 template <class Args>
 static int mlp_set_gather(Args& a, int p, int q, const MlpXGather* gather, int K0) {  // gather's problem q -> args' problem p
   const int ns = gather ? gather->nseg[q] : 0;
@@ -1321,14 +1326,18 @@ int mlp_big_fwd(int nprob, const float* const* x, int ldx, const float* const* p
   }
   a.dims[L] = dims[L]; a.L = L; a.ldx = ldx;
   if (maxM == 0) return TACORL_OK;
-  constexpr size_t lds = (size_t)2 * 128 * XP * 2, lds_mid = (size_t)2 * 32 * XP * 2;
+  constexpr size_t lds = (size_t)2 * 128 * XP * 2, lds_mid = (size_t)2 * 32 * XP * 2, lds_64 = (size_t)2 * 64 * XP * 2;
   static int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_big_fwd_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_m64_fwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_64) == hipSuccess &&
                      hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_mid_fwd_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid) == hipSuccess) ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
   const int maxMp = (maxM + 63) & ~63;  // (the blocks cover the zero rows up to a multiple of 64 too)
-  if (mlp_rows_huge(maxM)) hipLaunchKernelGGL(mlp_big_fwd_kernel, dim3((maxMp + 127) / 128, nprob), dim3(MF_NT), lds, st, a);
+  const int rows = mlp_rows_huge(maxM) ? mlp_huge_fwd_rows() : 32;
+  if (rows == 128) hipLaunchKernelGGL(mlp_big_fwd_kernel, dim3((maxMp + 127) / 128, nprob), dim3(MF_NT), lds, st, a);
+  else if (rows == 64) hipLaunchKernelGGL(mlp_m64_fwd_kernel, dim3(maxMp / 64, nprob), dim3(MF_NT), lds_64, st, a);
   else hipLaunchKernelGGL(mlp_mid_fwd_kernel, dim3(maxMp / 32, nprob), dim3(MF_NT), lds_mid, st, a);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
@@ -1357,7 +1366,7 @@ int mlp_big_bwd(int nprob, const float* const* act, const float* const* d_out, i
                      hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_mid_bwd_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid) == hipSuccess) ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
-  if (mlp_rows_huge(maxM)) hipLaunchKernelGGL(mlp_big_bwd_kernel, dim3((maxM + 63) / 64, nprob), dim3(MF_NT), lds, st, a);
+  if (mlp_rows_huge(maxM) && mlp_huge_bwd_rows() == 64) hipLaunchKernelGGL(mlp_big_bwd_kernel, dim3((maxM + 63) / 64, nprob), dim3(MF_NT), lds, st, a);
   else hipLaunchKernelGGL(mlp_mid_bwd_kernel, dim3(((maxM + 63) & ~63) / 32, nprob), dim3(MF_NT), lds_mid, st, a);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
