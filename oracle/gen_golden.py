@@ -71,6 +71,15 @@ CASES = {
     "val_cql": dict(kind="cql", B=3, cams={"rgb_static": (84, 84)}, epoch=5, steps=1, seed=33, validate=True),
     "val_playlmp": dict(kind="playlmp", B=3, T=16, cams={"rgb_static": (84, 84)}, latent=16, steps=1, seed=34,
                         validate=True),
+    # FREE-RUNNING trajectories (round 5): many optimiser steps of the reference from one initial state with nothing
+    # re-synchronised in between - Adam's bias-correction counters and moments, Polyak drift of the targets, and the
+    # BC -> Q switch of the actor loss when current_epoch reaches bc_epochs (cql_offline_lightning.py:459-466) in the
+    # middle of the run.  Per step: the logged scalars, the latent plan and the noise tape; parameter fingerprints at
+    # the steps listed in `param_steps`; torch's Adam step counters at the end.
+    "tacorl_traj": dict(kind="tacorl", B=4, T=16, cams={"rgb_static": (84, 84)}, latent=16, finetune_ad=True,
+                        steps=12, seed=41, epochs=[4] * 6 + [5] * 6, param_steps=[0, 5, 6, 11], traj=True),
+    "playlmp_traj": dict(kind="playlmp", B=4, T=16, cams={"rgb_static": (84, 84)}, latent=16, steps=8, seed=42,
+                         param_steps=[0, 3, 7], traj=True),
 }
 
 
@@ -164,6 +173,8 @@ def run_case(name, c):
     out["param_requires_grad"] = np.array([p.requires_grad for _, p in mod.named_parameters()])
 
     for step in range(c["steps"]):
+        if c.get("epochs"):
+            mod.current_epoch = c["epochs"][step]
         bseed = c["seed"] * 100 + step
         if c["kind"] == "cql":
             batch = synth.make_transition_batch(bseed, c["B"], cams)
@@ -225,6 +236,12 @@ def run_case(name, c):
         # grads as each optimiser saw them: the LAST backward that touched a group
         # before its step is the one right after its zero_grad (reference
         # cql_offline_lightning.py:452-454,401-404,520-538; tacorl.py:231-233).
+        if c.get("traj"):
+            if step in c["param_steps"]:
+                _stats_dict(f"s{step}/param", mod.named_parameters(), out)
+            print(f"[{name}] step {step} (epoch {mod.current_epoch}): " +
+                  ", ".join(f"{k.split('/')[-1]}={v:.5g}" for k, v in sorted(mod.logged.items())))
+            continue
         if c["kind"] == "playlmp":
             _stats_dict(f"s{step}/grad", mod.grad_log[0].items(), out)
         else:
@@ -236,6 +253,15 @@ def run_case(name, c):
         _stats_dict(f"s{step}/param", mod.named_parameters(), out)
         print(f"[{name}] step {step}: " + ", ".join(f"{k.split('/')[-1]}={v:.5g}" for k, v in sorted(mod.logged.items())))
 
+    if c.get("traj"):
+        # torch.optim.Adam's own step counters after the run, by optimiser (reference order: configure_optimizers)
+        opts = mod.optimizers() if c["kind"] != "playlmp" else [mod.optimizers()[0]]
+        counts = []
+        for o in opts:
+            ts = {int(st["step"]) for st in o.state.values() if "step" in st}
+            counts.append(sorted(ts))
+        out["adam_steps"] = np.array(json.dumps(counts))
+        print(f"[{name}] Adam step counters per optimiser: {counts}")
     cfg = {k: v for k, v in c.items()}
     out["config"] = np.array(json.dumps(cfg))
     os.makedirs(OUT, exist_ok=True)

@@ -35,26 +35,51 @@ LOG2 = math.log(2.0)
 
 # ------------------------------------------------------------- contractions (exact / bf16 operands)
 _OPERAND_DTYPE = None
+_ROUND_ONLY = None   # None: every contraction; else a set of contraction classes ("conv", "rnn", "attn", "linear")
+_REGION = []         # class of the contractions being evaluated (innermost first wins), "linear" outside any region
 
 
 class operand_rounding:
-    """with operand_rounding(torch.bfloat16): ... - see the module docstring."""
+    """with operand_rounding(torch.bfloat16): ... - see the module docstring.
+    only={"conv", "rnn", "attn", "linear"} (any subset) restricts the rounding to those contraction classes - the
+    convolutions, the action decoder's recurrent network and heads, the plan-recognition transformer, every other Linear -
+    for bisecting which rounding a gradient is sensitive to (profiles/r05_playlmp_bf16_bisect.md); the backward of a
+    contraction rounds exactly when its forward did."""
 
-    def __init__(self, dtype):
-        self.dtype = dtype
+    def __init__(self, dtype, only=None):
+        self.dtype, self.only = dtype, (None if only is None else frozenset(only))
 
     def __enter__(self):
-        global _OPERAND_DTYPE
-        self.prev, _OPERAND_DTYPE = _OPERAND_DTYPE, self.dtype
+        global _OPERAND_DTYPE, _ROUND_ONLY
+        self.prev, _OPERAND_DTYPE = (_OPERAND_DTYPE, _ROUND_ONLY), self.dtype
+        _ROUND_ONLY = self.only
 
     def __exit__(self, *exc):
-        global _OPERAND_DTYPE
-        _OPERAND_DTYPE = self.prev
+        global _OPERAND_DTYPE, _ROUND_ONLY
+        _OPERAND_DTYPE, _ROUND_ONLY = self.prev
         return False
 
 
-def _r(t):
-    return t.to(_OPERAND_DTYPE).to(torch.float32)
+class _region:
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        _REGION.append(self.kind)
+
+    def __exit__(self, *exc):
+        _REGION.pop()
+        return False
+
+
+def _rounds(kind):
+    if _OPERAND_DTYPE is None:
+        return False
+    return _ROUND_ONLY is None or (_REGION[-1] if _REGION and kind == "linear" else kind) in _ROUND_ONLY
+
+
+def _r(t, dt=None):
+    return t.to(dt if dt is not None else _OPERAND_DTYPE).to(torch.float32)
 
 
 class _RoundedLinear(torch.autograd.Function):
@@ -62,13 +87,13 @@ class _RoundedLinear(torch.autograd.Function):
     def forward(ctx, x, w, b):
         xr, wr = _r(x), _r(w)
         ctx.save_for_backward(xr, wr)
-        ctx.has_b = b is not None
+        ctx.has_b, ctx.dt = b is not None, _OPERAND_DTYPE
         return F.linear(xr, wr, b)
 
     @staticmethod
     def backward(ctx, dy):
         xr, wr = ctx.saved_tensors
-        dyr = _r(dy)
+        dyr = _r(dy, ctx.dt)
         d2, x2 = dyr.reshape(-1, dyr.shape[-1]), xr.reshape(-1, xr.shape[-1])
         return dyr @ wr, d2.t() @ x2, (d2.sum(0) if ctx.has_b else None)
 
@@ -78,24 +103,24 @@ class _RoundedConv2d(torch.autograd.Function):
     def forward(ctx, x, w, b, stride):
         xr, wr = _r(x), _r(w)
         ctx.save_for_backward(xr, wr)
-        ctx.stride, ctx.has_b = stride, b is not None
+        ctx.stride, ctx.has_b, ctx.dt = stride, b is not None, _OPERAND_DTYPE
         return F.conv2d(xr, wr, b, stride=stride)
 
     @staticmethod
     def backward(ctx, dy):
         xr, wr = ctx.saved_tensors
-        dyr = _r(dy)
+        dyr = _r(dy, ctx.dt)
         dx = torch.nn.grad.conv2d_input(xr.shape, wr, dyr, stride=ctx.stride)
         dw = torch.nn.grad.conv2d_weight(xr, wr.shape, dyr, stride=ctx.stride)
         return dx, dw, (dyr.sum(dim=(0, 2, 3)) if ctx.has_b else None), None
 
 
 def _linear(x, w, b=None):
-    return F.linear(x, w, b) if _OPERAND_DTYPE is None else _RoundedLinear.apply(x, w, b)
+    return _RoundedLinear.apply(x, w, b) if _rounds("linear") else F.linear(x, w, b)
 
 
 def _conv2d(x, w, b=None, stride=1):
-    return F.conv2d(x, w, b, stride=stride) if _OPERAND_DTYPE is None else _RoundedConv2d.apply(x, w, b, stride)
+    return _RoundedConv2d.apply(x, w, b, stride) if _rounds("conv") else F.conv2d(x, w, b, stride=stride)
 
 
 # ----------------------------------------------------------------------------- A1/A2
@@ -232,6 +257,7 @@ def plan_recognition(P, pre, emb, n_heads=8, n_layers=2, min_std=1e-4, dropout=N
     if masks is not None:
         x = drop_tbd(x, masks[0])
     hd = D // n_heads
+    _REGION.append("attn")  # (contraction class for operand_rounding(only=...); popped before returning)
     for l in range(n_layers):
         lp = f"{pre}transformer_encoder.layers.{l}."
         mk = masks[1 + 4 * l: 5 + 4 * l] if masks is not None else None
@@ -257,6 +283,7 @@ def plan_recognition(P, pre, emb, n_heads=8, n_layers=2, min_std=1e-4, dropout=N
     x = _linear(x, P[pre + "fc.weight"], P[pre + "fc.bias"]).mean(dim=1)
     mean = _linear(x, P[pre + "mean_fc.weight"], P[pre + "mean_fc.bias"])
     std = F.softplus(_linear(x, P[pre + "variance_fc.weight"], P[pre + "variance_fc.bias"])) + min_std
+    _REGION.pop()
     return mean, std
 
 
@@ -268,6 +295,7 @@ def action_decoder_fwd(P, pre, plan, emb, n_mix=10, n_layers=2, h0=None, return_
     B, T, _ = emb.shape
     x = torch.cat([plan.unsqueeze(1).expand(-1, T, -1), emb], dim=-1)
     hn = []
+    _REGION.append("rnn")  # (contraction class of everything below, for operand_rounding(only=...); popped before returning)
     for l in range(n_layers):
         wi, wh = P[f"{pre}rnn.weight_ih_l{l}"], P[f"{pre}rnn.weight_hh_l{l}"]
         bi, bh = P[f"{pre}rnn.bias_ih_l{l}"], P[f"{pre}rnn.bias_hh_l{l}"]
@@ -284,6 +312,7 @@ def action_decoder_fwd(P, pre, plan, emb, n_mix=10, n_layers=2, h0=None, return_
     log_scales = torch.clamp(_linear(x, P[pre + "log_scale_fc.weight"], P[pre + "log_scale_fc.bias"]),
                              min=LOG_SIG_MIN)
     grip = _linear(x, P[pre + "gripper_fc.weight"], P[pre + "gripper_fc.bias"])
+    _REGION.pop()
     v = lambda t: t.reshape(B, T, -1, n_mix)  # noqa: E731
     if return_hidden:
         return v(probs), v(log_scales), v(means), grip, torch.stack(hn)
@@ -670,7 +699,7 @@ def balanced_kl(mu_q, std_q, mu_p, std_p, kl_alpha=0.8):
             + (1 - kl_alpha) * kl(mu_q, std_q, mu_p.detach(), std_p.detach()).mean())
 
 
-def playlmp_step(P, opt, batch, noise, cams, kl_beta=1e-3, kl_alpha=0.8, step=True, dropout_p=0.0):
+def playlmp_step(P, opt, batch, noise, cams, kl_beta=1e-3, kl_alpha=0.8, step=True, dropout_p=0.0, extra=None):
     """PlayLMP.training_step + Adam (play_lmp_for_rl.py:200-257,307-317,362-368); with dropout_p > 0 the
     plan recognition runs in train mode with the keep masks noise['dropout'] (see plan_recognition).
     noise: 'eps_plan' (B,A) rsample; 'rand' list of 4 U(0,1) (B,T-1,6[,10]) for the two
@@ -704,6 +733,8 @@ def playlmp_step(P, opt, batch, noise, cams, kl_beta=1e-3, kl_alpha=0.8, step=Tr
     total = kl * kl_beta + action_loss
     logs["total_loss"] = total.item()
     names = [n for n, t in P.items() if t.requires_grad]
+    if extra is not None:  # (tests: the gradient that enters the encoders' backward, (B, T, 32 * cams))
+        extra["d_emb"] = torch.autograd.grad(total, cat, retain_graph=True)[0].detach()
     g = _grads(total, P, names, retain=False)
     if step:
         opt.step(P, g)

@@ -88,6 +88,31 @@ __device__ __forceinline__ void layer_norm32(f32x4 (&v)[2], const float* w, cons
 // RT: 16-row tiles per sequence (T = 16 RT: window 16 - one MFMA tile, as the reference's default - or 32, the real-world
 // configuration's window: BASELINE configs[3]; round 4 - at T = 32 the per-op path put 349 us of launches in front of BOTH
 // chains of the C4 step).  Everything row-shaped simply exists RT times per lane; the attention has 8 T (head, query) pairs.
+// the same with the weight / bias vectors already in registers (fetched at the top of the layer)
+__device__ __forceinline__ void layer_norm32_r(f32x4 (&v)[2], const f32x4 (&ww)[2], const f32x4 (&bb)[2], int g, float* st = nullptr) {
+  float s = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) s += v[nt][r];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s / 32.f;
+  float q = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const float c = v[nt][r] - mean; q += c * c; }
+  q += __shfl_xor(q, 16, 64);
+  q += __shfl_xor(q, 32, 64);
+  const float rstd = 1.0f / sqrtf(q / 32.f + 1e-5f);
+  if (st && g == 0) { st[0] = mean; st[1] = rstd; }
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[nt][r] = (v[nt][r] - mean) * rstd * ww[nt][r] + bb[nt][r];
+}
+
 template <int RT>
 __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
   constexpr int T = 16 * RT;
@@ -142,6 +167,41 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
   for (int l = 0; l < a.L; l++) {
     const PrLayerOff& o = a.l[l];
     const PrSaveL& S = a.sv[l];
+    // Every small operand of the layer in ONE global round trip at its top (round 5): projection weights (from the bf16
+    // mirror: the very values cvt8 of the fp32 block gives), biases, both LayerNorms' vectors and the first FFN chunk's
+    // W1 fragments.  Each used to be fetched where it is consumed, behind an LDS wait that also fences memory: five
+    // dependent round trips per layer on a kernel that is nothing but latency (~1.5 us each with 1 024 waves asking for
+    // the same lines) - and this launch is on the critical path of BOTH chains of the training step.
+    bf16x8 inw[6], outw[2];
+    f32x4 inb[6], outb[2], n1w[2], n1b[2], n2w[2], n2b[2], b2v[2];
+#pragma unroll
+    for (int nt = 0; nt < 6; nt++) {
+      inw[nt] = *reinterpret_cast<const bf16x8*>(a.Pb + o.in_w + (long)(16 * nt + i) * PR_D + 8 * g);
+      inb[nt] = *reinterpret_cast<const f32x4*>(a.P + o.in_b + 16 * nt + 4 * g);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+      outw[nt] = *reinterpret_cast<const bf16x8*>(a.Pb + o.out_w + (long)(16 * nt + i) * PR_D + 8 * g);
+      outb[nt] = *reinterpret_cast<const f32x4*>(a.P + o.out_b + 16 * nt + 4 * g);
+      n1w[nt] = *reinterpret_cast<const f32x4*>(a.P + o.n1w + 16 * nt + 4 * g);
+      n1b[nt] = *reinterpret_cast<const f32x4*>(a.P + o.n1b + 16 * nt + 4 * g);
+      n2w[nt] = *reinterpret_cast<const f32x4*>(a.P + o.n2w + 16 * nt + 4 * g);
+      n2b[nt] = *reinterpret_cast<const f32x4*>(a.P + o.n2b + 16 * nt + 4 * g);
+      b2v[nt] = *reinterpret_cast<const f32x4*>(a.P + o.b2 + 16 * nt + 4 * g);
+    }
+    const __bf16* W1 = a.Pb + o.w1;
+    const __bf16* W2 = a.Pb + o.w2;
+    bf16x8 w1f[16], w2f[8][2];
+    const int c0 = w < nchunk ? w : nchunk - 1;  // (a wave without chunks prefetches in bounds and skips the loop)
+#pragma unroll
+    for (int nt = 0; nt < 16; nt++) w1f[nt] = *reinterpret_cast<const bf16x8*>(W1 + (long)(PR_CH * c0 + 16 * nt + i) * PR_D + 8 * g);
+    if (RT == 1) {  // (window 16: 64 more registers fit - the first chunk's W2 fragments travel with the rest)
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+          w2f[ks][nt] = *reinterpret_cast<const bf16x8*>(W2 + (long)(16 * nt + i) * a.FF + PR_CH * c0 + 32 * ks + 8 * g);
+    }
     if (sv0) {
 #pragma unroll
       for (int rt = 0; rt < RT; rt++)
@@ -157,8 +217,8 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
       for (int rt = 0; rt < RT; rt++) xf[rt] = *reinterpret_cast<const bf16x8*>(xb + (16 * rt + i) * XB_P + 8 * g);
 #pragma unroll
       for (int nt = 0; nt < 6; nt++) {
-        const bf16x8 wf = cvt8(a.P + o.in_w + (long)(16 * nt + i) * PR_D + 8 * g);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.in_b + 16 * nt + 4 * g);
+        const bf16x8 wf = inw[nt];
+        const f32x4 bias = inb[nt];
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
           f32x4 acc = bias;
@@ -205,8 +265,8 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
       for (int rt = 0; rt < RT; rt++) af[rt] = *reinterpret_cast<const bf16x8*>(xb + (16 * rt + i) * XB_P + 8 * g);
 #pragma unroll
       for (int nt = 0; nt < 2; nt++) {
-        const bf16x8 wf = cvt8(a.P + o.out_w + (long)(16 * nt + i) * PR_D + 8 * g);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.out_b + 16 * nt + 4 * g);
+        const bf16x8 wf = outw[nt];
+        const f32x4 bias = outb[nt];
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
           f32x4 acc = bias;
@@ -217,7 +277,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
       }
 #pragma unroll
       for (int rt = 0; rt < RT; rt++) {
-        layer_norm32(x[rt], a.P + o.n1w, a.P + o.n1b, g, sv0 ? S.st1 + 2 * rrow[rt] : nullptr);
+        layer_norm32_r(x[rt], n1w, n1b, g, sv0 ? S.st1 + 2 * rrow[rt] : nullptr);
         if (sv0) {
 #pragma unroll
           for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(S.x1 + rrow[rt] * PR_D + 16 * nt + 4 * g) = x[rt][nt];
@@ -236,20 +296,16 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
       for (int nt = 0; nt < 2; nt++)
-        y[rt][nt] = w == 0 ? *reinterpret_cast<const f32x4*>(a.P + o.b2 + 16 * nt + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const __bf16* W1 = a.Pb + o.w1;
-    const __bf16* W2 = a.Pb + o.w2;
-    bf16x8 w1f[16], w2f[8][2];
-    const int c0 = w < nchunk ? w : nchunk - 1;  // (a wave without chunks prefetches in bounds and skips the loop)
-#pragma unroll
-    for (int nt = 0; nt < 16; nt++) w1f[nt] = *reinterpret_cast<const bf16x8*>(W1 + (long)(PR_CH * c0 + 16 * nt + i) * PR_D + 8 * g);
+        y[rt][nt] = w == 0 ? b2v[nt] : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c = w; c < nchunk; c += 4) {
-      // this chunk's W2 fragments travel while FFN1 runs
+      // this chunk's W2 fragments travel while FFN1 runs (window 16: the first chunk's came with the layer's other operands)
+      if (RT != 1 || c != w) {
 #pragma unroll
-      for (int ks = 0; ks < 8; ks++)
+        for (int ks = 0; ks < 8; ks++)
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-          w2f[ks][nt] = *reinterpret_cast<const bf16x8*>(W2 + (long)(16 * nt + i) * a.FF + PR_CH * c + 32 * ks + 8 * g);
+          for (int nt = 0; nt < 2; nt++)
+            w2f[ks][nt] = *reinterpret_cast<const bf16x8*>(W2 + (long)(16 * nt + i) * a.FF + PR_CH * c + 32 * ks + 8 * g);
+      }
 #pragma unroll
       for (int nt = 0; nt < 16; nt++) {
         const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.b1 + PR_CH * c + 16 * nt + 4 * g);
@@ -302,7 +358,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
         }
     }
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++) layer_norm32(x[rt], a.P + o.n2w, a.P + o.n2b, g, sv0 ? S.st2 + 2 * rrow[rt] : nullptr);
+    for (int rt = 0; rt < RT; rt++) layer_norm32_r(x[rt], n2w, n2b, g, sv0 ? S.st2 + 2 * rrow[rt] : nullptr);
   }
   if (w != 0) return;  // every wave holds the same result: wave 0 writes it
   // ---- mean over the T time steps (row tiles in order, then lanes i = 0..15 of each g)
