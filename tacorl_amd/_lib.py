@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libtacorl_hip.so")
+# (TACORL_HIP_LIB: another build of the same library - same-box A/B of a kernel change, scratch/mklib_file.sh)
+LIB_PATH = os.environ.get("TACORL_HIP_LIB") or os.path.join(HERE, "lib", "libtacorl_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2

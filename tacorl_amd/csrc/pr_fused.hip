@@ -21,6 +21,9 @@
 
 namespace {
 
+#ifndef PR_W2TOP
+#define PR_W2TOP 0  // 1: 510 registers - nothing else fits on a CU beside a plan-recognition workgroup (see DESIGN, round 5)
+#endif
 constexpr int PR_D = 32, PR_T = 16, PR_H = 8, PR_HD = 4, PR_MAXL = 4, PR_CH = 256;
 constexpr int XB_P = 40;    // bf16 row pitch of the 32-wide MFMA B operand (80 B: conflict-free b128 reads)
 constexpr int HB_P = 264;   // bf16 row pitch of one FFN hidden chunk
@@ -124,6 +127,11 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
   // (wave w: chunks w, w + 4, ...); the partial FFN outputs meet in LDS once per layer.  B workgroups instead
   // of B / 4: at B = 256 the launch covers every CU instead of a quarter of them.
   __shared__ __attribute__((aligned(16))) float ypart[2][4][T * PR_D];  // [layer parity][wave]
+  // this wave's FFN1 biases of the layer (its chunks w, w + 4: up to PR_B1C chunks of 256), fetched with the layer's other
+  // operands and parked here: read where the 16 column tiles of a chunk need them, they were one more exposed global
+  // round trip per chunk
+  constexpr int PR_B1C = 2;
+  __shared__ __attribute__((aligned(16))) float b1_s[4][PR_B1C * PR_CH];
   const int b = blockIdx.x;
   if (b >= a.B) return;  // block-uniform
   __bf16* xb = xb_s[w];
@@ -195,7 +203,16 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
     const int c0 = w < nchunk ? w : nchunk - 1;  // (a wave without chunks prefetches in bounds and skips the loop)
 #pragma unroll
     for (int nt = 0; nt < 16; nt++) w1f[nt] = *reinterpret_cast<const bf16x8*>(W1 + (long)(PR_CH * c0 + 16 * nt + i) * PR_D + 8 * g);
-    if (RT == 1) {  // (window 16: 64 more registers fit - the first chunk's W2 fragments travel with the rest)
+    f32x4 b1pre[PR_B1C];  // lane: floats 4 lane .. 4 lane + 3 of chunk w + 4 j
+    const bool b1_staged = nchunk <= 4 * PR_B1C;
+    if (b1_staged) {
+#pragma unroll
+      for (int j = 0; j < PR_B1C; j++) {
+        const int c = w + 4 * j;
+        b1pre[j] = *reinterpret_cast<const f32x4*>(a.P + o.b1 + PR_CH * (c < nchunk ? c : c0) + 4 * lane);
+      }
+    }
+    if (RT == 1 && PR_W2TOP) {  // (window 16: 64 more registers fit - the first chunk's W2 fragments travel with the rest)
 #pragma unroll
       for (int ks = 0; ks < 8; ks++)
 #pragma unroll
@@ -234,8 +251,10 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
     for (int j = 0; j < 2 * RT; j++) {
       const int p = lane + 64 * j, h = p / T, qi = p % T;
       f32x4 q = *reinterpret_cast<const f32x4*>(qkv + qi * QKV_P + PR_HD * h);
+      // 1 / sqrt(head_dim) and log2(e) in one factor: softmax(s) = 2^(s' - max s') / sum, s' = s log2 e (v_exp_f32 is 2^x;
+      // expf was ~15 instructions and the 16 IEEE divisions by the sum ~11 each, per (head, query) pair, on all four waves)
 #pragma unroll
-      for (int e = 0; e < 4; e++) q[e] *= 0.5f;  // 1 / sqrt(head_dim)
+      for (int e = 0; e < 4; e++) q[e] *= 0.5f * 1.44269504088896341f;
       float s[T], mx = -INFINITY;
 #pragma unroll
       for (int t = 0; t < T; t++) {
@@ -245,12 +264,13 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
       }
       float se = 0.f;
 #pragma unroll
-      for (int t = 0; t < T; t++) { s[t] = expf(s[t] - mx); se += s[t]; }
+      for (int t = 0; t < T; t++) { s[t] = __builtin_amdgcn_exp2f(s[t] - mx); se += s[t]; }
+      const float rse = __builtin_amdgcn_rcpf(se);
       f32x4 ov = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < T; t++) {
         const f32x4 vv = *reinterpret_cast<const f32x4*>(qkv + t * QKV_P + 2 * PR_D + PR_HD * h);
-        const float pr = s[t] / se;
+        const float pr = s[t] * rse;
 #pragma unroll
         for (int e = 0; e < 4; e++) ov[e] += pr * vv[e];
       }
@@ -288,6 +308,11 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
     put_xb(x);
     lds_sync();
     // ---- FFN: relu(x W1^T + b1) W2^T + b2, hidden processed in chunks of 256 kept in LDS as bf16
+    if (b1_staged) {
+#pragma unroll
+      for (int j = 0; j < PR_B1C; j++) *reinterpret_cast<f32x4*>(b1_s[w] + PR_CH * j + 4 * lane) = b1pre[j];
+      lds_sync();  // (wave-private: this wave wrote it, this wave reads it)
+    }
     bf16x8 xf[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) xf[rt] = *reinterpret_cast<const bf16x8*>(xb + (16 * rt + i) * XB_P + 8 * g);
@@ -299,7 +324,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
         y[rt][nt] = w == 0 ? b2v[nt] : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c = w; c < nchunk; c += 4) {
       // this chunk's W2 fragments travel while FFN1 runs (window 16: the first chunk's came with the layer's other operands)
-      if (RT != 1 || c != w) {
+      if (RT != 1 || !PR_W2TOP || c != w) {
 #pragma unroll
         for (int ks = 0; ks < 8; ks++)
 #pragma unroll
@@ -308,7 +333,8 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
       }
 #pragma unroll
       for (int nt = 0; nt < 16; nt++) {
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.b1 + PR_CH * c + 16 * nt + 4 * g);
+        const f32x4 bias = b1_staged ? *reinterpret_cast<const f32x4*>(b1_s[w] + PR_CH * ((c - w) >> 2) + 16 * nt + 4 * g)
+                                     : *reinterpret_cast<const f32x4*>(a.P + o.b1 + PR_CH * c + 16 * nt + 4 * g);
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
           f32x4 hacc = bias;
