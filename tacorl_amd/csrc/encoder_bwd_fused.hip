@@ -245,9 +245,8 @@ __global__ __launch_bounds__(NT) void ebw_wgrad_tr_kernel(WgArgs a) {
     const __bf16* dzs = buf;
     const __bf16* ins = buf + G::DZ_EL;
     const int npix = G::NBAND == 1 ? G::NPIX : band_rows(b) * L::OW;
-#pragma unroll
-    for (int s = 0; s < G::KS; s++) {
-      if (T::KGRP > 1 && (s % T::KGRP) != kg) continue;
+    auto kstep = [&](int s) {
+      if (T::KGRP > 1 && (s % T::KGRP) != kg) return;
       // this lane's two pixels of the k-step (dZ rows of padded pixels are zero; their input address is clamped)
       const int P0 = 32 * s + 4 * g + q, P1 = P0 + 16;
       const int Q0 = P0 < npix ? P0 : npix - 1, Q1 = P1 < npix ? P1 : npix - 1;
@@ -269,6 +268,15 @@ __global__ __launch_bounds__(NT) void ebw_wgrad_tr_kernel(WgArgs a) {
 #pragma unroll
         for (int i = 0; i < G::MPW; i++) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i], ones, bacc[i], 0, 0, 0);
       }
+    };
+    // (fully unrolled the k-steps hoist their pixel -> address arithmetic: at 7 steps - conv2 of a 128 x 128 camera, 196
+    // output pixels - beside 48 staging registers that was 256 registers + 54 spilled ones reloaded per image; round 5)
+    if constexpr (G::KS > 4 && !IMG) {
+#pragma unroll 1
+      for (int s = 0; s < G::KS; s++) kstep(s);
+    } else {
+#pragma unroll
+      for (int s = 0; s < G::KS; s++) kstep(s);
     }
   };
   __syncthreads();  // zero fill done

@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
     for (int j = 0; j < 2 * RT; j++) {
       const int p = lane + 64 * j, h = p / T, qi = p % T;
       f32x4 q0 = *reinterpret_cast<const f32x4*>(qkv + qi * QKV6_P + HD6 * h), q1 = *reinterpret_cast<const f32x4*>(qkv + qi * QKV6_P + HD6 * h + 4);
-      const float sc = 0.35355339059327379f;  // 1 / sqrt(8)
+      const float sc = 0.35355339059327379f * 1.44269504088896341f;  // 1 / sqrt(8) and log2 e: the softmax runs on 2^x (round 5)
       q0 *= sc; q1 *= sc;
       float s[T], mx = -INFINITY;
 #pragma unroll
@@ -536,12 +536,13 @@ __global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
       }
       float se = 0.f;
 #pragma unroll
-      for (int t = 0; t < T; t++) { s[t] = expf(s[t] - mx); se += s[t]; }
+      for (int t = 0; t < T; t++) { s[t] = __builtin_amdgcn_exp2f(s[t] - mx); se += s[t]; }
+      const float rse = __builtin_amdgcn_rcpf(se);
       f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < T; t++) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(qkv + t * QKV6_P + 2 * D6 + HD6 * h), v1 = *reinterpret_cast<const f32x4*>(qkv + t * QKV6_P + 2 * D6 + HD6 * h + 4);
-        const float pr = s[t] / se;
+        const float pr = s[t] * rse;
         o0 += pr * v0; o1 += pr * v1;
       }
       *reinterpret_cast<bf16x8*>(xb + qi * XB6_P + HD6 * h) =
