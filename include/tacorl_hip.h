@@ -290,6 +290,14 @@ int tacorl_pack_images(const float* src, long img_pitch, int src_nchw, void* dst
  * and the obs / goal / next-obs images of a TACORL step (reference get_rl_batch, tacorl.py:142-179). */
 int tacorl_pack_images_batch(int njobs, const float* const* src, const long* img_pitch, void* const* dst,
                              const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream);
+/* The same with second destinations for WINDOW jobs (window[j] = T >= 2, n_img[j] % T == 0): image i = b T + t of job j is
+ * also written to image b of dst_first[j] (t == 0) or of dst_last[j] (t == T - 1).  TACO-RL's transition (s, s') is the
+ * window's first and last frame (reference modules/tacorl/tacorl.py:147-168, get_rl_batch), so the step's obs / next
+ * images are packed from the one read of the window instead of being read again: 2 B of 19 B fp32 frames per step.
+ * window == NULL or window[j] == 0: a plain job. */
+int tacorl_pack_images_window_batch(int njobs, const float* const* src, const long* img_pitch, void* const* dst,
+                                    const int* n_img, void* const* dst_first, void* const* dst_last,
+                                    const int* window, int dst_dtype, int H, int W, tacorl_stream_t stream);
 /* The dataset's own frame format: uint8 HWC (reference datamodule/dataset/play_dataset.py) -> NHWC fp32 / bf16 with the
  * reference's transform pipeline applied on the way, ToTensor (x / 255) and Normalize(0.5, 0.5) ((t - 0.5) / 0.5) in
  * fp32 (config .../rl_train.yaml:12-14): bit-identical to packing the transformed fp32 frames, a quarter of the

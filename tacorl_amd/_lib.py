@@ -112,6 +112,7 @@ _SIGS = {
     "tacorl_mlp_bwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _sz, _p]),
     "tacorl_pack_images": (_i, [_p, _l, _i, _p, _i, _i, _i, _i, _i, _p]),
     "tacorl_pack_images_batch": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "tacorl_pack_images_window_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_pack_images_u8_batch": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_pack_images_u8_gather_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_pack_images_u8_aug_gather_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

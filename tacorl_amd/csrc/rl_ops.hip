@@ -56,6 +56,12 @@ struct PackTbl {
   void* dst[PACK_MAXJ];
   long pitch[PACK_MAXJ];
   int n[PACK_MAXJ];
+  // optional second destinations of a WINDOW job (dupT[j] = T > 0): image i = b T + t also goes to dupA[j] + b (t == 0)
+  // or dupB[j] + b (t == T - 1) - the transition's obs / next images ARE the window's first / last frames (reference
+  // tacorl.py:147-168 get_rl_batch: s = states[:, 0], s' = states[:, -1]), so they are read once
+  void* dupA[PACK_MAXJ];
+  void* dupB[PACK_MAXJ];
+  int dupT[PACK_MAXJ];
 };
 template <typename OutT>
 __global__ void pack_nchw3_batch_kernel(PackTbl t, int HW) {
@@ -71,19 +77,37 @@ __global__ void pack_nchw3_batch_kernel(PackTbl t, int HW) {
                 b = *reinterpret_cast<const f32x4*>(s + 2 * HW);
     const float v[12] = {r[0], g[0], b[0], r[1], g[1], b[1], r[2], g[2], b[2], r[3], g[3], b[3]};
     OutT* d = dst + (img * HW + p) * 3;
+    OutT* d2 = nullptr;
+    if (t.dupT[j] > 0) {
+      const long b = img / t.dupT[j];
+      const int tt = (int)(img - b * t.dupT[j]);
+      OutT* base = tt == 0 ? reinterpret_cast<OutT*>(t.dupA[j]) : (tt == t.dupT[j] - 1 ? reinterpret_cast<OutT*>(t.dupB[j]) : nullptr);
+      if (base) d2 = base + (b * HW + p) * 3;
+    }
     if constexpr (sizeof(OutT) == 2) {
 #pragma unroll
-      for (int k = 0; k < 3; k++)
-        *reinterpret_cast<bf16x4*>(d + 4 * k) = bf16x4{(__bf16)v[4 * k], (__bf16)v[4 * k + 1], (__bf16)v[4 * k + 2], (__bf16)v[4 * k + 3]};
+      for (int k = 0; k < 3; k++) {
+        const bf16x4 o = bf16x4{(__bf16)v[4 * k], (__bf16)v[4 * k + 1], (__bf16)v[4 * k + 2], (__bf16)v[4 * k + 3]};
+        *reinterpret_cast<bf16x4*>(d + 4 * k) = o;
+        if (d2) *reinterpret_cast<bf16x4*>(d2 + 4 * k) = o;
+      }
     } else {
 #pragma unroll
-      for (int k = 0; k < 3; k++)
-        *reinterpret_cast<f32x4*>(d + 4 * k) = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+      for (int k = 0; k < 3; k++) {
+        const f32x4 o = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+        *reinterpret_cast<f32x4*>(d + 4 * k) = o;
+        if (d2) *reinterpret_cast<f32x4*>(d2 + 4 * k) = o;
+      }
     }
   }
 }
 extern "C" int tacorl_pack_images_batch(int njobs, const float* const* src, const long* img_pitch, void* const* dst,
                                         const int* n_img, int dst_dtype, int H, int W, tacorl_stream_t stream) {
+  return tacorl_pack_images_window_batch(njobs, src, img_pitch, dst, n_img, nullptr, nullptr, nullptr, dst_dtype, H, W, stream);
+}
+extern "C" int tacorl_pack_images_window_batch(int njobs, const float* const* src, const long* img_pitch, void* const* dst,
+                                               const int* n_img, void* const* dst_first, void* const* dst_last,
+                                               const int* window, int dst_dtype, int H, int W, tacorl_stream_t stream) {
   if (njobs < 1 || njobs > PACK_MAXJ || (H * W) % 4) return TACORL_EINVAL;
   PackTbl t{};
   long mx = 0;
@@ -91,6 +115,11 @@ extern "C" int tacorl_pack_images_batch(int njobs, const float* const* src, cons
   for (int j = 0; j < njobs; j++) {
     if (n_img[j] <= 0) continue;
     if (((uintptr_t)src[j] & 15) || ((uintptr_t)dst[j] & 15) || img_pitch[j] % 4) return TACORL_EINVAL;
+    const int T = window ? window[j] : 0;
+    if (T < 0 || (T > 0 && (T < 2 || n_img[j] % T || !dst_first || !dst_last || !dst_first[j] || !dst_last[j] ||
+                            (((uintptr_t)dst_first[j] | (uintptr_t)dst_last[j]) & 15))))
+      return TACORL_EINVAL;
+    t.dupT[m] = T; t.dupA[m] = T ? dst_first[j] : nullptr; t.dupB[m] = T ? dst_last[j] : nullptr;
     t.src[m] = src[j]; t.dst[m] = dst[j]; t.pitch[m] = img_pitch[j]; t.n[m] = n_img[j];
     const long tot = (long)n_img[j] * (H * W / 4);
     mx = tot > mx ? tot : mx;
@@ -866,8 +895,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     __syncthreads();     // every thread has read the counter
     if (threadIdx.x == 0) step_counter[0] = t;
   }
-  const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
-  const float step_size = (float)((double)lr / bc1), rsq_bc2 = (float)sqrt(bc2);
+  __shared__ float bcs[2];  // the bias-correction factors once per block (two double-precision pow() per thread before round 5)
+  if (threadIdx.x == 0) {
+    const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
+    bcs[0] = (float)((double)lr / bc1);
+    bcs[1] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const float step_size = bcs[0], rsq_bc2 = bcs[1];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i] * coef;
     const float mi = m[i] * 0.9f + gi * 0.1f;
@@ -896,14 +931,23 @@ struct AdamTbl {
   long n[ADAM_MAXB];
   float lr[ADAM_MAXB], max_norm[ADAM_MAXB], tau[ADAM_MAXB];
   int blocks[ADAM_MAXB];
+  float* coef;                 // [ADAM_MAXB][2]: step size and sqrt(bias correction 2) of this step, written by the norm launch
   __bf16* mirror[ADAM_MAXB];   // optional bf16 copies of the updated parameters / of the updated Polyak target, same
   __bf16* tmirror[ADAM_MAXB];  // element offsets (the fused MLP kernels' MFMA operand: no conversion launch next step)
 };
 __global__ __launch_bounds__(256) void sqnorm_partial_batch_kernel(AdamTbl t) {
   __shared__ float sh[4];
   const int b = blockIdx.y;
-  // the step counters advance here, one launch ahead of the update that reads them (no bump launch behind it)
-  if (blockIdx.x == 0 && threadIdx.x == 0) t.step[b][0] += 1;
+  // the step counters advance here, one launch ahead of the update that reads them (no bump launch behind it) - and with
+  // them the two bias-correction factors: two double-precision pow() per THREAD of the update launch were most of its
+  // 16 us (round 5); the same double arithmetic, once per block of parameters
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int st = t.step[b][0] + 1;
+    t.step[b][0] = st;
+    const double bc1 = 1.0 - pow(0.9, (double)st), bc2 = 1.0 - pow(0.999, (double)st);
+    t.coef[2 * b] = (float)((double)t.lr[b] / bc1);
+    t.coef[2 * b + 1] = (float)sqrt(bc2);
+  }
   if ((int)blockIdx.x >= t.blocks[b] || !(t.max_norm[b] > 0.f)) return;
   const float* __restrict__ g = t.g[b];
   float s = 0.f;
@@ -922,9 +966,7 @@ __global__ __launch_bounds__(256) void adam_batch_kernel(AdamTbl t) {
     s = block_sum_256(s, sh);
     coef = fminf(t.max_norm[b] / (sqrtf(s) + 1e-6f), 1.0f);
   }
-  const int st = t.step[b][0];  // already advanced by the norm launch
-  const double bc1 = 1.0 - pow(0.9, (double)st), bc2 = 1.0 - pow(0.999, (double)st);
-  const float step_size = (float)((double)t.lr[b] / bc1), rsq_bc2 = (float)sqrt(bc2);
+  const float step_size = t.coef[2 * b], rsq_bc2 = t.coef[2 * b + 1];  // (of the step counter the norm launch advanced)
   float* __restrict__ p = t.p[b];
   const float* __restrict__ g = t.g[b];
   float* __restrict__ m = t.m[b];
@@ -973,7 +1015,7 @@ __global__ __launch_bounds__(256) void adam_batch_kernel(AdamTbl t) {
     if (tmir) tmir[i] = (__bf16)ti;
   }
 }
-extern "C" size_t tacorl_adam_batch_ws_bytes(int nb) { return (size_t)nb * 1024 * sizeof(float); }
+extern "C" size_t tacorl_adam_batch_ws_bytes(int nb) { return ((size_t)nb * 1024 + 2 * ADAM_MAXB) * sizeof(float); }
 extern "C" int tacorl_adam_step_batch(int nb, float* const* param, const float* const* grad, float* const* m,
                                       float* const* v, const long* n, const float* lr, const float* max_norm,
                                       int* const* step_counter, float* const* target, const float* tau, void* ws,
@@ -990,6 +1032,7 @@ extern "C" int tacorl_adam_step_batch_mirror(int nb, float* const* param, const 
   if (nb < 1 || nb > ADAM_MAXB) return TACORL_EINVAL;
   if (ws_bytes < tacorl_adam_batch_ws_bytes(nb)) return TACORL_ENOMEM;
   AdamTbl t{};
+  t.coef = (float*)ws + (long)nb * 1024;
   int maxb = 0;
   bool any_clip = false;
   for (int b = 0; b < nb; b++) {

@@ -246,6 +246,18 @@ class TACORL(CQL_Offline):
                 ops.pack_images_u8_batch(jobs, xd, H, W)  # pitches are in bytes = elements
             elif nchw and (H * W) % 4 == 0:  # one launch for the window frames and the obs / goal / next images
                 import ctypes as C
+                if (c in self.all_modalities and c in e.cams and len(jobs) == 4 and T >= 2
+                        and os.environ.get("TACORL_PACK_DEDUP", "1") == "1"):
+                    # obs = window frame 0 and next = window frame T - 1 (get_rl_batch): written from the one read of the
+                    # window; the goal image stays a job of its own
+                    win, _, goal, _ = jobs
+                    x3, img_b = e.X3[c].data_ptr(), H * W * 3 * e.X3[c].element_size()
+                    js = [win, goal]
+                    call("tacorl_pack_images_window_batch", 2, (C.c_void_p * 2)(*[j[0] for j in js]),
+                         (C.c_long * 2)(*[j[1] for j in js]), (C.c_void_p * 2)(*[j[2] for j in js]),
+                         ops.int_array([j[3] for j in js]), (C.c_void_p * 2)(x3, None), (C.c_void_p * 2)(x3 + 2 * B * img_b, None),
+                         ops.int_array([T, 0]), xd, H, W, ops.stream())
+                    continue
                 call("tacorl_pack_images_batch", len(jobs), (C.c_void_p * len(jobs))(*[j[0] for j in jobs]),
                      (C.c_long * len(jobs))(*[j[1] for j in jobs]), (C.c_void_p * len(jobs))(*[j[2] for j in jobs]),
                      ops.int_array([j[3] for j in jobs]), xd, H, W, ops.stream())
