@@ -28,6 +28,9 @@
 
 namespace {
 
+#ifndef EBW_ROLL_IMG
+#define EBW_ROLL_IMG 0  // 1: conv1 weight gradient with its k-steps as a loop - 210 -> 111 registers at 84 x 84 (it then fits beside a ring-GEMM workgroup) but 24.3 -> 27.7 us and the step +9 us (round 5, same-box A/B)
+#endif
 constexpr int NT = 512;  // 8 waves: 2 per SIMD
 constexpr int NW = NT / 64;
 
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(NT) void ebw_wgrad_tr_kernel(WgArgs a) {
     };
     // (fully unrolled the k-steps hoist their pixel -> address arithmetic: at 7 steps - conv2 of a 128 x 128 camera, 196
     // output pixels - beside 48 staging registers that was 256 registers + 54 spilled ones reloaded per image; round 5)
-    if constexpr (G::KS > 4 && !IMG) {
+    if constexpr (G::KS > 4 && (!IMG || EBW_ROLL_IMG)) {
 #pragma unroll 1
       for (int s = 0; s < G::KS; s++) kstep(s);
     } else {
