@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
-#define EBW_MAXP 4  // problems (networks) per call
+#define EBW_MAXP 8  // problems (networks x cameras of one geometry) per call (round 5: 4 before - two cameras were two launch sequences)
 
 struct EbwProblem {
   const void* img;   // [n][H][W][3] bf16

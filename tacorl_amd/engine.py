@@ -456,13 +456,15 @@ class ACEngine:
             for tag, params, M, dims in self._mlp_bwd_sites():
                 ops.mlp_bwd_fused_pack(params, M, dims, "mlp_bwdf_" + tag, self.dev)
             nets = [self.actor, self.q1, self.q2]
-            for c in self.cams:
+            for cs in self._ebw_sequences():
+                c = cs[0]
                 if self._fused_bwd_ok(c):
                     H, W = self.hw[c]
-                    n3 = ops.int_array([2 * self.B] * 3)
-                    nb = ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(3, n3, H, W)
-                    ws = ops.workspace(nb, self.dev, "enc_bwd_fused_" + c)
-                    call("tacorl_encoder_bwd_fused_pack", 3, ops.ptr_array([x.enc(c) for x in nets]), n3, H, W, ptr(ws),
+                    np_ = 3 * len(cs)
+                    n3 = ops.int_array([2 * self.B] * np_)
+                    nb = ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(np_, n3, H, W)
+                    ws = ops.workspace(nb, self.dev, "enc_bwd_fused_" + "+".join(cs))
+                    call("tacorl_encoder_bwd_fused_pack", np_, ops.ptr_array([x.enc(cc) for cc in cs for x in nets]), n3, H, W, ptr(ws),
                          ws.numel(), ops.stream())
         self._prepacked = True
 
@@ -750,6 +752,21 @@ class ACEngine:
                            [self.actor.head(self.actor.grad)], [self.dS["a"]], self.lds, [B], self.actor.head_dims,
                            self.actor.head_acts)
 
+    def _ebw_sequences(self):
+        """Camera groups that share one conv-backward launch sequence: the cameras of one (fused-backward) geometry, at
+        most 8 problems (3 networks per camera); everything else one camera at a time."""
+        groups = {}
+        for c in self.cams:
+            groups.setdefault((tuple(self.hw[c]), bool(self._fused_bwd_ok(c))), []).append(c)
+        merge = os.environ.get("TACORL_EBW_MERGE_CAMS", "1") == "1"
+        seqs = []
+        for (_, ok), cs in groups.items():
+            if ok and merge and 3 * len(cs) <= 8:
+                seqs.append(cs)
+            else:
+                seqs += [[c] for c in cs]
+        return seqs
+
     def _encoders_backward(self):
         """Goal encoders (3 nets, one batch), then the three encoders (actor(obs, goal), q1, q2)."""
         B = self.B
@@ -765,48 +782,30 @@ class ACEngine:
                 for k in ks:
                     ops.copy_cols(self.dS[k], 32 * j, self.lds, self.enc_dout[(ek[k], c)], 0, 32, B, 32)
                     ops.copy_cols(self.dgin[k], 32 * j, self.G, self.enc_dout[(ek[k], c)], B * 32, 32, B, 32)
-        for j, c in enumerate(self.cams):
+        # cameras of one geometry share a launch sequence (round 5; C4: both cameras 128 x 128 -> one 6-problem sequence
+        # instead of two 3-problem ones - the conv-backward launches cost ~6-10 us each before their first image)
+        for cs in self._ebw_sequences():
+            c = cs[0]
             H, W = self.hw[c]
-            imgs = [self._img_ptr(c, 0)] * 3
-            ops_n = [2 * B] * 3
-            pa = [ops.ptr_array(imgs), ops.ptr_array([nets[k].enc(c) for k in ks]),
-                  ops.ptr_array([self.enc_act[(ek[k], c)] for k in ks]),
-                  ops.ptr_array([self.enc_dout[(ek[k], c)] for k in ks]),
-                  ops.ptr_array([nets[k].enc(c, nets[k].grad) for k in ks]), ops.int_array(ops_n), H, W]
+            imgs = [self._img_ptr(cc, 0) for cc in cs for _ in ks]
+            ops_n = [2 * B] * (3 * len(cs))
+            pa = [ops.ptr_array(imgs), ops.ptr_array([nets[k].enc(cc) for cc in cs for k in ks]),
+                  ops.ptr_array([self.enc_act[(ek[k], cc)] for cc in cs for k in ks]),
+                  ops.ptr_array([self.enc_dout[(ek[k], cc)] for cc in cs for k in ks]),
+                  ops.ptr_array([nets[k].enc(cc, nets[k].grad) for cc in cs for k in ks]), ops.int_array(ops_n), H, W]
+            np_ = 3 * len(cs)
             if self._fused_bwd_ok(c):  # per-image LDS-resident conv backward (encoder_bwd_fused.hip)
-                nb = ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(3, ops.int_array(ops_n), H, W)
-                ws = ops.workspace(nb, self.dev, "enc_bwd_fused_" + c)
+                nb = ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(np_, ops.int_array(ops_n), H, W)
+                ws = ops.workspace(nb, self.dev, "enc_bwd_fused_" + "+".join(cs))
                 pk = int(getattr(self, "_prepacked", False))
                 img_p, par_p, act_p, dout_p, grad_p, n_p = pa[:6]
                 # dependent chain: FC-tail input gradients (one launch) -> soft-argmax + conv backward
-                call("tacorl_encoder_bwd_fused_head", 3, par_p, act_p, dout_p, n_p, H, W, pk, ptr(ws), ws.numel(), ops.stream())
-                if pk and self.conv_wgrad_side_stream:
-                    # conv backward on two streams (two graph branches): the chain dgrad3 -> dgrad2 -> wgrad1 on this one,
-                    # the weight gradients of conv3 / conv2 - which nothing on the chain reads - beside it
-                    conv = lambda parts: call("tacorl_encoder_bwd_fused_conv_parts", 3, img_p, par_p, act_p, grad_p, n_p, H, W, 0,  # noqa: E731
-                                              1, parts, ptr(ws), ws.numel(), ops.stream())
-                    if getattr(self, "_cw_stream", None) is None:
-                        self._cw_stream = torch.cuda.Stream(device=self.dev)
-                    main, side = torch.cuda.current_stream(), self._cw_stream
-                    conv(1)                      # soft-argmax backward: dz3
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        conv(4)                  # wgrad3 (dz3, y2)
-                    conv(2)                      # dgrad3 -> dz2
-                    e1 = torch.cuda.Event()
-                    e1.record(main)
-                    with torch.cuda.stream(side):
-                        side.wait_event(e1)
-                        conv(16)                 # wgrad2 (dz2, y1)
-                    conv(8 | 32)                 # dgrad2 -> dz1, wgrad1 (dz1, image)
-                    main.wait_stream(side)
-                    conv(64)                     # slabs -> gradients
-                else:
-                    call("tacorl_encoder_bwd_fused_conv", 3, img_p, par_p, act_p, grad_p, n_p, H, W, 0, pk, ptr(ws), ws.numel(),
-                         ops.stream())
+                call("tacorl_encoder_bwd_fused_head", np_, par_p, act_p, dout_p, n_p, H, W, pk, ptr(ws), ws.numel(), ops.stream())
+                call("tacorl_encoder_bwd_fused_conv", np_, img_p, par_p, act_p, grad_p, n_p, H, W, 0, pk, ptr(ws), ws.numel(),
+                     ops.stream())
                 # FC weight gradients last and in line: on a side branch they ran beside the conv-backward
                 # kernels, whose 255 one-per-CU workgroups then no longer fit in one round (+0.13 ms/step)
-                call("tacorl_encoder_bwd_fused_fc_wgrad", 3, act_p, dout_p, grad_p, n_p, H, W, 0, ptr(ws), ws.numel(),
+                call("tacorl_encoder_bwd_fused_fc_wgrad", np_, act_p, dout_p, grad_p, n_p, H, W, 0, ptr(ws), ws.numel(),
                      ops.stream())
                 continue
             nb = ops.L.lib().tacorl_encoder_bwd_ws_bytes(3, ops.int_array(ops_n), H, W)
