@@ -349,6 +349,47 @@ class ACEngine:
         pr += [(x["img"], x["net"], x["out"], x["act"], x["n"], False) for x in self.extra_enc if x["cam"] == c]
         return pr
 
+    # Packed conv weights of the fused encoder forward (bf16 MFMA fragments in the kernel's register order).  Round 5: the
+    # pack launch of the networks the optimiser moves runs BEHIND the Adam launch, at the end of the step - in the shadow of
+    # the action-decoder branch, which ends later - instead of in front of the encoder forward at the head of the next
+    # step's chain; a packed copy counts as current while the block's torch version counter is the one recorded when it was
+    # packed (see mirrors_stale), so frozen networks (TACORL's LMP encoder) are packed once, not every step.
+    # TACORL_EF_PACK_LATE=0: every network in front of every forward, as before.
+    ef_pack_late = os.environ.get("TACORL_EF_PACK_LATE", "1") == "1"
+
+    def _pack_encoders(self, c, nets, only_stale=False):
+        vers = self.__dict__.setdefault("_wpk_ver", {})
+        if only_stale:
+            nets = [n_ for n_ in nets if vers.get((id(n_), c)) != n_.param._version]
+        if not nets:
+            return
+        call("tacorl_encoder_pack_weights", len(nets), ops.ptr_array([n_.enc(c) for n_ in nets]),
+             ops.ptr_array([self._packed(n_, c) for n_ in nets]), ops.stream())
+        for n_ in nets:
+            vers[(id(n_), c)] = n_.param._version
+
+    def _late_pack_nets(self):
+        return [self.actor, self.q1, self.q2, self.tq1, self.tq2]
+
+    def packs_stale(self):
+        """Would a replayed step read a packed copy that no longer matches its parameter block?  (Every network of the
+        step's encoder launch: the optimiser's ones AND the extra, frozen ones.)"""
+        if not self.ef_pack_late or not getattr(self, "_wpk_ver", None):
+            return False
+        nets = {id(n_): n_ for n_ in self._late_pack_nets()}
+        nets.update({id(x["net"]): x["net"] for x in self.extra_enc})
+        return any(self._wpk_ver.get((i, c), n_.param._version) != n_.param._version
+                   for i, n_ in nets.items() for c in self.cams if (i, c) in self._wpk_ver)
+
+    def packs_written(self):
+        """The step's tail launch (eager, or the replayed graph's) has just re-packed the optimiser's networks: record it."""
+        vers = getattr(self, "_wpk_ver", None)
+        if self.ef_pack_late and vers:
+            for n_ in self._late_pack_nets():
+                for c in self.cams:
+                    if (id(n_), c) in vers:
+                        vers[(id(n_), c)] = n_.param._version
+
     def _launch_fused(self, c, pr):
         H, W = self.hw[c]
         call("tacorl_encoder_fwd_fused", len(pr), ops.ptr_array([x[0] for x in pr]),
@@ -378,8 +419,7 @@ class ACEngine:
                 slow = [] if self._fused_bwd_ok(c) else [x for x in pr if x[5]]
                 pr = [x for x in pr if not (slow and x[5])]
                 nets = {id(x[1]): x[1] for x in pr}
-                call("tacorl_encoder_pack_weights", len(nets), ops.ptr_array([n_.enc(c) for n_ in nets.values()]),
-                     ops.ptr_array([self._packed(n_, c) for n_ in nets.values()]), ops.stream())
+                self._pack_encoders(c, list(nets.values()), only_stale=self.ef_pack_late)
                 self._launch_fused(c, pr)
                 pr = slow
             if pr:
@@ -832,6 +872,10 @@ class ACEngine:
             ops.adam_step_batch(items, mirrors=mir if write else None)  # two launches for all blocks
             if write:  # (this launch rewrote every mirror from the updated parameters, whatever state they were in)
                 self.mirrors_written()
+            if self.ef_pack_late:
+                for c in self.cams:
+                    if self._fused_ok(c):
+                        self._pack_encoders(c, self._late_pack_nets())
         ops.mark("c:adam")
 
     def _allreduce(self, tensors):

@@ -157,11 +157,13 @@ class CQL_Offline(GraphMixin, ModuleMixin, LightningModuleBase):
     def _derived_stale(self):
         """GraphMixin asks before every replay: are the engine's Adam-written bf16 mirrors still those of the parameters?"""
         e = self.engine
-        return e.adam_writes_mirrors and e.mirrors_stale()
+        return (e.adam_writes_mirrors and e.mirrors_stale()) or e.packs_stale()
 
     def _after_replay_touch(self):
-        """A replay has just run (its optimiser launch rewrote the mirrors) and the version counters were bumped for it."""
+        """A replay has just run (its optimiser launch rewrote the mirrors, its tail re-packed the encoders' conv weights)
+        and the version counters were bumped for it."""
         self.engine.mirrors_written()
+        self.engine.packs_written()
 
     def named_gradients(self):
         e = self.engine
