@@ -55,8 +55,9 @@ def relerr(a, b):
 
 
 def compare_with_oracle_grads(mod, oracle_grads, rtol, floor=None):
-    """floor: {name: reproducibility of that gradient} (golden_util.gradient_floor) - the tolerance of a tensor is
-    max(rtol, 3 * floor)."""
+    """floor: {name: reproducibility of that gradient} (golden_util.gradient_floor).  A tensor is held to rtol; only one that
+    misses rtol is held to - and recorded with - the widened max(rtol, 3 * floor), so the margin report counts the
+    widenings the measured errors needed, not the ones the floor would have allowed."""
     bad = []
     got = mod.named_gradients()
     # A soft-argmax temperature gradient is ONE scalar: a signed sum over images x 64 channels x pixels whose absolute
@@ -65,15 +66,17 @@ def compare_with_oracle_grads(mod, oracle_grads, rtol, floor=None):
     t_scale = max([v.abs().max().item() for k, v in oracle_grads.items() if k.endswith(".temperature") and v is not None] or [0.0])
     for k, v in oracle_grads.items():
         if k in got:
-            tol = max(rtol, 3.0 * (floor or {}).get(k, 0.0))
+            wide = max(rtol, 3.0 * (floor or {}).get(k, 0.0))
             if k.endswith(".temperature"):
                 d = (got[k].reshape(v.shape).detach().cpu().double() - v.detach().double()).abs().max().item()
+                tol = rtol if d <= rtol * max(v.abs().max().item(), t_scale) else wide
                 if floor is not None:
                     record_margin(k, d / max(v.abs().max().item(), t_scale, 1e-30), tol, floor.get(k))
                 if d > tol * max(v.abs().max().item(), t_scale):
                     bad.append(f"grad {k}: {got[k].item():.6g} vs {v.item():.6g} (tolerance {tol:.3g} of {t_scale:.3g})")
                 continue
             e = relerr(got[k].reshape(v.shape), v)
+            tol = rtol if e <= rtol else wide
             if floor is not None and v.norm() > 1e-12:
                 record_margin(k, e, tol, floor.get(k))
             if e > tol and v.norm() > 1e-12:
