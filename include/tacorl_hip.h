@@ -275,6 +275,20 @@ int tacorl_mlp_bwd_fused_dgrad(int nprob, const float* const* params, const floa
  * another stream, then pass prepacked = 1 to _dgrad). */
 int tacorl_mlp_bwd_fused_pack(int nprob, const float* const* params, const int* M, int n_layers,
                               const int* dims, void* ws, size_t ws_bytes, tacorl_stream_t stream);
+/* Weight-only preparation of a step as ONE launch.  Between _begin() and _end(stream) - same host thread - the entry
+ * points whose launches read nothing but parameters (tacorl_to_bf16_batch, tacorl_mlp_bwd_fused_pack and the FC-tail
+ * transposes of tacorl_encoder_bwd_fused_pack) only record their jobs; _end issues them together on `stream`, which must
+ * be the stream those calls were given.  Replaces, in the reference's terms, nothing: torch.nn.Linear's backward
+ * (networks/actors/actor.py:28-60, critics/critic.py:92-97 via autograd) has no such step - the transposed bf16 copies
+ * are this implementation's MFMA operands.  _begin inside an open batch and _end without one return TACORL_EINVAL. */
+int tacorl_prep_batch_begin(void);
+/* The same for the slab reduces that finish the one-launch MLP weight gradients (tacorl_mlp_bwd_fused_wgrad,
+ * tacorl_encoder_bwd_fused_fc_wgrad): between tacorl_reduce_batch_begin() and _end(stream) they are recorded, and _end
+ * sums every site's slabs in one launch - the gradients are complete only after _end.  Their only readers are the
+ * gradient all-reduce and the optimiser (reference cql_offline_lightning.py:519-542: the three optimizer.step() calls). */
+int tacorl_reduce_batch_begin(void);
+int tacorl_reduce_batch_end(tacorl_stream_t stream);
+int tacorl_prep_batch_end(tacorl_stream_t stream);
 int tacorl_mlp_bwd_fused_wgrad(int nprob, const float* const* x, int ldx, const float* const* act,
                                const float* const* d_out, int ldo, float* const* grads, const int* M,
                                int n_layers, const int* dims, const int* acts, int accumulate, int lean,

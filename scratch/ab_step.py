@@ -17,6 +17,9 @@ def setv(path, v):
         mod._graphs = {}
         return
     o = mod
+    if path.startswith("ops:"):  # a switch of tacorl_amd.ops, e.g. ops:prep_batch.enabled
+        from tacorl_amd import ops as o
+        path = path[4:]
     *head, last = path.split(".")
     for h in head: o = getattr(o, h)
     setattr(o, last, v)

@@ -56,6 +56,10 @@ _SIGS = {
     "tacorl_mlp_bwd_fused_ws_bytes": (_sz, [_i, _p, _i, _p]),
     "tacorl_mlp_bwd_fused_dgrad": (_i, [_i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _sz, _p]),
     "tacorl_mlp_bwd_fused_pack": (_i, [_i, _p, _p, _i, _p, _p, _sz, _p]),
+    "tacorl_prep_batch_begin": (_i, []),
+    "tacorl_reduce_batch_begin": (_i, []),
+    "tacorl_reduce_batch_end": (_i, [_p]),
+    "tacorl_prep_batch_end": (_i, [_p]),
     "tacorl_mlp_bwd_fused_wgrad": (_i, [_i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _p, _sz, _p]),
     "tacorl_mlp_fwd_fused_supported": (_i, [_i, _i, _p, _i]),
     "tacorl_mlp_lean_supported": (_i, [_i, _i, _p, _i, _i, _i]),

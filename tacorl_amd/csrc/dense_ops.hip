@@ -1128,6 +1128,11 @@ extern "C" int tacorl_to_bf16_batch(int n, const float* const* src, void* const*
     mx = t.n4[i] > mx ? t.n4[i] : mx;
   }
   if (mx == 0) return TACORL_OK;
+  if (prep_deferring()) {  // part of the step's one weight-preparation launch (tacorl_prep_batch_end)
+    for (int i = 0; i < n; i++)
+      if (t.n4[i]) { const int rc = prep_defer_bf16(t.src[i], t.dst[i], 4 * t.n4[i], (hipStream_t)stream); if (rc != TACORL_OK) return rc; }
+    return TACORL_OK;
+  }
   hipLaunchKernelGGL(to_bf16_batch_kernel, dim3((unsigned)(cdiv(mx, 256) > 1024 ? 1024 : cdiv(mx, 256)), n), dim3(256), 0,
                      (hipStream_t)stream, t);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;

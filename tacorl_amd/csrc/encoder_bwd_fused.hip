@@ -421,6 +421,30 @@ __global__ __launch_bounds__(256) void ebw_pack_kernel(PkArgs a) {
   a.out[blockIdx.y][idx] = make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// both dgrads' fragments in one launch (they were two 3 - 6 us launches on the step's chain): blocks [0, B2) pack L2's
+template <class LA, class LB>
+__global__ __launch_bounds__(256) void ebw_pack2_kernel(PkArgs a, PkArgs b) {
+  constexpr int BA = (LA::NCOMBO * LA::KS * 64 + 255) / 256;
+  const bool first = (int)blockIdx.x < BA;
+  const int idx = (first ? blockIdx.x : blockIdx.x - BA) * 256 + threadIdx.x;
+  auto body = [&](auto tag, const PkArgs& k) {
+    using L = decltype(tag);
+    if (idx >= L::NCOMBO * L::KS * 64) return;
+    const int lane = idx & 63, ks = (idx >> 6) % L::KS, combo = (idx >> 6) / L::KS;
+    const int cls = combo / L::NTI, nt = combo % L::NTI, py = cls / L::S, px = cls % L::S;
+    const int tp = ks / (L::CO / 32), hf = ks % (L::CO / 32), ta = tp / L::KB, tb = tp % L::KB;
+    const int ky = py + L::S * ta, kx = px + L::S * tb, ci = 16 * nt + (lane & 15), co0 = 32 * hf + 8 * (lane >> 4);
+    const float* w = k.w[blockIdx.y];
+    uint32_t v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      v[e] = pack2(w[(((co0 + 2 * e) * L::KH + ky) * L::KW + kx) * L::CI + ci],
+                   w[(((co0 + 2 * e + 1) * L::KH + ky) * L::KW + kx) * L::CI + ci]);
+    k.out[blockIdx.y][idx] = make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  if (first) body(LA{}, a); else body(LB{}, b);
+}
+
 template <class L>
 constexpr int dgrad_mask_bytes() { return (L::IH * L::IW * L::CI / 8 + 15) / 16 * 16; }
 template <class L>
@@ -986,8 +1010,8 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
     k3.w[p] = pr[p].w3; k3.out[p] = (uint4*)(base + w.wpk3[p]);
   }
   if (mode != 2) {
-    hipLaunchKernelGGL(ebw_pack_kernel<L2>, dim3(cdivi(L2::NCOMBO * L2::KS * 64, 256), nprob), dim3(256), 0, st, k2);
-    hipLaunchKernelGGL(ebw_pack_kernel<L3>, dim3(cdivi(L3::NCOMBO * L3::KS * 64, 256), nprob), dim3(256), 0, st, k3);
+    hipLaunchKernelGGL((ebw_pack2_kernel<L2, L3>), dim3(cdivi(L2::NCOMBO * L2::KS * 64, 256) + cdivi(L3::NCOMBO * L3::KS * 64, 256), nprob),
+                       dim3(256), 0, st, k2, k3);
   }
   if (mode == 1) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
   DgArgs d3{}, d2{};

@@ -38,6 +38,10 @@ size_t mlp_fused_wt_elems(int L, const int* dims, long* wtoff);
 int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act, const float* const* d_out, int ldo,
                   float* const* dz, float* const* d_x, int ldd, void* const* wt, const int* M, int L, const int* dims,
                   const int* acts, const long* srcoff, const long* dzoff, const long* woff, hipStream_t st, int mode);
+// Deferred weight-only preparation (tacorl_prep_batch_begin / _end, mlp_fused.hip): while deferring, mlp_fused_bwd(mode 1)
+// and tacorl_to_bf16_batch record their jobs instead of launching them.
+bool prep_deferring();
+int prep_defer_bf16(const float* src, void* dst, long count, hipStream_t st);
 // mode: 0 = transpose the weights, then run the chain; 1 = transpose only (d_out / act / dz unused);
 //       2 = chain only (wt already holds this step's transposed weights)
 

@@ -291,6 +291,49 @@ __global__ __launch_bounds__(256) void mlp_pack_wt_kernel(WtPackArgs a) {
   }
 }
 
+// ---- weight-only preparation of a step in ONE launch (round 5).  The headline step issued eight 5 - 7 us launches that read
+// nothing but parameters - the bf16 mirrors of the five networks' MLP weights (tacorl_to_bf16_batch), the transposed
+// weights of four MLP backward sites and of the encoders' FC tail (mlp_pack_wt_kernel, one launch per site) - back to back
+// on the step's dependent chain: each a launch latency plus one L2 round trip for a few hundred KB.  Between
+// tacorl_prep_batch_begin() and tacorl_prep_batch_end(stream) those entry points only RECORD their job (this thread's
+// list); _end issues them as one launch (blockIdx.z = job: a (site, network) transpose or a conversion).
+#define PREP_MAXS 6   // transpose sites per launch
+#define PREP_MAXB 16  // conversion jobs per launch
+struct PrepMultiArgs {
+  WtPackArgs site[PREP_MAXS];
+  int first[PREP_MAXS + 1];  // jobs [first[s], first[s + 1]) are the networks of site s; conversions follow
+  int nsite, ncv;
+  const float* csrc[PREP_MAXB];
+  __bf16* cdst[PREP_MAXB];
+  long cn4[PREP_MAXB];
+};
+__global__ __launch_bounds__(256) void prep_multi_kernel(PrepMultiArgs a) {
+  const int z = blockIdx.z, nt = a.first[a.nsite];
+  if (z >= nt) {  // fp32 -> bf16 copy: the (x, y) blocks of the job stride over it
+    const int j = z - nt;
+    const float* __restrict__ src = a.csrc[j];
+    __bf16* __restrict__ dst = a.cdst[j];
+    const long n4 = a.cn4[j], step = (long)gridDim.x * gridDim.y * 256;
+    for (long q = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; q < n4; q += step) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(src)[q];
+      reinterpret_cast<bf16x4*>(dst)[q] = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+    return;
+  }
+  int s = 0;
+#pragma unroll
+  for (int t = 1; t < PREP_MAXS; t++) s = (t < a.nsite && z >= a.first[t]) ? t : s;
+  const WtPackArgs& k = a.site[s];
+  const int l = blockIdx.y, pp = z - a.first[s];
+  if (l >= k.L) return;
+  const int K = k.dims[l], N = k.dims[l + 1], NP = (N + 7) / 8 * 8;
+  const float* __restrict__ W = k.params[pp] + k.woff[l];
+  __bf16* __restrict__ T = k.wt[pp] + k.wtoff[l];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < K * NP; e += gridDim.x * 256) {
+    const int kin = e / NP, n = e - kin * NP;
+    T[e] = (__bf16)(n < N ? W[(long)n * K + kin] : 0.f);
+  }
+}
 // (rows per workgroup as in the forward: 32, or 64 for >= 16 k rows - 128 would need 128 accumulator + source registers)
 template <int BMF_>
 __device__ __forceinline__ void mlp_fused_bwd_body(const MlpBwdArgs& a) {
@@ -592,6 +635,57 @@ __global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(MlpWgReduceArgs a
   }
 }
 
+// Several sites' reduces as ONE launch (round 5: the headline step's five reduce launches - Q hidden layers, Q output
+// layer, policy head, goal encoders, encoder FC tails; 5 - 8 us each, their only reader is the optimiser - are recorded
+// between tacorl_reduce_batch_begin() and _end(stream) and leave together; host side below the kernels).
+#define RED_MAXJ 8
+struct MlpWgReduceMulti {
+  MlpWgReduceArgs job[RED_MAXJ];
+  int gx[RED_MAXJ], L[RED_MAXJ], first[RED_MAXJ + 1];  // blocks along x / layers / first blockIdx.z of job j
+  int njob;
+};
+__global__ __launch_bounds__(256) void mlp_wgrad_reduce_multi_kernel(MlpWgReduceMulti m) {
+  int j = 0;
+#pragma unroll
+  for (int t = 1; t < RED_MAXJ; t++) j = (t < m.njob && (int)blockIdx.z >= m.first[t]) ? t : j;
+  const int gx = m.gx[j];
+  if ((int)blockIdx.y >= m.L[j] || (int)blockIdx.x >= gx) return;
+  const MlpWgReduceArgs& a = m.job[j];
+  const int l = blockIdx.y, p = blockIdx.z - m.first[j], K = a.dims[l], N = a.dims[l + 1], ns = a.nslice[p];
+  const long nw = (long)N * K, tot = nw + N;
+  const float* __restrict__ s0 = a.slab[p] + a.sloff[l];
+  float* __restrict__ gr = a.grad[p];
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gx * 256) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < ns; s++) t += s0[(long)s * a.rec + e];  // slice order, as mlp_wgrad_reduce_kernel
+    float* d = gr + (e < nw ? a.woff[l] + e : a.boff[l] + (e - nw));
+    *d = a.accumulate ? *d + t : t;
+  }
+}
+struct RedState { bool on = false; MlpWgReduceMulti m{}; };
+thread_local RedState g_red;
+int red_flush(hipStream_t st) {
+  MlpWgReduceMulti& m = g_red.m;
+  if (m.njob == 0) return 0;
+  int gx = 1, Ly = 1;
+  for (int j = 0; j < m.njob; j++) { gx = m.gx[j] > gx ? m.gx[j] : gx; Ly = m.L[j] > Ly ? m.L[j] : Ly; }
+  hipLaunchKernelGGL(mlp_wgrad_reduce_multi_kernel, dim3(gx, Ly, m.first[m.njob]), dim3(256), 0, st, m);
+  m.njob = 0; m.first[0] = 0;
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// the reduce of one site: launched, or recorded while a batch is open
+int launch_reduce(const MlpWgReduceArgs& r, int gx, int Ly, int nprob, hipStream_t st) {
+  if (!g_red.on) {
+    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(gx, Ly, nprob), dim3(256), 0, st, r);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
+  MlpWgReduceMulti& m = g_red.m;
+  if (m.njob == RED_MAXJ && red_flush(st)) return -1;
+  m.job[m.njob] = r; m.gx[m.njob] = gx; m.L[m.njob] = Ly; m.first[m.njob + 1] = m.first[m.njob] + nprob;
+  m.njob++;
+  return 0;
+}
 
 // ------------------------------------------------------------------ forward / input gradients, tens of thousands of rows
 // C5's Q networks: 99 328 rows each.  With the kernels above (128 / 64 rows per workgroup) the forward wrote every hidden
@@ -1194,6 +1288,65 @@ __global__ __launch_bounds__(256) void mlp_wgrad_out_kernel(MlpWgOutArgs a) {
 
 }  // namespace
 
+// ---- deferred weight-only preparation: host side (kernel: prep_multi_kernel above)
+namespace {
+struct PrepState {
+  bool on = false;
+  PrepMultiArgs a{};
+  int nprob[PREP_MAXS] = {};
+};
+thread_local PrepState g_prep;
+int prep_flush(hipStream_t st) {
+  PrepMultiArgs& a = g_prep.a;
+  if (a.nsite == 0 && a.ncv == 0) return TACORL_OK;
+  int maxL = 1;
+  for (int s = 0; s < a.nsite; s++) maxL = a.site[s].L > maxL ? a.site[s].L : maxL;
+  hipLaunchKernelGGL(prep_multi_kernel, dim3(64, maxL, a.first[a.nsite] + a.ncv), dim3(256), 0, st, a);
+  a.nsite = 0; a.ncv = 0; a.first[0] = 0;
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+}  // namespace
+bool prep_deferring() { return g_prep.on; }
+// (stream: where a full list is flushed to - the same stream _end will be given)
+int prep_defer_wtpack(const WtPackArgs& k, int nprob, hipStream_t st) {
+  PrepMultiArgs& a = g_prep.a;
+  if (a.nsite == PREP_MAXS) { const int rc = prep_flush(st); if (rc != TACORL_OK) return rc; }
+  a.site[a.nsite] = k;
+  a.first[a.nsite + 1] = a.first[a.nsite] + nprob;
+  a.nsite++;
+  return TACORL_OK;
+}
+int prep_defer_bf16(const float* src, void* dst, long count, hipStream_t st) {
+  PrepMultiArgs& a = g_prep.a;
+  if (a.ncv == PREP_MAXB) { const int rc = prep_flush(st); if (rc != TACORL_OK) return rc; }
+  a.csrc[a.ncv] = src; a.cdst[a.ncv] = (__bf16*)dst; a.cn4[a.ncv] = count / 4;
+  a.ncv++;
+  return TACORL_OK;
+}
+extern "C" int tacorl_reduce_batch_begin(void) {
+  if (g_red.on) return TACORL_EINVAL;
+  g_red.on = true;
+  g_red.m.njob = 0; g_red.m.first[0] = 0;
+  return TACORL_OK;
+}
+extern "C" int tacorl_reduce_batch_end(void* stream) {
+  if (!g_red.on) return TACORL_EINVAL;
+  g_red.on = false;
+  return red_flush((hipStream_t)stream) ? TACORL_ELAUNCH : TACORL_OK;
+}
+extern "C" int tacorl_prep_batch_begin(void) {
+  if (g_prep.on) return TACORL_EINVAL;
+  g_prep.on = true;
+  g_prep.a.nsite = 0; g_prep.a.ncv = 0; g_prep.a.first[0] = 0;
+  return TACORL_OK;
+}
+extern "C" int tacorl_prep_batch_end(void* stream) {
+  if (!g_prep.on) return TACORL_EINVAL;
+  g_prep.on = false;
+  return prep_flush((hipStream_t)stream);
+}
+
+
 bool mlp_fused_wgrad_ok(int nprob, int L, const int* dims) {
   if (nprob < 1 || nprob > MF_MAXP || L < 1 || L > MF_MAXL) return false;
   for (int l = 0; l <= L; l++)
@@ -1257,7 +1410,7 @@ int mlp_fused_wgrad(int nprob, const float* const* x, int ldx, const float* cons
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_OPB) == hipSuccess ? 0 : -1;
   if (once) return -1;
   hipLaunchKernelGGL(mlp_wgrad_fused_kernel, dim3(maxs, L, n2), dim3(512), 4 * WG_OPB, st, a);
-  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(256, L, n2), dim3(256), 0, st, r);
+  if (launch_reduce(r, 256, L, n2, st)) return -1;
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1457,8 +1610,7 @@ int mlp_fused_wgrad_big(int nprob, const float* const* x, int ldx, const float* 
   hipLaunchKernelGGL(mlp_x_to_bf16_kernel, dim3(xblocks > 4096 ? 4096 : xblocks, n2), dim3(256), 0, st, xa);
   hipLaunchKernelGGL(mlp_wgrad_big_kernel, dim3(maxs, a.tile0[L - 1], n2), dim3(64 * BG_NW), lds, st, a);
   hipLaunchKernelGGL(mlp_wgrad_out_kernel, dim3(maxso, n2), dim3(256), 0, st, oa);
-  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(256, L - 1, n2), dim3(256), 0, st, r);
-  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(8, 1, n2), dim3(256), 0, st, ro);
+  if (launch_reduce(r, 256, L - 1, n2, st) || launch_reduce(ro, 8, 1, n2, st)) return -1;
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1497,6 +1649,7 @@ int mlp_fused_bwd(int nprob, const float* const* params, const float* const* act
   for (int l = 0; l <= L; l++) { a.dims[l] = dims[l]; k.dims[l] = dims[l]; }
   a.L = L; k.L = L; a.ldo = ldo; a.ldd = ldd;
   if (maxM == 0) return TACORL_OK;
+  if (mode == 1 && prep_deferring()) return prep_defer_wtpack(k, nprob, st);  // (tacorl_prep_batch_begin .. _end: one launch for all)
   if (mode != 2) hipLaunchKernelGGL(mlp_pack_wt_kernel, dim3(64, L, nprob), dim3(256), 0, st, k);
   if (mode == 1) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
   constexpr size_t lds = (size_t)2 * BMF * XP * 2, lds_big = (size_t)2 * 64 * XP * 2;

@@ -59,10 +59,19 @@ __global__ __launch_bounds__(64 * NW) void rnn_gemm_kernel(RnnBatch ab, int MT, 
   // L2-resident from one recurrent step's launch to the next instead of being re-fetched from the Infinity
   // Cache by every XCD.  Inside an XCD the M tiles of one N tile are adjacent (they share the weight rows).
   // Placement is a speed matter only: any block -> XCD assignment computes the same result.
-  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-  const int mt = jx % MT, rx = jx / MT, ntile = xcd * NTX + rx % NTX;
-  if (ntile >= NT) return;
-  const RnnArgs a = ab.p[rx / NTX];  // by value: keeps the fields in SGPRs (a reference re-loads them in the K loop)
+  // NTX == 0: plain map for FEW N tiles (the output heads: 192 columns = 3 - 6 tiles; the XCD map would leave the XCDs
+  // beyond the tile count idle and put every workgroup on the others): block -> (m tile fastest, n tile, problem), so the
+  // M tiles spread over all XCDs and each XCD reads the whole (small) weight matrix.
+  int mt, ntile, prob;
+  if (NTX == 0) {
+    const int jx = blockIdx.x;
+    mt = jx % MT; ntile = (jx / MT) % NT; prob = jx / (MT * NT);
+  } else {
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, rx = jx / MT;
+    mt = jx % MT; ntile = xcd * NTX + rx % NTX; prob = rx / NTX;
+    if (ntile >= NT) return;
+  }
+  const RnnArgs a = ab.p[prob];  // by value: keeps the fields in SGPRs (a reference re-loads them in the K loop)
   constexpr int STAGE_BYTES = (RB_M + RB_N) * ROW_BYTES;
   constexpr int DMA_PER_WAVE = (RB_M + RB_N) / 4 / NW;  // wave-instructions per stage and wave (4 rows each)
   constexpr int MI = RB_M / (16 * NW), NI = RB_N / 16;  // 16x16 tiles per wave (NW waves stacked along M)
@@ -153,22 +162,22 @@ __global__ __launch_bounds__(64 * NW) void rnn_gemm_kernel(RnnBatch ab, int MT, 
 
 // all problems of a batch share (M, K, N)
 template <int RB_M, int RB_N, int RB_S, int NW = 4>
-int launch_ring(const RnnBatch& ab, int nprob, hipStream_t st) {
+int launch_ring(const RnnBatch& ab, int nprob, hipStream_t st, bool plain_map = false) {
   constexpr int lds = RB_S * (RB_M + RB_N) * ROW_BYTES;
   auto kern = rnn_gemm_kernel<RB_M, RB_N, RB_S, NW>;
   static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) ==
                             hipSuccess ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
   const RnnArgs& a = ab.p[0];
-  const int MT = (a.M + a.M2 + RB_M - 1) / RB_M, NT = a.N / RB_N, NTX = (NT + 7) / 8;
-  hipLaunchKernelGGL(kern, dim3(8 * MT * NTX * nprob), dim3(64 * NW), lds, st, ab, MT, NT, NTX);
+  const int MT = (a.M + a.M2 + RB_M - 1) / RB_M, NT = a.N / RB_N, NTX = plain_map ? 0 : (NT + 7) / 8;
+  hipLaunchKernelGGL(kern, dim3(plain_map ? MT * NT * nprob : 8 * MT * NTX * nprob), dim3(64 * NW), lds, st, ab, MT, NT, NTX);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 template <int RB_M, int RB_N, int RB_S>
-int launch_ring(const RnnArgs& a, hipStream_t st) {
+int launch_ring(const RnnArgs& a, hipStream_t st, bool plain_map = false) {
   RnnBatch ab{};
   ab.p[0] = a;
-  return launch_ring<RB_M, RB_N, RB_S>(ab, 1, st);
+  return launch_ring<RB_M, RB_N, RB_S>(ab, 1, st, plain_map);
 }
 
 }  // namespace
@@ -202,6 +211,13 @@ extern "C" int tacorl_rnn_linear_fwd(const void* x_bf16, const void* w_bf16, con
   // a recurrent step (M = batch) wants many small tiles to fill the chip; the sequence-wide input projection
   // (M = batch*T) wants the larger tile (fewer re-reads of W)
   if ((long)M * N >= 256L * 64 * 128 && N % 64 == 0) return launch_ring<128, 64, 3>(a, (hipStream_t)stream);
+  // Few output columns over many rows (the decoder's output heads: 3 840 x 2048 -> 192): as 64 x 32 tiles under the XCD map
+  // they were 360 one-per-CU workgroups (96 KB ring) on SIX of the eight XCDs - two rounds, 35.5 us in the headline step.
+  // 64 x 64 tiles with the plain map: 180 workgroups over all XCDs, one round (round 5; TACORL_RNN_HEADS_TILE=0: as before).
+  const char* hte = getenv("TACORL_RNN_HEADS_TILE");  // (read per call: launches are captured once)
+  const int heads_tile = hte ? atoi(hte) : 1;
+  if (heads_tile == 1 && N % 64 == 0 && N / 64 < 8 && M >= 1024) return launch_ring<64, 64, 3>(a, (hipStream_t)stream, true);
+  if (heads_tile == 2 && N / 32 < 8 && M >= 1024) return launch_ring<64, 32, 4>(a, (hipStream_t)stream, true);
   return launch_ring<64, 32, 4>(a, (hipStream_t)stream);
 }
 

@@ -13,6 +13,7 @@ gradients, optimiser steps and soft target update, but scheduled MI355X-first:
 
 Random draws are explicit inputs (`noise` dict, reference draw order - SURVEY 8a note 1).
 """
+import contextlib
 import os
 
 import torch
@@ -610,8 +611,11 @@ class ACEngine:
         if not encoded:
             self._encode_all()
         ops.mark("a:start")
-        self._refresh_bf16()
-        self._prepack_backward()
+        # (round 5: the weight-only launches of the two calls below - bf16 mirrors, transposed weights of the four MLP backward
+        # sites and of the encoders' FC tails: 7 launches of 5 - 7 us on this chain - leave as ONE, ops.prep_batch)
+        with ops.prep_batch() if os.environ.get("TACORL_PACK_INLINE", "1") == "1" else contextlib.nullcontext():
+            self._refresh_bf16()
+            self._prepack_backward()
         self._assemble_states()
         self._policy_fwd()
         ops.mark("a:policy_fwd")
@@ -705,21 +709,24 @@ class ACEngine:
             self._bwd_stream = torch.cuda.Stream(device=self.dev)
         main_stream = torch.cuda.current_stream()
         self._bwd_stream.wait_stream(main_stream)
-        with torch.cuda.stream(self._bwd_stream):
-            self._actor_backward(bc_phase, head_cur, q1p, q2p, gs)
-            ops.mark("b:actor_bwd")
-        # ---- critic backward through the Q MLPs; sum the broadcast embedding gradient over samples
-        self._mlp_backward("q", [self.XQ["q1"], self.XQ["q2"]], self.ldq, [self.q1.head(), self.q2.head()],
-                           [self.qact["q1"], self.qact["q2"]], [self.dq["q1"], self.dq["q2"]], 1,
-                           [self.q1.head(self.q1.grad), self.q2.head(self.q2.grad)], [self.dXQ["q1"], self.dXQ["q2"]],
-                           self.ldq, [self.R, self.R], qd, qa)
-        call("tacorl_reduce_rows_mod_batch", 2, ops.ptr_array([self.dXQ["q1"], self.dXQ["q2"]]), self.ldq,
-             ops.ptr_array([self.dS["q1"], self.dS["q2"]]), self.lds, B, self.E, 3 * n + 1, ops.stream())
-        ops.mark("b:critic_bwd")
-        main_stream.wait_stream(self._bwd_stream)
-        self._encoders_backward()
-        ops.mark("b:enc_bwd")
-        self._join_wgrads()
+        # (round 5: the slab reduces behind the five one-launch weight gradients below - readers: all-reduce and optimiser -
+        # are recorded and leave as ONE launch at the end of the phase, ops.reduce_batch)
+        with ops.reduce_batch():
+            with torch.cuda.stream(self._bwd_stream):
+                self._actor_backward(bc_phase, head_cur, q1p, q2p, gs)
+                ops.mark("b:actor_bwd")
+            # ---- critic backward through the Q MLPs; sum the broadcast embedding gradient over samples
+            self._mlp_backward("q", [self.XQ["q1"], self.XQ["q2"]], self.ldq, [self.q1.head(), self.q2.head()],
+                               [self.qact["q1"], self.qact["q2"]], [self.dq["q1"], self.dq["q2"]], 1,
+                               [self.q1.head(self.q1.grad), self.q2.head(self.q2.grad)], [self.dXQ["q1"], self.dXQ["q2"]],
+                               self.ldq, [self.R, self.R], qd, qa)
+            call("tacorl_reduce_rows_mod_batch", 2, ops.ptr_array([self.dXQ["q1"], self.dXQ["q2"]]), self.ldq,
+                 ops.ptr_array([self.dS["q1"], self.dS["q2"]]), self.lds, B, self.E, 3 * n + 1, ops.stream())
+            ops.mark("b:critic_bwd")
+            main_stream.wait_stream(self._bwd_stream)
+            self._encoders_backward()
+            ops.mark("b:enc_bwd")
+            self._join_wgrads()
         ops.mark("b:end")
 
     lean_mlp_acts = True  # hidden-layer outputs of the fused MLPs are recomputed by the weight-gradient launch, not saved

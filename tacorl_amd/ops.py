@@ -1,6 +1,7 @@
 """Thin torch-tensor wrappers over the C ABI (device memory + streams are torch's; the
 arithmetic is libtacorl_hip.so's).  No function here computes anything itself."""
 import ctypes as C
+import os
 
 import torch
 
@@ -310,6 +311,48 @@ def mark(name):
     if name not in names:
         names.append(name)
     call("tacorl_time_mark", ptr(_marks["buf"]), names.index(name), stream())
+
+
+class prep_batch:
+    """`with ops.prep_batch():` - the weight-only preparation launches issued inside (to_bf16 mirrors, the MLP backward
+    sites' transposed weights, the encoders' FC-tail transposes) become ONE launch at the end of the block, on the
+    stream current THERE (tacorl_prep_batch_begin / _end).  TACORL_PREP_BATCH=0: every launch on its own, as before."""
+    enabled = os.environ.get("TACORL_PREP_BATCH", "1") == "1"
+
+    def __enter__(self):
+        self.on = prep_batch.enabled
+        if self.on:
+            call("tacorl_prep_batch_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.on:
+            rc = L.lib().tacorl_prep_batch_end(stream())
+            if et is None and rc != 0:
+                raise RuntimeError(f"tacorl_prep_batch_end failed ({rc})")
+        return False
+
+
+class reduce_batch:
+    """`with ops.reduce_batch():` - the slab reduces of the one-launch MLP weight gradients issued inside are summed by ONE
+    launch at the end of the block (on the stream current there); the gradients are complete only after it.
+    MEASURED SLOWER on the headline step, default off (same-process A/B, scratch/ab_step.py ops:reduce_batch.enabled:
+    0.8201 -> 0.8276 ms/step): the five reduces run in launch gaps of the step's other branch where they stand; as one
+    launch at the end of the backward they are 10 us of their own in front of the optimiser.  TACORL_REDUCE_BATCH=1 enables."""
+    enabled = os.environ.get("TACORL_REDUCE_BATCH", "0") == "1"
+
+    def __enter__(self):
+        self.on = reduce_batch.enabled
+        if self.on:
+            call("tacorl_reduce_batch_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.on:
+            rc = L.lib().tacorl_reduce_batch_end(stream())
+            if et is None and rc != 0:
+                raise RuntimeError(f"tacorl_reduce_batch_end failed ({rc})")
+        return False
 
 
 _copy_batch = None

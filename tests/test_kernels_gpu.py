@@ -769,6 +769,77 @@ def test_mlp_fused_lean_activations(dims, acts):
                 assert torch.isfinite(hidden).all()
 
 
+def test_prep_and_reduce_batches_equal_separate_launches():
+    """ops.prep_batch (weight-only preparation of several sites + bf16 mirrors as ONE launch) and ops.reduce_batch (the slab
+    reduces of several sites' one-launch weight gradients as ONE launch) against the same calls launched one by one:
+    bit-identical transposed weights / mirrors / gradients; nothing is written before the block ends; misuse is refused."""
+    from tacorl_amd import _lib, blocks, ops
+
+    dev = _dev()
+    sites = [([71, 256, 256, 256, 1], [2, 2, 2, 0], [70, 300]), ([32, 256, 256, 32], [1, 1, 0], [64, 9, 33]),
+             ([64, 256, 256, 256, 14], [2, 2, 2, 0], [128])]
+    data = []
+    for si, (dims, acts, Ms) in enumerate(sites):
+        L, ld = len(dims) - 1, (dims[0] + 3) // 4 * 4
+        xs, flats, actb, douts = [], [], [], []
+        for i, M in enumerate(Ms):
+            flat = torch.zeros(blocks.mlp_size(dims), device=dev)
+            v = blocks.mlp_views(flat, 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+            for l in range(L):
+                v[f"l{l}.w"].copy_(rnd(dims[l + 1], dims[l], seed=900 + 10 * si + i + l, scale=1 / math.sqrt(dims[l])))
+                v[f"l{l}.b"].copy_(rnd(dims[l + 1], seed=950 + 10 * si + i + l, scale=0.1))
+            xp = torch.zeros(M, ld, device=dev)
+            xp[:, :dims[0]] = rnd(M, dims[0], seed=970 + 10 * si + i).to(dev)
+            xs.append(xp); flats.append(flat)
+            actb.append(torch.zeros(ops.mlp_act_layout(M, dims, acts)[2], device=dev))
+            douts.append(rnd(M, dims[-1], seed=990 + 10 * si + i).to(dev))
+        ops.mlp_fwd(xs, ld, flats, actb, Ms, dims, acts, 1)
+        data.append((dims, acts, Ms, ld, xs, flats, actb, douts))
+
+    def run(batched):
+        tag = "t_batch_%d_" % int(batched)
+        mirrors = [torch.full((f.numel(),), 7.0, device=dev, dtype=torch.bfloat16) for d in data for f in d[5]]
+        srcs = [f for d in data for f in d[5]]
+        cm_p = ops.prep_batch() if batched else contextlib.nullcontext()
+        with cm_p:
+            _lib.call("tacorl_to_bf16_batch", len(srcs), ops.ptr_array(srcs), ops.ptr_array(mirrors),
+                      (ops.C.c_long * len(srcs))(*[f.numel() // 4 * 4 for f in srcs]), ops.stream())
+            for si, (dims, acts, Ms, ld, xs, flats, actb, douts) in enumerate(data):
+                ops.mlp_bwd_fused_pack(flats, Ms, dims, tag + str(si), dev)
+            if batched:  # recorded, not launched: the mirrors still hold their fill value
+                torch.cuda.synchronize()
+                assert all(bool((m.float() == 7.0).all()) for m in mirrors)
+        grads = [[torch.full_like(f, 3.0) for f in d[5]] for d in data]
+        cm_r = ops.reduce_batch() if batched else contextlib.nullcontext()
+        with cm_r:
+            for si, (dims, acts, Ms, ld, xs, flats, actb, douts) in enumerate(data):
+                ops.mlp_bwd_fused_dgrad(flats, actb, douts, dims[-1], None, ld, Ms, dims, acts, tag + str(si), prepacked=True)
+                ops.mlp_bwd_fused_wgrad(xs, ld, actb, douts, dims[-1], grads[si], Ms, dims, acts, tag + str(si))
+            if batched:  # the reduces are pending: no gradient element has been written yet
+                torch.cuda.synchronize()
+                assert all(bool((g == 3.0).all()) for gs in grads for g in gs)
+        torch.cuda.synchronize()
+        return mirrors, grads
+
+    import contextlib
+    saved = ops.prep_batch.enabled, ops.reduce_batch.enabled
+    ops.prep_batch.enabled = ops.reduce_batch.enabled = True  # (reduce_batch is off by default: measured slower in the step)
+    try:
+        m0, g0 = run(False)
+        m1, g1 = run(True)
+    finally:
+        ops.prep_batch.enabled, ops.reduce_batch.enabled = saved
+    for a, b in zip(m0, m1):
+        assert torch.equal(a, b)
+    for ga, gb in zip(g0, g1):
+        for a, b in zip(ga, gb):
+            assert torch.isfinite(b).all() and torch.equal(a, b)
+    lib = _lib.lib()
+    assert lib.tacorl_prep_batch_end(ops.stream()) != 0 and lib.tacorl_reduce_batch_end(ops.stream()) != 0  # no open batch
+    assert lib.tacorl_prep_batch_begin() == 0 and lib.tacorl_prep_batch_begin() != 0                       # no nesting
+    assert lib.tacorl_prep_batch_end(ops.stream()) == 0
+
+
 @pytest.mark.parametrize("dims,acts", [([64, 256, 256, 256, 32], [2, 2, 2, 0]), ([80, 256, 256, 256, 1], [2, 2, 2, 0]),
                                        ([71, 256, 256, 256, 1], [2, 2, 2, 0]), ([32, 256, 256, 32], [1, 1, 0])])
 @pytest.mark.parametrize("want_dx", [True, False])
@@ -832,7 +903,8 @@ def test_mlp_fused_backward(dims, acts, want_dx):
                 assert e < GRAD_BF16_ROUNDED, ("grad vs rounded autograd", i, k, e)
 
 
-@pytest.mark.parametrize("M,K,N,act", [(256, 2048, 2048, 1), (100, 256, 64, 0), (3840, 2048, 2048, 0), (64, 128, 32, 1)])
+@pytest.mark.parametrize("M,K,N,act", [(256, 2048, 2048, 1), (100, 256, 64, 0), (3840, 2048, 2048, 0), (64, 128, 32, 1),
+                                         (3840, 2048, 192, 0), (1030, 256, 64, 1), (2000, 384, 448, 0)])  # few N tiles over many rows: 64 x 64 tiles, plain map (the output heads)
 def test_rnn_linear_bf16(M, K, N, act):
     """LDS-DMA ring GEMM of the ReLU-RNN (bf16 operands in HBM): vs fp32 torch on the same bf16-rounded
     operands (only the fp32 accumulation order differs), with bias, addend, ReLU and the bf16 output copy."""
