@@ -75,6 +75,21 @@ int tacorl_rnn_linear_fwd_batch_twin(int nprob, const void* const* x_bf16, const
                                      const float* const* addend2, int ld_add, float* const* y, float* const* y2,
                                      void* const* y_bf16, void* const* y2_bf16, int M, int M2, int K, int N,
                                      const int* acts, tacorl_stream_t stream);
+/* The same launch with an optional K extension per problem (x_ext[p] != NULL; NULL arrays / entries: none):
+ * y[p] = act(x[p] W[p]^T + x_ext[p] w_ext[p]^T + b[p] + bias2[p] + addend[p]), x_ext bf16 [M][128] (x2_ext [M2][128] for the twin
+ * rows), w_ext bf16 [N][128], zero padded beyond the real width.  Layer 0's cell of the action decoder's ReLU-RNN as ONE
+ * contraction over [h_{t-1} | x_t] - reference networks/action_decoders/rnn_models.py:5-16 (torch nn.RNN: h_t = relu(W_ih x_t +
+ * b_ih + W_hh h_{t-1} + b_hh)) - instead of a separate input-projection launch + fp32 addend.  M2 = 0: no twin rows. */
+int tacorl_rnn_linear_fwd_batch_ext(int nprob, const void* const* x_bf16, const void* const* x2_bf16,
+                                    const void* const* w_bf16, const float* const* bias, const float* const* addend,
+                                    const float* const* addend2, int ld_add, float* const* y, float* const* y2,
+                                    void* const* y_bf16, void* const* y2_bf16, int M, int M2, int K, int N,
+                                    const int* acts, const void* const* x_ext, const void* const* x2_ext,
+                                    const void* const* w_ext, const float* const* bias2, tacorl_stream_t stream);
+/* out_bf16[(t*B + b)][0..127] = bf16([plan[b] (P) | emb[(b*T + t)] (E) | zeros]) for t < Tm: the time-major RNN input rows
+ * (reference action_decoder_logistic.py:279-281) as the K-extension operand above. */
+int tacorl_build_ad_input_bf16(const float* plan, const float* emb, int ld_emb, void* out_bf16, int B, int T, int Tm,
+                               int P, int E, tacorl_stream_t stream);
 /* BPTT step of the same RNN: y = (x Wt^T + addend) * [mask_src > 0], x = dZ_t (bf16), Wt = W_hh^T (bf16,
  * tacorl_transpose_to_bf16), addend = dH_{t-1}, mask_src = h_{t-1}; y fp32 + bf16 copy (next step's x). */
 int tacorl_rnn_linear_bwd_step(const void* x_bf16, const void* wt_bf16, const float* addend, int ld_add,

@@ -34,6 +34,7 @@ _SIGS = {
     "tacorl_rnn_linear_fwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "tacorl_rnn_linear_fwd_batch": (_i, [_i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p]),
     "tacorl_rnn_linear_fwd_batch_twin": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "tacorl_rnn_linear_fwd_batch_ext": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "tacorl_rnn_linear_bwd_step": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_rnn_linear_bwd_batch": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_rnn_wgrad_supported": (_i, [_i, _i, _i]),
@@ -75,6 +76,7 @@ _SIGS = {
     "tacorl_mean_over_t": (_i, [_p, _p, _i, _i, _i, _p]),
     "tacorl_pr_sample": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "tacorl_build_ad_input": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "tacorl_build_ad_input_bf16": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "tacorl_ad_input_proj": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "tacorl_logistic_mixture_ws_bytes": (_sz, [_i, _i, _i]),
     "tacorl_logistic_mixture_loss": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p]),

@@ -42,6 +42,14 @@ struct RnnArgs {
   float* y2;
   __bf16* yb2;
   int M2;
+  // optional K extension: one more K tile (RB_K columns) whose operands live in other buffers - x_ext [M][RB_K] (x2_ext for
+  // the twin rows), w_ext [N][RB_K], zero padded - and a second bias.  The RNN's layer-0 step as ONE contraction over
+  // [h_{t-1} | x_t]: W_hh h + W_ih x + b_hh + b_ih (torch nn.RNN's cell, rnn_models.py:5-16) without the separate input
+  // projection launch and its fp32 [T B][H] addend (33.5 MB written once and read once per step at the headline shapes).
+  const __bf16* x_ext;
+  const __bf16* x2_ext;
+  const __bf16* w_ext;
+  const float* bias2;
 };
 
 // One RB_M x RB_N output tile per workgroup (4 waves stacked along M), RB_S-stage ring.
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(64 * NW) void rnn_gemm_kernel(RnnBatch ab, int MT, 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
   const int m0 = mt * RB_M, n0 = ntile * RB_N;
-  const int nk = a.K / RB_K, mtot = a.M + a.M2;
+  const int nkm = a.K / RB_K, nk = nkm + (a.x_ext ? 1 : 0), mtot = a.M + a.M2;
 
   auto issue = [&](int kt, int slot) {
     unsigned char* base = lds + slot * STAGE_BYTES;
@@ -88,8 +96,14 @@ __global__ __launch_bounds__(64 * NW) void rnn_gemm_kernel(RnnBatch ab, int MT, 
       const int row4 = (w + NW * q) * 4;  // first of the 4 rows this wave-instruction fills
       const int r = row4 + (lane >> 4), cpos = lane & 15, c = cpos ^ (r & 15);
       const int xm = m0 + r < mtot ? m0 + r : mtot - 1;  // rows past the last one are loaded (clamped) but never stored
-      const __bf16* xrow = xm < a.M ? a.x + (long)xm * a.K : a.x2 + (long)(xm - a.M) * a.K;
-      const __bf16* src = (r < RB_M ? xrow : a.w + (long)(n0 + r - RB_M) * a.K) + kt * RB_K + c * 8;
+      const __bf16* src;
+      if (kt < nkm) {
+        const __bf16* xrow = xm < a.M ? a.x + (long)xm * a.K : a.x2 + (long)(xm - a.M) * a.K;
+        src = (r < RB_M ? xrow : a.w + (long)(n0 + r - RB_M) * a.K) + kt * RB_K + c * 8;
+      } else {  // the extension tile
+        const __bf16* xrow = xm < a.M ? a.x_ext + (long)xm * RB_K : a.x2_ext + (long)(xm - a.M) * RB_K;
+        src = (r < RB_M ? xrow : a.w_ext + (long)(n0 + r - RB_M) * RB_K) + c * 8;
+      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + row4 * ROW_BYTES), 16, 0, 0);
     }
@@ -146,6 +160,7 @@ __global__ __launch_bounds__(64 * NW) void rnn_gemm_kernel(RnnBatch ab, int MT, 
       const int n = n0 + 16 * nt + 4 * g;
       f32x4 z = acc[mi][nt];
       if (a.bias) z += *reinterpret_cast<const f32x4*>(a.bias + n);
+      if (a.bias2) z += *reinterpret_cast<const f32x4*>(a.bias2 + n);
       if (addend) z += *reinterpret_cast<const f32x4*>(addend + (long)m * a.ld_add + n);
 #pragma unroll
       for (int r = 0; r < 4; r++) z[r] = act_apply(a.act, z[r]);
@@ -512,7 +527,8 @@ extern "C" int tacorl_pad_to_bf16(const float* src, int ld_src, void* dst, int l
 static int rnn_fwd_batch(int nprob, const void* const* x_bf16, const void* const* w_bf16, const float* const* bias,
                          const float* const* addend, int ld_add, float* const* y, void* const* y_bf16, int M, int K, int N,
                          const int* acts, const void* const* x2_bf16, const float* const* addend2, float* const* y2,
-                         void* const* y2_bf16, int M2, tacorl_stream_t stream) {
+                         void* const* y2_bf16, int M2, tacorl_stream_t stream, const void* const* x_ext = nullptr,
+                         const void* const* x2_ext = nullptr, const void* const* w_ext = nullptr, const float* const* bias2 = nullptr) {
   if (nprob < 1 || nprob > RNN_MAXP || !tacorl_rnn_linear_supported(M, K, N) || ld_add % 4 || M2 < 0) return TACORL_EINVAL;
   if (M2 > 0 && (!x2_bf16 || !y2)) return TACORL_EINVAL;
   RnnBatch ab{};
@@ -523,6 +539,13 @@ static int rnn_fwd_batch(int nprob, const void* const* x_bf16, const void* const
     if (((uintptr_t)x_bf16[p] | (uintptr_t)w_bf16[p] | (uintptr_t)y[p] | (uintptr_t)bi | (uintptr_t)ad) & 15) return TACORL_EINVAL;
     if ((uintptr_t)yb & 7) return TACORL_EINVAL;
     ab.p[p] = RnnArgs{(const __bf16*)x_bf16[p], (const __bf16*)w_bf16[p], bi, ad, nullptr, y[p], (__bf16*)yb, M, K, N, ld_add, acts[p]};
+    if (x_ext && x_ext[p]) {  // K extension of this problem
+      if (!w_ext || !w_ext[p] || (((uintptr_t)x_ext[p] | (uintptr_t)w_ext[p] | (uintptr_t)(bias2 ? bias2[p] : nullptr)) & 15)) return TACORL_EINVAL;
+      if (M2 > 0 && x2_bf16[p] && (!x2_ext || !x2_ext[p] || ((uintptr_t)x2_ext[p] & 15))) return TACORL_EINVAL;
+      ab.p[p].x_ext = (const __bf16*)x_ext[p]; ab.p[p].w_ext = (const __bf16*)w_ext[p];
+      ab.p[p].x2_ext = M2 > 0 && x2_ext ? (const __bf16*)x2_ext[p] : nullptr;
+      ab.p[p].bias2 = bias2 ? bias2[p] : nullptr;
+    }
     if (M2 > 0 && x2_bf16[p]) {  // (a problem without twin rows: x2[p] == NULL)
       const float* ad2 = addend2 ? addend2[p] : nullptr;
       void* yb2 = y2_bf16 ? y2_bf16[p] : nullptr;
@@ -576,4 +599,17 @@ extern "C" int tacorl_rnn_linear_fwd_batch_twin(int nprob, const void* const* x_
                                                 int M, int M2, int K, int N, const int* acts, tacorl_stream_t stream) {
   return rnn_fwd_batch(nprob, x_bf16, w_bf16, bias, addend, ld_add, y, y_bf16, M, K, N, acts, x2_bf16, addend2, y2, y2_bf16, M2,
                        stream);
+}
+/* The same launch with an optional K extension per problem (x_ext[p] != NULL): y[p] = act(x[p] W[p]^T + x_ext[p] w_ext[p]^T + b[p] +
+ * bias2[p] + addend[p]) with x_ext [M][128] (x2_ext [M2][128] for the twin rows) and w_ext [N][128] bf16, zero padded beyond the
+ * real input width - the RNN cell of layer 0 as one contraction over [h | x] (reference rnn_models.py:5-16: torch nn.RNN,
+ * h_t = relu(W_ih x_t + b_ih + W_hh h_{t-1} + b_hh)); M2 = 0 and NULL twin arrays: no twin rows. */
+extern "C" int tacorl_rnn_linear_fwd_batch_ext(int nprob, const void* const* x_bf16, const void* const* x2_bf16,
+                                               const void* const* w_bf16, const float* const* bias, const float* const* addend,
+                                               const float* const* addend2, int ld_add, float* const* y, float* const* y2,
+                                               void* const* y_bf16, void* const* y2_bf16, int M, int M2, int K, int N,
+                                               const int* acts, const void* const* x_ext, const void* const* x2_ext,
+                                               const void* const* w_ext, const float* const* bias2, tacorl_stream_t stream) {
+  return rnn_fwd_batch(nprob, x_bf16, w_bf16, bias, addend, ld_add, y, y_bf16, M, K, N, acts, x2_bf16, addend2, y2, y2_bf16, M2,
+                       stream, x_ext, x2_ext, w_ext, bias2);
 }

@@ -197,6 +197,35 @@ extern "C" int tacorl_build_ad_input(const float* plan, const float* emb, int ld
   return LAUNCH_OK();
 }
 
+// The same rows as bf16, zero padded to 128 columns: out[(t*B + b)][0..127] = bf16([plan[b] | emb[b*T + t] | 0 ...]) - the
+// K-extension operand of the ring GEMM's layer-0 step (tacorl_rnn_linear_fwd_batch_ext), 16 bytes per thread.
+__global__ __launch_bounds__(256) void build_ad_input_bf16_kernel(const float* __restrict__ plan, const float* __restrict__ emb,
+                                                                  int ld_emb, __bf16* __restrict__ out, int B, int T, int Tm, int P,
+                                                                  int E) {
+  const long total = (long)Tm * B * 16;
+  const int K = P + E;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = ((int)i & 15) * 8;
+    const long r = i >> 4;
+    const int b = (int)(r % B), t = (int)(r / B);
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = c + j;
+      v[j] = (__bf16)(k < P ? plan[(long)b * P + k] : (k < K ? emb[((long)b * T + t) * ld_emb + (k - P)] : 0.f));
+    }
+    *reinterpret_cast<bf16x8*>(out + r * 128 + c) = v;
+  }
+}
+extern "C" int tacorl_build_ad_input_bf16(const float* plan, const float* emb, int ld_emb, void* out_bf16, int B, int T, int Tm,
+                                          int P, int E, tacorl_stream_t stream) {
+  if (P < 0 || E < 1 || P + E > 128 || B < 1 || Tm < 1 || ((uintptr_t)out_bf16 & 15)) return TACORL_EINVAL;
+  const long total = (long)Tm * B * 16;
+  hipLaunchKernelGGL(build_ad_input_bf16_kernel, dim3((int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, plan, emb, ld_emb, (__bf16*)out_bf16, B, T, Tm, P, E);
+  return LAUNCH_OK();
+}
+
 // The RNN's layer-0 input projection straight from (plan, frame embeddings): xin[t*B + b][n] = b_ih[n] +
 // sum_k bf16(x[t*B + b][k]) bf16(W_ih[n][k]),  x = [plan[b] | emb[b*T + t]]  (K = P + E <= 64) - build_ad_input + the generic
 // GEMM were two launches (4 + 21 us: a K = 48 contraction is all epilogue) at the head of the action-decoder branch.

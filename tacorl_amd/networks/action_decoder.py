@@ -8,6 +8,7 @@ contiguous row range; the four heads (mean_fc | log_scale_fc | prob_fc | gripper
 back to back and evaluated as one GEMM.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -130,6 +131,9 @@ class ActionDecoderLogistic:
         self.whb = [bf(H, H) for _ in range(self.L)]
         self.wib = [None] + [bf(H, H) for _ in range(1, self.L)]  # W_ih of layers >= 1 (H x H)
         self.headw_b, self.headb = bf(self.NHP, H), f(self.NHP)    # output heads, rows padded with zeros
+        # layer 0's input projection inside the ring GEMM (K extension, proj_in_ring): the bf16 input rows, zero padded to 128
+        # columns, and W_ih_l0 likewise
+        self.xb_seq, self.wih0_b = bf(R, 128), bf(H, 128)
         self._shape = (B, Tm)
 
     # ------------------------------------------------------------------ twin pass (logging-only second plan)
@@ -153,12 +157,25 @@ class ActionDecoderLogistic:
             tw.shape = (B, Tm)
             tw.xin, tw.h, tw.hb = [f(R, H) for _ in range(self.L)], [f(R, H) for _ in range(self.L)], [bf(R, H) for _ in range(self.L)]
             tw.heads = f(R, self.NHP)
+            tw.xb_seq = bf(R, 128)
             tw.ws = torch.empty(self.ws.numel(), dtype=torch.uint8, device=self.dev)
         return tw
+
+    # Round 5: layer 0's input projection W_ih [plan | emb_t] + b_ih is no launch of its own (tacorl_ad_input_proj: 19.8 us at the
+    # head of the action-decoder branch, 33.5 MB of fp32 addend written and read back) but ONE MORE K TILE of that layer's
+    # recurrent ring-GEMM step (tacorl_rnn_linear_fwd_batch_ext); what remains in front is a 1 MB bf16 copy of the input rows.
+    # TACORL_AD_PROJ_RING=0 (or proj_in_ring = False): the separate projection launch, as before.
+    proj_in_ring = os.environ.get("TACORL_AD_PROJ_RING", "1") == "1"
+
+    def _ring_proj(self):
+        return bool(self.proj_in_ring) and os.environ.get("TACORL_AD_PROJ_RING", "1") == "1" and self.P + self.E <= 128
 
     def twin_input_proj(self, plan, emb, ld_emb, B, T, Tm):
         """Layer-0 input projection of the twin pass (reads the fp32 weights: may run before forward(), on another stream)."""
         tw, blk = self.twin_state(B, Tm), self.blk
+        if self._ring_proj():  # only the bf16 input rows: the projection rides in the recurrent step's launch
+            call("tacorl_build_ad_input_bf16", ptr(plan), ptr(emb), ld_emb, ptr(tw.xb_seq), B, T, Tm, self.P, self.E, ops.stream())
+            return tw
         call("tacorl_ad_input_proj", ptr(plan), ptr(emb), ld_emb, blk.p("rnn.weight_ih_l0"), blk.p("rnn.bias_ih_l0"),
              ptr(tw.xin[0]), B, T, Tm, self.P, self.E, self.hidden, ops.stream())
         return tw
@@ -173,6 +190,9 @@ class ActionDecoderLogistic:
         dsts = self.whb + self.wib[1:] + [self.headw_b]
         call("tacorl_to_bf16_batch", len(srcs), ops.ptr_array(srcs), ops.ptr_array(dsts),
              (C.c_long * len(srcs))(*([H * H] * (len(srcs) - 1) + [self.NH * H])), ops.stream())
+        self._mirror_ring = self._ring_proj()
+        if self._mirror_ring:
+            call("tacorl_pad_to_bf16", blk.p("rnn.weight_ih_l0"), self.P + self.E, ptr(self.wih0_b), 128, H, self.P + self.E, ops.stream())
         ob = blk.off["mean_fc.bias"][0]  # the four heads' biases sit back to back
         self.headb[: self.NH].copy_(blk.param[ob: ob + self.NH])
 
@@ -256,6 +276,8 @@ class ActionDecoderLogistic:
         fresh = (frozen and getattr(self, "_bf16_version", None) == ver) or (mirrors_current and getattr(self, "_shape", None) == (B, Tm))
         if fast:
             self._bf16_version = ver if frozen else None
+        if fast and getattr(self, "_mirror_ring", None) != self._ring_proj():  # (the padded W_ih_l0 mirror exists only in ring mode)
+            fresh = False
         if fast and not fresh:
             self.refresh_mirrors(B, Tm)
         at = ops._at
@@ -264,7 +286,10 @@ class ActionDecoderLogistic:
             # input projection of step s-2l+1 of layers l >= 1 (operand h_{l-1}[s-2l+1] left launch s-1) as
             # independent problems of ONE batched ring-GEMM launch whose workgroups are co-resident:
             # T + 2(L-1) dependent launches instead of L*T + (L-1).
-            if proj_fused:
+            ring = proj_fused and self._ring_proj()
+            if ring:
+                call("tacorl_build_ad_input_bf16", ptr(plan), ptr(emb), ld_emb, ptr(self.xb_seq), B, T, Tm, self.P, self.E, ops.stream())
+            elif proj_fused:
                 call("tacorl_ad_input_proj", ptr(plan), ptr(emb), ld_emb, blk.p("rnn.weight_ih_l0"), blk.p("rnn.bias_ih_l0"),
                      ptr(self.xin[0]), B, T, Tm, self.P, self.E, H, ops.stream())
             else:
@@ -272,24 +297,41 @@ class ActionDecoderLogistic:
             L = self.L
             assert twin is None or (proj_fused and twin.shape == (B, Tm)), "twin pass: twin_ok() / twin_state(B, Tm)"
             hbp = lambda l, t, o=self: C.c_void_p(o.hb[l].data_ptr() + 2 * t * B * H)  # noqa: E731
+            xbp = lambda t, o=self: C.c_void_p(o.xb_seq.data_ptr() + 2 * t * B * 128)  # noqa: E731
             for s_ in range(Tm + 2 * (L - 1)):
                 xs, wt, bs, ad, ys, yb, ac = [], [], [], [], [], [], []
                 x2, ad2, y2, yb2 = [], [], [], []
+                xe, xe2, we, b2 = [], [], [], []  # K extension (ring): layer 0's input rows / W_ih_l0 / b_ih_l0
                 for l in range(L):
                     t = s_ - 2 * l
                     if 0 <= t < Tm:  # h_l[t] = relu(W_hh h_l[t-1] + b_hh + xin_l[t])
+                        ext = ring and l == 0  # ... with xin_0[t] = W_ih x_t + b_ih as one more K tile of this problem
                         xs.append(ptr(self.h0b) if t == 0 else hbp(l, t - 1)); wt.append(ptr(self.whb[l]))
-                        bs.append(blk.p(f"rnn.bias_hh_l{l}")); ad.append(at(self.xin[l], t * B * H))
+                        bs.append(blk.p(f"rnn.bias_hh_l{l}")); ad.append(None if ext else at(self.xin[l], t * B * H))
                         ys.append(at(self.h[l], t * B * H)); yb.append(hbp(l, t)); ac.append(ACT_RELU)
+                        xe.append(xbp(t) if ext else None); we.append(ptr(self.wih0_b) if ext else None)
+                        b2.append(blk.p("rnn.bias_ih_l0") if ext else None)
                         if twin is not None:
-                            x2.append(ptr(self.h0b) if t == 0 else hbp(l, t - 1, twin)); ad2.append(at(twin.xin[l], t * B * H))
+                            x2.append(ptr(self.h0b) if t == 0 else hbp(l, t - 1, twin))
+                            ad2.append(None if ext else at(twin.xin[l], t * B * H))
                             y2.append(at(twin.h[l], t * B * H)); yb2.append(hbp(l, t, twin))
+                            xe2.append(xbp(t, twin) if ext else None)
                     t = s_ - 2 * l + 1
                     if l >= 1 and 0 <= t < Tm:  # xin_l[t] = W_ih h_{l-1}[t] + b_ih
                         xs.append(hbp(l - 1, t)); wt.append(ptr(self.wib[l])); bs.append(blk.p(f"rnn.bias_ih_l{l}"))
                         ad.append(None); ys.append(at(self.xin[l], t * B * H)); yb.append(None); ac.append(ACT_NONE)
+                        xe.append(None); we.append(None); b2.append(None)
                         if twin is not None:
                             x2.append(hbp(l - 1, t, twin)); ad2.append(None); y2.append(at(twin.xin[l], t * B * H)); yb2.append(None)
+                            xe2.append(None)
+                if ring:
+                    tw_ = twin is not None
+                    call("tacorl_rnn_linear_fwd_batch_ext", len(xs), ops.ptr_array(xs), ops.ptr_array(x2) if tw_ else None,
+                         ops.ptr_array(wt), ops.ptr_array(bs), ops.ptr_array(ad), ops.ptr_array(ad2) if tw_ else None, H,
+                         ops.ptr_array(ys), ops.ptr_array(y2) if tw_ else None, ops.ptr_array(yb), ops.ptr_array(yb2) if tw_ else None,
+                         B, B if tw_ else 0, H, H, ops.int_array(ac), ops.ptr_array(xe), ops.ptr_array(xe2) if tw_ else None,
+                         ops.ptr_array(we), ops.ptr_array(b2), ops.stream())
+                    continue
                 if twin is not None:
                     call("tacorl_rnn_linear_fwd_batch_twin", len(xs), ops.ptr_array(xs), ops.ptr_array(x2), ops.ptr_array(wt),
                          ops.ptr_array(bs), ops.ptr_array(ad), ops.ptr_array(ad2), H, ops.ptr_array(ys), ops.ptr_array(y2),

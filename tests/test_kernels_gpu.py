@@ -973,6 +973,57 @@ def test_rnn_linear_fwd_batch_twin(M, M2, nprob):
         assert rc != 0
 
 
+@pytest.mark.parametrize("M,M2,nprob,Kx", [(256, 0, 3, 48), (64, 64, 2, 48), (256, 256, 3, 40), (40, 0, 1, 128)])
+def test_rnn_linear_fwd_batch_ext(M, M2, nprob, Kx):
+    """K extension of the batched ring GEMM (layer 0's input projection inside its recurrent step's launch): problem 0 adds
+    x_ext w_ext^T + bias2 over one more K tile (operands zero padded to 128 columns), with and without twin rows; against
+    fp32 torch on the same bf16-rounded operands, and the build_ad_input_bf16 rows against their fp32 originals."""
+    from tacorl_amd import ops
+
+    dev = _dev()
+    K = N = 2048 if M >= 256 else 256
+    mk = lambda *s, seed, dt=torch.float32: rnd(*s, seed=seed).to(dt).to(dev)  # noqa: E731
+    xs = [mk(M, K, seed=10 + p, dt=torch.bfloat16) for p in range(nprob)]
+    x2 = [mk(M2, K, seed=20 + p, dt=torch.bfloat16) for p in range(nprob)] if M2 else None
+    ws = [(rnd(N, K, seed=30 + p) / math.sqrt(K)).to(torch.bfloat16).to(dev) for p in range(nprob)]
+    bs = [mk(N, seed=40 + p) for p in range(nprob)]
+    ad = [None if p == 0 else mk(M, N, seed=50 + p) for p in range(nprob)]
+    ad2 = [None if p == 0 else mk(M2, N, seed=60 + p) for p in range(nprob)] if M2 else None
+    acts = [1] * nprob
+    pad = lambda t: torch.cat([t, torch.zeros(t.shape[0], 128 - t.shape[1], device=dev, dtype=t.dtype)], 1).contiguous()  # noqa: E731
+    xe, we = pad(mk(M, Kx, seed=70, dt=torch.bfloat16)), pad((rnd(N, Kx, seed=71) / math.sqrt(Kx)).to(torch.bfloat16).to(dev))
+    xe2 = pad(mk(M2, Kx, seed=72, dt=torch.bfloat16)) if M2 else None
+    b2 = mk(N, seed=73)
+    none = [None] * (nprob - 1)
+    nan = lambda r, dt=torch.float32: torch.full((r, N), float("nan"), device=dev, dtype=dt)  # noqa: E731
+    y, yb = [nan(M) for _ in range(nprob)], [nan(M, torch.bfloat16) for _ in range(nprob)]
+    y2, yb2 = ([nan(M2) for _ in range(nprob)], [nan(M2, torch.bfloat16) for _ in range(nprob)]) if M2 else (None, None)
+    pa = lambda v: ops.ptr_array(v) if v is not None else None  # noqa: E731
+    ops.call("tacorl_rnn_linear_fwd_batch_ext", nprob, pa(xs), pa(x2), pa(ws), pa(bs), pa(ad), pa(ad2), N, pa(y), pa(y2), pa(yb), pa(yb2),
+             M, M2, K, N, ops.int_array(acts), pa([xe] + none), pa([xe2] + none) if M2 else None, pa([we] + none), pa([b2] + none),
+             ops.stream())
+    torch.cuda.synchronize()
+    for rows, xx, aa, yy, yyb, xx_e in ((M, xs, ad, y, yb, xe), (M2, x2, ad2, y2, yb2, xe2)):
+        if not rows:
+            continue
+        for p in range(nprob):
+            z = xx[p].float() @ ws[p].float().t() + bs[p] + (aa[p] if aa[p] is not None else 0)
+            if p == 0:
+                z = z + xx_e.float() @ we.float().t() + b2
+            assert torch.isfinite(yy[p]).all() and relerr(yy[p], F.relu(z)) < 1e-5, (rows, p, relerr(yy[p], F.relu(z)))
+            assert torch.equal(yyb[p], yy[p].to(torch.bfloat16))
+    # the input rows: [plan | emb_t | zeros] time-major, bf16
+    B, T, Tm, P, E = 6, 5, 4, 16, 32
+    plan, emb = mk(B, P, seed=80), mk(B * T, E + 8, seed=81)
+    out = torch.full((Tm * B, 128), float("nan"), device=dev, dtype=torch.bfloat16)
+    ops.call("tacorl_build_ad_input_bf16", ops.ptr(plan), ops.ptr(emb), E + 8, ops.ptr(out), B, T, Tm, P, E, ops.stream())
+    torch.cuda.synchronize()
+    exp = torch.zeros(Tm, B, 128, device=dev)
+    exp[:, :, :P] = plan[None]
+    exp[:, :, P:P + E] = emb.view(B, T, E + 8)[:, :Tm, :E].transpose(0, 1)
+    assert torch.equal(out, exp.view(Tm * B, 128).to(torch.bfloat16))
+
+
 def test_rnn_bptt_step_and_transpose():
     """BPTT step through the ring GEMM: (x Wt^T + addend) * [mask > 0] with Wt from the transpose kernel."""
     from tacorl_amd import ops
