@@ -922,6 +922,249 @@ __global__ __launch_bounds__(MF_NT) void mlp_big_fwd_kernel(MlpBigFwdArgs a) { m
 __global__ __launch_bounds__(MF_NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void mlp_mid_fwd_kernel(MlpBigFwdArgs a) { mlp_big_fwd_body<32>(a); }
 __global__ __launch_bounds__(MF_NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void mlp_m64_fwd_kernel(MlpBigFwdArgs a) { mlp_big_fwd_body<64>(a); }
 
+// ---- persistent many-row forward (round 5).  The kernels above re-stream every layer's weights through the CU's L2 port for
+// each row block (300 KB per 128 rows, ~10 k clk at the ~29 B/clk a CU ingests), start every block with a prologue behind
+// the predecessor's 393 KB of stores, and alternate load / MFMA / epilogue / store phases behind three 16-wave barriers per
+// layer: 308 us for C5's 2 x 99 328 rows where the 610 MB of saves alone would take ~120 us (profiles/r04_pmc_sq_c5.md: 8 %
+// MFMA-busy, 55 % of the wave cycles waiting).  Here ONE workgroup per CU stays resident and walks over 64-row blocks:
+//  * the two 256 x 256 layers' weights live in REGISTERS for the whole launch (8 waves x 32 columns: 128 registers per
+//    lane), layer 0's (<= 96 x 256) in LDS in fragment order, biases and the output layer in LDS: no weight traffic per block;
+//  * the next block's input rows are requested at the top of a block and converted at its end (no prologue round trip);
+//  * act' has its own staging buffer, so a layer is MFMA -> barrier -> epilogue -> barrier -> coalesced copy-out, and the
+//    copy-out's stores drain under the next layer's MFMAs;
+//  * the 1 .. 4-column output layer is a 32-element dot product per thread on the bf16 row in LDS (no MFMA tile with one
+//    valid column).
+// Same saves, same layouts, same arithmetic as mlp_big_fwd_body (hidden layers bit-identical; the output layer differs in
+// its fp32 summation order only).
+constexpr int PF_NT = 512, PF_BM = 64, PF_MT = PF_BM / 16, PF_K0S = 3;
+constexpr int PF_XB = 2 * PF_BM * XP * 2, PF_SB = PF_BM * XP * 2, PF_W0B = 8 * PF_K0S * 2 * 1024, PF_MISC = 8192;
+constexpr int PF_LDS = PF_XB + PF_SB + PF_W0B + PF_MISC;
+static_assert(PF_LDS <= 160 * 1024, "persistent forward: LDS");
+typedef unsigned int pf_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NH>  // 256 x 256 hidden layers behind layer 0 (L = NH + 2)
+__global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* X = reinterpret_cast<__bf16*>(smem);                         // [2][PF_BM][XP]
+  _Float16* S = reinterpret_cast<_Float16*>(smem + PF_XB);             // [PF_BM][XP] act' of the layer being finished
+  pf_u32x4* W0 = reinterpret_cast<pf_u32x4*>(smem + PF_XB + PF_SB);    // layer 0: [(wave * PF_K0S + ks) * 2 + nt][lane]
+  float* BI = reinterpret_cast<float*>(smem + PF_XB + PF_SB + PF_W0B); // hidden biases [NH + 1][256]
+  float* WO = BI + 3 * 256;                                            // output layer [NL <= 4][256], then its bias [4]
+  constexpr int L = NH + 2;
+  const int p = blockIdx.y, M = a.M[p], Mp = (M + 63) & ~63, nblk = Mp / PF_BM;
+  if ((int)blockIdx.x >= nblk) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int n0 = 32 * w;
+  const int K0 = a.dims[0], KS0 = (K0 + 31) / 32, c8p = 4 * KS0, NL = a.dims[L];
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  // ---- launch-resident operands
+  pf_u32x4 WH[NH][8][2];
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+    const __bf16* Wb = a.pbf[p] + a.woff[h + 1];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) WH[h][ks][nt] = __builtin_bit_cast(pf_u32x4, load_w(Wb, 256, 256, n0 + 16 * nt + i, 32 * ks + 8 * g));
+  }
+  {
+    const __bf16* Wb = a.pbf[p] + a.woff[0];
+#pragma unroll
+    for (int ks = 0; ks < PF_K0S; ks++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++)
+        W0[((w * PF_K0S + ks) * 2 + nt) * 64 + lane] = __builtin_bit_cast(pf_u32x4, load_w(Wb, K0, 256, n0 + 16 * nt + i, 32 * ks + 8 * g));
+  }
+  for (int e = tid; e < (NH + 1) * 256; e += PF_NT) BI[e] = a.params[p][a.boff[e >> 8] + (e & 255)];
+  for (int e = tid; e < NL * 256; e += PF_NT) WO[e] = (float)a.pbf[p][a.woff[L - 1] + e];
+  if (tid < 4) WO[4 * 256 + tid] = tid < NL ? a.params[p][a.boff[L - 1] + tid] : 0.f;
+  for (int e = tid; e < 2 * PF_BM * XP / 8; e += PF_NT) reinterpret_cast<f32x4*>(X)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (the weights are values of this asm from here on: nothing the compiler could re-load instead of keeping)
+#pragma unroll
+  for (int h = 0; h < NH; h++)
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) asm volatile("" : "+v"(WH[h][ks][nt]));
+
+  // ---- input rows of a block: 8-column chunks, two per thread (PF_BM * c8p <= 2 * PF_NT), gathered as in mlp_big_fwd_body
+  f32x4 xr[2][2];
+  const float* x = a.x[p];
+  const int ns = a.nseg[p];
+  // (per-thread chunk coordinates are re-derived behind an opaque zero wherever they are used: hoisted out of the block loop
+  // they cost ~20 registers of a budget the resident weights leave no room in, i.e. spills inside the loop)
+  auto opaque_tid = [&] { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return tid + z; };
+  auto fetch_x = [&](int m0) {
+    const int tv = opaque_tid();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int c = tv + u * PF_NT, row = c / c8p, k = (c - row * c8p) * 8;
+      const bool ok = c < PF_BM * c8p && m0 + row < M && k < K0;
+      xr[u][0] = xr[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!ok) continue;
+      if (ns > 0) {
+        int sg = 0;
+#pragma unroll
+        for (int t = 1; t < MF_MAXSEG; t++) sg = (t < ns && k >= a.seg[p][t].c0) ? t : sg;
+        const MlpXSeg sgm = a.seg[p][sg];
+        const int cend = sg + 1 < ns ? a.seg[p][sg + 1].c0 : K0;
+        const int r = sgm.mod ? (m0 + row) % sgm.mod : m0 + row;
+        const float* q = sgm.p + (long)r * sgm.ld + (k - sgm.c0);
+        if (k + 8 <= cend) { xr[u][0] = *reinterpret_cast<const f32x4*>(q); xr[u][1] = *reinterpret_cast<const f32x4*>(q + 4); }
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { xr[u][0][j] = k + j < cend ? q[j] : 0.f; xr[u][1][j] = k + 4 + j < cend ? q[4 + j] : 0.f; }
+        }
+        continue;
+      }
+      const float* q = x + (long)(m0 + row) * a.ldx + k;
+      if (k + 8 <= a.ldx) { xr[u][0] = *reinterpret_cast<const f32x4*>(q); xr[u][1] = *reinterpret_cast<const f32x4*>(q + 4); }
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { xr[u][0][j] = k + j < K0 ? q[j] : 0.f; xr[u][1][j] = k + 4 + j < K0 ? q[4 + j] : 0.f; }
+      }
+    }
+  };
+  auto put_x = [&](int m0) {  // -> X[0] as bf16 (every chunk up to layer 0's padded width: the buffer held an activation before)
+    const int tv = opaque_tid();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int c = tv + u * PF_NT, row = c / c8p, k = (c - row * c8p) * 8;
+      if (c >= PF_BM * c8p) continue;
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { v[j] = (__bf16)(k + j < K0 ? xr[u][0][j] : 0.f); v[4 + j] = (__bf16)(k + 4 + j < K0 ? xr[u][1][j] : 0.f); }
+      *reinterpret_cast<bf16x8*>(X + row * XP + k) = v;
+      if (ns > 0 && a.xw[p] && m0 + row < M && k < a.ldx) {  // the assembled fp32 rows (pad columns are zeros)
+        float* o = a.xw[p] + (long)(m0 + row) * a.ldx + k;
+        if (k + 8 <= a.ldx) { *reinterpret_cast<f32x4*>(o) = xr[u][0]; *reinterpret_cast<f32x4*>(o + 4) = xr[u][1]; }
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { if (k + j < a.ldx) o[j] = xr[u][0][j]; if (k + 4 + j < a.ldx) o[4 + j] = xr[u][1][j]; }
+        }
+      }
+    }
+  };
+
+  fetch_x((int)blockIdx.x * PF_BM);
+  lds_barrier();  // zeros / layer-0 fragments / biases visible
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int m0 = blk * PF_BM;
+    put_x(m0);
+    lds_barrier();
+    if (blk + (int)gridDim.x < nblk) fetch_x((blk + (int)gridDim.x) * PF_BM);  // in flight during the whole block
+    int cur = 0;
+#pragma unroll
+    for (int l = 0; l <= NH; l++) {
+      const __bf16* xin = X + cur * PF_BM * XP;
+      __bf16* xout = X + (cur ^ 1) * PF_BM * XP;
+      f32x4 acc[PF_MT][2];
+#pragma unroll
+      for (int mt = 0; mt < PF_MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (l == 0) {
+#pragma unroll
+        for (int ks = 0; ks < PF_K0S; ks++) {
+          if (ks >= KS0) break;
+          bf16x8 A[PF_MT];
+#pragma unroll
+          for (int mt = 0; mt < PF_MT; mt++) A[mt] = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
+#pragma unroll
+          for (int nt = 0; nt < 2; nt++) {
+            const bf16x8 Bf = __builtin_bit_cast(bf16x8, W0[((w * PF_K0S + ks) * 2 + nt) * 64 + lane]);
+#pragma unroll
+            for (int mt = 0; mt < PF_MT; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf, A[mt], acc[mt][nt], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+          bf16x8 A[PF_MT];
+#pragma unroll
+          for (int mt = 0; mt < PF_MT; mt++) A[mt] = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
+#pragma unroll
+          for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int mt = 0; mt < PF_MT; mt++)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WH[l == 0 ? 0 : l - 1][ks][nt]), A[mt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+      lds_barrier();  // the previous layer's copy-out has left S and xout
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        const int col = n0 + 16 * nt + 4 * g;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(BI + 256 * l + col);
+#pragma unroll
+        for (int mt = 0; mt < PF_MT; mt++) {
+          const int row = 16 * mt + i;
+          const f32x4 z = acc[mt][nt] + bv;
+          f32x4 y, sd;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float sg = sigmoid_fast(z[r]);
+            y[r] = z[r] * sg;
+            sd[r] = sg + y[r] * (1.f - sg);
+          }
+          *reinterpret_cast<bf16x4*>(xout + row * XP + col) = bf16x4{(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
+          *reinterpret_cast<f16x4*>(S + row * XP + col) = f16x4{(_Float16)sd[0], (_Float16)sd[1], (_Float16)sd[2], (_Float16)sd[3]};
+        }
+      }
+      lds_barrier();
+      {  // both copies leave as 16-byte coalesced stores (zero rows beyond M up to Mp)
+        __bf16* y16 = reinterpret_cast<__bf16*>(a.act[p] + a.ybf[p][l]);
+        __bf16* s16 = reinterpret_cast<__bf16*>(a.act[p] + a.sbf[p][l]);
+        const int tv = opaque_tid();
+#pragma unroll
+        for (int u = 0; u < PF_BM * 32 / PF_NT; u++) {
+          const int c = tv + u * PF_NT, row = c >> 5, k = (c & 31) * 8;
+          const __bf16 z0 = (__bf16)0.f;
+          bf16x8 yv = {z0, z0, z0, z0, z0, z0, z0, z0}, sv = yv;
+          if (m0 + row < M) {
+            yv = *reinterpret_cast<const bf16x8*>(xout + row * XP + k);
+            sv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(S) + row * XP + k);
+          }
+          *reinterpret_cast<bf16x8*>(y16 + (long)(m0 + row) * 256 + k) = yv;
+          *reinterpret_cast<bf16x8*>(s16 + (long)(m0 + row) * 256 + k) = sv;
+        }
+      }
+      cur ^= 1;
+    }
+    {  // output layer: thread = (row, 32-column segment)
+      const int tv = opaque_tid(), row = tv >> 3, seg = tv & 7;
+      const __bf16* yr = X + cur * PF_BM * XP + row * XP + 32 * seg;
+      float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j8 = 0; j8 < 4; j8++) {
+        const bf16x8 yv = *reinterpret_cast<const bf16x8*>(yr + 8 * j8);
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+          if (n < NL) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(WO + 256 * n + 32 * seg + 8 * j8);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(WO + 256 * n + 32 * seg + 8 * j8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { part[n] += (float)yv[e] * w0[e]; part[n] += (float)yv[4 + e] * w1[e]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        part[n] += __shfl_xor(part[n], 1);
+        part[n] += __shfl_xor(part[n], 2);
+        part[n] += __shfl_xor(part[n], 4);
+      }
+      if (seg == 0 && m0 + row < M) {
+        float* yb = a.act[p] + a.yout[p] + (long)(m0 + row) * NL;
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+          if (n < NL) yb[n] = part[n] + WO[4 * 256 + n];
+      }
+    }
+    lds_barrier();  // (the next block's rows overwrite X[0], which the output layer has just read when NH is odd)
+  }
+}
+
 struct MlpBigBwdArgs {
   const float* d_out[MF_MAXP];
   const float* act[MF_MAXP];
@@ -1488,6 +1731,27 @@ int mlp_big_fwd(int nprob, const float* const* x, int ldx, const float* const* p
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid) == hipSuccess) ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
   const int maxMp = (maxM + 63) & ~63;  // (the blocks cover the zero rows up to a multiple of 64 too)
+  {
+    // tens of thousands of rows: the persistent kernel (one resident workgroup per CU, weights in registers).
+    // TACORL_MLP_PERS=0: the per-block kernels below, as before
+    const char* pe = getenv("TACORL_MLP_PERS");
+    bool pers = mlp_rows_huge(maxM) && (pe ? atoi(pe) : 1) && (L == 3 || L == 4) && dims[0] <= 32 * PF_K0S && dims[L] <= 4;
+    for (int l = 0; l + 1 < L && pers; l++) pers = acts[l] == ACT_SILU && dims[l + 1] == 256;
+    if (pers) {
+      static int once_p = (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_pers_fwd_kernel<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS) == hipSuccess &&
+                           hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_pers_fwd_kernel<2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS) == hipSuccess) ? 0 : -1;
+      if (once_p) return TACORL_ELAUNCH;
+      static const int ncu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 1) n = 256; return n; }();
+      int gx = ncu / nprob;
+      gx = gx < 1 ? 1 : gx;
+      gx = gx > maxMp / PF_BM ? maxMp / PF_BM : gx;
+      if (L == 3) hipLaunchKernelGGL(mlp_pers_fwd_kernel<1>, dim3(gx, nprob), dim3(PF_NT), PF_LDS, st, a);
+      else hipLaunchKernelGGL(mlp_pers_fwd_kernel<2>, dim3(gx, nprob), dim3(PF_NT), PF_LDS, st, a);
+      return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+    }
+  }
   const int rows = mlp_rows_huge(maxM) ? mlp_huge_fwd_rows() : 32;
   if (rows == 128) hipLaunchKernelGGL(mlp_big_fwd_kernel, dim3((maxMp + 127) / 128, nprob), dim3(MF_NT), lds, st, a);
   else if (rows == 64) hipLaunchKernelGGL(mlp_m64_fwd_kernel, dim3(maxMp / 64, nprob), dim3(MF_NT), lds_64, st, a);

@@ -543,7 +543,48 @@ def test_mlp_fused_forward_ragged_input_width():
         assert relerr(a_f[i], a_g[i]) < 2e-3, relerr(a_f[i], a_g[i])
 
 
-@pytest.mark.parametrize("A,cams,B,lean", [(16, 1, 37, False), (32, 2, 37, False), (7, 1, 37, False), (16, 1, 210, True)])
+@pytest.mark.parametrize("M,dims", [(16384 + 77, [71, 256, 256, 256, 1]), (20000, [80, 256, 256, 3]), (16500, [32, 256, 256, 256, 4])])
+def test_mlp_persistent_forward_equals_per_block_kernels(M, dims, monkeypatch):
+    """The persistent many-row forward (one resident workgroup per CU, the 256 x 256 layers' weights in registers) against
+    the per-block kernels it replaces (TACORL_MLP_PERS=0): the bf16 / fp16 saves of every hidden layer bit for bit (zero rows
+    up to the padded row count included), the 1 .. 4-column output layer to fp32 summation order."""
+    from tacorl_amd import blocks, ops
+
+    dev = _dev()
+    L = len(dims) - 1
+    acts = [2] * (L - 1) + [0]
+    ld = (dims[0] + 3) // 4 * 4
+    Ms = [M, M - 4000]
+    xs, flats, fb = [], [], []
+    for i, m in enumerate(Ms):
+        flat = torch.zeros(blocks.mlp_size(dims), device=dev)
+        v = blocks.mlp_views(flat, 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+        for l in range(L):
+            v[f"l{l}.w"].copy_(rnd(dims[l + 1], dims[l], seed=700 + i + l, scale=1 / math.sqrt(dims[l])))
+            v[f"l{l}.b"].copy_(rnd(dims[l + 1], seed=710 + i + l, scale=0.1))
+        xp = torch.zeros(m, ld, device=dev)
+        xp[:, :dims[0]] = rnd(m, dims[0], seed=720 + i).to(dev)
+        xs.append(xp); flats.append(flat); fb.append(flat.to(torch.bfloat16))
+    assert ops.mlp_lean_ok(len(Ms), dims, ld, dims[-1], ld, 1)
+    out = {}
+    for pers in ("0", "1"):
+        monkeypatch.setenv("TACORL_MLP_PERS", pers)
+        bufs = [torch.full((ops.mlp_act_layout(m, dims, acts)[2],), float("nan"), device=dev) for m in Ms]
+        ops.mlp_fwd(xs, ld, flats, bufs, Ms, dims, acts, 1, params_bf16=fb, lean=True)
+        torch.cuda.synchronize()
+        out[pers] = bufs
+    for i, m in enumerate(Ms):
+        yo = ops.mlp_act_layout(m, dims, acts)[1][-1]
+        a, b = out["0"][i], out["1"][i]
+        nl = m * dims[-1]
+        assert torch.isfinite(b[yo: yo + nl]).all() and relerr(b[yo: yo + nl], a[yo: yo + nl]) < 1e-5
+        a, b = a.clone(), b.clone()
+        a[yo: yo + nl] = 0
+        b[yo: yo + nl] = 0
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), i  # every saved hidden copy (and every untouched gap)
+
+
+@pytest.mark.parametrize("A,cams,B,lean", [(16, 1, 37, False), (32, 2, 37, False), (7, 1, 37, False), (16, 1, 210, True), (16, 1, 1700, True)])
 def test_mlp_fused_forward_gathered_input(A, cams, B, lean):
     """tacorl_mlp_fwd_fused_gather: the Q head's input [enc(obs) per camera | goal_enc | action] read in place - state rows
     repeating every B rows (expand_obs on embeddings, reference utils/misc.py:132-153), actions one row each - must give
