@@ -1306,6 +1306,228 @@ __device__ __forceinline__ void mlp_big_bwd_body(const MlpBigBwdArgs& a) {
 __global__ __launch_bounds__(MF_NT) void mlp_big_bwd_kernel(MlpBigBwdArgs a) { mlp_big_bwd_body<64>(a); }
 __global__ __launch_bounds__(MF_NT) void mlp_mid_bwd_kernel(MlpBigBwdArgs a) { mlp_big_bwd_body<32>(a); }
 
+// ---- persistent many-row input-gradient chain (round 5): the backward twin of mlp_pers_fwd_kernel, same saves and
+// layouts as mlp_big_bwd_body.  One resident workgroup per CU over 64-row blocks; W_l^T of the 256 x 256 layers in
+// registers, W_0^T (<= 96 output columns) in LDS in fragment order, the output layer's 1 .. 4 rows in LDS as fp32.
+//  * the last layer (dZ_{L-2} = (d_out W_out) * act'_{L-2}, a rank-NL product) is element-parallel: thread = (row, 8 columns),
+//    act' read 16 bytes per lane straight from its row-major copy, dZ written to LDS and to HBM from the same registers;
+//  * a 256 x 256 layer: act' of the layer below is requested before the MFMA loop, dropped into LDS behind it, applied to the
+//    accumulators; dZ leaves from LDS as 16-byte coalesced stores under the next layer's MFMAs;
+//  * layer 0 (d_x, fp32): waves 0 .. 5 own one 16-column tile each; the rows leave through LDS (the accumulator layout
+//    gives 64-byte segments - request-bound - straight from registers);
+//  * the next block's d_out and act'_{L-2} rows are requested during layer 0, where the register budget has room.
+constexpr int PB_W0B = 6 * 8 * 1024;                       // W_0^T fragments: [6 n tiles][8 k-steps][64 lanes] x 16 B
+constexpr int PB_LDS = PF_XB + PF_SB + PB_W0B + PF_MISC;
+static_assert(PB_LDS <= 160 * 1024, "persistent backward: LDS");
+
+template <int NH>
+__global__ __launch_bounds__(PF_NT) void mlp_pers_bwd_kernel(MlpBigBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* X = reinterpret_cast<__bf16*>(smem);                          // [2][PF_BM][XP]; X[0] also stages d_x as fp32 [PF_BM][100]
+  _Float16* S = reinterpret_cast<_Float16*>(smem + PF_XB);              // [PF_BM][XP] act' of the layer below
+  pf_u32x4* W0 = reinterpret_cast<pf_u32x4*>(smem + PF_XB + PF_SB);     // [(nt * 8 + ks)][lane]
+  float* WO = reinterpret_cast<float*>(smem + PF_XB + PF_SB + PB_W0B);  // [NL <= 4][256] the output layer's rows (bf16 values)
+  float* DQ = WO + 4 * 256;                                             // [PF_BM][4] this block's d_out, bf16-rounded
+  constexpr int L = NH + 2;
+  const int p = blockIdx.y, M = a.M[p], Mp = (M + 63) & ~63, nblk = Mp / PF_BM;
+  if ((int)blockIdx.x >= nblk) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int n0 = 32 * w;
+  const int K0 = a.dims[0], NL = a.dims[L], NPL = (NL + 7) / 8 * 8;
+  const bool want_dx = a.d_x[p] != nullptr;
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto opaque_tid = [&] { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return tid + z; };
+
+  // ---- launch-resident operands: WH[h] = W_{h+1}^T fragments (row n of the packed transpose = input feature n)
+  pf_u32x4 WH[NH][8][2];
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+    const __bf16* T = a.wt[p] + a.wtoff[h + 1];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) WH[h][ks][nt] = __builtin_bit_cast(pf_u32x4, load_w(T, 256, 256, n0 + 16 * nt + i, 32 * ks + 8 * g));
+  }
+  if (want_dx) {
+    const __bf16* T = a.wt[p] + a.wtoff[0];  // [K0][256]
+    for (int f = w; f < 6 * 8; f += PF_NT / 64) {
+      const int nt = f >> 3, ks = f & 7;
+      W0[f * 64 + lane] = __builtin_bit_cast(pf_u32x4, load_w(T, 256, K0, 16 * nt + i, 32 * ks + 8 * g));
+    }
+  }
+  {
+    const __bf16* T = a.wt[p] + a.wtoff[L - 1];  // [256][NPL]: T[k * NPL + n] = W_out[n][k]
+    for (int e = tid; e < 4 * 256; e += PF_NT) {
+      const int n = e >> 8, k = e & 255;
+      WO[e] = n < NL ? (float)T[k * NPL + n] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < NH; h++)
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) asm volatile("" : "+v"(WH[h][ks][nt]));
+
+  // act' rows of a block, 16 bytes per lane in row order (chunk c = tid + u * 512: row c >> 5, columns 8 (c & 31) ..)
+  const __bf16* s_top = reinterpret_cast<const __bf16*>(a.act[p] + a.sbf[p][L - 2]);
+  bf16x8 spre[4];
+  float dpre = 0.f;
+  auto fetch_top = [&](int m0) {  // the block's d_out and act'_{L-2}
+    const int tv = opaque_tid();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int c = tv + u * PF_NT, row = c >> 5, k = (c & 31) * 8;
+      spre[u] = *reinterpret_cast<const bf16x8*>(s_top + (m0 + row < M ? (long)(m0 + row) * 256 + k : 0));
+    }
+    const int row = tv >> 2, n = tv & 3;
+    dpre = (tv < PF_BM * 4 && n < NL && m0 + row < M) ? a.d_out[p][(long)(m0 + row) * a.ldo + n] : 0.f;
+  };
+  fetch_top((int)blockIdx.x * PF_BM);
+  lds_barrier();
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int m0 = blk * PF_BM;
+    if (tid < PF_BM * 4) DQ[tid] = (float)(__bf16)dpre;
+    lds_barrier();
+    // ---- last layer: dZ_{L-2}[row][k] = (sum_n d_out[row][n] W_out[n][k]) act'_{L-2}[row][k] -> X[0] and HBM
+    {
+      __bf16* d16 = reinterpret_cast<__bf16*>(a.dz[p] + a.dzoff[p][L - 2]);
+      const int tv = opaque_tid();
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = tv + u * PF_NT, row = c >> 5, k = (c & 31) * 8;
+        const bool rok = m0 + row < M;
+        const f32x4 dq = *reinterpret_cast<const f32x4*>(DQ + 4 * row);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+          if (n < NL) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(WO + 256 * n + k), w1 = *reinterpret_cast<const f32x4*>(WO + 256 * n + k + 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[e] += dq[n] * w0[e]; v[4 + e] += dq[n] * w1[e]; }
+          }
+        }
+        const _Float16* sv = reinterpret_cast<const _Float16*>(&spre[u]);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (__bf16)(rok ? v[e] * (float)sv[e] : 0.f);
+        *reinterpret_cast<bf16x8*>(X + row * XP + k) = o;
+        *reinterpret_cast<bf16x8*>(d16 + (long)(m0 + row) * 256 + k) = o;
+      }
+    }
+    lds_barrier();
+    int cur = 0;
+    // ---- the 256 x 256 layers l = L-2 .. 1: dZ_{l-1} = (dZ_l W_l) * act'_{l-1}
+#pragma unroll
+    for (int l = NH; l >= 1; l--) {
+      const __bf16* xin = X + cur * PF_BM * XP;
+      __bf16* xout = X + (cur ^ 1) * PF_BM * XP;
+      const __bf16* s16 = reinterpret_cast<const __bf16*>(a.act[p] + a.sbf[p][l - 1]);
+      bf16x8 sl[4];
+      {
+        const int tv = opaque_tid();
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int c = tv + u * PF_NT, row = c >> 5, k = (c & 31) * 8;
+          sl[u] = *reinterpret_cast<const bf16x8*>(s16 + (m0 + row < M ? (long)(m0 + row) * 256 + k : 0));
+        }
+      }
+      f32x4 acc[PF_MT][2];
+#pragma unroll
+      for (int mt = 0; mt < PF_MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        bf16x8 A[PF_MT];
+#pragma unroll
+        for (int mt = 0; mt < PF_MT; mt++) A[mt] = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+          for (int mt = 0; mt < PF_MT; mt++)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WH[l - 1][ks][nt]), A[mt], acc[mt][nt], 0, 0, 0);
+      }
+      {  // act' of the layer below -> S (nobody reads S any more: its last readers were the previous epilogue, two barriers ago)
+        const int tv = opaque_tid();
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int c = tv + u * PF_NT, row = c >> 5, k = (c & 31) * 8;
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(S) + row * XP + k) = sl[u];
+        }
+      }
+      lds_barrier();  // S complete; the previous copy-out has left xout
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        const int col = n0 + 16 * nt + 4 * g;
+#pragma unroll
+        for (int mt = 0; mt < PF_MT; mt++) {
+          const int row = 16 * mt + i;
+          const bool rok = m0 + row < M;
+          const f16x4 sv = *reinterpret_cast<const f16x4*>(S + row * XP + col);
+          f32x4 v = acc[mt][nt];
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[r] = rok ? v[r] * (float)sv[r] : 0.f;
+          *reinterpret_cast<bf16x4*>(xout + row * XP + col) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
+      }
+      lds_barrier();
+      {
+        __bf16* d16 = reinterpret_cast<__bf16*>(a.dz[p] + a.dzoff[p][l - 1]);
+        const int tv = opaque_tid();
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int c = tv + u * PF_NT, row = c >> 5, k = (c & 31) * 8;
+          *reinterpret_cast<bf16x8*>(d16 + (long)(m0 + row) * 256 + k) = *reinterpret_cast<const bf16x8*>(xout + row * XP + k);
+        }
+      }
+      cur ^= 1;
+    }
+    // ---- the next block's top rows travel during layer 0
+    if (blk + (int)gridDim.x < nblk) fetch_top((blk + (int)gridDim.x) * PF_BM);
+    // ---- layer 0: d_x = dZ_0 W_0 (fp32 rows, K0 columns), through LDS
+    if (want_dx) {
+      const __bf16* xin = X + cur * PF_BM * XP;
+      float* stage = reinterpret_cast<float*>(X + (cur ^ 1) * PF_BM * XP);  // [PF_BM][100]
+      if (w < 6 && 16 * w < K0) {
+        f32x4 acc[PF_MT];
+#pragma unroll
+        for (int mt = 0; mt < PF_MT; mt++) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+          const bf16x8 Bf = __builtin_bit_cast(bf16x8, W0[(w * 8 + ks) * 64 + lane]);
+#pragma unroll
+          for (int mt = 0; mt < PF_MT; mt++) {
+            const bf16x8 A = *reinterpret_cast<const bf16x8*>(xin + (16 * mt + i) * XP + 32 * ks + 8 * g);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf, A, acc[mt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < PF_MT; mt++) *reinterpret_cast<f32x4*>(stage + (16 * mt + i) * 100 + 16 * w + 4 * g) = acc[mt];
+      }
+      lds_barrier();
+      {
+        const int tv = opaque_tid();
+        const int c4 = (K0 + 3) / 4;  // 4-column chunks of a row (<= 24)
+        for (int c = tv; c < PF_BM * c4; c += PF_NT) {
+          const int row = c / c4, k = (c - row * c4) * 4;
+          if (m0 + row < M) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 100 + k);
+            float* o = a.d_x[p] + (long)(m0 + row) * a.ldd + k;
+            if (k + 4 <= K0 && (a.ldd & 3) == 0) *reinterpret_cast<f32x4*>(o) = v;
+            else {
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                if (k + r < K0) o[r] = v[r];
+            }
+          }
+        }
+      }
+    }
+    lds_barrier();  // (the next block's last layer writes X[0] and DQ)
+  }
+}
+
 // ------------------------------------------------------------------ weight gradients, tens of thousands of rows
 // C5's Q networks see (3 n + 1) B = 99 328 rows each.  mlp_wgrad_fused_kernel above reads both operands as fp32, recomputes
 // the SiLU of the lean forward per element and re-lays everything through registers: 915 us per step for the two
@@ -1783,6 +2005,27 @@ int mlp_big_bwd(int nprob, const float* const* act, const float* const* d_out, i
                      hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_mid_bwd_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid) == hipSuccess) ? 0 : -1;
   if (once) return TACORL_ELAUNCH;
+  {
+    const char* pe = getenv("TACORL_MLP_PERS_BWD");  // (=0: the per-block kernels below, as before)
+    bool pers = mlp_rows_huge(maxM) && (pe ? atoi(pe) : 1) && (L == 3 || L == 4) && dims[0] <= 96 && dims[L] <= 4;
+    for (int l = 1; l < L && pers; l++) pers = dims[l] == 256;
+    for (int p = 0; p < nprob && pers; p++) pers = !(d_x && d_x[p] && ((uintptr_t)d_x[p] & 15));
+    if (pers) {
+      static int once_p = (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_pers_bwd_kernel<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS) == hipSuccess &&
+                           hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_pers_bwd_kernel<2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS) == hipSuccess) ? 0 : -1;
+      if (once_p) return TACORL_ELAUNCH;
+      static const int ncu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 1) n = 256; return n; }();
+      const int nb = ((maxM + 63) & ~63) / PF_BM;
+      int gx = ncu / nprob;
+      gx = gx < 1 ? 1 : gx;
+      gx = gx > nb ? nb : gx;
+      if (L == 3) hipLaunchKernelGGL(mlp_pers_bwd_kernel<1>, dim3(gx, nprob), dim3(PF_NT), PB_LDS, st, a);
+      else hipLaunchKernelGGL(mlp_pers_bwd_kernel<2>, dim3(gx, nprob), dim3(PF_NT), PB_LDS, st, a);
+      return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+    }
+  }
   if (mlp_rows_huge(maxM) && mlp_huge_bwd_rows() == 64) hipLaunchKernelGGL(mlp_big_bwd_kernel, dim3((maxM + 63) / 64, nprob), dim3(MF_NT), lds, st, a);
   else hipLaunchKernelGGL(mlp_mid_bwd_kernel, dim3(((maxM + 63) & ~63) / 32, nprob), dim3(MF_NT), lds_mid, st, a);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;

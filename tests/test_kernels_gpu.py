@@ -584,6 +584,51 @@ def test_mlp_persistent_forward_equals_per_block_kernels(M, dims, monkeypatch):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), i  # every saved hidden copy (and every untouched gap)
 
 
+@pytest.mark.parametrize("M,dims,want_dx", [(16384 + 77, [71, 256, 256, 256, 1], True), (20000, [80, 256, 256, 3], True),
+                                            (16500, [32, 256, 256, 256, 1], False)])
+def test_mlp_persistent_backward_equals_per_block_kernels(M, dims, want_dx, monkeypatch):
+    """The persistent many-row input-gradient chain against the per-block kernels it replaces (TACORL_MLP_PERS_BWD=0), on
+    the same forward saves: d_x and every weight / bias gradient (they consume the chain's bf16 dZ copies) - bit for bit
+    with a 1-column output layer, to fp32 summation order of the rank-NL first product otherwise."""
+    from tacorl_amd import blocks, ops
+
+    dev = _dev()
+    L = len(dims) - 1
+    acts = [2] * (L - 1) + [0]
+    ld = (dims[0] + 3) // 4 * 4
+    Ms = [M, M - 4000]
+    xs, flats, fb, douts = [], [], [], []
+    for i, m in enumerate(Ms):
+        flat = torch.zeros(blocks.mlp_size(dims), device=dev)
+        v = blocks.mlp_views(flat, 0, dims, [(f"l{l}.w", f"l{l}.b") for l in range(L)])
+        for l in range(L):
+            v[f"l{l}.w"].copy_(rnd(dims[l + 1], dims[l], seed=800 + i + l, scale=1 / math.sqrt(dims[l])))
+            v[f"l{l}.b"].copy_(rnd(dims[l + 1], seed=810 + i + l, scale=0.1))
+        xp = torch.zeros(m, ld, device=dev)
+        xp[:, :dims[0]] = rnd(m, dims[0], seed=820 + i).to(dev)
+        xs.append(xp); flats.append(flat); fb.append(flat.to(torch.bfloat16))
+        douts.append(rnd(m, dims[-1], seed=830 + i).to(dev))
+    bufs = [torch.zeros(ops.mlp_act_layout(m, dims, acts)[2], device=dev) for m in Ms]
+    ops.mlp_fwd(xs, ld, flats, bufs, Ms, dims, acts, 1, params_bf16=fb, lean=True)
+    out = {}
+    for pers in ("0", "1"):
+        monkeypatch.setenv("TACORL_MLP_PERS_BWD", pers)
+        dx = [torch.full((m, ld), float("nan"), device=dev) for m in Ms] if want_dx else None
+        gr = [torch.zeros_like(f) for f in flats]
+        ops.mlp_bwd_fused_dgrad(flats, bufs, douts, dims[-1], dx, ld, Ms, dims, acts, "t_pers_bwd", lean=True)
+        ops.mlp_bwd_fused_wgrad(xs, ld, bufs, douts, dims[-1], gr, Ms, dims, acts, "t_pers_bwd", lean=True)
+        torch.cuda.synchronize()
+        out[pers] = (dx, gr)
+    exact = dims[-1] == 1
+    for i, m in enumerate(Ms):
+        for a, b in ((out["0"][0][i], out["1"][0][i]) if want_dx else (None, None), (out["0"][1][i], out["1"][1][i])):
+            if a is None:
+                continue
+            a, b = a[:, :dims[0]] if a.dim() == 2 else a, b[:, :dims[0]] if b.dim() == 2 else b
+            assert torch.isfinite(b).all()
+            assert torch.equal(a, b) if exact else relerr(b, a) < 2e-3, (i, relerr(b, a))
+
+
 @pytest.mark.parametrize("A,cams,B,lean", [(16, 1, 37, False), (32, 2, 37, False), (7, 1, 37, False), (16, 1, 210, True), (16, 1, 1700, True)])
 def test_mlp_fused_forward_gathered_input(A, cams, B, lean):
     """tacorl_mlp_fwd_fused_gather: the Q head's input [enc(obs) per camera | goal_enc | action] read in place - state rows
