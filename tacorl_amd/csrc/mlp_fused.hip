@@ -1966,7 +1966,9 @@ int mlp_big_fwd(int nprob, const float* const* x, int ldx, const float* const* p
                                                hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS) == hipSuccess) ? 0 : -1;
       if (once_p) return TACORL_ELAUNCH;
       static const int ncu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 1) n = 256; return n; }();
-      int gx = ncu / nprob;
+      // (TACORL_MLP_PERS_CUS: CUs the resident workgroups take together - fewer than all leaves room for another branch's launches)
+      const char* ce = getenv("TACORL_MLP_PERS_CUS");
+      int gx = (ce && atoi(ce) > 0 && atoi(ce) < ncu ? atoi(ce) : ncu) / nprob;
       gx = gx < 1 ? 1 : gx;
       gx = gx > maxMp / PF_BM ? maxMp / PF_BM : gx;
       if (L == 3) hipLaunchKernelGGL(mlp_pers_fwd_kernel<1>, dim3(gx, nprob), dim3(PF_NT), PF_LDS, st, a);
@@ -2018,7 +2020,8 @@ int mlp_big_bwd(int nprob, const float* const* act, const float* const* d_out, i
       if (once_p) return TACORL_ELAUNCH;
       static const int ncu = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 1) n = 256; return n; }();
       const int nb = ((maxM + 63) & ~63) / PF_BM;
-      int gx = ncu / nprob;
+      const char* ce = getenv("TACORL_MLP_PERS_CUS");
+      int gx = (ce && atoi(ce) > 0 && atoi(ce) < ncu ? atoi(ce) : ncu) / nprob;
       gx = gx < 1 ? 1 : gx;
       gx = gx > nb ? nb : gx;
       if (L == 3) hipLaunchKernelGGL(mlp_pers_bwd_kernel<1>, dim3(gx, nprob), dim3(PF_NT), PB_LDS, st, a);

@@ -250,6 +250,14 @@ class PlanRecognition:
         call("tacorl_linear_wgrad", 1, ops.ptr_array([x]), ldx, ops.ptr_array([dz]), ld_dz, ops.int_array([M]), K, O,
              ops.ptr_array([dw]), ops.ptr_array([db]), 0, compute, ptr(ws), ws.numel(), ops.stream())
 
+    def _wgrad_n(self, xs, ldx, dzs, ld_dz, M, K, O, dws, dbs, compute):
+        """Several weight gradients of one shape (the same Linear of every transformer layer) as one launch + one reduce."""
+        n = len(xs)
+        nb = ops.L.lib().tacorl_linear_wgrad_ws_bytes(n, ops.int_array([M] * n), K, O)
+        ws = ops.workspace(nb, self.dev, "lin_wgrad")
+        call("tacorl_linear_wgrad", n, ops.ptr_array(xs), ldx, ops.ptr_array(dzs), ld_dz, ops.int_array([M] * n), K, O,
+             ops.ptr_array(dws), ops.ptr_array(dbs), 0, compute, ptr(ws), ws.numel(), ops.stream())
+
     def _dgrad(self, dz, ld_dz, w, out, ld_out, M, O, I, compute, src=None, ld_src=0, act=ACT_NONE, addend=None,
                ld_add=0):
         nb = ops.L.lib().tacorl_linear_dgrad_ws_bytes(1, ops.int_array([M]), O, I)  # split reduction for skinny outputs
@@ -353,6 +361,20 @@ class PlanRecognition:
                  B, D, T, self.H, FF, self.L, ops.stream())
 
             def wgrads():
+                # (round 5: the layers' gradients of one shape share a launch - 4 GEMM + 4 slab-reduce launches instead of
+                # 4 L of each; every one of them is launch / latency bound.  pr_wgrad_batched = False: layer by layer)
+                lp = [f"transformer_encoder.layers.{l}." for l in range(self.L)]
+                ls = range(self.L)
+                if getattr(self, "pr_wgrad_batched", True) and self.L <= 16:
+                    self._wgrad_n([self.ff1[l] for l in ls], FF, [self.dv[l] for l in ls], D, R, FF, D,
+                                  [blk.g(p + "linear2.weight") for p in lp], [blk.g(p + "linear2.bias") for p in lp], compute)
+                    self._wgrad_n([self.x[2 * l + 1] for l in ls], D, [self.d_ff1[l] for l in ls], FF, R, D, FF,
+                                  [blk.g(p + "linear1.weight") for p in lp], [blk.g(p + "linear1.bias") for p in lp], compute)
+                    self._wgrad_n([self.att[l] for l in ls], D, [self.dv1[l] for l in ls], D, R, D, D,
+                                  [blk.g(p + "self_attn.out_proj.weight") for p in lp], [blk.g(p + "self_attn.out_proj.bias") for p in lp], compute)
+                    self._wgrad_n([self.x[2 * l] for l in ls], D, [self.d_qkv[l] for l in ls], 3 * D, R, D, 3 * D,
+                                  [blk.g(p + "self_attn.in_proj_weight") for p in lp], [blk.g(p + "self_attn.in_proj_bias") for p in lp], compute)
+                    return
                 for l in reversed(range(self.L)):
                     p = f"transformer_encoder.layers.{l}."
                     self._wgrad(self.ff1[l], FF, self.dv[l], D, R, FF, D, blk.g(p + "linear2.weight"), blk.g(p + "linear2.bias"), compute)
