@@ -117,6 +117,11 @@ int tacorl_rnn_linear_bwd_batch(int nprob, const void* const* x_bf16, const void
                                 float* const* y, void* const* y_bf16, int M, int K, int N, tacorl_stream_t stream);
 /* dst[c][r] = bf16(src[r][c]); R, C multiples of 32. */
 int tacorl_transpose_to_bf16(const float* src, void* dst, int R, int C, tacorl_stream_t stream);
+/* n <= 16 such transposes (dst[j][c][r] = bf16(src[j][r][c]), R[j] x C[j], multiples of 32) in ONE launch: the weights-only
+ * preparation of the plan recognition's and the action decoder's backward (W^T operands of their input-gradient GEMMs;
+ * autograd of nn.Linear / nn.RNN in the reference - plan_recognition_transformer.py:70-105, rnn_models.py:5-16). */
+int tacorl_transpose_to_bf16_batch(int n, const float* const* src, void* const* dst, const int* R, const int* C,
+                                   tacorl_stream_t stream);
 /* dst[c][r] = r < R ? bf16(src[r][c]) : 0 for r < ld_dst (C, ld_dst multiples of 32): a weight whose row count is no multiple
  * of the ring GEMM's k-step as its K-padded transposed operand (the action decoder's 182 x H output heads, reference
  * action_decoder_logistic.py:44-52, in dH = d_heads W). */

@@ -42,6 +42,7 @@ _SIGS = {
     "tacorl_rnn_wgrad_slabs_ws_bytes": (_sz, [_i, _i, _i]),
     "tacorl_rnn_wgrad_slabs": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _sz, _p]),
     "tacorl_transpose_to_bf16": (_i, [_p, _p, _i, _i, _p]),
+    "tacorl_transpose_to_bf16_batch": (_i, [_i, _p, _p, _p, _p, _p]),
     "tacorl_transpose_pad_to_bf16": (_i, [_p, _p, _i, _i, _i, _p]),
     "tacorl_pad_to_bf16": (_i, [_p, _i, _p, _i, _l, _i, _p]),
     "tacorl_pr_encoder_fused_supported": (_i, [_i, _i, _i, _i, _i]),

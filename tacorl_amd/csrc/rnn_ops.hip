@@ -480,6 +480,39 @@ extern "C" int tacorl_transpose_to_bf16(const float* src, void* dst, int R, int 
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
+// Several transposes in one launch (blockIdx.y = job, blockIdx.x = 32 x 32 tile of the job; jobs with fewer tiles leave
+// their surplus blocks idle): the weights-only preparation of the plan recognition's backward (8 launches of 5 us) and of
+// the decoder's BPTT (3).
+#define TR_MAXJ 16
+struct TrBatch { const float* src[TR_MAXJ]; __bf16* dst[TR_MAXJ]; int R[TR_MAXJ], C[TR_MAXJ]; };
+__global__ __launch_bounds__(256) void transpose_to_bf16_batch_kernel(TrBatch t) {
+  __shared__ float tile[32][33];
+  const int j = blockIdx.y, R = t.R[j], C = t.C[j], tx_n = C / 32;
+  if ((int)blockIdx.x >= tx_n * (R / 32)) return;
+  const float* __restrict__ src = t.src[j];
+  __bf16* __restrict__ dst = t.dst[j];
+  const int r0 = (blockIdx.x / tx_n) * 32, c0 = (blockIdx.x % tx_n) * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; k++) tile[ty + 8 * k][tx] = src[(long)(r0 + ty + 8 * k) * C + c0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) dst[(long)(c0 + ty + 8 * k) * R + r0 + tx] = (__bf16)tile[tx][ty + 8 * k];
+}
+extern "C" int tacorl_transpose_to_bf16_batch(int n, const float* const* src, void* const* dst, const int* R, const int* C,
+                                              tacorl_stream_t stream) {
+  if (n < 1 || n > TR_MAXJ) return TACORL_EINVAL;
+  TrBatch t{};
+  int mx = 0;
+  for (int j = 0; j < n; j++) {
+    if (R[j] % 32 || C[j] % 32 || R[j] < 32 || C[j] < 32 || !src[j] || !dst[j]) return TACORL_EINVAL;
+    t.src[j] = src[j]; t.dst[j] = (__bf16*)dst[j]; t.R[j] = R[j]; t.C[j] = C[j];
+    const int tiles = (R[j] / 32) * (C[j] / 32);
+    mx = tiles > mx ? tiles : mx;
+  }
+  hipLaunchKernelGGL(transpose_to_bf16_batch_kernel, dim3(mx, n), dim3(256), 0, (hipStream_t)stream, t);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
+}
+
 // The same with a row count that is no multiple of 32 and a padded destination: dst[c][r] = r < R ? bf16(src[r][c]) : 0 for
 // r < ld_dst (the output heads' 182 x H weight as the K-padded W^T operand of the ring GEMM: dH = d_heads W).
 __global__ __launch_bounds__(256) void transpose_pad_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int R,

@@ -494,10 +494,12 @@ class ActionDecoderLogistic:
 
     def _transpose_weights(self):
         blk, H = self.blk, self.hidden
-        for l in range(self.L):
-            call("tacorl_transpose_to_bf16", blk.p(f"rnn.weight_hh_l{l}"), ptr(self.whtb[l]), H, H, ops.stream())
-            if l >= 1:
-                call("tacorl_transpose_to_bf16", blk.p(f"rnn.weight_ih_l{l}"), ptr(self.wihtb[l]), H, H, ops.stream())
+        srcs = [blk.p(f"rnn.weight_hh_l{l}") for l in range(self.L)] + [blk.p(f"rnn.weight_ih_l{l}") for l in range(1, self.L)]
+        dsts = [self.whtb[l] for l in range(self.L)] + [self.wihtb[l] for l in range(1, self.L)]
+        for i in range(0, len(srcs), 16):  # one launch (round 5: 2 L - 1 before)
+            n = len(srcs[i: i + 16])
+            call("tacorl_transpose_to_bf16_batch", n, ops.ptr_array(srcs[i: i + 16]), ops.ptr_array(dsts[i: i + 16]),
+                 ops.int_array([H] * n), ops.int_array([H] * n), ops.stream())
 
     def backward(self, B, Tm, compute, need_input_grad=False, wgrad_stream=None, join=True, wavefront=True, prepared=False):
         """Gradients of the loss (dL/dheads in self.d_heads) into self.blk.grad; optionally

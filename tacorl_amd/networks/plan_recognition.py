@@ -281,12 +281,15 @@ class PlanRecognition:
             bf = lambda n: torch.zeros(n, device=self.dev, dtype=torch.bfloat16)  # noqa: E731
             self._wt = [t for _ in range(self.L) for t in (bf(FF * D), bf(FF * D), bf(D * D), bf(3 * D * D))]
             self._lnpart = torch.zeros(self.L * 2 * B * 64, device=self.dev)
+        srcs, shp = [], []
         for l in range(self.L):
             p = f"transformer_encoder.layers.{l}."
-            call("tacorl_transpose_to_bf16", blk.p(p + "linear1.weight"), ptr(self._wt[4 * l]), FF, D, ops.stream())
-            call("tacorl_transpose_to_bf16", blk.p(p + "linear2.weight"), ptr(self._wt[4 * l + 1]), D, FF, ops.stream())
-            call("tacorl_transpose_to_bf16", blk.p(p + "self_attn.out_proj.weight"), ptr(self._wt[4 * l + 2]), D, D, ops.stream())
-            call("tacorl_transpose_to_bf16", blk.p(p + "self_attn.in_proj_weight"), ptr(self._wt[4 * l + 3]), 3 * D, D, ops.stream())
+            srcs += [blk.p(p + "linear1.weight"), blk.p(p + "linear2.weight"), blk.p(p + "self_attn.out_proj.weight"), blk.p(p + "self_attn.in_proj_weight")]
+            shp += [(FF, D), (D, FF), (D, D), (3 * D, D)]
+        for i in range(0, len(srcs), 16):  # one launch for all of them (round 5: 4 L launches before)
+            j = slice(i, i + 16)
+            call("tacorl_transpose_to_bf16_batch", len(srcs[j]), ops.ptr_array(srcs[j]), ops.ptr_array(self._wt[j]),
+                 ops.int_array([r for r, _ in shp[j]]), ops.int_array([c for _, c in shp[j]]), ops.stream())
 
     def backward(self, d_head, B, T, compute, wgrad_stream=None, prepared=False):
         """d_head: (B, 2A) gradient w.r.t. [mean | var_raw].  Fills self.blk.grad and returns the

@@ -1110,6 +1110,23 @@ def test_rnn_linear_fwd_batch_ext(M, M2, nprob, Kx):
     assert torch.equal(out, exp.view(Tm * B, 128).to(torch.bfloat16))
 
 
+def test_transpose_to_bf16_batch():
+    """Several transposes in one launch (jobs of different shapes) against torch; refused shapes."""
+    from tacorl_amd import _lib, ops
+
+    dev = _dev()
+    shapes = [(2048, 32), (32, 2048), (64, 64), (96, 32), (256, 256)]
+    srcs = [rnd(r, c, seed=40 + i).to(dev) for i, (r, c) in enumerate(shapes)]
+    dsts = [torch.full((c, r), float("nan"), device=dev, dtype=torch.bfloat16) for r, c in shapes]
+    ops.call("tacorl_transpose_to_bf16_batch", len(srcs), ops.ptr_array(srcs), ops.ptr_array(dsts), ops.int_array([r for r, _ in shapes]),
+             ops.int_array([c for _, c in shapes]), ops.stream())
+    torch.cuda.synchronize()
+    for s_, d in zip(srcs, dsts):
+        assert torch.equal(d, s_.t().contiguous().to(torch.bfloat16))
+    rc = _lib.lib().tacorl_transpose_to_bf16_batch(1, ops.ptr_array(srcs[:1]), ops.ptr_array(dsts[:1]), ops.int_array([2048]), ops.int_array([30]), ops.stream())
+    assert rc != 0
+
+
 def test_rnn_bptt_step_and_transpose():
     """BPTT step through the ring GEMM: (x Wt^T + addend) * [mask > 0] with Wt from the transpose kernel."""
     from tacorl_amd import ops
