@@ -13,7 +13,7 @@ rm -rf $O/trace
 B="python3 bench.py --steps 5 --warmup 2 --no-configs --no-cpu-baseline --no-graph --no-distribution"
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES -d $O/pmc1 -- $B > /dev/null 2> $O/pmc1.err
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $O/pmc2 -- $B > /dev/null 2> $O/pmc2.err
-python scratch/pmc_summary.py $O/pmc_sq.md $O/pmc1 $O/pmc2 --match "encoder_fused_kernel,ebw_,softargmax_bwd,mlp_,pr_encoder,rnn_gemm" > /dev/null
+python scratch/pmc_summary.py $O/pmc_sq.md $O/pmc1 $O/pmc2 --match "encoder_fused_kernel,ebw_,softargmax_bwd,mlp_,pr_encoder,rnn_gemm,prep_multi" > /dev/null
 rm -rf $O/pmc1 $O/pmc2
 T="python3 bench.py --steps 20 --warmup 3 --no-configs --no-cpu-baseline --no-distribution --no-graph"
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/f -- $T > /dev/null 2> $O/f.err
@@ -26,7 +26,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5t -- py
 cp $(find $O/c5t -name "*kernel_stats.csv" | head -1) $O/c5_kernel_stats.csv; rm -rf $O/c5t
 NOGRAPH=1 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES -d $O/c5p1 -- python3 scratch/run_configs.py c5 > /dev/null 2> $O/c5p1.err
 NOGRAPH=1 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $O/c5p2 -- python3 scratch/run_configs.py c5 > /dev/null 2> $O/c5p2.err
-python scratch/pmc_summary.py $O/pmc_sq_c5.md $O/c5p1 $O/c5p2 --match "mlp_big,mlp_mid,mlp_wgrad_big,mlp_wgrad_out,mlp_x_to" > /dev/null
+python scratch/pmc_summary.py $O/pmc_sq_c5.md $O/c5p1 $O/c5p2 --match "mlp_pers,mlp_big,mlp_mid,mlp_wgrad_big,mlp_wgrad_out,mlp_x_to" > /dev/null
 rm -rf $O/c5p1 $O/c5p2
 # C3 / C4 share / PlayLMP kernel stats
 bash scratch/prof_c3.sh > $O/c3.txt 2>&1; cp gpurun_out/prof_c3/kernel_stats.csv $O/c3_kernel_stats.csv 2>/dev/null

@@ -718,6 +718,7 @@ struct MlpBigFwdArgs {
   long woff[MF_MAXL], boff[MF_MAXL];
   int dims[MF_MAXL + 1], acts[MF_MAXL];
   int L, ldx;
+  int dbg;  // scratch experiments of the persistent kernel (TACORL_MLP_PERS_DBG; 0 in production): 1 = no copy-out stores
 };
 
 // BMF_ rows per workgroup: 128 for >= 16 384 rows (C5), 32 for the thousands of rows of the other configurations' Q
@@ -1103,7 +1104,7 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
           f32x4 y, sd;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const float sg = sigmoid_fast(z[r]);
+            const float sg = (a.dbg & 2) ? 0.5f : sigmoid_fast(z[r]);  // (dbg 2: no transcendental - scratch timing only)
             y[r] = z[r] * sg;
             sd[r] = sg + y[r] * (1.f - sg);
           }
@@ -1125,8 +1126,10 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
             yv = *reinterpret_cast<const bf16x8*>(xout + row * XP + k);
             sv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(S) + row * XP + k);
           }
-          *reinterpret_cast<bf16x8*>(y16 + (long)(m0 + row) * 256 + k) = yv;
-          *reinterpret_cast<bf16x8*>(s16 + (long)(m0 + row) * 256 + k) = sv;
+          if (!(a.dbg & 1)) {
+            *reinterpret_cast<bf16x8*>(y16 + (long)(m0 + row) * 256 + k) = yv;
+            *reinterpret_cast<bf16x8*>(s16 + (long)(m0 + row) * 256 + k) = sv;
+          } else asm volatile("" :: "v"(yv), "v"(sv));
         }
       }
       cur ^= 1;
@@ -1960,6 +1963,7 @@ int mlp_big_fwd(int nprob, const float* const* x, int ldx, const float* const* p
     bool pers = mlp_rows_huge(maxM) && (pe ? atoi(pe) : 1) && (L == 3 || L == 4) && dims[0] <= 32 * PF_K0S && dims[L] <= 4;
     for (int l = 0; l + 1 < L && pers; l++) pers = acts[l] == ACT_SILU && dims[l + 1] == 256;
     if (pers) {
+      { const char* de = getenv("TACORL_MLP_PERS_DBG"); a.dbg = de ? atoi(de) : 0; }
       static int once_p = (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_pers_fwd_kernel<1>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS) == hipSuccess &&
                            hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_pers_fwd_kernel<2>),
