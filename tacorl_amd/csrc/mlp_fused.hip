@@ -942,6 +942,7 @@ constexpr int PF_XB = 2 * PF_BM * XP * 2, PF_SB = PF_BM * XP * 2, PF_W0B = 8 * P
 constexpr int PF_LDS = PF_XB + PF_SB + PF_W0B + PF_MISC;
 static_assert(PF_LDS <= 160 * 1024, "persistent forward: LDS");
 typedef unsigned int pf_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <int NH>  // 256 x 256 hidden layers behind layer 0 (L = NH + 2)
 __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
@@ -959,7 +960,9 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
   const int K0 = a.dims[0], KS0 = (K0 + 31) / 32, c8p = 4 * KS0, NL = a.dims[L];
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-  // ---- launch-resident operands
+  // ---- launch-resident operands.  MFMA row r of the wave's tile nt is output column n0 + 8 (r >> 2) + 4 nt + (r & 3): a lane's
+  // accumulators (rows 4 g .. 4 g + 3 of both tiles) are then the 8 ADJACENT columns n0 + 8 g .. + 7 - one 16-byte LDS store
+  // per 16-row tile for y and one for act' instead of two 8-byte ones each (whose 16 lanes, 544 B apart, hit 8 of 32 banks)
   pf_u32x4 WH[NH][8][2];
 #pragma unroll
   for (int h = 0; h < NH; h++) {
@@ -967,7 +970,7 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 8; ks++)
 #pragma unroll
-      for (int nt = 0; nt < 2; nt++) WH[h][ks][nt] = __builtin_bit_cast(pf_u32x4, load_w(Wb, 256, 256, n0 + 16 * nt + i, 32 * ks + 8 * g));
+      for (int nt = 0; nt < 2; nt++) WH[h][ks][nt] = __builtin_bit_cast(pf_u32x4, load_w(Wb, 256, 256, n0 + 8 * (i >> 2) + 4 * nt + (i & 3), 32 * ks + 8 * g));
   }
   {
     const __bf16* Wb = a.pbf[p] + a.woff[0];
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
     for (int ks = 0; ks < PF_K0S; ks++)
 #pragma unroll
       for (int nt = 0; nt < 2; nt++)
-        W0[((w * PF_K0S + ks) * 2 + nt) * 64 + lane] = __builtin_bit_cast(pf_u32x4, load_w(Wb, K0, 256, n0 + 16 * nt + i, 32 * ks + 8 * g));
+        W0[((w * PF_K0S + ks) * 2 + nt) * 64 + lane] = __builtin_bit_cast(pf_u32x4, load_w(Wb, K0, 256, n0 + 8 * (i >> 2) + 4 * nt + (i & 3), 32 * ks + 8 * g));
   }
   for (int e = tid; e < (NH + 1) * 256; e += PF_NT) BI[e] = a.params[p][a.boff[e >> 8] + (e & 255)];
   for (int e = tid; e < NL * 256; e += PF_NT) WO[e] = (float)a.pbf[p][a.woff[L - 1] + e];
@@ -1093,23 +1096,27 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
         }
       }
       lds_barrier();  // the previous layer's copy-out has left S and xout
-#pragma unroll
-      for (int nt = 0; nt < 2; nt++) {
-        const int col = n0 + 16 * nt + 4 * g;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(BI + 256 * l + col);
+      {
+        const int col = n0 + 8 * g;  // this lane's 8 adjacent columns: tile 0 -> col .. col + 3, tile 1 -> col + 4 .. col + 7
+        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(BI + 256 * l + col), bv1 = *reinterpret_cast<const f32x4*>(BI + 256 * l + col + 4);
 #pragma unroll
         for (int mt = 0; mt < PF_MT; mt++) {
           const int row = 16 * mt + i;
-          const f32x4 z = acc[mt][nt] + bv;
-          f32x4 y, sd;
+          bf16x8 yv;
+          f16x8 sv;
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const float sg = (a.dbg & 2) ? 0.5f : sigmoid_fast(z[r]);  // (dbg 2: no transcendental - scratch timing only)
-            y[r] = z[r] * sg;
-            sd[r] = sg + y[r] * (1.f - sg);
+          for (int nt = 0; nt < 2; nt++) {
+            const f32x4 z = acc[mt][nt] + (nt ? bv1 : bv0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const float sg = (a.dbg & 2) ? 0.5f : sigmoid_fast(z[r]);  // (dbg 2: no transcendental - scratch timing only)
+              const float y = z[r] * sg;
+              yv[4 * nt + r] = (__bf16)y;
+              sv[4 * nt + r] = (_Float16)(sg + y * (1.f - sg));
+            }
           }
-          *reinterpret_cast<bf16x4*>(xout + row * XP + col) = bf16x4{(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
-          *reinterpret_cast<f16x4*>(S + row * XP + col) = f16x4{(_Float16)sd[0], (_Float16)sd[1], (_Float16)sd[2], (_Float16)sd[3]};
+          *reinterpret_cast<bf16x8*>(xout + row * XP + col) = yv;
+          *reinterpret_cast<f16x8*>(S + row * XP + col) = sv;
         }
       }
       lds_barrier();
@@ -1349,7 +1356,8 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_bwd_kernel(MlpBigBwdArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 8; ks++)
 #pragma unroll
-      for (int nt = 0; nt < 2; nt++) WH[h][ks][nt] = __builtin_bit_cast(pf_u32x4, load_w(T, 256, 256, n0 + 16 * nt + i, 32 * ks + 8 * g));
+      for (int nt = 0; nt < 2; nt++)  // (column permutation of the wave's two tiles as in mlp_pers_fwd_kernel: 8 adjacent columns per lane)
+        WH[h][ks][nt] = __builtin_bit_cast(pf_u32x4, load_w(T, 256, 256, n0 + 8 * (i >> 2) + 4 * nt + (i & 3), 32 * ks + 8 * g));
   }
   if (want_dx) {
     const __bf16* T = a.wt[p] + a.wtoff[0];  // [K0][256]
@@ -1460,18 +1468,19 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_bwd_kernel(MlpBigBwdArgs a) {
         }
       }
       lds_barrier();  // S complete; the previous copy-out has left xout
-#pragma unroll
-      for (int nt = 0; nt < 2; nt++) {
-        const int col = n0 + 16 * nt + 4 * g;
+      {
+        const int col = n0 + 8 * g;
 #pragma unroll
         for (int mt = 0; mt < PF_MT; mt++) {
           const int row = 16 * mt + i;
           const bool rok = m0 + row < M;
-          const f16x4 sv = *reinterpret_cast<const f16x4*>(S + row * XP + col);
-          f32x4 v = acc[mt][nt];
+          const f16x8 sv = *reinterpret_cast<const f16x8*>(S + row * XP + col);
+          bf16x8 o;
 #pragma unroll
-          for (int r = 0; r < 4; r++) v[r] = rok ? v[r] * (float)sv[r] : 0.f;
-          *reinterpret_cast<bf16x4*>(xout + row * XP + col) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[4 * nt + r] = (__bf16)(rok ? acc[mt][nt][r] * (float)sv[4 * nt + r] : 0.f);
+          *reinterpret_cast<bf16x8*>(xout + row * XP + col) = o;
         }
       }
       lds_barrier();
