@@ -953,6 +953,11 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
   float* BI = reinterpret_cast<float*>(smem + PF_XB + PF_SB + PF_W0B); // hidden biases [NH + 1][256]
   float* WO = BI + 3 * 256;                                            // output layer [NL <= 4][256], then its bias [4]
   constexpr int L = NH + 2;
+#ifdef MLP_PERS_DBG  // scratch builds only (scratch/mklib_file.sh ... -DMLP_PERS_DBG, scratch/r5_mlp_dissect.sh): phases switched off at run time
+  const int dbg = a.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
   const int p = blockIdx.y, M = a.M[p], Mp = (M + 63) & ~63, nblk = Mp / PF_BM;
   if ((int)blockIdx.x >= nblk) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
@@ -1068,7 +1073,8 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
       for (int mt = 0; mt < PF_MT; mt++)
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (l == 0) {
+      if (dbg & 4) {  // (scratch timing: no MFMA loop)
+      } else if (l == 0) {
 #pragma unroll
         for (int ks = 0; ks < PF_K0S; ks++) {
           if (ks >= KS0) break;
@@ -1096,7 +1102,7 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
         }
       }
       lds_barrier();  // the previous layer's copy-out has left S and xout
-      {
+      if (!(dbg & 8)) {  // (dbg 8, scratch timing: no epilogue)
         const int col = n0 + 8 * g;  // this lane's 8 adjacent columns: tile 0 -> col .. col + 3, tile 1 -> col + 4 .. col + 7
         const f32x4 bv0 = *reinterpret_cast<const f32x4*>(BI + 256 * l + col), bv1 = *reinterpret_cast<const f32x4*>(BI + 256 * l + col + 4);
 #pragma unroll
@@ -1109,7 +1115,7 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
             const f32x4 z = acc[mt][nt] + (nt ? bv1 : bv0);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-              const float sg = (a.dbg & 2) ? 0.5f : sigmoid_fast(z[r]);  // (dbg 2: no transcendental - scratch timing only)
+              const float sg = (dbg & 2) ? 0.5f : sigmoid_fast(z[r]);  // (dbg 2: no transcendental - scratch timing only)
               const float y = z[r] * sg;
               yv[4 * nt + r] = (__bf16)y;
               sv[4 * nt + r] = (_Float16)(sg + y * (1.f - sg));
@@ -1133,7 +1139,7 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
             yv = *reinterpret_cast<const bf16x8*>(xout + row * XP + k);
             sv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(S) + row * XP + k);
           }
-          if (!(a.dbg & 1)) {
+          if (!(dbg & 1)) {
             *reinterpret_cast<bf16x8*>(y16 + (long)(m0 + row) * 256 + k) = yv;
             *reinterpret_cast<bf16x8*>(s16 + (long)(m0 + row) * 256 + k) = sv;
           } else asm volatile("" :: "v"(yv), "v"(sv));
