@@ -1112,13 +1112,20 @@ __global__ __launch_bounds__(PF_NT) void mlp_pers_fwd_kernel(MlpBigFwdArgs a) {
           f16x8 sv;
 #pragma unroll
           for (int nt = 0; nt < 2; nt++) {
-            const f32x4 z = acc[mt][nt] + (nt ? bv1 : bv0);
+            const f32x4 z4 = acc[mt][nt] + (nt ? bv1 : bv0);
+            // two elements per instruction (v_pk_mul_f32 / v_pk_add_f32): the epilogue is VALU-issue bound - 67 of the kernel's
+            // 211 us standalone (profiles/r05_mlp_persistent_dissect.md).  Same operations in the same order as sigmoid_fast /
+            // the scalar form (mul, exp2, add, rcp, mul, sub, mul, add: no contraction), so the saves stay bit-identical.
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const float sg = (dbg & 2) ? 0.5f : sigmoid_fast(z[r]);  // (dbg 2: no transcendental - scratch timing only)
-              const float y = z[r] * sg;
-              yv[4 * nt + r] = (__bf16)y;
-              sv[4 * nt + r] = (_Float16)(sg + y * (1.f - sg));
+            for (int r = 0; r < 4; r += 2) {
+              const f32x2 z = {z4[r], z4[r + 1]};
+              const f32x2 t = z * f32x2{-1.44269504088896341f, -1.44269504088896341f};
+              const f32x2 d = f32x2{(dbg & 2) ? 1.f : __builtin_amdgcn_exp2f(t[0]), (dbg & 2) ? 1.f : __builtin_amdgcn_exp2f(t[1])} + f32x2{1.f, 1.f};
+              const f32x2 sg = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+              const f32x2 y = z * sg;
+              const f32x2 sd = sg + y * (f32x2{1.f, 1.f} - sg);
+              yv[4 * nt + r] = (__bf16)y[0]; yv[4 * nt + r + 1] = (__bf16)y[1];
+              sv[4 * nt + r] = (_Float16)sd[0]; sv[4 * nt + r + 1] = (_Float16)sd[1];
             }
           }
           *reinterpret_cast<bf16x8*>(xout + row * XP + col) = yv;
