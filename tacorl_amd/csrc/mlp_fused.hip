@@ -280,15 +280,33 @@ struct WtPackArgs {
   int dims[MF_MAXL + 1];
   int L;
 };
-// grid (blocks, L, nprob): Wt[kin][n] = bf16(W[n][kin]), n < NP = roundup(N, 8) (zeros for n >= N)
+// Wt[kin][n] = bf16(W[n][kin]), n < NP = roundup(N, 8) (zeros for n >= N), as 32 x 32 tiles through LDS: rows of W are read
+// along kin and rows of Wt written along n, both coalesced (round 5; element by element every read was a 64-byte sector of
+// its own - ~70 MB of L2 traffic for the 1.1 M weights of the headline step's five sites, 15 us for their one launch)
+__device__ __forceinline__ void pack_wt_tiles(const float* __restrict__ W, __bf16* __restrict__ T, int K, int N, int NP, int b0,
+                                              int nb) {
+  __shared__ float tile[32][33];
+  const int tk = (K + 31) / 32, tn = (NP + 31) / 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int t = b0; t < tk * tn; t += nb) {
+    const int k0 = (t / tn) * 32, n0 = (t - (t / tn) * tn) * 32;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int n = n0 + ty + 8 * j, k = k0 + tx;
+      tile[ty + 8 * j][tx] = (n < N && k < K) ? W[(long)n * K + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int k = k0 + ty + 8 * j, n = n0 + tx;
+      if (k < K && n < NP) T[(long)k * NP + n] = (__bf16)tile[tx][ty + 8 * j];
+    }
+    __syncthreads();
+  }
+}
+// grid (blocks, L, nprob)
 __global__ __launch_bounds__(256) void mlp_pack_wt_kernel(WtPackArgs a) {
   const int l = blockIdx.y, p = blockIdx.z, K = a.dims[l], N = a.dims[l + 1], NP = (N + 7) / 8 * 8;
-  const float* __restrict__ W = a.params[p] + a.woff[l];
-  __bf16* __restrict__ T = a.wt[p] + a.wtoff[l];
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < K * NP; e += gridDim.x * 256) {
-    const int kin = e / NP, n = e - kin * NP;
-    T[e] = (__bf16)(n < N ? W[(long)n * K + kin] : 0.f);
-  }
+  pack_wt_tiles(a.params[p] + a.woff[l], a.wt[p] + a.wtoff[l], K, N, NP, blockIdx.x, gridDim.x);
 }
 
 // ---- weight-only preparation of a step in ONE launch (round 5).  The headline step issued eight 5 - 7 us launches that read
@@ -327,12 +345,7 @@ __global__ __launch_bounds__(256) void prep_multi_kernel(PrepMultiArgs a) {
   const int l = blockIdx.y, pp = z - a.first[s];
   if (l >= k.L) return;
   const int K = k.dims[l], N = k.dims[l + 1], NP = (N + 7) / 8 * 8;
-  const float* __restrict__ W = k.params[pp] + k.woff[l];
-  __bf16* __restrict__ T = k.wt[pp] + k.wtoff[l];
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < K * NP; e += gridDim.x * 256) {
-    const int kin = e / NP, n = e - kin * NP;
-    T[e] = (__bf16)(n < N ? W[(long)n * K + kin] : 0.f);
-  }
+  pack_wt_tiles(k.params[pp] + k.woff[l], k.wt[pp] + k.wtoff[l], K, N, NP, blockIdx.x, gridDim.x);
 }
 // (rows per workgroup as in the forward: 32, or 64 for >= 16 k rows - 128 would need 128 accumulator + source registers)
 template <int BMF_>
