@@ -509,6 +509,11 @@ int tacorl_logistic_mixture_loss(const float* heads, int ldh, const float* actio
                                  float* loss_out, int B, int T, int Tm, int Da, int K, int num_classes,
                                  float gripper_alpha, float grad_scale, void* ws, size_t ws_bytes,
                                  tacorl_stream_t stream);
+/* loss_out may be NULL: the per-block partial sums then stay in ws, and this call - any time before the next
+ * tacorl_logistic_mixture_loss on the same ws, same (B, Tm, Da) - writes {loss, gripper accuracy} (a loss that is only
+ * logged, reference tacorl.py:262-270, need not cost a launch per step). */
+int tacorl_logistic_mixture_finish(const void* ws, size_t ws_bytes, int B, int Tm, int Da, float* loss_out,
+                                   tacorl_stream_t stream);
 /* ActionDecoderLogistic._sample (:238-266), the action of `act` at rollout time: Gumbel-max mixture component,
  * inversion sampling of the chosen logistic, argmax gripper class.  rand_a [R][Da][K], rand_b [R][Da]: the
  * caller's U(0,1) draws in the heads' row order; out [R][Da+1] = [actions | gripper -1/+1]. */

@@ -81,6 +81,7 @@ _SIGS = {
     "tacorl_ad_input_proj": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "tacorl_logistic_mixture_ws_bytes": (_sz, [_i, _i, _i]),
     "tacorl_logistic_mixture_loss": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p]),
+    "tacorl_logistic_mixture_finish": (_i, [_p, _sz, _i, _i, _i, _p, _p]),
     "tacorl_logistic_mixture_sample": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_linear_dgrad": (_i, [_i, _p, _i, _p, _p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p]),
     "tacorl_linear_dgrad_ws_bytes": (_sz, [_i, _p, _i, _i]),

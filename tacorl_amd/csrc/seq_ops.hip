@@ -513,6 +513,23 @@ extern "C" int tacorl_logistic_mixture_loss(const float* heads, int ldh, const f
     hipLaunchKernelGGL(logistic_mixture_k16_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, heads, ldh, actions,
                        d_heads, (float*)ws, B, T, Tm, Da, K, 1.0f / (float)(num_classes - 1),
                        logf((float)(num_classes - 1) / 2.f), gripper_alpha, grad_scale);
+  // loss_out == NULL: the per-block partials stay in ws and tacorl_logistic_mixture_finish sums them when the scalar is read
+  // (a logging-only loss: the one-block sum was the last launch of the step's action-decoder branch, 9 us of launch latency
+  // per step for a number the host looks at every log_every_n_steps)
+  if (loss_out)
+    hipLaunchKernelGGL(scaled_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (int)blocks,
+                       1.0f / (float)(B * Tm), loss_out);
+  return LAUNCH_OK();
+}
+extern "C" int tacorl_logistic_mixture_finish(const void* ws, size_t ws_bytes, int B, int Tm, int Da, float* loss_out,
+                                              tacorl_stream_t stream) {
+  if (!loss_out || !ws) return TACORL_EINVAL;
+  if (ws_bytes < tacorl_logistic_mixture_ws_bytes(B, Tm, Da)) return TACORL_ENOMEM;
+  const char* lme = getenv("TACORL_LM_SCALAR");
+  const int scalar = lme ? atoi(lme) : 0;
+  long blocks = scalar ? ((long)B * Tm * Da + 255) / 256 : ((long)B * Tm * Da + 15) / 16;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks <= 0) return TACORL_OK;
   hipLaunchKernelGGL(scaled_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (int)blocks,
                      1.0f / (float)(B * Tm), loss_out);
   return LAUNCH_OK();

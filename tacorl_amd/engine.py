@@ -894,6 +894,8 @@ class ACEngine:
         """The logged scalars, read back (one D2H sync).  With several ranks they are first averaged over the ranks (one
         small collective on the steps that log): every slot is a per-rank batch mean or rank-independent, so the result is
         the full-batch value - what the reference's sync_dist=True logs give."""
+        for fn in getattr(self, "pre_metrics", ()):  # device work only the logged scalars need (TACORL: the lazy action-decoder loss sum)
+            fn()
         logs, div = D.reduce_logs_(self.logs, self.world)
         v = logs.cpu().tolist()
         return dict(zip(LOG_SLOTS, [x / div for x in v]))

@@ -79,6 +79,7 @@ class TACORL(CQL_Offline):
         register_views(self, "perceptual_encoder.", enc_views, requires_grad=False)
         register_views(self, "plan_recognition.", lmp.pr.blk.views, requires_grad=False)
         if self.ad is not None:
+            e.pre_metrics = [self.ad.finish_loss]  # (the logging-only decoder loss leaves its partial sums on the device: loss(lazy=True))
             self._pv["action_decoder"] = register_views(self, "action_decoder.", self.ad.blk.views)
             for k, v in self.ad.buffers.items():
                 self.action_decoder.register_buffer(k, v)

@@ -365,13 +365,23 @@ class ActionDecoderLogistic:
             self._lin(x, H, blk.p("mean_fc.weight"), blk.p("mean_fc.bias"), self.heads, R, H, self.NH, ACT_NONE, compute,
                       ldy=self.NHP)
 
-    def loss(self, actions, loss_out, B, T, Tm, want_grad, grad_scale=1.0, twin=None):
+    def loss(self, actions, loss_out, B, T, Tm, want_grad, grad_scale=1.0, twin=None, lazy=False):
         """actions: device [B][T][Da+1]; writes the scalar loss to loss_out (device float) and, if
-        want_grad, dL/dheads into self.d_heads.  twin: the loss of that twin pass's heads instead (no gradient)."""
+        want_grad, dL/dheads into self.d_heads.  twin: the loss of that twin pass's heads instead (no gradient).
+        lazy: the scalar is only logged - leave the per-block partial sums in the workspace; finish_loss() (the module calls it
+        before it reads the logs) sums them into loss_out.  One launch fewer at the end of the step's decoder branch."""
         heads, ws = (self.heads, self.ws) if twin is None else (twin.heads, twin.ws)
         call("tacorl_logistic_mixture_loss", ptr(heads), self.NHP, ptr(actions), ptr(self.d_heads) if want_grad and twin is None else None,
-             loss_out, B, T, Tm, self.Da, self.K, self.num_classes, float(self.gripper_alpha), float(grad_scale),
+             None if lazy else loss_out, B, T, Tm, self.Da, self.K, self.num_classes, float(self.gripper_alpha), float(grad_scale),
              ptr(ws), ws.numel(), ops.stream())
+        self._lazy_loss = (ws, B, Tm, loss_out) if lazy else None
+
+    def finish_loss(self):
+        """Sum the partials a lazy loss() left behind into its log slot (no-op otherwise)."""
+        pend = getattr(self, "_lazy_loss", None)
+        if pend is not None:
+            ws, B, Tm, loss_out = pend
+            call("tacorl_logistic_mixture_finish", ptr(ws), ws.numel(), B, Tm, self.Da, loss_out, ops.stream())
 
     def loss_step(self, module, actions, plan, B, T, optimize, frozen=False, defer_update=False, mirrors_current=False,
                   prepared=False):
@@ -395,7 +405,8 @@ class ActionDecoderLogistic:
         # (mirrors_current / prepared: the caller has issued refresh_mirrors() / prepare_backward() for the current weights)
         self.forward(plan, emb, ld, B, T, T - 1, module.compute, frozen=frozen and not optimize, mirrors_current=mirrors_current)
         slot = ops._at(module.engine.logs, LOG_SLOTS.index("action_loss"))
-        self.loss(acts, slot, B, T, T - 1, want_grad=optimize, grad_scale=1.0 / module.world_size)
+        self.loss(acts, slot, B, T, T - 1, want_grad=optimize, grad_scale=1.0 / module.world_size,
+                  lazy=bool(getattr(module, "ad_loss_lazy", True)) and os.environ.get("TACORL_AD_LOSS_LAZY", "1") == "1")
         if optimize:
             # (no wgrad_stream here.  This call already runs on a branch of the step's graph: a side stream joined back INTO
             # that branch crashed hipStreamEndCapture on ROCm 7.2; forked from and joined into the main stream instead - with
