@@ -345,9 +345,9 @@ class ACEngine:
 
     def _all_problems(self, c):
         """(image pointer, net, out, act, n_img, needs_backward) of every encoder problem of camera c."""
-        pr = [(self._img_ptr(c, r0), net, self.enc_out[(k, c)], self.enc_act[(k, c)], n, k in self.GRAD_PROBS)
+        pr = [(self._img_ptr(c, r0), net, self.enc_out[(k, c)], self.enc_act[(k, c)], n, k in self.GRAD_PROBS, c)
               for k, net, r0, n in self.enc_probs]
-        pr += [(x["img"], x["net"], x["out"], x["act"], x["n"], False) for x in self.extra_enc if x["cam"] == c]
+        pr += [(x["img"], x["net"], x["out"], x["act"], x["n"], False, c) for x in self.extra_enc if x["cam"] == c]
         return pr
 
     # Packed conv weights of the fused encoder forward (bf16 MFMA fragments in the kernel's register order).  Round 5: the
@@ -392,20 +392,36 @@ class ACEngine:
                         vers[(id(n_), c)] = n_.param._version
 
     def _launch_fused(self, c, pr):
+        """One fused encoder launch over the problems pr (each carries its camera, x[6]: cameras of one geometry may share a launch)."""
         H, W = self.hw[c]
         call("tacorl_encoder_fwd_fused", len(pr), ops.ptr_array([x[0] for x in pr]),
-             ops.ptr_array([self._packed(x[1], c) for x in pr]), ops.ptr_array([x[1].enc(c) for x in pr]),
+             ops.ptr_array([self._packed(x[1], x[6]) for x in pr]), ops.ptr_array([x[1].enc(x[6]) for x in pr]),
              ops.ptr_array([x[2] for x in pr]), ops.ptr_array([x[3] if x[5] else None for x in pr]),
              ops.int_array([x[4] for x in pr]), H, W, ops.stream())
 
-    def encode_fused_only(self):
-        """Just the fused encoder launch of the step (bench roofline probe).  Returns images per launch."""
-        n_total = 0
+    def _fused_groups(self):
+        """Cameras whose fused encoder problems share ONE launch: the cameras of one geometry when their problems fit the
+        launch's table (round 5; C4: two 128 x 128 cameras, 7 problems each - one launch over 5 504 images instead of two over
+        2 752: one prologue, one tail); every other fused camera alone.  TACORL_EF_MERGE_CAMS=0: one launch per camera."""
+        groups, out = {}, []
         for c in self.cams:
             if self._fused_ok(c):
-                pr = self._all_problems(c)
-                self._launch_fused(c, pr)
-                n_total += sum(x[4] for x in pr)
+                groups.setdefault((tuple(self.hw[c]), bool(self._fused_bwd_ok(c))), []).append(c)
+        for (_, bwd_ok), cs in groups.items():
+            if (bwd_ok and len(cs) > 1 and os.environ.get("TACORL_EF_MERGE_CAMS", "1") == "1"
+                    and sum(len(self._all_problems(c)) for c in cs) <= 16):
+                out.append(cs)
+            else:
+                out += [[c] for c in cs]
+        return out
+
+    def encode_fused_only(self):
+        """Just the fused encoder launch(es) of the step (bench roofline probe).  Returns images per step."""
+        n_total = 0
+        for cs in self._fused_groups():
+            pr = [x for c in cs for x in self._all_problems(c)]
+            self._launch_fused(cs[0], pr)
+            n_total += sum(x[4] for x in pr)
         return n_total
 
     def _encode_all(self):
@@ -413,9 +429,20 @@ class ACEngine:
         frozen LMP window, actor(obs, goal, next), q1, q2 and both targets), activations saved only for the
         problems that have a backward; the per-layer path covers fp32 mode / images too large for LDS."""
         xd = BF16 if self.img_dtype == torch.bfloat16 else F32
+        merged = {c: cs for cs in self._fused_groups() if len(cs) > 1 for c in cs}
         for c in self.cams:
             H, W = self.hw[c]
             pr = self._all_problems(c)
+            if c in merged:
+                if merged[c][0] != c:
+                    continue  # (launched with the group's first camera)
+                allp = []
+                for cc in merged[c]:
+                    prc = self._all_problems(cc)
+                    self._pack_encoders(cc, list({id(x[1]): x[1] for x in prc}.values()), only_stale=self.ef_pack_late)
+                    allp += prc
+                self._launch_fused(c, allp)
+                continue
             if self._fused_ok(c):
                 slow = [] if self._fused_bwd_ok(c) else [x for x in pr if x[5]]
                 pr = [x for x in pr if not (slow and x[5])]
