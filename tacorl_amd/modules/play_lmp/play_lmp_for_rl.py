@@ -331,7 +331,14 @@ def _playlmp_pp_forward(self, B, T, Ec, A, cd):
     from ..._lib import BF16, call
 
     net = self.net
-    ops.copy_cols(self.emb, (T - 1) * Ec, T * Ec, self.gin, 0, Ec, B, Ec)  # pp_goal input = emb[:, -1]
+    # round 5: both MLP inputs - emb[:, -1] for the goal encoder, [emb[:, 0] | goal_enc] for the policy head - are gathered by
+    # the fused forwards where their producers left them (ops.mlp_fwd_gather, as the actor-critic engine does): three copy
+    # launches off this chain; the assembled rows the weight gradients read are written from the forward's registers
+    gather = (cd == BF16 and getattr(self, "fused_mlps", True) and getattr(self, "pp_gather", True)
+              and ops.mlp_fwd_gather_ok([B], net.genc_dims, net.genc_acts, Ec, cd, False)
+              and ops.mlp_fwd_gather_ok([B], net.head_dims, net.head_acts, 2 * Ec, cd, False))
+    if not gather:
+        ops.copy_cols(self.emb, (T - 1) * Ec, T * Ec, self.gin, 0, Ec, B, Ec)  # pp_goal input = emb[:, -1]
     # bf16 mode: the goal encoder and the plan proposal's policy head run as the single-launch MLP kernels (forward, input
     # gradients, weight gradients) on a bf16 mirror of their weights, as in the actor-critic engine.  (Per layer they are 7
     # generic GEMM launches on this chain: hidden behind the random-plan decoder pass while that was a pass of its own -
@@ -343,6 +350,12 @@ def _playlmp_pp_forward(self, B, T, Ec, A, cd):
              (C.c_long * 1)(net.size - net.genc_off), ops.stream())
         pb_g, pb_h = [net.genc_bf16()], [net.head_bf16()]
     self._pp_bf16 = pb_g
+    if gather:
+        ops.mlp_fwd_gather([[(self.emb, (T - 1) * Ec, T * Ec, 0, 0)]], [self.gin], Ec, [net.genc()], pb_g, [self.gact], [B],
+                           net.genc_dims, net.genc_acts)
+        ops.mlp_fwd_gather([[(self.emb, 0, T * Ec, 0, 0), (self.gact, self.g_yoff, Ec, Ec, 0)]], [self.S], 2 * Ec, [net.head()], pb_h,
+                           [self.pact], [B], net.head_dims, net.head_acts)
+        return self.pact[self.p_yoff: self.p_yoff + B * 2 * A]
     ops.mlp_fwd([self.gin], Ec, [net.genc()], [self.gact], [B], net.genc_dims, net.genc_acts, cd, params_bf16=pb_g)
     ops.copy_cols(self.emb, 0, T * Ec, self.S, 0, 2 * Ec, B, Ec)  # pp_state = emb[:, 0]
     ops.copy_cols(self.gact, self.g_yoff, Ec, self.S, Ec, 2 * Ec, B, Ec)
