@@ -21,6 +21,7 @@
 //  * the FC tail runs once per chunk of 8 images (pixels -> images on the MFMA column axis).
 // HBM traffic = the bf16 image (42 336 B @84x84) + 128 B of output per image.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/tacorl_hip.h"
 #include "common.h"
@@ -1023,7 +1024,9 @@ extern "C" int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const
   // problems that also store their activations (1.28 x per image, EF_ACT_COST) at 27 - 35 image-units against an
   // average of 27.  Instead: the smallest per-workgroup budget M (in units of 1/64 image) for which sum_p ceil(cost_p
   // n_p / M) fits the CU count, found by bisection; spare workgroups go to the problems closest to the budget.
-  const int budget = 256;
+  // (TACORL_EF_BUDGET: workgroups this launch may take - fewer than the CU count leaves CUs to a concurrent branch; read per call)
+  const char* be = getenv("TACORL_EF_BUDGET");
+  const int budget = be && atoi(be) >= nprob && atoi(be) <= 256 ? atoi(be) : 256;
   long cost[EF_MAXP], units = 0;
   for (int p = 0; p < nprob; p++) {
     cost[p] = (act && act[p]) ? EF_ACT_COST : 64;

@@ -343,12 +343,38 @@ class ACEngine:
             self._wpk[key] = torch.empty(ops.L.lib().tacorl_encoder_fused_wpk_bytes(), dtype=torch.uint8, device=self.dev)
         return self._wpk[key]
 
-    def _all_problems(self, c):
-        """(image pointer, net, out, act, n_img, needs_backward) of every encoder problem of camera c."""
-        pr = [(self._img_ptr(c, r0), net, self.enc_out[(k, c)], self.enc_act[(k, c)], n, k in self.GRAD_PROBS, c)
-              for k, net, r0, n in self.enc_probs]
-        pr += [(x["img"], x["net"], x["out"], x["act"], x["n"], False, c) for x in self.extra_enc if x["cam"] == c]
+    def _all_problems(self, c, which="all"):
+        """(image pointer, net, out, act, n_img, needs_backward, camera) of every encoder problem of camera c
+        (which = "own": the update's networks only, "extra": the caller's frozen ones only - TACORL's LMP window)."""
+        pr = [] if which == "extra" else [
+            (self._img_ptr(c, r0), net, self.enc_out[(k, c)], self.enc_act[(k, c)], n, k in self.GRAD_PROBS, c)
+            for k, net, r0, n in self.enc_probs]
+        if which != "own":
+            pr += [(x["img"], x["net"], x["out"], x["act"], x["n"], False, c) for x in self.extra_enc if x["cam"] == c]
         return pr
+
+    def encode_split(self, between):
+        """Experiment (TACORL_EF_SPLIT_LMP=1, fused path only): the frozen extra problems (TACORL: the LMP window, whose
+        embeddings the plan recognition -> action decoder branch waits for) as a launch of their own FIRST, `between()` (the
+        caller forks that branch there), then the update's own problems on TACORL_EF_SPLIT_BUDGET workgroups (default 192:
+        64 CUs stay free for the branch).  Returns False when the split does not apply (nothing launched)."""
+        groups = self._fused_groups()
+        if not self.extra_enc or len(groups) != 1 or sorted(groups[0]) != sorted(self.cams) or not all(self._fused_bwd_ok(c) for c in self.cams):
+            return False
+        cs = groups[0]
+        for which in ("extra", "own"):
+            pr = [x for c in cs for x in self._all_problems(c, which)]
+            for c in cs:
+                self._pack_encoders(c, list({id(x[1]): x[1] for x in pr if x[6] == c}.values()), only_stale=self.ef_pack_late)
+            if which == "own":
+                os.environ["TACORL_EF_BUDGET"] = os.environ.get("TACORL_EF_SPLIT_BUDGET", "192")
+            try:
+                self._launch_fused(cs[0], pr)
+            finally:
+                os.environ.pop("TACORL_EF_BUDGET", None)
+            if which == "extra":
+                between()
+        return True
 
     # Packed conv weights of the fused encoder forward (bf16 MFMA fragments in the kernel's register order).  Round 5: the
     # pack launch of the networks the optimiser moves runs BEHIND the Adam launch, at the end of the step - in the shadow of

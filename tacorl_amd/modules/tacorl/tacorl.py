@@ -294,8 +294,45 @@ class TACORL(CQL_Offline):
                 ad_prepared = self.ad.prepare_backward(B, T - 1, self.compute)
                 ad_prep = torch.cuda.Event()
                 ad_prep.record(self._side_stream)
-        e._encode_all()
+        # Experiment (TACORL_EF_SPLIT_LMP=1): the frozen LMP window's encoder problems as a launch of their own FIRST, the
+        # plan recognition -> action decoder branch forked right behind it, the update's own encoder problems after that on
+        # fewer workgroups (engine.encode_split).  Default: one launch for everything, the branch forked behind it.
+        split = os.environ.get("TACORL_EF_SPLIT_LMP", "0") == "1"
+        forked = []
+
+        def fork_branches():
+            forked.append(self._fork_pr_ad(B, T, main, mods, emb, ld, with_ad, optimize, ad_prep, ad_prepared))
+
+        if not (split and e.encode_split(fork_branches)):
+            e._encode_all()
         ops.mark("front:encoded")
+        if not forked:
+            fork_branches()
+        ready, ad_on_side = forked[0]
+        e.action_ready = ready
+        e.phase_a(encoded=True, optimize=optimize)
+        if ad_prep is not None:
+            main.wait_stream(self._side_stream)  # (every forked stream joins the capture's origin)
+        segmented = self._segmented() or not self._use_graph
+        if with_ad and not ad_on_side:
+            if segmented or D.collectives_on(self.world_size):
+                # (collectives captured inside the one graph: the decoder's gradients are part of the arena the second
+                # all-reduce sums, so its branch joins here as well)
+                main.wait_stream(self._pr_stream)
+            else:
+                # one graph for the whole step: the fine-tuning chain (loss, BPTT, weight gradients, Adam - 1.4 ms, touching
+                # nothing but the decoder's own buffers) stays a branch beside the CQL update and joins at the end of the step
+                self._ad_join = self._pr_stream
+        if segmented:
+            # every segment must be self-contained (its graph is replayed on its own)
+            main.wait_stream(self._pr_stream)
+            e.action_ready = None
+            self._join_ad()
+
+    def _fork_pr_ad(self, B, T, main, mods, emb, ld, with_ad, optimize, ad_prep, ad_prepared):
+        """The plan recognition -> plan -> action-decoder branches of the step, forked from `main` where it stands.  Returns
+        (the event "plan / RL action written", whether the decoder pass runs on the second side stream)."""
+        e = self.engine
         # Plan recognition -> plan -> (action-decoder loss) only need the frame embeddings; the first phase of
         # the CQL update does not need the plan.  They run as parallel branches of the step's graph:
         #   side stream 1: PR transformer -> sampled plan (= the RL action, in place) -> event action_ready
@@ -332,25 +369,7 @@ class TACORL(CQL_Offline):
                 self.ad.loss_step(self, self.acts, self.plan, B, T, False, frozen=not self.finetune_action_decoder)
                 ops.mark("ad:end")
             self._ad_join = self._side_stream
-        e.action_ready = ready
-        e.phase_a(encoded=True, optimize=optimize)
-        if ad_prep is not None:
-            main.wait_stream(self._side_stream)  # (every forked stream joins the capture's origin)
-        segmented = self._segmented() or not self._use_graph
-        if with_ad and not ad_on_side:
-            if segmented or D.collectives_on(self.world_size):
-                # (collectives captured inside the one graph: the decoder's gradients are part of the arena the second
-                # all-reduce sums, so its branch joins here as well)
-                main.wait_stream(self._pr_stream)
-            else:
-                # one graph for the whole step: the fine-tuning chain (loss, BPTT, weight gradients, Adam - 1.4 ms, touching
-                # nothing but the decoder's own buffers) stays a branch beside the CQL update and joins at the end of the step
-                self._ad_join = self._pr_stream
-        if segmented:
-            # every segment must be self-contained (its graph is replayed on its own)
-            main.wait_stream(self._pr_stream)
-            e.action_ready = None
-            self._join_ad()
+        return ready, ad_on_side
 
     def _defer_ad_update(self):
         """More than one rank (or the split-graph test mode): the fine-tuned decoder's Adam step waits for the arena's
