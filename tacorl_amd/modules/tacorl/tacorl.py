@@ -278,7 +278,10 @@ class TACORL(CQL_Offline):
         e = self.engine
         ops.mark("front:start")
         if getattr(self, "_pr_stream", None) is None:
-            self._pr_stream, self._side_stream = torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)
+            # (TACORL_PR_PRIO=1, with the encoder-split experiment: the plan recognition's stream at high priority, so that
+            # its workgroups take the CUs the first encoder launch frees ahead of the second launch's)
+            prio = -1 if os.environ.get("TACORL_PR_PRIO", "0") == "1" else 0
+            self._pr_stream, self._side_stream = torch.cuda.Stream(device=self.dev, priority=prio), torch.cuda.Stream(device=self.dev)
         main = torch.cuda.current_stream()
         mods = self.plan_recognition_modalities
         # one camera: the frame embeddings are the transformer's input as they stand
@@ -294,10 +297,14 @@ class TACORL(CQL_Offline):
                 ad_prepared = self.ad.prepare_backward(B, T - 1, self.compute)
                 ad_prep = torch.cuda.Event()
                 ad_prep.record(self._side_stream)
-        # Experiment (TACORL_EF_SPLIT_LMP=1): the frozen LMP window's encoder problems as a launch of their own FIRST, the
-        # plan recognition -> action decoder branch forked right behind it, the update's own encoder problems after that on
-        # fewer workgroups (engine.encode_split).  Default: one launch for everything, the branch forked behind it.
-        split = os.environ.get("TACORL_EF_SPLIT_LMP", "0") == "1"
+        # The frozen LMP window's encoder problems as a launch of their own FIRST, the plan recognition -> action decoder
+        # branch forked right behind it, the update's own encoder problems after that on 192 workgroups (engine.encode_split):
+        # where that branch is the step's longer chain it starts ~80 us earlier.  Measured (round 5): C4's share (window 32: 33
+        # recurrent launches of 64 rows; `ad:end` 1 017 us against `c:adam` 864) 1.274 - 1.293 -> 1.222 - 1.238 ms/step in six
+        # of seven runs (one read 1.337: whose workgroups get the freed CUs first is a race); the headline step (window 16,
+        # balanced chains) +12 us.  TACORL_EF_SPLIT_LMP = auto (default: windows of 24 steps and more) / 0 / 1.
+        sp = os.environ.get("TACORL_EF_SPLIT_LMP", "auto")
+        split = with_ad and (sp == "1" or (sp == "auto" and T >= 24))
         forked = []
 
         def fork_branches():
