@@ -302,9 +302,11 @@ class TACORL(CQL_Offline):
         # where that branch is the step's longer chain it starts ~80 us earlier.  Measured (round 5): C4's share (window 32: 33
         # recurrent launches of 64 rows; `ad:end` 1 017 us against `c:adam` 864) 1.274 - 1.293 -> 1.222 - 1.238 ms/step in six
         # of seven runs (one read 1.337: whose workgroups get the freed CUs first is a race); the headline step (window 16,
-        # balanced chains) +12 us.  TACORL_EF_SPLIT_LMP = auto (default: windows of 24 steps and more) / 0 / 1.
+        # balanced chains) +12 us; the same step with the decoder fine-tuned (C3: loss, BPTT, weight gradients and Adam make
+        # that branch the critical one) 1.518 -> 1.497.  TACORL_EF_SPLIT_LMP = auto (default: windows of 24 steps and more, or
+        # a fine-tuned decoder) / 0 / 1.
         sp = os.environ.get("TACORL_EF_SPLIT_LMP", "auto")
-        split = with_ad and (sp == "1" or (sp == "auto" and T >= 24))
+        split = with_ad and (sp == "1" or (sp == "auto" and (T >= 24 or (optimize and self.finetune_action_decoder))))
         forked = []
 
         def fork_branches():
