@@ -114,10 +114,10 @@ def time_encoder_in_step(mod, batch, steps=40):
     marks = torch.zeros(2 * (steps + 8), dtype=torch.int64, device=mod.device)
     spin_ticks = 12000  # 120 us at 100 MHz
 
-    def timed(c, pr):
+    def timed(c, pr, max_wg=0):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()
-        orig(c, pr)
+        orig(c, pr, max_wg)
         ev[1].record()
         call("tacorl_time_spin", ptr(marks), 2 * len(pairs), spin_ticks, ops.stream())
         ev[2].record()

@@ -1012,7 +1012,15 @@ static int ef_launch(EFArgs& a, int nb, hipStream_t st) {
 extern "C" int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const void* const* packed,
                                         const float* const* params, float* const* out, float* const* act,
                                         const int* n_img, int H, int W, tacorl_stream_t stream) {
+  return tacorl_encoder_fwd_fused_wg(nprob, img, packed, params, out, act, n_img, H, W, 0, stream);
+}
+/* The same launch on at most max_workgroups workgroups (0: one per CU) - fewer than the CU count leaves CUs to a concurrent
+ * branch of the caller's graph (TACORL: the update's own encoder problems beside the plan recognition, engine.encode_split). */
+extern "C" int tacorl_encoder_fwd_fused_wg(int nprob, const void* const* img, const void* const* packed,
+                                           const float* const* params, float* const* out, float* const* act,
+                                           const int* n_img, int H, int W, int max_workgroups, tacorl_stream_t stream) {
   if (nprob < 1 || nprob > EF_MAXP || !tacorl_encoder_fused_supported(H, W)) return TACORL_EINVAL;
+  if (max_workgroups < 0 || (max_workgroups > 0 && max_workgroups < nprob)) return TACORL_EINVAL;
   EFArgs a{};
   a.nprob = nprob; a.H = H; a.W = W;
   long total = 0;
@@ -1024,9 +1032,7 @@ extern "C" int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const
   // problems that also store their activations (1.28 x per image, EF_ACT_COST) at 27 - 35 image-units against an
   // average of 27.  Instead: the smallest per-workgroup budget M (in units of 1/64 image) for which sum_p ceil(cost_p
   // n_p / M) fits the CU count, found by bisection; spare workgroups go to the problems closest to the budget.
-  // (TACORL_EF_BUDGET: workgroups this launch may take - fewer than the CU count leaves CUs to a concurrent branch; read per call)
-  const char* be = getenv("TACORL_EF_BUDGET");
-  const int budget = be && atoi(be) >= nprob && atoi(be) <= 256 ? atoi(be) : 256;
+  const int budget = max_workgroups > 0 && max_workgroups < 256 ? max_workgroups : 256;
   long cost[EF_MAXP], units = 0;
   for (int p = 0; p < nprob; p++) {
     cost[p] = (act && act[p]) ? EF_ACT_COST : 64;

@@ -367,12 +367,9 @@ class ACEngine:
             for c in cs:
                 self._pack_encoders(c, list({id(x[1]): x[1] for x in pr if x[6] == c}.values()), only_stale=self.ef_pack_late)
             if which == "own":
-                os.environ["TACORL_EF_BUDGET"] = os.environ.get("TACORL_EF_SPLIT_BUDGET", "192")
-            try:
+                self._launch_fused(cs[0], pr, max_wg=int(os.environ.get("TACORL_EF_SPLIT_BUDGET", "192")))
+            else:
                 self._launch_fused(cs[0], pr)
-            finally:
-                os.environ.pop("TACORL_EF_BUDGET", None)
-            if which == "extra":
                 between()
         return True
 
@@ -417,13 +414,14 @@ class ACEngine:
                     if (id(n_), c) in vers:
                         vers[(id(n_), c)] = n_.param._version
 
-    def _launch_fused(self, c, pr):
-        """One fused encoder launch over the problems pr (each carries its camera, x[6]: cameras of one geometry may share a launch)."""
+    def _launch_fused(self, c, pr, max_wg=0):
+        """One fused encoder launch over the problems pr (each carries its camera, x[6]: cameras of one geometry may share a
+        launch) on at most max_wg workgroups (0: one per CU)."""
         H, W = self.hw[c]
-        call("tacorl_encoder_fwd_fused", len(pr), ops.ptr_array([x[0] for x in pr]),
+        call("tacorl_encoder_fwd_fused_wg", len(pr), ops.ptr_array([x[0] for x in pr]),
              ops.ptr_array([self._packed(x[1], x[6]) for x in pr]), ops.ptr_array([x[1].enc(x[6]) for x in pr]),
              ops.ptr_array([x[2] for x in pr]), ops.ptr_array([x[3] if x[5] else None for x in pr]),
-             ops.int_array([x[4] for x in pr]), H, W, ops.stream())
+             ops.int_array([x[4] for x in pr]), H, W, int(max_wg), ops.stream())
 
     def _fused_groups(self):
         """Cameras whose fused encoder problems share ONE launch: the cameras of one geometry when their problems fit the
