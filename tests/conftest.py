@@ -28,7 +28,7 @@ def _release_gpu_objects(request):
     ROCm 7.2: with test_step_gpu.py run BEFORE test_fullsize_gpu.py, the C5 test's graph replay segfaulted in
     hipGraphLaunch; with the dead captures released after each test every order passes)."""
     yield
-    if "gpu" in request.keywords:
+    if "gpu" in request.keywords and os.environ.get("TACORL_TEST_NO_RELEASE") != "1":  # (=1: reproduce the crash this fixture avoids)
         import gc
 
         import torch
