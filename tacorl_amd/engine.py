@@ -762,7 +762,7 @@ class ACEngine:
         self._bwd_stream.wait_stream(main_stream)
         # (round 5: the slab reduces behind the five one-launch weight gradients below - readers: all-reduce and optimiser -
         # are recorded and leave as ONE launch at the end of the phase, ops.reduce_batch)
-        with ops.reduce_batch():
+        with ops.reduce_batch(auto=self.R >= 16384):
             with torch.cuda.stream(self._bwd_stream):
                 self._actor_backward(bc_phase, head_cur, q1p, q2p, gs)
                 ops.mark("b:actor_bwd")
