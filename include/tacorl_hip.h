@@ -532,6 +532,13 @@ int tacorl_relu_mask_mul(const float* dy, const float* add, const float* h, floa
                          tacorl_stream_t stream);
 int tacorl_ad_input_bwd(const float* dx, float* d_plan, float* d_emb, int ld_emb, int B, int T, int Tm,
                         int P, int E, int accumulate, tacorl_stream_t stream);
+/* PlayLMP.training_step (reference play_lmp_for_rl.py:200-257): the gradient entering the encoders in one launch.
+ * d_emb [(b T + t)][Ec] (holding the action decoder's share) += dx[..][0..D_in) (plan recognition) + dS[b][0..Ec) on t = 0
+ * (plan proposal, state) + dgin[b][0..Ec) on t = T - 1 (plan proposal, goal), in that order; camera j's 32 columns also go
+ * to f_dout[j] [(b T + t)][32] (NULL: skipped).  Ec = 32 ncam. */
+int tacorl_plmp_demb_finish(float* d_emb, const float* dx, int ld_dx, int D_in, const float* dS, int ld_ds,
+                            const float* dgin, float* const* f_dout, int ncam, int B, int T, int Ec,
+                            tacorl_stream_t stream);
 int tacorl_bcast_over_t(const float* src, float* dst, int B, int T, int D, float scale, int accumulate,
                         tacorl_stream_t stream);
 int tacorl_attention_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int D, int H,

@@ -90,6 +90,7 @@ _SIGS = {
     "tacorl_linear_wgrad": (_i, [_i, _p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _p, _sz, _p]),
     "tacorl_relu_mask_mul": (_i, [_p, _p, _p, _p, _l, _p]),
     "tacorl_ad_input_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "tacorl_plmp_demb_finish": (_i, [_p, _p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "tacorl_bcast_over_t": (_i, [_p, _p, _i, _i, _i, _f, _i, _p]),
     "tacorl_attention_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "tacorl_add_layernorm_bwd_ws_bytes": (_sz, [_i, _i]),

@@ -226,6 +226,45 @@ extern "C" int tacorl_build_ad_input_bf16(const float* plan, const float* emb, i
   return LAUNCH_OK();
 }
 
+// PlayLMP.training_step: the gradient entering the encoders, assembled in ONE launch.  d_emb[(b T + t)][c] already holds the
+// action decoder's share; this adds the plan recognition's (dx, first D_in columns), the plan proposal's state share on the
+// window's first frame (dS[b][c]) and its goal share on the last frame (dgin[b][c]) - in that order, as the four accumulating
+// copies it replaces did - writes the sum back and hands every camera its 32 columns (f_dout[cam][(b T + t)][0..31]).
+// (reference play_lmp_for_rl.py:200-257: autograd sums these paths into perceptual_emb.grad)
+struct DembArgs { float* f_dout[8]; };
+__global__ __launch_bounds__(256) void plmp_demb_finish_kernel(float* __restrict__ d_emb, const float* __restrict__ dx, int ld_dx,
+                                                               int D_in, const float* __restrict__ dS, int ld_ds,
+                                                               const float* __restrict__ dgin, DembArgs fo, int B, int T, int Ec) {
+  const int q4 = Ec / 4;
+  const long total = (long)B * T * q4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / q4;
+    const int c = (int)(i - r * q4) * 4, b = (int)(r / T), t = (int)(r - (long)b * T);
+    f32x4 v = *reinterpret_cast<const f32x4*>(d_emb + r * Ec + c);
+    if (c < D_in) v += *reinterpret_cast<const f32x4*>(dx + r * ld_dx + c);
+    if (t == 0) v += *reinterpret_cast<const f32x4*>(dS + (long)b * ld_ds + c);
+    if (t == T - 1) v += *reinterpret_cast<const f32x4*>(dgin + (long)b * Ec + c);
+    *reinterpret_cast<f32x4*>(d_emb + r * Ec + c) = v;
+    float* o = fo.f_dout[c >> 5];
+    if (o) *reinterpret_cast<f32x4*>(o + r * 32 + (c & 31)) = v;
+  }
+}
+extern "C" int tacorl_plmp_demb_finish(float* d_emb, const float* dx, int ld_dx, int D_in, const float* dS, int ld_ds,
+                                       const float* dgin, float* const* f_dout, int ncam, int B, int T, int Ec,
+                                       tacorl_stream_t stream) {
+  if (ncam < 1 || ncam > 8 || Ec != 32 * ncam || D_in % 4 || D_in > Ec || ld_dx % 4 || ld_ds % 4 || B < 1 || T < 1) return TACORL_EINVAL;
+  if (((uintptr_t)d_emb | (uintptr_t)dx | (uintptr_t)dS | (uintptr_t)dgin) & 15) return TACORL_EINVAL;
+  DembArgs fo{};
+  for (int j = 0; j < ncam; j++) {
+    if ((uintptr_t)f_dout[j] & 15) return TACORL_EINVAL;
+    fo.f_dout[j] = f_dout[j];
+  }
+  const long total = (long)B * T * (Ec / 4);
+  hipLaunchKernelGGL(plmp_demb_finish_kernel, dim3((int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_emb, dx, ld_dx, D_in, dS, ld_ds, dgin, fo, B, T, Ec);
+  return LAUNCH_OK();
+}
+
 // The RNN's layer-0 input projection straight from (plan, frame embeddings): xin[t*B + b][n] = b_ih[n] +
 // sum_k bf16(x[t*B + b][k]) bf16(W_ih[n][k]),  x = [plan[b] | emb[b*T + t]]  (K = P + E <= 64) - build_ad_input + the generic
 // GEMM were two launches (4 + 21 us: a K = 48 contraction is all epilogue) at the head of the action-decoder branch.

@@ -484,13 +484,22 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
          float(pr.min_std), ops.stream())
     dx = pr.backward(self.d_head_pr, B, T, cd, wgrad_stream=s_wg)
     ops.mark("pr:bwd")
-    ops.copy_cols(dx, 0, pr.D, self.d_emb, 0, Ec, R, pr.D_in, accumulate=True)
-    main.wait_stream(s_pp)
-    ops.copy_cols(self.dS, 0, 2 * Ec, self.d_emb, 0, T * Ec, B, Ec, accumulate=True)
-    ops.copy_cols(self.dgin, 0, Ec, self.d_emb, (T - 1) * Ec, T * Ec, B, Ec, accumulate=True)
+    # round 5: the four shares of d_emb and the cameras' slices in ONE launch (three accumulating copies + a copy per camera
+    # before, between the plan recognition's backward and the encoders'); demb_one_launch = False: as before
+    one = getattr(self, "demb_one_launch", True) and pr.D_in % 4 == 0 and pr.D % 4 == 0 and Ec == 32 * len(cams)
+    if one:
+        main.wait_stream(s_pp)
+        call("tacorl_plmp_demb_finish", ptr(self.d_emb), ptr(dx), pr.D, pr.D_in, ptr(self.dS), 2 * Ec, ptr(self.dgin),
+             ops.ptr_array([self.f_dout[c] for c in cams]), len(cams), B, T, Ec, ops.stream())
+    else:
+        ops.copy_cols(dx, 0, pr.D, self.d_emb, 0, Ec, R, pr.D_in, accumulate=True)
+        main.wait_stream(s_pp)
+        ops.copy_cols(self.dS, 0, 2 * Ec, self.d_emb, 0, T * Ec, B, Ec, accumulate=True)
+        ops.copy_cols(self.dgin, 0, Ec, self.d_emb, (T - 1) * Ec, T * Ec, B, Ec, accumulate=True)
     for j, c in enumerate(cams):
         H, W = hw[c]
-        ops.copy_cols(self.d_emb, 32 * j, Ec, self.f_dout[c], 0, 32, R, 32)
+        if not one:
+            ops.copy_cols(self.d_emb, 32 * j, Ec, self.f_dout[c], 0, 32, R, 32)
         fused = (cd == BF16 and xd == BF16 and bool(ops.L.lib().tacorl_encoder_fused_supported(H, W))
                  and ops.L.lib().tacorl_encoder_bwd_fused_ws_bytes(1, ops.int_array([R]), H, W) > 0)  # forward and backward
         ops.encoder_bwd([self.frames[c]], [net.enc(c)], [self.f_act[c]], [self.f_dout[c]], [net.enc(c, net.grad)], H, W, cd,
