@@ -530,6 +530,7 @@ int tacorl_logistic_mixture_sample(const float* heads, int ldh, const float* ran
 /* ---- backward glue: ReLU-RNN BPTT, transformer, seq-VAE KL ---------------------------------- */
 int tacorl_relu_mask_mul(const float* dy, const float* add, const float* h, float* out, long n,
                          tacorl_stream_t stream);
+/* accumulate: 0 = overwrite rows t < Tm, 1 = add to them, 2 = overwrite them and zero the rows Tm <= t < T */
 int tacorl_ad_input_bwd(const float* dx, float* d_plan, float* d_emb, int ld_emb, int B, int T, int Tm,
                         int P, int E, int accumulate, tacorl_stream_t stream);
 /* PlayLMP.training_step (reference play_lmp_for_rl.py:200-257): the gradient entering the encoders in one launch.

@@ -630,10 +630,11 @@ extern "C" int tacorl_relu_mask_mul(const float* dy, const float* add, const flo
 }
 
 // Backward of build_ad_input: d_plan[b] = sum_t dx[(t,b)][0:P]; d_emb[(b*T+t)][0:E] (+)= dx[(t,b)][P:], t < Tm.
+// accumulate = 2: overwrite AND zero the rows t >= Tm (the whole [B T][E] block is defined afterwards: no fill launch in front).
 __global__ void ad_input_bwd_kernel(const float* __restrict__ dx, float* __restrict__ d_plan, float* __restrict__ d_emb,
                                     int ld_emb, int B, int T, int Tm, int P, int E, int accumulate) {
-  const int W = P + E;
-  const long total = (long)B * (P + (long)Tm * E);
+  const int W = P + E, Te = accumulate == 2 ? T : Tm;
+  const long total = (long)B * (P + (long)Te * E);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     if (i < (long)B * P) {
       const int b = (int)(i / P), c = (int)(i % P);
@@ -644,16 +645,16 @@ __global__ void ad_input_bwd_kernel(const float* __restrict__ dx, float* __restr
       const long j = i - (long)B * P;
       const int c = (int)(j % E);
       const long r = j / E;
-      const int t = (int)(r % Tm), b = (int)(r / Tm);
+      const int t = (int)(r % Te), b = (int)(r / Te);
       float* d = d_emb + ((long)b * T + t) * ld_emb + c;
-      const float v = dx[((long)t * B + b) * W + P + c];
-      *d = accumulate ? *d + v : v;
+      const float v = t < Tm ? dx[((long)t * B + b) * W + P + c] : 0.f;
+      *d = accumulate == 1 ? *d + v : v;
     }
   }
 }
 extern "C" int tacorl_ad_input_bwd(const float* dx, float* d_plan, float* d_emb, int ld_emb, int B, int T, int Tm, int P,
                                    int E, int accumulate, tacorl_stream_t stream) {
-  const long total = (long)B * (P + (long)Tm * E);
+  const long total = (long)B * (P + (long)(accumulate == 2 ? T : Tm) * E);
   if (total <= 0) return TACORL_OK;
   hipLaunchKernelGGL(ad_input_bwd_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dx,
                      d_plan, d_emb, ld_emb, B, T, Tm, P, E, accumulate);

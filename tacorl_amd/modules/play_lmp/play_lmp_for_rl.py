@@ -476,9 +476,13 @@ def _playlmp_fwd_bwd(self, B, T, hw, acts, gs):
     ops.mark("ad:loss")
     # ---- backward
     ad.backward(B, T - 1, cd, need_input_grad=True, wgrad_stream=s_wg, join=False, prepared=ad_prepared)
-    self.d_emb.zero_()
-    call("tacorl_ad_input_bwd", ptr(ad.dx_seq), ptr(self.d_plan), ptr(self.d_emb), Ec, B, T, T - 1, ad.P, ad.E, 1,
-         ops.stream())
+    if ad.E == Ec:  # (the decoder sees every camera's embedding: its share defines the whole block - no fill launch in front)
+        call("tacorl_ad_input_bwd", ptr(ad.dx_seq), ptr(self.d_plan), ptr(self.d_emb), Ec, B, T, T - 1, ad.P, ad.E, 2,
+             ops.stream())
+    else:
+        self.d_emb.zero_()
+        call("tacorl_ad_input_bwd", ptr(ad.dx_seq), ptr(self.d_plan), ptr(self.d_emb), Ec, B, T, T - 1, ad.P, ad.E, 1,
+             ops.stream())
     ops.mark("ad:bwd")
     call("tacorl_pr_sample_bwd", ptr(head_pr), ptr(self.noise["eps_plan"]), ptr(self.d_plan), ptr(self.d_head_pr), B, A,
          float(pr.min_std), ops.stream())
