@@ -267,7 +267,10 @@ class ActionDecoderLogistic:
         # (the fused projection exists only on the ring-GEMM path: with a hidden size that path does not take - H % 128 != 0 -
         # the generic per-step path below reads x_seq, so it must be built; 32 <= K: the kernel's first k-step is unmasked)
         proj_fused = (fast and 32 <= K <= 64 and K % 8 == 0 and H % 16 == 0 and getattr(self, "fused_input_proj", True))
-        if not (proj_fused and frozen):
+        # (the K extension of the ring GEMM takes input widths up to 128: two cameras + a 32-wide plan = 96 at C4, where the
+        # separate projection was a generic GEMM launch at the head of the step's critical branch)
+        ring = fast and self._ring_proj() and getattr(self, "fused_input_proj", True) and (proj_fused or twin is None)
+        if not ((proj_fused or ring) and frozen):
             call("tacorl_build_ad_input", ptr(plan), ptr(emb), ld_emb, ptr(self.x_seq), B, T, Tm, self.P, self.E,
                  ops.stream())
         ver = blk.param._version
@@ -286,7 +289,6 @@ class ActionDecoderLogistic:
             # input projection of step s-2l+1 of layers l >= 1 (operand h_{l-1}[s-2l+1] left launch s-1) as
             # independent problems of ONE batched ring-GEMM launch whose workgroups are co-resident:
             # T + 2(L-1) dependent launches instead of L*T + (L-1).
-            ring = proj_fused and self._ring_proj()
             if ring:
                 call("tacorl_build_ad_input_bf16", ptr(plan), ptr(emb), ld_emb, ptr(self.xb_seq), B, T, Tm, self.P, self.E, ops.stream())
             elif proj_fused:
