@@ -342,6 +342,20 @@ def test_encoder_fused_forward(H, W):
         assert relerr(outs_f[i], refs[i]) < TOL_BF16, ("vs oracle", relerr(outs_f[i], refs[i]))
         e = relerr(outs_f[i], refs_r[i])
         assert e < FWD_BF16_ROUNDED, ("vs oracle with bf16 operand rounding", e)
+    # the same launch on a workgroup budget (tacorl_encoder_fwd_fused_wg: TACORL runs the update's own problems on 192
+    # workgroups beside the plan recognition): which workgroup serves which image changes nothing - bit-identical outputs
+    for budget in (3, 100):
+        outs_b = [torch.full((k, 32), float("nan"), device=dev) for k in n]
+        acts_b = [torch.full_like(a, float("nan")) for a in acts]
+        ops.call("tacorl_encoder_fwd_fused_wg", len(n), ops.ptr_array(imgs), ops.ptr_array(packed), ops.ptr_array(flats),
+                 ops.ptr_array(outs_b), ops.ptr_array([acts_b[0], None, acts_b[2]]), ops.int_array(n), H, W, budget, ops.stream())
+        torch.cuda.synchronize()
+        for i in range(len(n)):
+            assert torch.equal(outs_b[i], outs_f[i]), (budget, i)
+        for i in (0, 2):
+            assert torch.equal(acts_b[i].view(torch.int32), acts_f[i].view(torch.int32)), (budget, i)
+    assert _lib.lib().tacorl_encoder_fwd_fused_wg(len(n), ops.ptr_array(imgs), ops.ptr_array(packed), ops.ptr_array(flats), ops.ptr_array(outs_f),
+                                                  None, ops.int_array(n), H, W, 2, ops.stream()) != 0  # fewer workgroups than problems
     for i in (0, 2):  # saved activations (what tacorl_encoder_bwd reads) equal the per-layer path's
         offs, tot = ops.encoder_act_layout(n[i], H, W)
         for j, name in enumerate(["y1", "y2", "y3", "softargmax", "fc1"]):
