@@ -1142,6 +1142,66 @@ def test_transpose_to_bf16_batch():
     assert rc != 0
 
 
+@pytest.mark.parametrize("ncam", [1, 2])
+def test_playlmp_demb_assembly(ncam):
+    """tacorl_ad_input_bwd(accumulate=2) defines the whole d_emb block (rows beyond the decoder's window zeroed, no fill launch)
+    and tacorl_plmp_demb_finish adds the other three shares and slices the cameras - against torch, bit for bit (each element
+    is a sum of at most four terms in a fixed order)."""
+    from tacorl_amd import ops
+
+    dev = _dev()
+    B, T, P, Ec = 5, 6, 16, 32 * ncam
+    Tm, D, D_in = T - 1, 64, Ec
+    dx_seq = rnd(Tm * B, P + Ec, seed=1).to(dev)
+    d_plan = torch.full((B, P), float("nan"), device=dev)
+    d_emb = torch.full((B * T, Ec), float("nan"), device=dev)
+    ops.call("tacorl_ad_input_bwd", ops.ptr(dx_seq), ops.ptr(d_plan), ops.ptr(d_emb), Ec, B, T, Tm, P, Ec, 2, ops.stream())
+    torch.cuda.synchronize()
+    x = dx_seq.view(Tm, B, P + Ec)
+    exp = torch.zeros(B, T, Ec, device=dev)
+    exp[:, :Tm] = x[:, :, P:].transpose(0, 1)
+    assert torch.equal(d_emb.view(B, T, Ec), exp)
+    assert relerr(d_plan, x[:, :, :P].sum(0)) < 1e-6
+    dx_pr, dS, dgin = rnd(B * T, D, seed=2).to(dev), rnd(B, 2 * Ec, seed=3).to(dev), rnd(B, Ec, seed=4).to(dev)
+    f_dout = [torch.full((B * T, 32), float("nan"), device=dev) for _ in range(ncam)]
+    ops.call("tacorl_plmp_demb_finish", ops.ptr(d_emb), ops.ptr(dx_pr), D, D_in, ops.ptr(dS), 2 * Ec, ops.ptr(dgin), ops.ptr_array(f_dout),
+             ncam, B, T, Ec, ops.stream())
+    torch.cuda.synchronize()
+    want = exp + dx_pr.view(B, T, D)[:, :, :D_in]
+    want[:, 0] = want[:, 0] + dS[:, :Ec]
+    want[:, T - 1] = want[:, T - 1] + dgin
+    assert torch.equal(d_emb.view(B, T, Ec), want)
+    for j in range(ncam):
+        assert torch.equal(f_dout[j], want.view(B * T, Ec)[:, 32 * j: 32 * j + 32])
+
+
+def test_logistic_mixture_lazy_finish():
+    """A logging-only loss may leave its per-block partial sums on the device (loss_out = NULL) and have them summed later:
+    tacorl_logistic_mixture_finish gives the very two floats the one-call form writes."""
+    from tacorl_amd import _lib, ops
+
+    dev = _dev()
+    B, T, Da, K = 9, 7, 6, 10
+    Tm, ldh = T - 1, 192
+    heads = rnd(Tm * B, ldh, seed=5).to(dev)
+    actions = (rnd(B, T, Da + 1, seed=6).clamp(-1, 1)).to(dev)
+    actions[..., -1] = torch.where(actions[..., -1] >= 0, 1.0, -1.0)
+    nb = _lib.lib().tacorl_logistic_mixture_ws_bytes(B, Tm, Da)
+    outs = []
+    for lazy in (False, True):
+        ws = torch.zeros(max(256, nb), dtype=torch.uint8, device=dev)
+        out = torch.full((2,), float("nan"), device=dev)
+        ops.call("tacorl_logistic_mixture_loss", ops.ptr(heads), ldh, ops.ptr(actions), None, None if lazy else ops.ptr(out), B, T, Tm, Da, K,
+                 10, 0.0095, 1.0, ops.ptr(ws), ws.numel(), ops.stream())
+        if lazy:
+            torch.cuda.synchronize()
+            assert torch.isnan(out).all()  # nothing written yet
+            ops.call("tacorl_logistic_mixture_finish", ops.ptr(ws), ws.numel(), B, Tm, Da, ops.ptr(out), ops.stream())
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
 def test_rnn_bptt_step_and_transpose():
     """BPTT step through the ring GEMM: (x Wt^T + addend) * [mask > 0] with Wt from the transpose kernel."""
     from tacorl_amd import ops
