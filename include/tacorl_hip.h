@@ -190,7 +190,7 @@ int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const void* cons
 /* The same launch on at most max_workgroups workgroups (0 = one per CU): fewer than the CU count leaves CUs to a concurrent
  * branch of the caller's graph - TACORL issues the frozen LMP window's problems first, forks the plan recognition ->
  * action decoder branch (reference tacorl.py:142-179, 206-233: neither depends on the actor / critic encoders) and runs the
- * update's own encoder problems beside it on 192 workgroups. */
+ * update's own encoder problems beside it on 160 workgroups. */
 int tacorl_encoder_fwd_fused_wg(int nprob, const void* const* img, const void* const* packed,
                                 const float* const* params, float* const* out, float* const* act,
                                 const int* n_img, int H, int W, int max_workgroups, tacorl_stream_t stream);

@@ -354,10 +354,10 @@ class ACEngine:
         return pr
 
     def encode_split(self, between):
-        """Experiment (TACORL_EF_SPLIT_LMP=1, fused path only): the frozen extra problems (TACORL: the LMP window, whose
+        """(TACORL_EF_SPLIT_LMP, fused path only): the frozen extra problems (TACORL: the LMP window, whose
         embeddings the plan recognition -> action decoder branch waits for) as a launch of their own FIRST, `between()` (the
-        caller forks that branch there), then the update's own problems on TACORL_EF_SPLIT_BUDGET workgroups (default 192:
-        64 CUs stay free for the branch).  Returns False when the split does not apply (nothing launched)."""
+        caller forks that branch there), then the update's own problems on TACORL_EF_SPLIT_BUDGET workgroups (default 160:
+        96 CUs stay free for the branch; sweep 96 .. 240 on C4 / C3: 128 - 160 best).  Returns False when the split does not apply (nothing launched)."""
         groups = self._fused_groups()
         if not self.extra_enc or len(groups) != 1 or sorted(groups[0]) != sorted(self.cams) or not all(self._fused_bwd_ok(c) for c in self.cams):
             return False
@@ -367,7 +367,7 @@ class ACEngine:
             for c in cs:
                 self._pack_encoders(c, list({id(x[1]): x[1] for x in pr if x[6] == c}.values()), only_stale=self.ef_pack_late)
             if which == "own":
-                self._launch_fused(cs[0], pr, max_wg=int(os.environ.get("TACORL_EF_SPLIT_BUDGET", "192")))
+                self._launch_fused(cs[0], pr, max_wg=int(os.environ.get("TACORL_EF_SPLIT_BUDGET", "160")))
             else:
                 self._launch_fused(cs[0], pr)
                 between()

@@ -298,7 +298,7 @@ class TACORL(CQL_Offline):
                 ad_prep = torch.cuda.Event()
                 ad_prep.record(self._side_stream)
         # The frozen LMP window's encoder problems as a launch of their own FIRST, the plan recognition -> action decoder
-        # branch forked right behind it, the update's own encoder problems after that on 192 workgroups (engine.encode_split):
+        # branch forked right behind it, the update's own encoder problems after that on 160 workgroups (engine.encode_split):
         # where that branch is the step's longer chain it starts ~80 us earlier.  Measured (round 5): C4's share (window 32: 33
         # recurrent launches of 64 rows; `ad:end` 1 017 us against `c:adam` 864) 1.274 - 1.293 -> 1.222 - 1.238 ms/step in six
         # of seven runs (one read 1.337: whose workgroups get the freed CUs first is a race); the headline step (window 16,
