@@ -38,6 +38,23 @@ def test_layout_queries_run_without_gpu():
     assert w[0] == 0 and b[0] == 71 * 256 and tot >= 71 * 256 + 256 + 256 + 1
 
 
+def test_launch_batch_state_machine_without_gpu():
+    """tacorl_prep_batch_* / tacorl_reduce_batch_*: begin / end pair up per thread, nesting and a stray end are refused, and an
+    EMPTY batch launches nothing (so this runs without a GPU); supported-shape queries of the round-5 entry points."""
+    from tacorl_amd import _lib
+
+    L = _lib.lib()
+    for begin, end in ((L.tacorl_prep_batch_begin, L.tacorl_prep_batch_end), (L.tacorl_reduce_batch_begin, L.tacorl_reduce_batch_end)):
+        assert end(None) != 0          # no open batch
+        assert begin() == 0
+        assert begin() != 0            # no nesting
+        assert end(None) == 0          # empty: nothing to launch
+        assert end(None) != 0
+        assert begin() == 0 and end(None) == 0
+    assert L.tacorl_rnn_linear_supported(3840, 2048, 192) == 1 and L.tacorl_rnn_linear_supported(256, 100, 64) == 0
+    assert L.tacorl_encoder_fused_supported(84, 84) == 1 and L.tacorl_encoder_fused_supported(150, 200) == 0  # (DESIGN: why not)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from tacorl_amd import _lib
 
