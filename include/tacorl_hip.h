@@ -102,6 +102,11 @@ int tacorl_rnn_linear_bwd_step(const void* x_bf16, const void* wt_bf16, const fl
 int tacorl_rnn_wgrad_supported(int R, int M, int N);
 int tacorl_rnn_wgrad(const void* dz_bf16, int ld_dz, const void* x_bf16, int ld_x, int R, int M, int N, float* dw,
                      float* db, int accumulate, tacorl_stream_t stream);
+/* n <= 4 such gradients of one output shape in ONE launch (row counts R[p] may differ; db[p] may be NULL): the weight
+ * gradients of nn.RNN's square matrices - weight_hh of every layer, weight_ih of the upper ones (reference rnn_models.py:5-16,
+ * autograd) - behind the BPTT. */
+int tacorl_rnn_wgrad_batch(int n, const void* const* dz_bf16, int ld_dz, const void* const* x_bf16, int ld_x, const int* R,
+                           int M, int N, float* const* dw, float* const* db, int accumulate, tacorl_stream_t stream);
 /* The same products for a FEW output rows and many reduction rows (the action decoder's 182 x H output heads): dz bf16
  * [R][ld_dz] with Mp >= rows columns in use (Mp % 128 == 0, columns >= rows zero), x bf16 [R][ld_x]; R is cut into `slabs` row
  * ranges (R % (64 slabs) == 0) that run side by side, a second launch sums the partial results in slab order into

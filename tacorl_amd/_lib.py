@@ -39,6 +39,7 @@ _SIGS = {
     "tacorl_rnn_linear_bwd_batch": (_i, [_i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p]),
     "tacorl_rnn_wgrad_supported": (_i, [_i, _i, _i]),
     "tacorl_rnn_wgrad": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _i, _p]),
+    "tacorl_rnn_wgrad_batch": (_i, [_i, _p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _p]),
     "tacorl_rnn_wgrad_slabs_ws_bytes": (_sz, [_i, _i, _i]),
     "tacorl_rnn_wgrad_slabs": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _sz, _p]),
     "tacorl_transpose_to_bf16": (_i, [_p, _p, _i, _i, _p]),

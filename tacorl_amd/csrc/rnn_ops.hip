@@ -293,9 +293,9 @@ __device__ __forceinline__ bf16x8 tr_frag8(const unsigned char* lo, const unsign
 constexpr int WG_T = 128, WG_NW = 8;  // tile edge, waves
 
 template <int WG_R, int WG_S>  // rows per stage, stages
-__global__ __launch_bounds__(64 * WG_NW) void rnn_wgrad_kernel(const __bf16* __restrict__ dz, int ld_dz, const __bf16* __restrict__ x,
-                                                               int ld_x, int R, int MT, int NT, float* __restrict__ dw, int ld_w,
-                                                               float* __restrict__ db, int accumulate) {
+__device__ __forceinline__ void rnn_wgrad_body(const __bf16* __restrict__ dz, int ld_dz, const __bf16* __restrict__ x, int ld_x, int R,
+                                               int MT, int NT, float* __restrict__ dw, int ld_w, float* __restrict__ db,
+                                               int accumulate) {
   // tile map: XCD b % 8 owns a block of m tiles x n tiles (its operand columns stay in its L2 while all of its
   // workgroups walk down r together); any assignment computes the same result
   int mt, nt;
@@ -396,6 +396,24 @@ __global__ __launch_bounds__(64 * WG_NW) void rnn_wgrad_kernel(const __bf16* __r
   }
 }
 
+template <int WG_R, int WG_S>
+__global__ __launch_bounds__(64 * WG_NW) void rnn_wgrad_kernel(const __bf16* __restrict__ dz, int ld_dz, const __bf16* __restrict__ x,
+                                                               int ld_x, int R, int MT, int NT, float* __restrict__ dw, int ld_w,
+                                                               float* __restrict__ db, int accumulate) {
+  rnn_wgrad_body<WG_R, WG_S>(dz, ld_dz, x, ld_x, R, MT, NT, dw, ld_w, db, accumulate);
+}
+// Several weight gradients of one output shape in ONE launch (blockIdx.z = problem; row counts may differ): the RNN's square
+// matrices - W_hh of every layer and W_ih of the upper layers - were one launch each behind the BPTT, every one ingest-bound at
+// one 64 KB workgroup per CU; together two workgroups share a CU and one's LDS-DMA runs under the other's MFMAs (round 5).
+#define RNN_WG_MAXP 4
+struct RnnWgBatch { const __bf16* dz[RNN_WG_MAXP]; const __bf16* x[RNN_WG_MAXP]; float* dw[RNN_WG_MAXP]; float* db[RNN_WG_MAXP]; int R[RNN_WG_MAXP]; };
+template <int WG_R, int WG_S>
+__global__ __launch_bounds__(64 * WG_NW) void rnn_wgrad_batch_kernel(RnnWgBatch b, int ld_dz, int ld_x, int MT, int NT, int ld_w,
+                                                                     int accumulate) {
+  const int p = blockIdx.z;
+  rnn_wgrad_body<WG_R, WG_S>(b.dz[p], ld_dz, b.x[p], ld_x, b.R[p], MT, NT, b.dw[p], ld_w, b.db[p], accumulate);
+}
+
 constexpr int WG_RMIN = 64;
 extern "C" int tacorl_rnn_wgrad_supported(int R, int M, int N) {
   return R >= WG_RMIN && R % WG_RMIN == 0 && M >= WG_T && M % WG_T == 0 && N >= WG_T && N % WG_T == 0 ? 1 : 0;
@@ -420,6 +438,25 @@ extern "C" int tacorl_rnn_wgrad(const void* dz_bf16, int ld_dz, const void* x_bf
   // measured (R = 3840, 2048 x 2048, us): 64 rows x 2 stages 59.6, x 3 72.2, x 4 58.1, 128 x 2 83.8, 32 x 4 77.2 - the launch
   // moves 491 MB through LDS-DMA at 8.5 TB/s, the same chip-wide ingest rate the ring GEMM's DMA-only run reaches
   return launch_wgrad<64, 2>(dz_bf16, ld_dz, x_bf16, ld_x, R, M, N, dw, db, accumulate, (hipStream_t)stream);
+}
+
+/* n <= 4 such gradients of one (M, N) in one launch: dw[p][M][N] (+)= dz[p]^T x[p] over R[p] rows (db[p] may be NULL) */
+extern "C" int tacorl_rnn_wgrad_batch(int n, const void* const* dz_bf16, int ld_dz, const void* const* x_bf16, int ld_x, const int* R,
+                                      int M, int N, float* const* dw, float* const* db, int accumulate, tacorl_stream_t stream) {
+  if (n < 1 || n > RNN_WG_MAXP || ld_dz % 8 || ld_x % 8 || ld_dz < M || ld_x < N) return TACORL_EINVAL;
+  RnnWgBatch b{};
+  for (int p = 0; p < n; p++) {
+    if (!tacorl_rnn_wgrad_supported(R[p], M, N)) return TACORL_EINVAL;
+    if (((uintptr_t)dz_bf16[p] | (uintptr_t)x_bf16[p] | (uintptr_t)dw[p]) & 15) return TACORL_EINVAL;
+    b.dz[p] = (const __bf16*)dz_bf16[p]; b.x[p] = (const __bf16*)x_bf16[p]; b.dw[p] = dw[p]; b.db[p] = db ? db[p] : nullptr; b.R[p] = R[p];
+  }
+  constexpr int lds = 2 * 2 * 64 * WG_T * 2;
+  auto kern = rnn_wgrad_batch_kernel<64, 2>;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess ? 0 : -1;
+  if (once) return TACORL_ELAUNCH;
+  const int MT = M / WG_T, NT = N / WG_T;
+  hipLaunchKernelGGL(kern, dim3(MT * NT, 1, n), dim3(64 * WG_NW), lds, (hipStream_t)stream, b, ld_dz, ld_x, MT, NT, N, accumulate);
+  return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
 // out[r][c] (+)= sum over slabs of part[s][r][c] for r < rows (slab pitch Mp rows), in slab order; the bias column likewise

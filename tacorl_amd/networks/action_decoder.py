@@ -444,9 +444,36 @@ class ActionDecoderLogistic:
              ops.ptr_array([addend]) if addend is not None else None, ld_add, ops.int_array([M]), O, I, compute,
              ptr(ws), ws.numel(), ops.stream())
 
-    def _layer_wgrads(self, l, B, Tm, compute, fast):
+    def _square_wgrads(self, B, Tm):
+        """The square matrices' gradients of ALL layers (W_hh_l, W_ih_l for l >= 1, the latter with the bias) in one launch
+        (rnn_ops.hip tacorl_rnn_wgrad_batch; 2 L - 1 launches before), the bias copies behind it.  Returns False when the shapes
+        do not qualify - the caller then goes layer by layer."""
+        blk, H, R, L = self.blk, self.hidden, B * Tm, self.L
+        sup = ops.L.lib().tacorl_rnn_wgrad_supported
+        if (os.environ.get("TACORL_AD_WGRAD_BATCH", "1") != "1" or not getattr(self, "wgrad_batched", True) or Tm < 2
+                or 2 * L - 1 > 4 or L < 2 or not sup((Tm - 1) * B, H, H) or not sup(R, H, H)):
+            return False
+        bfp = lambda t, off: C.c_void_p(t.data_ptr() + 2 * off)  # noqa: E731
+        dz, x, rows, dw, db = [], [], [], [], []
+        for l in range(L):
+            dz.append(bfp(self.DZb[l], B * H)); x.append(ptr(self.hb[l])); rows.append((Tm - 1) * B)
+            dw.append(blk.g(f"rnn.weight_hh_l{l}")); db.append(None)
+        for l in range(1, L):
+            dz.append(ptr(self.DZb[l])); x.append(ptr(self.hb[l - 1])); rows.append(R)
+            dw.append(blk.g(f"rnn.weight_ih_l{l}")); db.append(blk.g(f"rnn.bias_ih_l{l}"))
+        call("tacorl_rnn_wgrad_batch", len(dz), ops.ptr_array(dz), H, ops.ptr_array(x), H, ops.int_array(rows), H, H,
+             ops.ptr_array(dw), ops.ptr_array(db), 0, ops.stream())
+        return True
+
+    def _layer_wgrads(self, l, B, Tm, compute, fast, square_done=False):
         """W_hh / W_ih / bias gradients of layer l (its BPTT has been issued)."""
         blk, H, R = self.blk, self.hidden, B * Tm
+        if square_done:  # _square_wgrads has the square matrices: layer 0's input matrix and the bias copies are left
+            if l == 0:
+                self._wgrad(self.x_seq, self.P + self.E, self.DZ[0], H, R, self.P + self.E, H, blk.g("rnn.weight_ih_l0"),
+                            blk.g("rnn.bias_ih_l0"), compute)
+            call("tacorl_copy_cols", blk.g(f"rnn.bias_ih_l{l}"), H, blk.g(f"rnn.bias_hh_l{l}"), H, 1, H, 0, 0, ops.stream())
+            return
         h, DZ, at = self.h[l], self.DZ[l], ops._at
         # the square matrices' gradients straight from the bf16 copies the ring GEMMs left (hb: forward, DZb: BPTT):
         # one launch per matrix, no slabs (rnn_ops.hip rnn_wgrad_kernel); other shapes: the generic split-R GEMM
@@ -576,8 +603,11 @@ class ActionDecoderLogistic:
             self._ensure_bptt(B, Tm)
         if fast and Tm > 1 and 2 * L - 1 <= 4 and wavefront and getattr(self, "bptt_wavefront", True):
             self._bptt_wavefront(B, Tm, prepared)
-            for l in reversed(range(L)):
-                side(lambda l=l: self._layer_wgrads(l, B, Tm, compute, fast))
+            def all_wgrads():
+                sq = self._square_wgrads(B, Tm)
+                for l in reversed(range(L)):
+                    self._layer_wgrads(l, B, Tm, compute, fast, sq)
+            side(all_wgrads)
             if need_input_grad:
                 K = self.P + self.E
                 self._dgrad(self.DZ[0], H, blk.p("rnn.weight_ih_l0"), self.dx_seq, K, R, H, K, compute)

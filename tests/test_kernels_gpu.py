@@ -1282,6 +1282,39 @@ def test_rnn_wgrad(R, M, N, ld, accumulate):
     assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("rows,M,accumulate", [((192, 192, 256), 256, False), ((3584, 3584, 3840, 3840), 2048, False), ((128,), 128, True)])
+def test_rnn_wgrad_batch(rows, M, accumulate):
+    """Several square weight gradients with different row counts in ONE launch (the RNN's W_hh_l / W_ih_l behind the BPTT):
+    bit-identical to one tacorl_rnn_wgrad launch per matrix (same kernel body, same summation order); > 4 problems, a bad
+    row count and misaligned pointers are refused."""
+    from tacorl_amd import _lib, ops
+
+    dev = _dev()
+    n = len(rows)
+    dz = [rnd(r, M, seed=10 + i).to(torch.bfloat16).to(dev) for i, r in enumerate(rows)]
+    x = [rnd(r, M, seed=20 + i).to(torch.bfloat16).to(dev) for i, r in enumerate(rows)]
+    base = 0.5 if accumulate else float("nan")
+    mk = lambda *s: torch.full(s, base, device=dev)  # noqa: E731
+    dw, db = [mk(M, M) for _ in rows], [mk(M) if i % 2 else None for i in range(n)]
+    dw1, db1 = [mk(M, M) for _ in rows], [mk(M) if i % 2 else None for i in range(n)]
+    args = lambda R, W, Bs: (n, ops.ptr_array(dz), M, ops.ptr_array(x), M, ops.int_array(list(R)), M, M, ops.ptr_array(W),  # noqa: E731
+                             ops.ptr_array(Bs), int(accumulate), ops.stream())
+    ops.call("tacorl_rnn_wgrad_batch", *args(rows, dw, db))
+    for i, r in enumerate(rows):
+        ops.call("tacorl_rnn_wgrad", ops.ptr(dz[i]), M, ops.ptr(x[i]), M, r, M, M, ops.ptr(dw1[i]), ops.ptr(db1[i]) if db1[i] is not None else None,
+                 int(accumulate), ops.stream())
+    torch.cuda.synchronize()
+    off = 0.5 if accumulate else 0.0
+    for i in range(n):
+        assert torch.equal(dw[i], dw1[i])
+        assert relerr(dw[i] - off, dz[i].float().t() @ x[i].float()) < 1e-5
+        if db[i] is not None:
+            assert torch.equal(db[i], db1[i])
+    f = _lib.lib().tacorl_rnn_wgrad_batch
+    assert f(*args(tuple(r + 32 for r in rows), dw, db)) != 0
+    assert f(5, *args(rows, dw, db)[1:]) != 0 and f(0, *args(rows, dw, db)[1:]) != 0
+
+
 @pytest.mark.parametrize("R,slabs,rows,N,accumulate", [(3840, 6, 182, 2048, False), (512, 8, 182, 2048, True), (128, 2, 100, 256, False),
                                                         (64, 1, 128, 128, False)])
 def test_rnn_wgrad_slabs(R, slabs, rows, N, accumulate):
