@@ -2,6 +2,7 @@
 // Linear / conv forward, backward-data, backward-weights (split-R slabs + reduce),
 // spatial soft-argmax, and the composite LMPVisionEncoder / MLP forward+backward.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -348,7 +349,15 @@ __global__ void slab_reduce_kernel_tbl(PtrTable t, int nsplit, int O, int K, int
   const long per = (long)O * (K + 1);
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int i = 0; i < nsplit; i++) s += slab[i * per + e];
+    int i = 0;
+    for (; i + 8 <= nsplit; i += 8) {  // eight slabs' values in flight, summed in slab order as before
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = slab[(i + j) * per + e];
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += v[j];
+    }
+    for (; i < nsplit; i++) s += slab[i * per + e];
     const int o = (int)(e / (K + 1)), k = (int)(e - (long)o * (K + 1));
     float* dst = (k == K) ? (db ? db + o : nullptr) : dw + (long)o * K + k;
     if (dst) *dst = accumulate ? *dst + s : s;
@@ -391,7 +400,11 @@ static int k_wgrad(LA& la, int nprob, const float* const* dz, int ld_dz, const i
     g.M[p] = K + 1; g.R[p] = R[p];
   }
   CHECK((gemm_launch<LA, RowMajorLoader, true, true, WgradStore>(la, lb, ep, g, cd, st)));
-  dim3 grid(cdiv(per, 256) > 256 ? 256 : cdiv(per, 256), nprob);
+  // up to 1024 workgroups (256 before: the 24-slab sums ran as 4 waves per CU, latency-bound).  PlayLMP, two processes per
+  // setting on one box: B = 32 1.195 -> 1.174 ms/step at 1024 (1.172 at 4096), B = 256 2.10 / 2.12 / 2.13 at 256 / 1024 / 4096
+  // (process noise +-1 %: wider crowds the step's other branches there) - round 5.  TACORL_SLAB_REDUCE_WGS overrides.
+  static const int cap = [] { const char* e = getenv("TACORL_SLAB_REDUCE_WGS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();
+  dim3 grid(cdiv(per, 256) > cap ? cap : cdiv(per, 256), nprob);
   hipLaunchKernelGGL(slab_reduce_kernel_tbl, grid, dim3(256), 0, st, t, ns, O, K, accumulate);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
