@@ -411,7 +411,8 @@ def test_playlmp_twin_pass_equals_own_pass(B):
 def test_bptt_wavefront_equals_per_layer():
     """Action-decoder backward at bench shapes: the wavefront of batched ring-GEMM launches (both layers' recurrent
     gradient steps + the projection onto the lower layer per launch) against one launch per (layer, step) + a projection
-    GEMM: same products in the same K order - the gradients agree to fp32 rounding."""
+    GEMM: same products in the same K order - the gradients agree to fp32 rounding; and the square weight gradients behind the
+    wavefront as one launch against one launch per matrix: bit-identical."""
     import bench
     from tacorl_amd.modules.play_lmp.play_lmp_for_rl import PlayLMP
 
@@ -424,17 +425,19 @@ def test_bptt_wavefront_equals_per_layer():
               rnn_model="rnn_decoder", include_goal=False)
     batch = bench.synth_batch(B, T, 84, 84, dev, 1)
     res = []
-    for wavefront in (True, False):
+    for wavefront, batched in ((True, True), (False, True), (True, False)):
         torch.manual_seed(0)
         m = PlayLMP(plan_proposal=actor, plan_recognition=pr, action_decoder=ad, plan_proposal_obs_modalities=cams,
                     plan_proposal_goal_modalities=cams, plan_recognition_modalities=cams, action_decoder_modalities=cams,
                     real_world=True, device=dev, compute_dtype="bf16", image_dtype="bf16")
-        m.ad.bptt_wavefront = wavefront
+        m.ad.bptt_wavefront, m.ad.wgrad_batched = wavefront, batched
         torch.manual_seed(5); torch.cuda.manual_seed(5)
         m.training_step(batch, 0)
         torch.cuda.synchronize()
         res.append((dict(m.logged), {k: v.clone() for k, v in m.named_gradients().items()}))
-    (la, ga), (lb, gb) = res
+    (la, ga), (lb, gb), (_, gc) = res
+    for k in ga:  # the square weight gradients as one launch (tacorl_rnn_wgrad_batch) or one launch each: the same sums
+        assert torch.equal(ga[k], gc[k]), k
     assert all(v == v for v in la.values())
     for k in la:
         assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
