@@ -5,7 +5,7 @@ import torch
 from tacorl_amd import _lib, ops
 from tacorl_amd.networks.plan_recognition import PlanRecognition
 dev = torch.device("cuda:0"); _lib.call("tacorl_hip_init", 0)
-B, T, D, A = 256, 16, 32, 16
+B, T, D, A = [int(x) for x in os.environ.get("PR_SHAPE", "256,16,32,16").split(",")]
 pr = PlanRecognition(state_dim=D, latent_plan_dim=A, device=dev, num_heads=8, num_layers=2, encoder_hidden_size=2048,
                      fc_hidden_size=4096, max_position_embeddings=T, trainable=False)
 emb = torch.randn(B * T, D, device=dev); eps = torch.randn(B, A, device=dev); plan = torch.zeros(B, A, device=dev)
