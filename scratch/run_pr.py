@@ -21,3 +21,18 @@ pr.prepare_inference()
 print(f"prepare_inference (bf16 mirror + head compose): {timeit(pr.prepare_inference):.1f} us")
 print(f"fused encoder + 2 GEMM head:                    {timeit(lambda: pr.forward(emb, D, B, T, 1, inference=True, prepared=True)):.1f} us")
 print(f"fused encoder + head + sample in launch:        {timeit(lambda: pr.forward(emb, D, B, T, 1, inference=True, sample=(eps, plan), prepared=True)):.1f} us")
+# phase stamps (only in a -DPR_STAMPS build: scratch/mklib_file.sh pr_st pr_fused.hip -DPR_STAMPS)
+import ctypes as C
+L = _lib.lib()
+if hasattr(L, "tacorl_pr_stamps_read") and D == 64:
+    buf = (C.c_ulonglong * 16)()
+    f = lambda: pr.forward(emb, D, B, T, 1, inference=True, sample=(eps, plan), prepared=True)
+    f(); torch.cuda.synchronize()
+    L.tacorl_pr_stamps_read(buf, 1)
+    for _ in range(10): f()
+    torch.cuda.synchronize()
+    L.tacorl_pr_stamps_read(buf, 0)
+    names = ["layer top (operand requests; first: x load)", "q|k|v", "attention", "out-proj + LN1 (+ put_xb)", "FFN chunks", "exchange + LN2"]
+    tot = sum(buf[:6])
+    for k, nm in enumerate(names): print(f"{nm:46s} {buf[k] / 10:9.0f} clk  {100.0 * buf[k] / tot:5.1f} %")
+    print("total clk per launch (wave 0 of workgroup 0, both layers)", tot / 10)

@@ -460,13 +460,60 @@ __device__ __forceinline__ void layer_norm64(f32x4 (&v)[4], const float* w, cons
   }
 }
 
+__device__ __forceinline__ void layer_norm64(f32x4 (&v)[4], const f32x4 (&ww)[4], const f32x4 (&bb)[4]) {  // same sums, operands in registers
+  float s = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) s += v[nt][r];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s / 64.f;
+  float q = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const float c = v[nt][r] - mean; q += c * c; }
+  q += __shfl_xor(q, 16, 64);
+  q += __shfl_xor(q, 32, 64);
+  const float rstd = 1.0f / sqrtf(q / 64.f + 1e-5f);
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[nt][r] = (v[nt][r] - mean) * rstd * ww[nt][r] + bb[nt][r];
+}
+
+// Phase clocks of the d_model-64 launch (scratch builds with -DPR_STAMPS only): wave 0 of workgroup 0 accumulates shader-clock
+// deltas per phase; read back (and reset) with tacorl_pr_stamps_read.
+#ifdef PR_STAMPS
+__device__ unsigned long long pr_stamps[16];
+#define PR_STAMP(k)                                          \
+  do {                                                       \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {               \
+      const unsigned long long t_ = clock64();               \
+      atomicAdd(&pr_stamps[k], t_ - t_prev);                 \
+      t_prev = t_;                                           \
+    }                                                        \
+  } while (0)
+#else
+#define PR_STAMP(k)
+#endif
+
 template <int RT>
 __global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
+#ifdef PR_STAMPS
+  unsigned long long t_prev = clock64();
+#endif
   constexpr int T = 16 * RT;
   constexpr int BIG = (T * QKV6_P * 4 > T * HB6_P * 2) ? T * QKV6_P * 4 : T * HB6_P * 2;
   __shared__ __attribute__((aligned(16))) __bf16 xb_s[4][T * XB6_P];
   __shared__ __attribute__((aligned(16))) unsigned char big_s[4][BIG];  // q|k|v (fp32) or FFN hidden chunk (bf16)
   __shared__ __attribute__((aligned(16))) float ypart[4][T * D6];
+  // The attention is SPLIT over the four waves (round 5; redundant before, as in the d_model-32 kernel): wave w owns heads 2 w and
+  // 2 w + 1 - the q / k / v column tiles w, 4 + w, 8 + w of the in-projection, 2 T (head, query) pairs - and writes its 16 columns
+  // of the result into this shared operand of the out-projection.  At T = 32 every lane read 2 x 32 B of k and of v per key as
+  // broadcast ds_read_b128 (1 KB of LDS return path for 32 distinct bytes), four waves at once: 35 % of the launch (phase clocks).
+  __shared__ __attribute__((aligned(16))) __bf16 xatt[T * XB6_P];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const int b = blockIdx.x;
   if (b >= a.B) return;  // block-uniform
@@ -500,30 +547,54 @@ __global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
   const int nchunk = a.FF / CH6;
   for (int l = 0; l < a.L; l++) {
     const PrLayerOff& o = a.l[l];
-    // ---- q|k|v = x Win^T + b  (12 N tiles, K = 64)
+    PR_STAMP(0);
+    // Operands are requested a phase ahead, in front of the LDS waits (which also fence memory for the compiler): fetched where
+    // they are consumed, each phase of this latency-bound launch began with an exposed L2 round trip (round 5; the d_model-32
+    // kernel above does the same).  Projection weights come from the bf16 mirror - the very values cvt8 of the fp32 block gives.
+    bf16x8 inw[3][2];
+    f32x4 inb[3];
+#pragma unroll
+    for (int k3 = 0; k3 < 3; k3++) {
+      const int nt = 4 * k3 + w;
+      inw[k3][0] = *reinterpret_cast<const bf16x8*>(a.Pb + o.in_w + (long)(16 * nt + i) * D6 + 8 * g);
+      inw[k3][1] = *reinterpret_cast<const bf16x8*>(a.Pb + o.in_w + (long)(16 * nt + i) * D6 + 32 + 8 * g);
+      inb[k3] = *reinterpret_cast<const f32x4*>(a.P + o.in_b + 16 * nt + 4 * g);
+    }
+    // ---- q|k|v = x Win^T + b  (this wave's 3 of the 12 N tiles, K = 64)
     put_xb(x);
     lds_sync();
     {
       bf16x8 xf[RT][2];
       get_xf(xf);
 #pragma unroll
-      for (int nt = 0; nt < 12; nt++) {
-        const bf16x8 wf0 = cvt8(a.P + o.in_w + (long)(16 * nt + i) * D6 + 8 * g), wf1 = cvt8(a.P + o.in_w + (long)(16 * nt + i) * D6 + 32 + 8 * g);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.in_b + 16 * nt + 4 * g);
+      for (int k3 = 0; k3 < 3; k3++) {
+        const int nt = 4 * k3 + w;
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
-          f32x4 acc = bias;
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, xf[rt][0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, xf[rt][1], acc, 0, 0, 0);
+          f32x4 acc = inb[k3];
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(inw[k3][0], xf[rt][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(inw[k3][1], xf[rt][1], acc, 0, 0, 0);
           *reinterpret_cast<f32x4*>(qkv + (16 * rt + i) * QKV6_P + 16 * nt + 4 * g) = acc;
         }
       }
     }
+    // (requested here, used behind the attention: out-projection and LayerNorm 1)
+    bf16x8 outw[4][2];
+    f32x4 outb[4], n1w[4], n1b[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+      outw[nt][0] = *reinterpret_cast<const bf16x8*>(a.Pb + o.out_w + (long)(16 * nt + i) * D6 + 8 * g);
+      outw[nt][1] = *reinterpret_cast<const bf16x8*>(a.Pb + o.out_w + (long)(16 * nt + i) * D6 + 32 + 8 * g);
+      outb[nt] = *reinterpret_cast<const f32x4*>(a.P + o.out_b + 16 * nt + 4 * g);
+      n1w[nt] = *reinterpret_cast<const f32x4*>(a.P + o.n1w + 16 * nt + 4 * g);
+      n1b[nt] = *reinterpret_cast<const f32x4*>(a.P + o.n1b + 16 * nt + 4 * g);
+    }
     lds_sync();
-    // ---- attention: 8 heads x T queries, 2 RT (head, query) pairs per lane, head_dim 8; result -> xb (bf16)
-#pragma unroll 1
-    for (int j = 0; j < 2 * RT; j++) {
-      const int p = lane + 64 * j, h = p / T, qi = p % T;
+    PR_STAMP(1);
+    // ---- attention: this wave's 2 heads x T queries, one (head, query) pair per lane (T = 16: the upper half of the wave repeats
+    // the lower one and does not store), head_dim 8; result -> xatt (bf16)
+    {
+      const int p = lane & (2 * T - 1), h = 2 * w + p / T, qi = p % T;
       f32x4 q0 = *reinterpret_cast<const f32x4*>(qkv + qi * QKV6_P + HD6 * h), q1 = *reinterpret_cast<const f32x4*>(qkv + qi * QKV6_P + HD6 * h + 4);
       const float sc = 0.35355339059327379f * 1.44269504088896341f;  // 1 / sqrt(8) and log2 e: the softmax runs on 2^x (round 5)
       q0 *= sc; q1 *= sc;
@@ -545,32 +616,60 @@ __global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
         const float pr = s[t] * rse;
         o0 += pr * v0; o1 += pr * v1;
       }
-      *reinterpret_cast<bf16x8*>(xb + qi * XB6_P + HD6 * h) =
-          bf16x8{(__bf16)o0[0], (__bf16)o0[1], (__bf16)o0[2], (__bf16)o0[3], (__bf16)o1[0], (__bf16)o1[1], (__bf16)o1[2], (__bf16)o1[3]};
+      if (lane < 2 * T)
+        *reinterpret_cast<bf16x8*>(xatt + qi * XB6_P + HD6 * h) =
+            bf16x8{(__bf16)o0[0], (__bf16)o0[1], (__bf16)o0[2], (__bf16)o0[3], (__bf16)o1[0], (__bf16)o1[1], (__bf16)o1[2], (__bf16)o1[3]};
     }
-    lds_sync();
+    // (requested here, used behind the out-projection: this wave's first hidden chunk of W1)
+    const __bf16* W1 = a.Pb + o.w1;
+    const __bf16* W2 = a.Pb + o.w2;
+    bf16x8 w1f[8][2], w2f[4][4];
+    auto fetch_w1 = [&](int c) {
+#pragma unroll
+      for (int nt = 0; nt < 8; nt++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) w1f[nt][ks] = *reinterpret_cast<const bf16x8*>(W1 + (long)(CH6 * c + 16 * nt + i) * D6 + 32 * ks + 8 * g);
+    };
+    auto fetch_w2 = [&](int c) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+          w2f[ks][nt] = *reinterpret_cast<const bf16x8*>(W2 + (long)(16 * nt + i) * a.FF + CH6 * c + 32 * ks + 8 * g);
+    };
+    const int c0 = w < nchunk ? w : nchunk - 1;  // (a wave without chunks prefetches in bounds and skips the loop)
+    fetch_w1(c0);
+    __syncthreads();  // the four waves' columns of the attention result (the previous layer's readers of xatt passed the two
+                      // barriers of its FFN exchange)
+    PR_STAMP(2);
     // ---- out-projection + residual + LayerNorm 1
     {
       bf16x8 af[RT][2];
-      get_xf(af);
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) af[rt][ks] = *reinterpret_cast<const bf16x8*>(xatt + (16 * rt + i) * XB6_P + 32 * ks + 8 * g);
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) {
-        const bf16x8 wf0 = cvt8(a.P + o.out_w + (long)(16 * nt + i) * D6 + 8 * g), wf1 = cvt8(a.P + o.out_w + (long)(16 * nt + i) * D6 + 32 + 8 * g);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.out_b + 16 * nt + 4 * g);
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
-          f32x4 acc = bias;
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, af[rt][0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, af[rt][1], acc, 0, 0, 0);
+          f32x4 acc = outb[nt];
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(outw[nt][0], af[rt][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(outw[nt][1], af[rt][1], acc, 0, 0, 0);
           x[rt][nt] += acc;
         }
       }
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++) layer_norm64(x[rt], a.P + o.n1w, a.P + o.n1b, g);
+      for (int rt = 0; rt < RT; rt++) layer_norm64(x[rt], n1w, n1b);
     }
-    lds_sync();  // every lane has read its out-projection operand before xb is overwritten
-    put_xb(x);
+    // (requested here, used behind the two waits below: the first chunk's W2 fragments, the FFN output bias)
+    fetch_w2(c0);
+    f32x4 b2v[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) b2v[nt] = *reinterpret_cast<const f32x4*>(a.P + o.b2 + 16 * nt + 4 * g);
+    put_xb(x);  // (the out-projection read xatt, not xb)
     lds_sync();
+    PR_STAMP(3);
     // ---- FFN: relu(x W1^T + b1) W2^T + b2, hidden in chunks of 128 kept in LDS as bf16
     bf16x8 xf[RT][2];
     get_xf(xf);
@@ -579,20 +678,8 @@ __global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
       for (int nt = 0; nt < 4; nt++)
-        y[rt][nt] = w == 0 ? *reinterpret_cast<const f32x4*>(a.P + o.b2 + 16 * nt + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const __bf16* W1 = a.Pb + o.w1;
-    const __bf16* W2 = a.Pb + o.w2;
+        y[rt][nt] = w == 0 ? b2v[nt] : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c = w; c < nchunk; c += 4) {
-      bf16x8 w1f[8][2], w2f[4][4];
-#pragma unroll
-      for (int nt = 0; nt < 8; nt++)
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) w1f[nt][ks] = *reinterpret_cast<const bf16x8*>(W1 + (long)(CH6 * c + 16 * nt + i) * D6 + 32 * ks + 8 * g);
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++)
-          w2f[ks][nt] = *reinterpret_cast<const bf16x8*>(W2 + (long)(16 * nt + i) * a.FF + CH6 * c + 32 * ks + 8 * g);
 #pragma unroll
       for (int nt = 0; nt < 8; nt++) {
         const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.b1 + CH6 * c + 16 * nt + 4 * g);
@@ -605,6 +692,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
               bf16x4{(__bf16)fmaxf(hacc[0], 0.f), (__bf16)fmaxf(hacc[1], 0.f), (__bf16)fmaxf(hacc[2], 0.f), (__bf16)fmaxf(hacc[3], 0.f)};
         }
       }
+      if (c + 4 < nchunk) fetch_w1(c + 4);  // (its registers are free: in flight under the second half of this chunk)
       lds_sync();
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
@@ -615,7 +703,16 @@ __global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
           for (int nt = 0; nt < 4; nt++) y[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks][nt], hf, y[rt][nt], 0, 0, 0);
         }
       }
+      if (c + 4 < nchunk) fetch_w2(c + 4);  // (in flight under the first half of the next chunk)
       lds_sync();  // hidden chunk consumed before the next one overwrites it
+    }
+    PR_STAMP(4);
+    // (requested in front of the workgroup barriers below: LayerNorm 2)
+    f32x4 n2w[4], n2b[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+      n2w[nt] = *reinterpret_cast<const f32x4*>(a.P + o.n2w + 16 * nt + 4 * g);
+      n2b[nt] = *reinterpret_cast<const f32x4*>(a.P + o.n2b + 16 * nt + 4 * g);
     }
     // the four partial FFN outputs meet in LDS (fixed summation order: every wave ends with the same bits)
     {
@@ -637,7 +734,8 @@ __global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
       __syncthreads();  // (one buffer: everyone has read the partials before the next layer's are written)
     }
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++) layer_norm64(x[rt], a.P + o.n2w, a.P + o.n2b, g);
+    for (int rt = 0; rt < RT; rt++) layer_norm64(x[rt], n2w, n2b);
+    PR_STAMP(5);
   }
   if (w != 0) return;  // every wave holds the same result: wave 0 writes it
   // ---- mean over the T time steps
@@ -1149,3 +1247,14 @@ extern "C" int tacorl_pr_encoder_bwd_fused(const float* params, const long* offs
   hipLaunchKernelGGL(pr_ln_reduce_kernel, dim3(2 * L), dim3(256), 0, (hipStream_t)stream, r);
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
+
+#ifdef PR_STAMPS
+extern "C" int tacorl_pr_stamps_read(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pr_stamps), sizeof(pr_stamps)) != hipSuccess) return TACORL_ELAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pr_stamps), z, sizeof(z)) != hipSuccess) return TACORL_ELAUNCH;
+  }
+  return TACORL_OK;
+}
+#endif
