@@ -624,11 +624,14 @@ __global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
     const __bf16* W1 = a.Pb + o.w1;
     const __bf16* W2 = a.Pb + o.w2;
     bf16x8 w1f[8][2], w2f[4][4];
+    f32x4 b1f[8];  // (the chunk's FFN1 biases travel with its W1 fragments: fetched inside the chunk they were one more exposed round trip)
     auto fetch_w1 = [&](int c) {
 #pragma unroll
-      for (int nt = 0; nt < 8; nt++)
+      for (int nt = 0; nt < 8; nt++) {
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) w1f[nt][ks] = *reinterpret_cast<const bf16x8*>(W1 + (long)(CH6 * c + 16 * nt + i) * D6 + 32 * ks + 8 * g);
+        b1f[nt] = *reinterpret_cast<const f32x4*>(a.P + o.b1 + CH6 * c + 16 * nt + 4 * g);
+      }
     };
     auto fetch_w2 = [&](int c) {
 #pragma unroll
@@ -682,10 +685,9 @@ __global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
     for (int c = w; c < nchunk; c += 4) {
 #pragma unroll
       for (int nt = 0; nt < 8; nt++) {
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.P + o.b1 + CH6 * c + 16 * nt + 4 * g);
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
-          f32x4 hacc = bias;
+          f32x4 hacc = b1f[nt];
           hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[nt][0], xf[rt][0], hacc, 0, 0, 0);
           hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[nt][1], xf[rt][1], hacc, 0, 0, 0);
           *reinterpret_cast<bf16x4*>(hb + (16 * rt + i) * HB6_P + 16 * nt + 4 * g) =
