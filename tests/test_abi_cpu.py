@@ -55,6 +55,25 @@ def test_launch_batch_state_machine_without_gpu():
     assert L.tacorl_encoder_fused_supported(84, 84) == 1 and L.tacorl_encoder_fused_supported(150, 200) == 0  # (DESIGN: why not)
 
 
+def test_rnn_wgrad_batch_refuses_bad_arguments_without_gpu():
+    """tacorl_rnn_wgrad_batch validates its arguments before it touches the device: problem counts outside 1..4, row counts the
+    kernel does not take, misaligned operands and leading dimensions are refused (nothing is launched, so this runs here)."""
+    import ctypes as C
+
+    from tacorl_amd import _lib
+
+    L = _lib.lib()
+    assert L.tacorl_rnn_wgrad_supported(3840, 2048, 2048) == 1 and L.tacorl_rnn_wgrad_supported(3840 + 32, 2048, 2048) == 0
+    P4, I4 = C.c_void_p * 4, C.c_int * 4
+    ok_ptr = P4(4096, 8192, 12288, 16384)  # (never dereferenced: every call below is refused in the argument checks)
+    rows = I4(3840, 3840, 3584, 3584)
+    call = lambda n, dz, x, R, dw, ld=2048: L.tacorl_rnn_wgrad_batch(n, dz, ld, x, ld, R, 2048, 2048, dw, None, 0, None)  # noqa: E731
+    assert call(0, ok_ptr, ok_ptr, rows, ok_ptr) != 0 and call(5, ok_ptr, ok_ptr, rows, ok_ptr) != 0
+    assert call(4, ok_ptr, ok_ptr, I4(3840, 3840, 3584, 3584 + 32), ok_ptr) != 0      # a row count that is not a whole stage
+    assert call(2, P4(4096, 8200, 0, 0), ok_ptr, rows, ok_ptr) != 0                     # 8-byte aligned operand
+    assert call(2, ok_ptr, ok_ptr, rows, ok_ptr, ld=2044) != 0 and call(2, ok_ptr, ok_ptr, rows, ok_ptr, ld=1024) != 0
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from tacorl_amd import _lib
 
