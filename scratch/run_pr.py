@@ -24,7 +24,7 @@ print(f"fused encoder + head + sample in launch:        {timeit(lambda: pr.forwa
 # phase stamps (only in a -DPR_STAMPS build: scratch/mklib_file.sh pr_st pr_fused.hip -DPR_STAMPS)
 import ctypes as C
 L = _lib.lib()
-if hasattr(L, "tacorl_pr_stamps_read") and D == 64:
+if hasattr(L, "tacorl_pr_stamps_read"):
     buf = (C.c_ulonglong * 16)()
     f = lambda: pr.forward(emb, D, B, T, 1, inference=True, sample=(eps, plan), prepared=True)
     f(); torch.cuda.synchronize()

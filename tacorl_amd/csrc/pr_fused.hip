@@ -116,8 +116,27 @@ __device__ __forceinline__ void layer_norm32_r(f32x4 (&v)[2], const f32x4 (&ww)[
     for (int r = 0; r < 4; r++) v[nt][r] = (v[nt][r] - mean) * rstd * ww[nt][r] + bb[nt][r];
 }
 
+// Phase clocks of the inference launches (scratch builds with -DPR_STAMPS only): wave 0 of workgroup 0 accumulates shader-clock
+// deltas per phase; read back (and reset) with tacorl_pr_stamps_read.
+#ifdef PR_STAMPS
+__device__ unsigned long long pr_stamps[16];
+#define PR_STAMP(k)                                          \
+  do {                                                       \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {               \
+      const unsigned long long t_ = clock64();               \
+      atomicAdd(&pr_stamps[k], t_ - t_prev);                 \
+      t_prev = t_;                                           \
+    }                                                        \
+  } while (0)
+#else
+#define PR_STAMP(k)
+#endif
+
 template <int RT>
 __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
+#ifdef PR_STAMPS
+  unsigned long long t_prev = clock64();
+#endif
   constexpr int T = 16 * RT;
   __shared__ __attribute__((aligned(16))) __bf16 xb_s[4][T * XB_P];
   __shared__ __attribute__((aligned(16))) unsigned char big_s[4][T * HB_P * 2];  // q|k|v (fp32) or FFN hidden chunk (bf16)
@@ -225,6 +244,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4*>(S.xin + rrow[rt] * PR_D + 16 * nt + 4 * g) = x[rt][nt];
     }
+    PR_STAMP(0);
     // ---- q|k|v = x Win^T + b  (6 N tiles, K = 32)
     put_xb(x);
     lds_sync();
@@ -246,6 +266,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
       }
     }
     lds_sync();
+    PR_STAMP(1);
     // ---- attention: 8 heads x T queries = 8 T (head, query) pairs, 2 RT per lane; result -> xb (bf16)
 #pragma unroll
     for (int j = 0; j < 2 * RT; j++) {
@@ -278,6 +299,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
       if (sv0) *reinterpret_cast<f32x4*>(S.att + ((long)b * T + qi) * PR_D + PR_HD * h) = ov;
     }
     lds_sync();
+    PR_STAMP(2);
     // ---- out-projection + residual + LayerNorm 1
     {
       bf16x8 af[RT];
@@ -307,6 +329,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
     lds_sync();  // every lane has read its out-projection operand before xb is overwritten
     put_xb(x);
     lds_sync();
+    PR_STAMP(3);
     // ---- FFN: relu(x W1^T + b1) W2^T + b2, hidden processed in chunks of 256 kept in LDS as bf16
     if (b1_staged) {
 #pragma unroll
@@ -362,6 +385,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
       }
       lds_sync();  // hidden chunk consumed before the next one overwrites it
     }
+    PR_STAMP(4);
     // the four partial FFN outputs meet in LDS (fixed summation order: every wave ends with the same bits).
     // One barrier per layer: the buffer alternates with the layer, and a wave can only reach layer l + 2's write
     // after every wave has passed layer l + 1's barrier, i.e. finished reading layer l's partials.
@@ -385,6 +409,7 @@ __global__ __launch_bounds__(256) void pr_encoder_fused_kernel(PrArgs a) {
     }
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) layer_norm32_r(x[rt], n2w, n2b, g, sv0 ? S.st2 + 2 * rrow[rt] : nullptr);
+    PR_STAMP(5);
   }
   if (w != 0) return;  // every wave holds the same result: wave 0 writes it
   // ---- mean over the T time steps (row tiles in order, then lanes i = 0..15 of each g)
@@ -482,22 +507,6 @@ __device__ __forceinline__ void layer_norm64(f32x4 (&v)[4], const f32x4 (&ww)[4]
 #pragma unroll
     for (int r = 0; r < 4; r++) v[nt][r] = (v[nt][r] - mean) * rstd * ww[nt][r] + bb[nt][r];
 }
-
-// Phase clocks of the d_model-64 launch (scratch builds with -DPR_STAMPS only): wave 0 of workgroup 0 accumulates shader-clock
-// deltas per phase; read back (and reset) with tacorl_pr_stamps_read.
-#ifdef PR_STAMPS
-__device__ unsigned long long pr_stamps[16];
-#define PR_STAMP(k)                                          \
-  do {                                                       \
-    if (blockIdx.x == 0 && threadIdx.x == 0) {               \
-      const unsigned long long t_ = clock64();               \
-      atomicAdd(&pr_stamps[k], t_ - t_prev);                 \
-      t_prev = t_;                                           \
-    }                                                        \
-  } while (0)
-#else
-#define PR_STAMP(k)
-#endif
 
 template <int RT>
 __global__ __launch_bounds__(256) void pr_encoder_fused64_kernel(PrArgs a) {
