@@ -3,7 +3,6 @@ same seeded inputs.  f32 MFMA mode must meet the north-star tolerance (1e-4 rel)
 MFMA mode is checked at bf16 operand precision (tolerance stated per test)."""
 import math
 
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
