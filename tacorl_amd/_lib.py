@@ -171,11 +171,24 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
                 "Build it with `python -m tacorl_amd.build`.")
         L = C.CDLL(LIB_PATH)
+        override = bool(os.environ.get("TACORL_HIP_LIB"))
+        missing = []
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name, None)
             if fn is None:
-                continue  # optional symbol of a later round; declared_symbols() reports it
+                missing.append(name)  # (the product library: __graft_entry__.build / tests/test_abi_cpu.py report it)
+                continue
             fn.restype, fn.argtypes = res, args
+        if override:
+            # another build stands in for the product library in this process (scratch A/B builds): say so, and refuse one
+            # whose entry points are not this binding's - a stale scratch .so with an older argument list would not fail
+            # here but corrupt memory at its first call
+            import sys
+
+            if missing:
+                raise TacorlHipError(f"TACORL_HIP_LIB={LIB_PATH} lacks {len(missing)} entry point(s) of this binding "
+                                     f"({', '.join(missing[:5])}...): rebuild it from this tree")
+            print(f"[tacorl_amd] TACORL_HIP_LIB override active: {LIB_PATH}", file=sys.stderr, flush=True)
         _lib = L
     return _lib
 

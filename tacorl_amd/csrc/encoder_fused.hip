@@ -30,6 +30,10 @@
 constexpr int cmaxi(int a, int b) { return a > b ? a : b; }
 #define EF_MAXCH 12     // 16-byte chunks per thread for one image (<= 49 152 B: up to ~90x90x3 bf16)
 #define EF_MAXP 16
+#ifndef EF_DEFER
+#define EF_DEFER 1      // 0: every pixel in the per-image tiles, as rounds 1-5 (A/B builds)
+#endif
+#define EF_DCHUNK 8     // images per leftover-pixel tile (8 of its 16 MFMA columns; 16 would not fit the LDS)
 #ifndef EF_ACT_COST
 #define EF_ACT_COST 72  // cost of an image whose activations are also stored, in 1/64 of a plain image: 10.7 k vs 9.5 k clk (per-workgroup clocks, -DEF_BLKCLK)
                         // (49 KB of stores through a ~14 B/clk per-CU store path; per-workgroup clocks of a -DEF_BLKCLK build,
@@ -265,7 +269,21 @@ struct EFGeom {
   // per fragment against 2 x 2.08; this file is compiled with the load-store-opt target feature off, build.py).
   // Row pitches other than 504 B do not have the property (bank_sim.py).
   static constexpr bool S2 = (H == 84 && W == 84);
-  static constexpr int FIXED_BYTES = ACT1_BYTES + ACT2_BYTES + EF_CHUNK * (272 + 528);
+  // Round 6 - the LEFTOVER PIXEL is deferred.  84 x 84: conv2 has 81 = 5 x 16 + 1 output pixels and conv3 49 = 3 x 16 + 1, so a
+  // sixth conv2 tile and a fourth conv3 tile carried ONE pixel each (15.6 % / 23.4 % of those layers' MFMAs, fragment
+  // reads and epilogues were padding).  The last conv2 pixel (OH2-1, OW2-1) feeds only the last conv3 pixel, so both can
+  // wait: per image the kernel runs 5 / 3 full tiles, keeps the two pixels' im2col rows (D1: the 4 x 4 x 32 window of
+  // conv1's output, D2: the 3 x 3 x 64 window of conv2's) and the soft-argmax state of the other 48 pixels (PS: running
+  // max / sum-exp / E[x] / E[y] per channel) in LDS, and once per EF_DCHUNK images ONE conv2 tile and ONE conv3 tile run
+  // over the leftover pixels of those images (image = MFMA column), whose result is merged into the soft-argmax state.
+  // PS lives in the FC tail's h1 buffer (dead until the tail, which follows the merge).
+  static constexpr int D1S = 16 * 64 + 16, D2S = 9 * 128 + 16;   // per-image pitches: 16-byte slots r16 apart -> conflict-free ds_read_b128
+  static constexpr bool DEFER = EF_DEFER != 0 && NPX2 % 16 == 1 && NPX3 % 16 == 1 && NPX2 > 16 && NPX3 > 16 &&
+                                2 * ((IMG_BYTES + 15) & ~15) + ACT1_BYTES + ACT2_BYTES + EF_CHUNK * (272 + 528) +
+                                        EF_DCHUNK * (D1S + D2S) <= 160 * 1024;
+  static constexpr int DEFER_BYTES = DEFER ? EF_DCHUNK * (D1S + D2S) : 0;
+  static constexpr int NPX2M = DEFER ? NPX2 - 1 : NPX2, NPX3M = DEFER ? NPX3 - 1 : NPX3;  // pixels of the per-image tiles
+  static constexpr int FIXED_BYTES = ACT1_BYTES + ACT2_BYTES + EF_CHUNK * (272 + 528) + DEFER_BYTES;
   // The image buffer is double: two whole images when they fit beside the activations (84 x 84: 2 x 42 KB); otherwise
   // conv1 runs over BANDS of BR output rows = 4 BR + 4 image rows (128 x 128: 8 bands of 20 rows, 2 x 15 KB; the 4
   // rows two bands share are fetched twice - from L2), the next band streaming in while the current one is computed.
@@ -345,6 +363,12 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
   unsigned char* act2 = act1 + G::ACT1_BYTES;
   unsigned char* sa = act2 + G::ACT2_BYTES;
   unsigned char* h1 = sa + EF_CHUNK * SA_STRIDE;
+  // leftover-pixel deferral (G::DEFER): D1 / D2 behind the FC staging, the soft-argmax state in h1 (dead outside the FC tail)
+  unsigned char* const d1 = h1 + EF_CHUNK * H1_STRIDE;
+  unsigned char* const d2 = d1 + EF_DCHUNK * G::D1S;
+  unsigned char* const ps = h1;
+  static_assert(!G::DEFER || EF_DCHUNK * 1024 <= EF_CHUNK * H1_STRIDE, "the soft-argmax state fits the FC tail's h1 buffer");
+  static_assert(EF_CHUNK % EF_DCHUNK == 0, "a leftover-pixel group never straddles an FC chunk");
 
   // ---- register-stationary weights and biases
   long po[11];
@@ -492,6 +516,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 
   while (true) {
     const int slot = it & (EF_CHUNK - 1);
+    const int dslot = it & (EF_DCHUNK - 1);  // position inside the leftover-pixel group (G::DEFER)
     const long nxt = cur + nworkers;
     const bool has_next = nxt < P.n_img;
     // Every conv phase is software-pipelined by hand: the LDS reads of the next half-tile are issued
@@ -661,7 +686,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 
     // ------------------------------------------------ conv2: 4x4 stride 2, 32 -> 64 (wave = 32 channels x half the tiles)
     {
-      constexpr int NT2 = (G::NPX2 + 15) >> 4;
+      constexpr int NT2 = (G::NPX2M + 15) >> 4;
       auto base2 = [&](int mt) {
         const int pc = min(mt * 16 + r16, npx2 - 1);
         const int oy = pc / a.OW2, ox = pc - oy * a.OW2;
@@ -719,7 +744,103 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         asm volatile("" : "+v"(C0[t2]));
         epi2(t2);
       };
-      if (ph < NT2) {
+      if constexpr (G::DEFER) {
+        // 5 full tiles: wave (cg, ph) takes tiles ph and ph + 2 whole (both channel tiles: a fragment read feeds two MFMAs)
+        // and ONE channel tile - fragment 2 cg + ph - of the last tile, whose reads feed one MFMA each: 80 MFMAs per wave.
+        static_assert(!G::DEFER || (NT2 == 5 && PER2 == 3 && G::NPX2M == 80), "leftover-pixel deferral: five full conv2 tiles");
+        // the leftover pixel's im2col row - conv1's output over rows / columns 2 (O?2 - 1) .. + 3 - goes to D1 now: read
+        // ahead of the first tile's fragment burst, stored behind it (LDS returns in order: the wait is the burst's own)
+        // (lane-constant address parts are re-derived behind an opaque zero: hoisted out of the image loop they are spilled,
+        // and a scratch reload inside the loop waits on vmcnt, i.e. on the next image's DMA)
+        u32x4 d1v;
+        const bool d1w = wu == 3;
+        int lz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(lz));
+        lz += l;
+        if (d1w) d1v = *reinterpret_cast<const u32x4*>(act1 + (2 * (G::OH2 - 1) + (lz >> 4)) * G::PITCH1 +
+                                                        (2 * (G::OW2 - 1) + ((lz >> 2) & 3)) * ACT1_STRIDE + (lz & 3) * 16);
+        const unsigned char* bcur = base2(ph);
+        const unsigned char* const bfirst = bcur;
+        ld2(bcur, 0, fa);
+        if (d1w) *reinterpret_cast<u32x4*>(d1 + dslot * G::D1S + (lz >> 2) * 64 + (lz & 3) * 16) = d1v;
+        auto epi2h = [&]() {  // the last tile's half: 4 channels 32 cg + 8 g + 4 ph .. + 3 of pixel 64 + r16
+          const f32x4 acc = C0[2];
+          int oz;
+          asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+          const int pm = (NT2 - 1) * 16 + r16 + oz;
+          const int gq = (l + oz) >> 4;
+          const u32x2 pk = pack4_bf16(relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3]));
+          const int oy2 = pm / a.OW2, ox2 = pm - oy2 * a.OW2;
+          *reinterpret_cast<u32x2*>(act2 + oy2 * G::PITCH2 + ox2 * G::PX2 + (32 * cg + 8 * gq + 4 * ph) * 2) = pk;
+          if (P.act) {
+            __bf16* y = reinterpret_cast<__bf16*>(P.act + P.a_y2) + (long)cur * (npx2 * 64) + (unsigned)(pm * 64 + 32 * cg + 8 * gq + 4 * ph);
+            *reinterpret_cast<u32x2*>(y) = pk;
+          }
+        };
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {
+          const int mt = ph + 2 * t2;
+          bcur = base2(t2 == 0 ? mt + 2 : NT2 - 1);  // tile t2 refills its fragment registers with the next tile's
+          __builtin_amdgcn_sched_barrier(0);
+          MFMA_FIRST_AW(C0[t2], wc2a[0], fa[0], bias2a);
+#pragma unroll
+          for (int i = 1; i < 8; i++) {
+            MFMA_AW(C0[t2], wc2a[i], fa[i]);
+            if (i == 4 && t2 > 0) {
+              asm volatile("" : "+v"(C0[t2 - 1]), "+v"(C1[t2 - 1]));
+              epi2(t2 - 1);
+            }
+            if (t2 == 0) fb[i - 1] = ld2one(bfirst, 8 + i - 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (t2 == 0) fb[7] = ld2one(bfirst, 15);
+          MFMA_FIRST_AW(C1[t2], wc2b[0], fa[0], bias2b);
+#pragma unroll
+          for (int i = 1; i < 8; i++) {
+            MFMA_AW(C1[t2], wc2b[i], fa[i]);
+            fa[i - 1] = ld2one(bcur, i - 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          MFMA_AW(C0[t2], wc2a[8], fb[0]);
+          fa[7] = ld2one(bcur, 7);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 1; i < 8; i++) MFMA_AW(C0[t2], wc2a[8 + i], fb[i]);
+          MFMA_AW(C1[t2], wc2b[8], fb[0]);
+#pragma unroll
+          for (int i = 1; i < 8; i++) {
+            MFMA_AW(C1[t2], wc2b[8 + i], fb[i]);
+            fb[i - 1] = ld2one(bcur, 8 + i - 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          fb[7] = ld2one(bcur, 15);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // the last tile's channel tile 2 cg + ph: one chain of 16, the previous tile's epilogue behind its fifth MFMA (ONE
+        // call site between two wave-uniform branches: every site's hoisted address registers count against a file that is full)
+        if (ph == 0) {
+          MFMA_FIRST_AW(C0[2], wc2a[0], fa[0], bias2a);
+#pragma unroll
+          for (int i = 1; i < 5; i++) MFMA_AW(C0[2], wc2a[i], fa[i]);
+        } else {
+          MFMA_FIRST_AW(C0[2], wc2b[0], fa[0], bias2b);
+#pragma unroll
+          for (int i = 1; i < 5; i++) MFMA_AW(C0[2], wc2b[i], fa[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(C0[1]), "+v"(C1[1]));
+        epi2(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph == 0) {
+#pragma unroll
+          for (int i = 5; i < 16; i++) { if (i < 8) MFMA_AW(C0[2], wc2a[i], fa[i]); else MFMA_AW(C0[2], wc2a[i], fb[i - 8]); }
+        } else {
+#pragma unroll
+          for (int i = 5; i < 16; i++) { if (i < 8) MFMA_AW(C0[2], wc2b[i], fa[i]); else MFMA_AW(C0[2], wc2b[i], fb[i - 8]); }
+        }
+        MFMA_CHAIN_END(C0[2]);
+        epi2h();
+      } else if (ph < NT2) {
         const unsigned char* bcur = base2(ph);
         const unsigned char* const bfirst = bcur;
         ld2(bcur, 0, fa);  // (the first tile's second half arrives in the gaps of its first block)
@@ -789,8 +910,18 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 
     // ------------------------------------------------ conv3: 3x3 stride 1, 64 -> 64 + soft-argmax in registers
     {
-      constexpr int NT3 = (G::NPX3 + 15) >> 4;
+      constexpr int NT3 = (G::NPX3M + 15) >> 4;
       const float inv_t = (1.0f / temp) * 1.44269504088896f;  // log2(e) folded in: the soft-argmax exponentials are exp2
+      // (G::DEFER) the 3 x 3 x 64 window of the leftover conv3 pixel, minus its last pixel - the leftover conv2 pixel, which
+      // the group's conv2 tile writes later - goes to D2: read ahead of the fragment burst, stored behind it
+      u32x4 d2v;
+      const bool d2w = G::DEFER && wu == 2;
+      int lz3 = 0;
+      if (G::DEFER) { asm volatile("v_mov_b32 %0, 0" : "=v"(lz3)); lz3 += l; }  // (opaque: see conv2's D1 copy)
+      if (d2w) {
+        const int j = lz3 >> 3, ky = (j * 11) >> 5, kx = j - 3 * ky;  // pixels 0 .. 7 of the window (j / 3 for j < 8), 16-byte part l & 7
+        d2v = *reinterpret_cast<const u32x4*>(act2 + (G::OH3 - 1 + ky) * G::PITCH2 + (G::OW3 - 1 + kx) * G::PX2 + (lz3 & 7) * 16);
+      }
       f32x4 v3[NT3];
       float fx[NT3], fy[NT3];
       auto base3 = [&](int mt, int& ox, int& oy) {
@@ -819,6 +950,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       const unsigned char* bcur = base3(0, ox, oy);
       const unsigned char* const bfirst = bcur;
       ld3(bcur, 0, fa);  // (only the first half in a burst: the first tile's chain fetches its own second half in its gaps)
+      if (d2w) *reinterpret_cast<u32x4*>(d2 + dslot * G::D2S + (lz3 >> 3) * 128 + (lz3 & 7) * 16) = d2v;
       auto ld3one = [&](const unsigned char* base, int s) -> u32x4 {
         const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
 #if EF_VAR & 1
@@ -833,13 +965,13 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       f32x4 accs[NT3];
       auto epi3 = [&](int mt) {
         const f32x4 acc = accs[mt];
-        const bool ok = mt * 16 + r16 < npx3;
+        const bool ok = mt * 16 + r16 < G::NPX3M;
         if (P.act && ok)
           *reinterpret_cast<f32x4*>(P.act + P.a_y3 + (long)cur * npx3 * 64 + (unsigned)((mt * 16 + r16) * 64 + 16 * w + 4 * g)) =
               f32x4{relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3])};
 #pragma unroll
         for (int q = 0; q < 4; q++)  // (only the last tile has padding lanes)
-          v3[mt][q] = (mt * 16 + 15 < G::NPX3 || ok) ? relu1(acc[q]) * inv_t : -INFINITY;
+          v3[mt][q] = (mt * 16 + 15 < G::NPX3M || ok) ? relu1(acc[q]) * inv_t : -INFINITY;
       };
 #pragma unroll
       for (int mt = 0; mt < NT3; mt++) {
@@ -896,6 +1028,15 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       EF_ROW16_4("v_add_f32_dpp", se);
       EF_ROW16_4("v_add_f32_dpp", sx);
       EF_ROW16_4("v_add_f32_dpp", sy);
+      if constexpr (G::DEFER) {
+        // running (max, sum exp, sum exp x, sum exp y) of this image's first 48 pixels, channel 16 w + 4 g + q: the
+        // leftover pixel joins them when its group's tiles have run
+        if (r16 == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            *reinterpret_cast<f32x4*>(ps + dslot * 1024 + (16 * w + 4 * g + q) * 16) = f32x4{mx[q], se[q], sx[q], sy[q]};
+        }
+      } else
       if (r16 == 0) {
         // features interleaved [x_c, y_c]; channels 16 w + 4 g + q
         float fx_[4], fy_[4];
@@ -916,6 +1057,88 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     }
 
     STAMP(7);  // soft-argmax
+    // ------------------------------------------------ the group's leftover pixels: one conv2 tile, one conv3 tile, the merge
+    if constexpr (G::DEFER) {
+      if (dslot == EF_DCHUNK - 1 || !has_next) {
+        int ld_;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(ld_));  // (opaque lane index: nothing of this block is hoisted out of the image loop)
+        ld_ += l;
+        const int r16 = ld_ & 15, g = ld_ >> 4;
+        const int nd = dslot + 1, jimg = min(r16, nd - 1);  // images of the group = MFMA columns (clamped: the others' results are dropped)
+        const long img0 = cur - (long)dslot * nworkers;      // the group's first image; image j = img0 + j nworkers
+        // conv2, pixel NPX2 - 1, channel tile 2 cg + ph of this wave (D1 of this image was stored before the conv2 -> conv3
+        // barrier; the earlier images' long before)
+        {
+          const unsigned char* bA = d1 + jimg * G::D1S + 16 * g;
+          u32x4 f[16];
+#pragma unroll
+          for (int s2 = 0; s2 < 16; s2++) f[s2] = *reinterpret_cast<const u32x4*>(bA + s2 * 64);
+          f32x4 acc;
+          __builtin_amdgcn_sched_barrier(0);
+          if (ph == 0) {
+            MFMA_FIRST_AW(acc, wc2a[0], f[0], bias2a);
+#pragma unroll
+            for (int s2 = 1; s2 < 16; s2++) MFMA_AW(acc, wc2a[s2], f[s2]);
+          } else {
+            MFMA_FIRST_AW(acc, wc2b[0], f[0], bias2b);
+#pragma unroll
+            for (int s2 = 1; s2 < 16; s2++) MFMA_AW(acc, wc2b[s2], f[s2]);
+          }
+          MFMA_CHAIN_END(acc);
+          const u32x2 pk = pack4_bf16(relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3]));
+          if (r16 < nd) {
+            *reinterpret_cast<u32x2*>(d2 + r16 * G::D2S + 8 * 128 + (32 * cg + 8 * g + 4 * ph) * 2) = pk;  // window pixel 8
+            if (P.act) {
+              __bf16* y = reinterpret_cast<__bf16*>(P.act + P.a_y2) + img0 * (npx2 * 64) +
+                          (unsigned)(r16 * (unsigned)nworkers * (unsigned)(npx2 * 64) + (npx2 - 1) * 64 + 32 * cg + 8 * g + 4 * ph);
+              *reinterpret_cast<u32x2*>(y) = pk;
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // D2 complete (and every wave's soft-argmax state of this image is in LDS)
+        // conv3, pixel NPX3 - 1, this wave's 16 channels; then the merge into the state and the features
+        {
+          const unsigned char* bB = d2 + jimg * G::D2S + 16 * g;
+          u32x4 f[18];
+#pragma unroll
+          for (int s3 = 0; s3 < 18; s3++) f[s3] = *reinterpret_cast<const u32x4*>(bB + (s3 >> 1) * 128 + 64 * (s3 & 1));
+          f32x4 st[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) st[q] = *reinterpret_cast<const f32x4*>(ps + jimg * 1024 + (16 * w + 4 * g + q) * 16);
+          f32x4 acc;
+          __builtin_amdgcn_sched_barrier(0);
+          MFMA_FIRST_AW(acc, wc3[0], f[0], bias3);
+#pragma unroll
+          for (int s3 = 1; s3 < 18; s3++) MFMA_AW(acc, wc3[s3], f[s3]);
+          MFMA_CHAIN_END(acc);
+          const float inv_t = (1.0f / temp) * 1.44269504088896f;
+          const f32x4 y3 = {relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3])};
+          float fx_[4], fy_[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float v = y3[q] * inv_t, m = st[q][0];
+            const float M = fmaxf(m, v);
+            const float ea = __builtin_amdgcn_exp2f(m - M), eb = __builtin_amdgcn_exp2f(v - M);
+            const float se = st[q][1] * ea + eb;
+            const float sx = st[q][2] * ea + eb * (float)(G::OW3 - 1), sy = st[q][3] * ea + eb * (float)(G::OH3 - 1);
+            const float r = __builtin_amdgcn_rcpf(se);
+            fx_[q] = sx * r; fy_[q] = sy * r;
+          }
+          if (r16 < nd) {
+            const u32x2 lo = pack4_bf16(fx_[0], fy_[0], fx_[1], fy_[1]), hi = pack4_bf16(fx_[2], fy_[2], fx_[3], fy_[3]);
+            *reinterpret_cast<u32x4*>(sa + (slot - dslot + r16) * SA_STRIDE + 4 * (16 * w + 4 * g)) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            if (P.act) {
+              const unsigned jo = (unsigned)r16 * (unsigned)nworkers;  // image offset of this lane's column
+              *reinterpret_cast<f32x4*>(P.act + P.a_y3 + img0 * (npx3 * 64) + (unsigned)(jo * (unsigned)(npx3 * 64) + (npx3 - 1) * 64 + 16 * w + 4 * g)) = y3;
+              float* fo = P.act + P.a_sa + img0 * 128 + (unsigned)(jo * 128u + 2 * (16 * w + 4 * g));
+              *reinterpret_cast<f32x4*>(fo) = f32x4{fx_[0], fy_[0], fx_[1], fy_[1]};
+              *reinterpret_cast<f32x4*>(fo + 4) = f32x4{fx_[2], fy_[2], fx_[3], fy_[3]};
+            }
+          }
+        }
+      }
+    }
     // ------------------------------------------------ FC tail once per chunk
     const bool chunk_done = (slot == EF_CHUNK - 1) || !has_next;
     if (chunk_done) {
@@ -966,6 +1189,10 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #pragma unroll
         for (int s = 0; s < 8; s++)
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wf2[s]), as_bf16x8(*reinterpret_cast<const u32x4*>(base + 64 * s)), acc, 0, 0, 0);
+        int lq;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(lq));  // (opaque lane index: the store's lane offset is not hoisted out of the image loop - and spilled)
+        lq += l;
+        const int r16 = lq & 15, g = lq >> 4;
         if (r16 < n_in_chunk) {
           float* o = P.out + (worker + (long)(it - slot) * nworkers) * 32 + (unsigned)(r16 * (unsigned)nworkers * 32u + 16 * w + 4 * g);
           f32x4 r = {acc[0] + c0, acc[1] + c1, acc[2] + c2, acc[3] + c3};

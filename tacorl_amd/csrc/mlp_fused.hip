@@ -694,7 +694,13 @@ int launch_reduce(const MlpWgReduceArgs& r, int gx, int Ly, int nprob, hipStream
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
   MlpWgReduceMulti& m = g_red.m;
-  if (m.njob == RED_MAXJ && red_flush(st)) return -1;
+  if (m.njob == RED_MAXJ) {
+    // table full: this site's reduce leaves now, on ITS stream, behind its own producers.  (Flushing the recorded jobs
+    // here instead would sum slabs whose weight-gradient launches sit on other streams that are joined only in front
+    // of tacorl_reduce_batch_end - ADVICE r5.)
+    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(gx, Ly, nprob), dim3(256), 0, st, r);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   m.job[m.njob] = r; m.gx[m.njob] = gx; m.L[m.njob] = Ly; m.first[m.njob + 1] = m.first[m.njob] + nprob;
   m.njob++;
   return 0;

@@ -577,8 +577,12 @@ class ACEngine:
             M, net, ldx = {"genc": ([B] * 5, (self.actor.genc_dims, self.actor.genc_acts), self.G),
                            "pi": ([B] * 2, (self.actor.head_dims, self.actor.head_acts), self.lds),
                            "q": ([self.R, self.R, B, B, B, B], (self.q1.head_dims, self.q1.head_acts), self.ldq)}[tag]
-            # (segment pitches must be multiples of 4 floats: the action block's is A - 7 for the CQL baseline)
-            cache[key] = (tag != "q" or self.A % 4 == 0) and ops.mlp_fwd_gather_ok(M, net[0], net[1], ldx, self.compute, self._lean(tag))
+            # (segment pitches must be multiples of 4 floats: the action block's is A - 7 for the CQL baseline; every
+            # segment starts on a multiple of 8 columns at a 16-byte aligned address - mlp_set_gather's conditions, checked
+            # here so that a geometry outside them takes the copy + forward path instead of failing inside the step)
+            geom_ok = self.G % 4 == 0 and self.Eo % 8 == 0 and self.E % 8 == 0 and self.g_yoff % 4 == 0
+            cache[key] = geom_ok and (tag != "q" or self.A % 4 == 0) and ops.mlp_fwd_gather_ok(
+                M, net[0], net[1], ldx, self.compute, self._lean(tag))
         return cache[key]
 
     def _emb_segs(self, ek, row0, gk, mod=0):

@@ -587,6 +587,9 @@ def test_fullsize_tacorl_configs_bf16_vs_rounded_oracle(name):
     bad = _compare(got, ologs, 2e-3, plan=mod.plan, oplan=oplan)
     ev = lambda Pp: O.tacorl_step(Pp, copy.deepcopy(opts0), spec, batch, nz, 5)[2]  # noqa: E731
     bad += _bf16_grad_check(mod, ev, ev, before, ograds)
+    if finetune:  # (the decoder's BPTT / weight-gradient kernels on the step's own inputs and head gradients)
+        cam = mod.action_decoder_modalities[0]
+        bad += _decoder_backward_in_situ(mod, before, f"{name} bf16", mod.ad, mod.plan, mod.f_out[cam], Bn, Tn)
     assert not bad, "\n".join(bad[:30])
 
 
@@ -681,6 +684,55 @@ def _encoder_backward_in_situ(mod, P, batch, ograds):
     return bad
 
 
+def _decoder_backward_in_situ(mod, P, label, ad, plan, emb, B, T, pre="action_decoder."):
+    """the tight row for the ring-GEMM BPTT / RNN weight-gradient kernels, as `_encoder_backward_in_situ` is
+    for the conv backward.  End to end the decoder's gradients can only be held to the oracle's own reproducibility (30
+    sequential ReLU layers amplify one flipped bf16 rounding: floors of 1 - 8 %).  Here the upstream is removed: the
+    step's OWN inputs (plan, frame embeddings) and its OWN dL/d(heads) - read back from the module - go through the
+    oracle's decoder forward and autograd under bf16 operand rounding, and the HIP gradients of every decoder parameter
+    (rnn.weight_ih / weight_hh / bias_* of both layers, the four heads) are held to that at 1.5e-2, nothing widened."""
+    from oracle import tacorl_oracle as O
+    from tests.golden_util import record_margin
+
+    Tm = T - 1
+    names = sorted(k for k in P if k.startswith(pre))
+    Pd = {k: P[k].detach().clone().requires_grad_(True) for k in names}
+    L = sum(1 for k in names if "rnn.weight_hh_l" in k)
+    pl = plan.detach().cpu().float()
+    em = emb.detach().cpu().float().reshape(B, T, -1)[:, :Tm]
+    NH = Pd[pre + "mean_fc.weight"].shape[0] * 3 + 2
+    # module rows are time-major (row t * B + b), the head columns [mean | log_scale | prob | gripper]
+    dh = ad.d_heads.detach().cpu()[: Tm * B, :NH].reshape(Tm, B, NH).transpose(0, 1).contiguous()
+    with O.operand_rounding(torch.bfloat16):
+        x = torch.cat([pl.unsqueeze(1).expand(-1, Tm, -1), em], dim=-1)
+        O._REGION.append("rnn")
+        for l in range(L):
+            wi, wh = Pd[f"{pre}rnn.weight_ih_l{l}"], Pd[f"{pre}rnn.weight_hh_l{l}"]
+            bi, bh = Pd[f"{pre}rnn.bias_ih_l{l}"], Pd[f"{pre}rnn.bias_hh_l{l}"]
+            h = torch.zeros(B, wh.shape[0])
+            xin = O._linear(x, wi, bi)
+            outs = []
+            for t in range(Tm):
+                h = torch.relu(xin[:, t] + O._linear(h, wh, bh))
+                outs.append(h)
+            x = torch.stack(outs, dim=1)
+        heads = torch.cat([O._linear(x, Pd[pre + f"{n}.weight"], Pd[pre + f"{n}.bias"])
+                           for n in ("mean_fc", "log_scale_fc", "prob_fc", "gripper_fc")], dim=-1)
+        O._REGION.pop()
+        gs = torch.autograd.grad(heads, [Pd[n] for n in names], grad_outputs=dh)
+    got = mod.named_gradients()
+    bad = []
+    for n, gexp in zip(names, gs):
+        if n not in got or gexp.norm() == 0:
+            continue
+        tol = 1.5e-2
+        e = ((got[n].detach().cpu().reshape(gexp.shape) - gexp).norm() / gexp.norm().clamp_min(1e-30)).item()
+        record_margin(f"{label} in situ (own plan, embeddings, d_heads): {n}", e, tol, kind="decoder BPTT + weight gradients vs rounded oracle")
+        if e > tol:
+            bad.append(f"in-situ decoder backward {n}: relerr {e:.3g} (tolerance {tol:.3g})")
+    return bad
+
+
 _last_noise = {}
 
 
@@ -719,7 +771,50 @@ def test_fullsize_playlmp_c1_matches_oracle(compute, rtol):
         ev = lambda Pp: O.playlmp_step(Pp, opt, batch, nz, ["rgb_static"], step=False)[1]  # noqa: E731
         bad += _bf16_grad_check(mod, ev, ev, P, ograds)
         bad += _encoder_backward_in_situ(mod, P, batch, ograds)
+        bad += _decoder_backward_in_situ(mod, P, "C1 bf16", mod.ad, mod.plan, mod.emb, 32, 16)
     else:
         ologs, ograds = O.playlmp_step(P, opt, batch, nz, ["rgb_static"], step=False)
         bad = _compare(got, ologs, rtol, mod.named_gradients(), ograds, 1e-3, min_common=5)
     assert not bad, "\n".join(bad[:30])
+
+
+def test_bf16_graph_replay_sees_in_place_parameter_edits():
+    """a replayed bf16 step reads weight-derived copies (the fused encoder's packed conv fragments, packed behind
+    the previous step's Adam launch; bf16 mirrors of the MLP weights) whose freshness is tracked through torch version
+    counters.  Replay, edit parameters in place the ways a user can (a conv weight and an MLP weight through their
+    nn.Parameter views, load_state_dict of a perturbed copy), replay again: the graph module must end bit-identical to an
+    eager twin that saw the same edits - and an undisturbed run must not re-capture."""
+    batch = _batch(64)
+    mods = {g: _mod("bf16", g) for g in (True, False)}
+    captures = []
+    orig = type(mods[True])._capture_only
+
+    def counting(self, *a, **k):
+        captures.append(1)
+        return orig(self, *a, **k)
+
+    for m in mods.values():
+        m._capture_only = counting.__get__(m)
+    ends = {}
+    for g, m in mods.items():
+        torch.manual_seed(5)
+        for _ in range(4):
+            m.training_step(batch)
+        if g:
+            assert len(captures) == 1, "an undisturbed run replays its one capture"
+        sd = m.state_dict()
+        conv = next(k for k in sd if k.startswith("q1.") and k.endswith("model.0.weight"))
+        lin = next(k for k in sd if k.startswith("actor.") and "fc_layers.0.weight" in k)
+        with torch.no_grad():
+            dict(m.named_parameters())[conv].mul_(1.03)
+            dict(m.named_parameters())[lin].add_(0.01)
+        for _ in range(2):
+            m.training_step(batch)
+        pert = {k: (v * 0.99 if v.dtype == torch.float32 and k.startswith("q2.") else v) for k, v in m.state_dict().items()}
+        m.load_state_dict(pert)
+        for _ in range(2):
+            m.training_step(batch)
+        torch.cuda.synchronize()
+        ends[g] = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    diff = [k for k in ends[True] if not torch.equal(ends[True][k], ends[False][k])]
+    assert not diff, diff[:10]
