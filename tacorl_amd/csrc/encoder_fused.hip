@@ -87,13 +87,23 @@ __device__ __forceinline__ float relu1(float x) {
                OP " %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
                OP " %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf"                             \
                : "+v"((x)[0]), "+v"((x)[1]), "+v"((x)[2]), "+v"((x)[3]))
-#define EF_ROW16_4(OP, x)                     \
-  do {                                        \
-    asm volatile("s_nop 1");                  \
-    EF_DPP4(OP, "quad_perm:[1,0,3,2]", x);    \
-    EF_DPP4(OP, "quad_perm:[2,3,0,1]", x);    \
-    EF_DPP4(OP, "row_half_mirror", x);        \
-    EF_DPP4(OP, "row_mirror", x);             \
+// (the wait states in front of the first step sit INSIDE its asm statement, behind the operands: as a statement of its own -
+// `asm volatile("s_nop 1")` - nothing kept hipcc from scheduling the VALU instruction that produces x[0] between the nop and
+// the first DPP read of x[0]; it did once the code around the soft-argmax changed in round 6, and channel q = 0 of every
+// lane came out wrong)
+#define EF_DPP4_FIRST(OP, CTRL, x)                                                            \
+  asm volatile("s_nop 1\n\t"                                                                   \
+               OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
+               OP " %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
+               OP " %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
+               OP " %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf"                             \
+               : "+v"((x)[0]), "+v"((x)[1]), "+v"((x)[2]), "+v"((x)[3]))
+#define EF_ROW16_4(OP, x)                          \
+  do {                                             \
+    EF_DPP4_FIRST(OP, "quad_perm:[1,0,3,2]", x);   \
+    EF_DPP4(OP, "quad_perm:[2,3,0,1]", x);         \
+    EF_DPP4(OP, "row_half_mirror", x);             \
+    EF_DPP4(OP, "row_mirror", x);                  \
   } while (0)
 __device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d) {
   bf16x4 t = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
@@ -502,6 +512,41 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     }
   };
   auto dma_load = [&](long img_idx, int band, int buf) { dma_pieces(img_idx, band, buf, 0, G::WHOLE ? DQ_HI : EF_MAXCH); };
+  // Round 6 - LEAN pieces for the whole-image geometries' in-loop DMA.  The kernel is bound by instruction issue (one wave per
+  // SIMD issues one instruction per ~4 clk whatever its kind; the launch takes 0.102 ms with every MFMA removed against
+  // 0.127 with them), and a piece as issued by dma_pieces() is ~11 instructions: a has_next branch, the 64-bit source
+  // address (s_add / s_addc), M0 saved, set, a wait state, restored, a lane-mask test for "is this the image's last,
+  // partial KiB".  Here: the wave's share of the NEXT image is addressed from one (source, LDS) base per 4 KiB - the
+  // instruction's 12-bit offset field moves both addresses - set when the group's first piece is issued; M0 simply STAYS
+  // (hipcc never touches it in this kernel: checked on the built code object by tests/test_abi_cpu.py); the last image of a
+  // workgroup fetches itself again instead of branching around every piece; only the one piece that can be the image's
+  // last KiB carries a lane mask.  A piece is then ONE instruction, + 4 per group of four.
+  constexpr int DQ0_LAST = NFULL == 4 ? 3 * DQ_HI : NFULL * DQ_LO + (3 - NFULL) * DQ_HI;  // first KiB of wave 3's share
+  constexpr int ILAST = NPC - 1 - DQ0_LAST;                                                // its piece that holds the last KiB
+  const unsigned char* lean_src = nullptr;
+  unsigned lean_dst = 0;
+  auto lean_begin = [&](long img_idx, int buf) {
+    lean_src = reinterpret_cast<const unsigned char*>(P.img) + img_idx * G::IMG_BYTES + dq0 * 1024;
+    lean_dst = lds_base + buf * a.lds_img + dq0 * 1024;
+  };
+#define EF_LEAN_LD(OFF) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #OFF :: "v"(dma_voff), "s"(gsrc) : "memory")
+  auto lean_piece = [&](int i) {  // piece i of this wave's share (i is a compile-time constant at every call site)
+    if (!G::WHOLE || i >= DQ_HI) return;
+    const bool on = i < DQ_LO || wu >= NFULL;       // (waves 0 .. NFULL - 1 issue DQ_LO pieces, the others DQ_HI)
+    if (!on) return;
+    if (i > ILAST && wu == 3) return;               // beyond the image's last KiB
+    const unsigned char* gsrc = lean_src + (i & ~3) * 1024;
+    if ((i & 3) == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(__builtin_amdgcn_readfirstlane(lean_dst + i * 1024)) : "memory");
+    constexpr int LASTN = (G::IMG_BYTES >> 4) - (NPC - 1) * 64;  // 16-byte chunks of the image's last KiB
+    if (i == ILAST && wu == 3 && l >= LASTN) return;
+    switch (i & 3) {
+      case 0: EF_LEAN_LD(0); break;
+      case 1: EF_LEAN_LD(1024); break;
+      case 2: EF_LEAN_LD(2048); break;
+      default: EF_LEAN_LD(3072); break;
+    }
+  };
+#undef EF_LEAN_LD
 
   // images this workgroup processes: worker, worker + nworkers, ... (image granularity: at most one image
   // of imbalance); the FC tail runs after every EF_CHUNK processed images (slots) or at the end.
@@ -531,6 +576,11 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
 #if !(EF_X & 1)
       if (band + 1 < G::NB) dma_load(cur, band + 1, buf ^ 1);
       else if (has_next && !G::WHOLE) dma_load(nxt, 0, buf ^ 1);
+#endif
+#if EF_X & 4  // scratch: every fetch re-reads the workgroup's FIRST image (L2-resident): the DMA without its HBM traffic
+      if (G::WHOLE) lean_begin(worker, buf ^ 1);
+#else
+      if (G::WHOLE) lean_begin(has_next ? nxt : cur, buf ^ 1);  // (the workgroup's last image fetches itself again: no branch per piece)
 #endif
       STAMP(1);  // DMA issue
       const unsigned char* ib = lds + buf * a.lds_img;
@@ -616,7 +666,10 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       u32x4 fa[6], fb[6];
       auto dma_of_tile = [&](int i) {
 #if !(EF_X & 1)
-        if (G::WHOLE && has_next) dma_pieces(nxt, 0, buf ^ 1, i * DPT, (i + 1) * DPT);
+        if (G::WHOLE) {
+#pragma unroll
+          for (int q = 0; q < DPT; q++) lean_piece(i * DPT + q);
+        }
 #endif
       };
       // the two chains of tile i; prev >= 0: that tile's epilogue rides in the first chain
@@ -629,7 +682,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
         for (int s = 1; s < 6; s++) {
           MFMA_AW(A0[i], wc1a[s], bf[s]);
 #if !(EF_X & 1)
-          if (G::WHOLE && has_next && (s == 1 || s == 3) && (s >> 1) < DPT) dma_pieces(nxt, 0, buf ^ 1, i * DPT + (s >> 1), i * DPT + (s >> 1) + 1);
+          if (G::WHOLE && (s == 1 || s == 3) && (s >> 1) < DPT) lean_piece(i * DPT + (s >> 1));
 #endif
           if (s == 4 && prev >= 0) {
             asm volatile("" : "+v"(A0[prev]), "+v"(A1[prev]));
@@ -1201,7 +1254,12 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       }
     }
     STAMP(8);  // FC tail (every 8th image)
-    if (!has_next) break;
+    if (!has_next) {
+      // (the last image's conv1 fetched that image once more - lean pieces never branch on has_next: an LDS-DMA write must
+      // not still be in flight when the workgroup's LDS is handed to the next one)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      break;
+    }
     if (!early_land) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next image has landed
       __syncthreads();                                  // ... and everyone's
