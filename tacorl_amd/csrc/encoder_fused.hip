@@ -34,6 +34,9 @@ constexpr int cmaxi(int a, int b) { return a > b ? a : b; }
 #define EF_DEFER 1      // 0: every pixel in the per-image tiles, as rounds 1-5 (A/B builds)
 #endif
 #define EF_DCHUNK 8     // images per leftover-pixel tile (8 of its 16 MFMA columns; 16 would not fit the LDS)
+#ifndef EF_SETUP_COST
+#define EF_SETUP_COST 128 // launch balance: the prologue of a workgroup's second problem (248 weight registers per lane from L2, first image), in 1/64 image: measured ~2 images (a 27-image workgroup that crosses: 256 k clk against 238 k)
+#endif
 #ifndef EF_ACT_COST
 #define EF_ACT_COST 72  // cost of an image whose activations are also stored, in 1/64 of a plain image: 10.7 k vs 9.5 k clk (per-workgroup clocks, -DEF_BLKCLK)
                         // (49 KB of stores through a ~14 B/clk per-CU store path; per-workgroup clocks of a -DEF_BLKCLK build,
@@ -51,10 +54,12 @@ struct EFProblem {
   float* act;          // optional saved activations (tacorl_encoder_act_layout) for a later backward
   long a_y2, a_y3, a_sa, a_h1;  // float offsets of y2 / y3 / soft-argmax / fc1 inside act (y1 at 0)
   int n_img;
-  int first_block, nblocks;
+  int cost;            // launch balance: cost of one image of this problem in 1/64 image (64, or EF_ACT_COST with saved activations)
+  long ustart;         // first work unit of this problem's images on the launch's unit line (see ef_partition)
 };
 struct EFArgs {
   EFProblem p[EF_MAXP];
+  long utotal;         // work units of the launch
   int nprob;
   int H, W, OH1, OW1, OH2, OW2, OH3, OW3;
   int img_bytes;   // H*W*3*2
@@ -312,8 +317,13 @@ struct EFGeom {
 #ifndef EF_VAR
 #define EF_VAR 0
 #endif
-#ifndef EF_X   // scratch experiments: 1 = no image DMA inside the loop, 2 = conv1 does not store its activations
-#define EF_X 0
+#ifndef EF_X   // scratch experiments (timing only, wrong results): 1 = no image DMA inside the loop, 2 = conv1 does not store its
+#define EF_X 0 // activations, 4 = every fetch re-reads one L2-resident image, 8 = no per-image barriers, 16 = no soft-argmax arithmetic
+#endif
+#if EF_X & 8
+#define EF_IMG_BARRIER() do { } while (0)
+#else
+#define EF_IMG_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
 #if defined(EF_STAMPS) || defined(EF_BLKCLK)  // scratch builds: per-workgroup shader clocks from entry to exit
 __device__ unsigned long long ef_blk[512];    // [0, 256) clocks, [256, 512) images served
@@ -353,20 +363,43 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
   a.W = G::W; a.OW1 = G::OW1; a.OW2 = G::OW2; a.OW3 = G::OW3; a.OH1 = G::OH1; a.OH2 = G::OH2; a.OH3 = G::OH3;
   a.img_bytes = G::IMG_BYTES; a.lds_img = G::LDS_IMG; a.nprob = a_.nprob; a.p = a_.p;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r16 = l & 15, g = l >> 4;
-  // which problem / worker am I
-  int pi = 0;
-  for (int i = 1; i < a.nprob; i++)
-    if ((int)blockIdx.x >= a_.p[i].first_block) pi = i;
-  const EFProblem P = a_.p[pi];
-  const int worker = blockIdx.x - P.first_block, nworkers = P.nblocks;
-  if (worker >= P.n_img) return;
+  // Round 6 - launch balance by WORK UNITS, not by whole workgroups per problem.  The launch lasts as long as its slowest
+  // workgroup; with a workgroup bound to one problem (rounds 2-5: ceil(images / workgroups) per problem, bisected budget)
+  // the image counts per workgroup came out 24 .. 29 at the bench shapes and the critical workgroup ran 7 % over the mean
+  // (per-workgroup shader clocks, -DEF_BLKCLK: 257 k against 240 k).  Now the problems' images lie on ONE line of work
+  // units (an image = its problem's cost; EF_SETUP_COST dead units in front of every problem but the first stand for the
+  // weight reload of a workgroup that crosses into it), workgroup b owns the units [b U / n, (b + 1) U / n) and serves the
+  // images that START inside them - a contiguous run of images of one problem, or the tail of one problem and the head of
+  // the next (then it reloads its register-stationary weights once).  Which workgroup serves which image changes nothing
+  // in the results (images are independent; FC chunks and leftover-pixel groups are per-column).
+  const unsigned long u_lo = (unsigned long)blockIdx.x * (unsigned long)a_.utotal / gridDim.x;
+  const unsigned long u_hi = (unsigned long)(blockIdx.x + 1) * (unsigned long)a_.utotal / gridDim.x;
 #if defined(EF_STAMPS) || defined(EF_BLKCLK)
   const unsigned long long t_entry = clock64();
+  int n_served = 0;
 #endif
 #ifdef EF_STAMPS
   unsigned long long t_prev = t_entry;
 #endif
+#pragma unroll 1
+  for (int pi = 0; pi < a_.nprob; pi++) {
+  const long seg_s = a_.p[pi].ustart, seg_e = seg_s + (long)a_.p[pi].n_img * a_.p[pi].cost;
+  if ((long)u_hi <= seg_s || (long)u_lo >= seg_e) continue;
+  const int pcost = a_.p[pi].cost;
+  const long f0 = (long)u_lo > seg_s ? ((long)u_lo - seg_s + pcost - 1) / pcost : 0;
+  const long f1 = (long)u_hi < seg_e ? ((long)u_hi - seg_s + pcost - 1) / pcost : a_.p[pi].n_img;
+  if (f1 <= f0) continue;
+  const EFProblem P = a_.p[pi];
+  // (the lane indices are derived behind an opaque zero INSIDE the problem loop: everything that depends on them is then
+  // computed per problem, as the one-problem kernel computed it once - hoisted out of this loop by LICM the same values
+  // overflowed the register file, and 60 serialised scratch reloads made a workgroup's prologue 35 k clocks instead of 12 k)
+  int tid;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(tid));
+  tid += threadIdx.x;
+  const int w = tid >> 6, l = tid & 63, r16 = l & 15, g = l >> 4;
+  // (this run of images is [f0, f1): the loop below walks it with `worker` = its first image and stride `nworkers` = 1)
+  const int nworkers = 1;
+  const long worker = f0, seg_end = f1;
 
   unsigned char* act1 = lds + 2 * a.lds_img;
   const int npx1 = a.OH1 * a.OW1, npx2 = a.OH2 * a.OW2, npx3 = a.OH3 * a.OW3;
@@ -563,7 +596,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     const int slot = it & (EF_CHUNK - 1);
     const int dslot = it & (EF_DCHUNK - 1);  // position inside the leftover-pixel group (G::DEFER)
     const long nxt = cur + nworkers;
-    const bool has_next = nxt < P.n_img;
+    const bool has_next = nxt < seg_end;
     // Every conv phase is software-pipelined by hand: the LDS reads of the next half-tile are issued
     // before the MFMA chain of the current one (one wave per SIMD: nothing else hides LDS latency).
     // ------------------------------------------------ conv1: 8x8 stride 4, 3 -> 32, band by band
@@ -734,7 +767,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     }
     STAMP(2);  // conv1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    EF_IMG_BARRIER();
     STAMP(3);  // barrier after conv1
 
     // ------------------------------------------------ conv2: 4x4 stride 2, 32 -> 64 (wave = 32 channels x half the tiles)
@@ -958,7 +991,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     const bool early_land = G::WHOLE && P.act == nullptr;
     if (early_land) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    EF_IMG_BARRIER();
     STAMP(5);  // barrier after conv2
 
     // ------------------------------------------------ conv3: 3x3 stride 1, 64 -> 64 + soft-argmax in registers
@@ -1019,8 +1052,10 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       auto epi3 = [&](int mt) {
         const f32x4 acc = accs[mt];
         const bool ok = mt * 16 + r16 < G::NPX3M;
+        int oz3;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(oz3));  // (opaque: the store's lane offset is not hoisted out of the image loop as a 64-bit pointer - and spilled)
         if (P.act && ok)
-          *reinterpret_cast<f32x4*>(P.act + P.a_y3 + (long)cur * npx3 * 64 + (unsigned)((mt * 16 + r16) * 64 + 16 * w + 4 * g)) =
+          *reinterpret_cast<f32x4*>(P.act + P.a_y3 + (long)cur * npx3 * 64 + (unsigned)((mt * 16 + r16 + oz3) * 64 + 16 * w + 4 * g)) =
               f32x4{relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3])};
 #pragma unroll
         for (int q = 0; q < 4; q++)  // (only the last tile has padding lanes)
@@ -1049,6 +1084,10 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       STAMP(6);  // conv3 MFMA part
       // pass 1: per-channel max over the image (tiles in registers, then the 16 pixel lanes)
       float mx[4], se[4], sx[4], sy[4];
+#if EF_X & 16
+#pragma unroll
+      for (int q = 0; q < 4; q++) { mx[q] = v3[0][q]; se[q] = v3[1][q]; sx[q] = v3[2][q]; sy[q] = v3[NT3 - 1][q]; }
+#else
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         float m = v3[0][q];
@@ -1081,6 +1120,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       EF_ROW16_4("v_add_f32_dpp", se);
       EF_ROW16_4("v_add_f32_dpp", sx);
       EF_ROW16_4("v_add_f32_dpp", sy);
+#endif
       if constexpr (G::DEFER) {
         // running (max, sum exp, sum exp x, sum exp y) of this image's first 48 pixels, channel 16 w + 4 g + q: the
         // leftover pixel joins them when its group's tiles have run
@@ -1198,6 +1238,10 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
       // fc1's 16 weight fragments travel while the slower waves finish their soft-argmax (the conv fragment
       // registers are free here); issued after the barrier their L2 round trip was exposed once per chunk
       u32x4 wf1[4][4];
+      int lf;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(lf));  // (opaque lane index for the tail's weight / bias addresses: not hoisted out of the image loop)
+      lf += tid;
+      const int w = lf >> 6, l = lf & 63, g = l >> 4;
 #pragma unroll
       for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -1268,7 +1312,12 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     cur = nxt; it++; buf ^= 1;
   }
 #if defined(EF_STAMPS) || defined(EF_BLKCLK)
-  if (tid == 0 && blockIdx.x < 256) { ef_blk[blockIdx.x] = clock64() - t_entry; ef_blk[256 + blockIdx.x] = it + 1; }
+  n_served += it + 1;
+#endif
+  __syncthreads();  // (a workgroup that goes on with the next problem: nobody still reads what its prologue overwrites)
+  }  // problems of this workgroup
+#if defined(EF_STAMPS) || defined(EF_BLKCLK)
+  if (threadIdx.x == 0 && blockIdx.x < 256) { ef_blk[blockIdx.x] = clock64() - t_entry; ef_blk[256 + blockIdx.x] = n_served; }
 #endif
 }
 
@@ -1311,59 +1360,29 @@ extern "C" int tacorl_encoder_fwd_fused_wg(int nprob, const void* const* img, co
   long total = 0;
   for (int p = 0; p < nprob; p++) total += n_img[p];
   if (total == 0) return TACORL_OK;
-  // One workgroup per CU.  A workgroup serves ONE problem (its weights are register-stationary), so the launch lasts as
-  // long as the slowest workgroup: the largest ceil(images / workgroups) x cost per image over the problems.  Shares
-  // proportional to the image counts left the 4 096-frame problem of the step at 28 images per workgroup and the
-  // problems that also store their activations (1.28 x per image, EF_ACT_COST) at 27 - 35 image-units against an
-  // average of 27.  Instead: the smallest per-workgroup budget M (in units of 1/64 image) for which sum_p ceil(cost_p
-  // n_p / M) fits the CU count, found by bisection; spare workgroups go to the problems closest to the budget.
+  // One workgroup per CU (or max_workgroups of them), each owning an equal share of the launch's WORK UNITS (see the kernel):
+  // an image costs 64 units, EF_ACT_COST when its activations are also stored; EF_SETUP_COST dead units lie in front of
+  // every problem but the first - the weight reload of a workgroup that crosses from one problem into the next.
   const int budget = max_workgroups > 0 && max_workgroups < 256 ? max_workgroups : 256;
-  long cost[EF_MAXP], units = 0;
+  long units = 0;
+  int first = 1;
   for (int p = 0; p < nprob; p++) {
-    cost[p] = (act && act[p]) ? EF_ACT_COST : 64;
-    units += cost[p] * n_img[p];
-  }
-  auto blocks_for = [&](long M, int* k) {
-    long nbk = 0;
-    for (int p = 0; p < nprob; p++) {
-      const long ipb = M / cost[p] > 0 ? M / cost[p] : 1;  // images per workgroup within the budget
-      k[p] = (int)((n_img[p] + ipb - 1) / ipb);
-      nbk += k[p];
-    }
-    return nbk;
-  };
-  int kk[EF_MAXP];
-  long lo = (units + budget - 1) / budget, hi = units;  // M in [lo, hi]: blocks_for(hi) = nprob <= budget
-  if (lo < 64) lo = 64;
-  if (hi < lo) hi = lo;
-  while (lo < hi) {
-    const long mid = (lo + hi) / 2;
-    if (blocks_for(mid, kk) <= budget) hi = mid; else lo = mid + 1;
-  }
-  long used = blocks_for(lo, kk);
-  for (; used < budget; used++) {  // spare workgroups: to the problem with the highest load per workgroup that can still split
-    int best = -1; double worst = 0.0;
-    for (int p = 0; p < nprob; p++) {
-      if (kk[p] >= n_img[p] || n_img[p] == 0) continue;
-      const double load = (double)cost[p] * ((n_img[p] + kk[p] - 1) / kk[p]);
-      if (load > worst) { worst = load; best = p; }
-    }
-    if (best < 0) break;
-    kk[best]++;
-  }
-  int nb = 0;
-  for (int p = 0; p < nprob; p++) {
-    const int k = n_img[p] > 0 ? kk[p] : 0;
     a.p[p].img = (const __bf16*)img[p]; a.p[p].wpk = (const u32x4*)packed[p]; a.p[p].params = params[p];
-    a.p[p].out = out[p]; a.p[p].n_img = n_img[p]; a.p[p].first_block = nb; a.p[p].nblocks = k;
+    a.p[p].out = out[p]; a.p[p].n_img = n_img[p];
     a.p[p].act = act ? act[p] : nullptr;
+    a.p[p].cost = a.p[p].act ? EF_ACT_COST : 64;
+    if (n_img[p] > 0 && !first) units += EF_SETUP_COST;
+    a.p[p].ustart = units;
+    units += (long)a.p[p].cost * n_img[p];
+    if (n_img[p] > 0) first = 0;
     if (a.p[p].act) {
       long ao[5];
       tacorl_encoder_act_layout(n_img[p], H, W, ao);
       a.p[p].a_y2 = ao[1]; a.p[p].a_y3 = ao[2]; a.p[p].a_sa = ao[3]; a.p[p].a_h1 = ao[4];
     }
-    nb += k;
   }
+  a.utotal = units;
+  const int nb = (int)(total < budget ? total : budget);  // (never more workgroups than images)
 #define X(h, w) if (H == h && W == w) return ef_launch<h, w>(a, nb, (hipStream_t)stream);
   EF_GEOMS(X)
 #undef X

@@ -81,3 +81,40 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libtacorl_hip.so")
     with pytest.raises(_lib.TacorlHipError):
         _lib.lib()
+
+
+def test_encoder_fused_code_object_leaves_m0_to_the_dma_pieces(tmp_path):
+    """Round 6: the fused encoder's in-loop LDS-DMA pieces set M0 (the LDS destination) once per group of four and rely on it
+    STAYING there between asm statements - legitimate only while hipcc itself never reads or writes M0 in these kernels.
+    Checked on the built gfx950 code object: inside every encoder_fused_kernel<H, W> the only instructions that mention m0
+    are `s_mov_b32 m0, <sgpr>` (a piece's set / restore) and `s_mov_b32 <sgpr>, m0` (the old-style pieces' save)."""
+    import re
+    import shutil
+    import subprocess
+
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = os.path.join(here, "tacorl_amd", "lib", "obj", "encoder_fused.o")
+    tools = "/opt/rocm/lib/llvm/bin"
+    need = [os.path.join(tools, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not os.path.exists(obj) or not all(os.path.exists(t) or shutil.which(os.path.basename(t)) for t in need):
+        pytest.skip("needs the in-tree object file (python -m tacorl_amd.build) and the ROCm llvm tools")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.run([need[0], "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+    subprocess.run([need[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    f"--output={co}"], check=True)
+    dis = subprocess.run([need[2], "-d", co], check=True, capture_output=True, text=True).stdout
+    ok = re.compile(r"^s_mov_b32 (m0, (s\d+|vcc_lo|vcc_hi)|(s\d+|vcc_lo|vcc_hi), m0)$")
+    kernel, seen, bad = None, 0, []
+    for ln in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+        if m:
+            kernel = m.group(1)
+            continue
+        if kernel is None or "encoder_fused_kernel" not in kernel or "m0" not in ln:
+            continue
+        ins = re.sub(r"\s+", " ", ln.split("//")[0]).strip()
+        seen += 1
+        if not ok.match(ins):
+            bad.append(f"{kernel}: {ins}")
+    assert seen > 0, "no M0 write found at all: has the kernel's DMA changed?"
+    assert not bad, bad[:10]
