@@ -48,7 +48,8 @@ else:
     u = lambda *s: torch.rand(*s, device=dev, generator=g) * 2 - 1
     acts = u(B, T, 7); acts[..., -1] = torch.where(acts[..., -1] >= 0, 1.0, -1.0)
     disp = torch.ones(B, device=dev).long()
-    batch = {"states": {c: u(B, T, 3, 128, 128) for c in cams}, "goal": {c: u(B, 3, 128, 128) for c in cams}, "actions": acts, "disp": disp}
+    hw = {"rgb_gripper": (84, 84), "rgb_static": (150, 200)} if which == "c4real" else {c: (128, 128) for c in cams}  # c4real: experiment=tacorl_real_world's geometry
+    batch = {"states": {c: u(B, T, 3, *hw[c]) for c in cams}, "goal": {c: u(B, 3, *hw[c]) for c in cams}, "actions": acts, "disp": disp}
     (None if os.environ.get('NOGRAPH') else mod.enable_graph()); mod.log_every_n_steps = 50
     if os.environ.get("MARKS"):  # device-mark timeline of the step's branches (MARKS=1; the module must be built after this)
         from tacorl_amd import ops

@@ -38,6 +38,8 @@ if hasattr(L, "tacorl_ef_stamps_read"):
     run(); torch.cuda.synchronize()
     L.tacorl_ef_stamps_read(buf, 0)
     names = ["prologue", "dma issue", "conv1", "barrier1", "conv2", "barrier2", "conv3 mfma", "soft-argmax", "fc tail", "img wait+barrier"]
+    if os.environ.get("EF8_NAMES"):
+        names = ["prologue", "conv1", "B1", "conv2 chains+store", "B2", "conv2 finish", "B3", "conv3 chains+store", "B4", "conv3 finish+softargmax", "B5(+land)", "merge+FC+B6", ""]
     if any(buf[10:13]): print("band phases: compute", buf[10], "own DMA wait", buf[11], "barrier", buf[12])
     tot = sum(buf[:13])
     for k, nm in enumerate(names): print(f"{nm:18s} {buf[k]:9d} clk  {100.0 * buf[k] / tot:5.1f} %")

@@ -989,7 +989,11 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
     // end-of-image barrier can go - the waves then absorb their skew (fc2 runs on two of them) instead of meeting a
     // fourth time per image.  With saved activations the wait would also cover conv2's global stores: old scheme there.
     const bool early_land = G::WHOLE && P.act == nullptr;
+#if EF_X & 32  // scratch: nobody waits for the next image's DMA (what would a landing wait that never stalls be worth?)
+    if (early_land) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     if (early_land) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     EF_IMG_BARRIER();
     STAMP(5);  // barrier after conv2
@@ -1320,6 +1324,7 @@ __global__ __launch_bounds__(256, 1) void encoder_fused_kernel(EFArgs a_) {
   if (threadIdx.x == 0 && blockIdx.x < 256) { ef_blk[blockIdx.x] = clock64() - t_entry; ef_blk[256 + blockIdx.x] = n_served; }
 #endif
 }
+
 
 #define EF_GEOMS(X) X(84, 84) X(64, 64) X(44, 60) X(128, 128)
 
