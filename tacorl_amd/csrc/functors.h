@@ -46,6 +46,34 @@ struct ConvColLoader {
 #pragma unroll
     for (int t = 0; t < 4; t++) v[t] = (float)q[t];
   }
+  // Row state (round 6).  In a forward convolution (TA = false) a thread of gemm_kernel stages the same few im2col rows m for
+  // every K tile: the pixel decomposition m -> (image, oy, ox) - two integer divisions and a 64-bit address - is done ONCE
+  // per row here, and load_row() is left with k -> (ky, offset in the row's run).  The per-layer conv forward of the
+  // geometries the fused encoder does not take (150 x 200: 3.4 ms/step, conv1 alone 0.82 ms at 72 TFLOP/s) was bound by
+  // exactly that index arithmetic: ~40 VALU instructions in front of every 4-element load.
+  static constexpr bool ROW_STATE = true;
+  struct Row { const InT* base; int valid; };
+  __device__ __forceinline__ Row row(int p, int m) const {
+    Row r;
+    r.valid = m < rows[p];
+    const int px = g.OH * g.OW, mc = r.valid ? m : 0;
+    const int img = mc / px, pp = mc - img * px, oy = pp / g.OW, ox = pp - oy * g.OW;
+    r.base = ptr[p] + (((long)img * g.H + oy * g.S) * g.W + ox * g.S) * g.C;
+    return r;
+  }
+  __device__ __forceinline__ void load_row(const Row& rw, int k, float (&v)[4]) const {
+    const int K = g.KH * g.KW * g.C;
+    if (!rw.valid || k >= K) {
+#pragma unroll
+      for (int t = 0; t < 4; t++) v[t] = (ones_col && rw.valid && k + t == K) ? 1.f : 0.f;
+      return;
+    }
+    const int run = g.KW * g.C, ky = k / run, r = k - ky * run;
+    const InT* q = rw.base + ky * g.W * g.C + r;
+    if (vec) { load4_as_float<InT>(q, v); return; }
+#pragma unroll
+    for (int t = 0; t < 4; t++) v[t] = (float)q[t];
+  }
 };
 
 // Conv backward-data as a gather.  Problem index = net * S*S + (py*S + px): one GEMM per

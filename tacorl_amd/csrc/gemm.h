@@ -46,6 +46,9 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], int q) {
   if (o2) { v[0] = y0; v[1] = y1; } else { v[2] = y0; v[3] = y1; }
 }
 
+template <class L, class = void> struct has_row_state { static constexpr bool value = false; };
+template <class L> struct has_row_state<L, decltype((void)L::ROW_STATE)> { static constexpr bool value = L::ROW_STATE; };
+
 template <class Atom, class LA, class LB, bool TA, bool TB, class Epi, int BM, int BN, int BKT = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmArgs g) {
   typedef typename Atom::elem T;
@@ -72,11 +75,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmAr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   float ra[ACH][4], rb[BCH][4];
+  // (loaders with a per-row state - implicit im2col - decompose this thread's ACH rows once, not per K tile)
+  auto arows = [&]() {
+    if constexpr (!TA && has_row_state<LA>::value) {
+      struct R_ { typename LA::Row r[ACH]; } o;
+#pragma unroll
+      for (int i = 0; i < ACH; i++) o.r[i] = la.row(p, m0 + (tid + i * 256) / (BK / 4));
+      return o;
+    } else {
+      return 0;
+    }
+  }();
   auto fetch = [&](int r0) {
 #pragma unroll
     for (int i = 0; i < ACH; i++) {
       int c = tid + i * 256;
-      if (!TA) la.load(p, m0 + c / (BK / 4), r0 + (c % (BK / 4)) * 4, ra[i]);
+      if constexpr (!TA && has_row_state<LA>::value) la.load_row(arows.r[i], r0 + (c % (BK / 4)) * 4, ra[i]);
+      else if (!TA) la.load(p, m0 + c / (BK / 4), r0 + (c % (BK / 4)) * 4, ra[i]);
       else     la.load(p, r0 + (c / BM) * 4 + (c & 3), m0 + ((c >> 2) % (BM / 4)) * 4, ra[i]);  // quad = 4 rows r, same 4 m
     }
 #pragma unroll
