@@ -152,12 +152,12 @@ def kernel_source_hash():
 
 
 def measured_traffic(n_img, fused, dtype):
-    """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/r05_fused_traffic.json:
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/r06_fused_traffic.json:
     FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of this very command, gfx950 correction applied;
     scratch/gpu_traffic.sh).  The file records the sha256 of the kernel source it was measured on: null when the source
     has changed since (a stale figure must not ride on a new kernel), or when this run's launch is not the measured one."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_fused_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r06_fused_traffic.json")) as f:
             doc = json.load(f)
         m = doc["bench_launch"]
         if doc.get("encoder_fused_hip_sha256") != kernel_source_hash():
