@@ -195,7 +195,9 @@ int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const void* cons
 /* The same launch on at most max_workgroups workgroups (0 = one per CU): fewer than the CU count leaves CUs to a concurrent
  * branch of the caller's graph - TACORL issues the frozen LMP window's problems first, forks the plan recognition ->
  * action decoder branch (reference tacorl.py:142-179, 206-233: neither depends on the actor / critic encoders) and runs the
- * update's own encoder problems beside it on 160 workgroups. */
+ * update's own encoder problems beside it on 160 workgroups.  The launch is shared out by WORK UNITS (an image costs 64, or 72
+ * with saved activations; a workgroup may serve the tail of one problem and the head of the next): which workgroup serves
+ * which image changes nothing in the results.  max_workgroups, when given, must be at least nprob (TACORL_EINVAL otherwise). */
 int tacorl_encoder_fwd_fused_wg(int nprob, const void* const* img, const void* const* packed,
                                 const float* const* params, float* const* out, float* const* act,
                                 const int* n_img, int H, int W, int max_workgroups, tacorl_stream_t stream);
