@@ -4,6 +4,7 @@ from tacorl_amd import _lib, blocks, ops
 if os.environ.get("TACORL_SCRATCH_LIB"): _lib.LIB_PATH = os.environ["TACORL_SCRATCH_LIB"]
 dev = torch.device('cuda:0')
 H = W = int(os.environ.get("HW", 84))
+if os.environ.get("HxW"): H, W = (int(v) for v in os.environ["HxW"].split("x"))
 spec = sys.argv[1:] or ["4096", "256", "512", "512"]   # "512a" = that problem also saves its activations (training problems)
 n = [int(x.rstrip("a")) for x in spec]
 flats, imgs, outs, packed, acts = [], [], [], [], []
@@ -15,6 +16,10 @@ for k, sp in zip(n, spec):
     outs.append(torch.empty(k, 32, device=dev))
     packed.append(torch.empty(_lib.lib().tacorl_encoder_fused_wpk_bytes(), dtype=torch.uint8, device=dev))
 ops.call("tacorl_encoder_pack_weights", len(n), ops.ptr_array(flats), ops.ptr_array(packed), ops.stream())
+def _flop(H, W):
+    o1 = ((H - 8) // 4 + 1, (W - 8) // 4 + 1); o2 = ((o1[0] - 4) // 2 + 1, (o1[1] - 4) // 2 + 1); o3 = (o2[0] - 2, o2[1] - 2)
+    return 2.0 * (o1[0] * o1[1] * 32 * 192 + o2[0] * o2[1] * 64 * 512 + o3[0] * o3[1] * 64 * 576 + 128 * 256 + 256 * 32)
+FLOP = _flop(H, W)
 def run():
     ops.call("tacorl_encoder_fwd_fused", len(n), ops.ptr_array(imgs), ops.ptr_array(packed), ops.ptr_array(flats),
              ops.ptr_array(outs), ops.ptr_array(acts) if any(a is not None for a in acts) else None, ops.int_array(n), H, W, ops.stream())
@@ -28,7 +33,7 @@ for rep in range(5):
     e1.record(); torch.cuda.synchronize()
     best.append(e0.elapsed_time(e1) / 50)
 ms = sorted(best)[2]
-print(f"imgs {sum(n)} ms {ms:.4f} (5 x 50 launches: min {min(best):.4f} max {max(best):.4f}) TF {sum(n)*13.918e6/ms/1e9:.1f}")
+print(f"imgs {sum(n)} ms {ms:.4f} (5 x 50 launches: min {min(best):.4f} max {max(best):.4f}) TF {sum(n)*FLOP/ms/1e9:.1f}")
 # phase stamps (only in a -DEF_STAMPS build of the library)
 import ctypes as C
 L = _lib.lib()

@@ -7,8 +7,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-NAMES = ("dense_ops", "rl_ops", "seq_ops", "encoder_fused", "encoder_bwd_fused", "mlp_fused", "rnn_ops", "pr_fused",
-         "data_ops")
+NAMES = ("dense_ops", "rl_ops", "seq_ops", "encoder_fused", "encoder_ring", "encoder_bwd_fused", "mlp_fused", "rnn_ops",
+         "pr_fused", "data_ops")
 SRC = [os.path.join(CSRC, f + ".hip") for f in NAMES]
 OBJ_DIR = os.path.join(HERE, "lib", "obj")
 OUT = os.path.join(HERE, "lib", "libtacorl_hip.so")
@@ -17,8 +17,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
 # per-file extras.  encoder_fused: neither the IR load/store vectorizer nor the SI load/store optimizer - either one
 # fuses the conv1 fragment reads (8-byte halves at a 24-byte pixel stride) into ds_read2_b64, which the LDS serves at
 # 128 B/clk in 16-lane groups; plain ds_read_b64 pairs run at 256 B/clk in the 32-lane groups the tile layout is made for.
-EXTRA = {"encoder_fused": ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllvm",
-                           "-amdgpu-load-store-vectorizer=0"]}
+_NO_LSOPT = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllvm", "-amdgpu-load-store-vectorizer=0"]
+EXTRA = {"encoder_fused": _NO_LSOPT, "encoder_ring": _NO_LSOPT}
 
 
 def _headers_mtime():

@@ -23,13 +23,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "../../include/tacorl_hip.h"
-#include "common.h"
+#include "encoder_fused.h"
 
-#define EF_CHUNK 16     // images per FC batch = the 16 columns of the FC MFMA tiles (8 left half of every tile empty)
-constexpr int cmaxi(int a, int b) { return a > b ? a : b; }
-#define EF_MAXCH 12     // 16-byte chunks per thread for one image (<= 49 152 B: up to ~90x90x3 bf16)
-#define EF_MAXP 16
 #ifndef EF_DEFER
 #define EF_DEFER 1      // 0: every pixel in the per-image tiles, as rounds 1-5 (A/B builds)
 #endif
@@ -43,77 +38,6 @@ constexpr int cmaxi(int a, int b) { return a > b ? a : b; }
                         // scratch/run_fused.py: critical workgroup 335 k clk at 64, 313 k at 72, 292 k at 80, 295 k at 84; mean 279 k)
 #endif
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-struct EFProblem {
-  const __bf16* img;   // [n][H][W][3]
-  const u32x4* wpk;    // packed bf16 fragments (tacorl_encoder_pack_weights)
-  const float* params; // fp32 block (biases, temperature)
-  float* out;          // [n][32]
-  float* act;          // optional saved activations (tacorl_encoder_act_layout) for a later backward
-  long a_y2, a_y3, a_sa, a_h1;  // float offsets of y2 / y3 / soft-argmax / fc1 inside act (y1 at 0)
-  int n_img;
-  int cost;            // launch balance: cost of one image of this problem in 1/64 image (64, or EF_ACT_COST with saved activations)
-  long ustart;         // first work unit of this problem's images on the launch's unit line (see ef_partition)
-};
-struct EFArgs {
-  EFProblem p[EF_MAXP];
-  long utotal;         // work units of the launch
-  int nprob;
-  int H, W, OH1, OW1, OH2, OW2, OH3, OW3;
-  int img_bytes;   // H*W*3*2
-  int lds_img;     // bytes reserved per image buffer (multiple of 16)
-};
-
-// packed-fragment offsets (in 16-byte units, 64 lanes per fragment)
-#define WP_C1 0                      // [2 ntile][6 kstep][64]
-#define WP_C2 (WP_C1 + 2 * 6 * 64)   // [4][16][64]
-#define WP_C3 (WP_C2 + 4 * 16 * 64)  // [4][18][64]
-#define WP_F1 (WP_C3 + 4 * 18 * 64)  // [16][4][64]
-#define WP_F2 (WP_F1 + 16 * 4 * 64)  // [2][8][64]
-#define WP_TOTAL (WP_F2 + 2 * 8 * 64)
-
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
-// max(x, 0) as ONE v_max_f32: fmaxf() costs two (hipcc first canonicalises x with v_max x, x - signalling-NaN
-// quieting the accumulators here cannot need); 20 of them per 16-pixel tile add up at one wave per SIMD
-__device__ __forceinline__ float relu1(float x) {
-  float r;
-  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
-// One butterfly step of a 16-lane (DPP row) reduction on FOUR independent values in four instructions: v_op_dpp reads its
-// first source through the lane permutation, so a step is one instruction instead of v_mov_dpp + v_op (hipcc fuses only
-// some of them).  Four values per statement: a VALU result needs two wait states before a DPP read of it, and inline
-// asm gets no hazard padding - the three other instructions of the group provide them.
-#define EF_DPP4(OP, CTRL, x)                                                                  \
-  asm volatile(OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
-               OP " %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
-               OP " %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
-               OP " %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf"                             \
-               : "+v"((x)[0]), "+v"((x)[1]), "+v"((x)[2]), "+v"((x)[3]))
-// (the wait states in front of the first step sit INSIDE its asm statement, behind the operands: as a statement of its own -
-// `asm volatile("s_nop 1")` - nothing kept hipcc from scheduling the VALU instruction that produces x[0] between the nop and
-// the first DPP read of x[0]; it did once the code around the soft-argmax changed in round 6, and channel q = 0 of every
-// lane came out wrong)
-#define EF_DPP4_FIRST(OP, CTRL, x)                                                            \
-  asm volatile("s_nop 1\n\t"                                                                   \
-               OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
-               OP " %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
-               OP " %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
-               OP " %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf"                             \
-               : "+v"((x)[0]), "+v"((x)[1]), "+v"((x)[2]), "+v"((x)[3]))
-#define EF_ROW16_4(OP, x)                          \
-  do {                                             \
-    EF_DPP4_FIRST(OP, "quad_perm:[1,0,3,2]", x);   \
-    EF_DPP4(OP, "quad_perm:[2,3,0,1]", x);         \
-    EF_DPP4(OP, "row_half_mirror", x);             \
-    EF_DPP4(OP, "row_mirror", x);                  \
-  } while (0)
-__device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d) {
-  bf16x4 t = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
-  return __builtin_bit_cast(u32x2, t);
-}
 
 // ------------------------------------------------------------------ weight packing
 // frag(j, s, l)[e] = W[16 j + (l & 15)][32 s + 8 (l >> 4) + e]   (W row-major [N][K], fp32 -> bf16)
@@ -163,35 +87,6 @@ extern "C" int tacorl_encoder_pack_weights(int nprob, const float* const* params
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
-// MFMA with the weight fragment held in AGPRs (the conv2/conv3 weights fill 136 AGPRs; as plain
-// builtin operands hipcc keeps them in arch VGPRs, runs out, and serialises every LDS read behind one
-// shared destination register).  Inline asm is invisible to hipcc's hazard recogniser, so the chain
-// brackets itself: s_nop before the first MFMA (VALU-written accumulator) and after the last one
-// (MFMA result read by VALU) - cdna_hip_programming.md section 5.7.
-#if EF_VAR & 2
-#define MFMA_AW(acc, wfrag, bfrag) asm volatile("" : "+v"(acc) : "a"(wfrag), "v"(bfrag))
-#else
-#define MFMA_AW(acc, wfrag, bfrag) \
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wfrag), "v"(bfrag))
-#endif
-#define MFMA_CHAIN_BEGIN(acc) asm volatile("s_nop 1" : "+v"(acc))
-// First MFMA of a chain: the bias registers are its C operand and the accumulator only its destination - no four
-// v_mov per chain to seed the accumulator (22 chains per image), and no VALU-write -> MFMA-read wait either: the
-// bias registers were written once, before the image loop.
-#if EF_VAR & 2
-#define MFMA_FIRST_AW(acc, wfrag, bfrag, bias) asm volatile("" : "=v"(acc) : "a"(wfrag), "v"(bfrag), "v"(bias))
-#else
-#define MFMA_FIRST_AW(acc, wfrag, bfrag, bias) \
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=v"(acc) : "a"(wfrag), "v"(bfrag), "v"(bias))
-#endif
-// (12 wait states: what an 8-pass XDL result needs before a non-MFMA reader, cdna_hip_programming.md section 5.7 item 2;
-// v_mfma_f32_16x16x32_bf16 issues every ~17 clk in a dependent chain, i.e. is a 4-pass op - 20 states were used before)
-#define MFMA_CHAIN_END(acc) asm volatile("s_nop 11" : "+v"(acc))
-#if EF_VAR & 2
-#define EF_MFMA_TXT(...) ""
-#else
-#define EF_MFMA_TXT(...) __VA_ARGS__
-#endif
 // ---- MFMA chains as ONE asm statement each (operands: %0 accumulator, then the N weight fragments, the N im2col fragments, the bias).  hipcc pads an
 // `s_nop 0` between two adjacent asm statements and a counted s_waitcnt in front of each one whose fragment is the
 // youngest LDS read: per 16x16x32 MFMA that was 1.3 scalar instructions, each a 4-5 clk issue slot at one wave per SIMD.
@@ -255,9 +150,6 @@ extern "C" int tacorl_encoder_pack_weights(int nprob, const float* const* params
       : "+v"(acc) : "a"((w)[(o) + 0]), "a"((w)[(o) + 1]), "a"((w)[(o) + 2]), "a"((w)[(o) + 3]), "a"((w)[(o) + 4]), "a"((w)[(o) + 5]), "a"((w)[(o) + 6]), "a"((w)[(o) + 7]), "a"((w)[(o) + 8]), "v"((f)[0]), "v"((f)[1]), "v"((f)[2]), "v"((f)[3]), "v"((f)[4]), "v"((f)[5]), "v"((f)[6]), "v"((f)[7]), "v"((f)[8]))
 
 // ------------------------------------------------------------------------- kernel
-#define ACT1_STRIDE 80   // bytes per conv1-output pixel (32 ch bf16 + 16 pad)
-#define SA_STRIDE 272    // bytes per image of soft-argmax features (128 bf16 + 16 pad)
-#define H1_STRIDE 528    // bytes per image of fc1 output (256 bf16 + 16 pad)
 
 template <int H_, int W_>
 struct EFGeom {
@@ -1332,7 +1224,7 @@ extern "C" int tacorl_encoder_fused_supported(int H, int W) {
 #define X(h, w) if (H == h && W == w) return EFGeom<h, w>::OK ? 1 : 0;
   EF_GEOMS(X)
 #undef X
-  return 0;
+  return ef_ring_supported(H, W);  // geometries whose conv1 output does not fit the LDS: encoder_ring.hip (no saved activations)
 }
 
 template <int H, int W>
@@ -1369,14 +1261,18 @@ extern "C" int tacorl_encoder_fwd_fused_wg(int nprob, const void* const* img, co
   // an image costs 64 units, EF_ACT_COST when its activations are also stored; EF_SETUP_COST dead units lie in front of
   // every problem but the first - the weight reload of a workgroup that crosses from one problem into the next.
   const int budget = max_workgroups > 0 && max_workgroups < 256 ? max_workgroups : 256;
+  const bool ring = ef_ring_supported(H, W) != 0;
+  // (ring geometries: an image is ~5 x the work of an 84 x 84 one, the prologue is the same)
+  const int setup_cost = ring ? EF_SETUP_COST / 4 : EF_SETUP_COST;
   long units = 0;
   int first = 1;
   for (int p = 0; p < nprob; p++) {
     a.p[p].img = (const __bf16*)img[p]; a.p[p].wpk = (const u32x4*)packed[p]; a.p[p].params = params[p];
     a.p[p].out = out[p]; a.p[p].n_img = n_img[p];
     a.p[p].act = act ? act[p] : nullptr;
+    if (ring && a.p[p].act) return TACORL_EINVAL;  // the ring kernel does not save activations
     a.p[p].cost = a.p[p].act ? EF_ACT_COST : 64;
-    if (n_img[p] > 0 && !first) units += EF_SETUP_COST;
+    if (n_img[p] > 0 && !first) units += setup_cost;
     a.p[p].ustart = units;
     units += (long)a.p[p].cost * n_img[p];
     if (n_img[p] > 0) first = 0;
@@ -1388,6 +1284,7 @@ extern "C" int tacorl_encoder_fwd_fused_wg(int nprob, const void* const* img, co
   }
   a.utotal = units;
   const int nb = (int)(total < budget ? total : budget);  // (never more workgroups than images)
+  if (ring) return ef_ring_launch(a, nb, H, W, (hipStream_t)stream);
 #define X(h, w) if (H == h && W == w) return ef_launch<h, w>(a, nb, (hipStream_t)stream);
   EF_GEOMS(X)
 #undef X
