@@ -183,12 +183,19 @@ int tacorl_encoder_bwd(int nprob, const void* const* img, const float* const* pa
  * (tacorl_encoder_fused_wpk_bytes() bytes per network; re-pack whenever the fp32 block changes). */
 long tacorl_encoder_fused_wpk_bytes(void);
 int tacorl_encoder_fused_supported(int H, int W);
+/* What the fused forward writes into a problem's act block for this geometry: 0 - not a fused geometry; 1 - y1 / y2 as bf16 at
+ * the start of their slots (tacorl_encoder_bwd_fused* read them); 2 - every activation as fp32, i.e. exactly what the per-layer
+ * tacorl_encoder_fwd leaves and tacorl_encoder_bwd reads (geometries whose conv1 output does not fit the LDS - 150 x 200, the
+ * un-resized rgb_static of the reference's experiment=tacorl_real_world, config/.../rl_real_world_train.yaml:2-10 - which
+ * have no LDS-resident backward: csrc/encoder_ring.hip). */
+int tacorl_encoder_fused_act_format(int H, int W);
 int tacorl_encoder_pack_weights(int nprob, const float* const* params, void* const* packed,
                                 tacorl_stream_t stream);
 /* act: NULL, or per-problem pointers (NULL entries allowed) to tacorl_encoder_act_layout blocks that
  * receive the fp32 activations tacorl_encoder_bwd needs.  Saved activations (act[p] != NULL, layout of
  * tacorl_encoder_act_layout): y3, the soft-argmax features and fc1 as fp32; y1 and y2 as **bf16** at the start of their
- * fp32-sized slots - the values the next layer consumed - which is what tacorl_encoder_bwd_fused* read. */
+ * fp32-sized slots - the values the next layer consumed - which is what tacorl_encoder_bwd_fused* read (geometries of
+ * tacorl_encoder_fused_act_format() == 2: all five as fp32, for tacorl_encoder_bwd). */
 int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const void* const* packed,
                              const float* const* params, float* const* out, float* const* act,
                              const int* n_img, int H, int W, tacorl_stream_t stream);

@@ -106,6 +106,7 @@ _SIGS = {
     "tacorl_encoder_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "tacorl_encoder_fused_wpk_bytes": (_l, []),
     "tacorl_encoder_fused_supported": (_i, [_i, _i]),
+    "tacorl_encoder_fused_act_format": (_i, [_i, _i]),
     "tacorl_encoder_pack_weights": (_i, [_i, _p, _p, _p]),
     "tacorl_encoder_fwd_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "tacorl_encoder_fwd_fused_wg": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

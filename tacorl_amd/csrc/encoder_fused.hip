@@ -1240,6 +1240,13 @@ static int ef_launch(EFArgs& a, int nb, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;
 }
 
+/* What the fused forward writes into a problem's act block for this geometry: 0 - not a fused geometry; 1 - y1 / y2 as bf16 at the
+ * start of their slots (what tacorl_encoder_bwd_fused reads); 2 - everything fp32 (what the per-layer tacorl_encoder_bwd reads). */
+extern "C" int tacorl_encoder_fused_act_format(int H, int W) {
+  if (ef_ring_supported(H, W)) return 2;
+  return tacorl_encoder_fused_supported(H, W) ? 1 : 0;
+}
+
 extern "C" int tacorl_encoder_fwd_fused(int nprob, const void* const* img, const void* const* packed,
                                         const float* const* params, float* const* out, float* const* act,
                                         const int* n_img, int H, int W, tacorl_stream_t stream) {
@@ -1270,8 +1277,7 @@ extern "C" int tacorl_encoder_fwd_fused_wg(int nprob, const void* const* img, co
     a.p[p].img = (const __bf16*)img[p]; a.p[p].wpk = (const u32x4*)packed[p]; a.p[p].params = params[p];
     a.p[p].out = out[p]; a.p[p].n_img = n_img[p];
     a.p[p].act = act ? act[p] : nullptr;
-    if (ring && a.p[p].act) return TACORL_EINVAL;  // the ring kernel does not save activations
-    a.p[p].cost = a.p[p].act ? EF_ACT_COST : 64;
+    a.p[p].cost = a.p[p].act ? (ring ? 96 : EF_ACT_COST) : 64;  // (ring: 406 KB of fp32 stores per 150 x 200 image)
     if (n_img[p] > 0 && !first) units += setup_cost;
     a.p[p].ustart = units;
     units += (long)a.p[p].cost * n_img[p];

@@ -17,8 +17,10 @@
 //    pixels the lane has seen, rescaled when the maximum moves - v3[NT3] of encoder_fused would be 80 registers here); the 16
 //    pixel lanes are merged once per image.  A tile's soft-argmax update runs inside the next tile's MFMA chain.
 // Every fragment set is double: the next tile's reads are issued between the running chain's MFMAs into the other set.
-// Activations are not saved (the problems a backward follows take the per-layer forward for such geometries: there is no
-// LDS-resident conv backward for them, engine._fused_bwd_ok).
+// Problems a backward follows save their activations from the same launch in the layout the PER-LAYER backward reads
+// (tacorl_encoder_bwd: there is no LDS-resident conv backward for these geometries) - y1 / y2 / y3, the soft-argmax features
+// and fc1 all as fp32 at their tacorl_encoder_act_layout offsets (encoder_fused_kernel stores y1 / y2 as bf16 for ITS backward);
+// tacorl_encoder_fused_act_format() tells the caller which of the two a geometry writes.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -34,7 +36,7 @@ struct ERGeom {
   static constexpr int OH2 = (OH1 - 4) / 2 + 1, OW2 = (OW1 - 4) / 2 + 1;
   static constexpr int OH3 = OH2 - 2, OW3 = OW2 - 2;
   static constexpr int ROW_BYTES = W * 6, IMG_BYTES = H * ROW_BYTES;
-  static constexpr int NPX2 = OH2 * OW2, NPX3 = OH3 * OW3;
+  static constexpr int NPX1 = OH1 * OW1, NPX2 = OH2 * OW2, NPX3 = OH3 * OW3;
   static constexpr int NB = (OH1 + ER_BR - 1) / ER_BR;
   static constexpr int BAND_ROWS = 4 * ER_BR + 4, BAND_BYTES = BAND_ROWS * ROW_BYTES, LDS_IMG = (BAND_BYTES + 15) & ~15;
   static constexpr int NPXB = ER_BR * OW1, NT1 = (NPXB + 15) >> 4, PER1 = (NT1 + 3) >> 2;
@@ -213,6 +215,11 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
               const u32x2 hi = pack4_bf16(relu1(A1[0]), relu1(A1[1]), relu1(A1[2]), relu1(A1[3]));
               *reinterpret_cast<u32x4*>(act1 + (oyi & (ER_R1 - 1)) * G::PITCH1 + OX[i] * ACT1_STRIDE + 16 * g) =
                   u32x4{lo[0], lo[1], hi[0], hi[1]};  // channels 8 g .. 8 g + 7
+              if (P.act) {  // saved for the per-layer backward: fp32, [pixel][32] (uniform base + 32-bit lane offset)
+                float* y = P.act + (long)cur * (G::NPX1 * 32) + (unsigned)((oyi * G::OW1 + OX[i]) * 32 + 8 * g);
+                *reinterpret_cast<f32x4*>(y) = f32x4{relu1(A0[0]), relu1(A0[1]), relu1(A0[2]), relu1(A0[3])};
+                *reinterpret_cast<f32x4*>(y + 4) = f32x4{relu1(A1[0]), relu1(A1[1]), relu1(A1[2]), relu1(A1[3])};
+              }
             }
           };
 #pragma unroll
@@ -270,6 +277,11 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
               const int oy2 = pm / G::OW2, ox2 = pm - oy2 * G::OW2;
               *reinterpret_cast<u32x4*>(act2 + oy2 * G::PITCH2 + ox2 * G::PX2 + (32 * cg + 8 * g) * 2) =
                   u32x4{lo[0], lo[1], hi[0], hi[1]};
+              if (P.act) {
+                float* y = P.act + P.a_y2 + (long)cur * (G::NPX2 * 64) + (unsigned)(pm * 64 + 32 * cg + 8 * g);
+                *reinterpret_cast<f32x4*>(y) = f32x4{relu1(C0[0]), relu1(C0[1]), relu1(C0[2]), relu1(C0[3])};
+                *reinterpret_cast<f32x4*>(y + 4) = f32x4{relu1(C1[0]), relu1(C1[1]), relu1(C1[2]), relu1(C1[3])};
+              }
             }
           };
           if (t0u < t2_hiu) {
@@ -312,6 +324,11 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
         };
         // one pixel per lane joins the lane's running state
         auto join = [&](const f32x4& acc, float fxv, float fyv, bool ok) {
+          if (P.act && ok) {  // y3 (fp32, [pixel][64]); the lane's pixel index back from its coordinates
+            const int px = (int)fyv * G::OW3 + (int)fxv;
+            *reinterpret_cast<f32x4*>(P.act + P.a_y3 + (long)cur * (G::NPX3 * 64) + (unsigned)(px * 64 + 16 * w + 4 * g)) =
+                f32x4{relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3])};
+          }
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const float v = ok ? relu1(acc[q]) * inv_t : NEG;
@@ -383,6 +400,11 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
           }
           const u32x2 lo = pack4_bf16(fx_[0], fy_[0], fx_[1], fy_[1]), hi = pack4_bf16(fx_[2], fy_[2], fx_[3], fy_[3]);
           *reinterpret_cast<u32x4*>(sa + slot * SA_STRIDE + 4 * (16 * w + 4 * g)) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          if (P.act) {
+            float* f = P.act + P.a_sa + (long)cur * 128 + (unsigned)(2 * (16 * w + 4 * g));
+            *reinterpret_cast<f32x4*>(f) = f32x4{fx_[0], fy_[0], fx_[1], fy_[1]};
+            *reinterpret_cast<f32x4*>(f + 4) = f32x4{fx_[2], fy_[2], fx_[3], fy_[3]};
+          }
         }
       }
 
@@ -416,6 +438,8 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
             const f32x4 r = {fmaxf(acc[0] + bf1[j][0], 0.f), fmaxf(acc[1] + bf1[j][1], 0.f), fmaxf(acc[2] + bf1[j][2], 0.f),
                              fmaxf(acc[3] + bf1[j][3], 0.f)};
             *reinterpret_cast<u32x2*>(h1 + r16 * H1_STRIDE + (16 * (4 * w + j) + 4 * g) * 2) = pack4_bf16(r[0], r[1], r[2], r[3]);
+            if (P.act && r16 < n_in_chunk)
+              *reinterpret_cast<f32x4*>(P.act + P.a_h1 + img0 * 256 + (unsigned)(r16 * 256 + 16 * (4 * w + j) + 4 * g)) = r;
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

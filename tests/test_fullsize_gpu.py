@@ -525,6 +525,9 @@ FULL_TACORL = {
     "c2": (256, 16, {"rgb_static": (84, 84)}, 16, False),  # the headline configuration (BASELINE configs[1])
     "c3": (256, 16, {"rgb_static": (84, 84)}, 16, True),
     "c4_share": (64, 32, {"rgb_static": (128, 128), "rgb_gripper": (128, 128)}, 32, False),
+    # experiment=tacorl_real_world at the reference's own geometry (rgb_static un-resized, rl_real_world_train.yaml:2-10): in bf16
+    # the 150 x 200 camera's no-grad problems take encoder_ring.hip, the ones a backward follows the per-layer path
+    "c4_real": (16, 32, {"rgb_static": (150, 200), "rgb_gripper": (84, 84)}, 32, False),
 }
 
 
