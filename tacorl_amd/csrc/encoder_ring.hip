@@ -87,7 +87,12 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
     tid += threadIdx.x;
     const int w = tid >> 6, l = tid & 63, r16 = l & 15, g = l >> 4;
     const int wu = __builtin_amdgcn_readfirstlane(w);
-    const int cg = w & 1, ph = w >> 1;  // conv2: wave = (channel half, tile parity)
+    // conv2: wave = (channel half, tile parity), as encoder_fused_kernel.  Measured and rejected (same-box A/B, 2 368 images,
+    // scratch/r6_ring_ab.sh): wave = ONE 16-channel tile of every pixel tile - balanced for any tile count per band, where the
+    // parity split idles a wave for a 32-MFMA tile whenever a band brings an odd count - 0.2628 -> 0.2815 ms: every fragment
+    // read then feeds one MFMA instead of two, and reads are what a lone wave per SIMD pays for; the band's DMA pieces issued
+    // by waves 1 - 3 only (wave 0 carries conv1's 13th tile) - 0.2626 -> 0.2690 ms.
+    const int cg = w & 1, ph = w >> 1;
 
     unsigned char* const act1 = lds + 2 * G::LDS_IMG;
     unsigned char* const act2 = act1 + G::ACT1_BYTES;
