@@ -527,6 +527,7 @@ __global__ __launch_bounds__(256) void softargmax_bwd_kernel(SaArgs a, int OH, i
 }
 // Same math, all problems of the fused backward in one launch: one workgroup per image, a wave owns 16
 // channels x 4 pixel groups, every activation is read once and kept in registers.
+#define SAB_MAXI_HUGE 80 // <= 320 pixels (150 x 200: 315), 160 registers of activations / exponentials per lane: the per-layer backward in bf16 mode
 #define SAB_MAXI_BIG 36  // pixels per lane: conv3 output <= 52 pixels (49 / 16 / 8 at 84 / 64 / 44x60) with 13, <= 144 (128 x 128) with 36
 struct SabArgs {
   const float* y3[EBW_MAXP];
@@ -764,10 +765,26 @@ extern "C" int tacorl_encoder_bwd(int nprob, const void* const* img, const float
       sg.dtp[p] = dtp[p]; sg.n[p] = n_img[p];
       mxn = n_img[p] > mxn ? n_img[p] : mxn;
     }
-    if (mxn > 0) hipLaunchKernelGGL(softargmax_bwd_kernel, dim3(mxn, nprob), dim3(256), 0, st, sg, d.c3.OH, d.c3.OW);
-    for (int p = 0; p < nprob; p++)
-      if (n_img[p] > 0)
-        hipLaunchKernelGGL(sum_to_scalar_kernel, dim3(1), dim3(256), 0, st, dtp[p], n_img[p], grads[p] + po[E_T], accumulate);
+    const int P3 = d.c3.OH * d.c3.OW;
+    if (cd == TACORL_BF16 && nprob <= EBW_MAXP && P3 > 4 * SAB_MAXI_BIG && P3 <= 4 * SAB_MAXI_HUGE) {
+      // Round 6 (bf16 mode, conv3 outputs beyond the LDS-resident backward's - 150 x 200: 15 x 21 pixels): the register-resident
+      // batch kernel of the fused backward - every activation read once, one exponential per element - instead of three passes
+      // with a division per element (89 us -> for 384 images at 150 x 200); the temperature partials of all problems in one launch.
+      SabArgs sb{};
+      for (int p = 0; p < nprob; p++) {
+        sb.y3[p] = y3[p]; sb.temp[p] = params[p] + po[E_T]; sb.sa[p] = sa[p]; sb.d_sa[p] = d_sa[p]; sb.dz3[p] = dz3[p];
+        sb.dtp[p] = dtp[p]; sb.gtemp[p] = grads[p] + po[E_T]; sb.n[p] = n_img[p];
+      }
+      if (mxn > 0) {
+        hipLaunchKernelGGL(softargmax_bwd_batch_kernel<SAB_MAXI_HUGE>, dim3(mxn, nprob), dim3(256), 0, st, sb, P3, d.c3.OW);
+        hipLaunchKernelGGL(sum_to_scalar_batch_kernel, dim3(nprob), dim3(256), 0, st, sb, accumulate);
+      }
+    } else {
+      if (mxn > 0) hipLaunchKernelGGL(softargmax_bwd_kernel, dim3(mxn, nprob), dim3(256), 0, st, sg, d.c3.OH, d.c3.OW);
+      for (int p = 0; p < nprob; p++)
+        if (n_img[p] > 0)
+          hipLaunchKernelGGL(sum_to_scalar_kernel, dim3(1), dim3(256), 0, st, dtp[p], n_img[p], grads[p] + po[E_T], accumulate);
+    }
   }
   // conv3
   CHECK(k_conv_wgrad<float>(nprob, (const void* const*)y2, (const float* const*)dz3, n_img, d.c3, g_w3, g_b3, accumulate, slab, slab_bytes, cd, st));
