@@ -332,6 +332,9 @@ static int k_conv_dgrad(int nnets, const float* const* dout, const float* const*
       ep.out[p] = din[n]; ep.src[p] = src ? src[n] : nullptr;
       g.M[p] = n_img[n] * nh * nw; g.R[p] = TA * TB * cg.CO;
     }
+  ep.vec = 1;  // C % 4 == 0 (checked above); 16-byte aligned buffers or the scalar stores
+  for (int n = 0; n < nnets; n++)
+    if (((uintptr_t)din[n] | (uintptr_t)(src ? src[n] : nullptr)) & 15) ep.vec = 0;
   return gemm_launch<ConvDgradALoader, ConvDgradWLoader, false, true, ConvDgradStore>(la, lb, ep, g, cd, st);
 }
 

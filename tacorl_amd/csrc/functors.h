@@ -74,6 +74,50 @@ struct ConvColLoader {
 #pragma unroll
     for (int t = 0; t < 4; t++) v[t] = (float)q[t];
   }
+  // Column / pixel state (round 6) for the weight gradients (TA = true: the im2col matrix is the [R = pixel][M = k] operand).
+  // There a thread of gemm_kernel keeps ONE k quad for the whole launch and walks down the pixels BK at a time: k -> (ky,
+  // offset in the run) is decomposed once (col), a pixel once (pix), and advance() steps the pixel by d with adds and carries -
+  // no integer division in the staging loop (the per-layer conv backward of 150 x 200: 183 + 172 us of weight gradients).
+  static constexpr bool COL_STATE = true;
+  struct Col { int off, k; };              // off < 0: k >= K (zero / ones column)
+  struct Pix { const InT* base; int ox, oy, left; };  // left = valid rows from this one on (<= 0: beyond the problem)
+  __device__ __forceinline__ Col col(int, int k) const {
+    const int K = g.KH * g.KW * g.C, run = g.KW * g.C;
+    Col c;
+    c.k = k;
+    if (k >= K) { c.off = -1; return c; }
+    const int ky = k / run;
+    c.off = ky * g.W * g.C + (k - ky * run);
+    return c;
+  }
+  __device__ __forceinline__ Pix pix(int p, int m) const {
+    Pix x;
+    x.left = rows[p] - m;
+    const int px = g.OH * g.OW, mc = x.left > 0 ? m : 0;
+    const int img = mc / px, pp = mc - img * px;
+    x.oy = pp / g.OW; x.ox = pp - x.oy * g.OW;
+    x.base = ptr[p] + (((long)img * g.H + x.oy * g.S) * g.W + x.ox * g.S) * g.C;
+    return x;
+  }
+  __device__ __forceinline__ void advance(Pix& x, int d) const {
+    x.left -= d;
+    x.ox += d;
+    x.base += d * g.S * g.C;
+    while (x.ox >= g.OW) { x.ox -= g.OW; x.oy++; x.base += (g.S * g.W - g.OW * g.S) * g.C; }
+    while (x.oy >= g.OH) { x.oy -= g.OH; x.base += (g.H - g.OH * g.S) * g.W * g.C; }
+  }
+  __device__ __forceinline__ void load_cp(const Col& c, const Pix& x, float (&v)[4]) const {
+    if (x.left <= 0 || c.off < 0) {
+      const int K = g.KH * g.KW * g.C;
+#pragma unroll
+      for (int t = 0; t < 4; t++) v[t] = (ones_col && x.left > 0 && c.k + t == K) ? 1.f : 0.f;
+      return;
+    }
+    const InT* q = x.base + c.off;
+    if (vec) { load4_as_float<InT>(q, v); return; }
+#pragma unroll
+    for (int t = 0; t < 4; t++) v[t] = (float)q[t];
+  }
 };
 
 // Conv backward-data as a gather.  Problem index = net * S*S + (py*S + px): one GEMM per
@@ -94,6 +138,31 @@ struct ConvDgradALoader {
     const int oy = y2 - a, ox = x2 - b;
     if (py + S * a >= g.KH || px + S * b >= g.KW || oy < 0 || oy >= g.OH || ox < 0 || ox >= g.OW) return;
     load4_as_float<float>(ptr[p] + (((long)img * g.OH + oy) * g.OW + ox) * g.CO + co, v);
+  }
+  // Row state (round 6, as ConvColLoader's): a thread of gemm_kernel stages the same few rows m = (img, y2, x2) of its parity
+  // class for every K tile - the class geometry and the row's decomposition (four integer divisions) once per launch, the
+  // per-load work is k -> (tap, co) and the halo test.  The per-layer conv backward of 150 x 200 spent 222 + 138 us here.
+  static constexpr bool ROW_STATE = true;
+  struct Row { const float* base; int y2, x2, py, px; };  // base: dOut[img][y2][x2][0]; y2 < 0: no such row
+  __device__ __forceinline__ Row row(int p, int m) const {
+    const int S = g.S, cls = p % (S * S);
+    Row r;
+    r.py = cls / S; r.px = cls % S;
+    const int nh = (g.H - r.py + S - 1) / S, nw = (g.W - r.px + S - 1) / S;
+    if (m >= n_img[p] * nh * nw) { r.y2 = -1; r.x2 = 0; r.base = ptr[p]; return r; }
+    const int img = m / (nh * nw), pp = m - img * nh * nw;
+    r.y2 = pp / nw; r.x2 = pp - r.y2 * nw;
+    r.base = ptr[p] + (((long)img * g.OH + r.y2) * g.OW + r.x2) * g.CO;
+    return r;
+  }
+  __device__ __forceinline__ void load_row(const Row& rw, int k, float (&v)[4]) const {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (rw.y2 < 0 || k >= TA * TB_ * g.CO) return;
+    const int S = g.S;
+    const int tap = k / g.CO, co = k - tap * g.CO, a = tap / TB_, b = tap - a * TB_;
+    const int oy = rw.y2 - a, ox = rw.x2 - b;
+    if (rw.py + S * a >= g.KH || rw.px + S * b >= g.KW || oy < 0 || oy >= g.OH || ox < 0 || ox >= g.OW) return;
+    load4_as_float<float>(rw.base - (a * g.OW + b) * g.CO + co, v);
   }
 };
 // Matching weights: logical [i = k' = (a, b, co)][j = ci] = W[co][py + S a][px + S b][ci].
@@ -179,13 +248,28 @@ struct ConvDgradStore {
   float* out[GEMM_MAXP];
   const float* src[GEMM_MAXP];  // the conv input activation (post-ReLU) or NULL
   ConvGeom g;
-  static constexpr bool VEC = false;
-  __device__ __forceinline__ void store(int p, int, int m, int n, float acc) const {
+  int vec;  // host-set: C % 4 == 0 and 16-byte aligned pointers -> store4 is legal
+  // Round 6: contiguous along n (the input channel) - a lane ends with 4 consecutive channels of one pixel: one row
+  // decomposition, one 16-byte mask load and one 16-byte store instead of four of each (the scalar form was most of what the
+  // per-layer conv backward of 150 x 200 cost).  Same products, same accumulation order: bit-identical to the scalar form.
+  static constexpr bool VEC = true;
+  __device__ __forceinline__ long pos(int p, int m) const {
     const int S = g.S, cls = p % (S * S), py = cls / S, px = cls % S;
     const int nh = (g.H - py + S - 1) / S, nw = (g.W - px + S - 1) / S;
     const int img = m / (nh * nw), pp = m - img * nh * nw, y2 = pp / nw, x2 = pp - y2 * nw;
-    long o = (((long)img * g.H + S * y2 + py) * g.W + S * x2 + px) * g.C + n;
+    return (((long)img * g.H + S * y2 + py) * g.W + S * x2 + px) * g.C;
+  }
+  __device__ __forceinline__ void store(int p, int, int m, int n, float acc) const {
+    const long o = pos(p, m) + n;
     out[p][o] = (src[p] && !(src[p][o] > 0.f)) ? 0.f : acc;
+  }
+  __device__ __forceinline__ void store4(int p, int, int m, int n, f32x4 acc) const {
+    const long o = pos(p, m) + n;
+    if (src[p]) {
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(src[p] + o);
+      acc = f32x4{sv[0] > 0.f ? acc[0] : 0.f, sv[1] > 0.f ? acc[1] : 0.f, sv[2] > 0.f ? acc[2] : 0.f, sv[3] > 0.f ? acc[3] : 0.f};
+    }
+    *reinterpret_cast<f32x4*>(out[p] + o) = acc;
   }
 };
 // wgrad: GEMM row = k (input feature / im2col column, k == K is the bias column),

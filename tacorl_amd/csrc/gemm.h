@@ -49,6 +49,9 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], int q) {
 template <class L, class = void> struct has_row_state { static constexpr bool value = false; };
 template <class L> struct has_row_state<L, decltype((void)L::ROW_STATE)> { static constexpr bool value = L::ROW_STATE; };
 
+template <class L, class = void> struct has_col_state { static constexpr bool value = false; };
+template <class L> struct has_col_state<L, decltype((void)L::COL_STATE)> { static constexpr bool value = L::COL_STATE; };
+
 template <class Atom, class LA, class LB, bool TA, bool TB, class Epi, int BM, int BN, int BKT = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmArgs g) {
   typedef typename Atom::elem T;
@@ -86,11 +89,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(LA la, LB lb, Epi epi, GemmAr
       return 0;
     }
   }();
+  // (transposed operands of loaders with a column / pixel state - implicit im2col in the weight gradients: this thread's k quad is
+  // the same for every tile, its ACH pixels step by BK from one fetch to the next - fetch() is called with r_begin, r_begin + BK, ...)
+  auto acols = [&]() {
+    if constexpr (TA && has_col_state<LA>::value) {
+      static_assert(64 % (BM / 4) == 0, "a thread keeps one k quad over its chunks");
+      struct C_ { typename LA::Col c; typename LA::Pix x[ACH]; } o;
+      o.c = la.col(p, m0 + ((tid >> 2) % (BM / 4)) * 4);
+#pragma unroll
+      for (int i = 0; i < ACH; i++) o.x[i] = la.pix(p, r_begin + ((tid + i * 256) / BM) * 4 + (tid & 3));
+      return o;
+    } else {
+      return 0;
+    }
+  }();
   auto fetch = [&](int r0) {
 #pragma unroll
     for (int i = 0; i < ACH; i++) {
       int c = tid + i * 256;
-      if constexpr (!TA && has_row_state<LA>::value) la.load_row(arows.r[i], r0 + (c % (BK / 4)) * 4, ra[i]);
+      if constexpr (TA && has_col_state<LA>::value) { la.load_cp(acols.c, acols.x[i], ra[i]); la.advance(acols.x[i], BK); }
+      else if constexpr (!TA && has_row_state<LA>::value) la.load_row(arows.r[i], r0 + (c % (BK / 4)) * 4, ra[i]);
       else if (!TA) la.load(p, m0 + c / (BK / 4), r0 + (c % (BK / 4)) * 4, ra[i]);
       else     la.load(p, r0 + (c / BM) * 4 + (c & 3), m0 + ((c >> 2) % (BM / 4)) * 4, ra[i]);  // quad = 4 rows r, same 4 m
     }
