@@ -604,7 +604,11 @@ def time_other_configs(dev, dtype, budget_s=1.0):
             ev1.record()
             torch.cuda.synchronize()
             ems = ev0.elapsed_time(ev1) / 50
-            res.update(enc_ms=round(ems, 4), enc_images=n_img, enc_frac=round(n_img * flop_per_img / (ems * 1e-3) / 1e12 / peak, 4))
+            if isinstance(flop_per_img, dict):  # cameras of different geometries (one fused launch each): FLOPs summed per camera
+                flop = sum(sum(x[4] for x in eng._all_problems(c)) * flop_per_img[c] for c in eng.cams)
+            else:
+                flop = n_img * flop_per_img
+            res.update(enc_ms=round(ems, 4), enc_images=n_img, enc_frac=round(flop / (ems * 1e-3) / 1e12 / peak, 4))
         fin = getattr(eng, "logs", getattr(mod, "logs", None))
         res["losses_finite"] = bool(torch.isfinite(fin).all().item()) if fin is not None else None
         return res
@@ -646,7 +650,9 @@ def time_other_configs(dev, dtype, budget_s=1.0):
         ("c3_tacorl_finetune_b256", lambda: tacorl(cams84, 16, 16, True), lambda: play_batch(256, 16, cams84), (), 256, ENC_FLOP_PER_IMG_84),
         # 2 * 17 676 288 MAC per 128 x 128 image
         ("c4_share_dualcam128_b64", lambda: tacorl(cams128, 32, 32, False), lambda: play_batch(64, 32, cams128), (), 64, 35.353e6),
-        ("c4_real_150x200_b64", lambda: tacorl(cams_rw, 32, 32, False), lambda: play_batch(64, 32, cams_rw), (), 64, None),
+        # 150 x 200: 2 * 35 303 424 MAC per image (encoder_ring.hip); enc_ms = both cameras' fused launches
+        ("c4_real_150x200_b64", lambda: tacorl(cams_rw, 32, 32, False), lambda: play_batch(64, 32, cams_rw), (), 64,
+         {"rgb_gripper": ENC_FLOP_PER_IMG_84, "rgb_static": 70.607e6}),
         ("c5_cql_n32_b1024", cql, lambda: to_dev(synth.make_transition_batch(7, 1024, cams84)), (0,), 1024, ENC_FLOP_PER_IMG_84),
         ("c1_playlmp_b32", lambda: lmp(["rgb_static"], 16, 16), lambda: play_batch(32, 16, cams84), (0,), 32, None),
         ("c1_playlmp_b256", lambda: lmp(["rgb_static"], 16, 16), lambda: play_batch(256, 16, cams84), (0,), 256, None),
