@@ -132,14 +132,16 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
     // + per-lane offset, LDS destination in M0).  Wave w moves the band's chunks [256 NPIECE w, 256 NPIECE (w + 1)).
     const unsigned dma_voff = (unsigned)l * 16u;
     const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)lds;
-    auto dma_band = [&](long img_idx, int band, int bufi) {
+    // pieces [i0, i1) of this wave's share of (image, band)
+    auto dma_pieces = [&](long img_idx, int band, int bufi, int i0, int i1) {
       const int row0 = 4 * ER_BR * band;
       const int rows = min(G::BAND_ROWS, G::H - row0);
       const int n16 = rows * (G::ROW_BYTES / 16);
       const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img) + img_idx * G::IMG_BYTES + row0 * G::ROW_BYTES;
       const int c0w = wu * (G::NPIECE * 64);
 #pragma unroll
-      for (int i = 0; i < G::NPIECE; i++) {
+      for (int i = i0; i < i1; i++) {
+        if (i >= G::NPIECE) break;
         const int c0 = c0w + 64 * i;  // first chunk of this piece (wave-uniform)
         if (c0 < n16) {
           if (c0 + l < n16) {
@@ -153,6 +155,12 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
         }
       }
     };
+    auto dma_band = [&](long img_idx, int band, int bufi) { dma_pieces(img_idx, band, bufi, 0, G::NPIECE); };
+    // In the image loop a band's pieces ride in conv1's MFMA chains, DPT per tile behind the second and fourth MFMA of the tile's
+    // first chain (every wave has at least PER1 - 1 tiles): issued in one burst in front of conv1 a piece stands 100 - 185 clk at
+    // issue (MI355X_MICROARCH.md, LDS-DMA piece issue cost), in the shadow of a running MFMA part of that is hidden.
+    constexpr int DPT = (G::NPIECE + G::PER1 - 2) / (G::PER1 - 1);
+    static_assert(G::PER1 >= 2 && DPT <= 2 && G::NT1 >= 4 * (G::PER1 - 1), "a tile's first chain places at most two DMA pieces");
 
     long cur = f0;
     int it = 0, buf = 0;
@@ -167,8 +175,10 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
 #pragma unroll 1
       for (int band = 0; band < G::NB; band++) {
         // the other buffer was last read by the previous band's conv1, two barriers ago
-        if (band + 1 < G::NB) dma_band(cur, band + 1, buf ^ 1);
-        else if (has_next) dma_band(cur + 1, 0, buf ^ 1);
+        // what streams in beside this band's conv1: the next band, or the next image's first (wave-uniform)
+        const bool dma_on = band + 1 < G::NB || has_next;
+        const long dma_img = band + 1 < G::NB ? cur : cur + 1;
+        const int dma_bnd = band + 1 < G::NB ? band + 1 : 0;
         // ------------------------------------------------ conv1: 8x8 stride 4, 3 -> 32, this band's 4 rows
         {
           const unsigned char* ib = lds + buf * G::LDS_IMG;
@@ -205,6 +215,7 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
             for (int s = 1; s < 6; s++) {
               MFMA_AW(A0, wc1a[s], fc[s]);
               if (pre) fn[s - 1] = ld1one(nb, s - 1);
+              if ((s == 1 || s == 3) && (s >> 1) < DPT && dma_on) dma_pieces(dma_img, dma_bnd, buf ^ 1, i * DPT + (s >> 1), i * DPT + (s >> 1) + 1);
               __builtin_amdgcn_sched_barrier(0);
             }
             MFMA_FIRST_AW(A1, wc1b[0], fc[0], bias1b);
@@ -234,9 +245,9 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
             }
           }
         }
-        // this wave's share of the next band has landed, its conv1 rows are written; the barrier publishes both and
-        // "everyone is done reading this band"
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // this wave's conv1 rows are written; the barrier publishes them and "everyone is done reading this band" (the next
+        // band's pieces have until the barrier behind conv2 to land)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         buf ^= 1;
 
@@ -305,8 +316,10 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
           }
           t2_lo = t2_hi;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // conv2's reads of the ring are over (the next band overwrites four slots), its rows are visible
+        // this wave's share of the next band has landed; conv2's reads of the ring are over (the next band overwrites four
+        // slots), its rows are visible
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
       }
 
       // ------------------------------------------------ conv3: 3x3 stride 1, 64 -> 64, online soft-argmax per lane
