@@ -121,3 +121,86 @@ def test_encoder_fused_code_object_leaves_m0_to_the_dma_pieces(tmp_path):
             bad.append(f"{kernel}: {ins}")
     assert seen > 0, "no M0 write found at all: has the kernel's DMA changed?"
     assert not bad, bad[:10]
+
+
+def _kernel_disassembly(obj_name, tmp_path):
+    """{kernel name: [instruction text]} of an in-tree gfx950 object file (None when it or the ROCm llvm tools are missing)."""
+    import re
+    import shutil
+    import subprocess
+
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = os.path.join(here, "tacorl_amd", "lib", "obj", obj_name)
+    tools = "/opt/rocm/lib/llvm/bin"
+    need = [os.path.join(tools, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not os.path.exists(obj) or not all(os.path.exists(t) or shutil.which(os.path.basename(t)) for t in need):
+        return None
+    fat, co = str(tmp_path / (obj_name + ".fat")), str(tmp_path / (obj_name + ".co"))
+    subprocess.run([need[0], "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+    subprocess.run([need[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    f"--output={co}"], check=True)
+    dis = subprocess.run([need[2], "-d", co], check=True, capture_output=True, text=True).stdout
+    out, kernel = {}, None
+    for ln in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+        if m:
+            kernel = m.group(1)
+            out.setdefault(kernel, [])
+            continue
+        ins = re.sub(r"\s+", " ", ln.split("//")[0]).strip()
+        if kernel is not None and ins and not ins.endswith(":"):
+            out[kernel].append(ins)
+    return out
+
+
+@pytest.mark.parametrize("obj,kernel", [("encoder_fused.o", "encoder_fused_kernel"), ("encoder_ring.o", "encoder_ring_kernel")])
+def test_encoder_code_objects_wait_for_mfma_results(obj, kernel, tmp_path):
+    """The fused encoder kernels issue their MFMAs from inline asm, which hipcc's hazard recogniser does not see: the
+    read-after-MFMA wait states (an XDL result needs ~12 before a non-MFMA reader, cdna_hip_programming.md section 5.7) are the
+    source's own `s_nop`s and the distance its schedules keep.  What the source cannot see are the register COPIES hipcc adds
+    at a branch merge or a loop edge for a live accumulator - round 6 met `v_mov_b64` copies three instructions behind a chain's
+    last MFMA (pre-MFMA values, wrong pixels).  Checked on the built code object, in program order: no non-MFMA instruction
+    reads a VGPR that an MFMA wrote fewer than 10 wait states earlier (s_nop N = N + 1, an MFMA in between = 4, anything else = 1)."""
+    import re
+
+    dis = _kernel_disassembly(obj, tmp_path)
+    if dis is None:
+        pytest.skip("needs the in-tree object file (python -m tacorl_amd.build) and the ROCm llvm tools")
+    vreg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+    def regs(tok):
+        r = set()
+        for m in vreg.finditer(tok):
+            if m.group(1) is not None:
+                r.add(int(m.group(1)))
+            else:
+                r.update(range(int(m.group(2)), int(m.group(3)) + 1))
+        return r
+
+    checked, bad = 0, []
+    for name, body in dis.items():
+        if kernel not in name:
+            continue
+        recent = []  # [set of destination VGPRs, wait states since]
+        for ins in body:
+            op, _, rest = ins.partition(" ")
+            ops_ = [t.strip() for t in rest.split(",")]
+            if op.startswith("v_mfma"):
+                for r in recent:
+                    r[1] += 4
+                recent.append([regs(ops_[0]), 0])
+                checked += 1
+            else:
+                # sources: every operand of a store / DS write, every operand but the first of anything else that names VGPRs
+                is_store = op.startswith(("ds_write", "global_store", "scratch_store", "buffer_store", "flat_store"))
+                src = set().union(*[regs(t) for t in (ops_ if is_store else ops_[1:])]) if ops_ else set()
+                for dst, age in recent:
+                    if age < 10 and src & dst:
+                        bad.append(f"{name}: `{ins}` reads v{sorted(src & dst)} {age} wait states behind the MFMA that writes them")
+                step = int(ops_[0], 0) + 1 if op == "s_nop" else 1
+                for r in recent:
+                    r[1] += step
+            recent = [r for r in recent if r[1] < 16]
+    assert checked > 100, f"no {kernel} MFMAs found: has the kernel changed?"
+    assert not bad, bad[:8]
+
