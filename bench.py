@@ -147,8 +147,11 @@ def time_encoder_in_step(mod, batch, steps=40):
 def kernel_source_hash():
     import hashlib
 
-    with open(os.path.join(ROOT, "tacorl_amd", "csrc", "encoder_fused.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()
+    h = hashlib.sha256()  # the kernel's source file and the header that holds its MFMA / DPP macros and launch table
+    for name in ("encoder_fused.hip", "encoder_fused.h"):
+        with open(os.path.join(ROOT, "tacorl_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def measured_traffic(n_img, fused, dtype):

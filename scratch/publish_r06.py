@@ -17,7 +17,9 @@ for k in ("c3", "c4", "c4real", "c5", "playlmp"):
         cp(f"{k}_kernel_stats.csv", f"r06_{k}_kernel_stats.csv")
 line = json.load(open(os.path.join(S, "bench_line.json")))
 raw = json.load(open(os.path.join(S, "fused_traffic_raw.json")))
-sha = hashlib.sha256(open(os.path.join(ROOT, "tacorl_amd", "csrc", "encoder_fused.hip"), "rb").read()).hexdigest()
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+sha = bench.kernel_source_hash()  # (encoder_fused.hip + encoder_fused.h)
 traffic = {"encoder_fused_hip_sha256": sha,
            "bench_launch": dict(raw, images_per_launch=6912,
                                 algorithmic_bytes={"images_bf16": 6912 * 42336, "outputs_f32": 6912 * 128, "saved_activations_1536_images": 77800000},
