@@ -966,7 +966,7 @@ extern "C" int tacorl_encoder_bwd_fused_conv_parts(int nprob, const void* const*
   EncBwdPlan pl;
   if (!enc_bwd_plan(nprob, n_img, H, W, pl)) FAIL(TACORL_EINVAL, "encoder_bwd_fused_conv: geometry %dx%d / nprob %d", H, W, nprob);
   if (ws_bytes < pl.total) FAIL(TACORL_ENOMEM, "encoder_bwd_fused_conv: workspace too small");
-  if (pl.d.c3.OH * pl.d.c3.OW > 4 * SAB_MAXI_BIG) FAIL(TACORL_EINVAL, "encoder_bwd_fused: conv3 output too large");
+  if (pl.d.c3.OH * pl.d.c3.OW > 4 * SAB_MAXI_HUGE) FAIL(TACORL_EINVAL, "encoder_bwd_fused: conv3 output too large");
   EbwProblem pr[EBW_MAXP];
   enc_bwd_conv_problems(nprob, img, params, act, grads, n_img, pl, ws, pr);
   SabArgs sb{};
@@ -990,7 +990,8 @@ extern "C" int tacorl_encoder_bwd_fused_conv_parts(int nprob, const void* const*
   if (pl.maxn > 0 && (parts & 1) && !fused3) {
     const int P3 = pl.d.c3.OH * pl.d.c3.OW;
     if (P3 <= 4 * 13) hipLaunchKernelGGL(softargmax_bwd_batch_kernel<13>, dim3((unsigned)pl.maxn, nprob), dim3(256), 0, st, sb, P3, pl.d.c3.OW);
-    else hipLaunchKernelGGL(softargmax_bwd_batch_kernel<SAB_MAXI_BIG>, dim3((unsigned)pl.maxn, nprob), dim3(256), 0, st, sb, P3, pl.d.c3.OW);
+    else if (P3 <= 4 * SAB_MAXI_BIG) hipLaunchKernelGGL(softargmax_bwd_batch_kernel<SAB_MAXI_BIG>, dim3((unsigned)pl.maxn, nprob), dim3(256), 0, st, sb, P3, pl.d.c3.OW);
+    else hipLaunchKernelGGL(softargmax_bwd_batch_kernel<SAB_MAXI_HUGE>, dim3((unsigned)pl.maxn, nprob), dim3(256), 0, st, sb, P3, pl.d.c3.OW);
     hipLaunchKernelGGL(sum_to_scalar_batch_kernel, dim3(nprob), dim3(256), 0, st, sb, accumulate);
   }
   if (!(parts & EBW_ALL)) return hipGetLastError() == hipSuccess ? TACORL_OK : TACORL_ELAUNCH;

@@ -146,8 +146,14 @@ struct TrGeo {
   static constexpr int NPIX_ALL = L::OH * L::OW;
   // conv1 of a large camera (128 x 128: 95 KB of dZ1 + the 98 KB image) does not fit LDS even single-buffered: the image
   // is then processed in NBAND bands of BR output rows = (BR - 1) S + KH input rows; dW simply keeps accumulating
-  static constexpr size_t WHOLE_BYTES = ((size_t)((NPIX_ALL + 31) / 32 * 32) * DZR + (size_t)(L::IH * L::IW * CIP + 7) / 8 * 8) * 2;
-  static constexpr int NBAND = (IMG && WHOLE_BYTES > 160 * 1024) ? 2 : 1;
+  // Round 6: any layer may be banded, in up to 4 bands (150 x 200: conv1 in 3 - 58 KB of dZ1 + 62 KB of image rows per band -,
+  // conv2 in 2 - 36 KB of dZ2 + 78 KB of conv1-output rows; conv3 fits whole): the smallest band count whose single buffer fits.
+  static constexpr size_t bytes_for(int nband) {
+    const int br = (L::OH + nband - 1) / nband, rows = nband == 1 ? L::IH : (br - 1) * L::S + L::KH;
+    return ((size_t)((br * L::OW + 31) / 32 * 32) * DZR + (size_t)(rows * L::IW * CIP + 7) / 8 * 8) * 2;
+  }
+  static constexpr size_t WHOLE_BYTES = bytes_for(1);
+  static constexpr int NBAND = bytes_for(1) <= 160 * 1024 ? 1 : bytes_for(2) <= 160 * 1024 ? 2 : bytes_for(3) <= 160 * 1024 ? 3 : 4;
   static constexpr int BR = (L::OH + NBAND - 1) / NBAND;       // output rows per band (the last band may have fewer)
   static constexpr int BROWS = NBAND == 1 ? L::IH : (BR - 1) * L::S + L::KH;  // input rows staged per band
   static constexpr int NPIX = BR * L::OW, KS = (NPIX + 31) / 32, KQ = KS * 32;
@@ -204,8 +210,8 @@ __global__ __launch_bounds__(NT) void ebw_wgrad_tr_kernel(WgArgs a) {
   const DzT* dz = reinterpret_cast<const DzT*>(a.dz[p]);
   // ---- staging: 8-element chunks, global -> registers (in flight during the MFMAs) -> LDS
   constexpr int DCG = L::CO / 8, DCH = G::NPIX * DCG, DCPT = (DCH + NT - 1) / NT;
-  constexpr int ICH = IMG ? G::BROWS * L::IW * L::CI / 8 : L::IH * L::IW * (L::CI / 8), ICPT = (ICH + NT - 1) / NT;
-  static_assert(!IMG || ((G::BROWS * L::IW * L::CI) % 8 == 0 && (G::BR * L::S * L::IW * L::CI) % 8 == 0), "image / band bytes");
+  constexpr int ICH = G::BROWS * L::IW * L::CI / 8, ICPT = (ICH + NT - 1) / NT;  // (one band's input rows; BROWS = IH without bands)
+  static_assert((G::BROWS * L::IW * L::CI) % 8 == 0 && (G::NBAND == 1 || (G::BR * L::S * L::IW * L::CI) % 8 == 0), "image / band bytes");
   bf16x8 dpre[DCPT], ipre[ICPT];
   // band b of an image: output rows [b BR, ...), dZ chunks [0, dch), input chunks [0, ich) from input row b BR S
   auto band_rows = [&](int b) { return G::NBAND == 1 ? L::OH : (L::OH - b * G::BR < G::BR ? L::OH - b * G::BR : G::BR); };
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(NT) void ebw_wgrad_tr_kernel(WgArgs a) {
     };
     // (fully unrolled the k-steps hoist their pixel -> address arithmetic: at 7 steps - conv2 of a 128 x 128 camera, 196
     // output pixels - beside 48 staging registers that was 256 registers + 54 spilled ones reloaded per image; round 5)
-    if constexpr (G::KS > 4 && (!IMG || EBW_ROLL_IMG)) {
+    if constexpr (G::KS > 4 && (!IMG || EBW_ROLL_IMG || G::KS > 16)) {  // (conv1 of 150 x 200 in 3 bands: 19 k-steps - unrolled they spill 74 registers)
 #pragma unroll 1
       for (int s = 0; s < G::KS; s++) kstep(s);
     } else {
@@ -447,14 +453,18 @@ __global__ __launch_bounds__(256) void ebw_pack2_kernel(PkArgs a, PkArgs b) {
 
 template <class L>
 constexpr int dgrad_mask_bytes() { return (L::IH * L::IW * L::CI / 8 + 15) / 16 * 16; }
+// two buffers (the next image's dZ / mask are put while this one is computed) where they fit, one otherwise (150 x 200: the
+// halo image of one conv2 / conv3 gradient is 100 / 94 KB)
 template <class L>
-constexpr size_t dgrad_lds_bytes() { return (size_t)2 * L::R * L::C * L::PP * 2 + 2 * dgrad_mask_bytes<L>(); }
+constexpr int dgrad_nbuf() { return (size_t)2 * L::R * L::C * L::PP * 2 + 2 * dgrad_mask_bytes<L>() <= 160 * 1024 ? 2 : 1; }
+template <class L>
+constexpr size_t dgrad_lds_bytes() { return (size_t)dgrad_nbuf<L>() * (L::R * L::C * L::PP * 2 + dgrad_mask_bytes<L>()); }
 
 template <class L, class DzT>
 __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
   constexpr int MPARTS = NW / L::NCOMBO, MTW = (L::MTC + MPARTS - 1) / MPARTS;
   static_assert(NW % L::NCOMBO == 0, "wave tiling");
-  constexpr int BUF = L::R * L::C * L::PP;
+  constexpr int BUF = L::R * L::C * L::PP, NB = dgrad_nbuf<L>();
   constexpr int NCG = L::CO / 8, NCH = L::OH * L::OW * NCG, CPT = (NCH + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* dzh = reinterpret_cast<__bf16*>(smem);  // 2 x [R][C][PP], zero halo
@@ -462,11 +472,11 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
   // activations are read once, coalesced, by the staging threads instead of 4 B gathers in the epilogue
   constexpr int MKB = dgrad_mask_bytes<L>(), NYC = L::IH * L::IW * L::CI / 8, CPY = (NYC + NT - 1) / NT;
   static_assert(L::CI % 8 == 0, "mask bytes hold 8 channels of one pixel");
-  unsigned char* mkb = smem + (size_t)2 * BUF * 2;
+  unsigned char* mkb = smem + (size_t)NB * BUF * 2;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, g = lane >> 4;
   const int p = blockIdx.x / a.wpp, j0 = blockIdx.x - p * a.wpp;
   const int n_img = a.n[p];
-  for (int e = tid; e < 2 * BUF / 2; e += NT) reinterpret_cast<uint32_t*>(dzh)[e] = 0u;
+  for (int e = tid; e < NB * BUF / 2; e += NT) reinterpret_cast<uint32_t*>(dzh)[e] = 0u;
   const int combo = w % L::NCOMBO, mpart = w / L::NCOMBO, cls = combo / L::NTI, nt = combo % L::NTI;
   const int py = cls / L::S, px = cls % L::S;
   bf16x8 Bf[L::KS];
@@ -539,7 +549,7 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
   if (j0 < n_img) { fetch(j0); put(dzh, mkb); }
   __syncthreads();
   int k = 0;
-  for (int img = j0; img < n_img; img += a.wpp, k ^= 1) {
+  for (int img = j0; img < n_img; img += a.wpp, k ^= (NB - 1)) {
     const int nxt = img + a.wpp;
     if (nxt < n_img) fetch(nxt);
     const __bf16* buf = dzh + k * BUF;
@@ -563,8 +573,14 @@ __global__ __launch_bounds__(NT) void ebw_dgrad_kernel(DgArgs a) {
                    (__bf16)((bits & 4) ? acc[2] : 0.f), (__bf16)((bits & 8) ? acc[3] : 0.f)};
       }
     }
-    if (nxt < n_img) put(dzh + (k ^ 1) * BUF, mkb + (k ^ 1) * MKB);
-    __syncthreads();
+    if constexpr (NB == 2) {
+      if (nxt < n_img) put(dzh + (k ^ 1) * BUF, mkb + (k ^ 1) * MKB);
+      __syncthreads();
+    } else {  // one buffer: everyone is done reading it, then the next image (already in registers) goes in
+      __syncthreads();
+      if (nxt < n_img) put(dzh, mkb);
+      __syncthreads();
+    }
   }
 }
 
@@ -1091,7 +1107,7 @@ int run(int nprob, const EbwProblem* pr, int accumulate, void* ws, size_t ws_byt
 }  // namespace
 
 // the geometries encoder_fused.hip is instantiated for (the cameras of the reference's configs)
-#define EBW_GEOMS(X) X(84, 84) X(64, 64) X(44, 60) X(128, 128)
+#define EBW_GEOMS(X) X(84, 84) X(64, 64) X(44, 60) X(128, 128) X(150, 200)
 
 // (conv3 outputs of up to 64 pixels: the soft-argmax keeps a wave's pixels of the image in registers; 128 x 128 - 144
 // pixels - spilled 155 registers and takes the separate launches)

@@ -34,6 +34,7 @@ struct EFArgs {
   int H, W, OH1, OW1, OH2, OW2, OH3, OW3;
   int img_bytes;   // H*W*3*2
   int lds_img;     // bytes reserved per image buffer (multiple of 16)
+  int act_bf16;    // encoder_ring.hip: saved y1 / y2 as bf16 at the start of their slots (1: what tacorl_encoder_bwd_fused* read) or fp32 (0)
 };
 
 // packed-fragment offsets (in 16-byte units, 64 lanes per fragment)

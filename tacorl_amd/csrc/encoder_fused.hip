@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "encoder_fused.h"
+#include "enc_bwd_fused.h"
 
 #ifndef EF_DEFER
 #define EF_DEFER 1      // 0: every pixel in the per-image tiles, as rounds 1-5 (A/B builds)
@@ -1243,7 +1244,7 @@ static int ef_launch(EFArgs& a, int nb, hipStream_t st) {
 /* What the fused forward writes into a problem's act block for this geometry: 0 - not a fused geometry; 1 - y1 / y2 as bf16 at the
  * start of their slots (what tacorl_encoder_bwd_fused reads); 2 - everything fp32 (what the per-layer tacorl_encoder_bwd reads). */
 extern "C" int tacorl_encoder_fused_act_format(int H, int W) {
-  if (ef_ring_supported(H, W)) return 2;
+  if (ef_ring_supported(H, W)) return ebw_supported(H, W) ? 1 : 2;  // (a ring geometry with / without the LDS-resident backward)
   return tacorl_encoder_fused_supported(H, W) ? 1 : 0;
 }
 
@@ -1269,6 +1270,7 @@ extern "C" int tacorl_encoder_fwd_fused_wg(int nprob, const void* const* img, co
   // every problem but the first - the weight reload of a workgroup that crosses from one problem into the next.
   const int budget = max_workgroups > 0 && max_workgroups < 256 ? max_workgroups : 256;
   const bool ring = ef_ring_supported(H, W) != 0;
+  a.act_bf16 = tacorl_encoder_fused_act_format(H, W) == 1;
   // (ring geometries: an image is ~5 x the work of an 84 x 84 one, the prologue is the same)
   const int setup_cost = ring ? EF_SETUP_COST / 4 : EF_SETUP_COST;
   long units = 0;
@@ -1277,7 +1279,7 @@ extern "C" int tacorl_encoder_fwd_fused_wg(int nprob, const void* const* img, co
     a.p[p].img = (const __bf16*)img[p]; a.p[p].wpk = (const u32x4*)packed[p]; a.p[p].params = params[p];
     a.p[p].out = out[p]; a.p[p].n_img = n_img[p];
     a.p[p].act = act ? act[p] : nullptr;
-    a.p[p].cost = a.p[p].act ? (ring ? 96 : EF_ACT_COST) : 64;  // (ring: 406 KB of fp32 stores per 150 x 200 image)
+    a.p[p].cost = a.p[p].act ? (ring ? (a.act_bf16 ? 84 : 96) : EF_ACT_COST) : 64;  // (ring, 150 x 200: 243 KB of stores per image with bf16 y1 / y2, 406 KB as fp32)
     if (n_img[p] > 0 && !first) units += setup_cost;
     a.p[p].ustart = units;
     units += (long)a.p[p].cost * n_img[p];

@@ -231,10 +231,15 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
               const u32x2 hi = pack4_bf16(relu1(A1[0]), relu1(A1[1]), relu1(A1[2]), relu1(A1[3]));
               *reinterpret_cast<u32x4*>(act1 + (oyi & (ER_R1 - 1)) * G::PITCH1 + OX[i] * ACT1_STRIDE + 16 * g) =
                   u32x4{lo[0], lo[1], hi[0], hi[1]};  // channels 8 g .. 8 g + 7
-              if (P.act) {  // saved for the per-layer backward: fp32, [pixel][32] (uniform base + 32-bit lane offset)
-                float* y = P.act + (long)cur * (G::NPX1 * 32) + (unsigned)((oyi * G::OW1 + OX[i]) * 32 + 8 * g);
-                *reinterpret_cast<f32x4*>(y) = f32x4{relu1(A0[0]), relu1(A0[1]), relu1(A0[2]), relu1(A0[3])};
-                *reinterpret_cast<f32x4*>(y + 4) = f32x4{relu1(A1[0]), relu1(A1[1]), relu1(A1[2]), relu1(A1[3])};
+              if (P.act) {  // saved for the backward (uniform base + 32-bit lane offset), [pixel][32]:
+                if (a_.act_bf16) {  // ... as bf16 at the start of y1's slot - the very value conv2 consumed (tacorl_encoder_bwd_fused*)
+                  *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(P.act) + (long)cur * (G::NPX1 * 32) +
+                                            (unsigned)((oyi * G::OW1 + OX[i]) * 32 + 8 * g)) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                } else {            // ... as fp32 (the per-layer tacorl_encoder_bwd)
+                  float* y = P.act + (long)cur * (G::NPX1 * 32) + (unsigned)((oyi * G::OW1 + OX[i]) * 32 + 8 * g);
+                  *reinterpret_cast<f32x4*>(y) = f32x4{relu1(A0[0]), relu1(A0[1]), relu1(A0[2]), relu1(A0[3])};
+                  *reinterpret_cast<f32x4*>(y + 4) = f32x4{relu1(A1[0]), relu1(A1[1]), relu1(A1[2]), relu1(A1[3])};
+                }
               }
             }
           };
@@ -294,9 +299,14 @@ __global__ __launch_bounds__(256, 1) void encoder_ring_kernel(EFArgs a_) {
               *reinterpret_cast<u32x4*>(act2 + oy2 * G::PITCH2 + ox2 * G::PX2 + (32 * cg + 8 * g) * 2) =
                   u32x4{lo[0], lo[1], hi[0], hi[1]};
               if (P.act) {
-                float* y = P.act + P.a_y2 + (long)cur * (G::NPX2 * 64) + (unsigned)(pm * 64 + 32 * cg + 8 * g);
-                *reinterpret_cast<f32x4*>(y) = f32x4{relu1(C0[0]), relu1(C0[1]), relu1(C0[2]), relu1(C0[3])};
-                *reinterpret_cast<f32x4*>(y + 4) = f32x4{relu1(C1[0]), relu1(C1[1]), relu1(C1[2]), relu1(C1[3])};
+                if (a_.act_bf16) {
+                  *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(P.act + P.a_y2) + (long)cur * (G::NPX2 * 64) +
+                                            (unsigned)(pm * 64 + 32 * cg + 8 * g)) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                } else {
+                  float* y = P.act + P.a_y2 + (long)cur * (G::NPX2 * 64) + (unsigned)(pm * 64 + 32 * cg + 8 * g);
+                  *reinterpret_cast<f32x4*>(y) = f32x4{relu1(C0[0]), relu1(C0[1]), relu1(C0[2]), relu1(C0[3])};
+                  *reinterpret_cast<f32x4*>(y + 4) = f32x4{relu1(C1[0]), relu1(C1[1]), relu1(C1[2]), relu1(C1[3])};
+                }
               }
             }
           };

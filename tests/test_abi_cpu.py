@@ -55,7 +55,8 @@ def test_launch_batch_state_machine_without_gpu():
         assert begin() == 0 and end(None) == 0
     assert L.tacorl_rnn_linear_supported(3840, 2048, 192) == 1 and L.tacorl_rnn_linear_supported(256, 100, 64) == 0
     assert L.tacorl_encoder_fused_supported(84, 84) == 1 and L.tacorl_encoder_fused_supported(150, 200) == 1  # (round 6: encoder_ring.hip)
-    assert L.tacorl_encoder_fused_supported(200, 200) == 0 and L.tacorl_encoder_bwd_fused_ws_bytes(1, (C.c_int * 1)(8), 150, 200) == 0
+    assert L.tacorl_encoder_fused_supported(200, 200) == 0 and L.tacorl_encoder_bwd_fused_ws_bytes(1, (C.c_int * 1)(8), 200, 200) == 0
+    assert L.tacorl_encoder_bwd_fused_ws_bytes(1, (C.c_int * 1)(8), 150, 200) > 0 and L.tacorl_encoder_fused_act_format(150, 200) == 1
 
 
 def test_rnn_wgrad_batch_refuses_bad_arguments_without_gpu():

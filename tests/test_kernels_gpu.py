@@ -306,7 +306,7 @@ def test_cql_loss(det_backup, lagrange, n):
 
 
 # 128 x 128: conv1 over row bands; 150 x 200 (rgb_static of experiment=tacorl_real_world): conv1 -> conv2 through a ring of
-# conv1 rows, online soft-argmax (encoder_ring.hip), activations saved as fp32 for the per-layer backward
+# conv1 rows, online soft-argmax (encoder_ring.hip)
 @pytest.mark.parametrize("H,W", [(84, 84), (44, 60), (128, 128), (150, 200)])
 def test_encoder_fused_forward(H, W):
     """Fused bf16 inference kernel vs the CPU oracle (bf16 tolerance) and vs the generic bf16 path."""
@@ -335,7 +335,8 @@ def test_encoder_fused_forward(H, W):
     ops.call("tacorl_encoder_pack_weights", len(n), ops.ptr_array(flats), ops.ptr_array(packed), ops.stream())
     acts_f = [torch.full_like(a, float("nan")) for a in acts]
     acts_arg = lambda a: ops.ptr_array([a[0], None, a[2]])  # noqa: E731
-    assert _lib.lib().tacorl_encoder_fused_act_format(H, W) == (2 if ring else 1)
+    fmt = _lib.lib().tacorl_encoder_fused_act_format(H, W)  # 1: y1 / y2 saved as bf16 (every geometry with the LDS-resident backward), 2: fp32
+    assert fmt == 1
     ops.call("tacorl_encoder_fwd_fused", len(n), ops.ptr_array(imgs), ops.ptr_array(packed), ops.ptr_array(flats),
              ops.ptr_array(outs_f), acts_arg(acts_f), ops.int_array(n), H, W, ops.stream())
     ops.encoder_fwd(imgs, flats, outs_g, acts, H, W, 1)
@@ -365,13 +366,14 @@ def test_encoder_fused_forward(H, W):
         for j, name in enumerate(["y1", "y2", "y3", "softargmax", "fc1"]):
             end = offs[j + 1] if j + 1 < 5 else tot
             a, b = acts_f[i][offs[j]:end], acts[i][offs[j]:end]
-            if j < 2 and not ring:  # the fused launch saves y1 / y2 as bf16 at the start of their fp32-sized slots (ring geometries: fp32)
+            if j < 2 and fmt == 1:  # the fused launch saves y1 / y2 as bf16 at the start of their fp32-sized slots
                 a = a.view(torch.bfloat16)[: b.numel()].float()
             assert torch.isfinite(a).all(), name
             assert relerr(a, b) < 1e-2, (name, relerr(a, b))
 
 
-@pytest.mark.parametrize("H,W", [(84, 84), (64, 64), (44, 60), (128, 128)])  # 128 x 128: conv1 weight gradient in 2 bands
+# 128 x 128: conv1 weight gradient in 2 bands; 150 x 200: conv1 / conv2 weight gradients in 3 / 2 bands, single-buffered dgrads
+@pytest.mark.parametrize("H,W", [(84, 84), (64, 64), (44, 60), (128, 128), (150, 200)])
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_encoder_fused_backward(H, W, accumulate):
     """Per-image LDS-resident conv backward (tacorl_encoder_bwd_fused) vs the generic bf16 path on the
@@ -435,7 +437,9 @@ def test_encoder_fused_backward(H, W, accumulate):
                 "vs oracle autograd with bf16 operand rounding", name, e, floors[i].get(name))
 
 
-@pytest.mark.parametrize("H,W,n", [(84, 84, [300, 90, 5]), (64, 64, [200, 171]), (44, 60, [260])])
+# (150 x 200 has no single-launch conv3 stage: both settings of the switch run the same launches there - what the case adds is
+# the image loop of the single-buffered dgrads and of the banded conv1 / conv2 weight gradients, and their run-to-run determinism)
+@pytest.mark.parametrize("H,W,n", [(84, 84, [300, 90, 5]), (64, 64, [200, 171]), (44, 60, [260]), (150, 200, [270, 33])])
 def test_encoder_fused_backward_image_loop_and_single_launch_conv3(H, W, n, monkeypatch):
     """More images than workgroups (every workgroup loops over several images through its double buffers, ragged
     counts, problems of different sizes): the conv3 stage as ONE launch (soft-argmax backward + dgrad3 + wgrad3 with wave
