@@ -185,9 +185,9 @@ long tacorl_encoder_fused_wpk_bytes(void);
 int tacorl_encoder_fused_supported(int H, int W);
 /* What the fused forward writes into a problem's act block for this geometry: 0 - not a fused geometry; 1 - y1 / y2 as bf16 at
  * the start of their slots (tacorl_encoder_bwd_fused* read them); 2 - every activation as fp32, i.e. exactly what the per-layer
- * tacorl_encoder_fwd leaves and tacorl_encoder_bwd reads (geometries whose conv1 output does not fit the LDS - 150 x 200, the
- * un-resized rgb_static of the reference's experiment=tacorl_real_world, config/.../rl_real_world_train.yaml:2-10 - which
- * have no LDS-resident backward: csrc/encoder_ring.hip). */
+ * tacorl_encoder_fwd leaves and tacorl_encoder_bwd reads (a geometry of csrc/encoder_ring.hip - conv1 output too large for the
+ * LDS - for which tacorl_encoder_bwd_fused_ws_bytes() is 0.  150 x 200, the un-resized rgb_static of the reference's
+ * experiment=tacorl_real_world, config/.../rl_real_world_train.yaml:2-10, has the LDS-resident backward and reports 1). */
 int tacorl_encoder_fused_act_format(int H, int W);
 int tacorl_encoder_pack_weights(int nprob, const float* const* params, void* const* packed,
                                 tacorl_stream_t stream);

@@ -17,10 +17,10 @@
 //    pixels the lane has seen, rescaled when the maximum moves - v3[NT3] of encoder_fused would be 80 registers here); the 16
 //    pixel lanes are merged once per image.  A tile's soft-argmax update runs inside the next tile's MFMA chain.
 // Every fragment set is double: the next tile's reads are issued between the running chain's MFMAs into the other set.
-// Problems a backward follows save their activations from the same launch in the layout the PER-LAYER backward reads
-// (tacorl_encoder_bwd: there is no LDS-resident conv backward for these geometries) - y1 / y2 / y3, the soft-argmax features
-// and fc1 all as fp32 at their tacorl_encoder_act_layout offsets (encoder_fused_kernel stores y1 / y2 as bf16 for ITS backward);
-// tacorl_encoder_fused_act_format() tells the caller which of the two a geometry writes.
+// Problems a backward follows save their activations from the same launch: y3, the soft-argmax features and fc1 as fp32 at
+// their tacorl_encoder_act_layout offsets; y1 / y2 as bf16 at the start of their slots where the geometry has the LDS-resident
+// backward (EFArgs::act_bf16 - what encoder_fused_kernel saves and tacorl_encoder_bwd_fused* read; 150 x 200 since later in
+// round 6), as fp32 for the per-layer tacorl_encoder_bwd otherwise.  tacorl_encoder_fused_act_format() tells the caller which.
 #include <stdio.h>
 #include <stdlib.h>
 

@@ -468,7 +468,8 @@ class ACEngine:
                 self._launch_fused(c, allp)
                 continue
             if self._fused_ok(c):
-                # (act format 2 - encoder_ring.hip, 150 x 200: the fused launch saves fp32 activations, which the per-layer backward reads)
+                # (act format 2 - a geometry of encoder_ring.hip without the LDS-resident backward: the fused launch saves fp32
+                # activations, which the per-layer backward reads)
                 saves = self._fused_bwd_ok(c) or ops.L.lib().tacorl_encoder_fused_act_format(H, W) == 2
                 slow = [] if saves else [x for x in pr if x[5]]
                 pr = [x for x in pr if not (slow and x[5])]
