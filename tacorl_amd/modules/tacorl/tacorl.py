@@ -324,13 +324,14 @@ class TACORL(CQL_Offline):
             main.wait_stream(self._side_stream)  # (every forked stream joins the capture's origin)
         segmented = self._segmented() or not self._use_graph
         if with_ad and not ad_on_side:
-            if segmented or D.collectives_on(self.world_size):
-                # (collectives captured inside the one graph: the decoder's gradients are part of the arena the second
-                # all-reduce sums, so its branch joins here as well)
+            if segmented:
                 main.wait_stream(self._pr_stream)
             else:
                 # one graph for the whole step: the fine-tuning chain (loss, BPTT, weight gradients, Adam - 1.4 ms, touching
-                # nothing but the decoder's own buffers) stays a branch beside the CQL update and joins at the end of the step
+                # nothing but the decoder's own buffers) stays a branch beside the CQL update and joins at the end of the step -
+                # or, with the collectives captured inside that graph (several ranks), in front of the SECOND all-reduce, whose
+                # arena holds the decoder's gradients (round 6: it used to join here, in front of the first one - the whole
+                # decoder chain then stood between phase_a and phase_b: 1.078 against 0.864 ms at C3's B = 32 share)
                 self._ad_join = self._pr_stream
         if segmented:
             # every segment must be self-contained (its graph is replayed on its own)
@@ -432,9 +433,13 @@ class TACORL(CQL_Offline):
         segmented = self._segmented()
         ad_side = with_ad and segmented and self._use_graph and not (optimize and self.finetune_action_decoder)
         side = (0, lambda: self.ad.loss_step(self, self.acts, self.plan, B, T, False, frozen=not self.finetune_action_decoder)) if ad_side else None
+        def allreduce_grads():
+            self._join_ad()  # (a fine-tuned decoder's branch: its gradient block is part of the arena; no-op otherwise)
+            e.allreduce_grads()
+
         self._run_segments(key, [lambda: self._device_front(B, T, hw, optimize, with_ad and not ad_side),
                                  lambda: e.phase_b(bc, optimize), tail],
-                           [e.allreduce_alpha, e.allreduce_grads], side=side)
+                           [e.allreduce_alpha, allreduce_grads], side=side)
         self._publish_logs(log_type, extra=("action_loss",) if with_ad else ())
 
     def configure_optimizers(self):
