@@ -265,10 +265,12 @@ class GraphMixin:
         `collectives[i]` runs between segs[i] and segs[i+1] (RCCL all-reduces; no-ops on one GPU).
         Eager, or - with enable_graph() - each segment replayed from a captured hipGraph (one graph for
         the whole step on a single GPU; collectives always stay eager between graphs).
-        side = (i, fn): work that depends only on segs[:i+1] and that nothing later in the step reads
-        (TACORL's logging-only action-decoder pass).  In split mode it is its own graph, replayed on a side
-        stream right after segment i and joined at the end of the step, so it overlaps the collectives and
-        the remaining segments; otherwise it simply runs after segment i."""
+        side = (i, fn) or (i, fn, j): work that depends only on segs[:i+1] and that nothing later in the step reads
+        (TACORL's logging-only action-decoder pass) - or that only collectives[j] and what follows read (the fine-tuned
+        decoder's loss + backward: its gradient block is part of the arena all-reduce #2 sums).  In split mode it is its own
+        graph, replayed on a side stream right after segment i and joined at the end of the step (in front of collectives[j]),
+        so it overlaps the collectives and the remaining segments; otherwise it simply runs after segment i."""
+        side_join = side[2] if side is not None and len(side) > 2 else None
         def eager():
             for i, f in enumerate(segs):
                 f()
@@ -321,6 +323,8 @@ class GraphMixin:
                 with torch.cuda.stream(self._side_replay_stream):
                     g_side.replay()
             if len(gs) > 1 and i < len(collectives):
+                if g_side is not None and side_join == i:
+                    cur.wait_stream(self._side_replay_stream)
                 collectives[i]()
         if g_side is not None:
             cur.wait_stream(self._side_replay_stream)

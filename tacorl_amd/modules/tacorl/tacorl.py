@@ -431,8 +431,15 @@ class TACORL(CQL_Offline):
         # split (multi-GPU) graphs: the frozen, logging-only action-decoder pass leaves the first segment
         # and runs as a side graph beside the all-reduces and the other segments
         segmented = self._segmented()
-        ad_side = with_ad and segmented and self._use_graph and not (optimize and self.finetune_action_decoder)
-        side = (0, lambda: self.ad.loss_step(self, self.acts, self.plan, B, T, False, frozen=not self.finetune_action_decoder)) if ad_side else None
+        ad_ft = optimize and self.finetune_action_decoder
+        ad_side = with_ad and segmented and self._use_graph
+        # (round 6: the FINE-TUNED decoder's loss + backward as the side graph too - joined in front of all-reduce #2, whose arena
+        # holds its gradients; inside the first segment its chain, the step's longest, stood in front of phase_b)
+        side = None
+        if ad_side and ad_ft:
+            side = (0, lambda: self.ad.loss_step(self, self.acts, self.plan, B, T, True, defer_update=True), 1)
+        elif ad_side:
+            side = (0, lambda: self.ad.loss_step(self, self.acts, self.plan, B, T, False, frozen=not self.finetune_action_decoder))
         def allreduce_grads():
             self._join_ad()  # (a fine-tuned decoder's branch: its gradient block is part of the arena; no-op otherwise)
             e.allreduce_grads()
