@@ -441,7 +441,8 @@ class TACORL(CQL_Offline):
         elif ad_side:
             side = (0, lambda: self.ad.loss_step(self, self.acts, self.plan, B, T, False, frozen=not self.finetune_action_decoder))
         def allreduce_grads():
-            self._join_ad()  # (a fine-tuned decoder's branch: its gradient block is part of the arena; no-op otherwise)
+            if ad_update:  # a fine-tuned decoder's branch: its gradient block is part of the arena (the frozen, logging-only
+                self._join_ad()  # pass keeps running beside the all-reduce and the optimiser and joins at the end of the step)
             e.allreduce_grads()
 
         self._run_segments(key, [lambda: self._device_front(B, T, hw, optimize, with_ad and not ad_side),
